@@ -1,0 +1,162 @@
+/*
+ * jslp_engine.h -- C ABI of the MI355X dense-tableau simplex engine.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / no C++ types.  One
+ * `jslp_engine` is the device-resident state of ONE reference `Tableau` (src/tableau/tableau.ts:46-99):
+ * the fp64 row-major matrix (row 0 = reduced costs, column 0 = RHS), the four index maps, the root
+ * snapshot used by branch-and-bound and the scratch the kernels need.  Every entry point replaces the
+ * reference method cited next to it and keeps its semantics bit for bit (no FMA contraction, IEEE
+ * division, first-index tie-breaks).
+ *
+ * Two libraries export exactly these symbols:
+ *   jslpsolver_amd/csrc/libjslp_hip.so   -- the product: hand-written HIP kernels for gfx950
+ *   oracle/libjslp_oracle.so             -- TEST ONLY: sequential C restatement of the reference
+ * All functions are synchronous for the caller (the reference is single-threaded and synchronous,
+ * src/main.ts:94-147); asynchrony (streams, chunked launches, per-node workgroups) stays inside.
+ *
+ * Error convention: the reference's hot path never throws -- outcomes are flags (simplex.ts:73-76,
+ * 86-92, 298-303).  So every function returns an int status (0 = OK, <0 = the call itself failed) and
+ * solver outcomes travel in jslp_simplex_result.
+ */
+#ifndef JSLP_ENGINE_H
+#define JSLP_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JSLP_OK 0
+#define JSLP_ERR_ARG (-1)         /* bad argument (null pointer, index out of range, size mismatch)  */
+#define JSLP_ERR_DEVICE (-2)      /* HIP runtime error or no gfx950 device; see jslp_last_error()      */
+#define JSLP_ERR_NOMEM (-3)
+#define JSLP_ERR_STATE (-4)       /* call order violated (e.g. simplex before upload)                  */
+#define JSLP_ERR_CAPACITY (-5)    /* add_cuts beyond row_capacity, pivot history beyond its limit      */
+#define JSLP_ERR_UNSUPPORTED (-6) /* feature outside the built scope                                   */
+
+/* cut direction, reference BranchCut.type (src/tableau/types.ts:17-21) */
+#define JSLP_CUT_MIN 0 /* "min": x >= value  (sign -1 in cutting-strategies.ts:41) */
+#define JSLP_CUT_MAX 1 /* "max": x <= value  (sign +1) */
+
+typedef struct jslp_engine jslp_engine;
+
+/* Outcome of one Tableau.simplex() call (src/tableau/simplex.ts:14-23). */
+typedef struct jslp_simplex_result {
+    int32_t feasible;            /* tableau.feasible: 0 when phase 1 fails OR a cycle is detected          */
+    int32_t bounded;             /* tableau.bounded (simplex.ts:15,300)                                     */
+    int32_t optimal;             /* 1 iff phase 2 hit "no entering column": setEvaluation() ran and
+                                    simplexIters += 1 (simplex.ts:265-269)                                  */
+    int32_t unbounded_var_index; /* tableau.unboundedVarIndex (simplex.ts:301) or -1                        */
+    int32_t pivots_phase1;       /* return value of phase1() (simplex.ts:53,75,91)                          */
+    int32_t pivots_phase2;       /* return value of phase2(); -1 when phase 2 did not run                   */
+    int32_t cycle_phase;         /* 0 = none, 1 / 2 = "Cycle in phase N" (simplex.ts:86,313)                */
+    int32_t cycle_start;         /* checkForCycles() result [start, length] (simplex.ts:415-440)            */
+    int32_t cycle_length;
+    int32_t height;              /* current number of rows (grows with cuts)                                */
+    double obj_cell;             /* raw matrix[0] after the call                                            */
+    double evaluation;           /* when optimal: round((EPS + matrix[0]) * rc) / rc, rc = round(1/precision)
+                                    (tableau.ts:420-426); -Infinity when unbounded; otherwise the previous
+                                    value is kept, exactly like tableau.evaluation                          */
+} jslp_simplex_result;
+
+/* Library identity: "hip-gfx950" for the product, "oracle-c" for the test restatement. */
+const char* jslp_backend_name(void);
+/* Human-readable text of the last failure on this thread ("" if none). */
+const char* jslp_last_error(void);
+/* Number of usable devices (0 for the oracle / when no GPU is visible). */
+int jslp_device_count(void);
+
+/*
+ * new Tableau(precision) + Tableau.initialize(width, height, ...) (tableau.ts:94-99, 292-317).
+ * row_capacity >= height bounds how many cut rows add_cuts may append (the reference reallocates in
+ * cutting-strategies.ts:24-30; device memory is sized once instead).  device = HIP device ordinal.
+ */
+int jslp_engine_create(jslp_engine** out, int device, int32_t height, int32_t width, int32_t row_capacity,
+                       double precision);
+void jslp_engine_destroy(jslp_engine* e);
+
+/*
+ * Hand over the tableau built by Tableau._resetMatrix (tableau.ts:319-380): matrix is height*width
+ * doubles, row-major, stride width (the reference layout, tableau.ts:49-54,304).  var_index_by_row[0] and
+ * var_index_by_col[0] are -1.  unrestricted_var_indexes lists model.unrestrictedVariables keys
+ * (model.ts:181-183).  The element-index counter continues at width+height-2 (tableau.ts:312-316).
+ * Resets snapshot, evaluation and pivot counters.
+ */
+int jslp_engine_upload(jslp_engine* e, const double* matrix, const int32_t* var_index_by_row,
+                       const int32_t* var_index_by_col, const int32_t* unrestricted_var_indexes,
+                       int32_t n_unrestricted);
+
+/* Tableau.simplex(): phase1 then phase2 (simplex.ts:14-23).  check_cycles = model.checkForCycles. */
+int jslp_engine_simplex(jslp_engine* e, int check_cycles, jslp_simplex_result* out);
+
+/* Tableau.pivot(r, c) on its own (simplex.ts:330-413); used by putInBase/takeOutOfBase and by tests. */
+int jslp_engine_pivot(jslp_engine* e, int32_t row, int32_t col);
+
+/* Tableau.save(): device-resident snapshot of matrix + index maps + counters (backup.ts:13-51). */
+int jslp_engine_save(jslp_engine* e);
+/* Tableau.restore(): no-op before the first save (backup.ts:53-105). */
+int jslp_engine_restore(jslp_engine* e);
+
+/*
+ * Tableau.addCutConstraints(cuts) (cutting-strategies.ts:16-72): appends n rows; each new row gets the
+ * next element index exactly as getNewElementIndex() (tableau.ts:393-401).
+ */
+int jslp_engine_add_cuts(jslp_engine* e, int32_t n, const int8_t* type, const int32_t* var_index,
+                         const double* value);
+
+/*
+ * One LP relaxation = BranchAndCutService.applyCuts (branch-and-cut.ts:33-37): restore + add_cuts +
+ * simplex, then the read-back branch-and-bound needs (mip-utils.ts:43-61,100-126): the RHS column and the
+ * row -> variable map, `height` entries each (rhs / var_index_by_row may be NULL to skip).
+ */
+int jslp_engine_relax(jslp_engine* e, int32_t n_cuts, const int8_t* type, const int32_t* var_index,
+                      const double* value, int check_cycles, jslp_simplex_result* out, double* rhs,
+                      int32_t* var_index_by_row);
+
+/*
+ * The same for a batch of independent branch-and-bound nodes (each a pure function of the saved root and
+ * its cut list): node i owns cuts [cut_offsets[i], cut_offsets[i+1]).  Results land in
+ * out[i]; rhs / var_index_by_row are n_nodes x out_stride arrays (row i = node i, first out[i].height
+ * entries valid).  The engine's own tableau is left holding the LAST node.  This is the unit that shards
+ * across GPUs (one engine per rank, disjoint node ranges).
+ */
+int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                            const int32_t* var_index, const double* value, int check_cycles,
+                            jslp_simplex_result* out, double* rhs, int32_t* var_index_by_row,
+                            int32_t out_stride);
+
+/* Current dimensions (height grows with cuts, restore() puts it back). */
+int jslp_engine_dims(const jslp_engine* e, int32_t* height, int32_t* width, int32_t* n_var_indexes);
+
+/* RHS column + varIndexByRow of the live tableau (height entries each; either may be NULL). */
+int jslp_engine_read_rhs(jslp_engine* e, double* rhs, int32_t* var_index_by_row);
+
+/*
+ * Full read-back for `Solve(model, precision, full=true)` and the post-solve editing API
+ * (main.ts:142-144): matrix in the reference layout (height*width, stride width); maps may be NULL.
+ * row_by_var_index / col_by_var_index have n_var_indexes entries (-1 = absent).
+ */
+int jslp_engine_download(jslp_engine* e, double* matrix, int32_t* var_index_by_row, int32_t* var_index_by_col,
+                         int32_t* row_by_var_index, int32_t* col_by_var_index);
+
+/*
+ * Diagnostics used by the parity tests: the (row, col) arguments of every pivot() since the last upload
+ * in order.  Returns the total count in *n_pivots and copies at most max_pairs pairs into row_col
+ * (interleaved r0,c0,r1,c1,...).  The FNV-1a digest of SURVEY.md Appendix C is computed by the caller.
+ */
+int jslp_engine_pivot_trace(jslp_engine* e, int32_t* row_col, int64_t max_pairs, int64_t* n_pivots);
+
+/*
+ * Measurement hooks (bench.py): device time in milliseconds and launch count of the dominant kernel
+ * (the row-update stream of pivot()) accumulated since the last reset, measured with HIP events on the
+ * engine's own stream.  Timing is off by default (it adds an event pair per launch).
+ */
+int jslp_engine_set_timing(jslp_engine* e, int enabled);
+int jslp_engine_get_timing(jslp_engine* e, double* update_kernel_ms, int64_t* update_kernel_launches,
+                           double* total_device_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JSLP_ENGINE_H */

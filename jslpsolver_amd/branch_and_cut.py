@@ -1,0 +1,162 @@
+"""Host-side branch-and-bound tree (CPU), calling the engine for every LP relaxation.
+
+Mirrors the reference's DEFAULT BranchAndCutService (src/tableau/branch-and-cut.ts:54-199) -- best-first
+with LIFO ties (src/tableau/min-heap.ts:43-49), most-fractional branching (src/tableau/mip-utils.ts:100-126)
+-- because its visiting order decides which incumbent wins.  The three bulk operations of a node
+(restore + addCutConstraints + simplex, branch-and-cut.ts:33-37) are ONE engine call (Tableau.applyCuts).
+"""
+import math
+import time
+
+
+def js_round(x):
+    """Math.round: nearest integer, ties toward +Infinity"""
+    if math.isinf(x) or math.isnan(x):
+        return x
+    f = math.floor(x)
+    return f + 1.0 if x - f >= 0.5 else float(f)
+
+
+class BranchMinHeap:
+    """src/tableau/min-heap.ts: key = relaxedEvaluation ascending, ties -> most recently pushed first."""
+
+    def __init__(self):
+        self.heap = []
+        self.seq = 0
+
+    def __len__(self):
+        return len(self.heap)
+
+    @staticmethod
+    def _before(a, b):
+        if a[0] != b[0]:
+            return a[0] < b[0]
+        return a[1] > b[1]
+
+    def push(self, relaxed_evaluation, cuts):
+        entry = (relaxed_evaluation, self.seq, cuts)
+        self.seq += 1
+        h = self.heap
+        h.append(entry)
+        i = len(h) - 1
+        while i > 0:
+            p = (i - 1) >> 1
+            if not self._before(entry, h[p]):
+                break
+            h[i] = h[p]
+            i = p
+        h[i] = entry
+
+    def pop(self):
+        h = self.heap
+        top = h[0]
+        last = h.pop()
+        n = len(h)
+        if n == 0:
+            return top
+        i = 0
+        half = n >> 1
+        while i < half:
+            c = 2 * i + 1
+            if c + 1 < n and self._before(h[c + 1], h[c]):
+                c += 1
+            if not self._before(h[c], last):
+                break
+            h[i] = h[c]
+            i = c
+        h[i] = last
+        return top
+
+
+def _rows_by_var(vibr):
+    return {int(v): r for r, v in enumerate(vibr) if r > 0}
+
+
+def is_integral(model, rhs, rows, precision):
+    """mip-utils.ts:43-61"""
+    for var in model.integerVariables:
+        r = rows.get(var["index"], -1)
+        if r != -1:
+            value = float(rhs[r])
+            if abs(value - js_round(value)) > precision:
+                return False
+    return True
+
+
+def most_fractional_var(model, rhs, rows):
+    """mip-utils.ts:100-126: first variable with the strictly biggest |v - round(v)|"""
+    biggest, sel_index, sel_value = 0.0, None, 0.0
+    for var in model.integerVariables:
+        r = rows.get(var["index"], -1)
+        if r != -1:
+            value = float(rhs[r])
+            fraction = abs(value - js_round(value))
+            if fraction > biggest:
+                biggest, sel_index, sel_value = fraction, var["index"], value
+    return sel_index, sel_value
+
+
+def branch_and_cut(tableau, model):
+    """branch-and-cut.ts:54-199.  Leaves `tableau` holding the incumbent; returns the iteration count and
+    whether an integral node was accepted (tableau.__isIntegral)."""
+    branches = BranchMinHeap()
+    iterations = 0
+    tolerance = model.tolerance or 0
+    tolerance_flag = True
+    terminal_time = 1e99
+    if model.timeout:
+        terminal_time = time.time() * 1000.0 + model.timeout
+    best_evaluation = math.inf
+    best_cuts = None
+    found_integral = False
+    check = model.checkForCycles
+    precision = tableau.precision
+
+    branches.push(-math.inf, [])
+    while len(branches) > 0 and tolerance_flag and time.time() * 1000.0 < terminal_time:
+        if model.isMinimization:
+            acceptable = tableau.bestPossibleEval * (1 + tolerance)
+        else:
+            acceptable = tableau.bestPossibleEval * (1 - tolerance)
+        if tolerance > 0 and best_evaluation < acceptable:
+            tolerance_flag = False
+        relaxed, _, cuts = branches.pop()
+        if relaxed > best_evaluation:
+            continue
+        _res, rhs, vibr = tableau.applyCuts(cuts, check_cycles=check)
+        iterations += 1
+        if not tableau.feasible:
+            continue
+        evaluation = tableau.evaluation
+        if evaluation > best_evaluation:
+            continue
+        if evaluation == best_evaluation:
+            continue  # no optional objectives: "isCurrentEvaluationWorse" stays true (:107-127)
+        rows = _rows_by_var(vibr)
+        if is_integral(model, rhs, rows, precision):
+            found_integral = True
+            if iterations == 1:
+                return iterations, True
+            best_cuts = cuts
+            best_evaluation = evaluation
+        else:
+            if iterations == 1:
+                tableau.save()
+            var_index, var_value = most_fractional_var(model, rhs, rows)
+            cuts_high, cuts_low = [], []
+            for cut in cuts:
+                if cut["varIndex"] == var_index:
+                    if cut["type"] == "min":
+                        cuts_low.append(cut)
+                    else:
+                        cuts_high.append(cut)
+                else:
+                    cuts_high.append(cut)
+                    cuts_low.append(cut)
+            cuts_high.append({"type": "min", "varIndex": var_index, "value": float(math.ceil(var_value))})
+            cuts_low.append({"type": "max", "varIndex": var_index, "value": float(math.floor(var_value))})
+            branches.push(evaluation, cuts_high)
+            branches.push(evaluation, cuts_low)
+    if best_cuts is not None:
+        tableau.applyCuts(best_cuts, check_cycles=check)
+    return iterations, found_integral

@@ -1,0 +1,191 @@
+"""Host-side mirror of the reference `Tableau` hot-path methods (src/tableau/tableau.ts:103-229) on top of
+the C ABI.  Method names follow the reference: simplex / pivot / save / restore / addCutConstraints /
+applyCuts, so parity tests read like the reference's own tests.
+"""
+import numpy as np
+
+from . import _capi
+from ._capi import SimplexResult
+
+
+class Tableau:
+    """Device-resident dense simplex tableau (one `jslp_engine`).
+
+    matrix is the reference layout (tableau.ts:49-54): row-major height x width float64, row 0 = reduced
+    costs, column 0 = RHS.
+    """
+
+    def __init__(self, matrix, var_index_by_row, var_index_by_col, unrestricted=(), precision=1e-8,
+                 row_capacity=None, device=0, lib=None):
+        self.lib = lib if lib is not None else _capi.load_hip()
+        matrix = _capi.as_f64(matrix)
+        if matrix.ndim != 2:
+            raise ValueError("matrix must be height x width")
+        self.height0, self.width = matrix.shape
+        self.precision = float(precision)
+        self.row_capacity = int(row_capacity if row_capacity is not None else self.height0)
+        self._h = _capi.C.c_void_p()
+        self.lib.check(self.lib.jslp_engine_create(_capi.C.byref(self._h), int(device), self.height0, self.width,
+                                                   self.row_capacity, self.precision), "jslp_engine_create")
+        vibr = _capi.as_i32(var_index_by_row)
+        vibc = _capi.as_i32(var_index_by_col)
+        unr = _capi.as_i32(list(unrestricted))
+        if vibr.shape[0] != self.height0 or vibc.shape[0] != self.width:
+            raise ValueError("index maps do not match the matrix shape")
+        self.lib.check(self.lib.jslp_engine_upload(self._h, _capi.ptr_f64(matrix), _capi.ptr_i32(vibr),
+                                                   _capi.ptr_i32(vibc), _capi.ptr_i32(unr), int(unr.shape[0])),
+                       "jslp_engine_upload")
+        # tableau scalars the reference keeps on the Tableau object (tableau.ts:59-61,83-87)
+        self.feasible = True
+        self.bounded = True
+        self.evaluation = 0.0
+        self.simplexIters = 0
+        self.bestPossibleEval = 0.0
+        self.unboundedVarIndex = None
+        self.last = None
+
+    # ---- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.jslp_engine_destroy(self._h)
+            self._h = _capi.C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference Tableau surface ------------------------------------------------------------
+    @property
+    def height(self):
+        h = _capi.C.c_int32()
+        self.lib.check(self.lib.jslp_engine_dims(self._h, _capi.C.byref(h), None, None), "jslp_engine_dims")
+        return h.value
+
+    def _absorb(self, res):
+        """fold a jslp_simplex_result into the Tableau scalars exactly as simplex.ts/tableau.ts do"""
+        self.last = res
+        self.feasible = bool(res.feasible)
+        self.bounded = bool(res.bounded)
+        if res.optimal:  # setEvaluation + simplexIters += 1 (simplex.ts:265-269, tableau.ts:420-430)
+            self.evaluation = res.evaluation
+            if self.simplexIters == 0:
+                self.bestPossibleEval = res.evaluation
+            self.simplexIters += 1
+        elif not res.bounded:  # simplex.ts:298-303
+            self.evaluation = float("-inf")
+            self.unboundedVarIndex = res.unbounded_var_index
+        return res
+
+    def simplex(self, check_cycles=True):
+        res = SimplexResult()
+        self.lib.check(self.lib.jslp_engine_simplex(self._h, int(bool(check_cycles)), _capi.C.byref(res)),
+                       "jslp_engine_simplex")
+        return self._absorb(res)
+
+    def pivot(self, row, col):
+        self.lib.check(self.lib.jslp_engine_pivot(self._h, int(row), int(col)), "jslp_engine_pivot")
+
+    def save(self):
+        self.lib.check(self.lib.jslp_engine_save(self._h), "jslp_engine_save")
+
+    def restore(self):
+        self.lib.check(self.lib.jslp_engine_restore(self._h), "jslp_engine_restore")
+
+    @staticmethod
+    def _pack_cuts(cuts):
+        n = len(cuts)
+        t = np.array([_capi.JSLP_CUT_MIN if c["type"] == "min" else _capi.JSLP_CUT_MAX for c in cuts], dtype=np.int8)
+        v = np.array([c["varIndex"] for c in cuts], dtype=np.int32)
+        x = np.array([c["value"] for c in cuts], dtype=np.float64)
+        return n, t, v, x
+
+    def addCutConstraints(self, cuts):
+        n, t, v, x = self._pack_cuts(cuts)
+        self.lib.check(self.lib.jslp_engine_add_cuts(self._h, n, _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x)),
+                       "jslp_engine_add_cuts")
+
+    def applyCuts(self, cuts, check_cycles=True):
+        """BranchAndCutService.applyCuts (branch-and-cut.ts:33-37) as ONE engine call; returns (result, rhs,
+        varIndexByRow) -- the read-back isIntegral()/getMostFractionalVar() need."""
+        n, t, v, x = self._pack_cuts(cuts)
+        res = SimplexResult()
+        rhs = np.empty(self.row_capacity, dtype=np.float64)
+        vibr = np.empty(self.row_capacity, dtype=np.int32)
+        self.lib.check(self.lib.jslp_engine_relax(self._h, n, _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x),
+                                                  int(bool(check_cycles)), _capi.C.byref(res), _capi.ptr_f64(rhs),
+                                                  _capi.ptr_i32(vibr)), "jslp_engine_relax")
+        self._absorb(res)
+        return res, rhs[:res.height], vibr[:res.height]
+
+    def applyCutsBatch(self, cut_lists, check_cycles=True):
+        """Independent branch-and-bound nodes in one call (jslp_engine_relax_batch)."""
+        n_nodes = len(cut_lists)
+        offs = np.zeros(n_nodes + 1, dtype=np.int32)
+        flat = []
+        for i, cuts in enumerate(cut_lists):
+            flat.extend(cuts)
+            offs[i + 1] = len(flat)
+        _, t, v, x = self._pack_cuts(flat)
+        out = (SimplexResult * max(n_nodes, 1))()
+        stride = self.row_capacity
+        rhs = np.empty((max(n_nodes, 1), stride), dtype=np.float64)
+        vibr = np.empty((max(n_nodes, 1), stride), dtype=np.int32)
+        self.lib.check(self.lib.jslp_engine_relax_batch(self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t),
+                                                        _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)),
+                                                        out, _capi.ptr_f64(rhs), _capi.ptr_i32(vibr), stride),
+                       "jslp_engine_relax_batch")
+        return [out[i] for i in range(n_nodes)], rhs, vibr
+
+    # ---- read-back --------------------------------------------------------------------------------
+    def read_rhs(self):
+        h = self.height
+        rhs = np.empty(h, dtype=np.float64)
+        vibr = np.empty(h, dtype=np.int32)
+        self.lib.check(self.lib.jslp_engine_read_rhs(self._h, _capi.ptr_f64(rhs), _capi.ptr_i32(vibr)),
+                       "jslp_engine_read_rhs")
+        return rhs, vibr
+
+    def download(self):
+        h = _capi.C.c_int32()
+        w = _capi.C.c_int32()
+        n = _capi.C.c_int32()
+        self.lib.check(self.lib.jslp_engine_dims(self._h, _capi.C.byref(h), _capi.C.byref(w), _capi.C.byref(n)),
+                       "jslp_engine_dims")
+        m = np.empty((h.value, w.value), dtype=np.float64)
+        vibr = np.empty(h.value, dtype=np.int32)
+        vibc = np.empty(w.value, dtype=np.int32)
+        rbv = np.empty(n.value, dtype=np.int32)
+        cbv = np.empty(n.value, dtype=np.int32)
+        self.lib.check(self.lib.jslp_engine_download(self._h, _capi.ptr_f64(m), _capi.ptr_i32(vibr), _capi.ptr_i32(vibc),
+                                                     _capi.ptr_i32(rbv), _capi.ptr_i32(cbv)), "jslp_engine_download")
+        return m, vibr, vibc, rbv, cbv
+
+    def pivot_trace(self):
+        n = _capi.C.c_int64()
+        self.lib.check(self.lib.jslp_engine_pivot_trace(self._h, None, 0, _capi.C.byref(n)), "jslp_engine_pivot_trace")
+        buf = np.empty(2 * max(n.value, 1), dtype=np.int32)
+        self.lib.check(self.lib.jslp_engine_pivot_trace(self._h, _capi.ptr_i32(buf), n.value, _capi.C.byref(n)),
+                       "jslp_engine_pivot_trace")
+        return buf[:2 * n.value].reshape(-1, 2)
+
+    def set_timing(self, enabled):
+        self.lib.check(self.lib.jslp_engine_set_timing(self._h, int(bool(enabled))), "jslp_engine_set_timing")
+
+    def get_timing(self):
+        ms = _capi.C.c_double()
+        n = _capi.C.c_int64()
+        tot = _capi.C.c_double()
+        self.lib.check(self.lib.jslp_engine_get_timing(self._h, _capi.C.byref(ms), _capi.C.byref(n), _capi.C.byref(tot)),
+                       "jslp_engine_get_timing")
+        return ms.value, n.value, tot.value
+
+
+def pivot_digest(pairs):
+    """FNV-1a-32 over the (row, col) arguments of every pivot."""
+    h = 2166136261
+    for r, c in np.asarray(pairs, dtype=np.int64).reshape(-1, 2):
+        h = ((h ^ int(r)) * 16777619) & 0xFFFFFFFF
+        h = ((h ^ int(c)) * 16777619) & 0xFFFFFFFF
+    return "%x" % h

@@ -1,0 +1,64 @@
+"""`Solve(model)` with the reference's JSON model API and result shape (src/main.ts:94-193), the simplex
+hot path running on the MI355X engine.  Model parsing and the branch-and-bound tree stay on the CPU.
+"""
+import math
+
+from . import _capi
+from .branch_and_cut import branch_and_cut, js_round
+from .engine import Tableau
+from .model import Model, js_keys
+
+EPSILON = 2.220446049250313e-16
+
+
+def _round_value(v, rounding_coeff):
+    """Math.round((Number.EPSILON + v) * rc) / rc (solution.ts:55-56)"""
+    return js_round((EPSILON + v) * rounding_coeff) / rounding_coeff
+
+
+def Solve(model, precision=None, full=False, validate=False, lib=None, device=0, row_capacity_extra=None):
+    """Drop-in for `solver.Solve(model, precision, full, validate)`.
+
+    `lib` selects the engine library (default: the HIP product library; tests pass the CPU oracle to exercise
+    the host logic without a GPU).  Returns the simplified result dict, or -- with full=True -- a dict that
+    also carries the final tableau read-back.
+    """
+    if model is None:
+        raise ValueError("Solver requires a model to operate on")  # main.ts:110-112
+    m = Model(model, precision)
+    matrix, vibr, vibc = m.build_tableau()
+    n_int = len(m.integerVariables)
+    # cut rows: at most one "min" and one "max" cut per integer variable (branch-and-cut.ts:166-179)
+    extra = 2 * n_int if row_capacity_extra is None else row_capacity_extra
+    t = Tableau(matrix, vibr, vibc, m.unrestricted, precision=m.precision, row_capacity=matrix.shape[0] + extra,
+                device=device, lib=lib)
+    iterations = 0
+    integral = False
+    if n_int > 0:  # tableau.ts:250-258
+        iterations, integral = branch_and_cut(t, m)
+    else:
+        t.simplex(check_cycles=m.checkForCycles)
+    rhs, rows = t.read_rhs()
+    evaluation = t.evaluation if m.isMinimization else -t.evaluation  # tableau.ts:261
+    result = {"feasible": t.feasible, "result": evaluation, "bounded": t.bounded}
+    if integral:
+        result["isIntegral"] = True
+    # generateSolutionSet (solution.ts:35-60) + buildSimplifiedResult (main.ts:173-193)
+    by_index = {v["index"]: v for v in m.variables}
+    rc = js_round(1 / m.precision)
+    solution_set = {}
+    for r in range(1, len(rows)):
+        var = by_index.get(int(rows[r]))
+        if var is None:
+            continue
+        solution_set[var["id"]] = _round_value(float(rhs[r]), rc)
+    for vid in js_keys(solution_set):
+        if solution_set[vid] != 0:
+            result[vid] = solution_set[vid]
+    result = {k: result[k] for k in js_keys(result)}  # JS property order: integer-like ids first
+    if full:
+        fm, fvibr, fvibc, _, _ = t.download()
+        result = {"result": result, "solutionSet": solution_set, "matrix": fm, "varIndexByRow": fvibr,
+                  "varIndexByCol": fvibc, "iter": iterations, "pivots": t.pivot_trace(), "model": m}
+    t.close()
+    return result

@@ -1,0 +1,597 @@
+/*
+ * jslp_oracle.c -- TEST INFRASTRUCTURE ONLY.  Sequential C restatement of the reference's dense-tableau
+ * hot path behind the C ABI of include/jslp_engine.h ("CPU fake device").
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (jslpsolver_amd/) never does and fails loudly when its HIP library is missing.
+ *
+ * Every function follows the reference file:line cited above it, statement by statement, in fp64 with the
+ * same operation order (compile with -ffp-contract=off: JavaScript never fuses a*b+c).
+ *
+ * Parity is PINNED: tests/test_oracle_golden.py checks this file against the golden vectors produced by
+ * the reference itself (oracle/_ref via tests/golden/gen_golden.js) -- every pivot (row, col) of all 47
+ * reference fixtures and of the reference's synthetic generators, the sha256 of the final tableau, the
+ * flags and every branch-and-bound relaxation outcome.
+ */
+#include "../include/jslp_engine.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct jslp_engine {
+    int32_t width, height, height0, cap_rows, n_idx_cap;
+    double precision;
+    double* matrix;        /* cap_rows * width, row-major, stride width (tableau.ts:49-54)      */
+    int32_t* vibr;         /* varIndexByRow  [cap_rows]                                          */
+    int32_t* vibc;         /* varIndexByCol  [width]                                             */
+    int32_t* rbv;          /* rowByVarIndex  [n_idx_cap]                                         */
+    int32_t* cbv;          /* colByVarIndex  [n_idx_cap]                                         */
+    uint8_t* unrestricted; /* unrestrictedVars[varIndex] === true  [n_idx_cap]                   */
+    int32_t last_element_index;
+    int uploaded;
+    /* savedState (backup.ts:49-51) */
+    int has_save;
+    int32_t s_height, s_last_element_index;
+    double* s_matrix;
+    int32_t *s_vibr, *s_vibc, *s_rbv, *s_cbv;
+    /* tableau scalars */
+    int32_t feasible, bounded, unbounded_var_index;
+    double evaluation;
+    /* diagnostics */
+    int32_t* trace;
+    int64_t n_trace, cap_trace;
+    int32_t* nz; /* nonZeroColumns scratch (simplex.ts:328) */
+};
+
+static __thread char g_err[256];
+static int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+
+const char* jslp_backend_name(void) { return "oracle-c"; }
+const char* jslp_last_error(void) { return g_err; }
+int jslp_device_count(void) { return 0; }
+
+int jslp_engine_create(jslp_engine** out, int device, int32_t height, int32_t width, int32_t row_capacity,
+                       double precision) {
+    (void)device;
+    if (!out || height < 1 || width < 1 || row_capacity < height) return fail(JSLP_ERR_ARG, "create: bad dims");
+    jslp_engine* e = (jslp_engine*)calloc(1, sizeof *e);
+    if (!e) return fail(JSLP_ERR_NOMEM, "create: oom");
+    e->width = width;
+    e->height = height;
+    e->height0 = height;
+    e->cap_rows = row_capacity;
+    e->n_idx_cap = width + 2 * row_capacity + 2;
+    e->precision = precision;
+    size_t cells = (size_t)row_capacity * (size_t)width;
+    e->matrix = (double*)calloc(cells, sizeof(double));
+    e->s_matrix = (double*)calloc(cells, sizeof(double));
+    e->vibr = (int32_t*)calloc(row_capacity, sizeof(int32_t));
+    e->s_vibr = (int32_t*)calloc(row_capacity, sizeof(int32_t));
+    e->vibc = (int32_t*)calloc(width, sizeof(int32_t));
+    e->s_vibc = (int32_t*)calloc(width, sizeof(int32_t));
+    e->rbv = (int32_t*)calloc(e->n_idx_cap, sizeof(int32_t));
+    e->cbv = (int32_t*)calloc(e->n_idx_cap, sizeof(int32_t));
+    e->s_rbv = (int32_t*)calloc(e->n_idx_cap, sizeof(int32_t));
+    e->s_cbv = (int32_t*)calloc(e->n_idx_cap, sizeof(int32_t));
+    e->unrestricted = (uint8_t*)calloc(e->n_idx_cap, 1);
+    e->nz = (int32_t*)calloc(width, sizeof(int32_t));
+    if (!e->matrix || !e->s_matrix || !e->vibr || !e->s_vibr || !e->vibc || !e->s_vibc || !e->rbv || !e->cbv ||
+        !e->s_rbv || !e->s_cbv || !e->unrestricted || !e->nz) {
+        jslp_engine_destroy(e);
+        return fail(JSLP_ERR_NOMEM, "create: oom");
+    }
+    e->feasible = 1;
+    e->bounded = 1;
+    e->unbounded_var_index = -1;
+    *out = e;
+    return JSLP_OK;
+}
+
+void jslp_engine_destroy(jslp_engine* e) {
+    if (!e) return;
+    free(e->matrix); free(e->s_matrix); free(e->vibr); free(e->s_vibr); free(e->vibc); free(e->s_vibc);
+    free(e->rbv); free(e->cbv); free(e->s_rbv); free(e->s_cbv); free(e->unrestricted); free(e->nz);
+    free(e->trace);
+    free(e);
+}
+
+/* Tableau.initialize + the index-map part of _resetMatrix (tableau.ts:292-317, 341-357) */
+int jslp_engine_upload(jslp_engine* e, const double* matrix, const int32_t* var_index_by_row,
+                       const int32_t* var_index_by_col, const int32_t* unrestricted_var_indexes,
+                       int32_t n_unrestricted) {
+    if (!e || !matrix || !var_index_by_row || !var_index_by_col) return fail(JSLP_ERR_ARG, "upload: null");
+    e->height = e->height0; /* cuts may have grown the tableau: an upload starts from the created height */
+    const int32_t H = e->height, W = e->width;
+    memcpy(e->matrix, matrix, (size_t)H * W * sizeof(double));
+    for (int32_t i = 0; i < e->n_idx_cap; i++) { e->rbv[i] = -1; e->cbv[i] = -1; e->unrestricted[i] = 0; }
+    e->vibr[0] = -1;
+    e->vibc[0] = -1;
+    for (int32_t r = 1; r < H; r++) {
+        int32_t v = var_index_by_row[r];
+        if (v < 0 || v >= e->n_idx_cap) return fail(JSLP_ERR_ARG, "upload: row var index out of range");
+        e->vibr[r] = v;
+        e->rbv[v] = r;
+    }
+    for (int32_t c = 1; c < W; c++) {
+        int32_t v = var_index_by_col[c];
+        if (v < 0 || v >= e->n_idx_cap) return fail(JSLP_ERR_ARG, "upload: col var index out of range");
+        e->vibc[c] = v;
+        e->cbv[v] = c;
+    }
+    for (int32_t i = 0; i < n_unrestricted; i++) {
+        int32_t v = unrestricted_var_indexes[i];
+        if (v < 0 || v >= e->n_idx_cap) return fail(JSLP_ERR_ARG, "upload: unrestricted index out of range");
+        e->unrestricted[v] = 1;
+    }
+    e->last_element_index = W + H - 2; /* tableau.ts:312-316 */
+    e->has_save = 0;
+    e->feasible = 1;
+    e->bounded = 1;
+    e->evaluation = 0;
+    e->unbounded_var_index = -1;
+    e->n_trace = 0;
+    e->uploaded = 1;
+    return JSLP_OK;
+}
+
+static void trace_push(jslp_engine* e, int32_t r, int32_t c) {
+    if (e->n_trace + 1 > e->cap_trace) {
+        int64_t nc = e->cap_trace ? e->cap_trace * 2 : 1024;
+        int32_t* p = (int32_t*)realloc(e->trace, (size_t)nc * 2 * sizeof(int32_t));
+        if (!p) return;
+        e->trace = p;
+        e->cap_trace = nc;
+    }
+    e->trace[2 * e->n_trace] = r;
+    e->trace[2 * e->n_trace + 1] = c;
+    e->n_trace++;
+}
+
+/* the reference's zero test `!(v >= -1e-16 && v <= 1e-16)` (simplex.ts:356,372,375,379): NaN counts as non-zero */
+static inline int nonzero16(double v) { return !(v >= -1e-16 && v <= 1e-16); }
+
+/* pivot (simplex.ts:330-413), optional-objective block :394-412 out of scope (no optional objectives) */
+static void pivot(jslp_engine* e, int32_t pr, int32_t pc) {
+    double* m = e->matrix;
+    const int32_t width = e->width, height = e->height;
+    const size_t pro = (size_t)pr * width;
+    const double quotient = m[pro + pc]; /* :335 */
+
+    const int32_t leaving = e->vibr[pr], entering = e->vibc[pc]; /* :339-340 */
+    e->vibr[pr] = entering;
+    e->vibc[pc] = leaving;
+    e->rbv[entering] = pr;
+    e->rbv[leaving] = -1;
+    e->cbv[entering] = -1;
+    e->cbv[leaving] = pc;
+
+    int32_t nnz = 0; /* :352-363 */
+    for (int32_t c = 0; c < width; c++) {
+        const double val = m[pro + c];
+        if (nonzero16(val)) {
+            m[pro + c] = val / quotient;
+            e->nz[nnz++] = c;
+        } else {
+            m[pro + c] = 0;
+        }
+    }
+    m[pro + pc] = 1 / quotient; /* :364 */
+
+    for (int32_t r = 0; r < height; r++) { /* :367-392 */
+        if (r == pr) continue;
+        const size_t ro = (size_t)r * width;
+        const double pcv = m[ro + pc];
+        if (nonzero16(pcv)) {
+            const double coefficient = pcv;
+            for (int32_t i = 0; i < nnz; i++) {
+                const int32_t c = e->nz[i];
+                const double v0 = m[pro + c];
+                if (nonzero16(v0)) {
+                    m[ro + c] = m[ro + c] - coefficient * v0; /* two roundings */
+                } else if (v0 != 0) {
+                    m[pro + c] = 0;
+                }
+            }
+            m[ro + pc] = -coefficient / quotient;
+        }
+        /* the reference's inner `else if (coefficient !== 0) matrix[...] = 0` (:388-390) is unreachable: it sits
+           inside `if (!(pivotColVal tiny))` with coefficient === pivotColVal, so tiny entries stay untouched */
+    }
+    trace_push(e, pr, pc);
+}
+
+/* checkForCycles (simplex.ts:415-440): returns 1 and fills start/len when a repeated block is found */
+static int check_for_cycles(const int32_t* h /* pairs */, int64_t n, int32_t* start, int32_t* len) {
+    for (int64_t e1 = 0; e1 < n - 1; e1++) {
+        for (int64_t e2 = e1 + 1; e2 < n; e2++) {
+            if (h[2 * e1] == h[2 * e2] && h[2 * e1 + 1] == h[2 * e2 + 1]) {
+                if (e2 - e1 > n - e2) break;
+                int found = 1;
+                for (int64_t i = 1; i < e2 - e1; i++) {
+                    if (h[2 * (e1 + i)] != h[2 * (e2 + i)] || h[2 * (e1 + i) + 1] != h[2 * (e2 + i) + 1]) {
+                        found = 0;
+                        break;
+                    }
+                }
+                if (found) {
+                    *start = (int32_t)e1;
+                    *len = (int32_t)(e2 - e1);
+                    return 1;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+typedef struct { int32_t* h; int64_t n, cap; } hist_t;
+static void hist_push(hist_t* hs, int32_t a, int32_t b) {
+    if (hs->n + 1 > hs->cap) {
+        hs->cap = hs->cap ? hs->cap * 2 : 256;
+        hs->h = (int32_t*)realloc(hs->h, (size_t)hs->cap * 2 * sizeof(int32_t));
+    }
+    hs->h[2 * hs->n] = a;
+    hs->h[2 * hs->n + 1] = b;
+    hs->n++;
+}
+
+/* phase1 (simplex.ts:25-98) */
+static int32_t phase1(jslp_engine* e, int check_cycles, jslp_simplex_result* res) {
+    const double* m = e->matrix;
+    const int32_t width = e->width, last_col = e->width - 1, last_row = e->height - 1;
+    const double precision = e->precision;
+    hist_t hs = {0, 0, 0};
+    int32_t iterations = 0;
+    for (;;) {
+        int32_t leaving_row = 0; /* :39-49 */
+        double rhs_value = -precision;
+        for (int32_t r = 1; r <= last_row; r++) {
+            const double value = m[(size_t)r * width];
+            if (value < rhs_value) {
+                rhs_value = value;
+                leaving_row = r;
+            }
+        }
+        if (leaving_row == 0) { /* :51-54 */
+            e->feasible = 1;
+            break;
+        }
+        int32_t entering_col = 0; /* :56-71 */
+        double max_quotient = -INFINITY;
+        const size_t lro = (size_t)leaving_row * width;
+        for (int32_t c = 1; c <= last_col; c++) {
+            const double coefficient = m[lro + c];
+            const int unrestricted = e->unrestricted[e->vibc[c]];
+            if (unrestricted || coefficient < -precision) {
+                const double quotient = -m[c] / coefficient;
+                if (max_quotient < quotient) {
+                    max_quotient = quotient;
+                    entering_col = c;
+                }
+            }
+        }
+        if (entering_col == 0) { /* :73-76 */
+            e->feasible = 0;
+            break;
+        }
+        if (check_cycles) { /* :78-93 */
+            hist_push(&hs, e->vibr[leaving_row], e->vibc[entering_col]);
+            int32_t s, l;
+            if (check_for_cycles(hs.h, hs.n, &s, &l)) {
+                res->cycle_phase = 1;
+                res->cycle_start = s;
+                res->cycle_length = l;
+                e->feasible = 0;
+                break;
+            }
+        }
+        pivot(e, leaving_row, entering_col);
+        m = e->matrix;
+        iterations++;
+    }
+    free(hs.h);
+    return iterations;
+}
+
+/* Math.round: nearest integer, ties toward +Infinity */
+static double js_round(double x) {
+    if (!isfinite(x)) return x;
+    double f = floor(x);
+    return (x - f >= 0.5) ? f + 1.0 : f;
+}
+
+/* setEvaluation (tableau.ts:420-430) */
+static double rounded_evaluation(const jslp_engine* e) {
+    const double rc = js_round(1 / e->precision);
+    return js_round((2.220446049250313e-16 + e->matrix[0]) * rc) / rc;
+}
+
+/* phase2 (simplex.ts:100-325) without optional objectives (nOptionalObjectives == 0) */
+static int32_t phase2(jslp_engine* e, int check_cycles, jslp_simplex_result* res) {
+    const double* m = e->matrix;
+    const int32_t width = e->width, last_col = e->width - 1, last_row = e->height - 1;
+    const double precision = e->precision;
+    hist_t hs = {0, 0, 0};
+    int32_t iterations = 0;
+
+    const int32_t n_columns = last_col; /* :118-127 */
+    int32_t batch = (int32_t)floor(sqrt((double)n_columns));
+    if (batch < 50) batch = 50;
+    if (batch > 500) batch = 500;
+    const int use_partial = n_columns > batch * 2;
+    int32_t pricing_batch_start = 1; /* tableau.ts:91; provably always 1 at loop entry */
+
+    for (;;) {
+        int32_t entering_col = 0; /* :136-219 */
+        double entering_value = precision;
+        int is_rc_negative = 0;
+        if (use_partial) {
+            const int32_t start_batch = pricing_batch_start;
+            int32_t scanned = 0;
+            const int32_t total = (n_columns + batch - 1) / batch;
+            while (entering_col == 0 && scanned < total) {
+                const int32_t bs = pricing_batch_start;
+                int32_t be = bs + batch - 1;
+                if (be > last_col) be = last_col;
+                for (int32_t c = bs; c <= be; c++) {
+                    const double rc = m[c];
+                    const int unrestricted = e->unrestricted[e->vibc[c]];
+                    if (unrestricted && rc < 0) {
+                        if (-rc > entering_value) {
+                            entering_value = -rc;
+                            entering_col = c;
+                            is_rc_negative = 1;
+                        }
+                        continue;
+                    }
+                    if (rc > entering_value) {
+                        entering_value = rc;
+                        entering_col = c;
+                        is_rc_negative = 0;
+                    }
+                }
+                pricing_batch_start = be >= last_col ? 1 : be + 1;
+                scanned++;
+            }
+            if (entering_col != 0) pricing_batch_start = start_batch;
+        } else {
+            for (int32_t c = 1; c <= last_col; c++) {
+                const double rc = m[c];
+                const int unrestricted = e->unrestricted[e->vibc[c]];
+                if (unrestricted && rc < 0) {
+                    if (-rc > entering_value) {
+                        entering_value = -rc;
+                        entering_col = c;
+                        is_rc_negative = 1;
+                    }
+                    continue;
+                }
+                if (rc > entering_value) {
+                    entering_value = rc;
+                    entering_col = c;
+                    is_rc_negative = 0;
+                }
+            }
+        }
+        if (entering_col == 0) { /* :265-269 */
+            e->evaluation = rounded_evaluation(e);
+            res->optimal = 1;
+            break;
+        }
+        int32_t leaving_row = 0; /* :271-296 */
+        double min_quotient = INFINITY;
+        for (int32_t r = 1; r <= last_row; r++) {
+            const size_t ro = (size_t)r * width;
+            const double rhs = m[ro];
+            const double col = m[ro + entering_col];
+            if (-precision < col && col < precision) continue;
+            if (col > 0 && precision > rhs && rhs > -precision) {
+                min_quotient = 0;
+                leaving_row = r;
+                break;
+            }
+            const double quotient = is_rc_negative ? -rhs / col : rhs / col;
+            if (quotient > precision && min_quotient > quotient) {
+                min_quotient = quotient;
+                leaving_row = r;
+            }
+        }
+        if (min_quotient == INFINITY) { /* :298-303 */
+            e->evaluation = -INFINITY;
+            e->bounded = 0;
+            e->unbounded_var_index = e->vibc[entering_col];
+            break;
+        }
+        if (check_cycles) { /* :305-320 */
+            hist_push(&hs, e->vibr[leaving_row], e->vibc[entering_col]);
+            int32_t s, l;
+            if (check_for_cycles(hs.h, hs.n, &s, &l)) {
+                res->cycle_phase = 2;
+                res->cycle_start = s;
+                res->cycle_length = l;
+                e->feasible = 0;
+                break;
+            }
+        }
+        pivot(e, leaving_row, entering_col);
+        m = e->matrix;
+        iterations++;
+    }
+    free(hs.h);
+    return iterations;
+}
+
+/* simplex (simplex.ts:14-23) */
+int jslp_engine_simplex(jslp_engine* e, int check_cycles, jslp_simplex_result* out) {
+    if (!e || !out) return fail(JSLP_ERR_ARG, "simplex: null");
+    if (!e->uploaded) return fail(JSLP_ERR_STATE, "simplex before upload");
+    memset(out, 0, sizeof *out);
+    out->pivots_phase2 = -1;
+    e->bounded = 1;
+    out->pivots_phase1 = phase1(e, check_cycles, out);
+    if (e->feasible) out->pivots_phase2 = phase2(e, check_cycles, out);
+    out->feasible = e->feasible;
+    out->bounded = e->bounded;
+    out->unbounded_var_index = e->bounded ? -1 : e->unbounded_var_index;
+    out->height = e->height;
+    out->obj_cell = e->matrix[0];
+    out->evaluation = e->evaluation;
+    return JSLP_OK;
+}
+
+int jslp_engine_pivot(jslp_engine* e, int32_t row, int32_t col) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "pivot before upload");
+    if (row < 0 || row >= e->height || col < 0 || col >= e->width) return fail(JSLP_ERR_ARG, "pivot: out of range");
+    pivot(e, row, col);
+    return JSLP_OK;
+}
+
+/* save = copy (backup.ts:13-51) */
+int jslp_engine_save(jslp_engine* e) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "save before upload");
+    memcpy(e->s_matrix, e->matrix, (size_t)e->height * e->width * sizeof(double));
+    memcpy(e->s_vibr, e->vibr, (size_t)e->height * sizeof(int32_t));
+    memcpy(e->s_vibc, e->vibc, (size_t)e->width * sizeof(int32_t));
+    memcpy(e->s_rbv, e->rbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+    memcpy(e->s_cbv, e->cbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+    e->s_height = e->height;
+    e->s_last_element_index = e->last_element_index;
+    e->has_save = 1;
+    return JSLP_OK;
+}
+
+/* restore (backup.ts:53-105): flags / evaluation are NOT part of the snapshot */
+int jslp_engine_restore(jslp_engine* e) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "restore before upload");
+    if (!e->has_save) return JSLP_OK; /* :54-56 */
+    e->height = e->s_height;
+    e->last_element_index = e->s_last_element_index;
+    memcpy(e->matrix, e->s_matrix, (size_t)e->height * e->width * sizeof(double));
+    memcpy(e->vibr, e->s_vibr, (size_t)e->height * sizeof(int32_t));
+    memcpy(e->vibc, e->s_vibc, (size_t)e->width * sizeof(int32_t));
+    /* the reference restores rowByVarIndex/colByVarIndex for v < save.nVars only (:87-92); cut slacks above
+       that keep stale entries there, which nothing reads before addCutConstraints rewrites them */
+    memcpy(e->rbv, e->s_rbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+    memcpy(e->cbv, e->s_cbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+    return JSLP_OK;
+}
+
+/* addCutConstraints (cutting-strategies.ts:16-72) */
+int jslp_engine_add_cuts(jslp_engine* e, int32_t n, const int8_t* type, const int32_t* var_index,
+                         const double* value) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "add_cuts before upload");
+    if (n < 0 || (n > 0 && (!type || !var_index || !value))) return fail(JSLP_ERR_ARG, "add_cuts: null");
+    if (e->height + n > e->cap_rows) return fail(JSLP_ERR_CAPACITY, "add_cuts: row capacity exceeded");
+    double* m = e->matrix;
+    const int32_t width = e->width, height = e->height, last_col = e->width - 1;
+    for (int32_t h = 0; h < n; h++) {
+        const int32_t cut_row = height + h;
+        const size_t cro = (size_t)cut_row * width;
+        const double sign = type[h] == JSLP_CUT_MIN ? -1 : 1; /* :41 */
+        const int32_t vi = var_index[h];
+        if (vi < 0 || vi >= e->n_idx_cap) return fail(JSLP_ERR_ARG, "add_cuts: var index out of range");
+        const int32_t var_row = e->rbv[vi];
+        if (var_row == -1) { /* :46-53 */
+            if (e->cbv[vi] < 0) return fail(JSLP_ERR_ARG, "add_cuts: variable neither basic nor non-basic");
+            m[cro] = sign * value[h];
+            for (int32_t c = 1; c <= last_col; c++) m[cro + c] = 0;
+            m[cro + e->cbv[vi]] = sign;
+        } else { /* :54-62 */
+            const size_t vro = (size_t)var_row * width;
+            const double var_value = m[vro];
+            m[cro] = sign * (value[h] - var_value);
+            for (int32_t c = 1; c <= last_col; c++) m[cro + c] = -sign * m[vro + c];
+        }
+        const int32_t slack = e->last_element_index++; /* getNewElementIndex, tableau.ts:393-401 */
+        if (slack >= e->n_idx_cap) return fail(JSLP_ERR_CAPACITY, "add_cuts: element index capacity exceeded");
+        e->vibr[cut_row] = slack;
+        e->rbv[slack] = cut_row;
+        e->cbv[slack] = -1;
+    }
+    e->height = height + n;
+    return JSLP_OK;
+}
+
+int jslp_engine_read_rhs(jslp_engine* e, double* rhs, int32_t* var_index_by_row) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "read_rhs before upload");
+    for (int32_t r = 0; r < e->height; r++) {
+        if (rhs) rhs[r] = e->matrix[(size_t)r * e->width];
+        if (var_index_by_row) var_index_by_row[r] = e->vibr[r];
+    }
+    return JSLP_OK;
+}
+
+/* applyCuts (branch-and-cut.ts:33-37) */
+int jslp_engine_relax(jslp_engine* e, int32_t n_cuts, const int8_t* type, const int32_t* var_index,
+                      const double* value, int check_cycles, jslp_simplex_result* out, double* rhs,
+                      int32_t* var_index_by_row) {
+    int rc = jslp_engine_restore(e);
+    if (rc) return rc;
+    rc = jslp_engine_add_cuts(e, n_cuts, type, var_index, value);
+    if (rc) return rc;
+    rc = jslp_engine_simplex(e, check_cycles, out);
+    if (rc) return rc;
+    return jslp_engine_read_rhs(e, rhs, var_index_by_row);
+}
+
+int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                            const int32_t* var_index, const double* value, int check_cycles,
+                            jslp_simplex_result* out, double* rhs, int32_t* var_index_by_row,
+                            int32_t out_stride) {
+    if (!e || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "relax_batch: null");
+    if ((rhs || var_index_by_row) && out_stride < e->cap_rows) return fail(JSLP_ERR_ARG, "relax_batch: out_stride < row capacity");
+    /* each node starts from the saved root, but flags carry over exactly as in a sequential B&B only through
+       `evaluation` of non-optimal nodes; nodes here are independent, so reset it per node */
+    for (int32_t i = 0; i < n_nodes; i++) {
+        const int32_t a = cut_offsets[i], n = cut_offsets[i + 1] - a;
+        int rc = jslp_engine_relax(e, n, type ? type + a : 0, var_index ? var_index + a : 0, value ? value + a : 0,
+                                   check_cycles, &out[i], rhs ? rhs + (size_t)i * out_stride : 0,
+                                   var_index_by_row ? var_index_by_row + (size_t)i * out_stride : 0);
+        if (rc) return rc;
+    }
+    return JSLP_OK;
+}
+
+int jslp_engine_dims(const jslp_engine* e, int32_t* height, int32_t* width, int32_t* n_var_indexes) {
+    if (!e) return fail(JSLP_ERR_ARG, "dims: null");
+    if (height) *height = e->height;
+    if (width) *width = e->width;
+    if (n_var_indexes) *n_var_indexes = e->n_idx_cap;
+    return JSLP_OK;
+}
+
+int jslp_engine_download(jslp_engine* e, double* matrix, int32_t* var_index_by_row, int32_t* var_index_by_col,
+                         int32_t* row_by_var_index, int32_t* col_by_var_index) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "download before upload");
+    if (matrix) memcpy(matrix, e->matrix, (size_t)e->height * e->width * sizeof(double));
+    if (var_index_by_row) memcpy(var_index_by_row, e->vibr, (size_t)e->height * sizeof(int32_t));
+    if (var_index_by_col) memcpy(var_index_by_col, e->vibc, (size_t)e->width * sizeof(int32_t));
+    if (row_by_var_index) memcpy(row_by_var_index, e->rbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+    if (col_by_var_index) memcpy(col_by_var_index, e->cbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+    return JSLP_OK;
+}
+
+int jslp_engine_pivot_trace(jslp_engine* e, int32_t* row_col, int64_t max_pairs, int64_t* n_pivots) {
+    if (!e || !n_pivots) return fail(JSLP_ERR_ARG, "pivot_trace: null");
+    *n_pivots = e->n_trace;
+    if (row_col && max_pairs > 0) {
+        int64_t n = e->n_trace < max_pairs ? e->n_trace : max_pairs;
+        memcpy(row_col, e->trace, (size_t)n * 2 * sizeof(int32_t));
+    }
+    return JSLP_OK;
+}
+
+int jslp_engine_set_timing(jslp_engine* e, int enabled) { (void)e; (void)enabled; return JSLP_OK; }
+int jslp_engine_get_timing(jslp_engine* e, double* update_kernel_ms, int64_t* update_kernel_launches,
+                           double* total_device_ms) {
+    (void)e;
+    if (update_kernel_ms) *update_kernel_ms = 0;
+    if (update_kernel_launches) *update_kernel_launches = 0;
+    if (total_device_ms) *total_device_ms = 0;
+    return JSLP_OK;
+}

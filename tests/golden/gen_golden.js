@@ -140,7 +140,11 @@ function run(model, keepPivots) {
     rec = null;
     const t = solution._tableau;
     const result = solver.buildSimplifiedResult(solution);
+    const pre = solver.lastSolvedModel && solver.lastSolvedModel.presolveResult;
     const out = {
+        // the host pre-pass the reference runs before the hot path (model.ts:429-440, out of scope here): it can
+        // declare infeasibility before any simplex runs and it zeroes the cost of variables it fixes
+        presolve: pre ? { isInfeasible: !!pre.isInfeasible, nFixed: pre.fixedVariables ? pre.fixedVariables.size : 0 } : null,
         tableau: r.tableau, // null when presolve declared the model infeasible before any simplex ran
         nPivots: r.pivots.length / 2,
         pivotDigest: (r.h >>> 0).toString(16),
@@ -229,4 +233,3 @@ for (const s of synth) {
         feasible: out.final.feasible, bounded: out.final.bounded, result: out.result.result, refWallMs: out.refWallMs });
     console.log("synthetic", name, out.nPivots, out.pivotDigest, out.final.feasible, out.result.result, out.refWallMs.toFixed(0) + "ms");
 }
-if (!only) fs.writeFileSync(path.join(__dirname, "index.json"), JSON.stringify(index, null, 1));
