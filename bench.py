@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement (BASELINE.json): simplex pivots/sec on the synthetic dense LP
+generateResourceAllocation({seed:12345, numVariables:2000, numConstraints:2000, density:1.0}) (config 3a:
+2001 x 2001 fp64 tableau, 9726 pivots, cycle check off -- the FASTER reference setting), 1 GPU; with
+--gpus N every rank solves its own replica (a single LP does not shard: SURVEY.md 8e "replicas only"), and
+the LP-relaxation throughput of the sharded branch-and-bound workload (config 4, Monster_II node batch,
+nodes split across ranks, no data-path collective) rides along in "relaxations".
+
+A "step" = one complete simplex() of the workload with the tableau already resident in HBM (restored from
+the device-side snapshot; the 32 MB host upload happens once, outside the timed region).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(n, sample_pivots):
+    """The reference itself (oracle/_ref, type-erased TypeScript under node, 1 thread) on the SAME instance,
+    stopped after `sample_pivots` pivots of its simplex(); time = simplex entry -> last sampled pivot."""
+    script = os.path.join(ROOT, "oracle", "ref_pivot_rate.js")
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "src", "solver.js")):
+        return None
+    try:
+        out = subprocess.run(["node", "--max-old-space-size=8192", script, str(n), str(sample_pivots)],
+                             capture_output=True, text=True, timeout=900)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        r = json.loads(line)
+        return {"value": r["pivots_per_sec"], "unit": "pivots/s", "cores": 1, "kind": "reference",
+                "sample": "first %d of the %d pivots of the same %dx%d instance, reference TS (type-erased) under node %s, "
+                          "options.exitOnCycles=false, simplex() time only; host has %d cores"
+                          % (r["pivots"], 9726 if n == 2000 else -1, n + 1, n + 1, r["node"], os.cpu_count())}
+    except Exception as e:  # the baseline is reported, never required
+        return {"value": None, "unit": "pivots/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=2000, help="variables = constraints of the dense LP (2000 = config 3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-pivots", type=int, default=1200)
+    ap.add_argument("--no-relaxations", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from jslpsolver_amd import _capi, generators
+    from jslpsolver_amd.engine import Tableau, pivot_digest
+
+    lib = _capi.load_hip()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    # ---- workload: config 3a ------------------------------------------------------------------------
+    n = args.n
+    m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
+    H, W = m.shape
+    t = Tableau(m, vibr, vibc, device=local_rank, lib=lib)
+    t.save()  # device-resident copy of the initial tableau: every step restarts from it without touching PCIe
+
+    def step():
+        t.restore()
+        return t.simplex(check_cycles=False)
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    pivots = 0
+    for _ in range(args.steps):
+        res = step()
+        pivots += res.pivots_phase1 + max(res.pivots_phase2, 0)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    total_pivots = sum_over_ranks(float(pivots))
+    value = total_pivots / elapsed
+    digest = pivot_digest(t.pivot_trace()[-(res.pivots_phase1 + max(res.pivots_phase2, 0)):])
+    pivots_per_solve = res.pivots_phase1 + max(res.pivots_phase2, 0)
+
+    # ---- roofline of the dominant kernel (k_update), measured live with HIP events on the engine's stream ---
+    roofline = None
+    if rank == 0:
+        t.set_timing(True)
+        step()
+        upd_ms, launches, total_ms = t.get_timing()
+        t.set_timing(False)
+        bytes_per_launch = 16.0 * H * W  # read + write every fp64 cell of the H x W tableau
+        avg_s = (upd_ms / 1e3) / max(launches, 1)
+        achieved = bytes_per_launch / avg_s if launches else 0.0
+        roofline = {"bound": "hbm", "kernel": "k_update", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                    "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches": launches,
+                    "whole_pivot_frac": (bytes_per_launch * value / max(world, 1)) / HBM_PEAK}
+    t.close()
+
+    # ---- LP relaxations/sec: Monster_II node batch sharded over ranks (config 4, throughput variant) -----
+    relax = None
+    if not args.no_relaxations:
+        relax = relaxation_throughput(lib, local_rank, rank, world, barrier, max_over_ranks, sum_over_ranks)
+
+    if rank == 0:
+        line = {
+            "metric": "simplex pivots/sec", "value": value, "unit": "pivots/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config 3a: generateResourceAllocation(seed 12345, %d vars x %d constraints, density 1.0), "
+                                   "%dx%d fp64 tableau, %d pivots per solve, cycle check off; one replica per GPU"
+                                   % (n, n, H, W, pivots_per_solve),
+                       "pivot_digest": digest, "result_evaluation": t.evaluation, "parallelism": "replicas%d" % world},
+            "roofline": roofline,
+        }
+        if relax is not None:
+            line["relaxations"] = relax
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(n, args.cpu_sample_pivots)
+            if line["cpu_baseline"] and line["cpu_baseline"].get("value"):
+                line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def relaxation_throughput(lib, device, rank, world, barrier, max_over_ranks, sum_over_ranks, reps=8):
+    """Config 4 throughput variant: the 151 cut lists the reference visits on Monster_II,
+    replicated `reps` times, evaluated as independent nodes; rank r takes nodes r, r+world, ... (no collective
+    in the data path).  Needs the committed golden fixture for the cut lists only."""
+    import gzip
+    from jslpsolver_amd import Model
+    from jslpsolver_amd.engine import Tableau
+    path = os.path.join(ROOT, "tests", "golden", "fixtures", "Monster_II.json.gz")
+    if not os.path.exists(path):
+        return None
+    with gzip.open(path, "rt") as fh:
+        g = json.load(fh)
+    model = Model(g["model"])
+    m, vibr, vibc = model.build_tableau()
+    nodes = [c["cuts"] or [] for c in g["simplexCalls"][1:]] * reps
+    mine = nodes[rank::world]
+    t = Tableau(m, vibr, vibc, model.unrestricted, precision=model.precision,
+                row_capacity=m.shape[0] + 2 * len(model.integerVariables), device=device, lib=lib)
+    t.applyCuts([], check_cycles=True)  # root relaxation
+    t.save()
+    t.applyCutsBatch(mine, check_cycles=True)  # warm-up (allocates the slots)
+    barrier()
+    t0 = time.perf_counter()
+    results, _, _ = t.applyCutsBatch(mine, check_cycles=True)
+    barrier()
+    el = max_over_ranks(time.perf_counter() - t0)
+    total = sum_over_ranks(float(len(mine)))
+    piv = sum_over_ranks(float(sum(r.pivots_phase1 + max(r.pivots_phase2, 0) for r in results)))
+    t.close()
+    return {"value": total / el, "unit": "LP relaxations/s", "nodes": int(total), "pivots": int(piv), "seconds": el,
+            "workload": "config 4: Monster_II (935x925 root, 112 ints), the reference's 151 visited cut lists x%d as one "
+                        "batch of independent nodes, sharded round-robin over %d rank(s)" % (reps, world)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,692 @@
+// jslp_hip.hip -- host side of the MI355X engine: the C ABI of include/jslp_engine.h over the kernels in
+// jslp_kernels.hip.h.  Build (see __graft_entry__.build):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -o libjslp_hip.so jslp_hip.hip
+//
+// Launch strategy (DESIGN.md "Kernels"):
+//   * large tableau  -> per pivot one k_select (1 workgroup) + one k_update (whole chip) on the engine's
+//     stream; pivots are enqueued in chunks and the 128-byte device state is polled once per chunk, so the
+//     GPU never waits for the host inside a chunk.  Kernels launched after the solve ended exit at once.
+//   * small tableau / batch of branch-and-bound nodes -> k_simplex_wg: one workgroup runs the whole
+//     simplex() of one tableau copy ("slot"); a batch is one launch with grid = #nodes.
+#include "../../include/jslp_engine.h"
+#include "jslp_kernels.hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+static thread_local char g_err[512];
+static int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
+    snprintf(g_err, sizeof g_err, fmt, a, b);
+    return code;
+}
+#define HIPC(expr)                                                                              \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) return fail(JSLP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+struct jslp_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int32_t H0 = 0, W = 0, ld = 0, cap_rows = 0, n_idx = 0;
+    double precision = 1e-8;
+    int32_t batch = 50, use_partial = 0;
+    int uploaded = 0, has_save = 0;
+    double evaluation = 0;
+    // slots (slot 0 = the live tableau)
+    int n_slots = 0;
+    Slots s{};
+    // snapshot
+    double* snap_A = nullptr;
+    int32_t *snap_vibr = nullptr, *snap_vibc = nullptr, *snap_rbv = nullptr, *snap_cbv = nullptr;
+    uint8_t* d_unr = nullptr;
+    // cuts staging
+    int32_t* d_cut_offs = nullptr; int8_t* d_cut_type = nullptr; int32_t* d_cut_var = nullptr; double* d_cut_val = nullptr;
+    size_t cut_cap = 0, node_cap = 0;
+    // read-back staging (device + pinned host)
+    double* d_rhs = nullptr; int32_t* d_rows = nullptr; DevState* d_states = nullptr;
+    double* h_rhs = nullptr; int32_t* h_rows = nullptr; DevState* h_states = nullptr;
+    size_t out_cap = 0;  // nodes
+    DevState* h_state = nullptr;  // pinned, 1 entry
+    // policy
+    int force_path = 0;  // 0 auto, 1 workgroup kernel, 2 select+update kernels
+    // timing
+    int timing = 0;
+    double upd_ms = 0, total_ms = 0;
+    long long upd_launches = 0;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+};
+
+static const long long WG_CELLS_SINGLE = 64 * 1024;         // one workgroup beats 2 launches/pivot below this
+static const long long WG_CELLS_BATCH = 4LL * 1024 * 1024;  // batches use one workgroup per node up to this
+static const size_t HIST_CAP_MAIN = 1u << 20;
+static const size_t HIST_CAP_SLOT = 1u << 16;
+static const long long TRACE_CAP = 1LL << 22;
+
+extern "C" const char* jslp_backend_name(void) { return "hip-gfx950"; }
+extern "C" const char* jslp_last_error(void) { return g_err; }
+extern "C" int jslp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int32_t round_up(int32_t x, int32_t m) { return (x + m - 1) / m * m; }
+
+static void free_slots(jslp_engine* e) {
+    hipFree(e->s.A); hipFree(e->s.vibr); hipFree(e->s.vibc); hipFree(e->s.rbv); hipFree(e->s.cbv);
+    hipFree(e->s.prow); hipFree(e->s.pcol); hipFree(e->s.st); hipFree(e->s.hist);
+    e->s.A = nullptr; e->s.vibr = e->s.vibc = e->s.rbv = e->s.cbv = nullptr;
+    e->s.prow = e->s.pcol = nullptr; e->s.st = nullptr; e->s.hist = nullptr;
+}
+
+// (re)allocate the slot arrays for n slots, preserving slot 0
+static int ensure_slots(jslp_engine* e, int n) {
+    if (n <= e->n_slots) return JSLP_OK;
+    Slots o = e->s, s = e->s;
+    const int old_n = e->n_slots;
+    s.A_stride = (long long)e->cap_rows * e->ld;
+    s.vibr_stride = e->cap_rows;
+    s.vibc_stride = e->W;
+    s.idx_stride = e->n_idx;
+    s.prow_stride = e->ld;
+    s.pcol_stride = e->cap_rows;
+    s.hist_cap = n == 1 ? (int32_t)HIST_CAP_MAIN : (int32_t)HIST_CAP_SLOT;
+    s.ld = e->ld; s.W = e->W; s.batch = e->batch; s.use_partial = e->use_partial; s.precision = e->precision;
+    s.unr = e->d_unr;
+    HIPC(hipMalloc(&s.A, sizeof(double) * s.A_stride * n));
+    HIPC(hipMalloc(&s.vibr, sizeof(int32_t) * (size_t)s.vibr_stride * n));
+    HIPC(hipMalloc(&s.vibc, sizeof(int32_t) * (size_t)s.vibc_stride * n));
+    HIPC(hipMalloc(&s.rbv, sizeof(int32_t) * (size_t)s.idx_stride * n));
+    HIPC(hipMalloc(&s.cbv, sizeof(int32_t) * (size_t)s.idx_stride * n));
+    HIPC(hipMalloc(&s.prow, sizeof(double) * (size_t)s.prow_stride * n));
+    HIPC(hipMalloc(&s.pcol, sizeof(double) * (size_t)s.pcol_stride * n));
+    HIPC(hipMalloc(&s.st, sizeof(DevState) * n));
+    HIPC(hipMalloc(&s.hist, sizeof(int2) * (size_t)s.hist_cap * n));
+    HIPC(hipMemsetAsync(s.A, 0, sizeof(double) * s.A_stride * n, e->stream));
+    HIPC(hipMemsetAsync(s.st, 0, sizeof(DevState) * n, e->stream));
+    HIPC(hipMemsetAsync(s.prow, 0, sizeof(double) * (size_t)s.prow_stride * n, e->stream));
+    HIPC(hipMemsetAsync(s.pcol, 0, sizeof(double) * (size_t)s.pcol_stride * n, e->stream));
+    if (!s.trace) {
+        HIPC(hipMalloc(&s.trace, sizeof(int2) * TRACE_CAP));
+        s.trace_cap = TRACE_CAP;
+    }
+    if (old_n > 0) {  // carry the live tableau over
+        HIPC(hipMemcpyAsync(s.A, o.A, sizeof(double) * o.A_stride, hipMemcpyDeviceToDevice, e->stream));
+        HIPC(hipMemcpyAsync(s.vibr, o.vibr, sizeof(int32_t) * o.vibr_stride, hipMemcpyDeviceToDevice, e->stream));
+        HIPC(hipMemcpyAsync(s.vibc, o.vibc, sizeof(int32_t) * o.vibc_stride, hipMemcpyDeviceToDevice, e->stream));
+        HIPC(hipMemcpyAsync(s.rbv, o.rbv, sizeof(int32_t) * o.idx_stride, hipMemcpyDeviceToDevice, e->stream));
+        HIPC(hipMemcpyAsync(s.cbv, o.cbv, sizeof(int32_t) * o.idx_stride, hipMemcpyDeviceToDevice, e->stream));
+        HIPC(hipMemcpyAsync(s.st, o.st, sizeof(DevState), hipMemcpyDeviceToDevice, e->stream));
+        HIPC(hipStreamSynchronize(e->stream));
+        e->s = o;
+        free_slots(e);
+    }
+    e->s = s;
+    e->n_slots = n;
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height, int32_t width, int32_t row_capacity,
+                                  double precision) {
+    if (!out || height < 1 || width < 1 || row_capacity < height) return fail(JSLP_ERR_ARG, "create: bad dimensions");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(JSLP_ERR_DEVICE, "create: no HIP device visible (this engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(JSLP_ERR_ARG, "create: device ordinal out of range");
+    HIPC(hipSetDevice(device));
+    jslp_engine* e = new jslp_engine();
+    e->device = device;
+    e->H0 = height; e->W = width; e->cap_rows = row_capacity; e->precision = precision;
+    e->ld = round_up(width, 16);
+    e->n_idx = width + 2 * row_capacity + 2;
+    // partial pricing parameters (simplex.ts:118-127)
+    const int32_t n_columns = width - 1;
+    int32_t b = (int32_t)floor(sqrt((double)n_columns));
+    b = std::min(500, std::max(50, b));
+    e->batch = b;
+    e->use_partial = n_columns > b * 2;
+    const char* fp = getenv("JSLP_FORCE_PATH");
+    if (fp && !strcmp(fp, "wg")) e->force_path = 1;
+    if (fp && !strcmp(fp, "sp")) e->force_path = 2;
+    int rc = JSLP_OK;
+    auto init = [&]() -> int {
+        HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        HIPC(hipMalloc(&e->d_unr, e->n_idx));
+        HIPC(hipMemsetAsync(e->d_unr, 0, e->n_idx, e->stream));
+        int r = ensure_slots(e, 1);
+        if (r) return r;
+        const size_t cells = (size_t)e->cap_rows * e->ld;
+        HIPC(hipMalloc(&e->snap_A, sizeof(double) * cells));
+        HIPC(hipMalloc(&e->snap_vibr, sizeof(int32_t) * e->cap_rows));
+        HIPC(hipMalloc(&e->snap_vibc, sizeof(int32_t) * e->W));
+        HIPC(hipMalloc(&e->snap_rbv, sizeof(int32_t) * e->n_idx));
+        HIPC(hipMalloc(&e->snap_cbv, sizeof(int32_t) * e->n_idx));
+        HIPC(hipHostMalloc(&e->h_state, sizeof(DevState)));
+        HIPC(hipEventCreate(&e->ev_begin));
+        HIPC(hipEventCreate(&e->ev_end));
+        HIPC(hipStreamSynchronize(e->stream));
+        return JSLP_OK;
+    };
+    rc = init();
+    if (rc) { jslp_engine_destroy(e); return rc; }
+    *out = e;
+    return JSLP_OK;
+}
+
+extern "C" void jslp_engine_destroy(jslp_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    free_slots(e);
+    hipFree(e->s.trace);
+    hipFree(e->snap_A); hipFree(e->snap_vibr); hipFree(e->snap_vibc); hipFree(e->snap_rbv); hipFree(e->snap_cbv);
+    hipFree(e->d_unr);
+    hipFree(e->d_cut_offs); hipFree(e->d_cut_type); hipFree(e->d_cut_var); hipFree(e->d_cut_val);
+    hipFree(e->d_rhs); hipFree(e->d_rows); hipFree(e->d_states);
+    if (e->h_rhs) hipHostFree(e->h_rhs);
+    if (e->h_rows) hipHostFree(e->h_rows);
+    if (e->h_states) hipHostFree(e->h_states);
+    if (e->h_state) hipHostFree(e->h_state);
+    for (auto ev : e->ev_pool) hipEventDestroy(ev);
+    if (e->ev_begin) hipEventDestroy(e->ev_begin);
+    if (e->ev_end) hipEventDestroy(e->ev_end);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const int32_t* var_index_by_row,
+                                  const int32_t* var_index_by_col, const int32_t* unrestricted_var_indexes,
+                                  int32_t n_unrestricted) {
+    if (!e || !matrix || !var_index_by_row || !var_index_by_col) return fail(JSLP_ERR_ARG, "upload: null pointer");
+    HIPC(hipSetDevice(e->device));
+    const int32_t H = e->H0, W = e->W;
+    std::vector<int32_t> rbv(e->n_idx, -1), cbv(e->n_idx, -1), vibr(e->cap_rows, -1), vibc(W, -1);
+    std::vector<uint8_t> unr(e->n_idx, 0);
+    for (int32_t r = 1; r < H; r++) {
+        const int32_t v = var_index_by_row[r];
+        if (v < 0 || v >= e->n_idx) return fail(JSLP_ERR_ARG, "upload: row variable index out of range");
+        vibr[r] = v; rbv[v] = r;
+    }
+    for (int32_t c = 1; c < W; c++) {
+        const int32_t v = var_index_by_col[c];
+        if (v < 0 || v >= e->n_idx) return fail(JSLP_ERR_ARG, "upload: column variable index out of range");
+        vibc[c] = v; cbv[v] = c;
+    }
+    for (int32_t i = 0; i < n_unrestricted; i++) {
+        const int32_t v = unrestricted_var_indexes[i];
+        if (v < 0 || v >= e->n_idx) return fail(JSLP_ERR_ARG, "upload: unrestricted variable index out of range");
+        unr[v] = 1;
+    }
+    DevState st;
+    memset(&st, 0, sizeof st);
+    st.H = H;
+    st.last_element_index = W + H - 2;  // tableau.ts:312-316
+    st.status = ST_DONE;
+    st.phase = 1;
+    st.feasible = 1;
+    st.bounded = 1;
+    st.unbounded_var = -1;
+    hipStream_t s = e->stream;
+    HIPC(hipMemsetAsync(e->s.A, 0, sizeof(double) * e->s.A_stride, s));
+    HIPC(hipMemcpy2DAsync(e->s.A, sizeof(double) * e->ld, matrix, sizeof(double) * W, sizeof(double) * W, H,
+                          hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(e->s.vibr, vibr.data(), sizeof(int32_t) * e->cap_rows, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(e->s.vibc, vibc.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(e->s.rbv, rbv.data(), sizeof(int32_t) * e->n_idx, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(e->s.cbv, cbv.data(), sizeof(int32_t) * e->n_idx, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(e->d_unr, unr.data(), e->n_idx, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(e->s.st, &st, sizeof st, hipMemcpyHostToDevice, s));
+    HIPC(hipStreamSynchronize(s));  // the host vectors die here
+    e->uploaded = 1;
+    e->has_save = 0;
+    e->evaluation = 0;
+    return JSLP_OK;
+}
+
+static Ctx host_ctx(const jslp_engine* e, int check_cycles) {
+    Ctx c;
+    c.A = e->s.A; c.vibr = e->s.vibr; c.vibc = e->s.vibc; c.rbv = e->s.rbv; c.cbv = e->s.cbv; c.unr = e->s.unr;
+    c.prow = e->s.prow; c.pcol = e->s.pcol; c.st = e->s.st; c.hist = e->s.hist; c.hist_cap = e->s.hist_cap;
+    c.trace = e->s.trace; c.trace_cap = e->s.trace_cap; c.ld = e->ld; c.W = e->W; c.check_cycles = check_cycles;
+    c.batch = e->batch; c.use_partial = e->use_partial; c.precision = e->precision;
+    return c;
+}
+
+static int iters_cap(const jslp_engine* e) {
+    // the reference has no iteration limit; this cap only turns an endless cycle (cycle check disabled) into
+    // an error instead of a hung GPU
+    long long cap = 2000000LL + 200LL * ((long long)e->cap_rows + e->W);
+    return (int)std::min<long long>(cap, 2000000000LL);
+}
+
+static bool use_wg_single(const jslp_engine* e) {
+    if (e->force_path == 1) return true;
+    if (e->force_path == 2) return false;
+    return (long long)e->cap_rows * e->ld <= WG_CELLS_SINGLE;
+}
+
+static dim3 update_grid(const jslp_engine* e, int H) {
+    return dim3((e->ld + JSLP_UPD_COLS - 1) / JSLP_UPD_COLS, (H + JSLP_UPD_ROWS - 1) / JSLP_UPD_ROWS, 1);
+}
+
+// Math.round: nearest integer, ties toward +Infinity
+static double js_round(double x) {
+    if (!std::isfinite(x)) return x;
+    const double f = floor(x);
+    return (x - f >= 0.5) ? f + 1.0 : f;
+}
+
+// checkForCycles (simplex.ts:415-440) on the downloaded history: only to rebuild the exact [start, length]
+// the reference pushes to model.messages; hit / no-hit was decided on the device.
+static void cycle_message(const std::vector<int2>& h, int32_t* start, int32_t* len) {
+    const long long n = (long long)h.size();
+    for (long long e1 = 0; e1 < n - 1; e1++)
+        for (long long e2 = e1 + 1; e2 < n; e2++)
+            if (h[e1].x == h[e2].x && h[e1].y == h[e2].y) {
+                if (e2 - e1 > n - e2) break;
+                bool found = true;
+                for (long long i = 1; i < e2 - e1; i++)
+                    if (h[e1 + i].x != h[e2 + i].x || h[e1 + i].y != h[e2 + i].y) { found = false; break; }
+                if (found) { *start = (int32_t)e1; *len = (int32_t)(e2 - e1); return; }
+            }
+    *start = -1; *len = 0;
+}
+
+static int state_error(const DevState& st) {
+    switch (st.err) {
+        case ERR_NONE: return JSLP_OK;
+        case ERR_HIST_FULL: return fail(JSLP_ERR_CAPACITY, "simplex: cycle-check history capacity exceeded");
+        case ERR_ITER_LIMIT: return fail(JSLP_ERR_CAPACITY, "simplex: iteration safety cap reached (endless cycle?)");
+        case ERR_CUT_ARG: return fail(JSLP_ERR_ARG, "add_cuts: variable index out of range or neither basic nor non-basic");
+        case ERR_CAPACITY: return fail(JSLP_ERR_CAPACITY, "add_cuts: row / element-index capacity exceeded");
+    }
+    return fail(JSLP_ERR_DEVICE, "unknown device error code");
+}
+
+// fold a finished DevState into the ABI result (evaluation semantics: see jslp_simplex_result)
+static int fill_result(jslp_engine* e, const DevState& st, int slot, double prev_evaluation, jslp_simplex_result* out,
+                       double* evaluation_out) {
+    memset(out, 0, sizeof *out);
+    out->feasible = st.feasible;
+    out->bounded = st.bounded;
+    out->optimal = st.optimal;
+    out->unbounded_var_index = st.bounded ? -1 : st.unbounded_var;
+    out->pivots_phase1 = st.it1;
+    out->pivots_phase2 = st.entered_phase2 ? st.it2 : -1;
+    out->cycle_phase = st.cycle_phase;
+    out->height = st.H;
+    out->obj_cell = st.obj_cell;
+    double ev = prev_evaluation;
+    if (st.optimal) {  // setEvaluation (tableau.ts:420-426)
+        const double rc = js_round(1.0 / e->precision);
+        ev = js_round((2.220446049250313e-16 + st.obj_cell) * rc) / rc;
+    } else if (!st.bounded) {
+        ev = -INFINITY;
+    }
+    out->evaluation = ev;
+    if (evaluation_out) *evaluation_out = ev;
+    if (st.cycle_phase) {
+        std::vector<int2> h(st.hist_n);
+        if (hipMemcpy(h.data(), e->s.hist + (size_t)slot * e->s.hist_cap, sizeof(int2) * st.hist_n, hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(JSLP_ERR_DEVICE, "cycle history read-back failed");
+        cycle_message(h, &out->cycle_start, &out->cycle_length);
+    }
+    return JSLP_OK;
+}
+
+static int ensure_events(jslp_engine* e, size_t n) {
+    while (e->ev_pool.size() < n) {
+        hipEvent_t ev;
+        HIPC(hipEventCreate(&ev));
+        e->ev_pool.push_back(ev);
+    }
+    return JSLP_OK;
+}
+
+// simplex() of the live tableau (slot 0), leaving the final DevState in e->h_state
+static int run_simplex(jslp_engine* e, int check_cycles) {
+    hipStream_t s = e->stream;
+    const int cap = iters_cap(e);
+    HIPC(hipEventRecord(e->ev_begin, s));
+    if (use_wg_single(e)) {
+        hipLaunchKernelGGL(k_simplex_wg, dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
+        HIPC(hipGetLastError());
+        HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+        HIPC(hipEventRecord(e->ev_end, s));
+        HIPC(hipStreamSynchronize(s));
+    } else {
+        const Ctx c = host_ctx(e, check_cycles);
+        // height is fixed during a simplex call; read it once
+        HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+        HIPC(hipStreamSynchronize(s));
+        const dim3 grid = update_grid(e, e->h_state->H);
+        hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, e->s, 0, cap);
+        int chunk = 8;
+        long long done_prev = 0;
+        for (;;) {
+            if (e->timing) { int r = ensure_events(e, 2 * (size_t)chunk); if (r) return r; }
+            for (int i = 0; i < chunk; i++) {
+                hipLaunchKernelGGL(k_select, dim3(1), dim3(JSLP_WG_THREADS), 0, s, c);
+                if (e->timing) HIPC(hipEventRecord(e->ev_pool[2 * i], s));
+                hipLaunchKernelGGL(k_update, grid, dim3(JSLP_UPD_THREADS), 0, s, c);
+                if (e->timing) HIPC(hipEventRecord(e->ev_pool[2 * i + 1], s));
+            }
+            HIPC(hipGetLastError());
+            HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+            HIPC(hipStreamSynchronize(s));
+            const DevState& st = *e->h_state;
+            if (e->timing) {
+                // launches after the solve ended are no-ops: only the first `real` of this chunk did a pivot
+                const long long done = (long long)st.it1 + st.it2;
+                const long long real = std::min<long long>(chunk, done - done_prev);
+                for (long long i = 0; i < real; i++) {
+                    float ms = 0;
+                    if (hipEventElapsedTime(&ms, e->ev_pool[2 * i], e->ev_pool[2 * i + 1]) == hipSuccess) e->upd_ms += ms;
+                }
+                e->upd_launches += real;
+                done_prev = done;
+            }
+            if (st.status == ST_DONE) break;
+            chunk = std::min(chunk * 2, 256);
+        }
+        HIPC(hipEventRecord(e->ev_end, s));
+        HIPC(hipStreamSynchronize(s));
+    }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e->ev_begin, e->ev_end) == hipSuccess) e->total_ms += ms;
+    return state_error(*e->h_state);
+}
+
+extern "C" int jslp_engine_simplex(jslp_engine* e, int check_cycles, jslp_simplex_result* out) {
+    if (!e || !out) return fail(JSLP_ERR_ARG, "simplex: null pointer");
+    if (!e->uploaded) return fail(JSLP_ERR_STATE, "simplex before upload");
+    HIPC(hipSetDevice(e->device));
+    int rc = run_simplex(e, check_cycles);
+    if (rc) return rc;
+    return fill_result(e, *e->h_state, 0, e->evaluation, out, &e->evaluation);
+}
+
+extern "C" int jslp_engine_pivot(jslp_engine* e, int32_t row, int32_t col) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "pivot before upload");
+    HIPC(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    const int H = e->h_state->H;
+    if (row < 0 || row >= H || col < 0 || col >= e->W) return fail(JSLP_ERR_ARG, "pivot: index out of range");
+    const Ctx c = host_ctx(e, 0);
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(JSLP_WG_THREADS), 0, s, c, (int)row, (int)col);
+    hipLaunchKernelGGL(k_update, update_grid(e, H), dim3(JSLP_UPD_THREADS), 0, s, c);
+    hipLaunchKernelGGL(k_end_pivot, dim3(1), dim3(1), 0, s, c);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(s));
+    return JSLP_OK;
+}
+
+static dim3 copy_grid(const jslp_engine* e, int slots) {
+    const long long n2 = (long long)e->cap_rows * e->ld / 2;
+    int bx = (int)std::min<long long>(2048 / std::max(1, std::min(slots, 8)), (n2 + 255) / 256);
+    return dim3(std::max(bx, 1), slots, 1);
+}
+
+extern "C" int jslp_engine_save(jslp_engine* e) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "save before upload");
+    HIPC(hipSetDevice(e->device));
+    SnapshotW w{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx};
+    hipLaunchKernelGGL(k_save, dim3(copy_grid(e, 1).x), dim3(256), 0, e->stream, e->s, w);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(e->stream));
+    e->has_save = 1;
+    return JSLP_OK;
+}
+
+static int enqueue_restore(jslp_engine* e, int first_slot, int n) {
+    if (!e->has_save) return JSLP_OK;  // backup.ts:54-56
+    Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx};
+    hipLaunchKernelGGL(k_restore, copy_grid(e, n), dim3(256), 0, e->stream, e->s, sn, first_slot);
+    HIPC(hipGetLastError());
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_restore(jslp_engine* e) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "restore before upload");
+    HIPC(hipSetDevice(e->device));
+    int rc = enqueue_restore(e, 0, 1);
+    if (rc) return rc;
+    HIPC(hipStreamSynchronize(e->stream));
+    return JSLP_OK;
+}
+
+// stage the cut lists of n_nodes nodes on the device
+static int upload_cuts(jslp_engine* e, int32_t n_nodes, const int32_t* offs, const int8_t* type, const int32_t* var,
+                       const double* value) {
+    const size_t n_cuts = (size_t)offs[n_nodes];
+    if (n_cuts > 0 && (!type || !var || !value)) return fail(JSLP_ERR_ARG, "cuts: null pointer");
+    if ((size_t)n_nodes + 1 > e->node_cap) {
+        hipFree(e->d_cut_offs);
+        e->node_cap = std::max<size_t>(2 * ((size_t)n_nodes + 1), 64);
+        HIPC(hipMalloc(&e->d_cut_offs, sizeof(int32_t) * e->node_cap));
+    }
+    if (n_cuts > e->cut_cap) {
+        hipFree(e->d_cut_type); hipFree(e->d_cut_var); hipFree(e->d_cut_val);
+        e->cut_cap = std::max<size_t>(2 * n_cuts, 1024);
+        HIPC(hipMalloc(&e->d_cut_type, e->cut_cap));
+        HIPC(hipMalloc(&e->d_cut_var, sizeof(int32_t) * e->cut_cap));
+        HIPC(hipMalloc(&e->d_cut_val, sizeof(double) * e->cut_cap));
+    }
+    hipStream_t s = e->stream;
+    HIPC(hipMemcpyAsync(e->d_cut_offs, offs, sizeof(int32_t) * ((size_t)n_nodes + 1), hipMemcpyHostToDevice, s));
+    if (n_cuts) {
+        HIPC(hipMemcpyAsync(e->d_cut_type, type, n_cuts, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(e->d_cut_var, var, sizeof(int32_t) * n_cuts, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(e->d_cut_val, value, sizeof(double) * n_cuts, hipMemcpyHostToDevice, s));
+    }
+    HIPC(hipStreamSynchronize(s));  // pageable sources
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_add_cuts(jslp_engine* e, int32_t n, const int8_t* type, const int32_t* var_index,
+                                    const double* value) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "add_cuts before upload");
+    if (n < 0) return fail(JSLP_ERR_ARG, "add_cuts: negative count");
+    HIPC(hipSetDevice(e->device));
+    const int32_t offs[2] = {0, n};
+    int rc = upload_cuts(e, 1, offs, type, var_index, value);
+    if (rc) return rc;
+    Cuts cu{e->d_cut_offs, e->d_cut_type, e->d_cut_var, e->d_cut_val};
+    hipLaunchKernelGGL(k_add_cuts, dim3(1), dim3(256), 0, e->stream, e->s, cu, 0, 0, (int)e->cap_rows);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    HIPC(hipStreamSynchronize(e->stream));
+    return state_error(*e->h_state);
+}
+
+static int ensure_out(jslp_engine* e, size_t nodes) {
+    if (nodes <= e->out_cap) return JSLP_OK;
+    hipFree(e->d_rhs); hipFree(e->d_rows); hipFree(e->d_states);
+    if (e->h_rhs) hipHostFree(e->h_rhs);
+    if (e->h_rows) hipHostFree(e->h_rows);
+    if (e->h_states) hipHostFree(e->h_states);
+    e->out_cap = std::max<size_t>(nodes, 16);
+    const size_t n = e->out_cap * (size_t)e->cap_rows;
+    HIPC(hipMalloc(&e->d_rhs, sizeof(double) * n));
+    HIPC(hipMalloc(&e->d_rows, sizeof(int32_t) * n));
+    HIPC(hipMalloc(&e->d_states, sizeof(DevState) * e->out_cap));
+    HIPC(hipHostMalloc(&e->h_rhs, sizeof(double) * n));
+    HIPC(hipHostMalloc(&e->h_rows, sizeof(int32_t) * n));
+    HIPC(hipHostMalloc(&e->h_states, sizeof(DevState) * e->out_cap));
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_read_rhs(jslp_engine* e, double* rhs, int32_t* var_index_by_row) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "read_rhs before upload");
+    HIPC(hipSetDevice(e->device));
+    int rc = ensure_out(e, 1);
+    if (rc) return rc;
+    hipStream_t s = e->stream;
+    hipLaunchKernelGGL(k_gather, dim3(1), dim3(256), 0, s, e->s, 0, e->d_rhs, e->d_rows, e->d_states, (int)e->cap_rows, 0);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(e->h_rhs, e->d_rhs, sizeof(double) * e->cap_rows, hipMemcpyDeviceToHost, s));
+    HIPC(hipMemcpyAsync(e->h_rows, e->d_rows, sizeof(int32_t) * e->cap_rows, hipMemcpyDeviceToHost, s));
+    HIPC(hipMemcpyAsync(e->h_states, e->d_states, sizeof(DevState), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    const int H = e->h_states[0].H;
+    if (rhs) memcpy(rhs, e->h_rhs, sizeof(double) * H);
+    if (var_index_by_row) memcpy(var_index_by_row, e->h_rows, sizeof(int32_t) * H);
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                       const int32_t* var_index, const double* value, int check_cycles,
+                                       jslp_simplex_result* out, double* rhs, int32_t* var_index_by_row,
+                                       int32_t out_stride) {
+    if (!e || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "relax_batch: null pointer");
+    if (!e->uploaded) return fail(JSLP_ERR_STATE, "relax before upload");
+    if ((rhs || var_index_by_row) && out_stride < e->cap_rows) return fail(JSLP_ERR_ARG, "relax_batch: out_stride < row capacity");
+    if (n_nodes == 0) return JSLP_OK;
+    if (n_nodes > 1 && !e->has_save) return fail(JSLP_ERR_STATE, "relax_batch: several nodes need a saved root (save() first)");
+    HIPC(hipSetDevice(e->device));
+    int rc = upload_cuts(e, n_nodes, cut_offsets, type, var_index, value);
+    if (rc) return rc;
+    hipStream_t s = e->stream;
+    Cuts cu{e->d_cut_offs, e->d_cut_type, e->d_cut_var, e->d_cut_val};
+    const int cap = iters_cap(e);
+    const long long cells = (long long)e->cap_rows * e->ld;
+    const bool wg = e->force_path == 1 || (e->force_path != 2 && (n_nodes > 1 ? cells <= WG_CELLS_BATCH : use_wg_single(e)));
+    const double prev_eval = e->evaluation;
+    // group size: bounded by memory (<= 8 GiB of tableau copies) and by what fills the chip twice over
+    int group = 1;
+    if (wg) {
+        const long long max_slots = std::max<long long>(1, (8LL << 30) / (cells * 8));
+        group = (int)std::min<long long>(std::min<long long>(n_nodes, 512), max_slots);
+        rc = ensure_slots(e, group);
+        if (rc) return rc;
+    }
+    rc = ensure_out(e, (size_t)group);
+    if (rc) return rc;
+    for (int first = 0; first < n_nodes; first += group) {
+        const int g = std::min(group, n_nodes - first);
+        rc = enqueue_restore(e, 0, g);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_add_cuts, dim3(g), dim3(256), 0, s, e->s, cu, 0, first, (int)e->cap_rows);
+        HIPC(hipGetLastError());
+        if (wg) {
+            HIPC(hipEventRecord(e->ev_begin, s));
+            hipLaunchKernelGGL(k_simplex_wg, dim3(g), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
+            HIPC(hipGetLastError());
+            HIPC(hipEventRecord(e->ev_end, s));
+        } else {
+            // big tableau: the chip-wide kernels on slot 0 (g == 1)
+            HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+            HIPC(hipStreamSynchronize(s));
+            rc = state_error(*e->h_state);
+            if (rc) return rc;
+            rc = run_simplex(e, check_cycles);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_gather, dim3(g), dim3(256), 0, s, e->s, 0, rhs ? e->d_rhs : nullptr,
+                           var_index_by_row ? e->d_rows : nullptr, e->d_states, (int)e->cap_rows, 0);
+        HIPC(hipGetLastError());
+        const size_t n = (size_t)g * e->cap_rows;
+        if (rhs) HIPC(hipMemcpyAsync(e->h_rhs, e->d_rhs, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+        if (var_index_by_row) HIPC(hipMemcpyAsync(e->h_rows, e->d_rows, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+        HIPC(hipMemcpyAsync(e->h_states, e->d_states, sizeof(DevState) * g, hipMemcpyDeviceToHost, s));
+        HIPC(hipStreamSynchronize(s));
+        if (wg) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e->ev_begin, e->ev_end) == hipSuccess) e->total_ms += ms;
+        }
+        for (int j = 0; j < g; j++) {
+            const int i = first + j;
+            const DevState& st = e->h_states[j];
+            rc = state_error(st);
+            if (rc) return rc;
+            double ev;
+            rc = fill_result(e, st, j, prev_eval, &out[i], &ev);
+            if (rc) return rc;
+            if (i == n_nodes - 1) e->evaluation = ev;
+            if (rhs) memcpy(rhs + (size_t)i * out_stride, e->h_rhs + (size_t)j * e->cap_rows, sizeof(double) * st.H);
+            if (var_index_by_row)
+                memcpy(var_index_by_row + (size_t)i * out_stride, e->h_rows + (size_t)j * e->cap_rows, sizeof(int32_t) * st.H);
+        }
+    }
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_relax(jslp_engine* e, int32_t n_cuts, const int8_t* type, const int32_t* var_index,
+                                 const double* value, int check_cycles, jslp_simplex_result* out, double* rhs,
+                                 int32_t* var_index_by_row) {
+    if (!e) return fail(JSLP_ERR_ARG, "relax: null engine");
+    if (n_cuts < 0) return fail(JSLP_ERR_ARG, "relax: negative cut count");
+    const int32_t offs[2] = {0, n_cuts};
+    return jslp_engine_relax_batch(e, 1, offs, type, var_index, value, check_cycles, out, rhs, var_index_by_row,
+                                   e->cap_rows);
+}
+
+extern "C" int jslp_engine_dims(const jslp_engine* e, int32_t* height, int32_t* width, int32_t* n_var_indexes) {
+    if (!e) return fail(JSLP_ERR_ARG, "dims: null engine");
+    if (height) {
+        if (hipSetDevice(e->device) != hipSuccess) return fail(JSLP_ERR_DEVICE, "dims: hipSetDevice failed");
+        DevState st;
+        if (hipMemcpy(&st, e->s.st, sizeof st, hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(JSLP_ERR_DEVICE, "dims: state read-back failed");
+        *height = e->uploaded ? st.H : e->H0;
+    }
+    if (width) *width = e->W;
+    if (n_var_indexes) *n_var_indexes = e->n_idx;
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_download(jslp_engine* e, double* matrix, int32_t* var_index_by_row, int32_t* var_index_by_col,
+                                    int32_t* row_by_var_index, int32_t* col_by_var_index) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "download before upload");
+    HIPC(hipSetDevice(e->device));
+    HIPC(hipStreamSynchronize(e->stream));
+    DevState st;
+    HIPC(hipMemcpy(&st, e->s.st, sizeof st, hipMemcpyDeviceToHost));
+    const int H = st.H, W = e->W;
+    if (matrix)
+        HIPC(hipMemcpy2D(matrix, sizeof(double) * W, e->s.A, sizeof(double) * e->ld, sizeof(double) * W, H, hipMemcpyDeviceToHost));
+    if (var_index_by_row) HIPC(hipMemcpy(var_index_by_row, e->s.vibr, sizeof(int32_t) * H, hipMemcpyDeviceToHost));
+    if (var_index_by_col) HIPC(hipMemcpy(var_index_by_col, e->s.vibc, sizeof(int32_t) * W, hipMemcpyDeviceToHost));
+    if (row_by_var_index) HIPC(hipMemcpy(row_by_var_index, e->s.rbv, sizeof(int32_t) * e->n_idx, hipMemcpyDeviceToHost));
+    if (col_by_var_index) HIPC(hipMemcpy(col_by_var_index, e->s.cbv, sizeof(int32_t) * e->n_idx, hipMemcpyDeviceToHost));
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_pivot_trace(jslp_engine* e, int32_t* row_col, int64_t max_pairs, int64_t* n_pivots) {
+    if (!e || !n_pivots) return fail(JSLP_ERR_ARG, "pivot_trace: null pointer");
+    HIPC(hipSetDevice(e->device));
+    HIPC(hipStreamSynchronize(e->stream));
+    DevState st;
+    HIPC(hipMemcpy(&st, e->s.st, sizeof st, hipMemcpyDeviceToHost));
+    *n_pivots = st.trace_n;
+    if (row_col && max_pairs > 0) {
+        const long long n = std::min<long long>(std::min<long long>(st.trace_n, max_pairs), e->s.trace_cap);
+        if (n > 0) HIPC(hipMemcpy(row_col, e->s.trace, sizeof(int2) * n, hipMemcpyDeviceToHost));
+    }
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_set_timing(jslp_engine* e, int enabled) {
+    if (!e) return fail(JSLP_ERR_ARG, "set_timing: null engine");
+    e->timing = enabled ? 1 : 0;
+    e->upd_ms = 0; e->upd_launches = 0; e->total_ms = 0;
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_get_timing(jslp_engine* e, double* update_kernel_ms, int64_t* update_kernel_launches,
+                                      double* total_device_ms) {
+    if (!e) return fail(JSLP_ERR_ARG, "get_timing: null engine");
+    if (update_kernel_ms) *update_kernel_ms = e->upd_ms;
+    if (update_kernel_launches) *update_kernel_launches = e->upd_launches;
+    if (total_device_ms) *total_device_ms = e->total_ms;
+    return JSLP_OK;
+}

@@ -1,0 +1,186 @@
+"""GPU parity tests proper: the HIP engine, called through the C ABI, against
+  (a) the golden vectors produced by the reference itself (every pivot, every relaxation, final tableau sha),
+  (b) the CPU oracle on seeded random inputs (bit-exact final tableau),
+for BOTH launch shapes (one workgroup per tableau / select + chip-wide update).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as G
+from jslpsolver_amd import generators
+from jslpsolver_amd.engine import Tableau, pivot_digest
+from test_host_solve import check_fixture
+from test_oracle_golden import replay, usable
+
+pytestmark = pytest.mark.gpu
+
+PATHS = ["auto", "wg", "sp"]
+
+
+@pytest.fixture(params=PATHS)
+def path_mode(request):
+    if request.param == "auto":
+        os.environ.pop("JSLP_FORCE_PATH", None)
+    else:
+        os.environ["JSLP_FORCE_PATH"] = request.param
+    yield request.param
+    os.environ.pop("JSLP_FORCE_PATH", None)
+
+
+def test_backend_is_hip(hip_lib):
+    assert hip_lib.backend == "hip-gfx950"
+    assert hip_lib.jslp_device_count() >= 1
+
+
+SMALL = [p for p in G.fixture_paths() if "LargeFarm" not in p and "Vendor" not in p and "Monster" not in p
+         and "StockCutting" not in p]
+
+
+@pytest.mark.parametrize("path", SMALL, ids=G.ident)
+def test_fixture_replay(hip_lib, path_mode, path):
+    g = G.load(path)
+    if not usable(g):
+        pytest.skip("outside the hot-path scope")
+    replay(hip_lib, g)
+
+
+@pytest.mark.parametrize("name", ["Monster_Problem", "Monster_II", "Vendor_Selection", "StockCuttingProblem", "LargeFarmMIP"])
+def test_big_fixture_replay(hip_lib, name):
+    replay(hip_lib, G.load(os.path.join(G.GOLDEN, "fixtures", name + ".json.gz")))
+
+
+@pytest.mark.parametrize("name", ["Monster_Problem", "Monster_II"])
+def test_big_fixture_replay_other_paths(hip_lib, name):
+    g = G.load(os.path.join(G.GOLDEN, "fixtures", name + ".json.gz"))
+    for mode in ("wg", "sp"):
+        os.environ["JSLP_FORCE_PATH"] = mode
+        try:
+            replay(hip_lib, g)
+        finally:
+            os.environ.pop("JSLP_FORCE_PATH", None)
+
+
+@pytest.mark.parametrize("path", [p for p in G.synthetic_paths() if "_1000x" not in p and "_2000x" not in p], ids=G.ident)
+def test_synthetic_replay(hip_lib, path_mode, path):
+    g = G.load(path)
+    if g["tableau"]["rows"] is None or not usable(g):
+        pytest.skip("dense instance: see test_dense_synthetic")
+    replay(hip_lib, g)
+
+
+@pytest.mark.parametrize("path", G.fixture_paths(), ids=G.ident)
+def test_fixture_through_host_and_hip_engine(hip_lib, path):
+    """solver.Solve(json) end to end: model layer + B&B on the host, every relaxation on the GPU"""
+    check_fixture(hip_lib, G.load(path))
+
+
+def _dense_case(lib, kind, n, check_cycles):
+    if kind == "ra":
+        m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
+    else:
+        m, vibr, vibc, _ = generators.dense_random_lp_tableau(12345, n, n)
+    t = Tableau(m, vibr, vibc, lib=lib)
+    res = t.simplex(check_cycles=check_cycles)
+    out = dict(feasible=bool(res.feasible), bounded=bool(res.bounded), p1=res.pivots_phase1, p2=res.pivots_phase2,
+               evaluation=t.evaluation, digest=pivot_digest(t.pivot_trace()), n=len(t.pivot_trace()),
+               matrix=t.download()[0])
+    t.close()
+    return out
+
+
+@pytest.mark.parametrize("kind,n", [("ra", 200), ("lp", 200), ("ra", 500), ("lp", 500), ("ra", 1000), ("lp", 1000)])
+def test_dense_synthetic_against_reference_golden(hip_lib, path_mode, kind, n):
+    if path_mode == "wg" and n > 500:
+        pytest.skip("one workgroup on a 1000x1000 dense tableau: correct but slow")
+    name = ("generateResourceAllocation" if kind == "ra" else "generateRandomLP") + "_%dx%d_seed12345" % (n, n)
+    g = G.load(os.path.join(G.GOLDEN, "synthetic", name + ".json.gz"))
+    out = _dense_case(hip_lib, kind, n, check_cycles=g["tableau"]["checkForCycles"])
+    assert out["n"] == g["nPivots"]
+    assert out["digest"] == g["pivotDigest"]
+    assert out["feasible"] == g["final"]["feasible"] and out["bounded"] == g["final"]["bounded"]
+    assert G.sha_matrix(out["matrix"]) == g["final"]["matrixSha"]
+    assert out["evaluation"] == G.num(g["final"]["tableauEvaluation"])
+
+
+def test_config3_full_size_against_reference_golden(hip_lib):
+    """BASELINE.json config 3 at full size (2001 x 2001, 9726 pivots): identical pivot sequence and an
+    identical final tableau (sha256 of all 4M doubles) to the reference."""
+    for kind, name in (("ra", "generateResourceAllocation"), ("lp", "generateRandomLP")):
+        g = G.load(os.path.join(G.GOLDEN, "synthetic", name + "_2000x2000_seed12345.json.gz"))
+        out = _dense_case(hip_lib, kind, 2000, check_cycles=False)
+        assert out["n"] == g["nPivots"]
+        assert out["digest"] == g["pivotDigest"]
+        assert G.sha_matrix(out["matrix"]) == g["final"]["matrixSha"]
+        assert out["feasible"] == g["final"]["feasible"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_lp_hip_equals_oracle(hip_lib, oracle_lib, path_mode, seed):
+    """seeded random LPs with ragged shapes, unrestricted variables, negative RHS (phase 1) and degenerate
+    rows: flags, pivot sequence and every double of the final tableau must match the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    n, m = int(rng.integers(1, 60)), int(rng.integers(1, 45))
+    A = np.zeros((m + 1, n + 1))
+    dens = rng.uniform(0.2, 1.0)
+    A[1:, 1:] = np.where(rng.random((m, n)) < dens, rng.integers(-9, 10, (m, n)), 0)
+    A[0, 1:] = rng.integers(-5, 20, n)
+    A[1:, 0] = rng.integers(-3 if seed % 2 else 0, 30, m)
+    if seed % 3 == 0:
+        A[1 + (seed % m), 0] = 0.0  # degenerate row
+    vibr = np.concatenate(([-1], np.arange(m))).astype(np.int32)
+    vibc = np.concatenate(([-1], m + np.arange(n))).astype(np.int32)
+    unr = [int(m + j) for j in range(n) if rng.random() < 0.15]
+    outs = []
+    for lib in (hip_lib, oracle_lib):
+        t = Tableau(A, vibr, vibc, unr, lib=lib)
+        res = t.simplex(check_cycles=True)
+        outs.append((res.as_dict(), t.pivot_trace().tolist(), t.download()[0].tobytes(), t.evaluation))
+        t.close()
+    d0, d1 = outs[0][0], outs[1][0]
+    for k in d0:
+        assert d0[k] == d1[k] or (isinstance(d0[k], float) and np.isnan(d0[k]) and np.isnan(d1[k])), k
+    assert outs[0][1] == outs[1][1]
+    assert outs[0][2] == outs[1][2]
+
+
+def test_relax_batch_equals_sequential_relax(hip_lib, oracle_lib):
+    """Monster_II (config 4): the 151 cut lists the reference visits, evaluated as ONE batch of independent
+    nodes, give the reference's per-node outcomes (flags, evaluation, RHS column sha)."""
+    g = G.load(os.path.join(G.GOLDEN, "fixtures", "Monster_II.json.gz"))
+    tab = g["tableau"]
+    m, vibr, vibc = G.dense_tableau(tab)
+    calls = g["simplexCalls"]
+    max_cuts = max(len(c["cuts"] or []) for c in calls)
+    t = Tableau(m, vibr, vibc, tab["unrestricted"], precision=tab["precision"], row_capacity=tab["height"] + max_cuts,
+                lib=hip_lib)
+    t.applyCuts([], check_cycles=True)
+    t.save()
+    nodes = [c["cuts"] or [] for c in calls[1:]]
+    results, rhs, rows = t.applyCutsBatch(nodes * 3, check_cycles=True)
+    for rep in range(3):
+        for i, call in enumerate(calls[1:]):
+            j = rep * len(nodes) + i
+            r = results[j]
+            assert bool(r.feasible) == call["feasible"] and r.height == call["height"]
+            assert r.pivots_phase1 == call["p1"] and r.pivots_phase2 == call["p2"]
+            assert G.sha_rhs(rhs[j, :r.height], rows[j, :r.height]) == call["rhsSha"]
+            if call["feasible"]:
+                assert r.evaluation == G.num(call["evaluation"])
+    t.close()
+
+
+def test_pivot_entry_point(hip_lib, oracle_lib):
+    rng = np.random.default_rng(5)
+    A = rng.integers(-5, 9, (9, 12)).astype(np.float64)
+    vibr = np.concatenate(([-1], np.arange(8))).astype(np.int32)
+    vibc = np.concatenate(([-1], 8 + np.arange(11))).astype(np.int32)
+    outs = []
+    for lib in (hip_lib, oracle_lib):
+        t = Tableau(A, vibr, vibc, lib=lib)
+        for r, c in ((3, 4), (1, 1), (8, 11), (3, 7)):
+            t.pivot(r, c)
+        outs.append([x.tobytes() for x in t.download()])
+        t.close()
+    assert outs[0] == outs[1]
