@@ -132,7 +132,7 @@ def main():
         bytes_per_launch = 16.0 * H * W  # read + write every fp64 cell of the H x W tableau
         avg_s = (upd_ms / 1e3) / max(launches, 1)
         achieved = bytes_per_launch / avg_s if launches else 0.0
-        roofline = {"bound": "hbm", "kernel": "k_update", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+        roofline = {"bound": "hbm", "kernel": "k_pivot_fused", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
                     "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches": launches,
                     "whole_pivot_frac": (bytes_per_launch * value / max(world, 1)) / HBM_PEAK}

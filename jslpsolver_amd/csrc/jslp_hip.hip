@@ -54,7 +54,12 @@ struct jslp_engine {
     size_t out_cap = 0;  // nodes
     DevState* h_state = nullptr;  // pinned, 1 entry
     // policy
-    int force_path = 0;  // 0 auto, 1 workgroup kernel, 2 select+update kernels
+    int force_path = 0;  // 0 auto, 1 workgroup kernel, 2 select+update kernels only, 3 fused phase 2
+    int32_t n_unr = 0;
+    int nt = 0;  // JSLP_NT=1: non-temporal hints in the fused kernel
+    // fused phase-2 pipeline (ping-pong buffer + per-workgroup candidates)
+    double* f_buf1 = nullptr; FCand* f_cands[2] = {nullptr, nullptr}; double* f_pcol[2] = {nullptr, nullptr};
+    DevState* f_st[2] = {nullptr, nullptr};
     // timing
     int timing = 0;
     double upd_ms = 0, total_ms = 0;
@@ -155,6 +160,9 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     const char* fp = getenv("JSLP_FORCE_PATH");
     if (fp && !strcmp(fp, "wg")) e->force_path = 1;
     if (fp && !strcmp(fp, "sp")) e->force_path = 2;
+    if (fp && !strcmp(fp, "fused")) e->force_path = 3;
+    const char* nt = getenv("JSLP_NT");
+    e->nt = (nt && nt[0] == '1') ? 1 : 0;
     int rc = JSLP_OK;
     auto init = [&]() -> int {
         HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -188,6 +196,8 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     hipFree(e->s.trace);
     hipFree(e->snap_A); hipFree(e->snap_vibr); hipFree(e->snap_vibc); hipFree(e->snap_rbv); hipFree(e->snap_cbv);
     hipFree(e->d_unr);
+    hipFree(e->f_buf1); hipFree(e->f_cands[0]); hipFree(e->f_cands[1]); hipFree(e->f_pcol[0]); hipFree(e->f_pcol[1]);
+    hipFree(e->f_st[0]); hipFree(e->f_st[1]);
     hipFree(e->d_cut_offs); hipFree(e->d_cut_type); hipFree(e->d_cut_var); hipFree(e->d_cut_val);
     hipFree(e->d_rhs); hipFree(e->d_rows); hipFree(e->d_states);
     if (e->h_rhs) hipHostFree(e->h_rhs);
@@ -247,6 +257,7 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
     e->uploaded = 1;
     e->has_save = 0;
     e->evaluation = 0;
+    e->n_unr = n_unrestricted;
     return JSLP_OK;
 }
 
@@ -255,7 +266,7 @@ static Ctx host_ctx(const jslp_engine* e, int check_cycles) {
     c.A = e->s.A; c.vibr = e->s.vibr; c.vibc = e->s.vibc; c.rbv = e->s.rbv; c.cbv = e->s.cbv; c.unr = e->s.unr;
     c.prow = e->s.prow; c.pcol = e->s.pcol; c.st = e->s.st; c.hist = e->s.hist; c.hist_cap = e->s.hist_cap;
     c.trace = e->s.trace; c.trace_cap = e->s.trace_cap; c.ld = e->ld; c.W = e->W; c.check_cycles = check_cycles;
-    c.batch = e->batch; c.use_partial = e->use_partial; c.precision = e->precision;
+    c.batch = e->batch; c.use_partial = e->use_partial; c.precision = e->precision; c.stop_at_phase2 = 0;
     return c;
 }
 
@@ -268,8 +279,28 @@ static int iters_cap(const jslp_engine* e) {
 
 static bool use_wg_single(const jslp_engine* e) {
     if (e->force_path == 1) return true;
-    if (e->force_path == 2) return false;
+    if (e->force_path == 2 || e->force_path == 3) return false;
     return (long long)e->cap_rows * e->ld <= WG_CELLS_SINGLE;
+}
+
+// the fused one-launch-per-pivot phase 2 (see k_pivot_fused for the preconditions)
+static bool fused_eligible(const jslp_engine* e) {
+    if (e->force_path == 2) return false;
+    return e->n_unr == 0 && e->ld <= 2 * JSLP_F_THREADS && e->cap_rows <= 64 * JSLP_F_MAXG && e->precision >= 1e-15;
+}
+
+static int ensure_fused(jslp_engine* e) {
+    if (e->f_buf1) return JSLP_OK;
+    const size_t cells = (size_t)e->cap_rows * e->ld;
+    HIPC(hipMalloc(&e->f_buf1, sizeof(double) * cells));
+    HIPC(hipMemsetAsync(e->f_buf1, 0, sizeof(double) * cells, e->stream));
+    for (int i = 0; i < 2; i++) {
+        HIPC(hipMalloc(&e->f_cands[i], sizeof(FCand) * JSLP_F_MAXG));
+        HIPC(hipMalloc(&e->f_pcol[i], sizeof(double) * e->cap_rows));
+        HIPC(hipMalloc(&e->f_st[i], sizeof(DevState)));
+        HIPC(hipMemsetAsync(e->f_st[i], 0, sizeof(DevState), e->stream));
+    }
+    return JSLP_OK;
 }
 
 static dim3 update_grid(const jslp_engine* e, int H) {
@@ -362,27 +393,31 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
         HIPC(hipEventRecord(e->ev_end, s));
         HIPC(hipStreamSynchronize(s));
     } else {
-        const Ctx c = host_ctx(e, check_cycles);
+        Ctx c = host_ctx(e, check_cycles);
+        const bool fused = fused_eligible(e);
+        c.stop_at_phase2 = fused ? 1 : 0;
         // height is fixed during a simplex call; read it once
         HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
         HIPC(hipStreamSynchronize(s));
-        const dim3 grid = update_grid(e, e->h_state->H);
+        const int H = e->h_state->H;
+        const dim3 grid = update_grid(e, H);
         hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, e->s, 0, cap);
-        int chunk = 8;
+        // ---- phase 1 (and phase 2 when the fused pipeline does not apply): k_select + k_update per pivot ----
+        int chunk = fused ? 1 : 8;
         long long done_prev = 0;
         for (;;) {
-            if (e->timing) { int r = ensure_events(e, 2 * (size_t)chunk); if (r) return r; }
+            if (e->timing && !fused) { int r = ensure_events(e, 2 * (size_t)chunk); if (r) return r; }
             for (int i = 0; i < chunk; i++) {
                 hipLaunchKernelGGL(k_select, dim3(1), dim3(JSLP_WG_THREADS), 0, s, c);
-                if (e->timing) HIPC(hipEventRecord(e->ev_pool[2 * i], s));
+                if (e->timing && !fused) HIPC(hipEventRecord(e->ev_pool[2 * i], s));
                 hipLaunchKernelGGL(k_update, grid, dim3(JSLP_UPD_THREADS), 0, s, c);
-                if (e->timing) HIPC(hipEventRecord(e->ev_pool[2 * i + 1], s));
+                if (e->timing && !fused) HIPC(hipEventRecord(e->ev_pool[2 * i + 1], s));
             }
             HIPC(hipGetLastError());
             HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
             HIPC(hipStreamSynchronize(s));
             const DevState& st = *e->h_state;
-            if (e->timing) {
+            if (e->timing && !fused) {
                 // launches after the solve ended are no-ops: only the first `real` of this chunk did a pivot
                 const long long done = (long long)st.it1 + st.it2;
                 const long long real = std::min<long long>(chunk, done - done_prev);
@@ -393,8 +428,53 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                 e->upd_launches += real;
                 done_prev = done;
             }
-            if (st.status == ST_DONE) break;
+            if (st.status != ST_RUNNING) break;
             chunk = std::min(chunk * 2, 256);
+        }
+        // ---- phase 2: one fused launch per pivot ----------------------------------------------------------
+        if (e->h_state->status == ST_PHASE1_DONE) {
+            int r = ensure_fused(e);
+            if (r) return r;
+            FusedCtx f;
+            f.c = c;
+            f.buf[0] = e->s.A; f.buf[1] = e->f_buf1;
+            for (int i = 0; i < 2; i++) { f.cands[i] = e->f_cands[i]; f.pcol[i] = e->f_pcol[i]; f.fst[i] = e->f_st[i]; }
+            f.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
+            f.G = (H + f.rpb - 1) / f.rpb;
+            f.H = H;
+            f.nt = e->nt;
+            int launch = 0;
+            hipLaunchKernelGGL(k_pivot_fused, dim3(f.G), dim3(JSLP_F_THREADS), 0, s, f, launch);
+            launch++;
+            chunk = 16;
+            long long it2_prev = e->h_state->it2;
+            for (;;) {
+                if (e->timing) { int r2 = ensure_events(e, 2 * (size_t)chunk); if (r2) return r2; }
+                for (int i = 0; i < chunk; i++) {
+                    if (e->timing) HIPC(hipEventRecord(e->ev_pool[2 * i], s));
+                    hipLaunchKernelGGL(k_pivot_fused, dim3(f.G), dim3(JSLP_F_THREADS), 0, s, f, launch);
+                    if (e->timing) HIPC(hipEventRecord(e->ev_pool[2 * i + 1], s));
+                    launch++;
+                }
+                HIPC(hipGetLastError());
+                HIPC(hipMemcpyAsync(e->h_state, f.fst[launch & 1], sizeof(DevState), hipMemcpyDeviceToHost, s));
+                HIPC(hipStreamSynchronize(s));
+                const DevState& st = *e->h_state;
+                if (e->timing) {
+                    const long long real = std::min<long long>(chunk, (long long)st.it2 - it2_prev);
+                    for (long long i = 0; i < real; i++) {
+                        float ms = 0;
+                        if (hipEventElapsedTime(&ms, e->ev_pool[2 * i], e->ev_pool[2 * i + 1]) == hipSuccess) e->upd_ms += ms;
+                    }
+                    e->upd_launches += real;
+                    it2_prev = st.it2;
+                }
+                if (st.status == ST_DONE) break;
+                chunk = std::min(chunk * 2, 512);
+            }
+            hipLaunchKernelGGL(k_fused_finish, dim3(512), dim3(256), 0, s, f, launch - 1);
+            HIPC(hipGetLastError());
+            HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
         }
         HIPC(hipEventRecord(e->ev_end, s));
         HIPC(hipStreamSynchronize(s));
