@@ -1,0 +1,428 @@
+/*
+ * jslp_napi.c -- thin synchronous N-API addon over the C ABI of include/jslp_engine.h.
+ *
+ * This is the binding the reference's TypeScript host calls (north star: "the TypeScript host keeps model
+ * parsing, validation and the branch-and-bound tree on the CPU, calling through a thin N-API C-ABI addon").
+ * Raw C N-API only (node_api.h; no node-addon-api, no node-gyp):
+ *     gcc -O2 -shared -fPIC -I/usr/include/node addon/jslp_napi.c -o addon/jslp_napi.node -ldl
+ * The engine library is dlopen'ed by path (`load(path)`), so the same addon binds the product
+ * (jslpsolver_amd/csrc/libjslp_hip.so) and -- in tests only -- the CPU oracle; there is no fallback: every call
+ * before a successful load() throws.  TypedArrays are passed zero-copy (napi_get_typedarray_info).
+ */
+#include <dlfcn.h>
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/jslp_engine.h"
+
+static struct {
+    void* dl;
+    const char* (*backend_name)(void);
+    const char* (*last_error)(void);
+    int (*device_count)(void);
+    int (*create)(jslp_engine**, int, int32_t, int32_t, int32_t, double);
+    void (*destroy)(jslp_engine*);
+    int (*upload)(jslp_engine*, const double*, const int32_t*, const int32_t*, const int32_t*, int32_t);
+    int (*simplex)(jslp_engine*, int, jslp_simplex_result*);
+    int (*pivot)(jslp_engine*, int32_t, int32_t);
+    int (*save)(jslp_engine*);
+    int (*restore)(jslp_engine*);
+    int (*add_cuts)(jslp_engine*, int32_t, const int8_t*, const int32_t*, const double*);
+    int (*relax)(jslp_engine*, int32_t, const int8_t*, const int32_t*, const double*, int, jslp_simplex_result*, double*, int32_t*);
+    int (*relax_batch)(jslp_engine*, int32_t, const int32_t*, const int8_t*, const int32_t*, const double*, int,
+                       jslp_simplex_result*, double*, int32_t*, int32_t);
+    int (*dims)(const jslp_engine*, int32_t*, int32_t*, int32_t*);
+    int (*read_rhs)(jslp_engine*, double*, int32_t*);
+    int (*download)(jslp_engine*, double*, int32_t*, int32_t*, int32_t*, int32_t*);
+    int (*pivot_trace)(jslp_engine*, int32_t*, int64_t, int64_t*);
+} L;
+
+#define THROW(env, msg)                       \
+    do {                                      \
+        napi_throw_error(env, "JSLP", msg);   \
+        return NULL;                          \
+    } while (0)
+#define NAPI_OK(env, call)                                     \
+    do {                                                       \
+        if ((call) != napi_ok) THROW(env, "N-API call failed: " #call); \
+    } while (0)
+#define ENGINE_OK(env, rc, what)                                                     \
+    do {                                                                             \
+        if ((rc) != JSLP_OK) {                                                       \
+            char _m[640];                                                            \
+            snprintf(_m, sizeof _m, "%s failed (%d): %s", what, (int)(rc), L.last_error()); \
+            THROW(env, _m);                                                          \
+        }                                                                            \
+    } while (0)
+
+static int get_args(napi_env env, napi_callback_info info, size_t n, napi_value* argv) {
+    size_t argc = n;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < n) {
+        napi_throw_type_error(env, "JSLP", "wrong number of arguments");
+        return 0;
+    }
+    return 1;
+}
+
+/* typed array -> pointer + length; `null`/`undefined` -> NULL */
+static int typed(napi_env env, napi_value v, napi_typedarray_type want, void** data, size_t* len) {
+    napi_valuetype t;
+    *data = NULL;
+    *len = 0;
+    if (napi_typeof(env, v, &t) != napi_ok) return 0;
+    if (t == napi_null || t == napi_undefined) return 1;
+    bool is;
+    if (napi_is_typedarray(env, v, &is) != napi_ok || !is) {
+        napi_throw_type_error(env, "JSLP", "typed array expected");
+        return 0;
+    }
+    napi_typedarray_type ty;
+    napi_value ab;
+    size_t off;
+    if (napi_get_typedarray_info(env, v, &ty, len, data, &ab, &off) != napi_ok) return 0;
+    if (ty != want) {
+        napi_throw_type_error(env, "JSLP", "typed array of the wrong element type");
+        return 0;
+    }
+    return 1;
+}
+
+static jslp_engine* handle(napi_env env, napi_value v) {
+    void* p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+        napi_throw_type_error(env, "JSLP", "engine handle expected");
+        return NULL;
+    }
+    jslp_engine* e = *(jslp_engine**)p;
+    if (!e) napi_throw_error(env, "JSLP", "engine already destroyed");
+    return e;
+}
+
+static void finalize_handle(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    jslp_engine** box = (jslp_engine**)data;
+    if (*box && L.destroy) L.destroy(*box);
+    free(box);
+}
+
+static napi_value result_object(napi_env env, const jslp_simplex_result* r) {
+    napi_value o, v;
+    NAPI_OK(env, napi_create_object(env, &o));
+#define SET_B(name, x) NAPI_OK(env, napi_get_boolean(env, (x) != 0, &v)); NAPI_OK(env, napi_set_named_property(env, o, name, v))
+#define SET_I(name, x) NAPI_OK(env, napi_create_int32(env, (x), &v)); NAPI_OK(env, napi_set_named_property(env, o, name, v))
+#define SET_D(name, x) NAPI_OK(env, napi_create_double(env, (x), &v)); NAPI_OK(env, napi_set_named_property(env, o, name, v))
+    SET_B("feasible", r->feasible);
+    SET_B("bounded", r->bounded);
+    SET_B("optimal", r->optimal);
+    SET_I("unboundedVarIndex", r->unbounded_var_index);
+    SET_I("pivotsPhase1", r->pivots_phase1);
+    SET_I("pivotsPhase2", r->pivots_phase2);
+    SET_I("cyclePhase", r->cycle_phase);
+    SET_I("cycleStart", r->cycle_start);
+    SET_I("cycleLength", r->cycle_length);
+    SET_I("height", r->height);
+    SET_D("objCell", r->obj_cell);
+    SET_D("evaluation", r->evaluation);
+    return o;
+}
+
+/* load(path) -> backend name */
+static napi_value fn_load(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    char path[4096];
+    size_t n;
+    NAPI_OK(env, napi_get_value_string_utf8(env, argv[0], path, sizeof path, &n));
+    void* dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!dl) {
+        char m[4600];
+        snprintf(m, sizeof m, "cannot load engine library %s: %s (there is no CPU fallback)", path, dlerror());
+        THROW(env, m);
+    }
+    memset(&L, 0, sizeof L);
+    L.dl = dl;
+#define SYM(field, name)                                                  \
+    do {                                                                  \
+        *(void**)(&L.field) = dlsym(dl, name);                            \
+        if (!L.field) { THROW(env, "engine library lacks symbol " name); } \
+    } while (0)
+    SYM(backend_name, "jslp_backend_name"); SYM(last_error, "jslp_last_error"); SYM(device_count, "jslp_device_count");
+    SYM(create, "jslp_engine_create"); SYM(destroy, "jslp_engine_destroy"); SYM(upload, "jslp_engine_upload");
+    SYM(simplex, "jslp_engine_simplex"); SYM(pivot, "jslp_engine_pivot"); SYM(save, "jslp_engine_save");
+    SYM(restore, "jslp_engine_restore"); SYM(add_cuts, "jslp_engine_add_cuts"); SYM(relax, "jslp_engine_relax");
+    SYM(relax_batch, "jslp_engine_relax_batch"); SYM(dims, "jslp_engine_dims"); SYM(read_rhs, "jslp_engine_read_rhs");
+    SYM(download, "jslp_engine_download"); SYM(pivot_trace, "jslp_engine_pivot_trace");
+    napi_value s;
+    NAPI_OK(env, napi_create_string_utf8(env, L.backend_name(), NAPI_AUTO_LENGTH, &s));
+    return s;
+}
+
+#define NEED_LIB(env) do { if (!L.dl) THROW(env, "engine library not loaded: call load(path) first"); } while (0)
+
+static napi_value fn_device_count(napi_env env, napi_callback_info info) {
+    (void)info;
+    NEED_LIB(env);
+    napi_value v;
+    NAPI_OK(env, napi_create_int32(env, L.device_count(), &v));
+    return v;
+}
+
+/* create(height, width, rowCapacity, precision, device) -> handle */
+static napi_value fn_create(napi_env env, napi_callback_info info) {
+    NEED_LIB(env);
+    napi_value argv[5];
+    if (!get_args(env, info, 5, argv)) return NULL;
+    int32_t h, w, cap, dev;
+    double precision;
+    NAPI_OK(env, napi_get_value_int32(env, argv[0], &h));
+    NAPI_OK(env, napi_get_value_int32(env, argv[1], &w));
+    NAPI_OK(env, napi_get_value_int32(env, argv[2], &cap));
+    NAPI_OK(env, napi_get_value_double(env, argv[3], &precision));
+    NAPI_OK(env, napi_get_value_int32(env, argv[4], &dev));
+    jslp_engine** box = (jslp_engine**)calloc(1, sizeof *box);
+    int rc = L.create(box, dev, h, w, cap, precision);
+    if (rc != JSLP_OK) free(box);
+    ENGINE_OK(env, rc, "jslp_engine_create");
+    napi_value ext;
+    NAPI_OK(env, napi_create_external(env, box, finalize_handle, NULL, &ext));
+    return ext;
+}
+
+static napi_value fn_destroy(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    void* p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+        jslp_engine** box = (jslp_engine**)p;
+        if (*box) { L.destroy(*box); *box = NULL; }
+    }
+    return NULL;
+}
+
+/* upload(h, Float64Array matrix, Int32Array varIndexByRow, Int32Array varIndexByCol, Int32Array unrestricted) */
+static napi_value fn_upload(napi_env env, napi_callback_info info) {
+    napi_value argv[5];
+    if (!get_args(env, info, 5, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    void *m, *r, *c, *u;
+    size_t nm, nr, nc, nu;
+    if (!typed(env, argv[1], napi_float64_array, &m, &nm) || !typed(env, argv[2], napi_int32_array, &r, &nr) ||
+        !typed(env, argv[3], napi_int32_array, &c, &nc) || !typed(env, argv[4], napi_int32_array, &u, &nu))
+        return NULL;
+    int32_t H, W;
+    ENGINE_OK(env, L.dims(e, NULL, &W, NULL), "jslp_engine_dims");
+    (void)H;
+    if (nc < (size_t)W || nm < (size_t)W) THROW(env, "upload: arrays shorter than the tableau");
+    ENGINE_OK(env, L.upload(e, (const double*)m, (const int32_t*)r, (const int32_t*)c, (const int32_t*)u, (int32_t)nu),
+              "jslp_engine_upload");
+    return NULL;
+}
+
+static napi_value fn_simplex(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    bool check;
+    NAPI_OK(env, napi_get_value_bool(env, argv[1], &check));
+    jslp_simplex_result r;
+    ENGINE_OK(env, L.simplex(e, check ? 1 : 0, &r), "jslp_engine_simplex");
+    return result_object(env, &r);
+}
+
+static napi_value fn_pivot(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    int32_t r, c;
+    NAPI_OK(env, napi_get_value_int32(env, argv[1], &r));
+    NAPI_OK(env, napi_get_value_int32(env, argv[2], &c));
+    ENGINE_OK(env, L.pivot(e, r, c), "jslp_engine_pivot");
+    return NULL;
+}
+
+static napi_value fn_save(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    ENGINE_OK(env, L.save(e), "jslp_engine_save");
+    return NULL;
+}
+
+static napi_value fn_restore(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    ENGINE_OK(env, L.restore(e), "jslp_engine_restore");
+    return NULL;
+}
+
+/* addCuts(h, Int8Array type, Int32Array varIndex, Float64Array value) */
+static napi_value fn_add_cuts(napi_env env, napi_callback_info info) {
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    void *t, *v, *x;
+    size_t nt, nv, nx;
+    if (!typed(env, argv[1], napi_int8_array, &t, &nt) || !typed(env, argv[2], napi_int32_array, &v, &nv) ||
+        !typed(env, argv[3], napi_float64_array, &x, &nx))
+        return NULL;
+    if (nt != nv || nv != nx) THROW(env, "addCuts: array lengths differ");
+    ENGINE_OK(env, L.add_cuts(e, (int32_t)nt, (const int8_t*)t, (const int32_t*)v, (const double*)x), "jslp_engine_add_cuts");
+    return NULL;
+}
+
+/* relax(h, type, varIndex, value, checkCycles, Float64Array rhsOut|null, Int32Array rowsOut|null) -> result */
+static napi_value fn_relax(napi_env env, napi_callback_info info) {
+    napi_value argv[7];
+    if (!get_args(env, info, 7, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    void *t, *v, *x, *rhs, *rows;
+    size_t nt, nv, nx, nrhs, nrows;
+    bool check;
+    if (!typed(env, argv[1], napi_int8_array, &t, &nt) || !typed(env, argv[2], napi_int32_array, &v, &nv) ||
+        !typed(env, argv[3], napi_float64_array, &x, &nx))
+        return NULL;
+    NAPI_OK(env, napi_get_value_bool(env, argv[4], &check));
+    if (!typed(env, argv[5], napi_float64_array, &rhs, &nrhs) || !typed(env, argv[6], napi_int32_array, &rows, &nrows)) return NULL;
+    if (nt != nv || nv != nx) THROW(env, "relax: array lengths differ");
+    int32_t H, W, N;
+    ENGINE_OK(env, L.dims(e, &H, &W, &N), "jslp_engine_dims");
+    /* the engine writes `height after the cuts` entries: bounded by the created row capacity, which the host
+       passed to create(); outputs must cover restore-height + cuts */
+    jslp_simplex_result r;
+    ENGINE_OK(env, L.relax(e, (int32_t)nt, (const int8_t*)t, (const int32_t*)v, (const double*)x, check ? 1 : 0, &r,
+                           (double*)rhs, (int32_t*)rows), "jslp_engine_relax");
+    return result_object(env, &r);
+}
+
+/* relaxBatch(h, Int32Array offsets, type, varIndex, value, checkCycles, rhsOut|null, rowsOut|null, stride) -> [result] */
+static napi_value fn_relax_batch(napi_env env, napi_callback_info info) {
+    napi_value argv[9];
+    if (!get_args(env, info, 9, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    void *o, *t, *v, *x, *rhs, *rows;
+    size_t no, nt, nv, nx, nrhs, nrows;
+    bool check;
+    int32_t stride;
+    if (!typed(env, argv[1], napi_int32_array, &o, &no) || !typed(env, argv[2], napi_int8_array, &t, &nt) ||
+        !typed(env, argv[3], napi_int32_array, &v, &nv) || !typed(env, argv[4], napi_float64_array, &x, &nx))
+        return NULL;
+    NAPI_OK(env, napi_get_value_bool(env, argv[5], &check));
+    if (!typed(env, argv[6], napi_float64_array, &rhs, &nrhs) || !typed(env, argv[7], napi_int32_array, &rows, &nrows)) return NULL;
+    NAPI_OK(env, napi_get_value_int32(env, argv[8], &stride));
+    if (no < 1) THROW(env, "relaxBatch: offsets must hold n_nodes + 1 entries");
+    const int32_t n_nodes = (int32_t)no - 1;
+    if ((rhs && nrhs < (size_t)n_nodes * (size_t)stride) || (rows && nrows < (size_t)n_nodes * (size_t)stride))
+        THROW(env, "relaxBatch: output arrays shorter than n_nodes * stride");
+    jslp_simplex_result* res = (jslp_simplex_result*)calloc((size_t)(n_nodes > 0 ? n_nodes : 1), sizeof *res);
+    int rc = L.relax_batch(e, n_nodes, (const int32_t*)o, (const int8_t*)t, (const int32_t*)v, (const double*)x,
+                           check ? 1 : 0, res, (double*)rhs, (int32_t*)rows, stride);
+    if (rc != JSLP_OK) free(res);
+    ENGINE_OK(env, rc, "jslp_engine_relax_batch");
+    napi_value arr;
+    if (napi_create_array_with_length(env, (size_t)n_nodes, &arr) != napi_ok) { free(res); THROW(env, "array"); }
+    for (int32_t i = 0; i < n_nodes; i++) {
+        napi_value ro = result_object(env, &res[i]);
+        if (!ro) { free(res); return NULL; }
+        napi_set_element(env, arr, (uint32_t)i, ro);
+    }
+    free(res);
+    return arr;
+}
+
+/* dims(h) -> {height, width, nVarIndexes} */
+static napi_value fn_dims(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    int32_t H, W, N;
+    ENGINE_OK(env, L.dims(e, &H, &W, &N), "jslp_engine_dims");
+    napi_value o, v;
+    NAPI_OK(env, napi_create_object(env, &o));
+    SET_I("height", H);
+    SET_I("width", W);
+    SET_I("nVarIndexes", N);
+    return o;
+}
+
+/* readRhs(h, Float64Array rhs|null, Int32Array rows|null) */
+static napi_value fn_read_rhs(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    void *rhs, *rows;
+    size_t n1, n2;
+    if (!typed(env, argv[1], napi_float64_array, &rhs, &n1) || !typed(env, argv[2], napi_int32_array, &rows, &n2)) return NULL;
+    int32_t H;
+    ENGINE_OK(env, L.dims(e, &H, NULL, NULL), "jslp_engine_dims");
+    if ((rhs && n1 < (size_t)H) || (rows && n2 < (size_t)H)) THROW(env, "readRhs: output arrays shorter than the height");
+    ENGINE_OK(env, L.read_rhs(e, (double*)rhs, (int32_t*)rows), "jslp_engine_read_rhs");
+    return NULL;
+}
+
+/* download(h, Float64Array matrix|null, Int32Array vibr|null, Int32Array vibc|null, Int32Array rbv|null, Int32Array cbv|null) */
+static napi_value fn_download(napi_env env, napi_callback_info info) {
+    napi_value argv[6];
+    if (!get_args(env, info, 6, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    void* p[5];
+    size_t n[5];
+    if (!typed(env, argv[1], napi_float64_array, &p[0], &n[0])) return NULL;
+    for (int i = 1; i < 5; i++)
+        if (!typed(env, argv[1 + i], napi_int32_array, &p[i], &n[i])) return NULL;
+    int32_t H, W, N;
+    ENGINE_OK(env, L.dims(e, &H, &W, &N), "jslp_engine_dims");
+    if ((p[0] && n[0] < (size_t)H * W) || (p[1] && n[1] < (size_t)H) || (p[2] && n[2] < (size_t)W) ||
+        (p[3] && n[3] < (size_t)N) || (p[4] && n[4] < (size_t)N))
+        THROW(env, "download: output arrays too short");
+    ENGINE_OK(env, L.download(e, (double*)p[0], (int32_t*)p[1], (int32_t*)p[2], (int32_t*)p[3], (int32_t*)p[4]),
+              "jslp_engine_download");
+    return NULL;
+}
+
+/* pivotTrace(h) -> Int32Array [r0, c0, r1, c1, ...] */
+static napi_value fn_pivot_trace(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    int64_t n = 0;
+    ENGINE_OK(env, L.pivot_trace(e, NULL, 0, &n), "jslp_engine_pivot_trace");
+    napi_value ab, ta;
+    void* data;
+    NAPI_OK(env, napi_create_arraybuffer(env, (size_t)n * 8 + 8, &data, &ab));
+    ENGINE_OK(env, L.pivot_trace(e, (int32_t*)data, n, &n), "jslp_engine_pivot_trace");
+    NAPI_OK(env, napi_create_typedarray(env, napi_int32_array, (size_t)n * 2, ab, 0, &ta));
+    return ta;
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+    static const struct { const char* name; napi_callback fn; } fns[] = {
+        {"load", fn_load}, {"deviceCount", fn_device_count}, {"create", fn_create}, {"destroy", fn_destroy},
+        {"upload", fn_upload}, {"simplex", fn_simplex}, {"pivot", fn_pivot}, {"save", fn_save}, {"restore", fn_restore},
+        {"addCuts", fn_add_cuts}, {"relax", fn_relax}, {"relaxBatch", fn_relax_batch}, {"dims", fn_dims},
+        {"readRhs", fn_read_rhs}, {"download", fn_download}, {"pivotTrace", fn_pivot_trace},
+    };
+    for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+        napi_value f;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+        if (napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) return NULL;
+    }
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

@@ -1,0 +1,234 @@
+// host/gpu-tableau.js -- the reference-side binding of the MI355X engine (node >= 12, plain CommonJS).
+//
+// jsLPSolver keeps everything it does today on the CPU -- JSON model parsing, validation, presolve, the
+// branch-and-bound tree (src/tableau/branch-and-cut.ts) and result assembly -- and only the hot path moves:
+// install() overrides, on the reference's own Tableau class, exactly the methods SURVEY.md 8b names as the seam
+//   Tableau.simplex()            src/tableau/tableau.ts:103-111  -> jslp_engine_simplex / jslp_engine_relax
+//   Tableau.save() / restore()   src/tableau/tableau.ts:223-229  -> jslp_engine_save / (folded into relax)
+//   Tableau.addCutConstraints()  src/tableau/tableau.ts:145-147  -> (folded into relax)
+// so `solver.Solve(model)` keeps its API and result shape.  One B&B node (restore + addCutConstraints +
+// simplex, branch-and-cut.ts:33-37) becomes ONE addon call; after it only what the host tree reads comes
+// back: flags, evaluation, the RHS column and the row -> variable map (mip-utils.ts:43-61,100-126).
+//
+// Out of the engine's scope (the reference's own TypeScript path keeps running for these tableaus):
+// optional objectives / soft constraints (simplex.ts:221-263,394-412) and MIR cuts (useMIRCuts).
+"use strict";
+const path = require("path");
+
+const DEFAULT_ADDON = path.join(__dirname, "..", "addon", "jslp_napi.node");
+const DEFAULT_LIBRARY = path.join(__dirname, "..", "jslpsolver_amd", "csrc", "libjslp_hip.so");
+
+let addon = null;
+let backend = null;
+
+function loadEngine(options) {
+    const o = options || {};
+    addon = require(o.addon || DEFAULT_ADDON);
+    backend = addon.load(o.library || DEFAULT_LIBRARY); // throws when the library is missing: no CPU fallback
+    return backend;
+}
+
+function eligible(t) {
+    return t.optionalObjectives.length === 0 && !(t.model && t.model.useMIRCuts);
+}
+
+function activate(t, opts) {
+    if (!eligible(t)) {
+        t.__gpu = { active: false };
+        return t.__gpu;
+    }
+    const nInts = t.model ? t.model.getNumberOfIntegerVariables() : 0;
+    const rowCapacity = t.height + 2 * nInts + 8; // <= one "min" and one "max" cut per integer variable
+    const h = addon.create(t.height, t.width, rowCapacity, t.precision, opts.device || 0);
+    const rows = Int32Array.from(t.varIndexByRow);
+    const cols = Int32Array.from(t.varIndexByCol);
+    rows[0] = -1;
+    cols[0] = -1;
+    const unrestricted = Int32Array.from(
+        Object.keys(t.unrestrictedVars).filter((k) => t.unrestrictedVars[k] === true).map(Number)
+    );
+    addon.upload(h, t.matrix.subarray(0, t.height * t.width), rows, cols, unrestricted);
+    t.__gpu = {
+        active: true,
+        h,
+        rowCapacity,
+        rhs: new Float64Array(rowCapacity),
+        rows: new Int32Array(rowCapacity),
+        pendingRestore: false,
+        pendingCuts: null,
+        saved: null,
+    };
+    return t.__gpu;
+}
+
+function state(t, opts) {
+    return t.__gpu || activate(t, opts);
+}
+
+function packCuts(cuts) {
+    const n = cuts.length;
+    const type = new Int8Array(n);
+    const varIndex = new Int32Array(n);
+    const value = new Float64Array(n);
+    for (let i = 0; i < n; i++) {
+        type[i] = cuts[i].type === "min" ? 0 : 1; // JSLP_CUT_MIN / JSLP_CUT_MAX
+        varIndex[i] = cuts[i].varIndex;
+        value[i] = cuts[i].value;
+    }
+    return { type, varIndex, value };
+}
+
+// fold the engine's outcome into the Tableau exactly as simplex.ts / tableau.ts do on the CPU
+function absorb(t, st, res) {
+    t.feasible = res.feasible;
+    t.bounded = res.bounded;
+    if (res.optimal) {
+        // setEvaluation + simplexIters += 1 (simplex.ts:265-269, tableau.ts:420-430)
+        t.evaluation = res.evaluation;
+        if (t.simplexIters === 0) t.bestPossibleEval = res.evaluation;
+        t.simplexIters += 1;
+    } else if (!res.bounded) {
+        t.evaluation = -Infinity; // simplex.ts:298-303
+        t.unboundedVarIndex = res.unboundedVarIndex;
+    }
+    if (res.cyclePhase !== 0 && t.model) {
+        t.model.messages.push("Cycle in phase " + res.cyclePhase); // simplex.ts:86-88 / 313-315
+        t.model.messages.push("Start :" + res.cycleStart);
+        t.model.messages.push("Length :" + res.cycleLength);
+    }
+    // read-back: RHS column + row map (and the inverse map the host tree indexes with)
+    const H = res.height;
+    const width = t.width;
+    const rhsColumn = t.rhsColumn;
+    const matrix = t.matrix;
+    const rowByVarIndex = t.rowByVarIndex;
+    for (let v = 0; v < rowByVarIndex.length; v++) rowByVarIndex[v] = -1;
+    for (let r = 0; r < H; r++) {
+        matrix[r * width + rhsColumn] = st.rhs[r];
+        const v = st.rows[r];
+        t.varIndexByRow[r] = v;
+        if (v >= 0) rowByVarIndex[v] = r;
+    }
+}
+
+function install(Tableau, options) {
+    const opts = options || {};
+    if (!addon) loadEngine(opts);
+    const P = Tableau.prototype;
+    const orig = { simplex: P.simplex, save: P.save, restore: P.restore, addCutConstraints: P.addCutConstraints };
+
+    P.simplex = function () {
+        const st = state(this, opts);
+        if (!st.active) return orig.simplex.call(this);
+        const check = this.model ? this.model.checkForCycles === true : false;
+        let res;
+        if (st.pendingRestore) {
+            // restore + addCutConstraints + simplex = one LP relaxation (branch-and-cut.ts:33-37)
+            const c = packCuts(st.pendingCuts || []);
+            res = addon.relax(st.h, c.type, c.varIndex, c.value, check, st.rhs, st.rows);
+        } else {
+            if (st.pendingCuts) {
+                const c = packCuts(st.pendingCuts);
+                addon.addCuts(st.h, c.type, c.varIndex, c.value);
+            }
+            res = addon.simplex(st.h, check);
+            addon.readRhs(st.h, st.rhs, st.rows);
+        }
+        st.pendingRestore = false;
+        st.pendingCuts = null;
+        absorb(this, st, res);
+        return this;
+    };
+
+    P.save = function () {
+        const st = state(this, opts);
+        if (!st.active) return orig.save.call(this);
+        addon.save(st.h); // device-resident snapshot (backup.ts:13-51)
+        st.saved = { height: this.height, nVars: this.nVars, lastElementIndex: this.lastElementIndex };
+    };
+
+    P.restore = function () {
+        const st = state(this, opts);
+        if (!st.active) return orig.restore.call(this);
+        if (st.saved === null) return; // backup.ts:54-56
+        this.height = st.saved.height; // backup.ts:58-68 (the scalars); matrix + maps live on the device
+        this.nVars = st.saved.nVars;
+        this.lastElementIndex = st.saved.lastElementIndex;
+        this.varIndexByRow.length = this.height;
+        st.pendingRestore = true;
+        st.pendingCuts = null;
+    };
+
+    P.addCutConstraints = function (cuts) {
+        const st = state(this, opts);
+        if (!st.active) return orig.addCutConstraints.call(this, cuts);
+        // host-side bookkeeping of cutting-strategies.ts:16-34,64-71; the rows themselves are built on the device
+        const n = cuts.length;
+        const height = this.height;
+        const heightWithCuts = height + n;
+        if (heightWithCuts > st.rowCapacity) throw new Error("[gpu-tableau] cut rows exceed the engine's row capacity");
+        const newSize = heightWithCuts * this.width;
+        if (this.matrix.length < newSize) {
+            const grown = new Float64Array(newSize);
+            grown.set(this.matrix);
+            this.matrix = grown;
+        }
+        this.height = heightWithCuts;
+        this.nVars = this.width + this.height - 2;
+        for (let h = 0; h < n; h++) {
+            const slack = this.getNewElementIndex();
+            this.varIndexByRow[height + h] = slack;
+            this.rowByVarIndex[slack] = height + h;
+            this.colByVarIndex[slack] = -1;
+            this.variablesPerIndex[slack] = opts.SlackVariable
+                ? new opts.SlackVariable("s" + slack, slack)
+                : { id: "s" + slack, cost: 0, index: slack, value: 0, priority: 0, isSlack: true };
+            this.nVars += 1;
+        }
+        st.pendingCuts = (st.pendingCuts || []).concat(cuts);
+    };
+
+    return function uninstall() {
+        P.simplex = orig.simplex;
+        P.save = orig.save;
+        P.restore = orig.restore;
+        P.addCutConstraints = orig.addCutConstraints;
+    };
+}
+
+// Full read-back for `Solve(model, precision, full=true)` consumers and the post-solve editing API.
+function sync(t) {
+    const st = t.__gpu;
+    if (!st || !st.active) return t;
+    const d = addon.dims(st.h);
+    const m = new Float64Array(d.height * d.width);
+    const rows = new Int32Array(d.height);
+    const cols = new Int32Array(d.width);
+    const rbv = new Int32Array(d.nVarIndexes);
+    const cbv = new Int32Array(d.nVarIndexes);
+    addon.download(st.h, m, rows, cols, rbv, cbv);
+    if (t.matrix.length < m.length) t.matrix = new Float64Array(m.length);
+    t.matrix.set(m);
+    for (let r = 0; r < d.height; r++) t.varIndexByRow[r] = rows[r];
+    for (let c = 0; c < d.width; c++) t.varIndexByCol[c] = cols[c];
+    for (let v = 0; v < t.rowByVarIndex.length && v < d.nVarIndexes; v++) {
+        t.rowByVarIndex[v] = rbv[v];
+        t.colByVarIndex[v] = cbv[v];
+    }
+    return t;
+}
+
+function pivotTrace(t) {
+    const st = t.__gpu;
+    return st && st.active ? addon.pivotTrace(st.h) : null;
+}
+
+function release(t) {
+    const st = t.__gpu;
+    if (st && st.active) {
+        addon.destroy(st.h);
+        st.active = false;
+    }
+}
+
+module.exports = { loadEngine, install, sync, pivotTrace, release, backend: () => backend };

@@ -96,9 +96,25 @@ def most_fractional_var(model, rhs, rows):
     return sel_index, sel_value
 
 
-def branch_and_cut(tableau, model):
+class _NodeEval:
+    """outcome of one LP relaxation as the host tree consumes it"""
+    __slots__ = ("res", "rhs", "vibr")
+
+    def __init__(self, res, rhs, vibr):
+        self.res, self.rhs, self.vibr = res, rhs, vibr
+
+
+def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
     """branch-and-cut.ts:54-199.  Leaves `tableau` holding the incumbent; returns the iteration count and
-    whether an integral node was accepted (tableau.__isIntegral)."""
+    whether an integral node was accepted (tableau.__isIntegral).
+
+    speculate > 1 turns on SPECULATIVE EVALUATION WITH IN-ORDER COMMIT: whenever the sequential
+    loop needs a node that has not been evaluated yet, that node and the next best `speculate - 1` heap entries
+    are evaluated as ONE batch of independent relaxations (every node is a pure function of the saved root and
+    its cut list); the loop itself still pops, prunes and commits in the reference's order, so the incumbent,
+    the iteration count and the result are those of the sequential run.  `evaluate_batch(cut_lists)` may shard
+    the batch over several GPUs (jslpsolver_amd.sharding); default: the tableau's own applyCutsBatch.
+    """
     branches = BranchMinHeap()
     iterations = 0
     tolerance = model.tolerance or 0
@@ -111,6 +127,17 @@ def branch_and_cut(tableau, model):
     found_integral = False
     check = model.checkForCycles
     precision = tableau.precision
+    cache = {}          # heap sequence number -> _NodeEval
+    saved = False
+    last_cuts = None    # cuts of the node the sequential run evaluated last
+    speculated = 0
+
+    def run_batch(cut_lists):
+        if evaluate_batch is not None:
+            return evaluate_batch(cut_lists)
+        results, rhs, vibr = tableau.applyCutsBatch(cut_lists, check_cycles=check)
+        return [_NodeEval(results[i], rhs[i, :results[i].height].copy(), vibr[i, :results[i].height].copy())
+                for i in range(len(cut_lists))]
 
     branches.push(-math.inf, [])
     while len(branches) > 0 and tolerance_flag and time.time() * 1000.0 < terminal_time:
@@ -120,10 +147,24 @@ def branch_and_cut(tableau, model):
             acceptable = tableau.bestPossibleEval * (1 - tolerance)
         if tolerance > 0 and best_evaluation < acceptable:
             tolerance_flag = False
-        relaxed, _, cuts = branches.pop()
+        relaxed, seq, cuts = branches.pop()
         if relaxed > best_evaluation:
             continue
-        _res, rhs, vibr = tableau.applyCuts(cuts, check_cycles=check)
+        if speculate > 1 and saved:
+            if seq not in cache:
+                # this node + the entries the heap would hand out next (best first, LIFO ties); nodes already
+                # prunable by the current incumbent are not worth speculating on
+                ahead = sorted(branches.heap, key=lambda e: (e[0], -e[1]))
+                batch = [(seq, cuts)] + [(e[1], e[2]) for e in ahead if e[1] not in cache and e[0] <= best_evaluation][:speculate - 1]
+                for (sq, _), ev in zip(batch, run_batch([c for _, c in batch])):
+                    cache[sq] = ev
+                speculated += len(batch)
+            ev = cache.pop(seq)
+            tableau._absorb(ev.res)
+            rhs, vibr = ev.rhs, ev.vibr
+        else:
+            _res, rhs, vibr = tableau.applyCuts(cuts, check_cycles=check)
+        last_cuts = cuts
         iterations += 1
         if not tableau.feasible:
             continue
@@ -142,6 +183,7 @@ def branch_and_cut(tableau, model):
         else:
             if iterations == 1:
                 tableau.save()
+                saved = True
             var_index, var_value = most_fractional_var(model, rhs, rows)
             cuts_high, cuts_low = [], []
             for cut in cuts:
@@ -159,4 +201,8 @@ def branch_and_cut(tableau, model):
             branches.push(evaluation, cuts_low)
     if best_cuts is not None:
         tableau.applyCuts(best_cuts, check_cycles=check)
+    elif speculate > 1 and saved and last_cuts is not None:
+        # no incumbent: the reference's tableau is left on the node it evaluated last; put ours there too
+        tableau.applyCuts(last_cuts, check_cycles=check)
+    tableau.speculated_nodes = speculated
     return iterations, found_integral

@@ -16,8 +16,13 @@ def _round_value(v, rounding_coeff):
     return js_round((EPSILON + v) * rounding_coeff) / rounding_coeff
 
 
-def Solve(model, precision=None, full=False, validate=False, lib=None, device=0, row_capacity_extra=None):
+def Solve(model, precision=None, full=False, validate=False, lib=None, device=0, row_capacity_extra=None,
+          speculate=1, group=None):
     """Drop-in for `solver.Solve(model, precision, full, validate)`.
+
+    speculate > 1: evaluate up to that many branch-and-bound nodes per engine call (speculation with in-order
+    commit: identical results, see branch_and_cut); `group`: a torch.distributed process group over which each
+    batch is sharded, one GPU per rank (every rank calls Solve with the same model and gets the same result).
 
     `lib` selects the engine library (default: the HIP product library; tests pass the CPU oracle to exercise
     the host logic without a GPU).  Returns the simplified result dict, or -- with full=True -- a dict that
@@ -35,7 +40,11 @@ def Solve(model, precision=None, full=False, validate=False, lib=None, device=0,
     iterations = 0
     integral = False
     if n_int > 0:  # tableau.ts:250-258
-        iterations, integral = branch_and_cut(t, m)
+        evaluate = None
+        if group is not None:
+            from .sharding import make_sharded_evaluator
+            evaluate = make_sharded_evaluator(t, m.checkForCycles, group)
+        iterations, integral = branch_and_cut(t, m, speculate=speculate, evaluate_batch=evaluate)
     else:
         t.simplex(check_cycles=m.checkForCycles)
     rhs, rows = t.read_rhs()

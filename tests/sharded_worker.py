@@ -1,0 +1,55 @@
+"""Worker for tests/test_sharded_gloo.py: launched by torch.distributed.run with WORLD_SIZE ranks (gloo, CPU).
+Each rank owns an engine (the TEST-ONLY oracle library stands in for a GPU), nodes are sharded across ranks."""
+import json
+import os
+import sys
+
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import golden_util as G  # noqa: E402
+from jslpsolver_amd import Solve, _capi  # noqa: E402
+from jslpsolver_amd.engine import Tableau  # noqa: E402
+from jslpsolver_amd.sharding import evaluate_nodes_sharded  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lib = _capi.Library(os.path.join(ROOT, "oracle", "libjslp_oracle.so"))
+    report = {"rank": rank, "world": world, "cases": []}
+    # 1. whole solves: sharded speculative B&B == the reference's result
+    for name in ("Monster_II", "Knapsack_1", "Integer_Wood_Shop_Problem", "Sudoku4x4"):
+        g = G.load(os.path.join(G.GOLDEN, "fixtures", name + ".json.gz"))
+        out = Solve(g["model"], full=True, lib=lib, speculate=4 * world, group=dist.group.WORLD)
+        ref = {k: (G.num(v) if not isinstance(v, bool) else v) for k, v in g["result"].items()}
+        ok = out["result"] == ref and out["iter"] == g["final"]["branchAndCutIterations"]
+        report["cases"].append({"name": name, "ok": bool(ok)})
+    # 2. the throughput unit: a batch of independent nodes sharded round-robin, outcomes all-gathered
+    g = G.load(os.path.join(G.GOLDEN, "fixtures", "Monster_II.json.gz"))
+    tab = g["tableau"]
+    m, vibr, vibc = G.dense_tableau(tab)
+    calls = g["simplexCalls"]
+    t = Tableau(m, vibr, vibc, tab["unrestricted"], precision=tab["precision"],
+                row_capacity=tab["height"] + max(len(c["cuts"] or []) for c in calls), lib=lib)
+    t.applyCuts([], check_cycles=True)
+    t.save()
+    nodes = [c["cuts"] or [] for c in calls[1:]]
+    evs = evaluate_nodes_sharded(t, nodes, True, dist.group.WORLD)
+    ok = len(evs) == len(nodes)
+    for ev, call in zip(evs, calls[1:]):
+        ok = ok and bool(ev.res.feasible) == call["feasible"] and ev.res.height == call["height"]
+        ok = ok and G.sha_rhs(ev.rhs, ev.vibr) == call["rhsSha"]
+    report["cases"].append({"name": "Monster_II node batch", "ok": bool(ok)})
+    gathered = [None] * world
+    dist.all_gather_object(gathered, report)
+    if rank == 0:
+        print("REPORT " + json.dumps(gathered))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
