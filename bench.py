@@ -46,6 +46,21 @@ def cpu_baseline(n, sample_pivots):
         return {"value": None, "unit": "pivots/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
 
 
+def pmc_traffic(H, W):
+    """HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    separate runs, gfx950 FETCH_SIZE x2 correction): counters cannot be read from inside this process, so the
+    committed summary of the latest pass on this workload is reported, with its provenance."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        if abs(d["algorithmic_bytes_per_launch"] - 16.0 * H * W) > 1:
+            return None, "profiles/pmc_latest.json is for another workload"
+        return d["traffic_bytes_per_launch"], "profiles/pmc_latest.json (%s; %s)" % (d["kernel"], d["source"])
+    except Exception:
+        return None, "no PMC summary committed"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,8 +147,9 @@ def main():
         bytes_per_launch = 16.0 * H * W  # read + write every fp64 cell of the H x W tableau
         avg_s = (upd_ms / 1e3) / max(launches, 1)
         achieved = bytes_per_launch / avg_s if launches else 0.0
+        traffic, traffic_note = pmc_traffic(H, W)
         roofline = {"bound": "hbm", "kernel": "k_pivot_fused", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_note,
                     "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches": launches,
                     "whole_pivot_frac": (bytes_per_launch * value / max(world, 1)) / HBM_PEAK}
     t.close()
