@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libjslp_hip.so")
+HIP_LIB_PATH = os.environ.get("JSLP_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libjslp_hip.so")  # env: debug builds only
 
 JSLP_OK = 0
 JSLP_CUT_MIN = 0

@@ -60,6 +60,9 @@ struct jslp_engine {
     // fused phase-2 pipeline (ping-pong buffer + per-workgroup candidates)
     double* f_buf1 = nullptr; FCand* f_cands[2] = {nullptr, nullptr}; double* f_pcol[2] = {nullptr, nullptr};
     DevState* f_st[2] = {nullptr, nullptr};
+    // register-resident phase 2 (one cooperative launch): hand-off buffers
+    u64_t* r_cands[2] = {nullptr, nullptr}; u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr;
+    int no_resident = 0;
     // timing
     int timing = 0;
     double upd_ms = 0, total_ms = 0;
@@ -160,7 +163,10 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     const char* fp = getenv("JSLP_FORCE_PATH");
     if (fp && !strcmp(fp, "wg")) e->force_path = 1;
     if (fp && !strcmp(fp, "sp")) e->force_path = 2;
-    if (fp && !strcmp(fp, "fused")) e->force_path = 3;
+    if (fp && !strcmp(fp, "fused")) { e->force_path = 3; e->no_resident = 1; }
+    if (fp && !strcmp(fp, "resident")) e->force_path = 3;
+    const char* nr = getenv("JSLP_NO_RESIDENT");
+    if (nr && nr[0] == '1') e->no_resident = 1;
     const char* nt = getenv("JSLP_NT");
     e->nt = (nt && nt[0] == '1') ? 1 : 0;
     int rc = JSLP_OK;
@@ -198,6 +204,7 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     hipFree(e->d_unr);
     hipFree(e->f_buf1); hipFree(e->f_cands[0]); hipFree(e->f_cands[1]); hipFree(e->f_pcol[0]); hipFree(e->f_pcol[1]);
     hipFree(e->f_st[0]); hipFree(e->f_st[1]);
+    hipFree(e->r_cands[0]); hipFree(e->r_cands[1]); hipFree(e->r_rows[0]); hipFree(e->r_rows[1]); hipFree(e->r_sync);
     hipFree(e->d_cut_offs); hipFree(e->d_cut_type); hipFree(e->d_cut_var); hipFree(e->d_cut_val);
     hipFree(e->d_rhs); hipFree(e->d_rows); hipFree(e->d_states);
     if (e->h_rhs) hipHostFree(e->h_rhs);
@@ -289,6 +296,20 @@ static bool fused_eligible(const jslp_engine* e) {
     return e->n_unr == 0 && e->ld <= 2 * JSLP_F_THREADS && e->cap_rows <= 64 * JSLP_F_MAXG && e->precision >= 1e-15;
 }
 
+static bool resident_eligible(const jslp_engine* e, int H) {
+    return !e->no_resident && fused_eligible(e) && H <= JSLP_R_ROWS * JSLP_F_MAXG;
+}
+
+static int ensure_resident(jslp_engine* e) {
+    if (e->r_sync) return JSLP_OK;
+    for (int i = 0; i < 2; i++) {
+        HIPC(hipMalloc(&e->r_cands[i], sizeof(u64_t) * 4 * JSLP_F_MAXG));
+        HIPC(hipMalloc(&e->r_rows[i], sizeof(u64_t) * (size_t)JSLP_F_MAXG * e->ld));
+    }
+    HIPC(hipMalloc(&e->r_sync, sizeof(unsigned) * 16));
+    return JSLP_OK;
+}
+
 static int ensure_fused(jslp_engine* e) {
     if (e->f_buf1) return JSLP_OK;
     const size_t cells = (size_t)e->cap_rows * e->ld;
@@ -337,6 +358,7 @@ static int state_error(const DevState& st) {
         case ERR_ITER_LIMIT: return fail(JSLP_ERR_CAPACITY, "simplex: iteration safety cap reached (endless cycle?)");
         case ERR_CUT_ARG: return fail(JSLP_ERR_ARG, "add_cuts: variable index out of range or neither basic nor non-basic");
         case ERR_CAPACITY: return fail(JSLP_ERR_CAPACITY, "add_cuts: row / element-index capacity exceeded");
+        case ERR_BARRIER: return fail(JSLP_ERR_DEVICE, "resident simplex kernel: grid barrier timed out (workgroups not co-resident?)");
     }
     return fail(JSLP_ERR_DEVICE, "unknown device error code");
 }
@@ -432,7 +454,76 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             chunk = std::min(chunk * 2, 256);
         }
         // ---- phase 2: one fused launch per pivot ----------------------------------------------------------
-        if (e->h_state->status == ST_PHASE1_DONE) {
+        bool resident_done = false;
+        if (e->h_state->status == ST_PHASE1_DONE && resident_eligible(e, H)) {
+            int r = ensure_resident(e);
+            if (r) return r;
+            ResCtx rc;
+            rc.c = c;
+            for (int i = 0; i < 2; i++) { rc.cands[i] = e->r_cands[i]; rc.rows_pub[i] = e->r_rows[i]; }
+            rc.counter = e->r_sync; rc.abort_flag = e->r_sync + 4; rc.verdict = e->r_sync + 8;
+            rc.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
+            rc.G = (H + rc.rpb - 1) / rc.rpb;
+            rc.H = H;
+            rc.iters_cap = cap;
+            rc.dbg = nullptr;
+#ifdef JSLP_DEBUG_RESIDENT
+            static u64_t* dbg_buf = nullptr;
+            if (!dbg_buf) HIPC(hipMalloc(&dbg_buf, sizeof(u64_t) * (512 * JSLP_F_MAXG * 2 + 16384)));
+            HIPC(hipMemsetAsync(dbg_buf, 0, sizeof(u64_t) * (512 * JSLP_F_MAXG * 2 + 16384), s));
+            rc.dbg = dbg_buf;
+#endif
+            HIPC(hipMemsetAsync(e->r_sync, 0, sizeof(unsigned) * 16, s));
+            hipEvent_t k0 = nullptr, k1 = nullptr;
+            if (e->timing) { r = ensure_events(e, 2); if (r) return r; k0 = e->ev_pool[0]; k1 = e->ev_pool[1]; HIPC(hipEventRecord(k0, s)); }
+            void* args[] = {&rc};
+            hipError_t le = hipLaunchCooperativeKernel((const void*)k_simplex_resident, dim3(rc.G), dim3(JSLP_F_THREADS), args, 0, s);
+            if (le == hipSuccess) {
+                if (e->timing) HIPC(hipEventRecord(k1, s));
+                const int it2_before = e->h_state->it2;
+                HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+                HIPC(hipStreamSynchronize(s));
+                if (e->timing) {
+                    float ms = 0;
+                    if (hipEventElapsedTime(&ms, k0, k1) == hipSuccess) e->upd_ms += ms;
+                    e->upd_launches += e->h_state->it2 - it2_before;  // unit = one pivot (16*H*W algorithmic bytes)
+                }
+                resident_done = true;
+#ifdef JSLP_DEBUG_RESIDENT
+                {
+                    std::vector<u64_t> h((size_t)512 * rc.G * 2);
+                    HIPC(hipMemcpy(h.data(), rc.dbg, sizeof(u64_t) * h.size(), hipMemcpyDeviceToHost));
+                    {
+                        std::vector<u64_t> d(16384);
+                        HIPC(hipMemcpy(d.data(), rc.dbg + (size_t)512 * rc.G * 2, sizeof(u64_t) * 16384, hipMemcpyDeviceToHost));
+                        FILE* fb = fopen("gpurun_out/resident_r0.bin", "wb");
+                        if (fb) { fwrite(d.data(), 8, 16384, fb); fclose(fb); }
+                    }
+                    FILE* fp2 = fopen("gpurun_out/resident_dbg.txt", "w");
+                    if (fp2) {
+                        for (int ep = 0; ep < 512; ep++) {
+                            // majority pc / hash = workgroup G-1's; list the deviants
+                            const u64_t pc_ref = h[((size_t)ep * rc.G + rc.G - 1) * 2], hs_ref = h[((size_t)ep * rc.G + rc.G - 1) * 2 + 1];
+                            int bad = 0;
+                            for (int b2 = 0; b2 < rc.G; b2++) {
+                                const u64_t pcv = h[((size_t)ep * rc.G + b2) * 2], hs = h[((size_t)ep * rc.G + b2) * 2 + 1];
+                                if (pcv != pc_ref || hs != hs_ref) {
+                                    if (bad < 12) fprintf(fp2, "epoch %d wg %d pc %llu hash %llx (ref pc %llu hash %llx)\n", ep, b2, pcv, hs, pc_ref, hs_ref);
+                                    bad++;
+                                }
+                            }
+                            if (bad) fprintf(fp2, "epoch %d: %d deviating workgroups\n", ep, bad);
+                            if (ep >= 236 && ep <= 246) fprintf(fp2, "epoch %d pc(all) %llu wg0 pc %llu\n", ep, pc_ref, h[((size_t)ep * rc.G) * 2]);
+                        }
+                        fclose(fp2);
+                    }
+                }
+#endif
+            } else {
+                (void)hipGetLastError();  // not co-resident on this device: use one launch per pivot instead
+            }
+        }
+        if (!resident_done && e->h_state->status == ST_PHASE1_DONE) {
             int r = ensure_fused(e);
             if (r) return r;
             FusedCtx f;

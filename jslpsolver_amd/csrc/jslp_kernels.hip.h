@@ -25,7 +25,7 @@
 #define JSLP_UPD_COLS (JSLP_UPD_THREADS * 2)
 
 enum { ST_RUNNING = 0, ST_DONE = 1, ST_PHASE1_DONE = 2 };
-enum { ERR_NONE = 0, ERR_HIST_FULL = 1, ERR_ITER_LIMIT = 2, ERR_CUT_ARG = 3, ERR_CAPACITY = 4 };
+enum { ERR_NONE = 0, ERR_HIST_FULL = 1, ERR_ITER_LIMIT = 2, ERR_CUT_ARG = 3, ERR_CAPACITY = 4, ERR_BARRIER = 5 };
 
 // Per-tableau device state (one per slot).  Plain ints so the host can read it back with one copy.
 struct DevState {
@@ -163,7 +163,10 @@ __device__ __forceinline__ Cand wave_reduce(Cand x, Better better) {
         y.v = __shfl_down(x.v, off, 64);
         y.i = __shfl_down(x.i, off, 64);
         y.b = __shfl_down(x.b, off, 64);
-        if (better(y, x)) x = y;
+        const bool take = better(y, x);  // field-wise selects on one predicate (see price_row)
+        x.v = take ? y.v : x.v;
+        x.i = take ? y.i : x.i;
+        x.b = take ? y.b : x.b;
     }
     return x;
 }
@@ -349,7 +352,11 @@ __device__ void select_step(const Ctx& c, Smem& sm) {
             // `precision` (strict >), which every thread applies itself
             if (val > precision) {
                 Cand cand; cand.v = val; cand.i = col; cand.b = b;
-                if (PriceFirst()(cand, e)) { e = cand; neg_flag = ng; }
+                const bool take = PriceFirst()(cand, e);
+                e.v = take ? cand.v : e.v;
+                e.i = take ? cand.i : e.i;
+                e.b = take ? cand.b : e.b;
+                neg_flag = take ? ng : neg_flag;
             }
         }
         e = block_reduce(e, PriceFirst(), sm);
@@ -805,18 +812,32 @@ __device__ __forceinline__ FCand fcand_block_reduce(FCand x, FSmem& sm) {
 }
 
 // pricing of a cost-row pair held in registers (columns c0, c0+1): simplex.ts:118-219 without unrestricted vars
-__device__ __forceinline__ int price_row(double x0, double x1, int c0, const Ctx& c, Smem& sm) {
-    Cand e; e.v = c.precision; e.i = 0; e.b = 0;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int col = c0 + j;
-        const double rc = j ? x1 : x0;
-        if (col >= 1 && col < c.W && rc > c.precision) {
-            Cand cand; cand.v = rc; cand.i = col; cand.b = c.use_partial ? (col - 1) / c.batch : 0;
-            if (PriceFirst()(cand, e)) e = cand;
-        }
+__device__ __forceinline__ int price_row(double x0, double x1, int c0, const Ctx& c, Smem& sm, unsigned long long* dbg = nullptr) {
+    // the lane's two columns, written out field by field (no struct select: a `Cand e = cand` inside an unrolled
+    // loop was observed to keep the FIRST column's index with the SECOND column's value on gfx950 / ROCm 7.2)
+    const int col1 = c0 + 1;
+    const bool ok0 = c0 >= 1 && c0 < c.W && x0 > c.precision;
+    const bool ok1 = col1 < c.W && x1 > c.precision;   // col1 >= 1 always
+    const int b0 = c.use_partial ? (c0 - 1) / c.batch : 0;
+    const int b1 = c.use_partial ? (col1 - 1) / c.batch : 0;
+    double bv = c.precision;
+    int bi = 0, bb = 0;
+    if (ok0) { bv = x0; bi = c0; bb = b0; }
+    // column c0+1 replaces column c0 only when strictly better in (batch asc, value desc); ties keep c0
+    const bool take1 = ok1 && (bi == 0 || b1 < bb || (b1 == bb && x1 > bv));
+    bv = take1 ? x1 : bv;
+    bi = take1 ? col1 : bi;
+    bb = take1 ? b1 : bb;
+    Cand e;
+    e.v = bv; e.i = bi; e.b = bb;
+    if (dbg) {
+        dbg[threadIdx.x * 4] = (unsigned long long)__double_as_longlong(e.v);
+        dbg[threadIdx.x * 4 + 1] = (unsigned long long)(unsigned)e.i | ((unsigned long long)(unsigned)e.b << 32);
+        dbg[threadIdx.x * 4 + 2] = (unsigned long long)__double_as_longlong(x0);
+        dbg[threadIdx.x * 4 + 3] = (unsigned long long)__double_as_longlong(x1);
     }
     e = block_reduce(e, PriceFirst(), sm);
+    if (dbg && threadIdx.x == 0) dbg[4096] = (unsigned long long)(unsigned)e.i;
     return e.i;
 }
 
@@ -1077,5 +1098,313 @@ __global__ void __launch_bounds__(256) k_fused_finish(FusedCtx f, int last_launc
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         copy_state(f.c.st, fin);
+    }
+}
+
+// ===================================================================================================
+// Register-resident phase 2: the whole tableau lives in the VGPRs of the chip for the whole solve.
+//
+// 256 CUs x 512 KB of vector registers = 128 MB; a 2001 x 2016 fp64 tableau is 32 MB.  Workgroup w keeps its
+// (<= 8) rows in registers -- lane pair (c0, c0+1) of each row -- together with a private copy of the cost row,
+// so a pivot moves NO tableau bytes through HBM: per pivot each workgroup publishes 32 bytes of ratio-test
+// summary plus the one row that would become the pivot row if it wins (16 KB), all workgroups meet at ONE
+// grid barrier, read the <= 256 summaries and the winning row back, and update their registers.
+// One cooperative launch runs the entire phase 2 (no host round trip, no kernel boundary per pivot).
+//
+// Inter-workgroup hand-off follows cdna_hip_programming.md Guideline 16: every shared word is written and read
+// with 8-byte agent-scope relaxed atomics (sc1, write-through / L1-bypassing), every storing wave drains its
+// stores (s_waitcnt vmcnt(0)) before the workgroup's leader arrives at the barrier counter, one lane polls with
+// s_sleep, buffers alternate by pivot parity, every spin is bounded and raises a device-wide abort flag.
+// Preconditions (host): those of the fused pipeline, plus H <= 8 * G (register residency) and a successful
+// hipLaunchCooperativeKernel (all workgroups co-resident).
+// ===================================================================================================
+#define JSLP_R_ROWS 8
+typedef unsigned long long u64_t;
+
+struct ResCtx {
+    Ctx c;
+    u64_t* cands[2];      // [G][4] words: q, kq, kdeg, (r | rdeg << 32)
+    u64_t* rows_pub[2];   // [G][ld] candidate rows (doubles as 8-byte words)
+    unsigned* counter;    // monotonic arrival counter (zeroed by the host before the launch)
+    unsigned* abort_flag; // set when any spin gives up
+    unsigned* verdict;    // workgroup 0's per-pivot cycle-check verdict: (epoch << 1) | stop
+    int32_t G, rpb, H;
+    int32_t iters_cap;
+    u64_t* dbg;  // JSLP_DEBUG_RESIDENT builds only: [epoch][G][2] = (pc, xor-hash of the cost-row copy)
+};
+
+#define AG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define AG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+struct RSmem {
+    FSmem f;
+    int32_t ok;
+    int32_t pubrow;
+};
+
+// arrive + wait on the monotonic counter; false = aborted
+__device__ __forceinline__ bool grid_barrier(const ResCtx& f, unsigned target, RSmem& sm) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(f.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        while (AG_LOAD(f.counter) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+            if ((spins & 127u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
+            if (spins > (1u << 23)) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+        }
+        sm.ok = ok;
+    }
+    __syncthreads();
+    return sm.ok != 0;
+}
+
+__global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
+    __shared__ RSmem sm;
+    const Ctx& c = f.c;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int ld = c.ld, W = c.W, H = f.H;
+    const double precision = c.precision;
+    const int c0 = tid * 2;
+    const bool colok = c0 < ld;
+    const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
+    DevState* st = c.st;
+
+    // ---- load my rows and the cost row into registers ---------------------------------------------------
+    double2 a[JSLP_R_ROWS];
+    double2 r0 = make_double2(0, 0);
+    if (colok) r0 = *reinterpret_cast<const double2*>(c.A + c0);
+#pragma unroll
+    for (int i = 0; i < JSLP_R_ROWS; i++) {
+        const int r = r_begin + i;
+        a[i] = make_double2(0, 0);
+        if (i < f.rpb && r < r_end && colok) a[i] = *reinterpret_cast<const double2*>(c.A + (long long)r * ld + c0);
+    }
+    const int status0 = st->status;
+    int hist_n = st->hist_n;
+    const int it2_start = st->it2;
+    int it2 = it2_start;
+    long long trace_n = st->trace_n;
+    if (status0 != ST_PHASE1_DONE) return;  // not handed over by phase 1: nothing to do (uniform)
+
+    int pc = price_row(r0.x, r0.y, c0, c, sm.f.red);
+    int end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted barrier, 6 history full
+    int unbounded_col = 0;
+    unsigned epoch = 0;
+    if (pc == 0) end_code = 1;
+
+    while (end_code == 0) {
+        if (it2 - it2_start >= f.iters_cap) { end_code = 4; break; }
+        const int par = epoch & 1;
+#ifdef JSLP_DEBUG_RESIDENT
+        if (f.dbg && epoch < 512) {
+            u64_t h = (u64_t)__double_as_longlong(r0.x) * 0x9E3779B97F4A7C15ull ^ ((u64_t)__double_as_longlong(r0.y) * 0xC2B2AE3D27D4EB4Full + (u64_t)c0);
+            if (!colok) h = 0;
+            for (int off = 32; off > 0; off >>= 1) h ^= __shfl_xor(h, off, 64);
+            if (tid == 0) sm.f.win.q = 0;
+            __syncthreads();
+            if ((tid & 63) == 0) atomicXor(reinterpret_cast<u64_t*>(&sm.f.win.q), h);
+            __syncthreads();
+            if (b == 0 && colok && (epoch == 241 || epoch == 100)) {
+                u64_t* dump = f.dbg + (long long)512 * f.G * 2 + (epoch == 241 ? 0 : 4096);
+                dump[c0] = (u64_t)__double_as_longlong(r0.x);
+                dump[c0 + 1] = (u64_t)__double_as_longlong(r0.y);
+            }
+            if (tid == 0) {
+                f.dbg[((long long)epoch * f.G + b) * 2] = (u64_t)pc;
+                f.dbg[((long long)epoch * f.G + b) * 2 + 1] = *reinterpret_cast<u64_t*>(&sm.f.win.q);
+            }
+            __syncthreads();
+        }
+#endif
+        // ---- A: my rows' ratio-test summary for column pc ------------------------------------------------
+        const bool has_pc = colok && ((pc == c0) || (pc == c0 + 1));
+        if (has_pc) {
+#pragma unroll
+            for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.col[i] = (pc == c0) ? a[i].x : a[i].y;
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.rhs[i] = a[i].x;
+        }
+        __syncthreads();
+        double k[JSLP_R_ROWS];
+#pragma unroll
+        for (int i = 0; i < JSLP_R_ROWS; i++) k[i] = sm.f.col[i];
+        if (tid < 64) {
+            FCand mine = fcand_none();
+            if (tid < JSLP_R_ROWS) {
+                const int r = r_begin + tid;
+                if (r >= 1 && r < r_end) fcand_consider(mine, r, sm.f.col[tid], sm.f.rhs[tid], precision);
+            }
+            mine = fcand_wave_reduce(mine);
+            if (tid == 0) {
+                u64_t* cw = f.cands[par] + 4 * b;
+                AG_STORE(cw + 0, (u64_t)__double_as_longlong(mine.q));
+                AG_STORE(cw + 1, (u64_t)__double_as_longlong(mine.kq));
+                AG_STORE(cw + 2, (u64_t)__double_as_longlong(mine.kdeg));
+                AG_STORE(cw + 3, (u64_t)(unsigned)mine.r | ((u64_t)(unsigned)mine.rdeg << 32));
+                sm.pubrow = mine.rdeg != 0x7fffffff ? mine.rdeg : mine.r;  // the only row of mine that can win
+            }
+        }
+        __syncthreads();
+        // ---- B: publish that row (write-through, 8-byte agent stores) ------------------------------------------
+        const int pubrow = sm.pubrow;
+        if (pubrow != 0 && colok) {
+            double2 v = make_double2(0, 0);
+#pragma unroll
+            for (int i = 0; i < JSLP_R_ROWS; i++)
+                if (r_begin + i == pubrow) v = a[i];
+            u64_t* rp = f.rows_pub[par] + (long long)b * ld + c0;
+            AG_STORE(rp, (u64_t)__double_as_longlong(v.x));
+            AG_STORE(rp + 1, (u64_t)__double_as_longlong(v.y));
+        }
+        // ---- C: the one grid barrier of this pivot ----------------------------------------------------------
+        if (!grid_barrier(f, (unsigned)f.G * (epoch + 1), sm)) { end_code = 5; break; }
+        // ---- D: winner ------------------------------------------------------------------------------------------
+        FCand cand = fcand_none();
+        if (tid < f.G) {
+            const u64_t* cw = f.cands[par] + 4 * tid;
+            cand.q = __longlong_as_double((long long)AG_LOAD(cw + 0));
+            cand.kq = __longlong_as_double((long long)AG_LOAD(cw + 1));
+            cand.kdeg = __longlong_as_double((long long)AG_LOAD(cw + 2));
+            const u64_t w3 = AG_LOAD(cw + 3);
+            cand.r = (int32_t)(unsigned)(w3 & 0xffffffffu);
+            cand.rdeg = (int32_t)(unsigned)(w3 >> 32);
+        }
+        const FCand win = fcand_block_reduce(cand, sm.f);
+        int pr; double quot;
+        if (win.rdeg != 0x7fffffff) { pr = win.rdeg; quot = win.kdeg; }
+        else if (win.r != 0) { pr = win.r; quot = win.kq; }
+        else { end_code = 2; unbounded_col = pc; break; }  // simplex.ts:298-303 (uniform decision)
+        // ---- cycle check by workgroup 0, verdict broadcast (only when the check is on) --------------------------------
+        if (c.check_cycles) {
+            if (b == 0) {
+                int stop = 0;
+                if (hist_n >= c.hist_cap) {
+                    stop = 2;
+                } else {
+                    if (tid == 0) c.hist[hist_n] = make_int2(c.vibr[pr], c.vibc[pc]);
+                    __syncthreads();
+                    hist_n += 1;
+                    if (suffix_is_square(c.hist, hist_n, sm.f.red)) stop = 1;
+                }
+                if (tid == 0) AG_STORE(f.verdict, ((epoch + 1) << 2) | (unsigned)stop);
+                if (stop) { end_code = stop == 1 ? 3 : 6; break; }
+            } else {
+                if (tid == 0) {
+                    unsigned spins = 0, v = 0;
+                    int ok = 1;
+                    for (;;) {
+                        v = AG_LOAD(f.verdict);
+                        if ((v >> 2) == epoch + 1) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        ++spins;
+                        if ((spins & 127u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
+                        if (spins > (1u << 23)) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+                    }
+                    sm.ok = ok ? (int)(v & 3u) : -1;
+                }
+                __syncthreads();
+                const int verdict = sm.ok;
+                __syncthreads();
+                if (verdict < 0) { end_code = 5; break; }
+                if (verdict == 1) { end_code = 3; break; }
+                if (verdict == 2) { end_code = 6; break; }
+            }
+        }
+        // ---- E: the winning row, normalised (simplex.ts:352-364) ------------------------------------------------------
+        const int bw = pr / f.rpb;
+        double2 p = make_double2(0, 0);
+        if (colok) {
+            const u64_t* rp = f.rows_pub[par] + (long long)bw * ld + c0;
+            const double pvx = __longlong_as_double((long long)AG_LOAD(rp));
+            const double pvy = __longlong_as_double((long long)AG_LOAD(rp + 1));
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = c0 + j;
+                const double val = j ? pvy : pvx;
+                double v = 0.0;
+                if (col < W) {
+                    const bool innz = nonzero16(val);
+                    v = innz ? val / quot : 0.0;
+                    if (col == pc) v = 1.0 / quot;
+                    if (innz && !nonzero16(v) && v != 0.0) v = 0.0;
+                }
+                if (j) p.y = v; else p.x = v;
+            }
+        }
+        const bool v0 = nonzero16(p.x), v1 = nonzero16(p.y);
+        // ---- F: update registers: cost row (every workgroup the same), then my rows ------------------------------------
+        // k0 = cost-row entry of column pc: held by the lane pair owning pc in EVERY workgroup's r0 copy
+        if (has_pc) sm.f.col[0] = (pc == c0) ? r0.x : r0.y;
+        __syncthreads();
+        const double k0 = sm.f.col[0];
+        __syncthreads();
+        if (nonzero16(k0)) {
+            if (v0) r0.x = eliminate(r0.x, k0, p.x);
+            if (v1) r0.y = eliminate(r0.y, k0, p.y);
+            if (has_pc) { const double nv = -k0 / quot; if (pc == c0) r0.x = nv; else r0.y = nv; }
+        }
+#pragma unroll
+        for (int i = 0; i < JSLP_R_ROWS; i++) {
+            const int r = r_begin + i;
+            if (r >= r_end) continue;
+            if (r == 0) { a[i] = r0; continue; }  // workgroup 0 owns the cost row
+            if (r == pr) { a[i] = p; continue; }
+            if (nonzero16(k[i])) {
+                if (v0) a[i].x = eliminate(a[i].x, k[i], p.x);
+                if (v1) a[i].y = eliminate(a[i].y, k[i], p.y);
+                if (has_pc) { const double nv = -k[i] / quot; if (pc == c0) a[i].x = nv; else a[i].y = nv; }
+            }
+        }
+        // workgroup 0 commits the basis change (simplex.ts:339-349)
+        if (b == 0 && tid == 0) {
+            const int leaving = c.vibr[pr], entering = c.vibc[pc];
+            c.vibr[pr] = entering;
+            c.vibc[pc] = leaving;
+            c.rbv[entering] = pr;
+            c.rbv[leaving] = -1;
+            c.cbv[entering] = -1;
+            c.cbv[leaving] = pc;
+            if (trace_n < c.trace_cap) c.trace[trace_n] = make_int2(pr, pc);
+        }
+        trace_n += 1;
+        it2 += 1;
+        epoch += 1;
+        // ---- G: price the new cost row -> entering column of the next pivot ----------------------------------------------
+#ifdef JSLP_DEBUG_RESIDENT
+        pc = price_row(r0.x, r0.y, c0, c, sm.f.red, (f.dbg && b == 0 && epoch == 241) ? f.dbg + (long long)512 * f.G * 2 + 8192 : nullptr);
+#else
+        pc = price_row(r0.x, r0.y, c0, c, sm.f.red);
+#endif
+        if (pc == 0) end_code = 1;
+    }
+
+    // ---- epilogue: registers -> tableau, workgroup 0 -> state -----------------------------------------------------------
+    if (end_code != 5) {
+#pragma unroll
+        for (int i = 0; i < JSLP_R_ROWS; i++) {
+            const int r = r_begin + i;
+            if (i < f.rpb && r < r_end && colok) *reinterpret_cast<double2*>(c.A + (long long)r * ld + c0) = a[i];
+        }
+    }
+    if (b == 0 && tid == 0) {
+        st->it2 = it2;
+        st->trace_n = trace_n;
+        st->hist_n = hist_n;
+        st->iters_left -= (it2 - it2_start);
+        st->do_pivot = 0;
+        st->status = ST_DONE;
+        st->obj_cell = r0.x;  // column 0 of the cost row
+        if (end_code == 1) st->optimal = 1;
+        if (end_code == 2) { st->bounded = 0; st->unbounded_var = c.vibc[unbounded_col]; }
+        if (end_code == 3) { st->cycle_phase = 2; st->feasible = 0; }
+        if (end_code == 4) st->err = ERR_ITER_LIMIT;
+        if (end_code == 5) st->err = ERR_BARRIER;
+        if (end_code == 6) st->err = ERR_HIST_FULL;
     }
 }

@@ -16,7 +16,7 @@ from test_oracle_golden import replay, usable
 
 pytestmark = pytest.mark.gpu
 
-PATHS = ["auto", "wg", "sp", "fused"]
+PATHS = ["auto", "wg", "sp", "fused", "resident"]
 
 
 @pytest.fixture(params=PATHS)
@@ -54,7 +54,7 @@ def test_big_fixture_replay(hip_lib, name):
 @pytest.mark.parametrize("name", ["Monster_Problem", "Monster_II"])
 def test_big_fixture_replay_other_paths(hip_lib, name):
     g = G.load(os.path.join(G.GOLDEN, "fixtures", name + ".json.gz"))
-    for mode in ("wg", "sp", "fused"):
+    for mode in ("wg", "sp", "fused", "resident"):
         os.environ["JSLP_FORCE_PATH"] = mode
         try:
             replay(hip_lib, g)

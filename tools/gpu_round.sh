@@ -7,6 +7,7 @@ out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 for s in $steps; do
   case $s in
+    quick) JSLP_FORCE_PATH=resident timeout 180 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "dense_synthetic and resident and 200" > $out/quick.log 2>&1 < /dev/null; echo "quick rc=$?"; tail -5 $out/quick.log ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1 < /dev/null; echo "smoke rc=$?" ;;
     tests) timeout 1200 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1 < /dev/null; echo "tests rc=$?"; tail -4 $out/pytest_gpu.log ;;
     bench) timeout 600 python bench.py --steps 3 --warmup 1 > $out/bench.log 2>&1 < /dev/null; echo "bench rc=$?"; grep '^{' $out/bench.log | cut -c1-1500 ;;
