@@ -61,7 +61,8 @@ struct jslp_engine {
     double* f_buf1 = nullptr; FCand* f_cands[2] = {nullptr, nullptr}; double* f_pcol[2] = {nullptr, nullptr};
     DevState* f_st[2] = {nullptr, nullptr};
     // register-resident phase 2 (one cooperative launch): hand-off buffers
-    u64_t* r_cands[2] = {nullptr, nullptr}; u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr;
+    u64_t* r_gran = nullptr;  // [2][G][8] granules then [2][G] row flags (one allocation, zeroed per launch)
+    u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr;
     int no_resident = 0;
     // timing
     int timing = 0;
@@ -204,7 +205,7 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     hipFree(e->d_unr);
     hipFree(e->f_buf1); hipFree(e->f_cands[0]); hipFree(e->f_cands[1]); hipFree(e->f_pcol[0]); hipFree(e->f_pcol[1]);
     hipFree(e->f_st[0]); hipFree(e->f_st[1]);
-    hipFree(e->r_cands[0]); hipFree(e->r_cands[1]); hipFree(e->r_rows[0]); hipFree(e->r_rows[1]); hipFree(e->r_sync);
+    hipFree(e->r_gran); hipFree(e->r_rows[0]); hipFree(e->r_rows[1]); hipFree(e->r_sync);
     hipFree(e->d_cut_offs); hipFree(e->d_cut_type); hipFree(e->d_cut_var); hipFree(e->d_cut_val);
     hipFree(e->d_rhs); hipFree(e->d_rows); hipFree(e->d_states);
     if (e->h_rhs) hipHostFree(e->h_rhs);
@@ -302,10 +303,8 @@ static bool resident_eligible(const jslp_engine* e, int H) {
 
 static int ensure_resident(jslp_engine* e) {
     if (e->r_sync) return JSLP_OK;
-    for (int i = 0; i < 2; i++) {
-        HIPC(hipMalloc(&e->r_cands[i], sizeof(u64_t) * 4 * JSLP_F_MAXG));
-        HIPC(hipMalloc(&e->r_rows[i], sizeof(u64_t) * (size_t)JSLP_F_MAXG * e->ld));
-    }
+    HIPC(hipMalloc(&e->r_gran, sizeof(u64_t) * (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 1) + 16)));
+    for (int i = 0; i < 2; i++) HIPC(hipMalloc(&e->r_rows[i], sizeof(u64_t) * (size_t)JSLP_F_MAXG * e->ld));
     HIPC(hipMalloc(&e->r_sync, sizeof(unsigned) * 16));
     return JSLP_OK;
 }
@@ -460,8 +459,15 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             if (r) return r;
             ResCtx rc;
             rc.c = c;
-            for (int i = 0; i < 2; i++) { rc.cands[i] = e->r_cands[i]; rc.rows_pub[i] = e->r_rows[i]; }
-            rc.counter = e->r_sync; rc.abort_flag = e->r_sync + 4; rc.verdict = e->r_sync + 8;
+            for (int i = 0; i < 2; i++) {
+                rc.gran[i] = e->r_gran + (size_t)i * JSLP_F_MAXG * JSLP_R_GRAN;
+                rc.rowflag[i] = e->r_gran + (size_t)2 * JSLP_F_MAXG * JSLP_R_GRAN + (size_t)i * JSLP_F_MAXG;
+                rc.rows_pub[i] = e->r_rows[i];
+            }
+            rc.decision[0] = e->r_gran + (size_t)2 * JSLP_F_MAXG * (JSLP_R_GRAN + 1);
+            rc.decision[1] = rc.decision[0] + 8;
+            rc.abort_flag = e->r_sync + 4;
+            HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 1) + 16), s));  // tags restart at 1
             rc.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
             rc.G = (H + rc.rpb - 1) / rc.rpb;
             rc.H = H;

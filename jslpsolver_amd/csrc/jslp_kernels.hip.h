@@ -1119,51 +1119,122 @@ __global__ void __launch_bounds__(256) k_fused_finish(FusedCtx f, int last_launc
 // hipLaunchCooperativeKernel (all workgroups co-resident).
 // ===================================================================================================
 #define JSLP_R_ROWS 8
+#define JSLP_R_GRAN 8        // 8-byte granules per workgroup summary (7 used)
 typedef unsigned long long u64_t;
 
 struct ResCtx {
     Ctx c;
-    u64_t* cands[2];      // [G][4] words: q, kq, kdeg, (r | rdeg << 32)
+    u64_t* gran[2];       // [G][8] data-tagged granules {tag = epoch + 1 : 32 | payload : 32}: q, kq, kdeg halves, rows
     u64_t* rows_pub[2];   // [G][ld] candidate rows (doubles as 8-byte words)
-    unsigned* counter;    // monotonic arrival counter (zeroed by the host before the launch)
+    u64_t* rowflag[2];    // [G] epoch tag: the workgroup's candidate row of that epoch is fully written through
     unsigned* abort_flag; // set when any spin gives up
-    unsigned* verdict;    // workgroup 0's per-pivot cycle-check verdict: (epoch << 1) | stop
+    u64_t* decision[2];   // leader's per-pivot decision: 3 tagged granules {pr | stop << 16}, {quot lo}, {quot hi}
     int32_t G, rpb, H;
     int32_t iters_cap;
-    u64_t* dbg;  // JSLP_DEBUG_RESIDENT builds only: [epoch][G][2] = (pc, xor-hash of the cost-row copy)
+    u64_t* dbg;  // JSLP_DEBUG_RESIDENT builds only
 };
 
 #define AG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define AG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define JSLP_SPIN_LIMIT (1u << 22)
 
 struct RSmem {
     FSmem f;
+    unsigned sweep[JSLP_F_MAXG * JSLP_R_GRAN];  // payloads of every workgroup's granules for the current pivot
+    // LDS-atomic reductions (a handful of participants each; far cheaper than 12 ds_bpermute stages)
+    u64_t p_val;      // pricing: bits of the best value in the winning batch
+    int32_t p_batch;  // pricing: first batch holding a candidate
+    int32_t p_col;    // pricing: first column with that value
+    u64_t l_q;        // leader: bits of the smallest accepted quotient
+    double l_k;       // leader: pivot-column entry of the winning row
+    int32_t l_rdeg, l_r;
     int32_t ok;
     int32_t pubrow;
+    unsigned dec[4];
 };
 
-// arrive + wait on the monotonic counter; false = aborted
-__device__ __forceinline__ bool grid_barrier(const ResCtx& f, unsigned target, RSmem& sm) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(f.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        int ok = 1;
-        while (AG_LOAD(f.counter) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            ++spins;
-            if ((spins & 127u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
-            if (spins > (1u << 23)) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+// The leader's last FOUR waves gather every workgroup's granules of this epoch (all-gather with the data as the
+// flag, Guideline 16 R2): lane l of the 256 re-reads granules l, l+256, ... -- all 8 loads in flight per pass --
+// until every tag matches; payloads land in LDS.  Returns false on abort (per wave).
+#define JSLP_SWEEP_LANES 256
+#define JSLP_SWEEP_K ((JSLP_F_MAXG * JSLP_R_GRAN) / JSLP_SWEEP_LANES)
+__device__ __forceinline__ bool sweep_granules(const ResCtx& f, int par, unsigned tag, RSmem& sm, int l) {
+    const int n = f.G * JSLP_R_GRAN;
+    const u64_t* g = f.gran[par];
+    unsigned spins = 0;
+    for (;;) {
+        u64_t x[JSLP_SWEEP_K];
+#pragma unroll
+        for (int k = 0; k < JSLP_SWEEP_K; k++) {
+            const int i = l + JSLP_SWEEP_LANES * k;
+            const bool used = i < n && (i & (JSLP_R_GRAN - 1)) != JSLP_R_GRAN - 1;  // granule 7 of each group is unused
+            x[k] = used ? AG_LOAD(g + i) : ((u64_t)tag << 32);
         }
-        sm.ok = ok;
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < JSLP_SWEEP_K; k++) {
+            const int i = l + JSLP_SWEEP_LANES * k;
+            if (i < n) {
+                if ((unsigned)(x[k] >> 32) == tag) sm.sweep[i] = (unsigned)x[k];
+                else ok = false;
+            }
+        }
+        if (__all(ok)) return true;
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+        if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) return false;
+        if (spins > JSLP_SPIN_LIMIT) { if ((l & 63) == 0) AG_STORE(f.abort_flag, 1u); return false; }
     }
+}
+
+// Pricing (simplex.ts:118-219, no unrestricted variables) of the cost-row pair (columns c0, c0+1) each lane
+// holds, reduced with three LDS atomics: first batch holding a candidate, best value in it, first column with
+// that value.  Positive doubles order like their bit patterns.  Returns the column (0 = none) and its value.
+// `sm.p_*` must have been reset (p_batch = INT_MAX, p_val = 0, p_col = INT_MAX) before a preceding barrier.
+__device__ __forceinline__ int price_row_lds(double x0, double x1, int c0, const Ctx& c, RSmem& sm, double* value) {
+    const int col1 = c0 + 1;
+    const bool ok0 = c0 >= 1 && c0 < c.W && x0 > c.precision;
+    const bool ok1 = col1 < c.W && x1 > c.precision;
+    const int b0 = c.use_partial ? (c0 - 1) / c.batch : 0;
+    const int b1 = c.use_partial ? (col1 - 1) / c.batch : 0;
+    double bv = c.precision;
+    int bi = 0, bb = 0;
+    if (ok0) { bv = x0; bi = c0; bb = b0; }
+    const bool take1 = ok1 && (bi == 0 || b1 < bb || (b1 == bb && x1 > bv));
+    bv = take1 ? x1 : bv;
+    bi = take1 ? col1 : bi;
+    bb = take1 ? b1 : bb;
+    if (bi != 0) atomicMin(&sm.p_batch, bb);
     __syncthreads();
-    return sm.ok != 0;
+    const int wb = sm.p_batch;
+    if (wb == 0x7fffffff) return 0;  // uniform: no candidate anywhere -> optimal
+    const u64_t bits = (u64_t)__double_as_longlong(bv);
+    if (bi != 0 && bb == wb) atomicMax(&sm.p_val, bits);
+    __syncthreads();
+    const u64_t wv = sm.p_val;
+    if (bi != 0 && bb == wb && bits == wv) atomicMin(&sm.p_col, bi);
+    __syncthreads();
+    *value = __longlong_as_double((long long)wv);
+    return sm.p_col;
+}
+
+#ifdef JSLP_DEBUG_RESIDENT
+#define RT_MARK(i) do { const u64_t _now = __builtin_amdgcn_s_memtime(); rt_acc[i] += _now - rt_prev; rt_prev = _now; } while (0)
+#else
+#define RT_MARK(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ void reset_reductions(RSmem& sm) {  // one thread, before a barrier
+    sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff;
+    sm.l_rdeg = 0x7fffffff; sm.l_q = ~0ull; sm.l_r = 0x7fffffff;
 }
 
 __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
     __shared__ RSmem sm;
+#ifdef JSLP_DEBUG_RESIDENT
+    u64_t rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64_t rt_prev = __builtin_amdgcn_s_memtime();
+#endif
     const Ctx& c = f.c;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int ld = c.ld, W = c.W, H = f.H;
@@ -1190,8 +1261,11 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
     long long trace_n = st->trace_n;
     if (status0 != ST_PHASE1_DONE) return;  // not handed over by phase 1: nothing to do (uniform)
 
-    int pc = price_row(r0.x, r0.y, c0, c, sm.f.red);
-    int end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted barrier, 6 history full
+    if (tid == 0) reset_reductions(sm);
+    __syncthreads();
+    double k0 = 0.0;  // reduced cost of the entering column = cost-row entry of column pc
+    int pc = price_row_lds(r0.x, r0.y, c0, c, sm, &k0);
+    int end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted hand-off, 6 history full
     int unbounded_col = 0;
     unsigned epoch = 0;
     if (pc == 0) end_code = 1;
@@ -1199,28 +1273,9 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
     while (end_code == 0) {
         if (it2 - it2_start >= f.iters_cap) { end_code = 4; break; }
         const int par = epoch & 1;
-#ifdef JSLP_DEBUG_RESIDENT
-        if (f.dbg && epoch < 512) {
-            u64_t h = (u64_t)__double_as_longlong(r0.x) * 0x9E3779B97F4A7C15ull ^ ((u64_t)__double_as_longlong(r0.y) * 0xC2B2AE3D27D4EB4Full + (u64_t)c0);
-            if (!colok) h = 0;
-            for (int off = 32; off > 0; off >>= 1) h ^= __shfl_xor(h, off, 64);
-            if (tid == 0) sm.f.win.q = 0;
-            __syncthreads();
-            if ((tid & 63) == 0) atomicXor(reinterpret_cast<u64_t*>(&sm.f.win.q), h);
-            __syncthreads();
-            if (b == 0 && colok && (epoch == 241 || epoch == 100)) {
-                u64_t* dump = f.dbg + (long long)512 * f.G * 2 + (epoch == 241 ? 0 : 4096);
-                dump[c0] = (u64_t)__double_as_longlong(r0.x);
-                dump[c0 + 1] = (u64_t)__double_as_longlong(r0.y);
-            }
-            if (tid == 0) {
-                f.dbg[((long long)epoch * f.G + b) * 2] = (u64_t)pc;
-                f.dbg[((long long)epoch * f.G + b) * 2 + 1] = *reinterpret_cast<u64_t*>(&sm.f.win.q);
-            }
-            __syncthreads();
-        }
-#endif
-        // ---- A: my rows' ratio-test summary for column pc ------------------------------------------------
+        const unsigned tag = epoch + 1;
+        RT_MARK(7);
+        // ---- A: my rows' ratio-test summary for column pc (simplex.ts:276-296) --------------------------------
         const bool has_pc = colok && ((pc == c0) || (pc == c0 + 1));
         if (has_pc) {
 #pragma unroll
@@ -1229,29 +1284,40 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
         if (tid == 0) {
 #pragma unroll
             for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.rhs[i] = a[i].x;
+            reset_reductions(sm);
         }
         __syncthreads();
         double k[JSLP_R_ROWS];
 #pragma unroll
         for (int i = 0; i < JSLP_R_ROWS; i++) k[i] = sm.f.col[i];
         if (tid < 64) {
+            // every lane of wave 0 walks the (<= 8) rows in order: same result in all lanes, no shuffles
             FCand mine = fcand_none();
-            if (tid < JSLP_R_ROWS) {
-                const int r = r_begin + tid;
-                if (r >= 1 && r < r_end) fcand_consider(mine, r, sm.f.col[tid], sm.f.rhs[tid], precision);
+#pragma unroll
+            for (int i = 0; i < JSLP_R_ROWS; i++) {
+                const int r = r_begin + i;
+                if (r >= 1 && r < r_end) fcand_consider(mine, r, sm.f.col[i], sm.f.rhs[i], precision);
             }
-            mine = fcand_wave_reduce(mine);
-            if (tid == 0) {
-                u64_t* cw = f.cands[par] + 4 * b;
-                AG_STORE(cw + 0, (u64_t)__double_as_longlong(mine.q));
-                AG_STORE(cw + 1, (u64_t)__double_as_longlong(mine.kq));
-                AG_STORE(cw + 2, (u64_t)__double_as_longlong(mine.kdeg));
-                AG_STORE(cw + 3, (u64_t)(unsigned)mine.r | ((u64_t)(unsigned)mine.rdeg << 32));
-                sm.pubrow = mine.rdeg != 0x7fffffff ? mine.rdeg : mine.r;  // the only row of mine that can win
+            if (tid < JSLP_R_GRAN - 1) {  // lanes 0..6 publish one tagged granule each
+                const u64_t qb = (u64_t)__double_as_longlong(mine.q), kqb = (u64_t)__double_as_longlong(mine.kq),
+                            kdb = (u64_t)__double_as_longlong(mine.kdeg);
+                unsigned payload;
+                switch (tid) {
+                    case 0: payload = (unsigned)qb; break;
+                    case 1: payload = (unsigned)(qb >> 32); break;
+                    case 2: payload = (unsigned)kqb; break;
+                    case 3: payload = (unsigned)(kqb >> 32); break;
+                    case 4: payload = (unsigned)kdb; break;
+                    case 5: payload = (unsigned)(kdb >> 32); break;
+                    default: payload = (unsigned)mine.r | ((mine.rdeg == 0x7fffffff ? 0xffffu : (unsigned)mine.rdeg) << 16); break;
+                }
+                AG_STORE(f.gran[par] + (long long)b * JSLP_R_GRAN + tid, ((u64_t)tag << 32) | payload);
             }
+            if (tid == 0) sm.pubrow = mine.rdeg != 0x7fffffff ? mine.rdeg : mine.r;  // the only row of mine that can win
         }
         __syncthreads();
-        // ---- B: publish that row (write-through, 8-byte agent stores) ------------------------------------------
+        RT_MARK(0);
+        // ---- B: publish that row (write-through 8-byte agent stores); its own flag follows the drain ---------------
         const int pubrow = sm.pubrow;
         if (pubrow != 0 && colok) {
             double2 v = make_double2(0, 0);
@@ -1262,28 +1328,49 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
             AG_STORE(rp, (u64_t)__double_as_longlong(v.x));
             AG_STORE(rp + 1, (u64_t)__double_as_longlong(v.y));
         }
-        // ---- C: the one grid barrier of this pivot ----------------------------------------------------------
-        if (!grid_barrier(f, (unsigned)f.G * (epoch + 1), sm)) { end_code = 5; break; }
-        // ---- D: winner ------------------------------------------------------------------------------------------
-        FCand cand = fcand_none();
-        if (tid < f.G) {
-            const u64_t* cw = f.cands[par] + 4 * tid;
-            cand.q = __longlong_as_double((long long)AG_LOAD(cw + 0));
-            cand.kq = __longlong_as_double((long long)AG_LOAD(cw + 1));
-            cand.kdeg = __longlong_as_double((long long)AG_LOAD(cw + 2));
-            const u64_t w3 = AG_LOAD(cw + 3);
-            cand.r = (int32_t)(unsigned)(w3 & 0xffffffffu);
-            cand.rdeg = (int32_t)(unsigned)(w3 >> 32);
-        }
-        const FCand win = fcand_block_reduce(cand, sm.f);
-        int pr; double quot;
-        if (win.rdeg != 0x7fffffff) { pr = win.rdeg; quot = win.kdeg; }
-        else if (win.r != 0) { pr = win.r; quot = win.kq; }
-        else { end_code = 2; unbounded_col = pc; break; }  // simplex.ts:298-303 (uniform decision)
-        // ---- cycle check by workgroup 0, verdict broadcast (only when the check is on) --------------------------------
-        if (c.check_cycles) {
-            if (b == 0) {
-                int stop = 0;
+        RT_MARK(1);
+        // ---- C: workgroup 0 is the LEADER: its last four waves gather everybody's tagged summaries (data = flag)
+        //         while all other waves, everywhere, drain their row stores -----------------------------------------------
+        bool swept = true;
+        if (b == 0 && tid >= JSLP_F_THREADS - JSLP_SWEEP_LANES)
+            swept = sweep_granules(f, par, tag, sm, tid - (JSLP_F_THREADS - JSLP_SWEEP_LANES));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int all_swept = __syncthreads_and(swept ? 1 : 0);
+        if (!all_swept) { end_code = 5; break; }
+        if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: row is visible
+        RT_MARK(2);
+        // ---- D: the leader decides (winner, unboundedness, cycle check) and broadcasts three tagged granules -----------
+        int pr = 0, stop = 0;
+        double quot = 0.0;
+        if (b == 0) {
+            double cq = 0, ckq = 0, ckdeg = 0;
+            int cr = 0, crdeg = 0x7fffffff;
+            if (tid < f.G) {
+                const unsigned* w = sm.sweep + tid * JSLP_R_GRAN;
+                cq = __longlong_as_double((long long)((u64_t)w[0] | ((u64_t)w[1] << 32)));
+                ckq = __longlong_as_double((long long)((u64_t)w[2] | ((u64_t)w[3] << 32)));
+                ckdeg = __longlong_as_double((long long)((u64_t)w[4] | ((u64_t)w[5] << 32)));
+                cr = (int)(w[6] & 0xffffu);
+                const unsigned rd = w[6] >> 16;
+                crdeg = rd == 0xffffu ? 0x7fffffff : (int)rd;
+            }
+            // (min rdeg) else (min q, then min r): accepted quotients are > precision > 0, so they order like their bits
+            const u64_t qbits = (u64_t)__double_as_longlong(cq);
+            if (crdeg != 0x7fffffff) atomicMin(&sm.l_rdeg, crdeg);
+            if (cr != 0) atomicMin(&sm.l_q, qbits);
+            __syncthreads();
+            const int wrdeg = sm.l_rdeg;
+            const u64_t wq = sm.l_q;
+            if (wrdeg == 0x7fffffff && cr != 0 && qbits == wq) atomicMin(&sm.l_r, cr);
+            __syncthreads();
+            const int wr = sm.l_r;
+            if (wrdeg != 0x7fffffff) { if (crdeg == wrdeg) sm.l_k = ckdeg; }
+            else if (wr != 0x7fffffff && cr == wr && qbits == wq) sm.l_k = ckq;
+            __syncthreads();
+            if (wrdeg != 0x7fffffff) { pr = wrdeg; quot = sm.l_k; }
+            else if (wr != 0x7fffffff) { pr = wr; quot = sm.l_k; }
+            else stop = 3;  // unbounded (simplex.ts:298-303)
+            if (!stop && c.check_cycles) {  // simplex.ts:305-320, before anything is committed
                 if (hist_n >= c.hist_cap) {
                     stop = 2;
                 } else {
@@ -1292,37 +1379,76 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
                     hist_n += 1;
                     if (suffix_is_square(c.hist, hist_n, sm.f.red)) stop = 1;
                 }
-                if (tid == 0) AG_STORE(f.verdict, ((epoch + 1) << 2) | (unsigned)stop);
-                if (stop) { end_code = stop == 1 ? 3 : 6; break; }
-            } else {
-                if (tid == 0) {
-                    unsigned spins = 0, v = 0;
-                    int ok = 1;
-                    for (;;) {
-                        v = AG_LOAD(f.verdict);
-                        if ((v >> 2) == epoch + 1) break;
+            }
+            if (tid < 3) {
+                const u64_t qb = (u64_t)__double_as_longlong(quot);
+                const unsigned payload = tid == 0 ? ((unsigned)pr | ((unsigned)stop << 16)) : (tid == 1 ? (unsigned)qb : (unsigned)(qb >> 32));
+                AG_STORE(f.decision[par] + tid, ((u64_t)tag << 32) | payload);
+            }
+        } else {
+            if (tid < 64) {
+                unsigned spins = 0;
+                int ok = 1;
+                u64_t x = 0;
+                for (;;) {
+                    bool have = true;
+                    if (tid < 3) { x = AG_LOAD(f.decision[par] + tid); have = (unsigned)(x >> 32) == tag; }
+                    if (__all(have)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                    if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
+                    if (spins > JSLP_SPIN_LIMIT) { if (tid == 0) AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+                }
+                if (tid < 3) sm.dec[tid] = (unsigned)x;
+                if (tid == 0) sm.ok = ok;
+            }
+            __syncthreads();
+            if (!sm.ok) { end_code = 5; break; }
+            pr = (int)(sm.dec[0] & 0xffffu);
+            stop = (int)(sm.dec[0] >> 16);
+            quot = __longlong_as_double((long long)((u64_t)sm.dec[1] | ((u64_t)sm.dec[2] << 32)));
+        }
+        RT_MARK(3);
+        if (stop == 3) { end_code = 2; unbounded_col = pc; break; }
+        if (stop == 1) { end_code = 3; break; }
+        if (stop == 2) { end_code = 6; break; }
+        // ---- E: the winning row: loaded speculatively together with its flag; re-loaded in the rare case the flag
+        //         (which follows the winner's drain) was not up yet ------------------------------------------------------
+        const int bw = pr / f.rpb;
+        const u64_t* rp_in = f.rows_pub[par] + (long long)bw * ld + c0;
+        double pvx = 0.0, pvy = 0.0;
+        for (;;) {
+            u64_t flag = 0;
+            if (tid == 0) flag = AG_LOAD(f.rowflag[par] + bw);
+            if (colok) {
+                pvx = __longlong_as_double((long long)AG_LOAD(rp_in));
+                pvy = __longlong_as_double((long long)AG_LOAD(rp_in + 1));
+            }
+            if (tid == 0) {
+                int ok = 1;
+                if ((unsigned)flag != tag) {
+                    unsigned spins = 0;
+                    ok = 2;  // row must be re-read once the flag is up
+                    while ((unsigned)AG_LOAD(f.rowflag[par] + bw) != tag) {
                         __builtin_amdgcn_s_sleep(1);
                         ++spins;
-                        if ((spins & 127u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
-                        if (spins > (1u << 23)) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+                        if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
+                        if (spins > JSLP_SPIN_LIMIT) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
                     }
-                    sm.ok = ok ? (int)(v & 3u) : -1;
                 }
-                __syncthreads();
-                const int verdict = sm.ok;
-                __syncthreads();
-                if (verdict < 0) { end_code = 5; break; }
-                if (verdict == 1) { end_code = 3; break; }
-                if (verdict == 2) { end_code = 6; break; }
+                sm.ok = ok;
             }
+            __syncthreads();
+            const int okv = sm.ok;
+            __syncthreads();
+            if (okv == 2) continue;
+            if (okv == 0) end_code = 5;
+            break;
         }
-        // ---- E: the winning row, normalised (simplex.ts:352-364) ------------------------------------------------------
-        const int bw = pr / f.rpb;
-        double2 p = make_double2(0, 0);
+        if (end_code == 5) break;
+        RT_MARK(4);
+        double2 p = make_double2(0, 0);  // normalised pivot row (simplex.ts:352-364)
         if (colok) {
-            const u64_t* rp = f.rows_pub[par] + (long long)bw * ld + c0;
-            const double pvx = __longlong_as_double((long long)AG_LOAD(rp));
-            const double pvy = __longlong_as_double((long long)AG_LOAD(rp + 1));
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int col = c0 + j;
@@ -1338,12 +1464,8 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
             }
         }
         const bool v0 = nonzero16(p.x), v1 = nonzero16(p.y);
+        RT_MARK(5);
         // ---- F: update registers: cost row (every workgroup the same), then my rows ------------------------------------
-        // k0 = cost-row entry of column pc: held by the lane pair owning pc in EVERY workgroup's r0 copy
-        if (has_pc) sm.f.col[0] = (pc == c0) ? r0.x : r0.y;
-        __syncthreads();
-        const double k0 = sm.f.col[0];
-        __syncthreads();
         if (nonzero16(k0)) {
             if (v0) r0.x = eliminate(r0.x, k0, p.x);
             if (v1) r0.y = eliminate(r0.y, k0, p.y);
@@ -1375,15 +1497,19 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
         trace_n += 1;
         it2 += 1;
         epoch += 1;
+        RT_MARK(6);
         // ---- G: price the new cost row -> entering column of the next pivot ----------------------------------------------
-#ifdef JSLP_DEBUG_RESIDENT
-        pc = price_row(r0.x, r0.y, c0, c, sm.f.red, (f.dbg && b == 0 && epoch == 241) ? f.dbg + (long long)512 * f.G * 2 + 8192 : nullptr);
-#else
-        pc = price_row(r0.x, r0.y, c0, c, sm.f.red);
-#endif
+        pc = price_row_lds(r0.x, r0.y, c0, c, sm, &k0);
         if (pc == 0) end_code = 1;
     }
 
+#ifdef JSLP_DEBUG_RESIDENT
+    if (f.dbg && tid == 0 && (b == 0 || b == 100 || b == f.G - 1)) {
+        u64_t* o = f.dbg + (long long)512 * f.G * 2 + 12288 + (b == 0 ? 0 : (b == 100 ? 16 : 32));
+        for (int i = 0; i < 8; i++) o[i] = rt_acc[i];
+        o[8] = epoch;
+    }
+#endif
     // ---- epilogue: registers -> tableau, workgroup 0 -> state -----------------------------------------------------------
     if (end_code != 5) {
 #pragma unroll

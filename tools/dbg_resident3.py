@@ -1,0 +1,17 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from jslpsolver_amd import _capi, generators
+from jslpsolver_amd.engine import Tableau
+lib = _capi.load_hip()
+os.environ["JSLP_FORCE_PATH"] = "resident"
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
+t = Tableau(m, vibr, vibc, lib=lib)
+res = t.simplex(check_cycles=False)
+print("pivots", len(t.pivot_trace()))
+d = np.fromfile("gpurun_out/resident_r0.bin", dtype=np.uint64)[12288:]
+names = ["A cands", "B row stores", "C sweep/drain/sync", "D decide/poll", "E0 rowflag", "E row load+norm", "F update", "G price"]
+for label, off in (("wg0", 0), ("wg100", 16), ("wgLast", 32)):
+    acc = d[off:off + 8].astype(np.float64); ep = float(d[off + 8])
+    print(label, "epochs", ep, " ".join("%s=%.0f" % (nm, a / max(ep, 1)) for nm, a in zip(names, acc)), "total cyc/pivot %.0f" % (acc.sum() / max(ep, 1)))
