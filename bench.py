@@ -46,7 +46,7 @@ def cpu_baseline(n, sample_pivots):
         return {"value": None, "unit": "pivots/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
 
 
-def pmc_traffic(H, W):
+def pmc_traffic(H, W, kernel):
     """HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     separate runs, gfx950 FETCH_SIZE x2 correction): counters cannot be read from inside this process, so the
     committed summary of the latest pass on this workload is reported, with its provenance."""
@@ -54,8 +54,8 @@ def pmc_traffic(H, W):
     try:
         with open(path) as fh:
             d = json.load(fh)
-        if abs(d["algorithmic_bytes_per_launch"] - 16.0 * H * W) > 1:
-            return None, "profiles/pmc_latest.json is for another workload"
+        if abs(d["algorithmic_bytes_per_launch"] - 16.0 * H * W) > 1 or d["kernel"] != kernel:
+            return None, "profiles/pmc_latest.json is for another workload / kernel (%s)" % d["kernel"]
         return d["traffic_bytes_per_launch"], "profiles/pmc_latest.json (%s; %s)" % (d["kernel"], d["source"])
     except Exception:
         return None, "no PMC summary committed"
@@ -147,8 +147,11 @@ def main():
         bytes_per_launch = 16.0 * H * W  # read + write every fp64 cell of the H x W tableau
         avg_s = (upd_ms / 1e3) / max(launches, 1)
         achieved = bytes_per_launch / avg_s if launches else 0.0
-        traffic, traffic_note = pmc_traffic(H, W)
-        roofline = {"bound": "hbm", "kernel": "k_pivot_fused", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+        # the register-resident kernel runs ALL pivots of phase 2 in one launch; its unit of work stays one pivot
+        # (16*H*W algorithmic bytes), so "launch" below means "pivot" for it
+        kernel_name = "k_simplex_resident" if launches == pivots_per_solve and os.environ.get("JSLP_FORCE_PATH", "") not in ("fused", "sp", "wg") and not os.environ.get("JSLP_NO_RESIDENT") else "k_pivot_fused"
+        traffic, traffic_note = pmc_traffic(H, W, kernel_name)
+        roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_note,
                     "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches": launches,
                     "whole_pivot_frac": (bytes_per_launch * value / max(world, 1)) / HBM_PEAK}

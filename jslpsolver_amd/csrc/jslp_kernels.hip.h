@@ -1137,6 +1137,9 @@ struct ResCtx {
 #define AG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define AG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define JSLP_SPIN_LIMIT (1u << 22)
+#ifndef JSLP_POLL_SLEEP
+#define JSLP_POLL_SLEEP 6
+#endif
 
 struct RSmem {
     FSmem f;
@@ -1151,12 +1154,14 @@ struct RSmem {
     int32_t ok;
     int32_t pubrow;
     unsigned dec[4];
+    double quo[JSLP_R_ROWS];
+    int32_t kind[JSLP_R_ROWS];
 };
 
-// The leader's last FOUR waves gather every workgroup's granules of this epoch (all-gather with the data as the
-// flag, Guideline 16 R2): lane l of the 256 re-reads granules l, l+256, ... -- all 8 loads in flight per pass --
+// The leader's last EIGHT waves gather every workgroup's granules of this epoch (all-gather with the data as the
+// flag, Guideline 16 R2): lane l of the 512 re-reads granules l, l+512, ... -- all 4 loads in flight per pass --
 // until every tag matches; payloads land in LDS.  Returns false on abort (per wave).
-#define JSLP_SWEEP_LANES 256
+#define JSLP_SWEEP_LANES 512
 #define JSLP_SWEEP_K ((JSLP_F_MAXG * JSLP_R_GRAN) / JSLP_SWEEP_LANES)
 __device__ __forceinline__ bool sweep_granules(const ResCtx& f, int par, unsigned tag, RSmem& sm, int l) {
     const int n = f.G * JSLP_R_GRAN;
@@ -1204,7 +1209,14 @@ __device__ __forceinline__ int price_row_lds(double x0, double x1, int c0, const
     bv = take1 ? x1 : bv;
     bi = take1 ? col1 : bi;
     bb = take1 ? b1 : bb;
-    if (bi != 0) atomicMin(&sm.p_batch, bb);
+    {   // batch ids grow with the lane index: the wave's earliest batch is that of its first candidate lane
+        const unsigned long long m = __ballot(bi != 0);
+        if (m != 0ull) {
+            const int first = __ffsll((long long)m) - 1;
+            const int wave_b = __builtin_amdgcn_readlane(bb, first);
+            if ((threadIdx.x & 63) == 0) atomicMin(&sm.p_batch, wave_b);
+        }
+    }
     __syncthreads();
     const int wb = sm.p_batch;
     if (wb == 0x7fffffff) return 0;  // uniform: no candidate anywhere -> optimal
@@ -1287,16 +1299,32 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
             reset_reductions(sm);
         }
         __syncthreads();
-        double k[JSLP_R_ROWS];
-#pragma unroll
-        for (int i = 0; i < JSLP_R_ROWS; i++) k[i] = sm.f.col[i];
         if (tid < 64) {
-            // every lane of wave 0 walks the (<= 8) rows in order: same result in all lanes, no shuffles
+            // lanes 0..7 classify one row each (the division runs in parallel), then every lane of wave 0 merges the
+            // eight verdicts in row order: same result in all lanes, no shuffles
+            if (tid < JSLP_R_ROWS) {
+                const int r = r_begin + tid;
+                const double colv = sm.f.col[tid], rhs = sm.f.rhs[tid];
+                int kind = 0;  // 0 skip, 1 degenerate winner, 2 quotient candidate
+                double quo = 0.0;
+                if (r >= 1 && r < r_end && !(-precision < colv && colv < precision)) {
+                    if (colv > 0 && precision > rhs && rhs > -precision) kind = 1;
+                    else { quo = rhs / colv; kind = quo > precision ? 2 : 0; }
+                }
+                sm.quo[tid] = quo;
+                sm.kind[tid] = kind;
+            }
+            // (wave 0 only: LDS writes above are visible to the same wave after the wave-level sync below)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
             FCand mine = fcand_none();
 #pragma unroll
             for (int i = 0; i < JSLP_R_ROWS; i++) {
+                const int kind = sm.kind[i];
+                const double quo = sm.quo[i], colv = sm.f.col[i];
                 const int r = r_begin + i;
-                if (r >= 1 && r < r_end) fcand_consider(mine, r, sm.f.col[i], sm.f.rhs[i], precision);
+                if (kind == 1) { if (r < mine.rdeg) { mine.rdeg = r; mine.kdeg = colv; } }
+                else if (kind == 2 && mine.q > quo) { mine.q = quo; mine.r = r; mine.kq = colv; }
             }
             if (tid < JSLP_R_GRAN - 1) {  // lanes 0..6 publish one tagged granule each
                 const u64_t qb = (u64_t)__double_as_longlong(mine.q), kqb = (u64_t)__double_as_longlong(mine.kq),
@@ -1394,7 +1422,7 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
                     bool have = true;
                     if (tid < 3) { x = AG_LOAD(f.decision[par] + tid); have = (unsigned)(x >> 32) == tag; }
                     if (__all(have)) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(JSLP_POLL_SLEEP);  // 250 workgroups poll this one line: keep the load on it light
                     ++spins;
                     if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
                     if (spins > JSLP_SPIN_LIMIT) { if (tid == 0) AG_STORE(f.abort_flag, 1u); ok = 0; break; }
@@ -1477,10 +1505,11 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
             if (r >= r_end) continue;
             if (r == 0) { a[i] = r0; continue; }  // workgroup 0 owns the cost row
             if (r == pr) { a[i] = p; continue; }
-            if (nonzero16(k[i])) {
-                if (v0) a[i].x = eliminate(a[i].x, k[i], p.x);
-                if (v1) a[i].y = eliminate(a[i].y, k[i], p.y);
-                if (has_pc) { const double nv = -k[i] / quot; if (pc == c0) a[i].x = nv; else a[i].y = nv; }
+            const double ki = sm.f.col[i];  // pivot-column entry of row i (still in LDS from step A)
+            if (nonzero16(ki)) {
+                if (v0) a[i].x = eliminate(a[i].x, ki, p.x);
+                if (v1) a[i].y = eliminate(a[i].y, ki, p.y);
+                if (has_pc) { const double nv = -ki / quot; if (pc == c0) a[i].x = nv; else a[i].y = nv; }
             }
         }
         // workgroup 0 commits the basis change (simplex.ts:339-349)

@@ -184,3 +184,16 @@ def test_pivot_entry_point(hip_lib, oracle_lib):
         outs.append([x.tobytes() for x in t.download()])
         t.close()
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("name", ["Monster_II", "Knapsack_1", "Sudoku4x4", "Integer_Wood_Shop_Problem", "StockCuttingProblem"])
+def test_speculative_batched_bnb_on_gpu(hip_lib, name):
+    """host tree with 16-node speculative batches (one k_simplex_wg launch per batch): the reference's result,
+    iteration count and final tableau"""
+    from jslpsolver_amd import Solve
+    g = G.load(os.path.join(G.GOLDEN, "fixtures", name + ".json.gz"))
+    out = Solve(g["model"], full=True, lib=hip_lib, speculate=16)
+    ref = {k: (G.num(v) if not isinstance(v, bool) else v) for k, v in g["result"].items()}
+    assert out["result"] == ref and list(out["result"]) == g["resultKeys"]
+    assert out["iter"] == g["final"]["branchAndCutIterations"]
+    assert G.sha_matrix(out["matrix"]) == g["final"]["matrixSha"]
