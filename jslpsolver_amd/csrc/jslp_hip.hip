@@ -46,9 +46,12 @@ struct jslp_engine {
     int32_t *snap_vibr = nullptr, *snap_vibc = nullptr, *snap_rbv = nullptr, *snap_cbv = nullptr;
     uint8_t* d_unr = nullptr;
     // cuts staging
+    // cuts staging: ONE pinned host buffer -> ONE device buffer per call: [value | offs | var | type]
+    char* d_cuts = nullptr; char* h_cuts = nullptr; size_t cuts_bytes = 0;
     int32_t* d_cut_offs = nullptr; int8_t* d_cut_type = nullptr; int32_t* d_cut_var = nullptr; double* d_cut_val = nullptr;
-    size_t cut_cap = 0, node_cap = 0;
     // read-back staging (device + pinned host)
+    // read-back staging: ONE device buffer -> ONE pinned buffer per group: [states | rhs | rows]
+    char* d_out = nullptr; char* h_out = nullptr;
     double* d_rhs = nullptr; int32_t* d_rows = nullptr; DevState* d_states = nullptr;
     double* h_rhs = nullptr; int32_t* h_rows = nullptr; DevState* h_states = nullptr;
     size_t out_cap = 0;  // nodes
@@ -74,6 +77,7 @@ struct jslp_engine {
 
 static const long long WG_CELLS_SINGLE = 64 * 1024;         // one workgroup beats 2 launches/pivot below this
 static const long long WG_CELLS_BATCH = 4LL * 1024 * 1024;  // batches use one workgroup per node up to this
+static const long long WG_CELLS_CHILD = 1536LL * 1024;      // a single B&B child (few repair pivots) stays in one workgroup up to this
 static const size_t HIST_CAP_MAIN = 1u << 20;
 static const size_t HIST_CAP_SLOT = 1u << 16;
 static const long long TRACE_CAP = 1LL << 22;
@@ -90,7 +94,8 @@ static int32_t round_up(int32_t x, int32_t m) { return (x + m - 1) / m * m; }
 
 static void free_slots(jslp_engine* e) {
     hipFree(e->s.A); hipFree(e->s.vibr); hipFree(e->s.vibc); hipFree(e->s.rbv); hipFree(e->s.cbv);
-    hipFree(e->s.prow); hipFree(e->s.pcol); hipFree(e->s.st); hipFree(e->s.hist);
+    hipFree(e->s.prow); hipFree(e->s.pcol); hipFree(e->s.st); hipFree(e->s.hist); hipFree(e->s.dirty);
+    e->s.dirty = nullptr;
     e->s.A = nullptr; e->s.vibr = e->s.vibc = e->s.rbv = e->s.cbv = nullptr;
     e->s.prow = e->s.pcol = nullptr; e->s.st = nullptr; e->s.hist = nullptr;
 }
@@ -116,10 +121,12 @@ static int ensure_slots(jslp_engine* e, int n) {
     HIPC(hipMalloc(&s.cbv, sizeof(int32_t) * (size_t)s.idx_stride * n));
     HIPC(hipMalloc(&s.prow, sizeof(double) * (size_t)s.prow_stride * n));
     HIPC(hipMalloc(&s.pcol, sizeof(double) * (size_t)s.pcol_stride * n));
+    HIPC(hipMalloc(&s.dirty, (size_t)s.pcol_stride * n));
+    HIPC(hipMemsetAsync(s.dirty, 0, (size_t)s.pcol_stride * n, e->stream));
     HIPC(hipMalloc(&s.st, sizeof(DevState) * n));
     HIPC(hipMalloc(&s.hist, sizeof(int2) * (size_t)s.hist_cap * n));
     HIPC(hipMemsetAsync(s.A, 0, sizeof(double) * s.A_stride * n, e->stream));
-    HIPC(hipMemsetAsync(s.st, 0, sizeof(DevState) * n, e->stream));
+    HIPC(hipMemsetAsync(s.st, 0, sizeof(DevState) * n, e->stream));  // gen = 0: slots hold no snapshot copy yet
     HIPC(hipMemsetAsync(s.prow, 0, sizeof(double) * (size_t)s.prow_stride * n, e->stream));
     HIPC(hipMemsetAsync(s.pcol, 0, sizeof(double) * (size_t)s.pcol_stride * n, e->stream));
     if (!s.trace) {
@@ -133,6 +140,7 @@ static int ensure_slots(jslp_engine* e, int n) {
         HIPC(hipMemcpyAsync(s.rbv, o.rbv, sizeof(int32_t) * o.idx_stride, hipMemcpyDeviceToDevice, e->stream));
         HIPC(hipMemcpyAsync(s.cbv, o.cbv, sizeof(int32_t) * o.idx_stride, hipMemcpyDeviceToDevice, e->stream));
         HIPC(hipMemcpyAsync(s.st, o.st, sizeof(DevState), hipMemcpyDeviceToDevice, e->stream));
+        HIPC(hipMemcpyAsync(s.dirty, o.dirty, (size_t)o.pcol_stride, hipMemcpyDeviceToDevice, e->stream));
         HIPC(hipStreamSynchronize(e->stream));
         e->s = o;
         free_slots(e);
@@ -206,11 +214,8 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     hipFree(e->f_buf1); hipFree(e->f_cands[0]); hipFree(e->f_cands[1]); hipFree(e->f_pcol[0]); hipFree(e->f_pcol[1]);
     hipFree(e->f_st[0]); hipFree(e->f_st[1]);
     hipFree(e->r_gran); hipFree(e->r_rows[0]); hipFree(e->r_rows[1]); hipFree(e->r_sync);
-    hipFree(e->d_cut_offs); hipFree(e->d_cut_type); hipFree(e->d_cut_var); hipFree(e->d_cut_val);
-    hipFree(e->d_rhs); hipFree(e->d_rows); hipFree(e->d_states);
-    if (e->h_rhs) hipHostFree(e->h_rhs);
-    if (e->h_rows) hipHostFree(e->h_rows);
-    if (e->h_states) hipHostFree(e->h_states);
+    hipFree(e->d_cuts); if (e->h_cuts) hipHostFree(e->h_cuts);
+    hipFree(e->d_out); if (e->h_out) hipHostFree(e->h_out);
     if (e->h_state) hipHostFree(e->h_state);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     if (e->ev_begin) hipEventDestroy(e->ev_begin);
@@ -251,6 +256,8 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
     st.feasible = 1;
     st.bounded = 1;
     st.unbounded_var = -1;
+    st.gen = 0;
+    st.s_gen = 0;
     hipStream_t s = e->stream;
     HIPC(hipMemsetAsync(e->s.A, 0, sizeof(double) * e->s.A_stride, s));
     HIPC(hipMemcpy2DAsync(e->s.A, sizeof(double) * e->ld, matrix, sizeof(double) * W, sizeof(double) * W, H,
@@ -272,7 +279,7 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
 static Ctx host_ctx(const jslp_engine* e, int check_cycles) {
     Ctx c;
     c.A = e->s.A; c.vibr = e->s.vibr; c.vibc = e->s.vibc; c.rbv = e->s.rbv; c.cbv = e->s.cbv; c.unr = e->s.unr;
-    c.prow = e->s.prow; c.pcol = e->s.pcol; c.st = e->s.st; c.hist = e->s.hist; c.hist_cap = e->s.hist_cap;
+    c.prow = e->s.prow; c.pcol = e->s.pcol; c.dirty = e->s.dirty; c.st = e->s.st; c.hist = e->s.hist; c.hist_cap = e->s.hist_cap;
     c.trace = e->s.trace; c.trace_cap = e->s.trace_cap; c.ld = e->ld; c.W = e->W; c.check_cycles = check_cycles;
     c.batch = e->batch; c.use_partial = e->use_partial; c.precision = e->precision; c.stop_at_phase2 = 0;
     return c;
@@ -609,8 +616,9 @@ extern "C" int jslp_engine_pivot(jslp_engine* e, int32_t row, int32_t col) {
 
 static dim3 copy_grid(const jslp_engine* e, int slots) {
     const long long n2 = (long long)e->cap_rows * e->ld / 2;
-    int bx = (int)std::min<long long>(2048 / std::max(1, std::min(slots, 8)), (n2 + 255) / 256);
-    return dim3(std::max(bx, 1), slots, 1);
+    long long bx = std::max<long long>(8, std::min<long long>(256, 4096 / std::max(1, slots)));
+    bx = std::min<long long>(bx, (n2 + 255) / 256);
+    return dim3((unsigned)std::max<long long>(bx, 1), slots, 1);
 }
 
 extern "C" int jslp_engine_save(jslp_engine* e) {
@@ -628,6 +636,7 @@ static int enqueue_restore(jslp_engine* e, int first_slot, int n) {
     if (!e->has_save) return JSLP_OK;  // backup.ts:54-56
     Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx};
     hipLaunchKernelGGL(k_restore, copy_grid(e, n), dim3(256), 0, e->stream, e->s, sn, first_slot);
+    hipLaunchKernelGGL(k_restore_commit, dim3(n), dim3(1), 0, e->stream, e->s, first_slot);
     HIPC(hipGetLastError());
     return JSLP_OK;
 }
@@ -641,31 +650,28 @@ extern "C" int jslp_engine_restore(jslp_engine* e) {
     return JSLP_OK;
 }
 
-// stage the cut lists of n_nodes nodes on the device
+// stage the cut lists of n_nodes nodes on the device: packed into one pinned buffer, one async copy, no sync
+// (the pinned buffer is reused only after the call's final stream synchronisation)
 static int upload_cuts(jslp_engine* e, int32_t n_nodes, const int32_t* offs, const int8_t* type, const int32_t* var,
                        const double* value) {
-    const size_t n_cuts = (size_t)offs[n_nodes];
-    if (n_cuts > 0 && (!type || !var || !value)) return fail(JSLP_ERR_ARG, "cuts: null pointer");
-    if ((size_t)n_nodes + 1 > e->node_cap) {
-        hipFree(e->d_cut_offs);
-        e->node_cap = std::max<size_t>(2 * ((size_t)n_nodes + 1), 64);
-        HIPC(hipMalloc(&e->d_cut_offs, sizeof(int32_t) * e->node_cap));
+    const size_t C = (size_t)offs[n_nodes], N1 = (size_t)n_nodes + 1;
+    if (C > 0 && (!type || !var || !value)) return fail(JSLP_ERR_ARG, "cuts: null pointer");
+    const size_t off_offs = 8 * C, off_var = off_offs + 4 * N1, off_type = off_var + 4 * C, total = off_type + C;
+    if (total > e->cuts_bytes) {
+        hipFree(e->d_cuts);
+        if (e->h_cuts) hipHostFree(e->h_cuts);
+        e->cuts_bytes = std::max<size_t>(2 * total, 4096);
+        HIPC(hipMalloc(&e->d_cuts, e->cuts_bytes));
+        HIPC(hipHostMalloc(&e->h_cuts, e->cuts_bytes));
     }
-    if (n_cuts > e->cut_cap) {
-        hipFree(e->d_cut_type); hipFree(e->d_cut_var); hipFree(e->d_cut_val);
-        e->cut_cap = std::max<size_t>(2 * n_cuts, 1024);
-        HIPC(hipMalloc(&e->d_cut_type, e->cut_cap));
-        HIPC(hipMalloc(&e->d_cut_var, sizeof(int32_t) * e->cut_cap));
-        HIPC(hipMalloc(&e->d_cut_val, sizeof(double) * e->cut_cap));
-    }
-    hipStream_t s = e->stream;
-    HIPC(hipMemcpyAsync(e->d_cut_offs, offs, sizeof(int32_t) * ((size_t)n_nodes + 1), hipMemcpyHostToDevice, s));
-    if (n_cuts) {
-        HIPC(hipMemcpyAsync(e->d_cut_type, type, n_cuts, hipMemcpyHostToDevice, s));
-        HIPC(hipMemcpyAsync(e->d_cut_var, var, sizeof(int32_t) * n_cuts, hipMemcpyHostToDevice, s));
-        HIPC(hipMemcpyAsync(e->d_cut_val, value, sizeof(double) * n_cuts, hipMemcpyHostToDevice, s));
-    }
-    HIPC(hipStreamSynchronize(s));  // pageable sources
+    if (C) memcpy(e->h_cuts, value, 8 * C);
+    memcpy(e->h_cuts + off_offs, offs, 4 * N1);
+    if (C) { memcpy(e->h_cuts + off_var, var, 4 * C); memcpy(e->h_cuts + off_type, type, C); }
+    HIPC(hipMemcpyAsync(e->d_cuts, e->h_cuts, total, hipMemcpyHostToDevice, e->stream));
+    e->d_cut_val = reinterpret_cast<double*>(e->d_cuts);
+    e->d_cut_offs = reinterpret_cast<int32_t*>(e->d_cuts + off_offs);
+    e->d_cut_var = reinterpret_cast<int32_t*>(e->d_cuts + off_var);
+    e->d_cut_type = reinterpret_cast<int8_t*>(e->d_cuts + off_type);
     return JSLP_OK;
 }
 
@@ -685,20 +691,28 @@ extern "C" int jslp_engine_add_cuts(jslp_engine* e, int32_t n, const int8_t* typ
     return state_error(*e->h_state);
 }
 
+// read-back buffers for `nodes` nodes laid out [states | rhs | rows] so that one copy brings a group back
+static size_t out_bytes(const jslp_engine* e, size_t nodes) {
+    return nodes * (sizeof(DevState) + (size_t)e->cap_rows * 12);
+}
+static void out_layout(jslp_engine* e, size_t nodes) {
+    const size_t o_rhs = nodes * sizeof(DevState), o_rows = o_rhs + nodes * (size_t)e->cap_rows * 8;
+    e->d_states = reinterpret_cast<DevState*>(e->d_out);
+    e->d_rhs = reinterpret_cast<double*>(e->d_out + o_rhs);
+    e->d_rows = reinterpret_cast<int32_t*>(e->d_out + o_rows);
+    e->h_states = reinterpret_cast<DevState*>(e->h_out);
+    e->h_rhs = reinterpret_cast<double*>(e->h_out + o_rhs);
+    e->h_rows = reinterpret_cast<int32_t*>(e->h_out + o_rows);
+}
 static int ensure_out(jslp_engine* e, size_t nodes) {
-    if (nodes <= e->out_cap) return JSLP_OK;
-    hipFree(e->d_rhs); hipFree(e->d_rows); hipFree(e->d_states);
-    if (e->h_rhs) hipHostFree(e->h_rhs);
-    if (e->h_rows) hipHostFree(e->h_rows);
-    if (e->h_states) hipHostFree(e->h_states);
-    e->out_cap = std::max<size_t>(nodes, 16);
-    const size_t n = e->out_cap * (size_t)e->cap_rows;
-    HIPC(hipMalloc(&e->d_rhs, sizeof(double) * n));
-    HIPC(hipMalloc(&e->d_rows, sizeof(int32_t) * n));
-    HIPC(hipMalloc(&e->d_states, sizeof(DevState) * e->out_cap));
-    HIPC(hipHostMalloc(&e->h_rhs, sizeof(double) * n));
-    HIPC(hipHostMalloc(&e->h_rows, sizeof(int32_t) * n));
-    HIPC(hipHostMalloc(&e->h_states, sizeof(DevState) * e->out_cap));
+    if (nodes > e->out_cap) {
+        hipFree(e->d_out);
+        if (e->h_out) hipHostFree(e->h_out);
+        e->out_cap = std::max<size_t>(nodes, 16);
+        HIPC(hipMalloc(&e->d_out, out_bytes(e, e->out_cap)));
+        HIPC(hipHostMalloc(&e->h_out, out_bytes(e, e->out_cap)));
+    }
+    out_layout(e, nodes);
     return JSLP_OK;
 }
 
@@ -710,9 +724,7 @@ extern "C" int jslp_engine_read_rhs(jslp_engine* e, double* rhs, int32_t* var_in
     hipStream_t s = e->stream;
     hipLaunchKernelGGL(k_gather, dim3(1), dim3(256), 0, s, e->s, 0, e->d_rhs, e->d_rows, e->d_states, (int)e->cap_rows, 0);
     HIPC(hipGetLastError());
-    HIPC(hipMemcpyAsync(e->h_rhs, e->d_rhs, sizeof(double) * e->cap_rows, hipMemcpyDeviceToHost, s));
-    HIPC(hipMemcpyAsync(e->h_rows, e->d_rows, sizeof(int32_t) * e->cap_rows, hipMemcpyDeviceToHost, s));
-    HIPC(hipMemcpyAsync(e->h_states, e->d_states, sizeof(DevState), hipMemcpyDeviceToHost, s));
+    HIPC(hipMemcpyAsync(e->h_out, e->d_out, out_bytes(e, 1), hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
     const int H = e->h_states[0].H;
     if (rhs) memcpy(rhs, e->h_rhs, sizeof(double) * H);
@@ -736,7 +748,10 @@ extern "C" int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const in
     Cuts cu{e->d_cut_offs, e->d_cut_type, e->d_cut_var, e->d_cut_val};
     const int cap = iters_cap(e);
     const long long cells = (long long)e->cap_rows * e->ld;
-    const bool wg = e->force_path == 1 || (e->force_path != 2 && (n_nodes > 1 ? cells <= WG_CELLS_BATCH : use_wg_single(e)));
+    // branch-and-bound children (a saved root exists) need a handful of repair pivots each: one workgroup, one launch,
+    // no host round trip.  A first solve / plain LP goes through the chip-wide path unless the tableau is tiny.
+    const bool wg = e->force_path == 1 ||
+                    (e->force_path == 0 && ((e->has_save && cells <= (n_nodes > 1 ? WG_CELLS_BATCH : WG_CELLS_CHILD)) || use_wg_single(e)));
     const double prev_eval = e->evaluation;
     // group size: bounded by memory (<= 8 GiB of tableau copies) and by what fills the chip twice over
     int group = 1;
@@ -755,10 +770,10 @@ extern "C" int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const in
         hipLaunchKernelGGL(k_add_cuts, dim3(g), dim3(256), 0, s, e->s, cu, 0, first, (int)e->cap_rows);
         HIPC(hipGetLastError());
         if (wg) {
-            HIPC(hipEventRecord(e->ev_begin, s));
+            if (e->timing) HIPC(hipEventRecord(e->ev_begin, s));
             hipLaunchKernelGGL(k_simplex_wg, dim3(g), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
             HIPC(hipGetLastError());
-            HIPC(hipEventRecord(e->ev_end, s));
+            if (e->timing) HIPC(hipEventRecord(e->ev_end, s));
         } else {
             // big tableau: the chip-wide kernels on slot 0 (g == 1)
             HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
@@ -768,15 +783,16 @@ extern "C" int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const in
             rc = run_simplex(e, check_cycles);
             if (rc) return rc;
         }
+        out_layout(e, (size_t)g);
         hipLaunchKernelGGL(k_gather, dim3(g), dim3(256), 0, s, e->s, 0, rhs ? e->d_rhs : nullptr,
                            var_index_by_row ? e->d_rows : nullptr, e->d_states, (int)e->cap_rows, 0);
         HIPC(hipGetLastError());
-        const size_t n = (size_t)g * e->cap_rows;
-        if (rhs) HIPC(hipMemcpyAsync(e->h_rhs, e->d_rhs, sizeof(double) * n, hipMemcpyDeviceToHost, s));
-        if (var_index_by_row) HIPC(hipMemcpyAsync(e->h_rows, e->d_rows, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-        HIPC(hipMemcpyAsync(e->h_states, e->d_states, sizeof(DevState) * g, hipMemcpyDeviceToHost, s));
+        // states come first in the buffer: copy only as far as the caller needs
+        const size_t need = var_index_by_row ? out_bytes(e, (size_t)g)
+                                             : (rhs ? (size_t)g * (sizeof(DevState) + (size_t)e->cap_rows * 8) : (size_t)g * sizeof(DevState));
+        HIPC(hipMemcpyAsync(e->h_out, e->d_out, need, hipMemcpyDeviceToHost, s));
         HIPC(hipStreamSynchronize(s));
-        if (wg) {
+        if (wg && e->timing) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, e->ev_begin, e->ev_end) == hipSuccess) e->total_ms += ms;
         }

@@ -48,6 +48,8 @@ struct DevState {
     // snapshot scalars (savedState)
     int32_t s_H, s_last_element_index;
     // fused phase-2 pipeline
+    int32_t gen;          // snapshot generation (>= 1) this slot's rows are in sync with except its dirty rows; 0 = unknown
+    int32_t s_gen;        // slot 0 only: generation of the current snapshot
     int32_t f_pc;         // entering column chosen for the NEXT launch's pivot
     int32_t f_final_buf;  // which ping-pong buffer holds the tableau when the pipeline stopped
 };
@@ -62,6 +64,7 @@ struct Ctx {
     const uint8_t* unr;
     double* prow;
     double* pcol;
+    uint8_t* dirty;       // [cap_rows] row differs from the snapshot (maintained by the per-node kernel only)
     DevState* st;
     int2* hist;
     int2* trace;
@@ -85,6 +88,7 @@ struct Slots {
     const uint8_t* unr;
     double* prow;    int32_t prow_stride;
     double* pcol;    int32_t pcol_stride;
+    uint8_t* dirty;  // stride = pcol_stride
     DevState* st;
     int2* hist;      int32_t hist_cap;
     int2* trace;     long long trace_cap;   // only slot 0 traces
@@ -103,6 +107,7 @@ __device__ __forceinline__ Ctx slot_ctx(const Slots& s, int slot, int check_cycl
     c.unr = s.unr;
     c.prow = s.prow + (long long)slot * s.prow_stride;
     c.pcol = s.pcol + (long long)slot * s.pcol_stride;
+    c.dirty = s.dirty + (long long)slot * s.pcol_stride;
     c.st = s.st + slot;
     c.hist = s.hist + (long long)slot * s.hist_cap;
     c.hist_cap = s.hist_cap;
@@ -490,29 +495,61 @@ __global__ void __launch_bounds__(JSLP_UPD_THREADS) k_update(Ctx c) {
     }
 }
 
-// The same elimination done by ONE workgroup (per-node kernel): waves take rows, lanes take column pairs.
-__device__ __forceinline__ void update_rows_wg(const Ctx& c) {
+// The same elimination done by ONE workgroup (per-node kernel).  The pivot column is read once by all threads in
+// parallel and the rows that pass the reference's gate (simplex.ts:370-375) are compacted into an LDS list, so
+// the waves only ever touch rows the reference touches (a Monster_II pivot: ~10 of 945) and never chain dependent
+// global loads; lanes take column pairs.  Touched rows are flagged dirty for the next restore().
+#define JSLP_ACT_CAP 4096
+struct ActSmem {
+    int32_t n;
+    int32_t row[JSLP_ACT_CAP];
+    double k[JSLP_ACT_CAP];
+};
+
+__device__ __forceinline__ void update_row_wave(const Ctx& c, int r, double k, int pc, double quot, int lane) {
+    const int ld = c.ld;
+    double* row = c.A + (long long)r * ld;
+    for (int c0 = lane * 2; c0 < ld; c0 += 128) {
+        const double2 p = *reinterpret_cast<const double2*>(c.prow + c0);
+        const bool v0 = nonzero16(p.x), v1 = nonzero16(p.y);
+        const bool has_pc = (pc == c0) || (pc == c0 + 1);
+        if (!v0 && !v1 && !has_pc) continue;
+        double2 x = *reinterpret_cast<const double2*>(row + c0);
+        if (v0) x.x = eliminate(x.x, k, p.x);
+        if (v1) x.y = eliminate(x.y, k, p.y);
+        if (has_pc) {
+            const double nv = -k / quot;
+            if (pc == c0) x.x = nv; else x.y = nv;
+        }
+        *reinterpret_cast<double2*>(row + c0) = x;
+    }
+}
+
+__device__ __forceinline__ void update_rows_wg(const Ctx& c, ActSmem& act) {
     const DevState* st = c.st;
-    const int H = st->H, ld = c.ld, pr = st->pr, pc = st->pc;
+    const int H = st->H, pr = st->pr, pc = st->pc;
     const double quot = st->quot;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int r = w; r < H; r += nw) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    if (tid == 0) { act.n = 0; c.dirty[pr] = 1; }
+    __syncthreads();
+    for (int r = tid; r < H; r += nt) {
         const double k = c.pcol[r];
-        if (r == pr || !nonzero16(k)) continue;  // wave-uniform gate
-        double* row = c.A + (long long)r * ld;
-        for (int c0 = lane * 2; c0 < ld; c0 += 128) {
-            const double2 p = *reinterpret_cast<const double2*>(c.prow + c0);
-            const bool v0 = nonzero16(p.x), v1 = nonzero16(p.y);
-            const bool has_pc = (pc == c0) || (pc == c0 + 1);
-            if (!v0 && !v1 && !has_pc) continue;
-            double2 x = *reinterpret_cast<const double2*>(row + c0);
-            if (v0) x.x = eliminate(x.x, k, p.x);
-            if (v1) x.y = eliminate(x.y, k, p.y);
-            if (has_pc) {
-                const double nv = -k / quot;
-                if (pc == c0) x.x = nv; else x.y = nv;
-            }
-            *reinterpret_cast<double2*>(row + c0) = x;
+        if (r != pr && nonzero16(k)) {
+            const int idx = atomicAdd(&act.n, 1);
+            if (idx < JSLP_ACT_CAP) { act.row[idx] = r; act.k[idx] = k; }
+            c.dirty[r] = 1;
+        }
+    }
+    __syncthreads();
+    const int n = act.n;
+    if (n <= JSLP_ACT_CAP) {
+        for (int i = w; i < n; i += nw) update_row_wave(c, act.row[i], act.k[i], pc, quot, lane);
+    } else {  // more gated-in rows than the list holds: walk all rows (wave-uniform gate)
+        for (int r = w; r < H; r += nw) {
+            const double k = c.pcol[r];
+            if (r == pr || !nonzero16(k)) continue;
+            update_row_wave(c, r, k, pc, quot, lane);
         }
     }
 }
@@ -529,7 +566,7 @@ __global__ void __launch_bounds__(JSLP_WG_THREADS) k_select(Ctx c) {
 // Tableau.pivot(r, c) on its own
 __global__ void __launch_bounds__(JSLP_WG_THREADS) k_prepare(Ctx c, int pr, int pc) {
     __shared__ Smem sm;
-    if (threadIdx.x == 0) c.st->status = ST_RUNNING;
+    if (threadIdx.x == 0) { c.st->status = ST_RUNNING; c.st->gen = 0; }
     __syncthreads();
     prepare_pivot(c, pr, pc, false, sm);
 }
@@ -556,11 +593,13 @@ __device__ __forceinline__ void begin_simplex(DevState* st, int iters_cap) {
 }
 __global__ void k_begin(Slots s, int first_slot, int iters_cap) {
     begin_simplex(s.st + first_slot + blockIdx.x, iters_cap);
+    s.st[first_slot + blockIdx.x].gen = 0;  // the chip-wide kernels do not maintain dirty-row flags
 }
 
 // One workgroup = one whole simplex() on one tableau (slot first_slot + blockIdx.x).
 __global__ void __launch_bounds__(JSLP_WG_THREADS) k_simplex_wg(Slots s, int first_slot, int check_cycles, int iters_cap) {
     __shared__ Smem sm;
+    __shared__ ActSmem act;
     const Ctx c = slot_ctx(s, first_slot + blockIdx.x, check_cycles);
     if (threadIdx.x == 0) begin_simplex(c.st, iters_cap);
     __syncthreads();
@@ -571,7 +610,7 @@ __global__ void __launch_bounds__(JSLP_WG_THREADS) k_simplex_wg(Slots s, int fir
     for (;;) {
         select_step(c, sm);
         if (!c.st->do_pivot) break;
-        update_rows_wg(c);
+        update_rows_wg(c, act);
         __syncthreads();
     }
 }
@@ -586,11 +625,29 @@ __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int fir
     const int slot = first_slot + blockIdx.y;
     DevState* st = s.st + slot;
     const int H = s.st[0].s_H;  // every slot shares slot 0's snapshot scalars
+    const int gen = s.st[0].s_gen;
+    const bool incremental = gen != 0 && st->gen == gen;  // this slot already holds the snapshot except for its dirty rows
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long long)gridDim.x * blockDim.x;
-    const long long n2 = (long long)H * s.ld / 2;
     const double2* src = reinterpret_cast<const double2*>(snap.A);
     double2* dst = reinterpret_cast<double2*>(s.A + (long long)slot * s.A_stride);
-    for (long long i = tid; i < n2; i += nt) dst[i] = src[i];
+    uint8_t* dirty = s.dirty + (long long)slot * s.pcol_stride;
+    if (!incremental) {
+        const long long n2 = (long long)H * s.ld / 2;
+        for (long long i = tid; i < n2; i += nt) dst[i] = src[i];
+        for (long long i = tid; i < s.pcol_stride; i += nt) dirty[i] = 0;
+    } else {
+        // one wave per dirty row: rows are found by a strided scan of the byte flags
+        const int lane = threadIdx.x & 63;
+        const long long wave = tid >> 6, nwaves = nt >> 6;
+        const int ld2 = s.ld / 2;
+        for (long long r = wave; r < H; r += nwaves) {
+            if (!dirty[r]) continue;
+            const double2* a = src + r * ld2;
+            double2* b = dst + r * ld2;
+            for (int i = lane; i < ld2; i += 64) b[i] = a[i];
+            if (lane == 0) dirty[r] = 0;
+        }
+    }
     int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
     for (long long i = tid; i < H; i += nt) vibr[i] = snap.vibr[i];
     int32_t* vibc = s.vibc + (long long)slot * s.vibc_stride;
@@ -603,6 +660,11 @@ __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int fir
         st->last_element_index = s.st[0].s_last_element_index;
         st->err = ERR_NONE;
     }
+}
+// second half of restore(): record that the slots are in sync (a separate tiny launch: k_restore's workgroups all
+// read st->gen, so none of them may write it)
+__global__ void k_restore_commit(Slots s, int first_slot) {
+    s.st[first_slot + blockIdx.x].gen = s.st[0].s_gen;
 }
 
 // save (backup.ts:13-51): slot 0 -> snapshot
@@ -625,6 +687,8 @@ __global__ void __launch_bounds__(256) k_save(Slots s, SnapshotW snap) {
     if (tid == 0) {
         st->s_H = H;
         st->s_last_element_index = st->last_element_index;
+        st->s_gen += 1;   // every slot's copy is stale now ...
+        st->gen = 0;      // ... including slot 0 (it equals the snapshot, but its dirty flags are not maintained by every path)
     }
 }
 
