@@ -20,6 +20,7 @@ const DEFAULT_LIBRARY = path.join(__dirname, "..", "jslpsolver_amd", "csrc", "li
 
 let addon = null;
 let backend = null;
+let bypass = 0; // > 0 while a Solve() that must stay on the reference's own path is running
 
 function loadEngine(options) {
     const o = options || {};
@@ -29,7 +30,7 @@ function loadEngine(options) {
 }
 
 function eligible(t) {
-    return t.optionalObjectives.length === 0 && !(t.model && t.model.useMIRCuts);
+    return bypass === 0 && t.optionalObjectives.length === 0 && !(t.model && t.model.useMIRCuts);
 }
 
 function activate(t, opts) {
@@ -188,11 +189,31 @@ function install(Tableau, options) {
         st.pendingCuts = (st.pendingCuts || []).concat(cuts);
     };
 
+    // The incremental B&B service (options.useIncremental, src/tableau/incremental-branch-and-cut.ts:55-107) keeps
+    // parent checkpoints by copying tableau.matrix on the host: device-resident checkpoints are a later row
+    // (SURVEY.md 8f.1), so such solves stay on the reference's own path.  Pass the solver to have it guarded.
+    let origSolve = null;
+    if (opts.solver) {
+        const solver = opts.solver;
+        origSolve = solver.Solve;
+        solver.Solve = function (model) {
+            const keepOut = !!(model && model.options && model.options.useIncremental === true);
+            if (!keepOut) return origSolve.apply(this, arguments);
+            bypass += 1;
+            try {
+                return origSolve.apply(this, arguments);
+            } finally {
+                bypass -= 1;
+            }
+        };
+    }
+
     return function uninstall() {
         P.simplex = orig.simplex;
         P.save = orig.save;
         P.restore = orig.restore;
         P.addCutConstraints = orig.addCutConstraints;
+        if (origSolve) opts.solver.Solve = origSolve;
     };
 }
 

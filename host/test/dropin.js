@@ -18,7 +18,21 @@ const library = path.resolve(process.argv[2]);
 const dir = process.argv[3];
 const filter = process.argv[4] || "";
 const backend = gpu.loadEngine({ library });
-gpu.install(Tableau, { SlackVariable });
+// reference results for the B&B strategy options BEFORE the binding is installed (these models are not in the goldens)
+const strategyFiles = ["Knapsack_1", "Integer_Wood_Shop_Problem", "Monster_II", "Sudoku4x4", "Integer_Sports_Complex_Problem"];
+const strategies = [{ nodeSelection: "best-first" }, { nodeSelection: "depth-first" }, { nodeSelection: "hybrid", branching: "pseudocost" },
+    { branching: "most-fractional" }, { branching: "strong" }, { useIncremental: true }];
+function loadGolden(d, f) { return JSON.parse(zlib.gunzipSync(fs.readFileSync(path.join(d, f))).toString()); }
+const strategyBase = {};
+const strategyDir = path.join(root, "tests", "golden", "fixtures");
+if (!filter && dir.indexOf("fixtures") >= 0) {
+    for (const f of strategyFiles) for (const v of strategies) {
+        const m = JSON.parse(JSON.stringify(loadGolden(strategyDir, f + ".json.gz").model));
+        m.options = Object.assign({}, m.options || {}, v);
+        strategyBase[f + JSON.stringify(v)] = JSON.stringify(solver.Solve(m));
+    }
+}
+gpu.install(Tableau, { SlackVariable, solver });
 
 function num(x) {
     if (typeof x !== "number") return x;
@@ -52,5 +66,17 @@ for (const f of fs.readdirSync(dir).filter((x) => x.endsWith(".json.gz") && x.in
     }
     if (bad.length) { fail += 1; console.log("FAIL", f, bad.join("; ")); } else { pass += 1; }
 }
-console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu }));
+// options.nodeSelection / options.branching (enhanced service) run over the same overridden methods; options.useIncremental
+// is kept on the reference's own path by the binding: both must reproduce the unpatched reference
+let strategyOk = 0;
+for (const key of Object.keys(strategyBase)) {
+    const f = key.slice(0, key.indexOf("{"));
+    const v = JSON.parse(key.slice(key.indexOf("{")));
+    const m = JSON.parse(JSON.stringify(loadGolden(strategyDir, f + ".json.gz").model));
+    m.options = Object.assign({}, m.options || {}, v);
+    const r = JSON.stringify(solver.Solve(m));
+    if (r === strategyBase[key]) strategyOk += 1;
+    else { fail += 1; console.log("FAIL strategy", f, JSON.stringify(v)); }
+}
+console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);

@@ -1,0 +1,118 @@
+"""Edge cases of the hot path (empty / ragged shapes, unbounded, infeasible, tiny entries around the 1e-16 zero test,
+capacity and argument errors), engine vs oracle.  The same body runs on the CPU against the oracle alone (API
+behaviour) and, under -m gpu, HIP vs oracle bit for bit on every launch shape."""
+import os
+
+import numpy as np
+import pytest
+
+from jslpsolver_amd import _capi
+from jslpsolver_amd.engine import Tableau
+
+
+def _maps(m, n):
+    return (np.concatenate(([-1], np.arange(m))).astype(np.int32), np.concatenate(([-1], m + np.arange(n))).astype(np.int32))
+
+
+def _cases():
+    rng = np.random.default_rng(7)
+    out = []
+    out.append(("1x1", np.zeros((1, 1))))
+    out.append(("no rows", np.array([[0.0, 3.0, -2.0, 5.0]])))
+    out.append(("no columns", np.array([[0.0], [4.0], [-1.0], [2.0]])))
+    out.append(("unbounded", np.array([[0.0, 1.0, 2.0], [4.0, -1.0, 0.0], [6.0, 0.0, -3.0]])))
+    out.append(("infeasible", np.array([[0.0, 1.0, 1.0], [-4.0, 1.0, 2.0], [6.0, 1.0, 3.0]])))
+    out.append(("degenerate", np.array([[0.0, 3.0, 2.0], [0.0, 1.0, 1.0], [0.0, 2.0, 1.0], [4.0, 1.0, 0.0]])))
+    tiny = rng.integers(-4, 9, (12, 15)).astype(np.float64)
+    tiny[1:, 1:] *= np.where(rng.random((11, 14)) < 0.3, 10.0 ** rng.integers(-18, -14, (11, 14)), 1.0)
+    tiny[1:, 0] = np.abs(tiny[1:, 0])
+    out.append(("entries around 1e-16", tiny))
+    big = rng.integers(-4, 9, (10, 9)).astype(np.float64) * 1e150
+    big[1:, 0] = np.abs(big[1:, 0])
+    out.append(("huge magnitudes", big))
+    wide = rng.integers(0, 7, (3, 300)).astype(np.float64)
+    out.append(("wide, partial pricing", wide))
+    tall = rng.integers(0, 7, (300, 4)).astype(np.float64)
+    tall[0, 1:] = [5, 3, 1]
+    out.append(("tall", tall))
+    return out
+
+
+def _run(lib, A, unr=()):
+    m, n = A.shape[0] - 1, A.shape[1] - 1
+    vibr, vibc = _maps(m, n)
+    t = Tableau(A, vibr, vibc, unr, lib=lib)
+    res = t.simplex(check_cycles=True)
+    out = (res.as_dict(), t.pivot_trace().tolist(), [x.tobytes() for x in t.download()], repr(t.evaluation))
+    t.close()
+    return out
+
+
+def _same(a, b):
+    assert a[1] == b[1]
+    for k in a[0]:
+        x, y = a[0][k], b[0][k]
+        assert x == y or (isinstance(x, float) and np.isnan(x) and np.isnan(y)), k
+    assert a[2] == b[2]
+    assert a[3] == b[3]
+
+
+@pytest.mark.parametrize("name,A", _cases(), ids=[c[0] for c in _cases()])
+def test_oracle_handles_edge_shapes(oracle_lib, name, A):
+    res = _run(oracle_lib, A)[0]
+    if name == "unbounded":
+        assert not res["bounded"] and res["evaluation"] == float("-inf") and res["unbounded_var_index"] >= 0
+    if name == "infeasible":
+        assert not res["feasible"] and res["pivots_phase2"] == -1
+    if name in ("1x1", "no rows", "no columns"):
+        assert res["feasible"] or name == "no columns"
+
+
+def test_argument_and_capacity_errors(oracle_lib):
+    A = np.array([[0.0, 3.0, 2.0], [4.0, 1.0, 1.0], [6.0, 1.0, 3.0]])
+    vibr, vibc = _maps(2, 2)
+    t = Tableau(A, vibr, vibc, lib=oracle_lib, row_capacity=4)
+    t.simplex()
+    t.save()
+    with pytest.raises(_capi.EngineError):
+        t.addCutConstraints([{"type": "max", "varIndex": 2, "value": 1.0}] * 3)  # 3 rows into 2 spare slots
+    with pytest.raises(_capi.EngineError):
+        t.applyCuts([{"type": "max", "varIndex": 999, "value": 1.0}])
+    with pytest.raises(_capi.EngineError):
+        t.pivot(7, 1)
+    t.close()
+    with pytest.raises(ValueError):
+        Tableau(A, vibr[:2], vibc, lib=oracle_lib)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["auto", "wg", "sp", "fused", "resident"])
+@pytest.mark.parametrize("name,A", _cases(), ids=[c[0] for c in _cases()])
+def test_hip_equals_oracle_on_edge_shapes(hip_lib, oracle_lib, mode, name, A):
+    if mode == "auto":
+        os.environ.pop("JSLP_FORCE_PATH", None)
+    else:
+        os.environ["JSLP_FORCE_PATH"] = mode
+    try:
+        _same(_run(hip_lib, A), _run(oracle_lib, A))
+        if A.shape[1] > 2:  # the same with an unrestricted variable (phase-1 / pricing special cases)
+            _same(_run(hip_lib, A, unr=[A.shape[0] - 1 + 1]), _run(oracle_lib, A, unr=[A.shape[0] - 1 + 1]))
+    finally:
+        os.environ.pop("JSLP_FORCE_PATH", None)
+
+
+@pytest.mark.gpu
+def test_hip_argument_and_capacity_errors(hip_lib):
+    A = np.array([[0.0, 3.0, 2.0], [4.0, 1.0, 1.0], [6.0, 1.0, 3.0]])
+    vibr, vibc = _maps(2, 2)
+    t = Tableau(A, vibr, vibc, lib=hip_lib, row_capacity=4)
+    t.simplex()
+    t.save()
+    with pytest.raises(_capi.EngineError):
+        t.addCutConstraints([{"type": "max", "varIndex": 2, "value": 1.0}] * 3)
+    t.restore()
+    with pytest.raises(_capi.EngineError):
+        t.applyCuts([{"type": "max", "varIndex": 999, "value": 1.0}])
+    with pytest.raises(_capi.EngineError):
+        t.pivot(7, 1)
+    t.close()

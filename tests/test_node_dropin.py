@@ -46,6 +46,7 @@ def test_reference_host_with_oracle_engine(oracle_lib):
     _prepare()
     r = _run(oracle_lib.path, "fixtures")
     assert r["backend"] == "oracle-c" and r["fail"] == 0 and r["pass"] == 47 and r["solved_on_engine"] >= 37
+    assert r["strategy_variants_ok"] == 30  # enhanced B&B services over the same seam; incremental kept on the TS path
     r = _run(oracle_lib.path, "synthetic", "40x")
     assert r["fail"] == 0 and r["pass"] >= 12
 
@@ -55,5 +56,6 @@ def test_reference_host_with_hip_engine(hip_lib):
     _prepare()
     r = _run(hip_lib.path, "fixtures")
     assert r["backend"] == "hip-gfx950" and r["fail"] == 0 and r["pass"] == 47 and r["solved_on_engine"] >= 37
+    assert r["strategy_variants_ok"] == 30
     r = _run(hip_lib.path, "synthetic", "_")
     assert r["fail"] == 0 and r["pass"] >= 40
