@@ -26,6 +26,8 @@ static struct {
     int (*create)(jslp_engine**, int, int32_t, int32_t, int32_t, double);
     void (*destroy)(jslp_engine*);
     int (*upload)(jslp_engine*, const double*, const int32_t*, const int32_t*, const int32_t*, int32_t);
+    int (*set_optional)(jslp_engine*, int32_t, const double*);
+    int (*get_optional)(jslp_engine*, double*, int32_t*);
     int (*simplex)(jslp_engine*, int, jslp_simplex_result*);
     int (*pivot)(jslp_engine*, int32_t, int32_t);
     int (*save)(jslp_engine*);
@@ -151,6 +153,7 @@ static napi_value fn_load(napi_env env, napi_callback_info info) {
     } while (0)
     SYM(backend_name, "jslp_backend_name"); SYM(last_error, "jslp_last_error"); SYM(device_count, "jslp_device_count");
     SYM(create, "jslp_engine_create"); SYM(destroy, "jslp_engine_destroy"); SYM(upload, "jslp_engine_upload");
+    SYM(set_optional, "jslp_engine_set_optional_objectives"); SYM(get_optional, "jslp_engine_get_optional_objectives");
     SYM(simplex, "jslp_engine_simplex"); SYM(pivot, "jslp_engine_pivot"); SYM(save, "jslp_engine_save");
     SYM(restore, "jslp_engine_restore"); SYM(add_cuts, "jslp_engine_add_cuts"); SYM(relax, "jslp_engine_relax");
     SYM(relax_batch, "jslp_engine_relax_batch"); SYM(dims, "jslp_engine_dims"); SYM(read_rhs, "jslp_engine_read_rhs");
@@ -220,6 +223,42 @@ static napi_value fn_upload(napi_env env, napi_callback_info info) {
     ENGINE_OK(env, L.upload(e, (const double*)m, (const int32_t*)r, (const int32_t*)c, (const int32_t*)u, (int32_t)nu),
               "jslp_engine_upload");
     return NULL;
+}
+
+/* setOptionalObjectives(h, n, Float64Array rows) -- rows holds n * width doubles */
+static napi_value fn_set_optional(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    int32_t n, W;
+    NAPI_OK(env, napi_get_value_int32(env, argv[1], &n));
+    void* rows;
+    size_t len;
+    if (!typed(env, argv[2], napi_float64_array, &rows, &len)) return NULL;
+    ENGINE_OK(env, L.dims(e, NULL, &W, NULL), "jslp_engine_dims");
+    if (n < 0 || len < (size_t)n * (size_t)W) THROW(env, "setOptionalObjectives: rows shorter than n * width");
+    ENGINE_OK(env, L.set_optional(e, n, (const double*)rows), "jslp_engine_set_optional_objectives");
+    return NULL;
+}
+
+/* getOptionalObjectives(h, Float64Array rows) -> n */
+static napi_value fn_get_optional(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    void* rows;
+    size_t len;
+    if (!typed(env, argv[1], napi_float64_array, &rows, &len)) return NULL;
+    int32_t n = 0, W;
+    ENGINE_OK(env, L.dims(e, NULL, &W, NULL), "jslp_engine_dims");
+    ENGINE_OK(env, L.get_optional(e, NULL, &n), "jslp_engine_get_optional_objectives");
+    if (len < (size_t)n * (size_t)W) THROW(env, "getOptionalObjectives: rows shorter than n * width");
+    ENGINE_OK(env, L.get_optional(e, (double*)rows, &n), "jslp_engine_get_optional_objectives");
+    napi_value v;
+    NAPI_OK(env, napi_create_int32(env, n, &v));
+    return v;
 }
 
 static napi_value fn_simplex(napi_env env, napi_callback_info info) {
@@ -413,7 +452,8 @@ static napi_value fn_pivot_trace(napi_env env, napi_callback_info info) {
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"load", fn_load}, {"deviceCount", fn_device_count}, {"create", fn_create}, {"destroy", fn_destroy},
-        {"upload", fn_upload}, {"simplex", fn_simplex}, {"pivot", fn_pivot}, {"save", fn_save}, {"restore", fn_restore},
+        {"upload", fn_upload}, {"setOptionalObjectives", fn_set_optional}, {"getOptionalObjectives", fn_get_optional},
+        {"simplex", fn_simplex}, {"pivot", fn_pivot}, {"save", fn_save}, {"restore", fn_restore},
         {"addCuts", fn_add_cuts}, {"relax", fn_relax}, {"relaxBatch", fn_relax_batch}, {"dims", fn_dims},
         {"readRhs", fn_read_rhs}, {"download", fn_download}, {"pivotTrace", fn_pivot_trace},
     };

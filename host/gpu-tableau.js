@@ -10,8 +10,9 @@
 // simplex, branch-and-cut.ts:33-37) becomes ONE addon call; after it only what the host tree reads comes
 // back: flags, evaluation, the RHS column and the row -> variable map (mip-utils.ts:43-61,100-126).
 //
-// Out of the engine's scope (the reference's own TypeScript path keeps running for these tableaus):
-// optional objectives / soft constraints (simplex.ts:221-263,394-412) and MIR cuts (useMIRCuts).
+// Optional objectives (soft constraints, simplex.ts:221-263,394-412) travel with the tableau: their reducedCosts rows are
+// uploaded next to the matrix and read back after every simplex().  Out of the engine's scope (the reference's own
+// TypeScript path keeps running for these tableaus): MIR cuts (useMIRCuts) and the incremental B&B service.
 "use strict";
 const path = require("path");
 
@@ -30,7 +31,7 @@ function loadEngine(options) {
 }
 
 function eligible(t) {
-    return bypass === 0 && t.optionalObjectives.length === 0 && !(t.model && t.model.useMIRCuts);
+    return bypass === 0 && !(t.model && t.model.useMIRCuts);
 }
 
 function activate(t, opts) {
@@ -49,7 +50,19 @@ function activate(t, opts) {
         Object.keys(t.unrestrictedVars).filter((k) => t.unrestrictedVars[k] === true).map(Number)
     );
     addon.upload(h, t.matrix.subarray(0, t.height * t.width), rows, cols, unrestricted);
+    const nOpt = t.optionalObjectives.length; // already sorted by priority (tableau.ts:286)
+    let optional = null;
+    if (nOpt > 0) {
+        optional = new Float64Array(nOpt * t.width);
+        for (let o = 0; o < nOpt; o++) {
+            const rc = t.optionalObjectives[o].reducedCosts;
+            for (let c = 0; c < t.width; c++) optional[o * t.width + c] = rc[c] || 0;
+        }
+        addon.setOptionalObjectives(h, nOpt, optional);
+    }
     t.__gpu = {
+        nOpt,
+        optional,
         active: true,
         h,
         rowCapacity,
@@ -96,6 +109,14 @@ function absorb(t, st, res) {
         t.model.messages.push("Cycle in phase " + res.cyclePhase); // simplex.ts:86-88 / 313-315
         t.model.messages.push("Start :" + res.cycleStart);
         t.model.messages.push("Length :" + res.cycleLength);
+    }
+    if (st.nOpt > 0) {
+        // the host reads optionalObjectives[o].reducedCosts[0] for its tie-break (branch-and-cut.ts:107-127)
+        addon.getOptionalObjectives(st.h, st.optional);
+        for (let o = 0; o < st.nOpt; o++) {
+            const rc = t.optionalObjectives[o].reducedCosts;
+            for (let c = 0; c < t.width; c++) rc[c] = st.optional[o * t.width + c];
+        }
     }
     // read-back: RHS column + row map (and the inverse map the host tree indexes with)
     const H = res.height;

@@ -87,6 +87,17 @@ int jslp_engine_upload(jslp_engine* e, const double* matrix, const int32_t* var_
                        const int32_t* var_index_by_col, const int32_t* unrestricted_var_indexes,
                        int32_t n_unrestricted);
 
+/*
+ * Optional objectives (soft constraints): the priority-ordered extra cost rows `optionalObjectives[o].reducedCosts`
+ * (tableau.ts:71, 278-290; built by _resetMatrix :335-338).  rows = n x width doubles, objective o at rows + o*width,
+ * already sorted by ascending priority; column 0 is the objective's evaluation cell (branch-and-cut.ts:107-127 reads it).
+ * pivot() updates them (simplex.ts:394-412), phase 2 consults them when no column prices out on the main cost row
+ * (simplex.ts:155-162, 221-263), save()/restore() snapshot them (backup.ts:37-43, 94-104).  Call after upload().
+ */
+int jslp_engine_set_optional_objectives(jslp_engine* e, int32_t n, const double* rows);
+/* Current optional-objective rows (n x width, as above); n_out receives n. */
+int jslp_engine_get_optional_objectives(jslp_engine* e, double* rows, int32_t* n_out);
+
 /* Tableau.simplex(): phase1 then phase2 (simplex.ts:14-23).  check_cycles = model.checkForCycles. */
 int jslp_engine_simplex(jslp_engine* e, int check_cycles, jslp_simplex_result* out);
 

@@ -54,6 +54,8 @@ SYMBOLS = {
     "jslp_engine_create": (C.c_int, [_P(C.c_void_p), C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
     "jslp_engine_destroy": (None, [C.c_void_p]),
     "jslp_engine_upload": (C.c_int, [C.c_void_p, _f64p, _i32p, _i32p, _i32p, C.c_int32]),
+    "jslp_engine_set_optional_objectives": (C.c_int, [C.c_void_p, C.c_int32, _f64p]),
+    "jslp_engine_get_optional_objectives": (C.c_int, [C.c_void_p, _f64p, _i32p]),
     "jslp_engine_simplex": (C.c_int, [C.c_void_p, C.c_int, _P(SimplexResult)]),
     "jslp_engine_pivot": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "jslp_engine_save": (C.c_int, [C.c_void_p]),

@@ -127,6 +127,10 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
     found_integral = False
     check = model.checkForCycles
     precision = tableau.precision
+    n_opt = getattr(tableau, "n_optional", 0)
+    best_optional = [math.inf] * n_opt  # bestOptionalObjectivesEvaluations (:66-69)
+    if n_opt > 0:
+        speculate = 1  # the tie-break below reads the live optional-objective cells: evaluate in order
     cache = {}          # heap sequence number -> _NodeEval
     saved = False
     last_cuts = None    # cuts of the node the sequential run evaluated last
@@ -171,8 +175,19 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
         evaluation = tableau.evaluation
         if evaluation > best_evaluation:
             continue
-        if evaluation == best_evaluation:
-            continue  # no optional objectives: "isCurrentEvaluationWorse" stays true (:107-127)
+        optional_cells = None
+        if evaluation == best_evaluation:  # :107-127: ties are broken on the optional objectives, in priority order
+            worse = True
+            if n_opt > 0:
+                optional_cells = tableau.optional_objectives()[:, 0]
+                for o in range(n_opt):
+                    if optional_cells[o] > best_optional[o]:
+                        break
+                    if optional_cells[o] < best_optional[o]:
+                        worse = False
+                        break
+            if worse:
+                continue
         rows = _rows_by_var(vibr)
         if is_integral(model, rhs, rows, precision):
             found_integral = True
@@ -180,6 +195,10 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
                 return iterations, True
             best_cuts = cuts
             best_evaluation = evaluation
+            if n_opt > 0:
+                if optional_cells is None:
+                    optional_cells = tableau.optional_objectives()[:, 0]
+                best_optional = [float(x) for x in optional_cells]
         else:
             if iterations == 1:
                 tableau.save()

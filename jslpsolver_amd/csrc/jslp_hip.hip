@@ -45,6 +45,7 @@ struct jslp_engine {
     double* snap_A = nullptr;
     int32_t *snap_vibr = nullptr, *snap_vibc = nullptr, *snap_rbv = nullptr, *snap_cbv = nullptr;
     uint8_t* d_unr = nullptr;
+    int32_t n_opt = 0; double* snap_oo = nullptr;  // optional objectives (slot copies live in s.oo)
     // cuts staging
     // cuts staging: ONE pinned host buffer -> ONE device buffer per call: [value | offs | var | type]
     char* d_cuts = nullptr; char* h_cuts = nullptr; size_t cuts_bytes = 0;
@@ -94,8 +95,8 @@ static int32_t round_up(int32_t x, int32_t m) { return (x + m - 1) / m * m; }
 
 static void free_slots(jslp_engine* e) {
     hipFree(e->s.A); hipFree(e->s.vibr); hipFree(e->s.vibc); hipFree(e->s.rbv); hipFree(e->s.cbv);
-    hipFree(e->s.prow); hipFree(e->s.pcol); hipFree(e->s.st); hipFree(e->s.hist); hipFree(e->s.dirty);
-    e->s.dirty = nullptr;
+    hipFree(e->s.prow); hipFree(e->s.pcol); hipFree(e->s.st); hipFree(e->s.hist); hipFree(e->s.dirty); hipFree(e->s.oo);
+    e->s.dirty = nullptr; e->s.oo = nullptr;
     e->s.A = nullptr; e->s.vibr = e->s.vibc = e->s.rbv = e->s.cbv = nullptr;
     e->s.prow = e->s.pcol = nullptr; e->s.st = nullptr; e->s.hist = nullptr;
 }
@@ -129,6 +130,13 @@ static int ensure_slots(jslp_engine* e, int n) {
     HIPC(hipMemsetAsync(s.st, 0, sizeof(DevState) * n, e->stream));  // gen = 0: slots hold no snapshot copy yet
     HIPC(hipMemsetAsync(s.prow, 0, sizeof(double) * (size_t)s.prow_stride * n, e->stream));
     HIPC(hipMemsetAsync(s.pcol, 0, sizeof(double) * (size_t)s.pcol_stride * n, e->stream));
+    s.n_opt = e->n_opt;
+    s.oo_stride = (long long)e->n_opt * e->ld;
+    s.oo = nullptr;
+    if (e->n_opt > 0) {
+        HIPC(hipMalloc(&s.oo, sizeof(double) * (size_t)s.oo_stride * n));
+        HIPC(hipMemsetAsync(s.oo, 0, sizeof(double) * (size_t)s.oo_stride * n, e->stream));
+    }
     if (!s.trace) {
         HIPC(hipMalloc(&s.trace, sizeof(int2) * TRACE_CAP));
         s.trace_cap = TRACE_CAP;
@@ -141,6 +149,7 @@ static int ensure_slots(jslp_engine* e, int n) {
         HIPC(hipMemcpyAsync(s.cbv, o.cbv, sizeof(int32_t) * o.idx_stride, hipMemcpyDeviceToDevice, e->stream));
         HIPC(hipMemcpyAsync(s.st, o.st, sizeof(DevState), hipMemcpyDeviceToDevice, e->stream));
         HIPC(hipMemcpyAsync(s.dirty, o.dirty, (size_t)o.pcol_stride, hipMemcpyDeviceToDevice, e->stream));
+        if (e->n_opt > 0 && o.oo) HIPC(hipMemcpyAsync(s.oo, o.oo, sizeof(double) * (size_t)o.oo_stride, hipMemcpyDeviceToDevice, e->stream));
         HIPC(hipStreamSynchronize(e->stream));
         e->s = o;
         free_slots(e);
@@ -210,7 +219,7 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     free_slots(e);
     hipFree(e->s.trace);
     hipFree(e->snap_A); hipFree(e->snap_vibr); hipFree(e->snap_vibc); hipFree(e->snap_rbv); hipFree(e->snap_cbv);
-    hipFree(e->d_unr);
+    hipFree(e->d_unr); hipFree(e->snap_oo);
     hipFree(e->f_buf1); hipFree(e->f_cands[0]); hipFree(e->f_cands[1]); hipFree(e->f_pcol[0]); hipFree(e->f_pcol[1]);
     hipFree(e->f_st[0]); hipFree(e->f_st[1]);
     hipFree(e->r_gran); hipFree(e->r_rows[0]); hipFree(e->r_rows[1]); hipFree(e->r_sync);
@@ -273,13 +282,50 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
     e->has_save = 0;
     e->evaluation = 0;
     e->n_unr = n_unrestricted;
+    if (e->n_opt > 0) {  // a new model: optional objectives are set again by the caller
+        hipFree(e->s.oo); hipFree(e->snap_oo);
+        e->s.oo = nullptr; e->snap_oo = nullptr; e->s.n_opt = 0; e->s.oo_stride = 0; e->n_opt = 0;
+    }
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_set_optional_objectives(jslp_engine* e, int32_t n, const double* rows) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "set_optional_objectives before upload");
+    if (n < 0 || (n > 0 && !rows)) return fail(JSLP_ERR_ARG, "set_optional_objectives: bad arguments");
+    HIPC(hipSetDevice(e->device));
+    HIPC(hipStreamSynchronize(e->stream));
+    hipFree(e->s.oo); hipFree(e->snap_oo);
+    e->s.oo = nullptr; e->snap_oo = nullptr;
+    e->n_opt = n;
+    e->s.n_opt = n;
+    e->s.oo_stride = (long long)n * e->ld;
+    if (n > 0) {
+        const size_t per = (size_t)e->s.oo_stride;
+        HIPC(hipMalloc(&e->s.oo, sizeof(double) * per * std::max(1, e->n_slots)));
+        HIPC(hipMalloc(&e->snap_oo, sizeof(double) * per));
+        HIPC(hipMemset(e->s.oo, 0, sizeof(double) * per * std::max(1, e->n_slots)));
+        HIPC(hipMemcpy2D(e->s.oo, sizeof(double) * e->ld, rows, sizeof(double) * e->W, sizeof(double) * e->W, n,
+                         hipMemcpyHostToDevice));
+    }
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_get_optional_objectives(jslp_engine* e, double* rows, int32_t* n_out) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "get_optional_objectives before upload");
+    HIPC(hipSetDevice(e->device));
+    if (n_out) *n_out = e->n_opt;
+    if (rows && e->n_opt > 0) {
+        HIPC(hipStreamSynchronize(e->stream));
+        HIPC(hipMemcpy2D(rows, sizeof(double) * e->W, e->s.oo, sizeof(double) * e->ld, sizeof(double) * e->W, e->n_opt,
+                         hipMemcpyDeviceToHost));
+    }
     return JSLP_OK;
 }
 
 static Ctx host_ctx(const jslp_engine* e, int check_cycles) {
     Ctx c;
     c.A = e->s.A; c.vibr = e->s.vibr; c.vibc = e->s.vibc; c.rbv = e->s.rbv; c.cbv = e->s.cbv; c.unr = e->s.unr;
-    c.prow = e->s.prow; c.pcol = e->s.pcol; c.dirty = e->s.dirty; c.st = e->s.st; c.hist = e->s.hist; c.hist_cap = e->s.hist_cap;
+    c.prow = e->s.prow; c.pcol = e->s.pcol; c.dirty = e->s.dirty; c.oo = e->s.oo; c.n_opt = e->n_opt; c.st = e->s.st; c.hist = e->s.hist; c.hist_cap = e->s.hist_cap;
     c.trace = e->s.trace; c.trace_cap = e->s.trace_cap; c.ld = e->ld; c.W = e->W; c.check_cycles = check_cycles;
     c.batch = e->batch; c.use_partial = e->use_partial; c.precision = e->precision; c.stop_at_phase2 = 0;
     return c;
@@ -301,7 +347,7 @@ static bool use_wg_single(const jslp_engine* e) {
 // the fused one-launch-per-pivot phase 2 (see k_pivot_fused for the preconditions)
 static bool fused_eligible(const jslp_engine* e) {
     if (e->force_path == 2) return false;
-    return e->n_unr == 0 && e->ld <= 2 * JSLP_F_THREADS && e->cap_rows <= 64 * JSLP_F_MAXG && e->precision >= 1e-15;
+    return e->n_unr == 0 && e->n_opt == 0 && e->ld <= 2 * JSLP_F_THREADS && e->cap_rows <= 64 * JSLP_F_MAXG && e->precision >= 1e-15;
 }
 
 static bool resident_eligible(const jslp_engine* e, int H) {
@@ -624,7 +670,7 @@ static dim3 copy_grid(const jslp_engine* e, int slots) {
 extern "C" int jslp_engine_save(jslp_engine* e) {
     if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "save before upload");
     HIPC(hipSetDevice(e->device));
-    SnapshotW w{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx};
+    SnapshotW w{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo};
     hipLaunchKernelGGL(k_save, dim3(copy_grid(e, 1).x), dim3(256), 0, e->stream, e->s, w);
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(e->stream));
@@ -634,7 +680,7 @@ extern "C" int jslp_engine_save(jslp_engine* e) {
 
 static int enqueue_restore(jslp_engine* e, int first_slot, int n) {
     if (!e->has_save) return JSLP_OK;  // backup.ts:54-56
-    Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx};
+    Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo};
     hipLaunchKernelGGL(k_restore, copy_grid(e, n), dim3(256), 0, e->stream, e->s, sn, first_slot);
     hipLaunchKernelGGL(k_restore_commit, dim3(n), dim3(1), 0, e->stream, e->s, first_slot);
     HIPC(hipGetLastError());

@@ -65,6 +65,8 @@ struct Ctx {
     double* prow;
     double* pcol;
     uint8_t* dirty;       // [cap_rows] row differs from the snapshot (maintained by the per-node kernel only)
+    double* oo;           // optional objectives: n_opt rows of ld doubles (optionalObjectives[o].reducedCosts)
+    int32_t n_opt;
     DevState* st;
     int2* hist;
     int2* trace;
@@ -89,6 +91,8 @@ struct Slots {
     double* prow;    int32_t prow_stride;
     double* pcol;    int32_t pcol_stride;
     uint8_t* dirty;  // stride = pcol_stride
+    double* oo;      long long oo_stride;  // n_opt * ld per slot
+    int32_t n_opt;
     DevState* st;
     int2* hist;      int32_t hist_cap;
     int2* trace;     long long trace_cap;   // only slot 0 traces
@@ -108,6 +112,8 @@ __device__ __forceinline__ Ctx slot_ctx(const Slots& s, int slot, int check_cycl
     c.prow = s.prow + (long long)slot * s.prow_stride;
     c.pcol = s.pcol + (long long)slot * s.pcol_stride;
     c.dirty = s.dirty + (long long)slot * s.pcol_stride;
+    c.oo = s.oo ? s.oo + (long long)slot * s.oo_stride : nullptr;
+    c.n_opt = s.n_opt;
     c.st = s.st + slot;
     c.hist = s.hist + (long long)slot * s.hist_cap;
     c.hist_cap = s.hist_cap;
@@ -125,6 +131,11 @@ __device__ __forceinline__ Ctx slot_ctx(const Slots& s, int slot, int check_cycl
 
 // the reference's zero test `!(v >= -1e-16 && v <= 1e-16)` (simplex.ts:356,372,379): NaN counts as non-zero
 __device__ __forceinline__ bool nonzero16(double v) { return !(v >= -1e-16 && v <= 1e-16); }
+
+__device__ __forceinline__ double eliminate(double a, double k, double p) {
+    // matrix[r,c] - coefficient * v0 with BOTH roundings (JavaScript never fuses)
+    return __dsub_rn(a, __dmul_rn(k, p));
+}
 
 // ---------------------------------------------------------------------------------------------------
 // (value, index) candidates and their reductions.  `i == 0` means "no candidate" (row/column 0 is never
@@ -239,6 +250,20 @@ __device__ __forceinline__ void prepare_pivot(const Ctx& c, int pr, int pc, bool
         }
         c.prow[col] = v;
     }
+    // optional objectives (simplex.ts:394-412): same elimination with exact `!== 0` tests, on the final pivot row
+    for (int o = 0; o < c.n_opt; o++) {
+        double* rc = c.oo + (long long)o * ld;
+        __syncthreads();                       // prow[] complete / previous objective done
+        const double coefficient = rc[pc];     // every thread reads it before anyone overwrites rc[pc]
+        __syncthreads();
+        if (coefficient != 0.0) {
+            for (int col = tid; col < W; col += nt) {
+                if (col == pc) { rc[col] = -coefficient / quot; continue; }
+                const double v0 = c.prow[col];
+                if (v0 != 0.0) rc[col] = eliminate(rc[col], coefficient, v0);
+            }
+        }
+    }
     if (tid == 0) {
         const int leaving = c.vibr[pr], entering = c.vibc[pc];  // :339-349
         c.vibr[pr] = entering;
@@ -347,6 +372,7 @@ __device__ void select_step(const Ctx& c, Smem& sm) {
         // [1..B], [B+1..2B], ... that holds a candidate wins; inside it the largest value, first index.
         Cand e; e.v = precision; e.i = 0; e.b = 0;
         int neg_flag = 0;
+        int st_opt_row = -1;  // which optional objective supplied the entering column (-1: the main cost row)
         for (int col = 1 + tid; col < W; col += nt) {
             const double rc = A[col];
             const bool un = c.unr[c.vibc[col]] != 0;
@@ -365,6 +391,29 @@ __device__ void select_step(const Ctx& c, Smem& sm) {
             }
         }
         e = block_reduce(e, PriceFirst(), sm);
+        // simplex.ts:221-263: no column prices out on the main row -> break the tie on the optional objectives, in
+        // priority order, among the columns whose reduced cost is within +-precision on every earlier row
+        for (int o = 0; e.i == 0 && o < c.n_opt; o++) {
+            Cand x; x.v = precision; x.i = 0; x.b = 0;
+            for (int col = 1 + tid; col < W; col += nt) {
+                const double rc0 = A[col];
+                bool deferred = -precision < rc0 && rc0 < precision;
+                for (int q = 0; deferred && q < o; q++) {
+                    const double rq = c.oo[(long long)q * ld + col];
+                    deferred = -precision < rq && rq < precision;
+                }
+                if (!deferred) continue;
+                const double rc = c.oo[(long long)o * ld + col];
+                if (-precision < rc && rc < precision) continue;
+                const bool un = c.unr[c.vibc[col]] != 0;
+                const double val = (un && rc < 0) ? -rc : rc;
+                const bool take = val > x.v;  // strict: first index wins ties inside a thread (ascending columns)
+                x.v = take ? val : x.v;
+                x.i = take ? col : x.i;
+            }
+            e = block_reduce(x, PriceFirst(), sm);
+            if (e.i != 0) st_opt_row = o;
+        }
         if (e.i == 0) {  // optimal (simplex.ts:265-269); setEvaluation happens on the host from obj_cell
             if (tid == 0) { st->optimal = 1; finish(c); }
             __syncthreads();
@@ -373,7 +422,7 @@ __device__ void select_step(const Ctx& c, Smem& sm) {
         pc = e.i;
         // isReducedCostNegative of the winner: recompute (cheap, uniform)
         {
-            const double rc = A[pc];
+            const double rc = st_opt_row < 0 ? A[pc] : c.oo[(long long)st_opt_row * ld + pc];
             const bool un = c.unr[c.vibc[pc]] != 0;
             neg_flag = (un && rc < 0) ? 1 : 0;
         }
@@ -448,10 +497,6 @@ __device__ void select_step(const Ctx& c, Smem& sm) {
 // ---------------------------------------------------------------------------------------------------
 // Row elimination (simplex.ts:367-391) for a set of rows.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double eliminate(double a, double k, double p) {
-    // matrix[r,c] - coefficient * v0 with BOTH roundings (JavaScript never fuses)
-    return __dsub_rn(a, __dmul_rn(k, p));
-}
 
 // Whole chip, one launch per pivot: workgroup (bx, by) owns rows [by*8, by*8+8) x columns [bx*512, +512).
 // Every lane keeps its two pivot-row values in registers, the 8 loads of a lane are issued back to back
@@ -620,6 +665,7 @@ struct Snapshot {
     const double* A;
     const int32_t *vibr, *vibc, *rbv, *cbv;
     int32_t n_idx;
+    const double* oo;  // n_opt * ld
 };
 __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int first_slot) {
     const int slot = first_slot + blockIdx.y;
@@ -655,6 +701,10 @@ __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int fir
     int32_t* rbv = s.rbv + (long long)slot * s.idx_stride;
     int32_t* cbv = s.cbv + (long long)slot * s.idx_stride;
     for (long long i = tid; i < snap.n_idx; i += nt) { rbv[i] = snap.rbv[i]; cbv[i] = snap.cbv[i]; }
+    if (s.n_opt > 0) {  // backup.ts:94-104
+        double* oo = s.oo + (long long)slot * s.oo_stride;
+        for (long long i = tid; i < s.oo_stride; i += nt) oo[i] = snap.oo[i];
+    }
     if (tid == 0) {
         st->H = H;
         st->last_element_index = s.st[0].s_last_element_index;
@@ -672,6 +722,7 @@ struct SnapshotW {
     double* A;
     int32_t *vibr, *vibc, *rbv, *cbv;
     int32_t n_idx;
+    double* oo;
 };
 __global__ void __launch_bounds__(256) k_save(Slots s, SnapshotW snap) {
     DevState* st = s.st;
@@ -684,6 +735,8 @@ __global__ void __launch_bounds__(256) k_save(Slots s, SnapshotW snap) {
     for (long long i = tid; i < H; i += nt) snap.vibr[i] = s.vibr[i];
     for (long long i = tid; i < s.W; i += nt) snap.vibc[i] = s.vibc[i];
     for (long long i = tid; i < snap.n_idx; i += nt) { snap.rbv[i] = s.rbv[i]; snap.cbv[i] = s.cbv[i]; }
+    if (s.n_opt > 0)  // backup.ts:37-43
+        for (long long i = tid; i < s.oo_stride; i += nt) snap.oo[i] = s.oo[i];
     if (tid == 0) {
         st->s_H = H;
         st->s_last_element_index = st->last_element_index;

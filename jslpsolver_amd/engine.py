@@ -16,7 +16,7 @@ class Tableau:
     """
 
     def __init__(self, matrix, var_index_by_row, var_index_by_col, unrestricted=(), precision=1e-8,
-                 row_capacity=None, device=0, lib=None):
+                 row_capacity=None, device=0, lib=None, optional_objectives=None):
         self.lib = lib if lib is not None else _capi.load_hip()
         matrix = _capi.as_f64(matrix)
         if matrix.ndim != 2:
@@ -35,6 +35,14 @@ class Tableau:
         self.lib.check(self.lib.jslp_engine_upload(self._h, _capi.ptr_f64(matrix), _capi.ptr_i32(vibr),
                                                    _capi.ptr_i32(vibc), _capi.ptr_i32(unr), int(unr.shape[0])),
                        "jslp_engine_upload")
+        self.n_optional = 0
+        if optional_objectives is not None and len(optional_objectives) > 0:
+            oo = _capi.as_f64(optional_objectives)
+            if oo.ndim != 2 or oo.shape[1] != self.width:
+                raise ValueError("optional objectives must be n x width")
+            self.lib.check(self.lib.jslp_engine_set_optional_objectives(self._h, int(oo.shape[0]), _capi.ptr_f64(oo)),
+                           "jslp_engine_set_optional_objectives")
+            self.n_optional = int(oo.shape[0])
         # tableau scalars the reference keeps on the Tableau object (tableau.ts:59-61,83-87)
         self.feasible = True
         self.bounded = True
@@ -161,6 +169,14 @@ class Tableau:
         self.lib.check(self.lib.jslp_engine_download(self._h, _capi.ptr_f64(m), _capi.ptr_i32(vibr), _capi.ptr_i32(vibc),
                                                      _capi.ptr_i32(rbv), _capi.ptr_i32(cbv)), "jslp_engine_download")
         return m, vibr, vibc, rbv, cbv
+
+    def optional_objectives(self):
+        """current optionalObjectives[o].reducedCosts rows (n x width)"""
+        rows = np.zeros((max(self.n_optional, 1), self.width), dtype=np.float64)
+        n = _capi.C.c_int32()
+        self.lib.check(self.lib.jslp_engine_get_optional_objectives(self._h, _capi.ptr_f64(rows), _capi.C.byref(n)),
+                       "jslp_engine_get_optional_objectives")
+        return rows[:n.value]
 
     def pivot_trace(self):
         n = _capi.C.c_int64()

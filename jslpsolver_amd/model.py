@@ -5,8 +5,10 @@ Mirrors, for the hot path only, what the reference does between `Solve(json)` an
 `Tableau._resetMatrix` (src/tableau/tableau.ts:319-380: sign conventions).  The order matters for parity:
 it fixes which row/column every first-index tie-break of the pivot rules sees.
 
-Out of scope here (raises UnsupportedModel): soft constraints (`weight`/`priority` => optional objectives,
-SURVEY.md 8f.3), multi-objective `optimize` objects (polyopt), `external` solvers and the presolve pre-pass.
+Soft constraints (`weight` / `priority`) are modelled as the reference does (src/expressions.ts:73-94,186-202):
+one relaxation variable per relaxed bound, whose cost lands in a priority-ordered optional objective row
+(tableau.ts:278-290, 335-338).  Out of scope here (raises UnsupportedModel): multi-objective `optimize` objects
+(polyopt), `external` solvers, MIR cuts and the presolve pre-pass.
 """
 import math
 
@@ -47,8 +49,9 @@ class Model:
             raise UnsupportedModel("external solver delegation is out of scope")
         self.isMinimization = json_model.get("opType") != "max"  # model.ts:279
         self._next_index = 0
+        self.relaxationIndex = 1  # model.ts:69
         self.constraints = []  # dicts: index, isUpperBound, rhs, terms [(var_pos, coefficient)]
-        self.variables = []    # dicts: id, cost, index, isInteger
+        self.variables = []    # dicts: id, cost, index, isInteger, priority
         self.integerVariables = []
         self.unrestricted = []
         cons_min, cons_max = {}, {}
@@ -57,16 +60,22 @@ class Model:
             c = constraints[cid]
             if not isinstance(c, dict):
                 continue
-            if c.get("weight") is not None or c.get("priority") is not None:
-                raise UnsupportedModel("soft constraints (weight/priority) need optional objectives (out of scope)")
+            weight, priority = c.get("weight"), c.get("priority")
+            relaxed = weight is not None or priority is not None  # model.ts:301
             if c.get("equal") is None:
                 if c.get("min") is not None:
                     cons_min[cid] = self._add_constraint(c["min"], False)
+                    if relaxed:
+                        self._relax([cons_min[cid]], weight, priority)
                 if c.get("max") is not None:
                     cons_max[cid] = self._add_constraint(c["max"], True)
+                    if relaxed:
+                        self._relax([cons_max[cid]], weight, priority)
             else:
                 cons_min[cid] = self._add_constraint(c["equal"], False)
                 cons_max[cid] = self._add_constraint(c["equal"], True)
+                if relaxed:  # Equality.relax: ONE variable shared by both bounds (expressions.ts:240-246)
+                    self._relax([cons_min[cid], cons_max[cid]], weight, priority)
 
         # options (model.ts:338-374)
         self.tolerance = json_model.get("tolerance") or 0
@@ -104,7 +113,7 @@ class Model:
             is_binary = _truthy(binaries.get(vid))
             is_integer = _truthy(ints.get(vid)) or is_binary
             pos = len(self.variables)
-            var = {"id": vid, "cost": cost, "index": self._new_index(), "isInteger": is_integer}
+            var = {"id": vid, "cost": cost, "index": self._new_index(), "isInteger": is_integer, "priority": 0}
             self.variables.append(var)
             if is_integer:
                 self.integerVariables.append(var)
@@ -120,6 +129,24 @@ class Model:
                     cons_min[name]["terms"].append((pos, coefficient))
                 if name in cons_max:
                     cons_max[name]["terms"].append((pos, coefficient))
+
+    _PRIORITIES = {"required": 0, "strong": 1, "medium": 2, "weak": 3}
+
+    def _relax(self, constraints, weight, priority):
+        """createRelaxationVariable + Constraint._relax (expressions.ts:73-94, 186-202)"""
+        if priority == 0 or priority == "required":
+            return
+        w = 1 if weight is None else weight
+        p = 1 if priority is None else priority
+        if isinstance(p, str):
+            p = self._PRIORITIES.get(p, 0)  # model.addVariable's string mapping (model.ts:143-160)
+        actual = -w if not self.isMinimization else w
+        pos = len(self.variables)
+        self.variables.append({"id": "r%d" % self.relaxationIndex, "cost": actual, "index": self._new_index(),
+                               "isInteger": False, "priority": p})
+        self.relaxationIndex += 1
+        for c in constraints:
+            c["terms"].append((pos, -1 if c["isUpperBound"] else 1))
 
     def _new_index(self):
         i = self._next_index
@@ -140,7 +167,8 @@ class Model:
         vibc = np.full(W, -1, dtype=np.int32)
         coeff = -1 if self.isMinimization else 1
         for v, var in enumerate(self.variables):
-            matrix[0, v + 1] = float(coeff) * float(var["cost"])
+            if var["priority"] == 0:
+                matrix[0, v + 1] = float(coeff) * float(var["cost"])
             vibc[v + 1] = var["index"]
         for r, c in enumerate(self.constraints, start=1):
             vibr[r] = c["index"]
@@ -153,3 +181,16 @@ class Model:
                     matrix[r, pos + 1] = -float(coefficient)  # -0.0 for a zero coefficient, like JS
                 matrix[r, 0] = -float(c["rhs"])
         return matrix, vibr, vibc
+
+    def optional_objectives(self):
+        """(priorities ascending, rows n x width): Tableau.setOptionalObjective via _resetMatrix (tableau.ts:278-290,335-338)"""
+        coeff = -1 if self.isMinimization else 1
+        by_priority = {}
+        W = len(self.variables) + 1
+        for v, var in enumerate(self.variables):
+            if var["priority"] != 0:
+                row = by_priority.setdefault(var["priority"], np.zeros(W, dtype=np.float64))
+                row[v + 1] = float(coeff) * float(var["cost"])
+        pr = sorted(by_priority)
+        rows = np.stack([by_priority[p] for p in pr]) if pr else np.zeros((0, W), dtype=np.float64)
+        return pr, rows

@@ -35,8 +35,9 @@ def Solve(model, precision=None, full=False, validate=False, lib=None, device=0,
     n_int = len(m.integerVariables)
     # cut rows: at most one "min" and one "max" cut per integer variable (branch-and-cut.ts:166-179)
     extra = 2 * n_int if row_capacity_extra is None else row_capacity_extra
+    _priorities, optional_rows = m.optional_objectives()
     t = Tableau(matrix, vibr, vibc, m.unrestricted, precision=m.precision, row_capacity=matrix.shape[0] + extra,
-                device=device, lib=lib)
+                device=device, lib=lib, optional_objectives=optional_rows)
     iterations = 0
     integral = False
     if n_int > 0:  # tableau.ts:250-258

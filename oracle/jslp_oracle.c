@@ -43,6 +43,11 @@ struct jslp_engine {
     int32_t* trace;
     int64_t n_trace, cap_trace;
     int32_t* nz; /* nonZeroColumns scratch (simplex.ts:328) */
+    /* optionalObjectives[o].reducedCosts (tableau.ts:71), sorted by priority; + their copy in savedState */
+    int32_t n_opt;
+    double* oo;
+    double* s_oo;
+    int32_t* defer; /* optionalCostsColumns scratch (simplex.ts:132-134) */
 };
 
 static __thread char g_err[256];
@@ -97,6 +102,7 @@ void jslp_engine_destroy(jslp_engine* e) {
     free(e->matrix); free(e->s_matrix); free(e->vibr); free(e->s_vibr); free(e->vibc); free(e->s_vibc);
     free(e->rbv); free(e->cbv); free(e->s_rbv); free(e->s_cbv); free(e->unrestricted); free(e->nz);
     free(e->trace);
+    free(e->oo); free(e->s_oo); free(e->defer);
     free(e);
 }
 
@@ -136,6 +142,27 @@ int jslp_engine_upload(jslp_engine* e, const double* matrix, const int32_t* var_
     e->unbounded_var_index = -1;
     e->n_trace = 0;
     e->uploaded = 1;
+    e->n_opt = 0;
+    return JSLP_OK;
+}
+
+int jslp_engine_set_optional_objectives(jslp_engine* e, int32_t n, const double* rows) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "set_optional_objectives before upload");
+    if (n < 0 || (n > 0 && !rows)) return fail(JSLP_ERR_ARG, "set_optional_objectives: bad arguments");
+    free(e->oo); free(e->s_oo); free(e->defer);
+    e->oo = (double*)calloc((size_t)(n > 0 ? n : 1) * e->width, sizeof(double));
+    e->s_oo = (double*)calloc((size_t)(n > 0 ? n : 1) * e->width, sizeof(double));
+    e->defer = (int32_t*)calloc((size_t)e->width * 2, sizeof(int32_t));
+    if (!e->oo || !e->s_oo || !e->defer) return fail(JSLP_ERR_NOMEM, "set_optional_objectives: oom");
+    if (n > 0) memcpy(e->oo, rows, (size_t)n * e->width * sizeof(double));
+    e->n_opt = n;
+    return JSLP_OK;
+}
+
+int jslp_engine_get_optional_objectives(jslp_engine* e, double* rows, int32_t* n_out) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "get_optional_objectives before upload");
+    if (n_out) *n_out = e->n_opt;
+    if (rows && e->n_opt > 0) memcpy(rows, e->oo, (size_t)e->n_opt * e->width * sizeof(double));
     return JSLP_OK;
 }
 
@@ -155,7 +182,7 @@ static void trace_push(jslp_engine* e, int32_t r, int32_t c) {
 /* the reference's zero test `!(v >= -1e-16 && v <= 1e-16)` (simplex.ts:356,372,375,379): NaN counts as non-zero */
 static inline int nonzero16(double v) { return !(v >= -1e-16 && v <= 1e-16); }
 
-/* pivot (simplex.ts:330-413), optional-objective block :394-412 out of scope (no optional objectives) */
+/* pivot (simplex.ts:330-413) */
 static void pivot(jslp_engine* e, int32_t pr, int32_t pc) {
     double* m = e->matrix;
     const int32_t width = e->width, height = e->height;
@@ -201,6 +228,19 @@ static void pivot(jslp_engine* e, int32_t pr, int32_t pc) {
         }
         /* the reference's inner `else if (coefficient !== 0) matrix[...] = 0` (:388-390) is unreachable: it sits
            inside `if (!(pivotColVal tiny))` with coefficient === pivotColVal, so tiny entries stay untouched */
+    }
+    /* optional objectives (:394-412): exact `!== 0` tests instead of the 1e-16 band */
+    for (int32_t o = 0; o < e->n_opt; o++) {
+        double* rc = e->oo + (size_t)o * width;
+        const double coefficient = rc[pc];
+        if (coefficient != 0) {
+            for (int32_t i = 0; i < nnz; i++) {
+                const int32_t c = e->nz[i];
+                const double v0 = m[pro + c];
+                if (v0 != 0) rc[c] = rc[c] - coefficient * v0;
+            }
+            rc[pc] = -coefficient / quotient;
+        }
     }
     trace_push(e, pr, pc);
 }
@@ -311,7 +351,7 @@ static double rounded_evaluation(const jslp_engine* e) {
     return js_round((2.220446049250313e-16 + e->matrix[0]) * rc) / rc;
 }
 
-/* phase2 (simplex.ts:100-325) without optional objectives (nOptionalObjectives == 0) */
+/* phase2 (simplex.ts:100-325) */
 static int32_t phase2(jslp_engine* e, int check_cycles, jslp_simplex_result* res) {
     const double* m = e->matrix;
     const int32_t width = e->width, last_col = e->width - 1, last_row = e->height - 1;
@@ -330,6 +370,8 @@ static int32_t phase2(jslp_engine* e, int check_cycles, jslp_simplex_result* res
         int32_t entering_col = 0; /* :136-219 */
         double entering_value = precision;
         int is_rc_negative = 0;
+        const int32_t n_opt = e->n_opt;
+        int32_t n_defer = 0; /* optionalCostsColumns (:132-134) */
         if (use_partial) {
             const int32_t start_batch = pricing_batch_start;
             int32_t scanned = 0;
@@ -341,6 +383,10 @@ static int32_t phase2(jslp_engine* e, int check_cycles, jslp_simplex_result* res
                 for (int32_t c = bs; c <= be; c++) {
                     const double rc = m[c];
                     const int unrestricted = e->unrestricted[e->vibc[c]];
+                    if (n_opt > 0 && -precision < rc && rc < precision) { /* :155-162 */
+                        e->defer[n_defer++] = c;
+                        continue;
+                    }
                     if (unrestricted && rc < 0) {
                         if (-rc > entering_value) {
                             entering_value = -rc;
@@ -363,6 +409,10 @@ static int32_t phase2(jslp_engine* e, int check_cycles, jslp_simplex_result* res
             for (int32_t c = 1; c <= last_col; c++) {
                 const double rc = m[c];
                 const int unrestricted = e->unrestricted[e->vibc[c]];
+                if (n_opt > 0 && -precision < rc && rc < precision) { /* :195-202 */
+                    e->defer[n_defer++] = c;
+                    continue;
+                }
                 if (unrestricted && rc < 0) {
                     if (-rc > entering_value) {
                         entering_value = -rc;
@@ -376,6 +426,41 @@ static int32_t phase2(jslp_engine* e, int check_cycles, jslp_simplex_result* res
                     entering_col = c;
                     is_rc_negative = 0;
                 }
+            }
+        }
+        if (n_opt > 0) { /* :221-263: break ties on the priority-ordered secondary objectives */
+            int32_t o = 0;
+            int32_t* cur = e->defer;
+            int32_t* nxt = e->defer + e->width;
+            while (entering_col == 0 && n_defer > 0 && o < n_opt) {
+                const double* rcs = e->oo + (size_t)o * width;
+                int32_t n_next = 0;
+                entering_value = precision;
+                for (int32_t i = 0; i < n_defer; i++) {
+                    const int32_t c = cur[i];
+                    const double rc = rcs[c];
+                    const int unrestricted = e->unrestricted[e->vibc[c]];
+                    if (-precision < rc && rc < precision) {
+                        nxt[n_next++] = c;
+                        continue;
+                    }
+                    if (unrestricted && rc < 0) {
+                        if (-rc > entering_value) {
+                            entering_value = -rc;
+                            entering_col = c;
+                            is_rc_negative = 1;
+                        }
+                        continue;
+                    }
+                    if (rc > entering_value) {
+                        entering_value = rc;
+                        entering_col = c;
+                        is_rc_negative = 0;
+                    }
+                }
+                int32_t* t = cur; cur = nxt; nxt = t;
+                n_defer = n_next;
+                o += 1;
             }
         }
         if (entering_col == 0) { /* :265-269 */
@@ -459,6 +544,7 @@ int jslp_engine_save(jslp_engine* e) {
     memcpy(e->s_vibc, e->vibc, (size_t)e->width * sizeof(int32_t));
     memcpy(e->s_rbv, e->rbv, (size_t)e->n_idx_cap * sizeof(int32_t));
     memcpy(e->s_cbv, e->cbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+    if (e->n_opt > 0) memcpy(e->s_oo, e->oo, (size_t)e->n_opt * e->width * sizeof(double)); /* backup.ts:37-43 */
     e->s_height = e->height;
     e->s_last_element_index = e->last_element_index;
     e->has_save = 1;
@@ -478,6 +564,7 @@ int jslp_engine_restore(jslp_engine* e) {
        that keep stale entries there, which nothing reads before addCutConstraints rewrites them */
     memcpy(e->rbv, e->s_rbv, (size_t)e->n_idx_cap * sizeof(int32_t));
     memcpy(e->cbv, e->s_cbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+    if (e->n_opt > 0) memcpy(e->oo, e->s_oo, (size_t)e->n_opt * e->width * sizeof(double)); /* backup.ts:94-104 */
     return JSLP_OK;
 }
 

@@ -1,8 +1,8 @@
 """Pins the C restatement (oracle/jslp_oracle.c) against the reference's own behaviour.
 
 Golden vectors come from the reference itself (type-erased, oracle/_ref) -- see tests/golden/gen_golden.js.
-For every fixture whose model has no optional objectives (soft constraints are outside the built scope,
-SURVEY.md 8f.3) the oracle must reproduce, bit for bit: every pivot (row, col) in order, every simplex
+For every fixture that reaches the hot path (soft-constraint models with their optional objectives included)
+the oracle must reproduce, bit for bit: every pivot (row, col) in order, every simplex
 call's flags / evaluation / RHS column, and the final tableau.
 """
 import numpy as np
@@ -19,8 +19,12 @@ def replay(lib, g):
     assert G.sha_matrix(m) == tab["matrixSha"]
     calls = g["simplexCalls"]
     max_cuts = max([len(c["cuts"] or []) for c in calls] + [0])
+    oo = None
+    if tab["optionalObjectives"]:
+        oo = np.array([[G.num(x) for x in o["reducedCosts"]] + [0.0] * (tab["width"] - len(o["reducedCosts"]))
+                       for o in tab["optionalObjectives"]], dtype=np.float64)
     t = Tableau(m, vibr, vibc, tab["unrestricted"], precision=tab["precision"],
-                row_capacity=tab["height"] + max_cuts, lib=lib)
+                row_capacity=tab["height"] + max_cuts, lib=lib, optional_objectives=oo)
     check = tab["checkForCycles"]
     is_mip = len(tab["integerVarIndexes"]) > 0
     for i, call in enumerate(calls):
@@ -53,14 +57,14 @@ def replay(lib, g):
 
 
 def usable(g):
-    return g["tableau"] is not None and len(g["tableau"]["optionalObjectives"]) == 0 and not g["tableau"]["useMIRCuts"]
+    return g["tableau"] is not None and not g["tableau"]["useMIRCuts"]
 
 
 @pytest.mark.parametrize("path", G.fixture_paths(), ids=G.ident)
 def test_oracle_reproduces_reference_fixture(oracle_lib, path):
     g = G.load(path)
     if not usable(g):
-        pytest.skip("presolve-infeasible or soft-constraint model: no hot-path trace in scope")
+        pytest.skip("presolve-infeasible model: the reference never reached the hot path")
     replay(oracle_lib, g)
 
 
