@@ -114,6 +114,7 @@ static int ensure_slots(jslp_engine* e, int n) {
     s.pcol_stride = e->cap_rows;
     s.hist_cap = n == 1 ? (int32_t)HIST_CAP_MAIN : (int32_t)HIST_CAP_SLOT;
     s.ld = e->ld; s.W = e->W; s.batch = e->batch; s.use_partial = e->use_partial; s.precision = e->precision;
+    s.has_unr = e->n_unr > 0 ? 1 : 0;
     s.unr = e->d_unr;
     HIPC(hipMalloc(&s.A, sizeof(double) * s.A_stride * n));
     HIPC(hipMalloc(&s.vibr, sizeof(int32_t) * (size_t)s.vibr_stride * n));
@@ -282,6 +283,7 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
     e->has_save = 0;
     e->evaluation = 0;
     e->n_unr = n_unrestricted;
+    e->s.has_unr = n_unrestricted > 0 ? 1 : 0;
     if (e->n_opt > 0) {  // a new model: optional objectives are set again by the caller
         hipFree(e->s.oo); hipFree(e->snap_oo);
         e->s.oo = nullptr; e->snap_oo = nullptr; e->s.n_opt = 0; e->s.oo_stride = 0; e->n_opt = 0;
@@ -328,6 +330,7 @@ static Ctx host_ctx(const jslp_engine* e, int check_cycles) {
     c.prow = e->s.prow; c.pcol = e->s.pcol; c.dirty = e->s.dirty; c.oo = e->s.oo; c.n_opt = e->n_opt; c.st = e->s.st; c.hist = e->s.hist; c.hist_cap = e->s.hist_cap;
     c.trace = e->s.trace; c.trace_cap = e->s.trace_cap; c.ld = e->ld; c.W = e->W; c.check_cycles = check_cycles;
     c.batch = e->batch; c.use_partial = e->use_partial; c.precision = e->precision; c.stop_at_phase2 = 0;
+    c.has_unr = e->n_unr > 0 ? 1 : 0;
     return c;
 }
 

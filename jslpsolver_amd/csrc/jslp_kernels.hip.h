@@ -77,6 +77,7 @@ struct Ctx {
     int32_t batch;        // partial-pricing batch size (simplex.ts:118-124)
     int32_t use_partial;  // simplex.ts:127
     int32_t stop_at_phase2;  // hand phase 2 to the fused pipeline instead of continuing here
+    int32_t has_unr;         // any unrestricted variable at all (else the per-column map lookups are skipped)
     double precision;
 };
 
@@ -98,6 +99,7 @@ struct Slots {
     int2* trace;     long long trace_cap;   // only slot 0 traces
     int32_t ld, W;
     int32_t batch, use_partial;
+    int32_t has_unr;
     double precision;
 };
 
@@ -125,6 +127,7 @@ __device__ __forceinline__ Ctx slot_ctx(const Slots& s, int slot, int check_cycl
     c.batch = s.batch;
     c.use_partial = s.use_partial;
     c.stop_at_phase2 = 0;
+    c.has_unr = s.has_unr;
     c.precision = s.precision;
     return c;
 }
@@ -351,7 +354,7 @@ __device__ void select_step(const Ctx& c, Smem& sm) {
             Cand q; q.v = -INFINITY; q.i = 0; q.b = 0;
             for (int col = 1 + tid; col < W; col += nt) {
                 const double coef = row[col];
-                const bool un = c.unr[c.vibc[col]] != 0;
+                const bool un = c.has_unr && c.unr[c.vibc[col]] != 0;
                 if (un || coef < -precision) {
                     const double quo = -A[col] / coef;
                     if (q.v < quo) { q.v = quo; q.i = col; }
@@ -375,7 +378,7 @@ __device__ void select_step(const Ctx& c, Smem& sm) {
         int st_opt_row = -1;  // which optional objective supplied the entering column (-1: the main cost row)
         for (int col = 1 + tid; col < W; col += nt) {
             const double rc = A[col];
-            const bool un = c.unr[c.vibc[col]] != 0;
+            const bool un = c.has_unr && c.unr[c.vibc[col]] != 0;
             const int b = c.use_partial ? (col - 1) / c.batch : 0;
             double val; int ng;
             if (un && rc < 0) { val = -rc; ng = 1; } else { val = rc; ng = 0; }
@@ -405,7 +408,7 @@ __device__ void select_step(const Ctx& c, Smem& sm) {
                 if (!deferred) continue;
                 const double rc = c.oo[(long long)o * ld + col];
                 if (-precision < rc && rc < precision) continue;
-                const bool un = c.unr[c.vibc[col]] != 0;
+                const bool un = c.has_unr && c.unr[c.vibc[col]] != 0;
                 const double val = (un && rc < 0) ? -rc : rc;
                 const bool take = val > x.v;  // strict: first index wins ties inside a thread (ascending columns)
                 x.v = take ? val : x.v;
@@ -423,7 +426,7 @@ __device__ void select_step(const Ctx& c, Smem& sm) {
         // isReducedCostNegative of the winner: recompute (cheap, uniform)
         {
             const double rc = st_opt_row < 0 ? A[pc] : c.oo[(long long)st_opt_row * ld + pc];
-            const bool un = c.unr[c.vibc[pc]] != 0;
+            const bool un = c.has_unr && c.unr[c.vibc[pc]] != 0;
             neg_flag = (un && rc < 0) ? 1 : 0;
         }
         // ratio test (simplex.ts:271-296) in its order-free form: r_deg = first row passing the
@@ -1390,6 +1393,27 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
     long long trace_n = st->trace_n;
     if (status0 != ST_PHASE1_DONE) return;  // not handed over by phase 1: nothing to do (uniform)
 
+#ifdef JSLP_DEBUG_RESIDENT
+    if (f.dbg) {  // micro-costs in this kernel's own geometry
+        u64_t t0 = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 64; i++) __syncthreads();
+        u64_t t1 = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 64; i++) { atomicMin(&sm.p_batch, tid + i); }
+        __syncthreads();
+        u64_t t2 = __builtin_amdgcn_s_memtime();
+        u64_t acc = 0;
+        for (int i = 0; i < 16; i++) { acc += AG_LOAD(f.rowflag[0] + ((acc + i) & 63)); }
+        u64_t t3 = __builtin_amdgcn_s_memtime();
+        double dv = 1.0 + (double)tid;
+        for (int i = 0; i < 16; i++) dv = 3.0 / dv + 1.0;
+        u64_t t4 = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && b == 1) {
+            u64_t* o = f.dbg + (long long)512 * f.G * 2 + 12288 + 64;
+            o[0] = (t1 - t0) / 64; o[1] = (t2 - t1) / 64; o[2] = (t3 - t2) / 16; o[3] = (t4 - t3) / 16; o[4] = acc + (u64_t)dv;
+        }
+        __syncthreads();
+    }
+#endif
     if (tid == 0) reset_reductions(sm);
     __syncthreads();
     double k0 = 0.0;  // reduced cost of the entering column = cost-row entry of column pc

@@ -1,3 +1,9 @@
+"""In-kernel phase timing of k_simplex_resident (s_memtime deltas per pivot phase) and micro-costs in its geometry.
+Needs the debug build of the library:
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DJSLP_DEBUG_RESIDENT \
+        -o /tmp/libjslp_hip_dbg.so jslpsolver_amd/csrc/jslp_hip.hip
+  JSLP_HIP_LIBRARY=/tmp/libjslp_hip_dbg.so python tools/resident_phase_timing.py 2000
+(the debug build dumps its counters to gpurun_out/resident_r0.bin)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,3 +21,5 @@ names = ["A cands", "B row stores", "C sweep/drain/sync", "D decide/poll", "E0 r
 for label, off in (("wg0", 0), ("wg100", 16), ("wgLast", 32)):
     acc = d[off:off + 8].astype(np.float64); ep = float(d[off + 8])
     print(label, "epochs", ep, " ".join("%s=%.0f" % (nm, a / max(ep, 1)) for nm, a in zip(names, acc)), "total cyc/pivot %.0f" % (acc.sum() / max(ep, 1)))
+mc = d[64:69]
+print("micro: syncthreads %d ticks, 1024-way LDS atomicMin %d ticks, dependent agent load %d ticks, dependent f64 div+add %d ticks" % (mc[0], mc[1], mc[2], mc[3]))
