@@ -1263,7 +1263,8 @@ struct ResCtx {
 
 struct RSmem {
     FSmem f;
-    unsigned sweep[JSLP_F_MAXG * JSLP_R_GRAN];  // payloads of every workgroup's granules for the current pivot
+    u64_t w_q[4];        // leader: per sweep wave, bits of its smallest quotient / its row / its first degenerate row
+    int32_t w_r[4], w_rdeg[4];
     // LDS-atomic reductions (a handful of participants each; far cheaper than 12 ds_bpermute stages)
     u64_t p_val;      // pricing: bits of the best value in the winning batch
     int32_t p_batch;  // pricing: first batch holding a candidate
@@ -1278,38 +1279,43 @@ struct RSmem {
     int32_t kind[JSLP_R_ROWS];
 };
 
-// The leader's last EIGHT waves gather every workgroup's granules of this epoch (all-gather with the data as the
-// flag, Guideline 16 R2): lane l of the 512 re-reads granules l, l+512, ... -- all 4 loads in flight per pass --
-// until every tag matches; payloads land in LDS.  Returns false on abort (per wave).
-#define JSLP_SWEEP_LANES 512
-#define JSLP_SWEEP_K ((JSLP_F_MAXG * JSLP_R_GRAN) / JSLP_SWEEP_LANES)
-__device__ __forceinline__ bool sweep_granules(const ResCtx& f, int par, unsigned tag, RSmem& sm, int l) {
-    const int n = f.G * JSLP_R_GRAN;
-    const u64_t* g = f.gran[par];
+// The leader's last FOUR waves gather every workgroup's summary of this epoch (all-gather with the data as the flag,
+// Guideline 16 R2): lane w of the 256 owns workgroup w and re-reads its 7 granules -- all in flight per pass -- until
+// every tag matches, so the complete summary ends up in that lane's registers.  Returns false on abort (per wave).
+#define JSLP_SWEEP_LANES 256
+struct SweptCand {
+    u64_t qbits;   // bits of the smallest accepted quotient (positive doubles order like their bits); ~0 when none
+    double kq, kdeg;
+    int32_t r, rdeg;
+};
+__device__ __forceinline__ bool sweep_summary(const ResCtx& f, int par, unsigned tag, int w, SweptCand& out) {
+    const bool used = w < f.G;
+    const u64_t* g = f.gran[par] + (long long)(used ? w : 0) * JSLP_R_GRAN;
     unsigned spins = 0;
+    u64_t x[JSLP_R_GRAN - 1];
     for (;;) {
-        u64_t x[JSLP_SWEEP_K];
-#pragma unroll
-        for (int k = 0; k < JSLP_SWEEP_K; k++) {
-            const int i = l + JSLP_SWEEP_LANES * k;
-            const bool used = i < n && (i & (JSLP_R_GRAN - 1)) != JSLP_R_GRAN - 1;  // granule 7 of each group is unused
-            x[k] = used ? AG_LOAD(g + i) : ((u64_t)tag << 32);
-        }
         bool ok = true;
 #pragma unroll
-        for (int k = 0; k < JSLP_SWEEP_K; k++) {
-            const int i = l + JSLP_SWEEP_LANES * k;
-            if (i < n) {
-                if ((unsigned)(x[k] >> 32) == tag) sm.sweep[i] = (unsigned)x[k];
-                else ok = false;
-            }
-        }
-        if (__all(ok)) return true;
+        for (int j = 0; j < JSLP_R_GRAN - 1; j++) x[j] = used ? AG_LOAD(g + j) : ((u64_t)tag << 32);
+#pragma unroll
+        for (int j = 0; j < JSLP_R_GRAN - 1; j++) ok = ok && (unsigned)(x[j] >> 32) == tag;
+        if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(1);
         ++spins;
         if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) return false;
-        if (spins > JSLP_SPIN_LIMIT) { if ((l & 63) == 0) AG_STORE(f.abort_flag, 1u); return false; }
+        if (spins > JSLP_SPIN_LIMIT) { if ((w & 63) == 0) AG_STORE(f.abort_flag, 1u); return false; }
     }
+    const u64_t qb = (x[0] & 0xffffffffull) | (x[1] << 32);
+    const u64_t kqb = (x[2] & 0xffffffffull) | (x[3] << 32);
+    const u64_t kdb = (x[4] & 0xffffffffull) | (x[5] << 32);
+    const unsigned rr = (unsigned)x[6];
+    out.r = used ? (int32_t)(rr & 0xffffu) : 0;
+    const unsigned rd = rr >> 16;
+    out.rdeg = (!used || rd == 0xffffu) ? 0x7fffffff : (int32_t)rd;
+    out.qbits = out.r != 0 ? qb : ~0ull;
+    out.kq = __longlong_as_double((long long)kqb);
+    out.kdeg = __longlong_as_double((long long)kdb);
+    return true;
 }
 
 // Pricing (simplex.ts:118-219, no unrestricted variables) of the cost-row pair (columns c0, c0+1) each lane
@@ -1501,8 +1507,10 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
         // ---- C: workgroup 0 is the LEADER: its last four waves gather everybody's tagged summaries (data = flag)
         //         while all other waves, everywhere, drain their row stores -----------------------------------------------
         bool swept = true;
-        if (b == 0 && tid >= JSLP_F_THREADS - JSLP_SWEEP_LANES)
-            swept = sweep_granules(f, par, tag, sm, tid - (JSLP_F_THREADS - JSLP_SWEEP_LANES));
+        SweptCand sc;
+        sc.qbits = ~0ull; sc.kq = 0; sc.kdeg = 0; sc.r = 0; sc.rdeg = 0x7fffffff;
+        const bool sweeper = b == 0 && tid >= JSLP_F_THREADS - JSLP_SWEEP_LANES;
+        if (sweeper) swept = sweep_summary(f, par, tag, tid - (JSLP_F_THREADS - JSLP_SWEEP_LANES), sc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { end_code = 5; break; }
@@ -1512,33 +1520,44 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
         int pr = 0, stop = 0;
         double quot = 0.0;
         if (b == 0) {
-            double cq = 0, ckq = 0, ckdeg = 0;
-            int cr = 0, crdeg = 0x7fffffff;
-            if (tid < f.G) {
-                const unsigned* w = sm.sweep + tid * JSLP_R_GRAN;
-                cq = __longlong_as_double((long long)((u64_t)w[0] | ((u64_t)w[1] << 32)));
-                ckq = __longlong_as_double((long long)((u64_t)w[2] | ((u64_t)w[3] << 32)));
-                ckdeg = __longlong_as_double((long long)((u64_t)w[4] | ((u64_t)w[5] << 32)));
-                cr = (int)(w[6] & 0xffffu);
-                const unsigned rd = w[6] >> 16;
-                crdeg = rd == 0xffffu ? 0x7fffffff : (int)rd;
+            // (min rdeg) else (min q, then min r): each sweep wave reduces its 64 summaries with shuffles on the keys
+            // only, the four wave results meet in LDS, the lane that holds the winner supplies its pivot-column entry
+            if (sweeper) {
+                u64_t q = sc.qbits;
+                int r = sc.r, rdeg = sc.rdeg;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const u64_t q2 = __shfl_xor(q, off, 64);
+                    const int r2 = __shfl_xor(r, off, 64), rd2 = __shfl_xor(rdeg, off, 64);
+                    const bool take = r2 != 0 && (r == 0 || q2 < q || (q2 == q && r2 < r));
+                    q = take ? q2 : q;
+                    r = take ? r2 : r;
+                    rdeg = rd2 < rdeg ? rd2 : rdeg;
+                }
+                if ((tid & 63) == 0) {
+                    const int wv = (tid - (JSLP_F_THREADS - JSLP_SWEEP_LANES)) >> 6;
+                    sm.w_q[wv] = q; sm.w_r[wv] = r; sm.w_rdeg[wv] = rdeg;
+                }
             }
-            // (min rdeg) else (min q, then min r): accepted quotients are > precision > 0, so they order like their bits
-            const u64_t qbits = (u64_t)__double_as_longlong(cq);
-            if (crdeg != 0x7fffffff) atomicMin(&sm.l_rdeg, crdeg);
-            if (cr != 0) atomicMin(&sm.l_q, qbits);
             __syncthreads();
-            const int wrdeg = sm.l_rdeg;
-            const u64_t wq = sm.l_q;
-            if (wrdeg == 0x7fffffff && cr != 0 && qbits == wq) atomicMin(&sm.l_r, cr);
-            __syncthreads();
-            const int wr = sm.l_r;
-            if (wrdeg != 0x7fffffff) { if (crdeg == wrdeg) sm.l_k = ckdeg; }
-            else if (wr != 0x7fffffff && cr == wr && qbits == wq) sm.l_k = ckq;
-            __syncthreads();
-            if (wrdeg != 0x7fffffff) { pr = wrdeg; quot = sm.l_k; }
-            else if (wr != 0x7fffffff) { pr = wr; quot = sm.l_k; }
+            u64_t wq = ~0ull;
+            int wr = 0, wrdeg = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u64_t q2 = sm.w_q[i];
+                const int r2 = sm.w_r[i], rd2 = sm.w_rdeg[i];
+                const bool take = r2 != 0 && (wr == 0 || q2 < wq || (q2 == wq && r2 < wr));
+                wq = take ? q2 : wq;
+                wr = take ? r2 : wr;
+                wrdeg = rd2 < wrdeg ? rd2 : wrdeg;
+            }
+            if (wrdeg != 0x7fffffff) pr = wrdeg;
+            else if (wr != 0) pr = wr;
             else stop = 3;  // unbounded (simplex.ts:298-303)
+            if (!stop && sweeper && tid - (JSLP_F_THREADS - JSLP_SWEEP_LANES) == pr / f.rpb)
+                sm.l_k = wrdeg != 0x7fffffff ? sc.kdeg : sc.kq;  // the owner of row pr published both entries
+            __syncthreads();
+            quot = stop ? 0.0 : sm.l_k;
             if (!stop && c.check_cycles) {  // simplex.ts:305-320, before anything is committed
                 if (hist_n >= c.hist_cap) {
                     stop = 2;
