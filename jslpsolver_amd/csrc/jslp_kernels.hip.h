@@ -1322,12 +1322,11 @@ __device__ __forceinline__ bool sweep_summary(const ResCtx& f, int par, unsigned
 // holds, reduced with three LDS atomics: first batch holding a candidate, best value in it, first column with
 // that value.  Positive doubles order like their bit patterns.  Returns the column (0 = none) and its value.
 // `sm.p_*` must have been reset (p_batch = INT_MAX, p_val = 0, p_col = INT_MAX) before a preceding barrier.
-__device__ __forceinline__ int price_row_lds(double x0, double x1, int c0, const Ctx& c, RSmem& sm, double* value) {
+__device__ __forceinline__ int price_row_lds(double x0, double x1, int c0, int b0, int b1, const Ctx& c, RSmem& sm,
+                                             double* value) {
     const int col1 = c0 + 1;
     const bool ok0 = c0 >= 1 && c0 < c.W && x0 > c.precision;
     const bool ok1 = col1 < c.W && x1 > c.precision;
-    const int b0 = c.use_partial ? (c0 - 1) / c.batch : 0;
-    const int b1 = c.use_partial ? (col1 - 1) / c.batch : 0;
     double bv = c.precision;
     int bi = 0, bb = 0;
     if (ok0) { bv = x0; bi = c0; bb = b0; }
@@ -1422,8 +1421,11 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
 #endif
     if (tid == 0) reset_reductions(sm);
     __syncthreads();
+    // pricing batch of my two columns (simplex.ts:118-127): fixed for the whole solve
+    const int pb0 = c.use_partial && c0 >= 1 ? (c0 - 1) / c.batch : 0;
+    const int pb1 = c.use_partial ? c0 / c.batch : 0;
     double k0 = 0.0;  // reduced cost of the entering column = cost-row entry of column pc
-    int pc = price_row_lds(r0.x, r0.y, c0, c, sm, &k0);
+    int pc = price_row_lds(r0.x, r0.y, c0, pb0, pb1, c, sm, &k0);
     int end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted hand-off, 6 history full
     int unbounded_col = 0;
     unsigned epoch = 0;
@@ -1688,7 +1690,7 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
         epoch += 1;
         RT_MARK(6);
         // ---- G: price the new cost row -> entering column of the next pivot ----------------------------------------------
-        pc = price_row_lds(r0.x, r0.y, c0, c, sm, &k0);
+        pc = price_row_lds(r0.x, r0.y, c0, pb0, pb1, c, sm, &k0);
         if (pc == 0) end_code = 1;
     }
 
