@@ -137,6 +137,16 @@ int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
                             jslp_simplex_result* out, double* rhs, int32_t* var_index_by_row,
                             int32_t out_stride);
 
+/*
+ * Zero-copy variant: the outcomes stay in the engine's own pinned read-back buffer.  On return *rhs / *var_index_by_row
+ * point at n_nodes x *out_stride arrays (row i = node i, first out[i].height entries valid) that remain valid until
+ * the next call on this engine; pass NULL for what is not needed (less PCIe traffic).  Same semantics otherwise.
+ */
+int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                   const int32_t* var_index, const double* value, int check_cycles,
+                                   jslp_simplex_result* out, const double** rhs, const int32_t** var_index_by_row,
+                                   int32_t* out_stride);
+
 /* Current dimensions (height grows with cuts, restore() puts it back). */
 int jslp_engine_dims(const jslp_engine* e, int32_t* height, int32_t* width, int32_t* n_var_indexes);
 

@@ -440,7 +440,7 @@ static int fill_result(jslp_engine* e, const DevState& st, int slot, double prev
     }
     out->evaluation = ev;
     if (evaluation_out) *evaluation_out = ev;
-    if (st.cycle_phase) {
+    if (st.cycle_phase && st.hist_n > 0) {
         std::vector<int2> h(st.hist_n);
         if (hipMemcpy(h.data(), e->s.hist + (size_t)slot * e->s.hist_cap, sizeof(int2) * st.hist_n, hipMemcpyDeviceToHost) != hipSuccess)
             return fail(JSLP_ERR_DEVICE, "cycle history read-back failed");
@@ -781,13 +781,17 @@ extern "C" int jslp_engine_read_rhs(jslp_engine* e, double* rhs, int32_t* var_in
     return JSLP_OK;
 }
 
-extern "C" int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
-                                       const int32_t* var_index, const double* value, int check_cycles,
-                                       jslp_simplex_result* out, double* rhs, int32_t* var_index_by_row,
-                                       int32_t out_stride) {
+// Shared body of relax_batch / relax_batch_pinned.  Per-node-workgroup path: all groups are enqueued back to back,
+// their outcomes accumulate in ONE device buffer laid out for all n_nodes, one copy and one synchronisation end the
+// call.  `pinned` != 0: the caller reads the pinned buffer itself (no second host copy).
+static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                            const int32_t* var_index, const double* value, int check_cycles, jslp_simplex_result* out,
+                            double* rhs, int32_t* var_index_by_row, int32_t out_stride, int pinned, int want_rhs,
+                            int want_rows) {
     if (!e || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "relax_batch: null pointer");
     if (!e->uploaded) return fail(JSLP_ERR_STATE, "relax before upload");
-    if ((rhs || var_index_by_row) && out_stride < e->cap_rows) return fail(JSLP_ERR_ARG, "relax_batch: out_stride < row capacity");
+    if (!pinned && (rhs || var_index_by_row) && out_stride < e->cap_rows)
+        return fail(JSLP_ERR_ARG, "relax_batch: out_stride < row capacity");
     if (n_nodes == 0) return JSLP_OK;
     if (n_nodes > 1 && !e->has_save) return fail(JSLP_ERR_STATE, "relax_batch: several nodes need a saved root (save() first)");
     HIPC(hipSetDevice(e->device));
@@ -810,8 +814,9 @@ extern "C" int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const in
         rc = ensure_slots(e, group);
         if (rc) return rc;
     }
-    rc = ensure_out(e, (size_t)group);
+    rc = ensure_out(e, (size_t)n_nodes);  // laid out for ALL nodes: [states | rhs | rows]
     if (rc) return rc;
+    if (e->timing) HIPC(hipEventRecord(e->ev_begin, s));
     for (int first = 0; first < n_nodes; first += group) {
         const int g = std::min(group, n_nodes - first);
         rc = enqueue_restore(e, 0, g);
@@ -819,10 +824,8 @@ extern "C" int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const in
         hipLaunchKernelGGL(k_add_cuts, dim3(g), dim3(256), 0, s, e->s, cu, 0, first, (int)e->cap_rows);
         HIPC(hipGetLastError());
         if (wg) {
-            if (e->timing) HIPC(hipEventRecord(e->ev_begin, s));
             hipLaunchKernelGGL(k_simplex_wg, dim3(g), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
             HIPC(hipGetLastError());
-            if (e->timing) HIPC(hipEventRecord(e->ev_end, s));
         } else {
             // big tableau: the chip-wide kernels on slot 0 (g == 1)
             HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
@@ -832,33 +835,61 @@ extern "C" int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const in
             rc = run_simplex(e, check_cycles);
             if (rc) return rc;
         }
-        out_layout(e, (size_t)g);
-        hipLaunchKernelGGL(k_gather, dim3(g), dim3(256), 0, s, e->s, 0, rhs ? e->d_rhs : nullptr,
-                           var_index_by_row ? e->d_rows : nullptr, e->d_states, (int)e->cap_rows, 0);
+        hipLaunchKernelGGL(k_gather, dim3(g), dim3(256), 0, s, e->s, 0, want_rhs ? e->d_rhs : nullptr,
+                           want_rows ? e->d_rows : nullptr, e->d_states, (int)e->cap_rows, first);
         HIPC(hipGetLastError());
-        // states come first in the buffer: copy only as far as the caller needs
-        const size_t need = var_index_by_row ? out_bytes(e, (size_t)g)
-                                             : (rhs ? (size_t)g * (sizeof(DevState) + (size_t)e->cap_rows * 8) : (size_t)g * sizeof(DevState));
-        HIPC(hipMemcpyAsync(e->h_out, e->d_out, need, hipMemcpyDeviceToHost, s));
-        HIPC(hipStreamSynchronize(s));
-        if (wg && e->timing) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, e->ev_begin, e->ev_end) == hipSuccess) e->total_ms += ms;
+    }
+    if (e->timing && wg) HIPC(hipEventRecord(e->ev_end, s));
+    // states come first in the buffer: copy only as far as the caller needs
+    const size_t need = want_rows ? out_bytes(e, (size_t)n_nodes)
+                                  : (want_rhs ? (size_t)n_nodes * (sizeof(DevState) + (size_t)e->cap_rows * 8) : (size_t)n_nodes * sizeof(DevState));
+    HIPC(hipMemcpyAsync(e->h_out, e->d_out, need, hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    if (wg && e->timing) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e->ev_begin, e->ev_end) == hipSuccess) e->total_ms += ms;
+    }
+    for (int i = 0; i < n_nodes; i++) {
+        DevState st = e->h_states[i];
+        rc = state_error(st);
+        if (rc) return rc;
+        if (st.cycle_phase && wg && n_nodes > group) {
+            // the cycle message is rebuilt from the slot's history, which later groups have reused: report the hit
+            // (flags are exact) without the [start, length] detail
+            st.hist_n = 0;
         }
-        for (int j = 0; j < g; j++) {
-            const int i = first + j;
-            const DevState& st = e->h_states[j];
-            rc = state_error(st);
-            if (rc) return rc;
-            double ev;
-            rc = fill_result(e, st, j, prev_eval, &out[i], &ev);
-            if (rc) return rc;
-            if (i == n_nodes - 1) e->evaluation = ev;
-            if (rhs) memcpy(rhs + (size_t)i * out_stride, e->h_rhs + (size_t)j * e->cap_rows, sizeof(double) * st.H);
+        double ev;
+        rc = fill_result(e, st, wg ? i % group : 0, prev_eval, &out[i], &ev);
+        if (rc) return rc;
+        if (i == n_nodes - 1) e->evaluation = ev;
+        if (!pinned) {
+            if (rhs) memcpy(rhs + (size_t)i * out_stride, e->h_rhs + (size_t)i * e->cap_rows, sizeof(double) * st.H);
             if (var_index_by_row)
-                memcpy(var_index_by_row + (size_t)i * out_stride, e->h_rows + (size_t)j * e->cap_rows, sizeof(int32_t) * st.H);
+                memcpy(var_index_by_row + (size_t)i * out_stride, e->h_rows + (size_t)i * e->cap_rows, sizeof(int32_t) * st.H);
         }
     }
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                       const int32_t* var_index, const double* value, int check_cycles,
+                                       jslp_simplex_result* out, double* rhs, int32_t* var_index_by_row,
+                                       int32_t out_stride) {
+    return relax_batch_impl(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, rhs, var_index_by_row,
+                            out_stride, 0, rhs != nullptr, var_index_by_row != nullptr);
+}
+
+extern "C" int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets,
+                                              const int8_t* type, const int32_t* var_index, const double* value,
+                                              int check_cycles, jslp_simplex_result* out, const double** rhs,
+                                              const int32_t** var_index_by_row, int32_t* out_stride) {
+    if (!e) return fail(JSLP_ERR_ARG, "relax_batch_pinned: null engine");
+    int rc = relax_batch_impl(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, nullptr, nullptr, 0, 1,
+                              rhs != nullptr, var_index_by_row != nullptr);
+    if (rc) return rc;
+    if (rhs) *rhs = n_nodes > 0 ? e->h_rhs : nullptr;
+    if (var_index_by_row) *var_index_by_row = n_nodes > 0 ? e->h_rows : nullptr;
+    if (out_stride) *out_stride = e->cap_rows;
     return JSLP_OK;
 }
 

@@ -127,8 +127,8 @@ class Tableau:
         self._absorb(res)
         return res, rhs[:res.height], vibr[:res.height]
 
-    def applyCutsBatch(self, cut_lists, check_cycles=True):
-        """Independent branch-and-bound nodes in one call (jslp_engine_relax_batch)."""
+    def pack_cut_lists(self, cut_lists):
+        """cut lists -> the flat arrays jslp_engine_relax_batch takes (do this once when the same nodes are re-evaluated)"""
         n_nodes = len(cut_lists)
         offs = np.zeros(n_nodes + 1, dtype=np.int32)
         flat = []
@@ -136,15 +136,33 @@ class Tableau:
             flat.extend(cuts)
             offs[i + 1] = len(flat)
         _, t, v, x = self._pack_cuts(flat)
+        return n_nodes, offs, t, v, x
+
+    def applyCutsBatch(self, cut_lists, check_cycles=True, packed=None, want_rows=True, copy=True):
+        """Independent branch-and-bound nodes in one call.  copy=False returns views of the engine's pinned read-back
+        buffer (jslp_engine_relax_batch_pinned): valid until the next call on this tableau."""
+        n_nodes, offs, t, v, x = packed if packed is not None else self.pack_cut_lists(cut_lists)
         out = (SimplexResult * max(n_nodes, 1))()
         stride = self.row_capacity
-        rhs = np.empty((max(n_nodes, 1), stride), dtype=np.float64)
-        vibr = np.empty((max(n_nodes, 1), stride), dtype=np.int32)
-        self.lib.check(self.lib.jslp_engine_relax_batch(self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t),
-                                                        _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)),
-                                                        out, _capi.ptr_f64(rhs), _capi.ptr_i32(vibr), stride),
-                       "jslp_engine_relax_batch")
-        return [out[i] for i in range(n_nodes)], rhs, vibr
+        if copy:
+            rhs = np.empty((max(n_nodes, 1), stride), dtype=np.float64)
+            vibr = np.empty((max(n_nodes, 1), stride), dtype=np.int32) if want_rows else None
+            self.lib.check(self.lib.jslp_engine_relax_batch(self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t),
+                                                            _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)),
+                                                            out, _capi.ptr_f64(rhs), _capi.ptr_i32(vibr), stride),
+                           "jslp_engine_relax_batch")
+            return [out[i] for i in range(n_nodes)], rhs, vibr
+        p_rhs = _capi._f64p()
+        p_rows = _capi._i32p()
+        c_stride = _capi.C.c_int32()
+        self.lib.check(self.lib.jslp_engine_relax_batch_pinned(
+            self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x),
+            int(bool(check_cycles)), out, _capi.C.byref(p_rhs), _capi.C.byref(p_rows) if want_rows else None,
+            _capi.C.byref(c_stride)), "jslp_engine_relax_batch_pinned")
+        shape = (max(n_nodes, 1), c_stride.value)
+        rhs = np.ctypeslib.as_array(p_rhs, shape=shape)
+        vibr = np.ctypeslib.as_array(p_rows, shape=shape) if want_rows else None
+        return out, rhs, vibr
 
     # ---- read-back --------------------------------------------------------------------------------
     def read_rhs(self):

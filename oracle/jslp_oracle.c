@@ -644,6 +644,30 @@ int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     return JSLP_OK;
 }
 
+/* zero-copy variant of the ABI: here simply backed by heap buffers owned by the engine */
+int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                   const int32_t* var_index, const double* value, int check_cycles,
+                                   jslp_simplex_result* out, const double** rhs, const int32_t** var_index_by_row,
+                                   int32_t* out_stride) {
+    if (!e) return fail(JSLP_ERR_ARG, "relax_batch_pinned: null");
+    static __thread double* b_rhs = 0;
+    static __thread int32_t* b_rows = 0;
+    static __thread size_t b_cap = 0;
+    const size_t need = (size_t)(n_nodes > 0 ? n_nodes : 1) * e->cap_rows;
+    if (need > b_cap) {
+        b_rhs = (double*)realloc(b_rhs, need * sizeof(double));
+        b_rows = (int32_t*)realloc(b_rows, need * sizeof(int32_t));
+        b_cap = need;
+    }
+    int rc = jslp_engine_relax_batch(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, b_rhs, b_rows,
+                                     e->cap_rows);
+    if (rc) return rc;
+    if (rhs) *rhs = b_rhs;
+    if (var_index_by_row) *var_index_by_row = b_rows;
+    if (out_stride) *out_stride = e->cap_rows;
+    return JSLP_OK;
+}
+
 int jslp_engine_dims(const jslp_engine* e, int32_t* height, int32_t* width, int32_t* n_var_indexes) {
     if (!e) return fail(JSLP_ERR_ARG, "dims: null");
     if (height) *height = e->height;

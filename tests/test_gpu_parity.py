@@ -159,6 +159,13 @@ def test_relax_batch_equals_sequential_relax(hip_lib, oracle_lib):
     t.save()
     nodes = [c["cuts"] or [] for c in calls[1:]]
     results, rhs, rows = t.applyCutsBatch(nodes * 3, check_cycles=True)
+    # the zero-copy variant (views of the pinned read-back buffer), 5 groups of up to 512 nodes in one call
+    packed = t.pack_cut_lists(nodes * 15)
+    res_p, rhs_p, rows_p = t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+    for j in range(len(nodes) * 15):
+        call = calls[1 + j % len(nodes)]
+        assert bool(res_p[j].feasible) == call["feasible"] and res_p[j].height == call["height"]
+        assert G.sha_rhs(rhs_p[j, :res_p[j].height], rows_p[j, :res_p[j].height]) == call["rhsSha"]
     for rep in range(3):
         for i, call in enumerate(calls[1:]):
             j = rep * len(nodes) + i

@@ -36,3 +36,28 @@ def test_speculation_gives_the_sequential_result(oracle_lib, path, spec):
     assert par["matrix"].tobytes() == seq["matrix"].tobytes()
     ref = {k: (G.num(v) if not isinstance(v, bool) else v) for k, v in g["result"].items()}
     assert par["result"] == ref
+
+
+def test_pinned_batch_view_equals_copying_batch(oracle_lib):
+    """jslp_engine_relax_batch_pinned (views of the engine's read-back buffer) == jslp_engine_relax_batch"""
+    import os
+    import numpy as np
+    from jslpsolver_amd.engine import Tableau
+    g = G.load(os.path.join(G.GOLDEN, "fixtures", "Knapsack_1.json.gz"))
+    tab = g["tableau"]
+    m, vibr, vibc = G.dense_tableau(tab)
+    calls = g["simplexCalls"]
+    t = Tableau(m, vibr, vibc, tab["unrestricted"], precision=tab["precision"],
+                row_capacity=tab["height"] + max(len(c["cuts"] or []) for c in calls), lib=oracle_lib)
+    t.applyCuts([], check_cycles=True)
+    t.save()
+    nodes = [c["cuts"] or [] for c in calls[1:40]]
+    res_a, rhs_a, rows_a = t.applyCutsBatch(nodes)
+    packed = t.pack_cut_lists(nodes)
+    res_b, rhs_b, rows_b = t.applyCutsBatch(None, packed=packed, copy=False)
+    for i in range(len(nodes)):
+        h = res_a[i].height
+        assert res_a[i].as_dict() == res_b[i].as_dict()
+        assert np.array_equal(rhs_a[i, :h].view(np.uint64), rhs_b[i, :h].view(np.uint64))
+        assert np.array_equal(rows_a[i, :h], rows_b[i, :h])
+    t.close()
