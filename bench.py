@@ -149,7 +149,8 @@ def main():
         achieved = bytes_per_launch / avg_s if launches else 0.0
         # the register-resident kernel runs ALL pivots of phase 2 in one launch; its unit of work stays one pivot
         # (16*H*W algorithmic bytes), so "launch" below means "pivot" for it
-        kernel_name = "k_simplex_resident" if launches == pivots_per_solve and os.environ.get("JSLP_FORCE_PATH", "") not in ("fused", "sp", "wg") and not os.environ.get("JSLP_NO_RESIDENT") else "k_pivot_fused"
+        kernel_name = {"resident": "k_simplex_resident", "fused": "k_pivot_fused", "select+update": "k_update",
+                       "workgroup": "k_simplex_wg"}.get(t.last_path(), t.last_path())
         traffic, traffic_note = pmc_traffic(H, W, kernel_name)
         roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_note,

@@ -169,6 +169,13 @@ int jslp_engine_download(jslp_engine* e, double* matrix, int32_t* var_index_by_r
 int jslp_engine_pivot_trace(jslp_engine* e, int32_t* row_col, int64_t max_pairs, int64_t* n_pivots);
 
 /*
+ * Which launch shape the last simplex() / relax() used: "workgroup" (one workgroup per tableau), "select+update"
+ * (two chip-wide launches per pivot), "fused" (one launch per phase-2 pivot) or "resident" (register-resident
+ * phase 2 in one cooperative launch); "oracle" for the test library, "none" before the first solve.
+ */
+const char* jslp_engine_last_path(const jslp_engine* e);
+
+/*
  * Measurement hooks (bench.py): device time in milliseconds and launch count of the dominant kernel
  * (the row-update stream of pivot()) accumulated since the last reset, measured with HIP events on the
  * engine's own stream.  Timing is off by default (it adds an event pair per launch).

@@ -70,6 +70,7 @@ SYMBOLS = {
     "jslp_engine_read_rhs": (C.c_int, [C.c_void_p, _f64p, _i32p]),
     "jslp_engine_download": (C.c_int, [C.c_void_p, _f64p, _i32p, _i32p, _i32p, _i32p]),
     "jslp_engine_pivot_trace": (C.c_int, [C.c_void_p, _i32p, C.c_int64, _P(C.c_int64)]),
+    "jslp_engine_last_path": (C.c_char_p, [C.c_void_p]),
     "jslp_engine_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "jslp_engine_get_timing": (C.c_int, [C.c_void_p, _f64p, _P(C.c_int64), _f64p]),
 }

@@ -68,6 +68,7 @@ struct jslp_engine {
     u64_t* r_gran = nullptr;  // [2][G][8] granules then [2][G] row flags (one allocation, zeroed per launch)
     u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr;
     int no_resident = 0;
+    const char* last_path = "none";
     // timing
     int timing = 0;
     double upd_ms = 0, total_ms = 0;
@@ -464,6 +465,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
     const int cap = iters_cap(e);
     HIPC(hipEventRecord(e->ev_begin, s));
     if (use_wg_single(e)) {
+        e->last_path = "workgroup";
         hipLaunchKernelGGL(k_simplex_wg, dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
         HIPC(hipGetLastError());
         HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
@@ -472,6 +474,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
     } else {
         Ctx c = host_ctx(e, check_cycles);
         const bool fused = fused_eligible(e);
+        e->last_path = "select+update";
         c.stop_at_phase2 = fused ? 1 : 0;
         // height is fixed during a simplex call; read it once
         HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
@@ -551,6 +554,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                     e->upd_launches += e->h_state->it2 - it2_before;  // unit = one pivot (16*H*W algorithmic bytes)
                 }
                 resident_done = true;
+                e->last_path = "resident";
 #ifdef JSLP_DEBUG_RESIDENT
                 {
                     std::vector<u64_t> h((size_t)512 * rc.G * 2);
@@ -588,6 +592,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
         if (!resident_done && e->h_state->status == ST_PHASE1_DONE) {
             int r = ensure_fused(e);
             if (r) return r;
+            e->last_path = "fused";
             FusedCtx f;
             f.c = c;
             f.buf[0] = e->s.A; f.buf[1] = e->f_buf1;
@@ -824,6 +829,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         hipLaunchKernelGGL(k_add_cuts, dim3(g), dim3(256), 0, s, e->s, cu, 0, first, (int)e->cap_rows);
         HIPC(hipGetLastError());
         if (wg) {
+            e->last_path = "workgroup";
             hipLaunchKernelGGL(k_simplex_wg, dim3(g), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
             HIPC(hipGetLastError());
         } else {
@@ -947,6 +953,8 @@ extern "C" int jslp_engine_pivot_trace(jslp_engine* e, int32_t* row_col, int64_t
     }
     return JSLP_OK;
 }
+
+extern "C" const char* jslp_engine_last_path(const jslp_engine* e) { return e ? e->last_path : "none"; }
 
 extern "C" int jslp_engine_set_timing(jslp_engine* e, int enabled) {
     if (!e) return fail(JSLP_ERR_ARG, "set_timing: null engine");

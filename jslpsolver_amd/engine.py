@@ -204,6 +204,9 @@ class Tableau:
                        "jslp_engine_pivot_trace")
         return buf[:2 * n.value].reshape(-1, 2)
 
+    def last_path(self):
+        return self.lib.jslp_engine_last_path(self._h).decode()
+
     def set_timing(self, enabled):
         self.lib.check(self.lib.jslp_engine_set_timing(self._h, int(bool(enabled))), "jslp_engine_set_timing")
 

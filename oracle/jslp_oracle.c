@@ -697,6 +697,8 @@ int jslp_engine_pivot_trace(jslp_engine* e, int32_t* row_col, int64_t max_pairs,
     return JSLP_OK;
 }
 
+const char* jslp_engine_last_path(const jslp_engine* e) { (void)e; return "oracle"; }
+
 int jslp_engine_set_timing(jslp_engine* e, int enabled) { (void)e; (void)enabled; return JSLP_OK; }
 int jslp_engine_get_timing(jslp_engine* e, double* update_kernel_ms, int64_t* update_kernel_launches,
                            double* total_device_ms) {

@@ -102,6 +102,28 @@ def test_hip_equals_oracle_on_edge_shapes(hip_lib, oracle_lib, mode, name, A):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["auto", "fused", "sp"])
+@pytest.mark.parametrize("shape", [(3000, 40), (30, 2500), (2300, 300)])
+def test_hip_equals_oracle_beyond_the_register_resident_sizes(hip_lib, oracle_lib, mode, shape):
+    """taller than 8 x 256 rows (several row groups per workgroup in the fused kernel, not register-resident) and
+    wider than 2048 columns (falls back to select + update)"""
+    m, n = shape
+    rng = np.random.default_rng(m * 7 + n)
+    A = np.zeros((m + 1, n + 1))
+    A[1:, 1:] = rng.integers(1, 9, (m, n)) * (rng.random((m, n)) < 0.6)
+    A[0, 1:] = rng.integers(1, 30, n)
+    A[1:, 0] = rng.integers(50, 400, m)
+    if mode == "auto":
+        os.environ.pop("JSLP_FORCE_PATH", None)
+    else:
+        os.environ["JSLP_FORCE_PATH"] = mode
+    try:
+        _same(_run(hip_lib, A), _run(oracle_lib, A))
+    finally:
+        os.environ.pop("JSLP_FORCE_PATH", None)
+
+
+@pytest.mark.gpu
 def test_hip_argument_and_capacity_errors(hip_lib):
     A = np.array([[0.0, 3.0, 2.0], [4.0, 1.0, 1.0], [6.0, 1.0, 3.0]])
     vibr, vibc = _maps(2, 2)

@@ -83,7 +83,7 @@ def _dense_case(lib, kind, n, check_cycles):
         m, vibr, vibc, _ = generators.dense_random_lp_tableau(12345, n, n)
     t = Tableau(m, vibr, vibc, lib=lib)
     res = t.simplex(check_cycles=check_cycles)
-    out = dict(feasible=bool(res.feasible), bounded=bool(res.bounded), p1=res.pivots_phase1, p2=res.pivots_phase2,
+    out = dict(path=t.last_path(), feasible=bool(res.feasible), bounded=bool(res.bounded), p1=res.pivots_phase1, p2=res.pivots_phase2,
                evaluation=t.evaluation, digest=pivot_digest(t.pivot_trace()), n=len(t.pivot_trace()),
                matrix=t.download()[0])
     t.close()
@@ -110,6 +110,8 @@ def test_config3_full_size_against_reference_golden(hip_lib):
     for kind, name in (("ra", "generateResourceAllocation"), ("lp", "generateRandomLP")):
         g = G.load(os.path.join(G.GOLDEN, "synthetic", name + "_2000x2000_seed12345.json.gz"))
         out = _dense_case(hip_lib, kind, 2000, check_cycles=False)
+        # 3a is all phase 2 -> register-resident kernel; 3b never leaves phase 1 -> select + update
+        assert out["path"] == ("resident" if kind == "ra" else "select+update")
         assert out["n"] == g["nPivots"]
         assert out["digest"] == g["pivotDigest"]
         assert G.sha_matrix(out["matrix"]) == g["final"]["matrixSha"]
