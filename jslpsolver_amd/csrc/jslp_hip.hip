@@ -38,9 +38,13 @@ struct jslp_engine {
     int32_t batch = 50, use_partial = 0;
     int uploaded = 0, has_save = 0;
     double evaluation = 0;
-    // slots (slot 0 = the live tableau)
+    // slots (slot 0 = the live tableau).  All per-slot arrays live in ONE device allocation (slot_arena), the
+    // snapshot / flags / trace in another (static_arena): hipMalloc / hipFree cost ~0.1 ms apiece, and a Solve of a
+    // small model creates and destroys an engine
     int n_slots = 0;
     Slots s{};
+    char* slot_arena = nullptr;
+    char* static_arena = nullptr;
     // snapshot
     double* snap_A = nullptr;
     int32_t *snap_vibr = nullptr, *snap_vibc = nullptr, *snap_rbv = nullptr, *snap_cbv = nullptr;
@@ -82,7 +86,7 @@ static const long long WG_CELLS_BATCH = 4LL * 1024 * 1024;  // batches use one w
 static const long long WG_CELLS_CHILD = 1536LL * 1024;      // a single B&B child (few repair pivots) stays in one workgroup up to this
 static const size_t HIST_CAP_MAIN = 1u << 20;
 static const size_t HIST_CAP_SLOT = 1u << 16;
-static const long long TRACE_CAP = 1LL << 22;
+static const long long TRACE_CAP = 1LL << 20;
 
 extern "C" const char* jslp_backend_name(void) { return "hip-gfx950"; }
 extern "C" const char* jslp_last_error(void) { return g_err; }
@@ -94,18 +98,45 @@ extern "C" int jslp_device_count(void) {
 
 static int32_t round_up(int32_t x, int32_t m) { return (x + m - 1) / m * m; }
 
+struct Carver {  // hands out 256-byte aligned pieces of one allocation; first pass (base == nullptr) just sizes it
+    char* base;
+    size_t off;
+    template <class T>
+    T* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += sizeof(T) * count;
+        return p;
+    }
+};
+
 static void free_slots(jslp_engine* e) {
-    hipFree(e->s.A); hipFree(e->s.vibr); hipFree(e->s.vibc); hipFree(e->s.rbv); hipFree(e->s.cbv);
-    hipFree(e->s.prow); hipFree(e->s.pcol); hipFree(e->s.st); hipFree(e->s.hist); hipFree(e->s.dirty); hipFree(e->s.oo);
+    hipFree(e->slot_arena);
+    hipFree(e->s.oo);
+    e->slot_arena = nullptr;
     e->s.dirty = nullptr; e->s.oo = nullptr;
     e->s.A = nullptr; e->s.vibr = e->s.vibc = e->s.rbv = e->s.cbv = nullptr;
     e->s.prow = e->s.pcol = nullptr; e->s.st = nullptr; e->s.hist = nullptr;
+}
+
+static void carve_slots(Slots& s, Carver& cv, int n) {
+    s.A = cv.take<double>((size_t)s.A_stride * n);
+    s.vibr = cv.take<int32_t>((size_t)s.vibr_stride * n);
+    s.vibc = cv.take<int32_t>((size_t)s.vibc_stride * n);
+    s.rbv = cv.take<int32_t>((size_t)s.idx_stride * n);
+    s.cbv = cv.take<int32_t>((size_t)s.idx_stride * n);
+    s.prow = cv.take<double>((size_t)s.prow_stride * n);
+    s.pcol = cv.take<double>((size_t)s.pcol_stride * n);
+    s.dirty = cv.take<uint8_t>((size_t)s.pcol_stride * n);
+    s.st = cv.take<DevState>((size_t)n);
+    s.hist = cv.take<int2>((size_t)s.hist_cap * n);
 }
 
 // (re)allocate the slot arrays for n slots, preserving slot 0
 static int ensure_slots(jslp_engine* e, int n) {
     if (n <= e->n_slots) return JSLP_OK;
     Slots o = e->s, s = e->s;
+    char* old_arena = e->slot_arena;
     const int old_n = e->n_slots;
     s.A_stride = (long long)e->cap_rows * e->ld;
     s.vibr_stride = e->cap_rows;
@@ -117,31 +148,21 @@ static int ensure_slots(jslp_engine* e, int n) {
     s.ld = e->ld; s.W = e->W; s.batch = e->batch; s.use_partial = e->use_partial; s.precision = e->precision;
     s.has_unr = e->n_unr > 0 ? 1 : 0;
     s.unr = e->d_unr;
-    HIPC(hipMalloc(&s.A, sizeof(double) * s.A_stride * n));
-    HIPC(hipMalloc(&s.vibr, sizeof(int32_t) * (size_t)s.vibr_stride * n));
-    HIPC(hipMalloc(&s.vibc, sizeof(int32_t) * (size_t)s.vibc_stride * n));
-    HIPC(hipMalloc(&s.rbv, sizeof(int32_t) * (size_t)s.idx_stride * n));
-    HIPC(hipMalloc(&s.cbv, sizeof(int32_t) * (size_t)s.idx_stride * n));
-    HIPC(hipMalloc(&s.prow, sizeof(double) * (size_t)s.prow_stride * n));
-    HIPC(hipMalloc(&s.pcol, sizeof(double) * (size_t)s.pcol_stride * n));
-    HIPC(hipMalloc(&s.dirty, (size_t)s.pcol_stride * n));
+    Carver sizing{nullptr, 0};
+    carve_slots(s, sizing, n);
+    char* arena = nullptr;
+    HIPC(hipMalloc(&arena, sizing.off + 256));
+    Carver cv{arena, 0};
+    carve_slots(s, cv, n);
+    // slot 0's matrix is zero-filled by upload(); other slots are filled by their first (full) restore
     HIPC(hipMemsetAsync(s.dirty, 0, (size_t)s.pcol_stride * n, e->stream));
-    HIPC(hipMalloc(&s.st, sizeof(DevState) * n));
-    HIPC(hipMalloc(&s.hist, sizeof(int2) * (size_t)s.hist_cap * n));
-    HIPC(hipMemsetAsync(s.A, 0, sizeof(double) * s.A_stride * n, e->stream));
     HIPC(hipMemsetAsync(s.st, 0, sizeof(DevState) * n, e->stream));  // gen = 0: slots hold no snapshot copy yet
-    HIPC(hipMemsetAsync(s.prow, 0, sizeof(double) * (size_t)s.prow_stride * n, e->stream));
-    HIPC(hipMemsetAsync(s.pcol, 0, sizeof(double) * (size_t)s.pcol_stride * n, e->stream));
     s.n_opt = e->n_opt;
     s.oo_stride = (long long)e->n_opt * e->ld;
     s.oo = nullptr;
     if (e->n_opt > 0) {
         HIPC(hipMalloc(&s.oo, sizeof(double) * (size_t)s.oo_stride * n));
         HIPC(hipMemsetAsync(s.oo, 0, sizeof(double) * (size_t)s.oo_stride * n, e->stream));
-    }
-    if (!s.trace) {
-        HIPC(hipMalloc(&s.trace, sizeof(int2) * TRACE_CAP));
-        s.trace_cap = TRACE_CAP;
     }
     if (old_n > 0) {  // carry the live tableau over
         HIPC(hipMemcpyAsync(s.A, o.A, sizeof(double) * o.A_stride, hipMemcpyDeviceToDevice, e->stream));
@@ -153,10 +174,11 @@ static int ensure_slots(jslp_engine* e, int n) {
         HIPC(hipMemcpyAsync(s.dirty, o.dirty, (size_t)o.pcol_stride, hipMemcpyDeviceToDevice, e->stream));
         if (e->n_opt > 0 && o.oo) HIPC(hipMemcpyAsync(s.oo, o.oo, sizeof(double) * (size_t)o.oo_stride, hipMemcpyDeviceToDevice, e->stream));
         HIPC(hipStreamSynchronize(e->stream));
-        e->s = o;
-        free_slots(e);
+        hipFree(old_arena);
+        hipFree(o.oo);
     }
     e->s = s;
+    e->slot_arena = arena;
     e->n_slots = n;
     return JSLP_OK;
 }
@@ -192,16 +214,24 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     int rc = JSLP_OK;
     auto init = [&]() -> int {
         HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        HIPC(hipMalloc(&e->d_unr, e->n_idx));
+        {   // snapshot, unrestricted flags and pivot trace: one allocation
+            const size_t cells = (size_t)e->cap_rows * e->ld;
+            for (int pass = 0; pass < 2; pass++) {
+                Carver cv{pass ? e->static_arena : nullptr, 0};
+                e->d_unr = cv.take<uint8_t>((size_t)e->n_idx);
+                e->snap_A = cv.take<double>(cells);
+                e->snap_vibr = cv.take<int32_t>((size_t)e->cap_rows);
+                e->snap_vibc = cv.take<int32_t>((size_t)e->W);
+                e->snap_rbv = cv.take<int32_t>((size_t)e->n_idx);
+                e->snap_cbv = cv.take<int32_t>((size_t)e->n_idx);
+                e->s.trace = cv.take<int2>((size_t)TRACE_CAP);
+                if (!pass) HIPC(hipMalloc(&e->static_arena, cv.off + 256));
+            }
+            e->s.trace_cap = TRACE_CAP;
+        }
         HIPC(hipMemsetAsync(e->d_unr, 0, e->n_idx, e->stream));
         int r = ensure_slots(e, 1);
         if (r) return r;
-        const size_t cells = (size_t)e->cap_rows * e->ld;
-        HIPC(hipMalloc(&e->snap_A, sizeof(double) * cells));
-        HIPC(hipMalloc(&e->snap_vibr, sizeof(int32_t) * e->cap_rows));
-        HIPC(hipMalloc(&e->snap_vibc, sizeof(int32_t) * e->W));
-        HIPC(hipMalloc(&e->snap_rbv, sizeof(int32_t) * e->n_idx));
-        HIPC(hipMalloc(&e->snap_cbv, sizeof(int32_t) * e->n_idx));
         HIPC(hipHostMalloc(&e->h_state, sizeof(DevState)));
         HIPC(hipEventCreate(&e->ev_begin));
         HIPC(hipEventCreate(&e->ev_end));
@@ -219,9 +249,7 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     free_slots(e);
-    hipFree(e->s.trace);
-    hipFree(e->snap_A); hipFree(e->snap_vibr); hipFree(e->snap_vibc); hipFree(e->snap_rbv); hipFree(e->snap_cbv);
-    hipFree(e->d_unr); hipFree(e->snap_oo);
+    hipFree(e->static_arena); hipFree(e->snap_oo);
     hipFree(e->f_buf1); hipFree(e->f_cands[0]); hipFree(e->f_cands[1]); hipFree(e->f_pcol[0]); hipFree(e->f_pcol[1]);
     hipFree(e->f_st[0]); hipFree(e->f_st[1]);
     hipFree(e->r_gran); hipFree(e->r_rows[0]); hipFree(e->r_rows[1]); hipFree(e->r_sync);
