@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=2000, help="variables = constraints of the dense LP (2000 = config 3)")
+    ap.add_argument("--lp-size", dest="n", type=int, default=2000, help="variables = constraints of the dense LP (2000 = config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pivots", type=int, default=1200)
     ap.add_argument("--no-relaxations", action="store_true")
@@ -81,9 +81,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU over RCCL.  JSLP_BENCH_BACKEND=gloo (tests only) lets several ranks share the one GPU of the
+    # test box so that the N > 1 code path of this file can be exercised there.
+    backend = os.environ.get("JSLP_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    red_device = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     from jslpsolver_amd import _capi, generators
     from jslpsolver_amd.engine import Tableau, pivot_digest
@@ -99,14 +107,14 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
@@ -114,7 +122,7 @@ def main():
     n = args.n
     m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
     H, W = m.shape
-    t = Tableau(m, vibr, vibc, device=local_rank, lib=lib)
+    t = Tableau(m, vibr, vibc, device=device_index, lib=lib)
     t.save()  # device-resident copy of the initial tableau: every step restarts from it without touching PCIe
 
     def step():
@@ -161,7 +169,7 @@ def main():
     # ---- LP relaxations/sec: Monster_II node batch sharded over ranks (config 4, throughput variant) -----
     relax = None
     if not args.no_relaxations:
-        relax = relaxation_throughput(lib, local_rank, rank, world, barrier, max_over_ranks, sum_over_ranks)
+        relax = relaxation_throughput(lib, device_index, rank, world, barrier, max_over_ranks, sum_over_ranks)
 
     if rank == 0:
         line = {

@@ -7,6 +7,30 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+import pytest
+
+
+def _run(engine, nproc, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", JSLP_TEST_ENGINE=engine)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("REPORT ")][-1]
+    return json.loads(line[len("REPORT "):])
+
+
+@pytest.mark.gpu
+def test_virtual_shards_on_one_gpu(hip_lib):
+    """4 ranks, each with its own HIP engine on the one visible GPU ("N virtual shards"), nodes sharded round-robin,
+    outcomes all-gathered over gloo: every rank reproduces the reference results"""
+    reports = _run("hip", 4, 29547)
+    assert len(reports) == 4
+    for rep in reports:
+        assert rep["backend"] == "hip-gfx950" and rep["world"] == 4
+        assert all(c["ok"] for c in rep["cases"]), rep
+
+
 def test_two_ranks_shard_nodes_and_agree(oracle_lib):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -19,3 +43,21 @@ def test_two_ranks_shard_nodes_and_agree(oracle_lib):
     for rep in reports:
         assert rep["world"] == 2
         assert all(c["ok"] for c in rep["cases"]), rep
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_code_path_on_one_gpu(hip_lib):
+    """bench.py's N > 1 branch (process group, barrier, max / sum over ranks, replica + sharded-relaxation accounting)
+    with 2 ranks sharing the one GPU of the test box (gloo instead of RCCL): the JSON line must be well formed and the
+    aggregate must count both ranks' pivots"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", JSLP_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--lp-size", "500"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["unit"] == "pivots/s" and line["value"] > 0
+    assert line["config"]["pivot_digest"] == "1cda2607"  # the reference's digest for n = 500 (SURVEY.md Appendix C)
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - 2 * 657) < 1e-6 * 2 * 657
+    assert line["relaxations"]["nodes"] == 2 * 8 * 151
+    assert "cpu_baseline" not in line

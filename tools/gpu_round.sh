@@ -13,8 +13,8 @@ for s in $steps; do
     bench) timeout 600 python bench.py --steps 3 --warmup 1 > $out/bench.log 2>&1 < /dev/null; echo "bench rc=$?"; grep '^{' $out/bench.log | cut -c1-1500 ;;
     benchfast) timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench.log 2>&1 < /dev/null; echo "bench rc=$?"; grep '^{' $out/bench.log | cut -c1-1200 ;;
     prof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/prof -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/prof.log 2>&1 < /dev/null); echo "prof rc=$?"; timeout 120 python tools/rocpd_stats.py $(ls $out/prof/*.db | head -1) $out/kernel_stats.md < /dev/null | tail -12 ;;
-    pmc) (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/$out/pmc_fetch -o pf -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-relaxations --n 2000 > $GRAFT_REPO_ROOT/$out/pmc_fetch.log 2>&1 < /dev/null); echo "pmc fetch rc=$?"
-         (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/$out/pmc_write -o pw -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-relaxations --n 2000 > $GRAFT_REPO_ROOT/$out/pmc_write.log 2>&1 < /dev/null); echo "pmc write rc=$?"
+    pmc) (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/$out/pmc_fetch -o pf -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-relaxations --lp-size 2000 > $GRAFT_REPO_ROOT/$out/pmc_fetch.log 2>&1 < /dev/null); echo "pmc fetch rc=$?"
+         (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/$out/pmc_write -o pw -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-relaxations --lp-size 2000 > $GRAFT_REPO_ROOT/$out/pmc_write.log 2>&1 < /dev/null); echo "pmc write rc=$?"
          timeout 120 python tools/rocpd_pmc.py $out $out/pmc_summary.json < /dev/null | head -60 ;;
   esac
 done
