@@ -388,7 +388,7 @@ static bool resident_eligible(const jslp_engine* e, int H) {
 
 static int ensure_resident(jslp_engine* e) {
     if (e->r_sync) return JSLP_OK;
-    HIPC(hipMalloc(&e->r_gran, sizeof(u64_t) * (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 1) + 16)));
+    HIPC(hipMalloc(&e->r_gran, sizeof(u64_t) * (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32)));
     for (int i = 0; i < 2; i++) HIPC(hipMalloc(&e->r_rows[i], sizeof(u64_t) * (size_t)JSLP_F_MAXG * e->ld));
     HIPC(hipMalloc(&e->r_sync, sizeof(unsigned) * 16));
     return JSLP_OK;
@@ -510,6 +510,67 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
         const int H = e->h_state->H;
         const dim3 grid = update_grid(e, H);
         hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, e->s, 0, cap);
+        bool resident_done = false;
+        // ---- register-resident path: the WHOLE simplex (phase 1 and phase 2) in one cooperative launch -------------
+        if (resident_eligible(e, H)) {
+            int r = ensure_resident(e);
+            if (r) return r;
+            ResCtx rc;
+            rc.c = c;
+            for (int i = 0; i < 2; i++) {
+                rc.gran[i] = e->r_gran + (size_t)i * JSLP_F_MAXG * JSLP_R_GRAN;
+                rc.rowflag[i] = e->r_gran + (size_t)2 * JSLP_F_MAXG * JSLP_R_GRAN + (size_t)i * JSLP_F_MAXG;
+                rc.rows_pub[i] = e->r_rows[i];
+            }
+            rc.decision[0] = e->r_gran + (size_t)2 * JSLP_F_MAXG * (JSLP_R_GRAN + 1);
+            rc.decision[1] = rc.decision[0] + 8;
+            rc.verdict[0] = rc.decision[0] + 16;
+            rc.verdict[1] = rc.decision[0] + 24;
+            rc.gor[0] = rc.decision[0] + 32;
+            rc.gor[1] = rc.gor[0] + JSLP_F_MAXG;
+            rc.abort_flag = e->r_sync + 4;
+            HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32), s));  // tags restart at 1
+            rc.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
+            rc.G = (H + rc.rpb - 1) / rc.rpb;
+            rc.H = H;
+            rc.iters_cap = cap;
+            rc.dbg = nullptr;
+#ifdef JSLP_DEBUG_RESIDENT
+            static u64_t* dbg_buf = nullptr;
+            if (!dbg_buf) HIPC(hipMalloc(&dbg_buf, sizeof(u64_t) * (512 * JSLP_F_MAXG * 2 + 16384)));
+            HIPC(hipMemsetAsync(dbg_buf, 0, sizeof(u64_t) * (512 * JSLP_F_MAXG * 2 + 16384), s));
+            rc.dbg = dbg_buf;
+#endif
+            HIPC(hipMemsetAsync(e->r_sync, 0, sizeof(unsigned) * 16, s));
+            hipEvent_t k0 = nullptr, k1 = nullptr;
+            if (e->timing) { r = ensure_events(e, 2); if (r) return r; k0 = e->ev_pool[0]; k1 = e->ev_pool[1]; HIPC(hipEventRecord(k0, s)); }
+            void* args[] = {&rc};
+            hipError_t le = hipLaunchCooperativeKernel((const void*)k_simplex_resident, dim3(rc.G), dim3(JSLP_F_THREADS), args, 0, s);
+            if (le == hipSuccess) {
+                if (e->timing) HIPC(hipEventRecord(k1, s));
+                const int it_before = 0;  // k_begin zeroed the pivot counters
+                HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+                HIPC(hipStreamSynchronize(s));
+                if (e->timing) {
+                    float ms = 0;
+                    if (hipEventElapsedTime(&ms, k0, k1) == hipSuccess) e->upd_ms += ms;
+                    e->upd_launches += e->h_state->it1 + e->h_state->it2 - it_before;  // unit = one pivot (16*H*W algorithmic bytes)
+                }
+                resident_done = true;
+                e->last_path = "resident";
+#ifdef JSLP_DEBUG_RESIDENT
+                {   // phase timing + micro-costs of the debug build (tools/resident_phase_timing.py reads this file)
+                    std::vector<u64_t> d(16384);
+                    HIPC(hipMemcpy(d.data(), rc.dbg + (size_t)512 * rc.G * 2, sizeof(u64_t) * 16384, hipMemcpyDeviceToHost));
+                    FILE* fb = fopen("gpurun_out/resident_r0.bin", "wb");
+                    if (fb) { fwrite(d.data(), 8, 16384, fb); fclose(fb); }
+                }
+#endif
+            } else {
+                (void)hipGetLastError();  // not co-resident on this device: use one launch per pivot instead
+            }
+        }
+        if (!resident_done) {
         // ---- phase 1 (and phase 2 when the fused pipeline does not apply): k_select + k_update per pivot ----
         int chunk = fused ? 1 : 8;
         long long done_prev = 0;
@@ -540,84 +601,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             chunk = std::min(chunk * 2, 256);
         }
         // ---- phase 2: one fused launch per pivot ----------------------------------------------------------
-        bool resident_done = false;
-        if (e->h_state->status == ST_PHASE1_DONE && resident_eligible(e, H)) {
-            int r = ensure_resident(e);
-            if (r) return r;
-            ResCtx rc;
-            rc.c = c;
-            for (int i = 0; i < 2; i++) {
-                rc.gran[i] = e->r_gran + (size_t)i * JSLP_F_MAXG * JSLP_R_GRAN;
-                rc.rowflag[i] = e->r_gran + (size_t)2 * JSLP_F_MAXG * JSLP_R_GRAN + (size_t)i * JSLP_F_MAXG;
-                rc.rows_pub[i] = e->r_rows[i];
-            }
-            rc.decision[0] = e->r_gran + (size_t)2 * JSLP_F_MAXG * (JSLP_R_GRAN + 1);
-            rc.decision[1] = rc.decision[0] + 8;
-            rc.abort_flag = e->r_sync + 4;
-            HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 1) + 16), s));  // tags restart at 1
-            rc.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
-            rc.G = (H + rc.rpb - 1) / rc.rpb;
-            rc.H = H;
-            rc.iters_cap = cap;
-            rc.dbg = nullptr;
-#ifdef JSLP_DEBUG_RESIDENT
-            static u64_t* dbg_buf = nullptr;
-            if (!dbg_buf) HIPC(hipMalloc(&dbg_buf, sizeof(u64_t) * (512 * JSLP_F_MAXG * 2 + 16384)));
-            HIPC(hipMemsetAsync(dbg_buf, 0, sizeof(u64_t) * (512 * JSLP_F_MAXG * 2 + 16384), s));
-            rc.dbg = dbg_buf;
-#endif
-            HIPC(hipMemsetAsync(e->r_sync, 0, sizeof(unsigned) * 16, s));
-            hipEvent_t k0 = nullptr, k1 = nullptr;
-            if (e->timing) { r = ensure_events(e, 2); if (r) return r; k0 = e->ev_pool[0]; k1 = e->ev_pool[1]; HIPC(hipEventRecord(k0, s)); }
-            void* args[] = {&rc};
-            hipError_t le = hipLaunchCooperativeKernel((const void*)k_simplex_resident, dim3(rc.G), dim3(JSLP_F_THREADS), args, 0, s);
-            if (le == hipSuccess) {
-                if (e->timing) HIPC(hipEventRecord(k1, s));
-                const int it2_before = e->h_state->it2;
-                HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
-                HIPC(hipStreamSynchronize(s));
-                if (e->timing) {
-                    float ms = 0;
-                    if (hipEventElapsedTime(&ms, k0, k1) == hipSuccess) e->upd_ms += ms;
-                    e->upd_launches += e->h_state->it2 - it2_before;  // unit = one pivot (16*H*W algorithmic bytes)
-                }
-                resident_done = true;
-                e->last_path = "resident";
-#ifdef JSLP_DEBUG_RESIDENT
-                {
-                    std::vector<u64_t> h((size_t)512 * rc.G * 2);
-                    HIPC(hipMemcpy(h.data(), rc.dbg, sizeof(u64_t) * h.size(), hipMemcpyDeviceToHost));
-                    {
-                        std::vector<u64_t> d(16384);
-                        HIPC(hipMemcpy(d.data(), rc.dbg + (size_t)512 * rc.G * 2, sizeof(u64_t) * 16384, hipMemcpyDeviceToHost));
-                        FILE* fb = fopen("gpurun_out/resident_r0.bin", "wb");
-                        if (fb) { fwrite(d.data(), 8, 16384, fb); fclose(fb); }
-                    }
-                    FILE* fp2 = fopen("gpurun_out/resident_dbg.txt", "w");
-                    if (fp2) {
-                        for (int ep = 0; ep < 512; ep++) {
-                            // majority pc / hash = workgroup G-1's; list the deviants
-                            const u64_t pc_ref = h[((size_t)ep * rc.G + rc.G - 1) * 2], hs_ref = h[((size_t)ep * rc.G + rc.G - 1) * 2 + 1];
-                            int bad = 0;
-                            for (int b2 = 0; b2 < rc.G; b2++) {
-                                const u64_t pcv = h[((size_t)ep * rc.G + b2) * 2], hs = h[((size_t)ep * rc.G + b2) * 2 + 1];
-                                if (pcv != pc_ref || hs != hs_ref) {
-                                    if (bad < 12) fprintf(fp2, "epoch %d wg %d pc %llu hash %llx (ref pc %llu hash %llx)\n", ep, b2, pcv, hs, pc_ref, hs_ref);
-                                    bad++;
-                                }
-                            }
-                            if (bad) fprintf(fp2, "epoch %d: %d deviating workgroups\n", ep, bad);
-                            if (ep >= 236 && ep <= 246) fprintf(fp2, "epoch %d pc(all) %llu wg0 pc %llu\n", ep, pc_ref, h[((size_t)ep * rc.G) * 2]);
-                        }
-                        fclose(fp2);
-                    }
-                }
-#endif
-            } else {
-                (void)hipGetLastError();  // not co-resident on this device: use one launch per pivot instead
-            }
-        }
-        if (!resident_done && e->h_state->status == ST_PHASE1_DONE) {
+        if (e->h_state->status == ST_PHASE1_DONE) {
             int r = ensure_fused(e);
             if (r) return r;
             e->last_path = "fused";
@@ -662,6 +646,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             HIPC(hipGetLastError());
             HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
         }
+        }  // !resident_done
         HIPC(hipEventRecord(e->ev_end, s));
         HIPC(hipStreamSynchronize(s));
     }

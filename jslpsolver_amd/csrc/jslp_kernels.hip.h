@@ -1249,6 +1249,8 @@ struct ResCtx {
     u64_t* rowflag[2];    // [G] epoch tag: the workgroup's candidate row of that epoch is fully written through
     unsigned* abort_flag; // set when any spin gives up
     u64_t* decision[2];   // leader's per-pivot decision: 3 tagged granules {pr | stop << 16}, {quot lo}, {quot hi}
+    u64_t* verdict[2];    // phase 1 only: leader's cycle-check verdict {tag | stop} (the entering column is known late there)
+    u64_t* gor[2];        // [G] rare slow path: tagged per-workgroup flags for a chip-wide OR
     int32_t G, rpb, H;
     int32_t iters_cap;
     u64_t* dbg;  // JSLP_DEBUG_RESIDENT builds only
@@ -1275,6 +1277,7 @@ struct RSmem {
     int32_t ok;
     int32_t pubrow;
     unsigned dec[4];
+    double xq[2];   // phase 1: quot and k0 broadcast by the lane pair owning column pc
     double quo[JSLP_R_ROWS];
     int32_t kind[JSLP_R_ROWS];
 };
@@ -1366,6 +1369,28 @@ __device__ __forceinline__ void reset_reductions(RSmem& sm) {  // one thread, be
     sm.l_rdeg = 0x7fffffff; sm.l_q = ~0ull; sm.l_r = 0x7fffffff;
 }
 
+// Chip-wide OR of one flag per workgroup (rare slow path of phase 1, see the lazily-zeroed pivot-row entries):
+// every workgroup publishes a tagged granule and polls everybody else's.  Returns -1 on abort.
+__device__ __forceinline__ int global_or(const ResCtx& f, int par, unsigned tag, int flag, RSmem& sm) {
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (tid == 0) AG_STORE(f.gor[par] + b, ((u64_t)tag << 32) | (unsigned)(flag ? 1 : 0));
+    int mine = 0, ok = 1;
+    if (tid < f.G) {
+        unsigned spins = 0;
+        for (;;) {
+            const u64_t x = AG_LOAD(f.gor[par] + tid);
+            if ((unsigned)(x >> 32) == tag) { mine = (int)(x & 1u); break; }
+            __builtin_amdgcn_s_sleep(JSLP_POLL_SLEEP);
+            ++spins;
+            if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
+            if (spins > JSLP_SPIN_LIMIT) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+        }
+    }
+    const int bad = __syncthreads_or(ok ? 0 : 1);
+    const int any = __syncthreads_or(mine);
+    return bad ? -1 : (any ? 1 : 0);
+}
+
 __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
     __shared__ RSmem sm;
 #ifdef JSLP_DEBUG_RESIDENT
@@ -1393,10 +1418,12 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
     }
     const int status0 = st->status;
     int hist_n = st->hist_n;
-    const int it2_start = st->it2;
-    int it2 = it2_start;
+    const int it1_start = st->it1, it2_start = st->it2;
+    int it1 = it1_start, it2 = it2_start;
     long long trace_n = st->trace_n;
-    if (status0 != ST_PHASE1_DONE) return;  // not handed over by phase 1: nothing to do (uniform)
+    // fresh simplex() (k_begin ran: phase 1 first) or a hand-over after a phase 1 done elsewhere
+    if (status0 != ST_RUNNING && status0 != ST_PHASE1_DONE) return;  // uniform
+    int phase = status0 == ST_PHASE1_DONE ? 2 : 1;
 
 #ifdef JSLP_DEBUG_RESIDENT
     if (f.dbg) {  // micro-costs in this kernel's own geometry
@@ -1425,19 +1452,23 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
     const int pb0 = c.use_partial && c0 >= 1 ? (c0 - 1) / c.batch : 0;
     const int pb1 = c.use_partial ? c0 / c.batch : 0;
     double k0 = 0.0;  // reduced cost of the entering column = cost-row entry of column pc
-    int pc = price_row_lds(r0.x, r0.y, c0, pb0, pb1, c, sm, &k0);
-    int end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted hand-off, 6 history full
+    int pc = 0;
+    int end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted hand-off, 6 history full, 7 infeasible
     int unbounded_col = 0;
     unsigned epoch = 0;
-    if (pc == 0) end_code = 1;
+    if (phase == 2) {
+        pc = price_row_lds(r0.x, r0.y, c0, pb0, pb1, c, sm, &k0);
+        if (pc == 0) end_code = 1;
+    }
 
     while (end_code == 0) {
-        if (it2 - it2_start >= f.iters_cap) { end_code = 4; break; }
+        if ((it1 - it1_start) + (it2 - it2_start) >= f.iters_cap) { end_code = 4; break; }
         const int par = epoch & 1;
         const unsigned tag = epoch + 1;
         RT_MARK(7);
-        // ---- A: my rows' ratio-test summary for column pc (simplex.ts:276-296) --------------------------------
-        const bool has_pc = colok && ((pc == c0) || (pc == c0 + 1));
+        // ---- A: my rows' summary: phase 2 = ratio test for column pc (simplex.ts:276-296); phase 1 = most negative RHS
+        //         below -precision (simplex.ts:39-49) -------------------------------------------------------------------
+        bool has_pc = phase == 2 && colok && ((pc == c0) || (pc == c0 + 1));
         if (has_pc) {
 #pragma unroll
             for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.col[i] = (pc == c0) ? a[i].x : a[i].y;
@@ -1454,9 +1485,11 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
             if (tid < JSLP_R_ROWS) {
                 const int r = r_begin + tid;
                 const double colv = sm.f.col[tid], rhs = sm.f.rhs[tid];
-                int kind = 0;  // 0 skip, 1 degenerate winner, 2 quotient candidate
+                int kind = 0;  // 0 skip, 1 degenerate winner, 2 quotient candidate (phase 1: RHS candidate)
                 double quo = 0.0;
-                if (r >= 1 && r < r_end && !(-precision < colv && colv < precision)) {
+                if (phase == 1) {
+                    if (r >= 1 && r < r_end && rhs < -precision) { quo = rhs; kind = 2; }
+                } else if (r >= 1 && r < r_end && !(-precision < colv && colv < precision)) {
                     if (colv > 0 && precision > rhs && rhs > -precision) kind = 1;
                     else { quo = rhs / colv; kind = quo > precision ? 2 : 0; }
                 }
@@ -1531,7 +1564,8 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
                 for (int off = 32; off > 0; off >>= 1) {
                     const u64_t q2 = __shfl_xor(q, off, 64);
                     const int r2 = __shfl_xor(r, off, 64), rd2 = __shfl_xor(rdeg, off, 64);
-                    const bool take = r2 != 0 && (r == 0 || q2 < q || (q2 == q && r2 < r));
+                    const double d2 = __longlong_as_double((long long)q2), d1 = __longlong_as_double((long long)q);
+                    const bool take = r2 != 0 && (r == 0 || d2 < d1 || (d2 == d1 && r2 < r));  // smallest value, first row
                     q = take ? q2 : q;
                     r = take ? r2 : r;
                     rdeg = rd2 < rdeg ? rd2 : rdeg;
@@ -1548,19 +1582,20 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
             for (int i = 0; i < 4; i++) {
                 const u64_t q2 = sm.w_q[i];
                 const int r2 = sm.w_r[i], rd2 = sm.w_rdeg[i];
-                const bool take = r2 != 0 && (wr == 0 || q2 < wq || (q2 == wq && r2 < wr));
+                const double d2 = __longlong_as_double((long long)q2), d1 = __longlong_as_double((long long)wq);
+                const bool take = r2 != 0 && (wr == 0 || d2 < d1 || (d2 == d1 && r2 < wr));
                 wq = take ? q2 : wq;
                 wr = take ? r2 : wr;
                 wrdeg = rd2 < wrdeg ? rd2 : wrdeg;
             }
             if (wrdeg != 0x7fffffff) pr = wrdeg;
             else if (wr != 0) pr = wr;
-            else stop = 3;  // unbounded (simplex.ts:298-303)
+            else stop = phase == 1 ? 4 : 3;  // phase 1: no violated row -> feasible (:51-54); phase 2: unbounded (:298-303)
             if (!stop && sweeper && tid - (JSLP_F_THREADS - JSLP_SWEEP_LANES) == pr / f.rpb)
                 sm.l_k = wrdeg != 0x7fffffff ? sc.kdeg : sc.kq;  // the owner of row pr published both entries
             __syncthreads();
             quot = stop ? 0.0 : sm.l_k;
-            if (!stop && c.check_cycles) {  // simplex.ts:305-320, before anything is committed
+            if (!stop && phase == 2 && c.check_cycles) {  // simplex.ts:305-320, before anything is committed
                 if (hist_n >= c.hist_cap) {
                     stop = 2;
                 } else {
@@ -1602,6 +1637,14 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
         if (stop == 3) { end_code = 2; unbounded_col = pc; break; }
         if (stop == 1) { end_code = 3; break; }
         if (stop == 2) { end_code = 6; break; }
+        if (stop == 4) {  // phase 1 is over: phase 2 starts with a fresh history (simplex.ts:14-23, 102)
+            phase = 2;
+            hist_n = 0;
+            epoch += 1;
+            pc = price_row_lds(r0.x, r0.y, c0, pb0, pb1, c, sm, &k0);
+            if (pc == 0) end_code = 1;
+            continue;
+        }
         // ---- E: the winning row: loaded speculatively together with its flag; re-loaded in the rare case the flag
         //         (which follows the winner's drain) was not up yet ------------------------------------------------------
         const int bw = pr / f.rpb;
@@ -1637,7 +1680,72 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
         }
         if (end_code == 5) break;
         RT_MARK(4);
+        bool anyrow = true;  // phase 2: the entering cost is > precision, so some row always runs simplex.ts:381-383
+        if (phase == 1) {
+            // entering column: max -cost/coef over coef < -precision (simplex.ts:56-71; no unrestricted variables here)
+            Cand best; best.v = -INFINITY; best.i = 0; best.b = 0;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = c0 + j;
+                const double coef = j ? pvy : pvx;
+                if (col >= 1 && col < W && coef < -precision) {
+                    const double quo = -(j ? r0.y : r0.x) / coef;
+                    const bool take = best.v < quo;
+                    best.v = take ? quo : best.v;
+                    best.i = take ? col : best.i;
+                }
+            }
+            best = block_reduce(best, MaxFirst(), sm.f.red);
+            if (best.i == 0) { end_code = 7; break; }  // infeasible (simplex.ts:73-76), uniform
+            pc = best.i;
+            has_pc = colok && ((pc == c0) || (pc == c0 + 1));
+            if (has_pc) {
+#pragma unroll
+                for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.col[i] = (pc == c0) ? a[i].x : a[i].y;
+                sm.xq[0] = (pc == c0) ? pvx : pvy;    // quot = A[pr, pc]
+                sm.xq[1] = (pc == c0) ? r0.x : r0.y;  // k0 = A[0, pc]
+            }
+            __syncthreads();
+            quot = sm.xq[0];
+            k0 = sm.xq[1];
+            if (c.check_cycles) {  // simplex.ts:78-93: only now is the (leaving, entering) pair known
+                if (b == 0) {
+                    int cstop = 0;
+                    if (hist_n >= c.hist_cap) {
+                        cstop = 2;
+                    } else {
+                        if (tid == 0) c.hist[hist_n] = make_int2(c.vibr[pr], c.vibc[pc]);
+                        __syncthreads();
+                        hist_n += 1;
+                        if (suffix_is_square(c.hist, hist_n, sm.f.red)) cstop = 1;
+                    }
+                    if (tid == 0) AG_STORE(f.verdict[par], ((u64_t)tag << 32) | (unsigned)cstop);
+                    stop = cstop;
+                } else {
+                    if (tid == 0) {
+                        unsigned spins = 0;
+                        int v = -1;
+                        for (;;) {
+                            const u64_t x = AG_LOAD(f.verdict[par]);
+                            if ((unsigned)(x >> 32) == tag) { v = (int)(x & 3u); break; }
+                            __builtin_amdgcn_s_sleep(JSLP_POLL_SLEEP);
+                            ++spins;
+                            if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) break;
+                            if (spins > JSLP_SPIN_LIMIT) { AG_STORE(f.abort_flag, 1u); break; }
+                        }
+                        sm.ok = v;
+                    }
+                    __syncthreads();
+                    stop = sm.ok;
+                    __syncthreads();
+                }
+                if (stop < 0) { end_code = 5; break; }
+                if (stop == 1) { end_code = 3; break; }
+                if (stop == 2) { end_code = 6; break; }
+            }
+        }
         double2 p = make_double2(0, 0);  // normalised pivot row (simplex.ts:352-364)
+        int tiny = 0;                    // entries simplex.ts:381-383 zeroes as soon as ANY other row is eliminated
         if (colok) {
 #pragma unroll
             for (int j = 0; j < 2; j++) {
@@ -1648,10 +1756,26 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
                     const bool innz = nonzero16(val);
                     v = innz ? val / quot : 0.0;
                     if (col == pc) v = 1.0 / quot;
-                    if (innz && !nonzero16(v) && v != 0.0) v = 0.0;
+                    if (innz && !nonzero16(v) && v != 0.0) tiny |= 1 << j;
                 }
                 if (j) p.y = v; else p.x = v;
             }
+        }
+        if (phase == 1 && __syncthreads_or(tiny)) {
+            // rare: the stored pivot row depends on whether any OTHER row has a non-zero entry in column pc
+            int local_any = 0;
+#pragma unroll
+            for (int i = 0; i < JSLP_R_ROWS; i++) {
+                const int r = r_begin + i;
+                if (r < r_end && r != pr && nonzero16(sm.f.col[i])) local_any = 1;
+            }
+            const int g = global_or(f, par, tag, local_any, sm);
+            if (g < 0) { end_code = 5; break; }
+            anyrow = g != 0;
+        }
+        if (anyrow) {
+            if (tiny & 1) p.x = 0.0;
+            if (tiny & 2) p.y = 0.0;
         }
         const bool v0 = nonzero16(p.x), v1 = nonzero16(p.y);
         RT_MARK(5);
@@ -1686,12 +1810,14 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
             if (trace_n < c.trace_cap) c.trace[trace_n] = make_int2(pr, pc);
         }
         trace_n += 1;
-        it2 += 1;
+        if (phase == 1) it1 += 1; else it2 += 1;
         epoch += 1;
         RT_MARK(6);
-        // ---- G: price the new cost row -> entering column of the next pivot ----------------------------------------------
-        pc = price_row_lds(r0.x, r0.y, c0, pb0, pb1, c, sm, &k0);
-        if (pc == 0) end_code = 1;
+        // ---- G: phase 2: price the new cost row -> entering column of the next pivot -----------------------------------
+        if (phase == 2) {
+            pc = price_row_lds(r0.x, r0.y, c0, pb0, pb1, c, sm, &k0);
+            if (pc == 0) end_code = 1;
+        }
     }
 
 #ifdef JSLP_DEBUG_RESIDENT
@@ -1710,16 +1836,20 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
         }
     }
     if (b == 0 && tid == 0) {
+        st->it1 = it1;
         st->it2 = it2;
         st->trace_n = trace_n;
         st->hist_n = hist_n;
-        st->iters_left -= (it2 - it2_start);
+        st->iters_left -= (it1 - it1_start) + (it2 - it2_start);
         st->do_pivot = 0;
         st->status = ST_DONE;
+        st->phase = phase;
+        if (phase == 2) { st->entered_phase2 = 1; st->feasible = 1; }  // phase 1 found no violated row (simplex.ts:51-54)
         st->obj_cell = r0.x;  // column 0 of the cost row
         if (end_code == 1) st->optimal = 1;
         if (end_code == 2) { st->bounded = 0; st->unbounded_var = c.vibc[unbounded_col]; }
-        if (end_code == 3) { st->cycle_phase = 2; st->feasible = 0; }
+        if (end_code == 3) { st->cycle_phase = phase; st->feasible = 0; }
+        if (end_code == 7) st->feasible = 0;
         if (end_code == 4) st->err = ERR_ITER_LIMIT;
         if (end_code == 5) st->err = ERR_BARRIER;
         if (end_code == 6) st->err = ERR_HIST_FULL;

@@ -23,6 +23,13 @@ def _cases():
     out.append(("unbounded", np.array([[0.0, 1.0, 2.0], [4.0, -1.0, 0.0], [6.0, 0.0, -3.0]])))
     out.append(("infeasible", np.array([[0.0, 1.0, 1.0], [-4.0, 1.0, 2.0], [6.0, 1.0, 3.0]])))
     out.append(("degenerate", np.array([[0.0, 3.0, 2.0], [0.0, 1.0, 1.0], [0.0, 2.0, 1.0], [4.0, 1.0, 0.0]])))
+    # phase-1 pivot whose normalised pivot row holds a tiny non-zero entry (2e-16 / -4): the reference zeroes it only if
+    # some OTHER row has a non-zero entry in the pivot column (simplex.ts:381-383) -- both variants
+    lazy = np.array([[0.0, 0.0, 3.0, 2.0], [-4.0, -4.0, 2e-16, 1.0], [5.0, 0.0, 1.0, 1.0]])
+    out.append(("lazy zero: no other row", lazy))
+    lazy2 = lazy.copy()
+    lazy2[2, 1] = 2.0
+    out.append(("lazy zero: another row", lazy2))
     tiny = rng.integers(-4, 9, (12, 15)).astype(np.float64)
     tiny[1:, 1:] *= np.where(rng.random((11, 14)) < 0.3, 10.0 ** rng.integers(-18, -14, (11, 14)), 1.0)
     tiny[1:, 0] = np.abs(tiny[1:, 0])

@@ -110,8 +110,8 @@ def test_config3_full_size_against_reference_golden(hip_lib):
     for kind, name in (("ra", "generateResourceAllocation"), ("lp", "generateRandomLP")):
         g = G.load(os.path.join(G.GOLDEN, "synthetic", name + "_2000x2000_seed12345.json.gz"))
         out = _dense_case(hip_lib, kind, 2000, check_cycles=False)
-        # 3a is all phase 2 -> register-resident kernel; 3b never leaves phase 1 -> select + update
-        assert out["path"] == ("resident" if kind == "ra" else "select+update")
+        # 3a is all phase 2, 3b never leaves phase 1: both run as ONE launch of the register-resident kernel
+        assert out["path"] == "resident"
         assert out["n"] == g["nPivots"]
         assert out["digest"] == g["pivotDigest"]
         assert G.sha_matrix(out["matrix"]) == g["final"]["matrixSha"]
