@@ -166,6 +166,23 @@ def main():
                     "whole_pivot_frac": (bytes_per_launch * value / max(world, 1)) / HBM_PEAK}
     t.close()
 
+    # ---- the other config-3 instance (3b: generateRandomLP, every pivot is a phase-1 pivot; ends infeasible) ------------
+    phase1 = None
+    if rank == 0:
+        m1, vibr1, vibc1, _op = generators.dense_random_lp_tableau(12345, n, n)
+        t1 = Tableau(m1, vibr1, vibc1, device=device_index, lib=lib)
+        t1.save()
+        t1.simplex(check_cycles=False)
+        t1.restore()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r1 = t1.simplex(check_cycles=False)
+        dt = time.perf_counter() - t0
+        phase1 = {"workload": "config 3b: generateRandomLP(seed 12345, %d x %d, density 1.0), phase 1 only" % (n, n),
+                  "pivots": r1.pivots_phase1, "feasible": bool(r1.feasible), "pivots_per_s": r1.pivots_phase1 / dt,
+                  "pivot_digest": pivot_digest(t1.pivot_trace()[-r1.pivots_phase1:]), "kernel": t1.last_path()}
+        t1.close()
+
     # ---- LP relaxations/sec: Monster_II node batch sharded over ranks (config 4, throughput variant) -----
     relax = None
     if not args.no_relaxations:
@@ -184,6 +201,8 @@ def main():
         }
         if relax is not None:
             line["relaxations"] = relax
+        if phase1 is not None:
+            line["phase1_instance"] = phase1
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(n, args.cpu_sample_pivots)
             if line["cpu_baseline"] and line["cpu_baseline"].get("value"):

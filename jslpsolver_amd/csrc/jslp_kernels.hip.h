@@ -1391,12 +1391,26 @@ __device__ __forceinline__ int global_or(const ResCtx& f, int par, unsigned tag,
     return bad ? -1 : (any ? 1 : 0);
 }
 
-__global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
-    __shared__ RSmem sm;
+// Loop-carried state of the resident kernel (kept in registers: every member is a scalar or a fully unrolled array)
+struct ResRegs {
+    double2 a[JSLP_R_ROWS];
+    double2 r0;
+    double k0;
+    int pc, end_code, unbounded_col, hist_n, it1, it2;
+    unsigned epoch;
+    long long trace_n;
 #ifdef JSLP_DEBUG_RESIDENT
-    u64_t rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    u64_t rt_prev = __builtin_amdgcn_s_memtime();
+    u64_t rt_acc[8];
+    u64_t rt_prev;
 #endif
+};
+
+// One phase of the solve.  PHASE is a compile-time constant so that the phase-2 loop -- the hot one -- carries none of
+// the phase-1 branches; returns when the solve ends (R.end_code != 0) or, for PHASE == 1, when phase 1 is over
+// (end_code stays 0 and the caller starts phase 2).
+template <int PHASE>
+__device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRegs& R, int it1_start, int it2_start,
+                                               int pb0, int pb1) {
     const Ctx& c = f.c;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int ld = c.ld, W = c.W, H = f.H;
@@ -1404,63 +1418,23 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
     const int c0 = tid * 2;
     const bool colok = c0 < ld;
     const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
-    DevState* st = c.st;
-
-    // ---- load my rows and the cost row into registers ---------------------------------------------------
-    double2 a[JSLP_R_ROWS];
-    double2 r0 = make_double2(0, 0);
-    if (colok) r0 = *reinterpret_cast<const double2*>(c.A + c0);
-#pragma unroll
-    for (int i = 0; i < JSLP_R_ROWS; i++) {
-        const int r = r_begin + i;
-        a[i] = make_double2(0, 0);
-        if (i < f.rpb && r < r_end && colok) a[i] = *reinterpret_cast<const double2*>(c.A + (long long)r * ld + c0);
-    }
-    const int status0 = st->status;
-    int hist_n = st->hist_n;
-    const int it1_start = st->it1, it2_start = st->it2;
-    int it1 = it1_start, it2 = it2_start;
-    long long trace_n = st->trace_n;
-    // fresh simplex() (k_begin ran: phase 1 first) or a hand-over after a phase 1 done elsewhere
-    if (status0 != ST_RUNNING && status0 != ST_PHASE1_DONE) return;  // uniform
-    int phase = status0 == ST_PHASE1_DONE ? 2 : 1;
-
+    constexpr int phase = PHASE;
+    double2 (&a)[JSLP_R_ROWS] = R.a;
+    double2& r0 = R.r0;
+    double& k0 = R.k0;
+    int& pc = R.pc;
+    int& end_code = R.end_code;
+    int& unbounded_col = R.unbounded_col;
+    int& hist_n = R.hist_n;
+    int& it1 = R.it1;
+    int& it2 = R.it2;
+    unsigned& epoch = R.epoch;
+    long long& trace_n = R.trace_n;
 #ifdef JSLP_DEBUG_RESIDENT
-    if (f.dbg) {  // micro-costs in this kernel's own geometry
-        u64_t t0 = __builtin_amdgcn_s_memtime();
-        for (int i = 0; i < 64; i++) __syncthreads();
-        u64_t t1 = __builtin_amdgcn_s_memtime();
-        for (int i = 0; i < 64; i++) { atomicMin(&sm.p_batch, tid + i); }
-        __syncthreads();
-        u64_t t2 = __builtin_amdgcn_s_memtime();
-        u64_t acc = 0;
-        for (int i = 0; i < 16; i++) { acc += AG_LOAD(f.rowflag[0] + ((acc + i) & 63)); }
-        u64_t t3 = __builtin_amdgcn_s_memtime();
-        double dv = 1.0 + (double)tid;
-        for (int i = 0; i < 16; i++) dv = 3.0 / dv + 1.0;
-        u64_t t4 = __builtin_amdgcn_s_memtime();
-        if (tid == 0 && b == 1) {
-            u64_t* o = f.dbg + (long long)512 * f.G * 2 + 12288 + 64;
-            o[0] = (t1 - t0) / 64; o[1] = (t2 - t1) / 64; o[2] = (t3 - t2) / 16; o[3] = (t4 - t3) / 16; o[4] = acc + (u64_t)dv;
-        }
-        __syncthreads();
-    }
+    u64_t (&rt_acc)[8] = R.rt_acc;
+    u64_t& rt_prev = R.rt_prev;
 #endif
-    if (tid == 0) reset_reductions(sm);
-    __syncthreads();
-    // pricing batch of my two columns (simplex.ts:118-127): fixed for the whole solve
-    const int pb0 = c.use_partial && c0 >= 1 ? (c0 - 1) / c.batch : 0;
-    const int pb1 = c.use_partial ? c0 / c.batch : 0;
-    double k0 = 0.0;  // reduced cost of the entering column = cost-row entry of column pc
-    int pc = 0;
-    int end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted hand-off, 6 history full, 7 infeasible
-    int unbounded_col = 0;
-    unsigned epoch = 0;
-    if (phase == 2) {
-        pc = price_row_lds(r0.x, r0.y, c0, pb0, pb1, c, sm, &k0);
-        if (pc == 0) end_code = 1;
-    }
-
+    (void)H; (void)pb0; (void)pb1;
     while (end_code == 0) {
         if ((it1 - it1_start) + (it2 - it2_start) >= f.iters_cap) { end_code = 4; break; }
         const int par = epoch & 1;
@@ -1637,13 +1611,10 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
         if (stop == 3) { end_code = 2; unbounded_col = pc; break; }
         if (stop == 1) { end_code = 3; break; }
         if (stop == 2) { end_code = 6; break; }
-        if (stop == 4) {  // phase 1 is over: phase 2 starts with a fresh history (simplex.ts:14-23, 102)
-            phase = 2;
+        if (stop == 4) {  // phase 1 is over: the caller starts phase 2 with a fresh history (simplex.ts:14-23, 102)
             hist_n = 0;
             epoch += 1;
-            pc = price_row_lds(r0.x, r0.y, c0, pb0, pb1, c, sm, &k0);
-            if (pc == 0) end_code = 1;
-            continue;
+            return;
         }
         // ---- E: the winning row: loaded speculatively together with its flag; re-loaded in the rare case the flag
         //         (which follows the winner's drain) was not up yet ------------------------------------------------------
@@ -1819,11 +1790,94 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
             if (pc == 0) end_code = 1;
         }
     }
+}
+
+__global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
+    __shared__ RSmem sm;
+    ResRegs R;
+#ifdef JSLP_DEBUG_RESIDENT
+    for (int i = 0; i < 8; i++) R.rt_acc[i] = 0;
+    R.rt_prev = __builtin_amdgcn_s_memtime();
+#endif
+    const Ctx& c = f.c;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int ld = c.ld, W = c.W, H = f.H;
+    const double precision = c.precision;
+    const int c0 = tid * 2;
+    const bool colok = c0 < ld;
+    const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
+    DevState* st = c.st;
+
+    // ---- load my rows and the cost row into registers ---------------------------------------------------
+    double2 (&a)[JSLP_R_ROWS] = R.a;
+    double2& r0 = R.r0;
+    r0 = make_double2(0, 0);
+    if (colok) r0 = *reinterpret_cast<const double2*>(c.A + c0);
+#pragma unroll
+    for (int i = 0; i < JSLP_R_ROWS; i++) {
+        const int r = r_begin + i;
+        a[i] = make_double2(0, 0);
+        if (i < f.rpb && r < r_end && colok) a[i] = *reinterpret_cast<const double2*>(c.A + (long long)r * ld + c0);
+    }
+    const int status0 = st->status;
+    R.hist_n = st->hist_n;
+    const int it1_start = st->it1, it2_start = st->it2;
+    R.it1 = it1_start; R.it2 = it2_start;
+    R.trace_n = st->trace_n;
+    // fresh simplex() (k_begin ran: phase 1 first) or a hand-over after a phase 1 done elsewhere
+    if (status0 != ST_RUNNING && status0 != ST_PHASE1_DONE) return;  // uniform
+    int phase = status0 == ST_PHASE1_DONE ? 2 : 1;
+
+#ifdef JSLP_DEBUG_RESIDENT
+    if (f.dbg) {  // micro-costs in this kernel's own geometry
+        u64_t t0 = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 64; i++) __syncthreads();
+        u64_t t1 = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 64; i++) { atomicMin(&sm.p_batch, tid + i); }
+        __syncthreads();
+        u64_t t2 = __builtin_amdgcn_s_memtime();
+        u64_t acc = 0;
+        for (int i = 0; i < 16; i++) { acc += AG_LOAD(f.rowflag[0] + ((acc + i) & 63)); }
+        u64_t t3 = __builtin_amdgcn_s_memtime();
+        double dv = 1.0 + (double)tid;
+        for (int i = 0; i < 16; i++) dv = 3.0 / dv + 1.0;
+        u64_t t4 = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && b == 1) {
+            u64_t* o = f.dbg + (long long)512 * f.G * 2 + 12288 + 64;
+            o[0] = (t1 - t0) / 64; o[1] = (t2 - t1) / 64; o[2] = (t3 - t2) / 16; o[3] = (t4 - t3) / 16; o[4] = acc + (u64_t)dv;
+        }
+        __syncthreads();
+    }
+#endif
+    if (tid == 0) reset_reductions(sm);
+    __syncthreads();
+    // pricing batch of my two columns (simplex.ts:118-127): fixed for the whole solve
+    const int pb0 = c.use_partial && c0 >= 1 ? (c0 - 1) / c.batch : 0;
+    const int pb1 = c.use_partial ? c0 / c.batch : 0;
+    R.k0 = 0.0;  // reduced cost of the entering column = cost-row entry of column pc
+    R.pc = 0;
+    R.end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted hand-off, 6 history full, 7 infeasible
+    R.unbounded_col = 0;
+    R.epoch = 0;
+    if (phase == 1) {
+        resident_phase<1>(f, sm, R, it1_start, it2_start, pb0, pb1);
+        if (R.end_code == 0) phase = 2;
+    }
+    if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
+        R.pc = price_row_lds(r0.x, r0.y, c0, pb0, pb1, c, sm, &R.k0);
+        if (R.pc == 0) R.end_code = 1;
+        else resident_phase<2>(f, sm, R, it1_start, it2_start, pb0, pb1);
+    }
+    const int end_code = R.end_code, unbounded_col = R.unbounded_col, hist_n = R.hist_n, it1 = R.it1, it2 = R.it2;
+    const unsigned epoch = R.epoch;
+    const long long trace_n = R.trace_n;
+    (void)epoch;
+
 
 #ifdef JSLP_DEBUG_RESIDENT
     if (f.dbg && tid == 0 && (b == 0 || b == 100 || b == f.G - 1)) {
         u64_t* o = f.dbg + (long long)512 * f.G * 2 + 12288 + (b == 0 ? 0 : (b == 100 ? 16 : 32));
-        for (int i = 0; i < 8; i++) o[i] = rt_acc[i];
+        for (int i = 0; i < 8; i++) o[i] = R.rt_acc[i];
         o[8] = epoch;
     }
 #endif
