@@ -334,10 +334,8 @@ static napi_value fn_relax(napi_env env, napi_callback_info info) {
     NAPI_OK(env, napi_get_value_bool(env, argv[4], &check));
     if (!typed(env, argv[5], napi_float64_array, &rhs, &nrhs) || !typed(env, argv[6], napi_int32_array, &rows, &nrows)) return NULL;
     if (nt != nv || nv != nx) THROW(env, "relax: array lengths differ");
-    int32_t H, W, N;
-    ENGINE_OK(env, L.dims(e, &H, &W, &N), "jslp_engine_dims");
-    /* the engine writes `height after the cuts` entries: bounded by the created row capacity, which the host
-       passed to create(); outputs must cover restore-height + cuts */
+    /* the engine writes `height after the cuts` entries: bounded by the created row capacity, which the host passed
+       to create() and sized its output arrays by */
     jslp_simplex_result r;
     ENGINE_OK(env, L.relax(e, (int32_t)nt, (const int8_t*)t, (const int32_t*)v, (const double*)x, check ? 1 : 0, &r,
                            (double*)rhs, (int32_t*)rows), "jslp_engine_relax");
