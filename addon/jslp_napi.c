@@ -36,6 +36,11 @@ static struct {
     int (*relax)(jslp_engine*, int32_t, const int8_t*, const int32_t*, const double*, int, jslp_simplex_result*, double*, int32_t*);
     int (*relax_batch)(jslp_engine*, int32_t, const int32_t*, const int8_t*, const int32_t*, const double*, int,
                        jslp_simplex_result*, double*, int32_t*, int32_t);
+    int (*checkpoint_create)(jslp_engine*, int32_t*);
+    int (*checkpoint_restore)(jslp_engine*, int32_t);
+    int (*checkpoint_release)(jslp_engine*, int32_t);
+    int (*relax_from)(jslp_engine*, int32_t, int32_t, const int32_t*, const int8_t*, const int32_t*, const double*, int,
+                      jslp_simplex_result*, double*, int32_t*, int32_t);
     int (*dims)(const jslp_engine*, int32_t*, int32_t*, int32_t*);
     int (*read_rhs)(jslp_engine*, double*, int32_t*);
     int (*download)(jslp_engine*, double*, int32_t*, int32_t*, int32_t*, int32_t*);
@@ -53,9 +58,10 @@ static struct {
     } while (0)
 #define ENGINE_OK(env, rc, what)                                                     \
     do {                                                                             \
-        if ((rc) != JSLP_OK) {                                                       \
+        const int _rc = (rc);                                                        \
+        if (_rc != JSLP_OK) {                                                        \
             char _m[640];                                                            \
-            snprintf(_m, sizeof _m, "%s failed (%d): %s", what, (int)(rc), L.last_error()); \
+            snprintf(_m, sizeof _m, "%s failed (%d): %s", what, _rc, L.last_error()); \
             THROW(env, _m);                                                          \
         }                                                                            \
     } while (0)
@@ -158,6 +164,8 @@ static napi_value fn_load(napi_env env, napi_callback_info info) {
     SYM(restore, "jslp_engine_restore"); SYM(add_cuts, "jslp_engine_add_cuts"); SYM(relax, "jslp_engine_relax");
     SYM(relax_batch, "jslp_engine_relax_batch"); SYM(dims, "jslp_engine_dims"); SYM(read_rhs, "jslp_engine_read_rhs");
     SYM(download, "jslp_engine_download"); SYM(pivot_trace, "jslp_engine_pivot_trace");
+    SYM(checkpoint_create, "jslp_engine_checkpoint_create"); SYM(checkpoint_restore, "jslp_engine_checkpoint_restore");
+    SYM(checkpoint_release, "jslp_engine_checkpoint_release"); SYM(relax_from, "jslp_engine_relax_from");
     napi_value s;
     NAPI_OK(env, napi_create_string_utf8(env, L.backend_name(), NAPI_AUTO_LENGTH, &s));
     return s;
@@ -342,6 +350,61 @@ static napi_value fn_relax(napi_env env, napi_callback_info info) {
     return result_object(env, &r);
 }
 
+/* checkpointCreate(h) -> id   (incremental-branch-and-cut.ts:55-70, the device part) */
+static napi_value fn_checkpoint_create(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    int32_t id = -1;
+    ENGINE_OK(env, L.checkpoint_create(e, &id), "jslp_engine_checkpoint_create");
+    napi_value v;
+    NAPI_OK(env, napi_create_int32(env, id, &v));
+    return v;
+}
+
+/* checkpointRestore(h, id) / checkpointRelease(h, id) */
+static napi_value checkpoint_op(napi_env env, napi_callback_info info, int release) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    int32_t id;
+    NAPI_OK(env, napi_get_value_int32(env, argv[1], &id));
+    if (release) ENGINE_OK(env, L.checkpoint_release(e, id), "jslp_engine_checkpoint_release");
+    else ENGINE_OK(env, L.checkpoint_restore(e, id), "jslp_engine_checkpoint_restore");
+    return NULL;
+}
+static napi_value fn_checkpoint_restore(napi_env env, napi_callback_info info) { return checkpoint_op(env, info, 0); }
+static napi_value fn_checkpoint_release(napi_env env, napi_callback_info info) { return checkpoint_op(env, info, 1); }
+
+/* relaxFrom(h, checkpointId, type, varIndex, value, checkCycles, rhsOut, rowsOut) -> result
+   one child of a checkpointed parent: restoreCheckpoint + addCutConstraints + simplex (incremental-branch-and-cut.ts:248-253) */
+static napi_value fn_relax_from(napi_env env, napi_callback_info info) {
+    napi_value argv[8];
+    if (!get_args(env, info, 8, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    int32_t id;
+    NAPI_OK(env, napi_get_value_int32(env, argv[1], &id));
+    void *t, *v, *x, *rhs, *rows;
+    size_t nt, nv, nx, nrhs, nrows;
+    bool check;
+    if (!typed(env, argv[2], napi_int8_array, &t, &nt) || !typed(env, argv[3], napi_int32_array, &v, &nv) ||
+        !typed(env, argv[4], napi_float64_array, &x, &nx))
+        return NULL;
+    NAPI_OK(env, napi_get_value_bool(env, argv[5], &check));
+    if (!typed(env, argv[6], napi_float64_array, &rhs, &nrhs) || !typed(env, argv[7], napi_int32_array, &rows, &nrows)) return NULL;
+    if (nt != nv || nv != nx) THROW(env, "relaxFrom: array lengths differ");
+    const int32_t offs[2] = {0, (int32_t)nt};
+    /* one node: the stride only has to cover the row capacity, which is what the host sized its arrays by */
+    const int32_t stride = (int32_t)(nrhs < nrows ? nrhs : nrows);
+    jslp_simplex_result r;
+    ENGINE_OK(env, L.relax_from(e, id, 1, offs, (const int8_t*)t, (const int32_t*)v, (const double*)x, check ? 1 : 0, &r,
+                                (double*)rhs, (int32_t*)rows, stride), "jslp_engine_relax_from");
+    return result_object(env, &r);
+}
+
 /* relaxBatch(h, Int32Array offsets, type, varIndex, value, checkCycles, rhsOut|null, rowsOut|null, stride) -> [result] */
 static napi_value fn_relax_batch(napi_env env, napi_callback_info info) {
     napi_value argv[9];
@@ -454,6 +517,8 @@ static napi_value init(napi_env env, napi_value exports) {
         {"simplex", fn_simplex}, {"pivot", fn_pivot}, {"save", fn_save}, {"restore", fn_restore},
         {"addCuts", fn_add_cuts}, {"relax", fn_relax}, {"relaxBatch", fn_relax_batch}, {"dims", fn_dims},
         {"readRhs", fn_read_rhs}, {"download", fn_download}, {"pivotTrace", fn_pivot_trace},
+        {"checkpointCreate", fn_checkpoint_create}, {"checkpointRestore", fn_checkpoint_restore},
+        {"checkpointRelease", fn_checkpoint_release}, {"relaxFrom", fn_relax_from},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -11,8 +11,9 @@
 // back: flags, evaluation, the RHS column and the row -> variable map (mip-utils.ts:43-61,100-126).
 //
 // Optional objectives (soft constraints, simplex.ts:221-263,394-412) travel with the tableau: their reducedCosts rows are
-// uploaded next to the matrix and read back after every simplex().  Out of the engine's scope (the reference's own
-// TypeScript path keeps running for these tableaus): MIR cuts (useMIRCuts) and the incremental B&B service.
+// uploaded next to the matrix and read back after every simplex().  The incremental B&B service (options.useIncremental)
+// runs over device-resident checkpoints (host/gpu-incremental-service.js) when install() is given the solver.  Out of
+// the engine's scope (the reference's own TypeScript path keeps running for these tableaus): MIR cuts (useMIRCuts).
 "use strict";
 const path = require("path");
 
@@ -22,6 +23,9 @@ const DEFAULT_LIBRARY = path.join(__dirname, "..", "jslpsolver_amd", "csrc", "li
 let addon = null;
 let backend = null;
 let bypass = 0; // > 0 while a Solve() that must stay on the reference's own path is running
+// extra cut rows for the incremental service: it stacks one row per tree level and never merges cuts on one variable
+// (incremental-branch-and-cut.ts:248-253); the reference reallocates, device memory is sized once
+const INCREMENTAL_EXTRA_ROWS = 256;
 
 function loadEngine(options) {
     const o = options || {};
@@ -40,7 +44,9 @@ function activate(t, opts) {
         return t.__gpu;
     }
     const nInts = t.model ? t.model.getNumberOfIntegerVariables() : 0;
-    const rowCapacity = t.height + 2 * nInts + 8; // <= one "min" and one "max" cut per integer variable
+    const incremental = !!(t.branchAndCutService && t.branchAndCutService.__gpuIncremental);
+    // <= one "min" and one "max" cut per integer variable for the services that start every node from the root
+    const rowCapacity = t.height + 2 * nInts + 8 + (incremental ? INCREMENTAL_EXTRA_ROWS : 0);
     const h = addon.create(t.height, t.width, rowCapacity, t.precision, opts.device || 0);
     const rows = Int32Array.from(t.varIndexByRow);
     const cols = Int32Array.from(t.varIndexByCol);
@@ -210,32 +216,100 @@ function install(Tableau, options) {
         st.pendingCuts = (st.pendingCuts || []).concat(cuts);
     };
 
-    // The incremental B&B service (options.useIncremental, src/tableau/incremental-branch-and-cut.ts:55-107) keeps
-    // parent checkpoints by copying tableau.matrix on the host: device-resident checkpoints are a later row
-    // (SURVEY.md 8f.1), so such solves stay on the reference's own path.  Pass the solver to have it guarded.
-    let origSolve = null;
+    // The reference's incremental B&B service (options.useIncremental, src/tableau/incremental-branch-and-cut.ts:55-107)
+    // checkpoints a parent by copying tableau.matrix on the host, which no Tableau method can intercept.  Given the
+    // solver, install() therefore answers its service selection (src/main.ts:62-83) with the same policy over device
+    // checkpoints; without the solver (or with MIR cuts) such a Solve stays wholly on the reference's own path.
+    let hadOwnSelect = false;
+    let origSelect = null;
     if (opts.solver) {
         const solver = opts.solver;
-        origSolve = solver.Solve;
-        solver.Solve = function (model) {
-            const keepOut = !!(model && model.options && model.options.useIncremental === true);
-            if (!keepOut) return origSolve.apply(this, arguments);
-            bypass += 1;
-            try {
-                return origSolve.apply(this, arguments);
-            } finally {
-                bypass -= 1;
+        const service = require("./gpu-incremental-service.js");
+        hadOwnSelect = Object.prototype.hasOwnProperty.call(solver, "selectBranchAndCutService");
+        origSelect = solver.selectBranchAndCutService;
+        solver.selectBranchAndCutService = function (model) {
+            const o = model && model.options;
+            if (o && o.useIncremental === true && !o.useMIRCuts) {
+                return service.createGpuIncrementalService(api, { nodeSelection: o.nodeSelection, branching: o.branching });
             }
+            return origSelect.call(this, model);
         };
     }
-
+    // without the solver the only safe thing for useIncremental is to keep the engine out: callers that cannot hand over
+    // the solver can still wrap Solve themselves with guardIncremental()
     return function uninstall() {
         P.simplex = orig.simplex;
         P.save = orig.save;
         P.restore = orig.restore;
         P.addCutConstraints = orig.addCutConstraints;
-        if (origSolve) opts.solver.Solve = origSolve;
+        if (opts.solver) {
+            if (hadOwnSelect) opts.solver.selectBranchAndCutService = origSelect;
+            else delete opts.solver.selectBranchAndCutService;
+        }
     };
+}
+
+// keep a useIncremental Solve entirely on the reference's CPU path (for hosts that install() without the solver)
+function guardIncremental(solver) {
+    const solve = solver.Solve;
+    solver.Solve = function (model) {
+        const keepOut = !!(model && model.options && model.options.useIncremental === true);
+        if (!keepOut) return solve.apply(this, arguments);
+        bypass += 1;
+        try {
+            return solve.apply(this, arguments);
+        } finally {
+            bypass -= 1;
+        }
+    };
+    return function unguard() {
+        solver.Solve = solve;
+    };
+}
+
+// ---- device-resident checkpoints (incremental-branch-and-cut.ts:31-107) -----------------------------------------------
+// createCheckpoint: the matrix and the maps stay in HBM; the host scalars of a StateCheckpoint ride along
+function createCheckpoint(t) {
+    const st = t.__gpu;
+    if (!st || !st.active) throw new Error("[gpu-tableau] createCheckpoint: tableau is not on the engine");
+    return {
+        id: addon.checkpointCreate(st.h),
+        height: t.height,
+        nVars: t.nVars,
+        lastElementIndex: t.lastElementIndex,
+        availableIndexes: t.availableIndexes.slice(),
+        evaluation: t.evaluation,
+        feasible: t.feasible,
+    };
+}
+
+// applyIncrementalCuts' fast path (:248-253): restoreCheckpoint + addCutConstraints(cuts) + simplex as ONE addon call
+function relaxFromCheckpoint(t, cp, cuts) {
+    const st = t.__gpu;
+    t.height = cp.height; // restoreCheckpoint's host side (:82-106); matrix + maps are restored on the device
+    t.nVars = cp.nVars;
+    t.lastElementIndex = cp.lastElementIndex;
+    t.availableIndexes = cp.availableIndexes.slice();
+    t.evaluation = cp.evaluation;
+    t.feasible = cp.feasible;
+    t.varIndexByRow.length = t.height;
+    st.pendingRestore = false;
+    st.pendingCuts = null;
+    t.addCutConstraints(cuts); // the override: slack bookkeeping, queues the cuts
+    const c = packCuts(st.pendingCuts || []);
+    st.pendingCuts = null;
+    const check = t.model ? t.model.checkForCycles === true : false;
+    const res = addon.relaxFrom(st.h, cp.id, c.type, c.varIndex, c.value, check, st.rhs, st.rows);
+    absorb(t, st, res);
+    return t;
+}
+
+function releaseCheckpoint(t, cp) {
+    const st = t.__gpu;
+    if (st && st.active && cp && cp.id >= 0) {
+        addon.checkpointRelease(st.h, cp.id);
+        cp.id = -1;
+    }
 }
 
 // Full read-back for `Solve(model, precision, full=true)` consumers and the post-solve editing API.
@@ -273,4 +347,8 @@ function release(t) {
     }
 }
 
-module.exports = { loadEngine, install, sync, pivotTrace, release, backend: () => backend };
+const api = {
+    loadEngine, install, sync, pivotTrace, release, guardIncremental, createCheckpoint, relaxFromCheckpoint, releaseCheckpoint,
+    backend: () => backend,
+};
+module.exports = api;

@@ -66,8 +66,8 @@ for (const f of fs.readdirSync(dir).filter((x) => x.endsWith(".json.gz") && x.in
     }
     if (bad.length) { fail += 1; console.log("FAIL", f, bad.join("; ")); } else { pass += 1; }
 }
-// options.nodeSelection / options.branching (enhanced service) run over the same overridden methods; options.useIncremental
-// is kept on the reference's own path by the binding: both must reproduce the unpatched reference
+// options.nodeSelection / options.branching (enhanced service) run over the same overridden methods and must reproduce
+// the unpatched reference
 let strategyOk = 0;
 for (const key of Object.keys(strategyBase)) {
     const f = key.slice(0, key.indexOf("{"));
@@ -78,5 +78,38 @@ for (const key of Object.keys(strategyBase)) {
     if (r === strategyBase[key]) strategyOk += 1;
     else { fail += 1; console.log("FAIL strategy", f, JSON.stringify(v)); }
 }
-console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk }));
+// options.useIncremental: host/gpu-incremental-service.js over device checkpoints against the reference's own incremental
+// service (tests/golden/incremental.json.gz): same pivots, same number of relaxations, same result
+let incrementalOk = 0, checkpointsTaken = 0;
+const incFile = path.join(root, "tests", "golden", "incremental.json.gz");
+if (!filter && dir.indexOf("fixtures") >= 0 && fs.existsSync(incFile)) {
+    const cases = JSON.parse(zlib.gunzipSync(fs.readFileSync(incFile)).toString());
+    for (const c of cases) {
+        if (c.iterations <= 1 && !(c.options.nodeSelection === "depth-first")) continue; // single-relaxation cases: a sample
+        const g = loadGolden(path.join(root, "tests", "golden"), c.file);
+        const m = JSON.parse(JSON.stringify(g.model));
+        m.options = Object.assign({}, c.options);
+        delete m.options.timeout; // wall-clock limits are not replayable; no golden run was ended by one
+        const solution = solver.Solve(m, undefined, true);
+        const res = solver.buildSimplifiedResult(solution);
+        const got = {};
+        for (const k of Object.keys(res)) got[k] = num(res[k]);
+        const bad = [];
+        if (JSON.stringify(Object.keys(res)) !== JSON.stringify(c.resultKeys)) bad.push("keys");
+        if (JSON.stringify(got) !== JSON.stringify(c.result)) bad.push("values");
+        const trace = gpu.pivotTrace(solution._tableau);
+        if (!trace) bad.push("not on the engine");
+        else {
+            if (trace.length / 2 !== c.nPivots) bad.push("pivot count " + trace.length / 2 + " != " + c.nPivots);
+            else if (digest(trace) !== c.pivotDigest) bad.push("pivot digest");
+            if (solution._tableau.branchAndCutIterations !== c.iterations) bad.push("B&B iterations");
+            checkpointsTaken += solution._tableau.__gpuCheckpoints || 0;
+            gpu.release(solution._tableau);
+        }
+        if (bad.length) { fail += 1; console.log("FAIL incremental", c.file, JSON.stringify(c.options), bad.join("; ")); }
+        else incrementalOk += 1;
+    }
+}
+console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk,
+    incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);

@@ -147,6 +147,29 @@ int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, const int32_
                                    jslp_simplex_result* out, const double** rhs, const int32_t** var_index_by_row,
                                    int32_t* out_stride);
 
+/*
+ * Device-resident checkpoints: the StateCheckpoint of the incremental branch-and-bound service
+ * (src/tableau/incremental-branch-and-cut.ts:31-44).  createCheckpoint (:55-70) copies the live matrix, the four index
+ * maps, height and lastElementIndex; restoreCheckpoint (:72-107) puts them back.  Exactly like the reference, a
+ * checkpoint does NOT carry the optional-objective rows or the saved root (restoring one leaves both untouched); the
+ * host keeps `evaluation` / `feasible` (:42-43) next to the id, the engine remembers `evaluation` for the "kept when not
+ * optimal" rule.  Checkpoints live in HBM (H x W x 8 bytes each; 288 GB hold thousands) until released, the next
+ * upload() or destroy().
+ */
+int jslp_engine_checkpoint_create(jslp_engine* e, int32_t* id_out);
+int jslp_engine_checkpoint_restore(jslp_engine* e, int32_t id);
+int jslp_engine_checkpoint_release(jslp_engine* e, int32_t id);
+
+/*
+ * applyIncrementalCuts' fast path (incremental-branch-and-cut.ts:248-253) for the children of one parent: every node
+ * = restoreCheckpoint(checkpoint) + addCutConstraints(its cuts, normally the single new cut) + simplex() + the
+ * read-back of jslp_engine_relax_batch.  checkpoint = -1 starts from the saved root instead (= relax_batch, the
+ * fallback path :254-258).  The live tableau is left holding the LAST node.
+ */
+int jslp_engine_relax_from(jslp_engine* e, int32_t checkpoint, int32_t n_nodes, const int32_t* cut_offsets,
+                           const int8_t* type, const int32_t* var_index, const double* value, int check_cycles,
+                           jslp_simplex_result* out, double* rhs, int32_t* var_index_by_row, int32_t out_stride);
+
 /* Current dimensions (height grows with cuts, restore() puts it back). */
 int jslp_engine_dims(const jslp_engine* e, int32_t* height, int32_t* width, int32_t* n_var_indexes);
 
@@ -170,8 +193,8 @@ int jslp_engine_pivot_trace(jslp_engine* e, int32_t* row_col, int64_t max_pairs,
 
 /*
  * Which launch shape the last simplex() / relax() used: "workgroup" (one workgroup per tableau), "select+update"
- * (two chip-wide launches per pivot), "fused" (one launch per phase-2 pivot) or "resident" (register-resident
- * phase 2 in one cooperative launch); "oracle" for the test library, "none" before the first solve.
+ * (two chip-wide launches per pivot), "fused" (one launch per phase-2 pivot) or "resident" (the whole simplex() on a
+ * register-resident tableau in one cooperative launch); "oracle" for the test library, "none" before the first solve.
  */
 const char* jslp_engine_last_path(const jslp_engine* e);
 

@@ -61,6 +61,17 @@ struct jslp_engine {
     double* h_rhs = nullptr; int32_t* h_rows = nullptr; DevState* h_states = nullptr;
     size_t out_cap = 0;  // nodes
     DevState* h_state = nullptr;  // pinned, 1 entry
+    // checkpoints (incremental-branch-and-cut.ts:31-44): equally sized device buffers, recycled through a free list
+    struct Ckpt {
+        char* mem = nullptr;
+        double* A = nullptr;
+        int32_t *vibr = nullptr, *vibc = nullptr, *rbv = nullptr, *cbv = nullptr;
+        int32_t H = 0, last_element_index = 0;
+        double evaluation = 0;
+        int live = 0;
+    };
+    std::vector<Ckpt> ckpts;
+    std::vector<char*> ck_free;
     // policy
     int force_path = 0;  // 0 auto, 1 workgroup kernel, 2 select+update kernels only, 3 fused phase 2
     int32_t n_unr = 0;
@@ -183,6 +194,17 @@ static int ensure_slots(jslp_engine* e, int n) {
     return JSLP_OK;
 }
 
+// forget every checkpoint; their buffers go to the free list (or back to the driver)
+static void drop_checkpoints(jslp_engine* e, int free_memory) {
+    for (auto& c : e->ckpts)
+        if (c.live) e->ck_free.push_back(c.mem);
+    e->ckpts.clear();
+    if (free_memory) {
+        for (char* m : e->ck_free) hipFree(m);
+        e->ck_free.clear();
+    }
+}
+
 extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height, int32_t width, int32_t row_capacity,
                                   double precision) {
     if (!out || height < 1 || width < 1 || row_capacity < height) return fail(JSLP_ERR_ARG, "create: bad dimensions");
@@ -250,6 +272,7 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     free_slots(e);
     hipFree(e->static_arena); hipFree(e->snap_oo);
+    drop_checkpoints(e, 1);
     hipFree(e->f_buf1); hipFree(e->f_cands[0]); hipFree(e->f_cands[1]); hipFree(e->f_pcol[0]); hipFree(e->f_pcol[1]);
     hipFree(e->f_st[0]); hipFree(e->f_st[1]);
     hipFree(e->r_gran); hipFree(e->r_rows[0]); hipFree(e->r_rows[1]); hipFree(e->r_sync);
@@ -310,6 +333,7 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
     HIPC(hipStreamSynchronize(s));  // the host vectors die here
     e->uploaded = 1;
     e->has_save = 0;
+    drop_checkpoints(e, 0);
     e->evaluation = 0;
     e->n_unr = n_unrestricted;
     e->s.has_unr = n_unrestricted > 0 ? 1 : 0;
@@ -699,12 +723,86 @@ extern "C" int jslp_engine_save(jslp_engine* e) {
     return JSLP_OK;
 }
 
-static int enqueue_restore(jslp_engine* e, int first_slot, int n) {
-    if (!e->has_save) return JSLP_OK;  // backup.ts:54-56
-    Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo};
-    hipLaunchKernelGGL(k_restore, copy_grid(e, n), dim3(256), 0, e->stream, e->s, sn, first_slot);
-    hipLaunchKernelGGL(k_restore_commit, dim3(n), dim3(1), 0, e->stream, e->s, first_slot);
+// restore slots [first_slot, first_slot + n) from the saved root (checkpoint < 0) or from a checkpoint
+static int enqueue_restore(jslp_engine* e, int first_slot, int n, int checkpoint = -1) {
+    if (checkpoint < 0) {
+        if (!e->has_save) return JSLP_OK;  // backup.ts:54-56
+        Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0};
+        hipLaunchKernelGGL(k_restore, copy_grid(e, n), dim3(256), 0, e->stream, e->s, sn, first_slot);
+    } else {
+        const jslp_engine::Ckpt& c = e->ckpts[checkpoint];
+        Snapshot sn{c.A, c.vibr, c.vibc, c.rbv, c.cbv, e->n_idx, nullptr, c.H, c.last_element_index};
+        hipLaunchKernelGGL(k_restore, copy_grid(e, n), dim3(256), 0, e->stream, e->s, sn, first_slot);
+    }
+    hipLaunchKernelGGL(k_restore_commit, dim3(n), dim3(1), 0, e->stream, e->s, first_slot, checkpoint < 0 ? 1 : 0);
     HIPC(hipGetLastError());
+    return JSLP_OK;
+}
+
+static int checkpoint_check(const jslp_engine* e, int32_t id, const char* who) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "%s%s", who, ": before upload");
+    if (id < 0 || id >= (int32_t)e->ckpts.size() || !e->ckpts[id].live) return fail(JSLP_ERR_ARG, "%s%s", who, ": no such checkpoint");
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_checkpoint_create(jslp_engine* e, int32_t* id_out) {
+    if (!e || !id_out) return fail(JSLP_ERR_ARG, "checkpoint_create: null pointer");
+    if (!e->uploaded) return fail(JSLP_ERR_STATE, "checkpoint_create before upload");
+    HIPC(hipSetDevice(e->device));
+    // height / lastElementIndex of the live tableau
+    HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    HIPC(hipStreamSynchronize(e->stream));
+    jslp_engine::Ckpt c;
+    for (int pass = 0; pass < 2; pass++) {  // every buffer is sized for the row capacity, so freed ones fit any later checkpoint
+        Carver cv{pass ? c.mem : nullptr, 0};
+        c.A = cv.take<double>((size_t)e->cap_rows * e->ld);
+        c.vibr = cv.take<int32_t>((size_t)e->cap_rows);
+        c.vibc = cv.take<int32_t>((size_t)e->W);
+        c.rbv = cv.take<int32_t>((size_t)e->n_idx);
+        c.cbv = cv.take<int32_t>((size_t)e->n_idx);
+        if (!pass) {
+            if (!e->ck_free.empty()) {
+                c.mem = e->ck_free.back();
+                e->ck_free.pop_back();
+            } else if (hipMalloc(&c.mem, cv.off + 256) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(JSLP_ERR_NOMEM, "checkpoint_create: out of device memory");
+            }
+        }
+    }
+    c.H = e->h_state->H;
+    c.last_element_index = e->h_state->last_element_index;
+    c.evaluation = e->evaluation;
+    c.live = 1;
+    SnapshotW w{c.A, c.vibr, c.vibc, c.rbv, c.cbv, e->n_idx, nullptr};
+    hipLaunchKernelGGL(k_checkpoint, dim3(copy_grid(e, 1).x), dim3(256), 0, e->stream, e->s, w, (int)c.H);
+    HIPC(hipGetLastError());
+    int32_t id = -1;
+    for (size_t i = 0; i < e->ckpts.size(); i++)
+        if (!e->ckpts[i].live) { id = (int32_t)i; break; }
+    if (id < 0) { id = (int32_t)e->ckpts.size(); e->ckpts.push_back(c); } else e->ckpts[id] = c;
+    *id_out = id;
+    return JSLP_OK;  // stream-ordered: no synchronisation needed before the next engine call
+}
+
+extern "C" int jslp_engine_checkpoint_restore(jslp_engine* e, int32_t id) {
+    int rc = checkpoint_check(e, id, "checkpoint_restore");
+    if (rc) return rc;
+    HIPC(hipSetDevice(e->device));
+    rc = enqueue_restore(e, 0, 1, id);
+    if (rc) return rc;
+    HIPC(hipStreamSynchronize(e->stream));
+    e->evaluation = e->ckpts[id].evaluation;  // incremental-branch-and-cut.ts:105
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_checkpoint_release(jslp_engine* e, int32_t id) {
+    int rc = checkpoint_check(e, id, "checkpoint_release");
+    if (rc) return rc;
+    HIPC(hipSetDevice(e->device));
+    HIPC(hipStreamSynchronize(e->stream));  // a restore from it may still be in flight
+    e->ck_free.push_back(e->ckpts[id].mem);
+    e->ckpts[id] = jslp_engine::Ckpt();
     return JSLP_OK;
 }
 
@@ -805,13 +903,18 @@ extern "C" int jslp_engine_read_rhs(jslp_engine* e, double* rhs, int32_t* var_in
 static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
                             const int32_t* var_index, const double* value, int check_cycles, jslp_simplex_result* out,
                             double* rhs, int32_t* var_index_by_row, int32_t out_stride, int pinned, int want_rhs,
-                            int want_rows) {
+                            int want_rows, int checkpoint = -1) {
     if (!e || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "relax_batch: null pointer");
     if (!e->uploaded) return fail(JSLP_ERR_STATE, "relax before upload");
+    if (checkpoint >= 0) {
+        int rc0 = checkpoint_check(e, checkpoint, "relax_from");
+        if (rc0) return rc0;
+    }
     if (!pinned && (rhs || var_index_by_row) && out_stride < e->cap_rows)
         return fail(JSLP_ERR_ARG, "relax_batch: out_stride < row capacity");
     if (n_nodes == 0) return JSLP_OK;
-    if (n_nodes > 1 && !e->has_save) return fail(JSLP_ERR_STATE, "relax_batch: several nodes need a saved root (save() first)");
+    if (n_nodes > 1 && !e->has_save && checkpoint < 0)
+        return fail(JSLP_ERR_STATE, "relax_batch: several nodes need a saved root (save() first)");
     HIPC(hipSetDevice(e->device));
     int rc = upload_cuts(e, n_nodes, cut_offsets, type, var_index, value);
     if (rc) return rc;
@@ -822,8 +925,10 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     // branch-and-bound children (a saved root exists) need a handful of repair pivots each: one workgroup, one launch,
     // no host round trip.  A first solve / plain LP goes through the chip-wide path unless the tableau is tiny.
     const bool wg = e->force_path == 1 ||
-                    (e->force_path == 0 && ((e->has_save && cells <= (n_nodes > 1 ? WG_CELLS_BATCH : WG_CELLS_CHILD)) || use_wg_single(e)));
-    const double prev_eval = e->evaluation;
+                    (e->force_path == 0 && (((e->has_save || checkpoint >= 0) && cells <= (n_nodes > 1 ? WG_CELLS_BATCH : WG_CELLS_CHILD)) || use_wg_single(e)));
+    // a node that does not reach an optimum keeps the evaluation it started with: the checkpoint's (restoreCheckpoint,
+    // incremental-branch-and-cut.ts:105) or the live one (restore() leaves it alone)
+    const double prev_eval = checkpoint >= 0 ? e->ckpts[checkpoint].evaluation : e->evaluation;
     // group size: bounded by memory (<= 8 GiB of tableau copies) and by what fills the chip twice over
     int group = 1;
     if (wg) {
@@ -837,7 +942,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     if (e->timing) HIPC(hipEventRecord(e->ev_begin, s));
     for (int first = 0; first < n_nodes; first += group) {
         const int g = std::min(group, n_nodes - first);
-        rc = enqueue_restore(e, 0, g);
+        rc = enqueue_restore(e, 0, g, checkpoint);
         if (rc) return rc;
         hipLaunchKernelGGL(k_add_cuts, dim3(g), dim3(256), 0, s, e->s, cu, 0, first, (int)e->cap_rows);
         HIPC(hipGetLastError());
@@ -910,6 +1015,14 @@ extern "C" int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, c
     if (var_index_by_row) *var_index_by_row = n_nodes > 0 ? e->h_rows : nullptr;
     if (out_stride) *out_stride = e->cap_rows;
     return JSLP_OK;
+}
+
+extern "C" int jslp_engine_relax_from(jslp_engine* e, int32_t checkpoint, int32_t n_nodes, const int32_t* cut_offsets,
+                                      const int8_t* type, const int32_t* var_index, const double* value, int check_cycles,
+                                      jslp_simplex_result* out, double* rhs, int32_t* var_index_by_row,
+                                      int32_t out_stride) {
+    return relax_batch_impl(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, rhs, var_index_by_row,
+                            out_stride, 0, rhs != nullptr, var_index_by_row != nullptr, checkpoint < 0 ? -1 : checkpoint);
 }
 
 extern "C" int jslp_engine_relax(jslp_engine* e, int32_t n_cuts, const int8_t* type, const int32_t* var_index,

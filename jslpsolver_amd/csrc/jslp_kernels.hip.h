@@ -663,19 +663,29 @@ __global__ void __launch_bounds__(JSLP_WG_THREADS) k_simplex_wg(Slots s, int fir
     }
 }
 
+struct SnapshotW {
+    double* A;
+    int32_t *vibr, *vibc, *rbv, *cbv;
+    int32_t n_idx;
+    double* oo;
+};
 // restore (backup.ts:53-105): snapshot -> slots [first_slot, first_slot+gridDim.y).  Grid-stride copy.
 struct Snapshot {
     const double* A;
     const int32_t *vibr, *vibc, *rbv, *cbv;
     int32_t n_idx;
-    const double* oo;  // n_opt * ld
+    const double* oo;  // n_opt * ld; nullptr = leave the optional objectives alone (restoreCheckpoint does)
+    // H < 0: the saved root (scalars in slot 0's DevState).  Otherwise a checkpoint (incremental-branch-and-cut.ts:72-107)
+    // with its own scalars; the dirty-row shortcut does not apply to it.
+    int32_t H, last_element_index;
 };
 __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int first_slot) {
     const int slot = first_slot + blockIdx.y;
     DevState* st = s.st + slot;
-    const int H = s.st[0].s_H;  // every slot shares slot 0's snapshot scalars
+    const bool root = snap.H < 0;
+    const int H = root ? s.st[0].s_H : snap.H;  // every slot shares slot 0's snapshot scalars
     const int gen = s.st[0].s_gen;
-    const bool incremental = gen != 0 && st->gen == gen;  // this slot already holds the snapshot except for its dirty rows
+    const bool incremental = root && gen != 0 && st->gen == gen;  // this slot already holds the snapshot except for its dirty rows
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long long)gridDim.x * blockDim.x;
     const double2* src = reinterpret_cast<const double2*>(snap.A);
     double2* dst = reinterpret_cast<double2*>(s.A + (long long)slot * s.A_stride);
@@ -704,29 +714,36 @@ __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int fir
     int32_t* rbv = s.rbv + (long long)slot * s.idx_stride;
     int32_t* cbv = s.cbv + (long long)slot * s.idx_stride;
     for (long long i = tid; i < snap.n_idx; i += nt) { rbv[i] = snap.rbv[i]; cbv[i] = snap.cbv[i]; }
-    if (s.n_opt > 0) {  // backup.ts:94-104
+    if (s.n_opt > 0 && snap.oo) {  // backup.ts:94-104
         double* oo = s.oo + (long long)slot * s.oo_stride;
         for (long long i = tid; i < s.oo_stride; i += nt) oo[i] = snap.oo[i];
     }
     if (tid == 0) {
         st->H = H;
-        st->last_element_index = s.st[0].s_last_element_index;
+        st->last_element_index = root ? s.st[0].s_last_element_index : snap.last_element_index;
         st->err = ERR_NONE;
     }
 }
-// second half of restore(): record that the slots are in sync (a separate tiny launch: k_restore's workgroups all
-// read st->gen, so none of them may write it)
-__global__ void k_restore_commit(Slots s, int first_slot) {
-    s.st[first_slot + blockIdx.x].gen = s.st[0].s_gen;
+// second half of restore(): record that the slots are in sync with the saved root (a separate tiny launch: k_restore's
+// workgroups all read st->gen, so none of them may write it); after a checkpoint restore they are in sync with nothing
+__global__ void k_restore_commit(Slots s, int first_slot, int from_root) {
+    s.st[first_slot + blockIdx.x].gen = from_root ? s.st[0].s_gen : 0;
+}
+
+// createCheckpoint (incremental-branch-and-cut.ts:55-70): slot 0 -> a checkpoint buffer; the snapshot generation and the
+// saved root are not touched
+__global__ void __launch_bounds__(256) k_checkpoint(Slots s, SnapshotW ck, int H) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long long)gridDim.x * blockDim.x;
+    const long long n2 = (long long)H * s.ld / 2;
+    const double2* src = reinterpret_cast<const double2*>(s.A);
+    double2* dst = reinterpret_cast<double2*>(ck.A);
+    for (long long i = tid; i < n2; i += nt) dst[i] = src[i];
+    for (long long i = tid; i < H; i += nt) ck.vibr[i] = s.vibr[i];
+    for (long long i = tid; i < s.W; i += nt) ck.vibc[i] = s.vibc[i];
+    for (long long i = tid; i < ck.n_idx; i += nt) { ck.rbv[i] = s.rbv[i]; ck.cbv[i] = s.cbv[i]; }
 }
 
 // save (backup.ts:13-51): slot 0 -> snapshot
-struct SnapshotW {
-    double* A;
-    int32_t *vibr, *vibc, *rbv, *cbv;
-    int32_t n_idx;
-    double* oo;
-};
 __global__ void __launch_bounds__(256) k_save(Slots s, SnapshotW snap) {
     DevState* st = s.st;
     const int H = st->H;

@@ -164,6 +164,44 @@ class Tableau:
         vibr = np.ctypeslib.as_array(p_rows, shape=shape) if want_rows else None
         return out, rhs, vibr
 
+    # ---- checkpoints (incremental-branch-and-cut.ts:31-107) -------------------------------------------
+    def createCheckpoint(self):
+        """createCheckpoint (:55-70): the matrix and the index maps stay in HBM; the host part of a StateCheckpoint
+        (`evaluation`, `feasible`, :42-43) travels in the returned dict."""
+        cid = _capi.C.c_int32(-1)
+        self.lib.check(self.lib.jslp_engine_checkpoint_create(self._h, _capi.C.byref(cid)), "jslp_engine_checkpoint_create")
+        return {"id": cid.value, "evaluation": self.evaluation, "feasible": self.feasible}
+
+    def restoreCheckpoint(self, checkpoint):
+        """restoreCheckpoint (:72-107)"""
+        self.lib.check(self.lib.jslp_engine_checkpoint_restore(self._h, checkpoint["id"]), "jslp_engine_checkpoint_restore")
+        self.evaluation = checkpoint["evaluation"]
+        self.feasible = checkpoint["feasible"]
+
+    def releaseCheckpoint(self, checkpoint):
+        self.lib.check(self.lib.jslp_engine_checkpoint_release(self._h, checkpoint["id"]), "jslp_engine_checkpoint_release")
+
+    def applyCutsFrom(self, checkpoint, cut_lists, check_cycles=True):
+        """applyIncrementalCuts' fast path (:248-253) for one or more children of `checkpoint` in ONE engine call:
+        restoreCheckpoint + addCutConstraints(cuts) + simplex + read-back per node.  Returns per node
+        (result, rhs, varIndexByRow); the tableau scalars end as after the LAST node."""
+        n_nodes, offs, t, v, x = self.pack_cut_lists(cut_lists)
+        out = (SimplexResult * max(n_nodes, 1))()
+        stride = self.row_capacity
+        rhs = np.empty((max(n_nodes, 1), stride), dtype=np.float64)
+        vibr = np.empty((max(n_nodes, 1), stride), dtype=np.int32)
+        self.lib.check(self.lib.jslp_engine_relax_from(self._h, checkpoint["id"], n_nodes, _capi.ptr_i32(offs),
+                                                       _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x),
+                                                       int(bool(check_cycles)), out, _capi.ptr_f64(rhs),
+                                                       _capi.ptr_i32(vibr), stride), "jslp_engine_relax_from")
+        return [(out[i], rhs[i, :out[i].height], vibr[i, :out[i].height]) for i in range(n_nodes)]
+
+    def absorb_from(self, checkpoint, res):
+        """the tableau scalars after restoreCheckpoint(checkpoint) + simplex() with outcome `res`"""
+        self.evaluation = checkpoint["evaluation"]
+        self.feasible = checkpoint["feasible"]
+        return self._absorb(res)
+
     # ---- read-back --------------------------------------------------------------------------------
     def read_rhs(self):
         h = self.height

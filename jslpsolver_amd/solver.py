@@ -35,6 +35,13 @@ def Solve(model, precision=None, full=False, validate=False, lib=None, device=0,
     n_int = len(m.integerVariables)
     # cut rows: at most one "min" and one "max" cut per integer variable (branch-and-cut.ts:166-179)
     extra = 2 * n_int if row_capacity_extra is None else row_capacity_extra
+    incremental = n_int > 0 and (m.options.get("useIncremental") is True)
+    if incremental and row_capacity_extra is None:
+        # the incremental service stacks ONE row per tree level on the parent's tableau and never merges cuts on the
+        # same variable (incremental-branch-and-cut.ts:248-253), so its height is bounded by the depth of the tree, not
+        # by the number of integer variables; the reference reallocates (cutting-strategies.ts:24-30), device memory
+        # is sized once -- a deeper tree fails loudly with JSLP_ERR_CAPACITY (pass row_capacity_extra)
+        extra = 2 * n_int + 256
     _priorities, optional_rows = m.optional_objectives()
     t = Tableau(matrix, vibr, vibc, m.unrestricted, precision=m.precision, row_capacity=matrix.shape[0] + extra,
                 device=device, lib=lib, optional_objectives=optional_rows)
@@ -45,7 +52,13 @@ def Solve(model, precision=None, full=False, validate=False, lib=None, device=0,
         if group is not None:
             from .sharding import make_sharded_evaluator
             evaluate = make_sharded_evaluator(t, m.checkForCycles, group)
-        iterations, integral = branch_and_cut(t, m, speculate=speculate, evaluate_batch=evaluate)
+        if incremental:  # selectBranchAndCutService (main.ts:62-72)
+            from .incremental_branch_and_cut import incremental_branch_and_cut
+            iterations, integral = incremental_branch_and_cut(
+                t, m, node_selection=m.options.get("nodeSelection") or "hybrid",
+                branching=m.options.get("branching") or "pseudocost")
+        else:
+            iterations, integral = branch_and_cut(t, m, speculate=speculate, evaluate_batch=evaluate)
     else:
         t.simplex(check_cycles=m.checkForCycles)
     rhs, rows = t.read_rhs()
@@ -69,6 +82,7 @@ def Solve(model, precision=None, full=False, validate=False, lib=None, device=0,
     if full:
         fm, fvibr, fvibc, _, _ = t.download()
         result = {"result": result, "solutionSet": solution_set, "matrix": fm, "varIndexByRow": fvibr,
-                  "varIndexByCol": fvibc, "iter": iterations, "pivots": t.pivot_trace(), "model": m}
+                  "varIndexByCol": fvibc, "iter": iterations, "pivots": t.pivot_trace(), "model": m,
+                  "checkpoints": getattr(t, "checkpoints_used", 0), "incrementalNodes": getattr(t, "incremental_nodes", 0)}
     t.close()
     return result

@@ -48,7 +48,29 @@ struct jslp_engine {
     double* oo;
     double* s_oo;
     int32_t* defer; /* optionalCostsColumns scratch (simplex.ts:132-134) */
+    /* StateCheckpoint list (incremental-branch-and-cut.ts:31-44) */
+    struct checkpoint* ck;
+    int32_t n_ck;
 };
+
+struct checkpoint {
+    int live;
+    int32_t height, last_element_index;
+    double evaluation;
+    double* matrix;
+    int32_t *vibr, *vibc, *rbv, *cbv;
+};
+
+static void checkpoint_free(struct checkpoint* c) {
+    free(c->matrix); free(c->vibr); free(c->vibc); free(c->rbv); free(c->cbv);
+    memset(c, 0, sizeof *c);
+}
+static void checkpoints_clear(jslp_engine* e) {
+    for (int32_t i = 0; i < e->n_ck; i++) checkpoint_free(&e->ck[i]);
+    free(e->ck);
+    e->ck = 0;
+    e->n_ck = 0;
+}
 
 static __thread char g_err[256];
 static int fail(int code, const char* msg) {
@@ -103,6 +125,7 @@ void jslp_engine_destroy(jslp_engine* e) {
     free(e->rbv); free(e->cbv); free(e->s_rbv); free(e->s_cbv); free(e->unrestricted); free(e->nz);
     free(e->trace);
     free(e->oo); free(e->s_oo); free(e->defer);
+    checkpoints_clear(e);
     free(e);
 }
 
@@ -136,6 +159,7 @@ int jslp_engine_upload(jslp_engine* e, const double* matrix, const int32_t* var_
     }
     e->last_element_index = W + H - 2; /* tableau.ts:312-316 */
     e->has_save = 0;
+    checkpoints_clear(e);
     e->feasible = 1;
     e->bounded = 1;
     e->evaluation = 0;
@@ -665,6 +689,91 @@ int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, const int32_
     if (rhs) *rhs = b_rhs;
     if (var_index_by_row) *var_index_by_row = b_rows;
     if (out_stride) *out_stride = e->cap_rows;
+    return JSLP_OK;
+}
+
+/* createCheckpoint (incremental-branch-and-cut.ts:55-70) */
+int jslp_engine_checkpoint_create(jslp_engine* e, int32_t* id_out) {
+    if (!e || !id_out) return fail(JSLP_ERR_ARG, "checkpoint_create: null");
+    if (!e->uploaded) return fail(JSLP_ERR_STATE, "checkpoint before upload");
+    int32_t id = -1;
+    for (int32_t i = 0; i < e->n_ck; i++)
+        if (!e->ck[i].live) { id = i; break; }
+    if (id < 0) {
+        struct checkpoint* g = (struct checkpoint*)realloc(e->ck, (size_t)(e->n_ck + 1) * sizeof *g);
+        if (!g) return fail(JSLP_ERR_NOMEM, "checkpoint_create: out of memory");
+        e->ck = g;
+        id = e->n_ck++;
+        memset(&e->ck[id], 0, sizeof e->ck[id]);
+    }
+    struct checkpoint* c = &e->ck[id];
+    const size_t cells = (size_t)e->height * e->width;
+    c->matrix = (double*)malloc(cells * sizeof(double));
+    c->vibr = (int32_t*)malloc((size_t)e->height * sizeof(int32_t));
+    c->vibc = (int32_t*)malloc((size_t)e->width * sizeof(int32_t));
+    c->rbv = (int32_t*)malloc((size_t)e->n_idx_cap * sizeof(int32_t));
+    c->cbv = (int32_t*)malloc((size_t)e->n_idx_cap * sizeof(int32_t));
+    if (!c->matrix || !c->vibr || !c->vibc || !c->rbv || !c->cbv) {
+        checkpoint_free(c);
+        return fail(JSLP_ERR_NOMEM, "checkpoint_create: out of memory");
+    }
+    memcpy(c->matrix, e->matrix, cells * sizeof(double));
+    memcpy(c->vibr, e->vibr, (size_t)e->height * sizeof(int32_t));
+    memcpy(c->vibc, e->vibc, (size_t)e->width * sizeof(int32_t));
+    memcpy(c->rbv, e->rbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+    memcpy(c->cbv, e->cbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+    c->height = e->height;
+    c->last_element_index = e->last_element_index;
+    c->evaluation = e->evaluation;
+    c->live = 1;
+    *id_out = id;
+    return JSLP_OK;
+}
+
+/* restoreCheckpoint (incremental-branch-and-cut.ts:72-107): optional objectives and the saved root stay as they are */
+int jslp_engine_checkpoint_restore(jslp_engine* e, int32_t id) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "checkpoint_restore before upload");
+    if (id < 0 || id >= e->n_ck || !e->ck[id].live) return fail(JSLP_ERR_ARG, "checkpoint_restore: no such checkpoint");
+    const struct checkpoint* c = &e->ck[id];
+    e->height = c->height;
+    e->last_element_index = c->last_element_index;
+    e->evaluation = c->evaluation;
+    memcpy(e->matrix, c->matrix, (size_t)c->height * e->width * sizeof(double));
+    memcpy(e->vibr, c->vibr, (size_t)c->height * sizeof(int32_t));
+    memcpy(e->vibc, c->vibc, (size_t)e->width * sizeof(int32_t));
+    memcpy(e->rbv, c->rbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+    memcpy(e->cbv, c->cbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+    return JSLP_OK;
+}
+
+int jslp_engine_checkpoint_release(jslp_engine* e, int32_t id) {
+    if (!e) return fail(JSLP_ERR_ARG, "checkpoint_release: null");
+    if (id < 0 || id >= e->n_ck || !e->ck[id].live) return fail(JSLP_ERR_ARG, "checkpoint_release: no such checkpoint");
+    checkpoint_free(&e->ck[id]);
+    return JSLP_OK;
+}
+
+/* applyIncrementalCuts (incremental-branch-and-cut.ts:246-259), one node after the other */
+int jslp_engine_relax_from(jslp_engine* e, int32_t checkpoint, int32_t n_nodes, const int32_t* cut_offsets,
+                           const int8_t* type, const int32_t* var_index, const double* value, int check_cycles,
+                           jslp_simplex_result* out, double* rhs, int32_t* var_index_by_row, int32_t out_stride) {
+    if (checkpoint < 0)
+        return jslp_engine_relax_batch(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, rhs,
+                                       var_index_by_row, out_stride);
+    if (!e || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "relax_from: null");
+    if ((rhs || var_index_by_row) && out_stride < e->cap_rows) return fail(JSLP_ERR_ARG, "relax_from: out_stride < row capacity");
+    for (int32_t i = 0; i < n_nodes; i++) {
+        const int32_t a = cut_offsets[i], n = cut_offsets[i + 1] - a;
+        int rc = jslp_engine_checkpoint_restore(e, checkpoint);
+        if (rc) return rc;
+        rc = jslp_engine_add_cuts(e, n, type ? type + a : 0, var_index ? var_index + a : 0, value ? value + a : 0);
+        if (rc) return rc;
+        rc = jslp_engine_simplex(e, check_cycles, &out[i]);
+        if (rc) return rc;
+        rc = jslp_engine_read_rhs(e, rhs ? rhs + (size_t)i * out_stride : 0,
+                                  var_index_by_row ? var_index_by_row + (size_t)i * out_stride : 0);
+        if (rc) return rc;
+    }
     return JSLP_OK;
 }
 

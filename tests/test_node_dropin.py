@@ -38,15 +38,18 @@ def test_addon_exports_the_abi():
     out = subprocess.run(["node", "-e", "console.log(Object.keys(require(%r)).sort().join(','))" % ADDON],
                          capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
-    assert out.stdout.strip() == ("addCuts,create,destroy,deviceCount,dims,download,getOptionalObjectives,load,pivot,"
-                                  "pivotTrace,readRhs,relax,relaxBatch,restore,save,setOptionalObjectives,simplex,upload")
+    assert out.stdout.strip() == ("addCuts,checkpointCreate,checkpointRelease,checkpointRestore,create,destroy,deviceCount,"
+                                  "dims,download,getOptionalObjectives,load,pivot,pivotTrace,readRhs,relax,relaxBatch,"
+                                  "relaxFrom,restore,save,setOptionalObjectives,simplex,upload")
 
 
 def test_reference_host_with_oracle_engine(oracle_lib):
     _prepare()
     r = _run(oracle_lib.path, "fixtures")
     assert r["backend"] == "oracle-c" and r["fail"] == 0 and r["pass"] == 47 and r["solved_on_engine"] >= 43
-    assert r["strategy_variants_ok"] == 30  # enhanced B&B services over the same seam; incremental kept on the TS path
+    assert r["strategy_variants_ok"] == 30  # enhanced B&B services over the same seam
+    # options.useIncremental: the reference's policy over device checkpoints (host/gpu-incremental-service.js)
+    assert r["incremental_ok"] >= 100 and r["device_checkpoints"] > 300
     r = _run(oracle_lib.path, "synthetic", "40x")
     assert r["fail"] == 0 and r["pass"] >= 12
 
@@ -57,5 +60,6 @@ def test_reference_host_with_hip_engine(hip_lib):
     r = _run(hip_lib.path, "fixtures")
     assert r["backend"] == "hip-gfx950" and r["fail"] == 0 and r["pass"] == 47 and r["solved_on_engine"] >= 43
     assert r["strategy_variants_ok"] == 30
+    assert r["incremental_ok"] >= 100 and r["device_checkpoints"] > 300
     r = _run(hip_lib.path, "synthetic", "_")
     assert r["fail"] == 0 and r["pass"] >= 40
