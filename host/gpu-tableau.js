@@ -195,12 +195,11 @@ function install(Tableau, options) {
         const height = this.height;
         const heightWithCuts = height + n;
         if (heightWithCuts > st.rowCapacity) throw new Error("[gpu-tableau] cut rows exceed the engine's row capacity");
-        const newSize = heightWithCuts * this.width;
-        if (this.matrix.length < newSize) {
-            const grown = new Float64Array(newSize);
-            grown.set(this.matrix);
-            this.matrix = grown;
-        }
+        // The reference grows the host matrix by reallocating and copying it (cutting-strategies.ts:24-30).  With the
+        // tableau on the device only the RHS column of the host copy is live, and absorb() rewrites it for every row
+        // after each simplex(): size the host array once for the row capacity and skip the copy (22 MB per new tree
+        // depth on Vendor Selection).
+        if (this.matrix.length < heightWithCuts * this.width) this.matrix = new Float64Array(st.rowCapacity * this.width);
         this.height = heightWithCuts;
         this.nVars = this.width + this.height - 2;
         for (let h = 0; h < n; h++) {
