@@ -36,6 +36,8 @@ static struct {
     int (*relax)(jslp_engine*, int32_t, const int8_t*, const int32_t*, const double*, int, jslp_simplex_result*, double*, int32_t*);
     int (*relax_batch)(jslp_engine*, int32_t, const int32_t*, const int8_t*, const int32_t*, const double*, int,
                        jslp_simplex_result*, double*, int32_t*, int32_t);
+    int (*set_integer_variables)(jslp_engine*, const int32_t*, int32_t);
+    int (*apply_mir_cuts)(jslp_engine*, int32_t*);
     int (*checkpoint_create)(jslp_engine*, int32_t*);
     int (*checkpoint_restore)(jslp_engine*, int32_t);
     int (*checkpoint_release)(jslp_engine*, int32_t);
@@ -164,6 +166,7 @@ static napi_value fn_load(napi_env env, napi_callback_info info) {
     SYM(restore, "jslp_engine_restore"); SYM(add_cuts, "jslp_engine_add_cuts"); SYM(relax, "jslp_engine_relax");
     SYM(relax_batch, "jslp_engine_relax_batch"); SYM(dims, "jslp_engine_dims"); SYM(read_rhs, "jslp_engine_read_rhs");
     SYM(download, "jslp_engine_download"); SYM(pivot_trace, "jslp_engine_pivot_trace");
+    SYM(set_integer_variables, "jslp_engine_set_integer_variables"); SYM(apply_mir_cuts, "jslp_engine_apply_mir_cuts");
     SYM(checkpoint_create, "jslp_engine_checkpoint_create"); SYM(checkpoint_restore, "jslp_engine_checkpoint_restore");
     SYM(checkpoint_release, "jslp_engine_checkpoint_release"); SYM(relax_from, "jslp_engine_relax_from");
     napi_value s;
@@ -350,6 +353,32 @@ static napi_value fn_relax(napi_env env, napi_callback_info info) {
     return result_object(env, &r);
 }
 
+/* setIntegerVariables(h, Int32Array varIndexes): variable.isInteger for the MIR cuts (cutting-strategies.ts:82-85) */
+static napi_value fn_set_integer_variables(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    void* v;
+    size_t nv;
+    if (!typed(env, argv[1], napi_int32_array, &v, &nv)) return NULL;
+    ENGINE_OK(env, L.set_integer_variables(e, (const int32_t*)v, (int32_t)nv), "jslp_engine_set_integer_variables");
+    return NULL;
+}
+
+/* applyMirCuts(h) -> number of rows appended   (Tableau.applyMIRCuts, cutting-strategies.ts:199-212) */
+static napi_value fn_apply_mir_cuts(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    int32_t n = 0;
+    ENGINE_OK(env, L.apply_mir_cuts(e, &n), "jslp_engine_apply_mir_cuts");
+    napi_value v;
+    NAPI_OK(env, napi_create_int32(env, n, &v));
+    return v;
+}
+
 /* checkpointCreate(h) -> id   (incremental-branch-and-cut.ts:55-70, the device part) */
 static napi_value fn_checkpoint_create(napi_env env, napi_callback_info info) {
     napi_value argv[1];
@@ -517,6 +546,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"simplex", fn_simplex}, {"pivot", fn_pivot}, {"save", fn_save}, {"restore", fn_restore},
         {"addCuts", fn_add_cuts}, {"relax", fn_relax}, {"relaxBatch", fn_relax_batch}, {"dims", fn_dims},
         {"readRhs", fn_read_rhs}, {"download", fn_download}, {"pivotTrace", fn_pivot_trace},
+        {"setIntegerVariables", fn_set_integer_variables}, {"applyMirCuts", fn_apply_mir_cuts},
         {"checkpointCreate", fn_checkpoint_create}, {"checkpointRestore", fn_checkpoint_restore},
         {"checkpointRelease", fn_checkpoint_release}, {"relaxFrom", fn_relax_from},
     };

@@ -100,16 +100,33 @@ function createGpuIncrementalService(gpu, options) {
         return best;
     }
 
-    // the default path: from the saved root with the whole cut list (:224-245, MIR excluded: such models never get here)
+    // the MIR loop both evaluation paths end with (:228-243, :261-276): feasible tableaus only, at most 3 rounds, stop when
+    // the fractional volume shrinks by less than 10 %
+    function mirLoop(t) {
+        if (!(t.model && t.model.useMIRCuts) || !t.feasible) return;
+        for (let round = 0; round < 3; round++) {
+            const before = t.computeFractionalVolume(true);
+            t.applyMIRCuts();
+            t.simplex();
+            if (t.computeFractionalVolume(true) >= 0.9 * before) break;
+        }
+    }
+
+    // the default path: from the saved root with the whole cut list (:224-245)
     function applyCuts(t, cuts) {
         t.restore();
         t.addCutConstraints(cuts);
         t.simplex();
+        mirLoop(t);
     }
 
     function evaluate(t, branch) {
-        if (branch.checkpoint && branch.newCut) gpu.relaxFromCheckpoint(t, branch.checkpoint, [branch.newCut]); // :248-253
-        else applyCuts(t, branch.cuts); // :254-258
+        if (branch.checkpoint && branch.newCut) {
+            gpu.relaxFromCheckpoint(t, branch.checkpoint, [branch.newCut]); // :248-253
+            mirLoop(t);
+        } else {
+            applyCuts(t, branch.cuts); // :254-258
+        }
     }
 
     function branchAndCut(t) {

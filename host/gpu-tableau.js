@@ -12,8 +12,8 @@
 //
 // Optional objectives (soft constraints, simplex.ts:221-263,394-412) travel with the tableau: their reducedCosts rows are
 // uploaded next to the matrix and read back after every simplex().  The incremental B&B service (options.useIncremental)
-// runs over device-resident checkpoints (host/gpu-incremental-service.js) when install() is given the solver.  Out of
-// the engine's scope (the reference's own TypeScript path keeps running for these tableaus): MIR cuts (useMIRCuts).
+// runs over device-resident checkpoints (host/gpu-incremental-service.js) when install() is given the solver; MIR cuts
+// (options.useMIRCuts) are built on the device by Tableau.applyMIRCuts()'s override.
 "use strict";
 const path = require("path");
 
@@ -26,6 +26,9 @@ let bypass = 0; // > 0 while a Solve() that must stay on the reference's own pat
 // extra cut rows for the incremental service: it stacks one row per tree level and never merges cuts on one variable
 // (incremental-branch-and-cut.ts:248-253); the reference reallocates, device memory is sized once
 const INCREMENTAL_EXTRA_ROWS = 256;
+// MIR cuts: every round appends up to 10 rows (cutting-strategies.ts:199-212) and the default service's loop is bounded
+// only by a 10 % volume gain per round (branch-and-cut.ts:38-52): 32 rounds of headroom, loud failure beyond
+const MIR_EXTRA_ROWS = 320;
 
 function loadEngine(options) {
     const o = options || {};
@@ -34,19 +37,20 @@ function loadEngine(options) {
     return backend;
 }
 
-function eligible(t) {
-    return bypass === 0 && !(t.model && t.model.useMIRCuts);
+function eligible() {
+    return bypass === 0;
 }
 
 function activate(t, opts) {
-    if (!eligible(t)) {
+    if (!eligible()) {
         t.__gpu = { active: false };
         return t.__gpu;
     }
     const nInts = t.model ? t.model.getNumberOfIntegerVariables() : 0;
     const incremental = !!(t.branchAndCutService && t.branchAndCutService.__gpuIncremental);
     // <= one "min" and one "max" cut per integer variable for the services that start every node from the root
-    const rowCapacity = t.height + 2 * nInts + 8 + (incremental ? INCREMENTAL_EXTRA_ROWS : 0);
+    const useMir = !!(t.model && t.model.useMIRCuts);
+    const rowCapacity = t.height + 2 * nInts + 8 + (incremental ? INCREMENTAL_EXTRA_ROWS : 0) + (useMir ? MIR_EXTRA_ROWS : 0);
     const h = addon.create(t.height, t.width, rowCapacity, t.precision, opts.device || 0);
     const rows = Int32Array.from(t.varIndexByRow);
     const cols = Int32Array.from(t.varIndexByCol);
@@ -56,6 +60,7 @@ function activate(t, opts) {
         Object.keys(t.unrestrictedVars).filter((k) => t.unrestrictedVars[k] === true).map(Number)
     );
     addon.upload(h, t.matrix.subarray(0, t.height * t.width), rows, cols, unrestricted);
+    if (useMir) addon.setIntegerVariables(h, Int32Array.from(t.model.integerVariables.map((v) => v.index)));
     const nOpt = t.optionalObjectives.length; // already sorted by priority (tableau.ts:286)
     let optional = null;
     if (nOpt > 0) {
@@ -143,7 +148,34 @@ function install(Tableau, options) {
     const opts = options || {};
     if (!addon) loadEngine(opts);
     const P = Tableau.prototype;
-    const orig = { simplex: P.simplex, save: P.save, restore: P.restore, addCutConstraints: P.addCutConstraints };
+    const orig = { simplex: P.simplex, save: P.save, restore: P.restore, addCutConstraints: P.addCutConstraints,
+        applyMIRCuts: P.applyMIRCuts };
+
+    // slack bookkeeping of one appended row (cutting-strategies.ts:64-71 / :104-109); the row itself is built on the device
+    function newSlackRow(t, row) {
+        const slack = t.getNewElementIndex();
+        t.varIndexByRow[row] = slack;
+        t.rowByVarIndex[slack] = row;
+        t.colByVarIndex[slack] = -1;
+        t.variablesPerIndex[slack] = opts.SlackVariable
+            ? new opts.SlackVariable("s" + slack, slack)
+            : { id: "s" + slack, cost: 0, index: slack, value: 0, priority: 0, isSlack: true };
+    }
+
+    // Tableau.applyMIRCuts (cutting-strategies.ts:199-212): the scan and the <= 10 new rows happen on the device
+    P.applyMIRCuts = function () {
+        const st = state(this, opts);
+        if (!st.active) return orig.applyMIRCuts.call(this);
+        if (st.pendingRestore || st.pendingCuts) throw new Error("[gpu-tableau] applyMIRCuts before the pending simplex()");
+        const n = addon.applyMirCuts(st.h);
+        if (this.matrix.length < (this.height + n) * this.width) this.matrix = new Float64Array(st.rowCapacity * this.width);
+        for (let k = 0; k < n; k++) {
+            const row = this.height;
+            this.height += 1; // :101-102
+            this.nVars += 1;
+            newSlackRow(this, row);
+        }
+    };
 
     P.simplex = function () {
         const st = state(this, opts);
@@ -203,13 +235,7 @@ function install(Tableau, options) {
         this.height = heightWithCuts;
         this.nVars = this.width + this.height - 2;
         for (let h = 0; h < n; h++) {
-            const slack = this.getNewElementIndex();
-            this.varIndexByRow[height + h] = slack;
-            this.rowByVarIndex[slack] = height + h;
-            this.colByVarIndex[slack] = -1;
-            this.variablesPerIndex[slack] = opts.SlackVariable
-                ? new opts.SlackVariable("s" + slack, slack)
-                : { id: "s" + slack, cost: 0, index: slack, value: 0, priority: 0, isSlack: true };
+            newSlackRow(this, height + h);
             this.nVars += 1;
         }
         st.pendingCuts = (st.pendingCuts || []).concat(cuts);
@@ -218,7 +244,7 @@ function install(Tableau, options) {
     // The reference's incremental B&B service (options.useIncremental, src/tableau/incremental-branch-and-cut.ts:55-107)
     // checkpoints a parent by copying tableau.matrix on the host, which no Tableau method can intercept.  Given the
     // solver, install() therefore answers its service selection (src/main.ts:62-83) with the same policy over device
-    // checkpoints; without the solver (or with MIR cuts) such a Solve stays wholly on the reference's own path.
+    // checkpoints; without the solver such a Solve must be kept on the reference's own path (guardIncremental).
     let hadOwnSelect = false;
     let origSelect = null;
     if (opts.solver) {
@@ -228,7 +254,7 @@ function install(Tableau, options) {
         origSelect = solver.selectBranchAndCutService;
         solver.selectBranchAndCutService = function (model) {
             const o = model && model.options;
-            if (o && o.useIncremental === true && !o.useMIRCuts) {
+            if (o && o.useIncremental === true) {
                 return service.createGpuIncrementalService(api, { nodeSelection: o.nodeSelection, branching: o.branching });
             }
             return origSelect.call(this, model);
@@ -241,6 +267,7 @@ function install(Tableau, options) {
         P.save = orig.save;
         P.restore = orig.restore;
         P.addCutConstraints = orig.addCutConstraints;
+        P.applyMIRCuts = orig.applyMIRCuts;
         if (opts.solver) {
             if (hadOwnSelect) opts.solver.selectBranchAndCutService = origSelect;
             else delete opts.solver.selectBranchAndCutService;

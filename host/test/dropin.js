@@ -110,6 +110,36 @@ if (!filter && dir.indexOf("fixtures") >= 0 && fs.existsSync(incFile)) {
         else incrementalOk += 1;
     }
 }
+// options.useMIRCuts: Tableau.applyMIRCuts() built on the device, under the default, enhanced and incremental services,
+// against the reference (tests/golden/mir.json.gz)
+let mirOk = 0;
+const mirFile = path.join(root, "tests", "golden", "mir.json.gz");
+if (!filter && dir.indexOf("fixtures") >= 0 && fs.existsSync(mirFile)) {
+    const doc = JSON.parse(zlib.gunzipSync(fs.readFileSync(mirFile)).toString());
+    for (const c of doc.cases) {
+        if (c.mirCuts === 0 || c.nPivots > 20000) continue;
+        const g = loadGolden(path.join(root, "tests", "golden"), c.file);
+        const m = JSON.parse(JSON.stringify(g.model));
+        m.options = Object.assign({}, c.options);
+        const solution = solver.Solve(m, undefined, true);
+        const res = solver.buildSimplifiedResult(solution);
+        const got = {};
+        for (const k of Object.keys(res)) got[k] = num(res[k]);
+        const bad = [];
+        if (JSON.stringify(Object.keys(res)) !== JSON.stringify(c.resultKeys)) bad.push("keys");
+        if (JSON.stringify(got) !== JSON.stringify(c.result)) bad.push("values");
+        const trace = gpu.pivotTrace(solution._tableau);
+        if (!trace) bad.push("not on the engine");
+        else {
+            if (trace.length / 2 !== c.nPivots) bad.push("pivot count " + trace.length / 2 + " != " + c.nPivots);
+            else if (digest(trace) !== c.pivotDigest) bad.push("pivot digest");
+            if (solution._tableau.branchAndCutIterations !== c.iterations) bad.push("B&B iterations");
+            gpu.release(solution._tableau);
+        }
+        if (bad.length) { fail += 1; console.log("FAIL mir", c.file, JSON.stringify(c.options), bad.join("; ")); }
+        else mirOk += 1;
+    }
+}
 console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk,
-    incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken }));
+    incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);

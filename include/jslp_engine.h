@@ -148,6 +148,20 @@ int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, const int32_
                                    int32_t* out_stride);
 
 /*
+ * MIR cuts (options.useMIRCuts, src/model.ts:354-356).  set_integer_variables hands over model.integerVariables' indexes:
+ * the `variable.isInteger` test of addLowerBoundMIRCut (src/tableau/cutting-strategies.ts:82-85, 120-121); call after
+ * upload().  apply_mir_cuts = Tableau.applyMIRCuts() (cutting-strategies.ts:199-212): scans rows 1..height-1 in order
+ * and appends a lower-bound MIR cut (:74-135) for the first <= 10 rows whose basic variable is an integer variable with
+ * a fractional value; each new row gets the next element index (tableau.ts:393-401).  *n_added receives the number of
+ * rows appended.  mir_round = one turn of the services' MIR loop (branch-and-cut.ts:41-43): applyMIRCuts() + simplex()
+ * + the read-back of jslp_engine_relax (the host computes computeFractionalVolume, mip-utils.ts:67-92, from it).
+ */
+int jslp_engine_set_integer_variables(jslp_engine* e, const int32_t* var_indexes, int32_t n);
+int jslp_engine_apply_mir_cuts(jslp_engine* e, int32_t* n_added);
+int jslp_engine_mir_round(jslp_engine* e, int check_cycles, int32_t* n_added, jslp_simplex_result* out, double* rhs,
+                          int32_t* var_index_by_row);
+
+/*
  * Device-resident checkpoints: the StateCheckpoint of the incremental branch-and-bound service
  * (src/tableau/incremental-branch-and-cut.ts:31-44).  createCheckpoint (:55-70) copies the live matrix, the four index
  * maps, height and lastElementIndex; restoreCheckpoint (:72-107) puts them back.  Exactly like the reference, a

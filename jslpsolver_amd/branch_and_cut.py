@@ -96,6 +96,37 @@ def most_fractional_var(model, rhs, rows):
     return sel_index, sel_value
 
 
+def fractional_volume(model, rhs, vibr, precision):
+    """computeFractionalVolume(ignoreIntegerValues = true) (mip-utils.ts:67-92): the product, in row order, of |value|
+    over the basic integer variables that are not at an integer value"""
+    integer = model.integer_index_set
+    volume = -1.0
+    for r in range(1, len(vibr)):
+        if int(vibr[r]) in integer:
+            distance = abs(float(rhs[r]))
+            if min(distance - math.floor(distance), math.floor(distance + 1)) < precision:
+                continue
+            volume = distance if volume == -1.0 else volume * distance
+    return 0.0 if volume == -1.0 else volume
+
+
+def mir_loop(tableau, model, rhs, vibr, check, max_rounds=None, need_feasible=False):
+    """The MIR loop that follows the simplex() of a node: branch-and-cut.ts:38-52 (unbounded, no feasibility test) or
+    incremental-branch-and-cut.ts:228-243, 261-276 (at most 3 rounds, feasible tableaus only).  Every round is one
+    engine call (applyMIRCuts + simplex + read-back); the stopping rule needs only the RHS column."""
+    if not model.useMIRCuts or (need_feasible and not tableau.feasible):
+        return rhs, vibr
+    rounds = 0
+    while max_rounds is None or rounds < max_rounds:
+        before = fractional_volume(model, rhs, vibr, tableau.precision)
+        _n, _res, rhs, vibr = tableau.mirRound(check_cycles=check)
+        after = fractional_volume(model, rhs, vibr, tableau.precision)
+        rounds += 1
+        if after >= 0.9 * before:
+            break
+    return rhs, vibr
+
+
 class _NodeEval:
     """outcome of one LP relaxation as the host tree consumes it"""
     __slots__ = ("res", "rhs", "vibr")
@@ -129,8 +160,8 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
     precision = tableau.precision
     n_opt = getattr(tableau, "n_optional", 0)
     best_optional = [math.inf] * n_opt  # bestOptionalObjectivesEvaluations (:66-69)
-    if n_opt > 0:
-        speculate = 1  # the tie-break below reads the live optional-objective cells: evaluate in order
+    if n_opt > 0 or model.useMIRCuts:
+        speculate = 1  # the tie-break below reads the live optional-objective cells / the MIR loop is driven per node
     cache = {}          # heap sequence number -> _NodeEval
     saved = False
     last_cuts = None    # cuts of the node the sequential run evaluated last
@@ -168,6 +199,7 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
             rhs, vibr = ev.rhs, ev.vibr
         else:
             _res, rhs, vibr = tableau.applyCuts(cuts, check_cycles=check)
+            rhs, vibr = mir_loop(tableau, model, rhs, vibr, check)  # :38-52
         last_cuts = cuts
         iterations += 1
         if not tableau.feasible:
@@ -219,7 +251,8 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
             branches.push(evaluation, cuts_high)
             branches.push(evaluation, cuts_low)
     if best_cuts is not None:
-        tableau.applyCuts(best_cuts, check_cycles=check)
+        _res, rhs, vibr = tableau.applyCuts(best_cuts, check_cycles=check)
+        mir_loop(tableau, model, rhs, vibr, check)
     elif speculate > 1 and saved and last_cuts is not None:
         # no incumbent: the reference's tableau is left on the node it evaluated last; put ours there too
         tableau.applyCuts(last_cuts, check_cycles=check)

@@ -49,6 +49,7 @@ struct jslp_engine {
     double* snap_A = nullptr;
     int32_t *snap_vibr = nullptr, *snap_vibc = nullptr, *snap_rbv = nullptr, *snap_cbv = nullptr;
     uint8_t* d_unr = nullptr;
+    uint8_t* d_isint = nullptr;  // variable.isInteger per variable index (MIR cuts)
     int32_t n_opt = 0; double* snap_oo = nullptr;  // optional objectives (slot copies live in s.oo)
     // cuts staging
     // cuts staging: ONE pinned host buffer -> ONE device buffer per call: [value | offs | var | type]
@@ -241,6 +242,7 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
             for (int pass = 0; pass < 2; pass++) {
                 Carver cv{pass ? e->static_arena : nullptr, 0};
                 e->d_unr = cv.take<uint8_t>((size_t)e->n_idx);
+                e->d_isint = cv.take<uint8_t>((size_t)e->n_idx);
                 e->snap_A = cv.take<double>(cells);
                 e->snap_vibr = cv.take<int32_t>((size_t)e->cap_rows);
                 e->snap_vibc = cv.take<int32_t>((size_t)e->W);
@@ -329,6 +331,7 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
     HIPC(hipMemcpyAsync(e->s.rbv, rbv.data(), sizeof(int32_t) * e->n_idx, hipMemcpyHostToDevice, s));
     HIPC(hipMemcpyAsync(e->s.cbv, cbv.data(), sizeof(int32_t) * e->n_idx, hipMemcpyHostToDevice, s));
     HIPC(hipMemcpyAsync(e->d_unr, unr.data(), e->n_idx, hipMemcpyHostToDevice, s));
+    HIPC(hipMemsetAsync(e->d_isint, 0, e->n_idx, s));
     HIPC(hipMemcpyAsync(e->s.st, &st, sizeof st, hipMemcpyHostToDevice, s));
     HIPC(hipStreamSynchronize(s));  // the host vectors die here
     e->uploaded = 1;
@@ -895,6 +898,43 @@ extern "C" int jslp_engine_read_rhs(jslp_engine* e, double* rhs, int32_t* var_in
     if (rhs) memcpy(rhs, e->h_rhs, sizeof(double) * H);
     if (var_index_by_row) memcpy(var_index_by_row, e->h_rows, sizeof(int32_t) * H);
     return JSLP_OK;
+}
+
+extern "C" int jslp_engine_set_integer_variables(jslp_engine* e, const int32_t* var_indexes, int32_t n) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "set_integer_variables before upload");
+    if (n < 0 || (n > 0 && !var_indexes)) return fail(JSLP_ERR_ARG, "set_integer_variables: bad arguments");
+    HIPC(hipSetDevice(e->device));
+    std::vector<uint8_t> flags(e->n_idx, 0);
+    for (int32_t i = 0; i < n; i++) {
+        if (var_indexes[i] < 0 || var_indexes[i] >= e->n_idx) return fail(JSLP_ERR_ARG, "set_integer_variables: index out of range");
+        flags[var_indexes[i]] = 1;
+    }
+    HIPC(hipMemcpyAsync(e->d_isint, flags.data(), e->n_idx, hipMemcpyHostToDevice, e->stream));
+    HIPC(hipStreamSynchronize(e->stream));
+    return JSLP_OK;
+}
+
+// Tableau.applyMIRCuts() (cutting-strategies.ts:199-212)
+extern "C" int jslp_engine_apply_mir_cuts(jslp_engine* e, int32_t* n_added) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "apply_mir_cuts before upload");
+    HIPC(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_mir_cuts, dim3(1), dim3(256), 0, e->stream, e->s, e->d_isint, 10, (int)e->cap_rows);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    HIPC(hipStreamSynchronize(e->stream));
+    int rc = state_error(*e->h_state);
+    if (rc) return rc;
+    if (n_added) *n_added = e->h_state->mir_added;
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_mir_round(jslp_engine* e, int check_cycles, int32_t* n_added, jslp_simplex_result* out,
+                                     double* rhs, int32_t* var_index_by_row) {
+    int rc = jslp_engine_apply_mir_cuts(e, n_added);
+    if (rc) return rc;
+    rc = jslp_engine_simplex(e, check_cycles, out);
+    if (rc) return rc;
+    return jslp_engine_read_rhs(e, rhs, var_index_by_row);
 }
 
 // Shared body of relax_batch / relax_batch_pinned.  Per-node-workgroup path: all groups are enqueued back to back,

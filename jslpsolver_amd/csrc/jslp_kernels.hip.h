@@ -52,6 +52,7 @@ struct DevState {
     int32_t s_gen;        // slot 0 only: generation of the current snapshot
     int32_t f_pc;         // entering column chosen for the NEXT launch's pivot
     int32_t f_final_buf;  // which ping-pong buffer holds the tableau when the pipeline stopped
+    int32_t mir_added;    // rows appended by the last k_mir_cuts
 };
 
 // Everything a step needs for ONE tableau.
@@ -728,6 +729,93 @@ __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int fir
 // workgroups all read st->gen, so none of them may write it); after a checkpoint restore they are in sync with nothing
 __global__ void k_restore_commit(Slots s, int first_slot, int from_root) {
     s.st[first_slot + blockIdx.x].gen = from_root ? s.st[0].s_gen : 0;
+}
+
+// Math.max(0, x) / Math.min(0, x) with JavaScript's treatment of NaN and signed zeros
+__device__ __forceinline__ double js_max0(double x) { return x != x ? x : (x > 0 ? x : 0.0); }
+__device__ __forceinline__ double js_min0(double x) {
+    return x != x ? x : ((x < 0 || (x == 0 && (__double_as_longlong(x) < 0))) ? x : 0.0);
+}
+
+// applyMIRCuts (cutting-strategies.ts:199-212) on slot 0: rows 1..H-1 are scanned in order and the first <= max_cuts rows
+// whose basic variable is an integer variable with a fractional value each append one lower-bound MIR cut
+// (addLowerBoundMIRCut, :74-135).  One workgroup: the scan is an ordered compaction (ballot + popcount), the new rows are
+// elementwise in the columns.
+__global__ void __launch_bounds__(256) k_mir_cuts(Slots s, const uint8_t* is_int, int max_cuts, int cap_rows) {
+    __shared__ int sel[64];
+    __shared__ unsigned long long masks[4];
+    DevState* st = s.st;
+    double* A = s.A;
+    int32_t* vibr = s.vibr;
+    const int32_t* vibc = s.vibc;
+    const int H = st->H, W = s.W, ld = s.ld;
+    const double precision = s.precision;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int r0 = 1; r0 < H && base < max_cuts; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        bool ok = false;
+        if (r < H) {
+            const int v = vibr[r];
+            if (v >= 0 && is_int[v]) {  // :82-85
+                const double rhs = A[(long long)r * ld];
+                const double f = rhs - floor(rhs);
+                ok = !(f < precision || f > 1 - precision);  // :88-90
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) masks[wave] = m;
+        __syncthreads();
+        int before = __popcll(m & ((1ull << lane) - 1)), total = 0;
+        for (int k = 0; k < 4; k++) {
+            const int n = __popcll(masks[k]);
+            if (k < wave) before += n;
+            total += n;
+        }
+        if (ok && base + before < max_cuts) sel[base + before] = r;
+        base += total;
+        __syncthreads();
+    }
+    const int n = base < max_cuts ? base : max_cuts;
+    if (H + n > cap_rows) {
+        if (threadIdx.x == 0) { st->err = ERR_CAPACITY; st->mir_added = 0; }
+        return;
+    }
+    for (int k = 0; k < n; k++) {
+        const double* src = A + (long long)sel[k] * ld;
+        double* dst = A + (long long)(H + k) * ld;
+        const double rhs = src[0];
+        const double f = rhs - floor(rhs);
+        for (int c = threadIdx.x; c < ld; c += 256) {
+            double out = 0.0;
+            if (c == 0) {
+                out = floor(rhs) - rhs;  // :112 then :128-130
+            } else if (c < W) {
+                const double a = src[c];
+                const int v = vibc[c];
+                double cut;
+                if (v >= 0 && is_int[v]) {  // :117-123
+                    const double fl = floor(a);
+                    cut = fl + js_max0(a - fl - f) / (1 - f);
+                } else {
+                    cut = js_min0(a / (1 - f));  // :124-125
+                }
+                out = cut - a;  // :128-130
+            }
+            dst[c] = out;
+        }
+    }
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < n; k++) {  // :104-109
+            const int slack = st->last_element_index++;
+            vibr[H + k] = slack;
+            s.rbv[slack] = H + k;
+            s.cbv[slack] = -1;
+            s.dirty[H + k] = 1;
+        }
+        st->H = H + n;
+        st->mir_added = n;
+    }
 }
 
 // createCheckpoint (incremental-branch-and-cut.ts:55-70): slot 0 -> a checkpoint buffer; the snapshot generation and the

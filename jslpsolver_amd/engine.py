@@ -16,7 +16,7 @@ class Tableau:
     """
 
     def __init__(self, matrix, var_index_by_row, var_index_by_col, unrestricted=(), precision=1e-8,
-                 row_capacity=None, device=0, lib=None, optional_objectives=None):
+                 row_capacity=None, device=0, lib=None, optional_objectives=None, integer_variables=None):
         self.lib = lib if lib is not None else _capi.load_hip()
         matrix = _capi.as_f64(matrix)
         if matrix.ndim != 2:
@@ -43,6 +43,10 @@ class Tableau:
             self.lib.check(self.lib.jslp_engine_set_optional_objectives(self._h, int(oo.shape[0]), _capi.ptr_f64(oo)),
                            "jslp_engine_set_optional_objectives")
             self.n_optional = int(oo.shape[0])
+        if integer_variables is not None and len(integer_variables) > 0:  # variable.isInteger for the MIR cuts
+            iv = _capi.as_i32(list(integer_variables))
+            self.lib.check(self.lib.jslp_engine_set_integer_variables(self._h, _capi.ptr_i32(iv), int(iv.shape[0])),
+                           "jslp_engine_set_integer_variables")
         # tableau scalars the reference keeps on the Tableau object (tableau.ts:59-61,83-87)
         self.feasible = True
         self.bounded = True
@@ -163,6 +167,25 @@ class Tableau:
         rhs = np.ctypeslib.as_array(p_rhs, shape=shape)
         vibr = np.ctypeslib.as_array(p_rows, shape=shape) if want_rows else None
         return out, rhs, vibr
+
+    # ---- MIR cuts (cutting-strategies.ts:74-212) --------------------------------------------------------
+    def applyMIRCuts(self):
+        """Tableau.applyMIRCuts (:199-212); returns the number of rows appended"""
+        n = _capi.C.c_int32(0)
+        self.lib.check(self.lib.jslp_engine_apply_mir_cuts(self._h, _capi.C.byref(n)), "jslp_engine_apply_mir_cuts")
+        return n.value
+
+    def mirRound(self, check_cycles=True):
+        """one turn of the services' MIR loop (branch-and-cut.ts:41-43): applyMIRCuts + simplex + read-back.
+        Returns (rows appended, result, rhs, varIndexByRow)."""
+        n = _capi.C.c_int32(0)
+        res = SimplexResult()
+        rhs = np.empty(self.row_capacity, dtype=np.float64)
+        vibr = np.empty(self.row_capacity, dtype=np.int32)
+        self.lib.check(self.lib.jslp_engine_mir_round(self._h, int(bool(check_cycles)), _capi.C.byref(n), _capi.C.byref(res),
+                                                      _capi.ptr_f64(rhs), _capi.ptr_i32(vibr)), "jslp_engine_mir_round")
+        self._absorb(res)
+        return n.value, res, rhs[:res.height], vibr[:res.height]
 
     # ---- checkpoints (incremental-branch-and-cut.ts:31-107) -------------------------------------------
     def createCheckpoint(self):

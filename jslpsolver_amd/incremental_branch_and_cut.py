@@ -15,7 +15,7 @@ update from `tableau.evaluation` (:339, 354-365, 172-221), the checkpoint budget
 import math
 import time
 
-from .branch_and_cut import BranchMinHeap, _rows_by_var, is_integral, js_round
+from .branch_and_cut import BranchMinHeap, _rows_by_var, is_integral, js_round, mir_loop
 
 
 class _Branch:
@@ -136,6 +136,7 @@ def incremental_branch_and_cut(tableau, model, node_selection="hybrid", branchin
             incremental_nodes += 1
         else:
             _res, rhs, vibr = tableau.applyCuts(branch.cuts, check_cycles=check)
+        rhs, vibr = mir_loop(tableau, model, rhs, vibr, check, max_rounds=3, need_feasible=True)  # :261-276
         iterations += 1
         if not tableau.feasible:
             continue
@@ -210,7 +211,8 @@ def incremental_branch_and_cut(tableau, model, node_selection="hybrid", branchin
                 heap.push(b_high.relaxed, b_high)
                 heap.push(b_low.relaxed, b_low)
     if best_branch is not None:
-        tableau.applyCuts(best_branch.cuts, check_cycles=check)  # :491-493, always from the root
+        _res, rhs, vibr = tableau.applyCuts(best_branch.cuts, check_cycles=check)  # :491-493, always from the root
+        mir_loop(tableau, model, rhs, vibr, check, max_rounds=3, need_feasible=True)  # :228-243
     for c in checkpoints:
         tableau.releaseCheckpoint(c)
     tableau.checkpoints_used, tableau.incremental_nodes = checkpoint_count, incremental_nodes

@@ -97,8 +97,6 @@ class Model:
             self.keep_solutions = bool(options.get("keep_solutions"))
             if options.get("presolve") is not None:
                 self.usePresolve = options["presolve"]
-        if self.useMIRCuts:
-            raise UnsupportedModel("MIR cuts are out of scope (off by default, model.ts:71)")
         self.options = options or {}
 
         ints = json_model.get("ints") or {}
@@ -129,6 +127,8 @@ class Model:
                     cons_min[name]["terms"].append((pos, coefficient))
                 if name in cons_max:
                     cons_max[name]["terms"].append((pos, coefficient))
+
+        self.integer_index_set = frozenset(v["index"] for v in self.integerVariables)
 
     _PRIORITIES = {"required": 0, "strong": 1, "medium": 2, "weak": 3}
 

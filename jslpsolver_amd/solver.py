@@ -42,9 +42,14 @@ def Solve(model, precision=None, full=False, validate=False, lib=None, device=0,
         # by the number of integer variables; the reference reallocates (cutting-strategies.ts:24-30), device memory
         # is sized once -- a deeper tree fails loudly with JSLP_ERR_CAPACITY (pass row_capacity_extra)
         extra = 2 * n_int + 256
+    if n_int > 0 and m.useMIRCuts and row_capacity_extra is None:
+        # every MIR round appends up to 10 rows (cutting-strategies.ts:199-212); the default service's loop has no bound
+        # but a 10 % volume gain per round (branch-and-cut.ts:38-52): 32 rounds of headroom, loud failure beyond
+        extra += 320
     _priorities, optional_rows = m.optional_objectives()
     t = Tableau(matrix, vibr, vibc, m.unrestricted, precision=m.precision, row_capacity=matrix.shape[0] + extra,
-                device=device, lib=lib, optional_objectives=optional_rows)
+                device=device, lib=lib, optional_objectives=optional_rows,
+                integer_variables=[v["index"] for v in m.integerVariables] if m.useMIRCuts else None)
     iterations = 0
     integral = False
     if n_int > 0:  # tableau.ts:250-258

@@ -48,6 +48,7 @@ struct jslp_engine {
     double* oo;
     double* s_oo;
     int32_t* defer; /* optionalCostsColumns scratch (simplex.ts:132-134) */
+    uint8_t* is_int;       /* variablesPerIndex[v].isInteger  [n_idx_cap] */
     /* StateCheckpoint list (incremental-branch-and-cut.ts:31-44) */
     struct checkpoint* ck;
     int32_t n_ck;
@@ -126,6 +127,7 @@ void jslp_engine_destroy(jslp_engine* e) {
     free(e->trace);
     free(e->oo); free(e->s_oo); free(e->defer);
     checkpoints_clear(e);
+    free(e->is_int);
     free(e);
 }
 
@@ -160,6 +162,7 @@ int jslp_engine_upload(jslp_engine* e, const double* matrix, const int32_t* var_
     e->last_element_index = W + H - 2; /* tableau.ts:312-316 */
     e->has_save = 0;
     checkpoints_clear(e);
+    if (e->is_int) memset(e->is_int, 0, (size_t)e->n_idx_cap);
     e->feasible = 1;
     e->bounded = 1;
     e->evaluation = 0;
@@ -690,6 +693,81 @@ int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, const int32_
     if (var_index_by_row) *var_index_by_row = b_rows;
     if (out_stride) *out_stride = e->cap_rows;
     return JSLP_OK;
+}
+
+int jslp_engine_set_integer_variables(jslp_engine* e, const int32_t* var_indexes, int32_t n) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "set_integer_variables before upload");
+    if (n < 0 || (n > 0 && !var_indexes)) return fail(JSLP_ERR_ARG, "set_integer_variables: bad arguments");
+    if (!e->is_int) e->is_int = (uint8_t*)calloc((size_t)e->n_idx_cap, 1);
+    if (!e->is_int) return fail(JSLP_ERR_NOMEM, "set_integer_variables: out of memory");
+    memset(e->is_int, 0, (size_t)e->n_idx_cap);
+    for (int32_t i = 0; i < n; i++) {
+        if (var_indexes[i] < 0 || var_indexes[i] >= e->n_idx_cap) return fail(JSLP_ERR_ARG, "set_integer_variables: index out of range");
+        e->is_int[var_indexes[i]] = 1;
+    }
+    return JSLP_OK;
+}
+
+static int is_integer_var(const jslp_engine* e, int32_t v) { return v >= 0 && e->is_int && e->is_int[v]; }
+
+/* Math.max(0, x) / Math.min(0, x) with JavaScript's treatment of NaN and signed zeros */
+static double js_max0(double x) { return x != x ? x : (x > 0 ? x : 0.0); }
+static double js_min0(double x) { return x != x ? x : ((x < 0 || (x == 0 && signbit(x))) ? x : 0.0); }
+
+/* addLowerBoundMIRCut (cutting-strategies.ts:74-135); 1 = a row was appended */
+static int add_lower_bound_mir_cut(jslp_engine* e, int32_t row, int* err) {
+    if (row == 0) return 0; /* costRowIndex */
+    const int32_t width = e->width;
+    double* m = e->matrix;
+    const size_t src = (size_t)row * width;
+    if (!is_integer_var(e, e->vibr[row])) return 0; /* :82-85 */
+    const double rhs = m[src];
+    const double f = rhs - floor(rhs);
+    if (f < e->precision || f > 1 - e->precision) return 0; /* :88-90 */
+    const int32_t height = e->height;
+    if (height + 1 > e->cap_rows) { *err = JSLP_ERR_CAPACITY; return 0; }
+    const size_t dst = (size_t)height * width;
+    e->height += 1;
+    const int32_t slack = e->last_element_index++; /* getNewElementIndex */
+    if (slack >= e->n_idx_cap) { *err = JSLP_ERR_CAPACITY; return 0; }
+    e->vibr[height] = slack;
+    e->rbv[slack] = height;
+    e->cbv[slack] = -1;
+    m[dst] = floor(rhs); /* :112 */
+    for (int32_t c = 1; c < width; c++) { /* :114-126 */
+        const double a = m[src + c];
+        if (is_integer_var(e, e->vibc[c])) {
+            const double fl = floor(a);
+            m[dst + c] = fl + js_max0(a - fl - f) / (1 - f);
+        } else {
+            m[dst + c] = js_min0(a / (1 - f));
+        }
+    }
+    for (int32_t c = 0; c < width; c++) m[dst + c] -= m[src + c]; /* :128-130 */
+    return 1;
+}
+
+/* applyMIRCuts (cutting-strategies.ts:199-212) */
+int jslp_engine_apply_mir_cuts(jslp_engine* e, int32_t* n_added) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "apply_mir_cuts before upload");
+    const int32_t height = e->height;
+    int32_t added = 0;
+    int err = 0;
+    for (int32_t r = 1; r < height && added < 10; r++) {
+        if (add_lower_bound_mir_cut(e, r, &err)) added++;
+        if (err) return fail(err, "apply_mir_cuts: row capacity exceeded");
+    }
+    if (n_added) *n_added = added;
+    return JSLP_OK;
+}
+
+int jslp_engine_mir_round(jslp_engine* e, int check_cycles, int32_t* n_added, jslp_simplex_result* out, double* rhs,
+                          int32_t* var_index_by_row) {
+    int rc = jslp_engine_apply_mir_cuts(e, n_added);
+    if (rc) return rc;
+    rc = jslp_engine_simplex(e, check_cycles, out);
+    if (rc) return rc;
+    return jslp_engine_read_rhs(e, rhs, var_index_by_row);
 }
 
 /* createCheckpoint (incremental-branch-and-cut.ts:55-70) */

@@ -38,9 +38,9 @@ def test_addon_exports_the_abi():
     out = subprocess.run(["node", "-e", "console.log(Object.keys(require(%r)).sort().join(','))" % ADDON],
                          capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
-    assert out.stdout.strip() == ("addCuts,checkpointCreate,checkpointRelease,checkpointRestore,create,destroy,deviceCount,"
-                                  "dims,download,getOptionalObjectives,load,pivot,pivotTrace,readRhs,relax,relaxBatch,"
-                                  "relaxFrom,restore,save,setOptionalObjectives,simplex,upload")
+    assert out.stdout.strip() == ("addCuts,applyMirCuts,checkpointCreate,checkpointRelease,checkpointRestore,create,destroy,"
+                                  "deviceCount,dims,download,getOptionalObjectives,load,pivot,pivotTrace,readRhs,relax,"
+                                  "relaxBatch,relaxFrom,restore,save,setIntegerVariables,setOptionalObjectives,simplex,upload")
 
 
 def test_reference_host_with_oracle_engine(oracle_lib):
@@ -50,6 +50,7 @@ def test_reference_host_with_oracle_engine(oracle_lib):
     assert r["strategy_variants_ok"] == 30  # enhanced B&B services over the same seam
     # options.useIncremental: the reference's policy over device checkpoints (host/gpu-incremental-service.js)
     assert r["incremental_ok"] >= 100 and r["device_checkpoints"] > 300
+    assert r["mir_ok"] >= 60  # options.useMIRCuts under the default, enhanced and incremental services
     r = _run(oracle_lib.path, "synthetic", "40x")
     assert r["fail"] == 0 and r["pass"] >= 12
 
@@ -61,5 +62,6 @@ def test_reference_host_with_hip_engine(hip_lib):
     assert r["backend"] == "hip-gfx950" and r["fail"] == 0 and r["pass"] == 47 and r["solved_on_engine"] >= 43
     assert r["strategy_variants_ok"] == 30
     assert r["incremental_ok"] >= 100 and r["device_checkpoints"] > 300
+    assert r["mir_ok"] >= 60
     r = _run(hip_lib.path, "synthetic", "_")
     assert r["fail"] == 0 and r["pass"] >= 40
