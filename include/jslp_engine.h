@@ -162,6 +162,17 @@ int jslp_engine_mir_round(jslp_engine* e, int check_cycles, int32_t* n_added, js
                           int32_t* var_index_by_row);
 
 /*
+ * fp32-vs-fp64 tolerance sweep.  Runs simplex() on an fp32 COPY of the live tableau with the
+ * tolerance `precision` (the reference's `precision`, tableau.ts:96) and returns what jslp_engine_relax returns (the RHS
+ * column widened back to double); *device_ms receives the device time of the pivot loop.  Same pivoting rules, same
+ * kernels compiled for float; the fp64 state of the engine is NOT modified and no pivot is traced.  This is an
+ * experiment, not a drop-in path: fp32 has no reference to be exact against, the caller compares flags / objective /
+ * pivot counts with the fp64 solve.  The test library answers JSLP_ERR_UNSUPPORTED.
+ */
+int jslp_engine_simplex_f32(jslp_engine* e, double precision, int check_cycles, jslp_simplex_result* out, double* rhs,
+                            int32_t* var_index_by_row, double* device_ms);
+
+/*
  * Device-resident checkpoints: the StateCheckpoint of the incremental branch-and-bound service
  * (src/tableau/incremental-branch-and-cut.ts:31-44).  createCheckpoint (:55-70) copies the live matrix, the four index
  * maps, height and lastElementIndex; restoreCheckpoint (:72-107) puts them back.  Exactly like the reference, a

@@ -69,6 +69,7 @@ SYMBOLS = {
     "jslp_engine_set_integer_variables": (C.c_int, [C.c_void_p, _i32p, C.c_int32]),
     "jslp_engine_apply_mir_cuts": (C.c_int, [C.c_void_p, _i32p]),
     "jslp_engine_mir_round": (C.c_int, [C.c_void_p, C.c_int, _i32p, _P(SimplexResult), _f64p, _i32p]),
+    "jslp_engine_simplex_f32": (C.c_int, [C.c_void_p, C.c_double, C.c_int, _P(SimplexResult), _f64p, _i32p, _f64p]),
     "jslp_engine_checkpoint_create": (C.c_int, [C.c_void_p, _i32p]),
     "jslp_engine_checkpoint_restore": (C.c_int, [C.c_void_p, C.c_int32]),
     "jslp_engine_checkpoint_release": (C.c_int, [C.c_void_p, C.c_int32]),

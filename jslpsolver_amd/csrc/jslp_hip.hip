@@ -73,6 +73,9 @@ struct jslp_engine {
     };
     std::vector<Ckpt> ckpts;
     std::vector<char*> ck_free;
+    // fp32 twin of slot 0 (jslp_engine_simplex_f32), allocated on first use
+    f32::Slots s32{};
+    char* arena32 = nullptr;
     // policy
     int force_path = 0;  // 0 auto, 1 workgroup kernel, 2 select+update kernels only, 3 fused phase 2
     int32_t n_unr = 0;
@@ -275,6 +278,7 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     free_slots(e);
     hipFree(e->static_arena); hipFree(e->snap_oo);
     drop_checkpoints(e, 1);
+    hipFree(e->arena32);
     hipFree(e->f_buf1); hipFree(e->f_cands[0]); hipFree(e->f_cands[1]); hipFree(e->f_pcol[0]); hipFree(e->f_pcol[1]);
     hipFree(e->f_st[0]); hipFree(e->f_st[1]);
     hipFree(e->r_gran); hipFree(e->r_rows[0]); hipFree(e->r_rows[1]); hipFree(e->r_sync);
@@ -935,6 +939,109 @@ extern "C" int jslp_engine_mir_round(jslp_engine* e, int check_cycles, int32_t* 
     rc = jslp_engine_simplex(e, check_cycles, out);
     if (rc) return rc;
     return jslp_engine_read_rhs(e, rhs, var_index_by_row);
+}
+
+// ---- fp32 twin -----------------------------------------------------------------------------------------------------
+static int ensure_f32(jslp_engine* e) {
+    if (e->arena32) return JSLP_OK;
+    f32::Slots& s = e->s32;
+    s.A_stride = (long long)e->cap_rows * e->ld;
+    s.vibr_stride = e->cap_rows; s.vibc_stride = e->W; s.idx_stride = e->n_idx;
+    s.prow_stride = e->ld; s.pcol_stride = e->cap_rows;
+    s.hist_cap = (int32_t)HIST_CAP_SLOT;
+    s.ld = e->ld; s.W = e->W; s.batch = e->batch; s.use_partial = e->use_partial;
+    s.oo = nullptr; s.oo_stride = 0; s.n_opt = 0;
+    s.trace = nullptr; s.trace_cap = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        Carver cv{pass ? e->arena32 : nullptr, 0};
+        s.A = cv.take<float>((size_t)s.A_stride);
+        s.vibr = cv.take<int32_t>((size_t)s.vibr_stride);
+        s.vibc = cv.take<int32_t>((size_t)s.vibc_stride);
+        s.rbv = cv.take<int32_t>((size_t)s.idx_stride);
+        s.cbv = cv.take<int32_t>((size_t)s.idx_stride);
+        s.prow = cv.take<float>((size_t)s.prow_stride);
+        s.pcol = cv.take<float>((size_t)s.pcol_stride);
+        s.dirty = cv.take<uint8_t>((size_t)s.pcol_stride);
+        s.st = cv.take<DevState>(1);
+        s.hist = cv.take<int2>((size_t)s.hist_cap);
+        if (!pass) HIPC(hipMalloc(&e->arena32, cv.off + 256));
+    }
+    HIPC(hipMemsetAsync(e->arena32, 0, sizeof(float) * (size_t)s.A_stride, e->stream));  // padding columns / rows stay 0
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_simplex_f32(jslp_engine* e, double precision, int check_cycles, jslp_simplex_result* out,
+                                       double* rhs, int32_t* var_index_by_row, double* device_ms) {
+    if (!e || !out) return fail(JSLP_ERR_ARG, "simplex_f32: null pointer");
+    if (!e->uploaded) return fail(JSLP_ERR_STATE, "simplex_f32 before upload");
+    if (e->n_opt > 0) return fail(JSLP_ERR_UNSUPPORTED, "simplex_f32: optional objectives are not part of the fp32 experiment");
+    if (!(precision > 0)) return fail(JSLP_ERR_ARG, "simplex_f32: precision must be positive");
+    HIPC(hipSetDevice(e->device));
+    int rc = ensure_f32(e);
+    if (rc) return rc;
+    rc = ensure_out(e, 1);
+    if (rc) return rc;
+    hipStream_t s = e->stream;
+    f32::Slots& d = e->s32;
+    d.unr = e->d_unr;
+    d.has_unr = e->n_unr > 0 ? 1 : 0;
+    d.precision = (float)precision;
+    hipLaunchKernelGGL(k32_convert, dim3(copy_grid(e, 1).x), dim3(256), 0, s, e->s, d, 0);
+    hipLaunchKernelGGL(f32::k_begin, dim3(1), dim3(1), 0, s, d, 0, iters_cap(e));
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(e->h_state, d.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    const int H = e->h_state->H;
+    f32::Ctx c;
+    c.A = d.A; c.vibr = d.vibr; c.vibc = d.vibc; c.rbv = d.rbv; c.cbv = d.cbv; c.unr = d.unr;
+    c.prow = d.prow; c.pcol = d.pcol; c.dirty = d.dirty; c.oo = nullptr; c.n_opt = 0; c.st = d.st; c.hist = d.hist;
+    c.hist_cap = d.hist_cap; c.trace = nullptr; c.trace_cap = 0; c.ld = e->ld; c.W = e->W; c.check_cycles = check_cycles;
+    c.batch = e->batch; c.use_partial = e->use_partial; c.precision = (float)precision; c.stop_at_phase2 = 0;
+    c.has_unr = d.has_unr;
+    const dim3 grid = update_grid(e, H);
+    HIPC(hipEventRecord(e->ev_begin, s));
+    for (int chunk = 8;; chunk = std::min(chunk * 2, 256)) {
+        for (int i = 0; i < chunk; i++) {
+            hipLaunchKernelGGL(f32::k_select, dim3(1), dim3(JSLP_WG_THREADS), 0, s, c);
+            hipLaunchKernelGGL(f32::k_update, grid, dim3(JSLP_UPD_THREADS), 0, s, c);
+        }
+        HIPC(hipGetLastError());
+        HIPC(hipMemcpyAsync(e->h_state, d.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+        HIPC(hipStreamSynchronize(s));
+        if (e->h_state->status != ST_RUNNING) break;
+    }
+    HIPC(hipEventRecord(e->ev_end, s));
+    hipLaunchKernelGGL(k32_gather, dim3(1), dim3(256), 0, s, d, e->d_rhs, e->d_rows, e->d_states);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(e->h_out, e->d_out, out_bytes(e, 1), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    const DevState st = e->h_states[0];
+    rc = state_error(st);
+    if (rc) return rc;
+    if (device_ms) {
+        float ms = 0;
+        *device_ms = hipEventElapsedTime(&ms, e->ev_begin, e->ev_end) == hipSuccess ? ms : -1.0;
+    }
+    memset(out, 0, sizeof *out);
+    out->feasible = st.feasible;
+    out->bounded = st.bounded;
+    out->optimal = st.optimal;
+    out->unbounded_var_index = st.bounded ? -1 : st.unbounded_var;
+    out->pivots_phase1 = st.it1;
+    out->pivots_phase2 = st.entered_phase2 ? st.it2 : -1;
+    out->cycle_phase = st.cycle_phase;
+    out->height = st.H;
+    out->obj_cell = st.obj_cell;
+    out->evaluation = e->evaluation;
+    if (st.optimal) {
+        const double rcoef = js_round(1.0 / precision);
+        out->evaluation = js_round((2.220446049250313e-16 + st.obj_cell) * rcoef) / rcoef;
+    } else if (!st.bounded) {
+        out->evaluation = -INFINITY;
+    }
+    if (rhs) memcpy(rhs, e->h_rhs, sizeof(double) * st.H);
+    if (var_index_by_row) memcpy(var_index_by_row, e->h_rows, sizeof(int32_t) * st.H);
+    return JSLP_OK;
 }
 
 // Shared body of relax_batch / relax_batch_pinned.  Per-node-workgroup path: all groups are enqueued back to back,

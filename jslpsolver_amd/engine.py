@@ -168,6 +168,19 @@ class Tableau:
         vibr = np.ctypeslib.as_array(p_rows, shape=shape) if want_rows else None
         return out, rhs, vibr
 
+    # ---- fp32 experiment ------------------------------------------------------------------------------------
+    def simplex_f32(self, precision, check_cycles=True):
+        """simplex() on an fp32 copy of the live tableau with tolerance `precision` (SURVEY.md 8d, config 5's fp32-vs-fp64
+        sweep).  The fp64 tableau and the Tableau scalars are left alone.  Returns (result, rhs, varIndexByRow, device ms)."""
+        res = SimplexResult()
+        rhs = np.empty(self.row_capacity, dtype=np.float64)
+        vibr = np.empty(self.row_capacity, dtype=np.int32)
+        ms = _capi.C.c_double(0.0)
+        self.lib.check(self.lib.jslp_engine_simplex_f32(self._h, float(precision), int(bool(check_cycles)), _capi.C.byref(res),
+                                                        _capi.ptr_f64(rhs), _capi.ptr_i32(vibr), _capi.C.byref(ms)),
+                       "jslp_engine_simplex_f32")
+        return res, rhs[:res.height], vibr[:res.height], ms.value
+
     # ---- MIR cuts (cutting-strategies.ts:74-212) --------------------------------------------------------
     def applyMIRCuts(self):
         """Tableau.applyMIRCuts (:199-212); returns the number of rows appended"""

@@ -770,6 +770,13 @@ int jslp_engine_mir_round(jslp_engine* e, int check_cycles, int32_t* n_added, js
     return jslp_engine_read_rhs(e, rhs, var_index_by_row);
 }
 
+/* the fp32 experiment has no reference semantics to restate */
+int jslp_engine_simplex_f32(jslp_engine* e, double precision, int check_cycles, jslp_simplex_result* out, double* rhs,
+                            int32_t* var_index_by_row, double* device_ms) {
+    (void)e; (void)precision; (void)check_cycles; (void)out; (void)rhs; (void)var_index_by_row; (void)device_ms;
+    return fail(JSLP_ERR_UNSUPPORTED, "simplex_f32: not part of the reference (HIP engine only)");
+}
+
 /* createCheckpoint (incremental-branch-and-cut.ts:55-70) */
 int jslp_engine_checkpoint_create(jslp_engine* e, int32_t* id_out) {
     if (!e || !id_out) return fail(JSLP_ERR_ARG, "checkpoint_create: null");

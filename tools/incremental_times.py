@@ -34,6 +34,8 @@ POLICIES = [
     ("default service (every node from the root)", {}),
     ("useIncremental (hybrid + pseudocost)", {"useIncremental": True}),
     ("useIncremental, depth-first + most-fractional", {"useIncremental": True, "nodeSelection": "depth-first", "branching": "most-fractional"}),
+    ("default service + useMIRCuts", {"useMIRCuts": True}),
+    ("useIncremental + useMIRCuts", {"useIncremental": True, "useMIRCuts": True}),
 ]
 
 
@@ -49,7 +51,7 @@ def main(out_path=None):
     lib = _capi.load_hip()
     lines = ["| model | service | relaxations | pivots | checkpoints | Python host + HIP (ms) | reference host + N-API + HIP (ms) | reference on CPU, node 12 (ms) | result (py / shim / ref) |",
              "|---|---|---|---|---|---|---|---|---|"]
-    for name in ("Vendor_Selection", "Monster_II", "Integer_Wood_Shop_Problem"):
+    for name in ("Vendor_Selection", "Monster_II", "Knapsack_1"):
         path = os.path.join(ROOT, "tests", "golden", "fixtures", name + ".json.gz")
         with gzip.open(path, "rt") as fh:
             g = json.load(fh)
