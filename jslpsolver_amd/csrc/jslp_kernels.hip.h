@@ -15,6 +15,10 @@
 //   * k_select + k_update: one tableau spread over all CUs (large LPs, HBM-bandwidth bound)
 //   * k_simplex_wg: one WORKGROUP runs a whole simplex() for one tableau (small tableaus and batches of
 //     independent branch-and-bound nodes: grid = #nodes, no host round trip per pivot).
+// Those functions live in jslp_core.inc.h, written over `real_t` and compiled below for double (the engine) and for
+// float (namespace f32: the fp32 twin used by the fp32-vs-fp64 sweep only).  This file adds what exists once:
+// snapshots / checkpoints / cuts / MIR cuts / read-back, the fused one-launch-per-pivot phase 2 and the
+// register-resident whole-solve kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
