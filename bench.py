@@ -204,6 +204,12 @@ def main():
         if phase1 is not None:
             line["phase1_instance"] = phase1
         if not args.no_cpu_baseline and world == 1:
+            if relax is not None:
+                relax["cpu_baseline"] = cpu_relaxation_baseline()
+                if relax["cpu_baseline"] and relax["cpu_baseline"].get("value"):
+                    relax["speedup_vs_cpu_1_thread"] = relax["value"] / relax["cpu_baseline"]["value"]
+                    if relax["cpu_baseline"].get("aggregate_value"):
+                        relax["speedup_vs_cpu_all_cores"] = relax["value"] / relax["cpu_baseline"]["aggregate_value"]
             line["cpu_baseline"] = cpu_baseline(n, args.cpu_sample_pivots)
             if line["cpu_baseline"] and line["cpu_baseline"].get("value"):
                 line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
@@ -237,17 +243,64 @@ def relaxation_throughput(lib, device, rank, world, barrier, max_over_ranks, sum
     # engine entry point itself: restore + add cuts + simplex + RHS / row-map read-back for every node
     packed = t.pack_cut_lists(mine)
     t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)  # warm-up (allocates the slots)
+    calls = 5
     barrier()
     t0 = time.perf_counter()
-    results, rhs, rows = t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+    for _ in range(calls):
+        results, rhs, rows = t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
     barrier()
-    el = max_over_ranks(time.perf_counter() - t0)
+    el = max_over_ranks(time.perf_counter() - t0) / calls
     total = sum_over_ranks(float(len(mine)))
-    piv = sum_over_ranks(float(sum(results[i].pivots_phase1 + max(results[i].pivots_phase2, 0) for i in range(len(mine)))))
+    my_pivots = [results[i].pivots_phase1 + max(results[i].pivots_phase2, 0) for i in range(len(mine))]
+    piv = sum_over_ranks(float(sum(my_pivots)))
+    # algorithmic bytes of one relaxation: restore = 16*H*W, then p pivots of 16*H'*W with H' = H + #cuts
+    H, W = m.shape
+    my_bytes = sum(16.0 * H * W + p * 16.0 * results[i].height * W for i, p in enumerate(my_pivots))
+    alg_bytes = sum_over_ranks(float(my_bytes))
     t.close()
     return {"value": total / el, "unit": "LP relaxations/s", "nodes": int(total), "pivots": int(piv), "seconds": el,
+            "calls_averaged": calls,
+            "roofline": {"bound": "latency (per-node kernel); hbm for reference", "achieved": alg_bytes / el / 1e9 / world,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s per GPU", "frac": alg_bytes / el / world / HBM_PEAK,
+                         "note": "algorithmic bytes per relaxation = 16*H*W (restore) + pivots * 16*H'*W as SURVEY.md 8d defines "
+                                 "them (dense update of every cell); the per-node kernel restores only dirty rows and updates "
+                                 "only the rows/columns the reference's zero gate touches, so its real HBM traffic is far "
+                                 "below this figure and the fraction can exceed 1"},
             "workload": "config 4: Monster_II (935x925 root, 112 ints), the reference's 151 visited cut lists x%d as one "
                         "batch of independent nodes per rank, sharded round-robin over %d rank(s) (weak scaling)" % (reps, world)}
+
+
+def cpu_relaxation_baseline(seconds=4.0):
+    """The reference itself on config 4 on this box's host cores: LP relaxations/s of solver.Solve(Monster_II) with one
+    thread, and the aggregate of one such process per core (the generous CPU figure of SURVEY.md 8d)."""
+    script = os.path.join(ROOT, "oracle", "ref_relax_rate.js")
+    fixture = os.path.join(ROOT, "tests", "golden", "fixtures", "Monster_II.json.gz")
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "src", "solver.js")):
+        return None
+
+    def run(n_proc):
+        procs = [subprocess.Popen(["node", script, fixture, str(seconds)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                  stdin=subprocess.DEVNULL, text=True) for _ in range(n_proc)]
+        rates = []
+        for pr in procs:
+            try:
+                out, _ = pr.communicate(timeout=120)
+                rates.append(json.loads([l for l in out.splitlines() if l.startswith("{")][-1])["relaxations_per_sec"])
+            except Exception:
+                pr.kill()
+        return rates
+
+    try:
+        one = run(1)
+        cores = os.cpu_count() or 1
+        many = run(cores)
+        return {"value": one[0] if one else None, "unit": "LP relaxations/s", "cores": 1, "kind": "reference",
+                "aggregate_value": sum(many) if many else None, "aggregate_processes": len(many),
+                "sample": "solver.Solve(Monster_II) repeated for ~%.0f s per process after one warm-up (151 B&B relaxations + root + "
+                          "final per solve), clock = Tableau.solve() only; aggregate = one independent node process per host core "
+                          "(%d), all running concurrently" % (seconds, cores)}
+    except Exception as e:
+        return {"value": None, "unit": "LP relaxations/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
 
 
 if __name__ == "__main__":
