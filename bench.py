@@ -218,7 +218,7 @@ def main():
         dist.destroy_process_group()
 
 
-def relaxation_throughput(lib, device, rank, world, barrier, max_over_ranks, sum_over_ranks, reps=8):
+def relaxation_throughput(lib, device, rank, world, barrier, max_over_ranks, sum_over_ranks, reps=16):
     """Config 4 throughput variant: the 151 cut lists the reference visits on Monster_II,
     replicated `reps` times, evaluated as independent nodes; rank r takes nodes r, r+world, ... (no collective
     in the data path).  Needs the committed golden fixture for the cut lists only."""

@@ -18,6 +18,7 @@ struct Ctx {
     real_t* prow;
     real_t* pcol;
     uint8_t* dirty;       // [cap_rows] row differs from the snapshot (maintained by the per-node kernel only)
+    real_t* rhs;          // [cap_rows] contiguous mirror of column 0 (valid iff st->rhs_valid; nullptr = read A with a stride)
     real_t* oo;           // optional objectives: n_opt rows of ld doubles (optionalObjectives[o].reducedCosts)
     int32_t n_opt;
     DevState* st;
@@ -45,6 +46,7 @@ struct Slots {
     real_t* prow;    int32_t prow_stride;
     real_t* pcol;    int32_t pcol_stride;
     uint8_t* dirty;  // stride = pcol_stride
+    real_t* rhs;     // stride = pcol_stride; see Ctx::rhs
     real_t* oo;      long long oo_stride;  // n_opt * ld per slot
     int32_t n_opt;
     DevState* st;
@@ -67,6 +69,7 @@ __device__ __forceinline__ Ctx slot_ctx(const Slots& s, int slot, int check_cycl
     c.prow = s.prow + (long long)slot * s.prow_stride;
     c.pcol = s.pcol + (long long)slot * s.pcol_stride;
     c.dirty = s.dirty + (long long)slot * s.pcol_stride;
+    c.rhs = s.rhs ? s.rhs + (long long)slot * s.pcol_stride : nullptr;
     c.oo = s.oo ? s.oo + (long long)slot * s.oo_stride : nullptr;
     c.n_opt = s.n_opt;
     c.st = s.st + slot;
@@ -203,6 +206,7 @@ __device__ __forceinline__ void prepare_pivot(const Ctx& c, int pr, int pc, bool
             if (col == pc) v = 1.0 / quot;          // :364 (membership of pc in nonZeroColumns is decided by `val`)
             if (in_list && anyrow && !nonzero16(v) && v != 0.0) v = 0.0;  // :381-383
             prow_A[col] = v;
+            if (col == 0 && c.rhs) c.rhs[pr] = v;
         }
         c.prow[col] = v;
     }
@@ -287,7 +291,7 @@ __device__ void select_step(const Ctx& c, Smem& sm) {
         // leaving row: most negative RHS below -precision, first index on ties (simplex.ts:39-49)
         Cand best; best.v = -precision; best.i = 0; best.b = 0;
         for (int r = 1 + tid; r < H; r += nt) {
-            const real_t v = A[(long long)r * ld];
+            const real_t v = c.rhs ? c.rhs[r] : A[(long long)r * ld];
             if (v < best.v) { best.v = v; best.i = r; }
         }
         best = block_reduce(best, MinFirst(), sm);
@@ -390,7 +394,7 @@ __device__ void select_step(const Ctx& c, Smem& sm) {
             const real_t colv = A[(long long)r * ld + pc];
             c.pcol[r] = colv;  // the update step needs the whole column anyway (row 0 included)
             if (r == 0) continue;
-            const real_t rhs = A[(long long)r * ld];
+            const real_t rhs = c.rhs ? c.rhs[r] : A[(long long)r * ld];
             if (-precision < colv && colv < precision) continue;
             if (colv > 0 && precision > rhs && rhs > -precision) {
                 if (r < rdeg) rdeg = r;
@@ -500,11 +504,11 @@ __global__ void __launch_bounds__(JSLP_UPD_THREADS) k_update(Ctx c) {
 // parallel and the rows that pass the reference's gate (simplex.ts:370-375) are compacted into an LDS list, so
 // the waves only ever touch rows the reference touches (a Monster_II pivot: ~10 of 945) and never chain dependent
 // global loads; lanes take column pairs.  Touched rows are flagged dirty for the next restore().
-#define JSLP_ACT_CAP 4096
+template <int CAP>
 struct ActSmem {
     int32_t n;
-    int32_t row[JSLP_ACT_CAP];
-    real_t k[JSLP_ACT_CAP];
+    int32_t row[CAP];
+    real_t k[CAP];
 };
 
 __device__ __forceinline__ void update_row_wave(const Ctx& c, int r, real_t k, int pc, real_t quot, int lane) {
@@ -523,10 +527,12 @@ __device__ __forceinline__ void update_row_wave(const Ctx& c, int r, real_t k, i
             if (pc == c0) x.x = nv; else x.y = nv;
         }
         *reinterpret_cast<real2_t*>(row + c0) = x;
+        if (c0 == 0 && c.rhs) c.rhs[r] = x.x;
     }
 }
 
-__device__ __forceinline__ void update_rows_wg(const Ctx& c, ActSmem& act) {
+template <int CAP>
+__device__ __forceinline__ void update_rows_wg(const Ctx& c, ActSmem<CAP>& act) {
     const DevState* st = c.st;
     const int H = st->H, pr = st->pr, pc = st->pc;
     const real_t quot = st->quot;
@@ -538,13 +544,13 @@ __device__ __forceinline__ void update_rows_wg(const Ctx& c, ActSmem& act) {
         const real_t k = c.pcol[r];
         if (r != pr && nonzero16(k)) {
             const int idx = atomicAdd(&act.n, 1);
-            if (idx < JSLP_ACT_CAP) { act.row[idx] = r; act.k[idx] = k; }
+            if (idx < CAP) { act.row[idx] = r; act.k[idx] = k; }
             c.dirty[r] = 1;
         }
     }
     __syncthreads();
     const int n = act.n;
-    if (n <= JSLP_ACT_CAP) {
+    if (n <= CAP) {
         for (int i = w; i < n; i += nw) update_row_wave(c, act.row[i], act.k[i], pc, quot, lane);
     } else {  // more gated-in rows than the list holds: walk all rows (wave-uniform gate)
         for (int r = w; r < H; r += nw) {
@@ -567,7 +573,7 @@ __global__ void __launch_bounds__(JSLP_WG_THREADS) k_select(Ctx c) {
 // Tableau.pivot(r, c) on its own
 __global__ void __launch_bounds__(JSLP_WG_THREADS) k_prepare(Ctx c, int pr, int pc) {
     __shared__ Smem sm;
-    if (threadIdx.x == 0) { c.st->status = ST_RUNNING; c.st->gen = 0; }
+    if (threadIdx.x == 0) { c.st->status = ST_RUNNING; c.st->gen = 0; c.st->rhs_valid = 0; }
     __syncthreads();
     prepare_pivot(c, pr, pc, false, sm);
 }
@@ -594,16 +600,28 @@ __device__ __forceinline__ void begin_simplex(DevState* st, int iters_cap) {
 }
 __global__ void k_begin(Slots s, int first_slot, int iters_cap) {
     begin_simplex(s.st + first_slot + blockIdx.x, iters_cap);
-    s.st[first_slot + blockIdx.x].gen = 0;  // the chip-wide kernels do not maintain dirty-row flags
+    s.st[first_slot + blockIdx.x].gen = 0;  // the chip-wide kernels do not maintain dirty-row flags ...
+    s.st[first_slot + blockIdx.x].rhs_valid = 0;  // ... nor the RHS mirror
 }
 
 // One workgroup = one whole simplex() on one tableau (slot first_slot + blockIdx.x).
-__global__ void __launch_bounds__(JSLP_WG_THREADS) k_simplex_wg(Slots s, int first_slot, int check_cycles, int iters_cap) {
+// THREADS = workgroup size the launch uses, CAP = capacity of the LDS list of gated-in rows (more rows than that: every
+// row is walked).  <1024, 4096> is the latency shape for ONE tableau; batches of nodes trade per-node latency for nodes
+// in flight per CU with smaller workgroups (chosen by the host, jslp_hip.hip).
+template <int THREADS, int CAP>
+__global__ void __launch_bounds__(THREADS) k_simplex_wg(Slots s, int first_slot, int check_cycles, int iters_cap) {
     __shared__ Smem sm;
-    __shared__ ActSmem act;
+    __shared__ ActSmem<CAP> act;
     const Ctx c = slot_ctx(s, first_slot + blockIdx.x, check_cycles);
     if (threadIdx.x == 0) begin_simplex(c.st, iters_cap);
     __syncthreads();
+    if (c.rhs && !c.st->rhs_valid) {  // first use after a chip-wide solve / an upload: one strided gather, then contiguous
+        const int H = c.st->H;
+        for (int r = threadIdx.x; r < H; r += blockDim.x) c.rhs[r] = c.A[(long long)r * c.ld];
+        __syncthreads();
+        if (threadIdx.x == 0) c.st->rhs_valid = 1;
+        __syncthreads();
+    }
     if (c.st->err != ERR_NONE) {  // a bad cut list: report, do not solve
         if (threadIdx.x == 0) finish(c);
         return;

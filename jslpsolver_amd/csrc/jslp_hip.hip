@@ -46,7 +46,7 @@ struct jslp_engine {
     char* slot_arena = nullptr;
     char* static_arena = nullptr;
     // snapshot
-    double* snap_A = nullptr;
+    double* snap_A = nullptr; double* snap_rhs = nullptr;
     int32_t *snap_vibr = nullptr, *snap_vibc = nullptr, *snap_rbv = nullptr, *snap_cbv = nullptr;
     uint8_t* d_unr = nullptr;
     uint8_t* d_isint = nullptr;  // variable.isInteger per variable index (MIR cuts)
@@ -65,7 +65,7 @@ struct jslp_engine {
     // checkpoints (incremental-branch-and-cut.ts:31-44): equally sized device buffers, recycled through a free list
     struct Ckpt {
         char* mem = nullptr;
-        double* A = nullptr;
+        double* A = nullptr; double* rhs = nullptr;
         int32_t *vibr = nullptr, *vibc = nullptr, *rbv = nullptr, *cbv = nullptr;
         int32_t H = 0, last_element_index = 0;
         double evaluation = 0;
@@ -98,7 +98,32 @@ struct jslp_engine {
 
 static const long long WG_CELLS_SINGLE = 64 * 1024;         // one workgroup beats 2 launches/pivot below this
 static const long long WG_CELLS_BATCH = 4LL * 1024 * 1024;  // batches use one workgroup per node up to this
-static const long long WG_CELLS_CHILD = 1536LL * 1024;      // a single B&B child (few repair pivots) stays in one workgroup up to this
+static int wg_batch_threads() {  // workgroup size of the per-node kernel when a call carries several nodes
+    static int v = -1;
+    if (v < 0) {
+        const char* t = getenv("JSLP_WG_BATCH_THREADS");  // tuning knob (tools/relax_batch_scaling.py)
+        v = t ? atoi(t) : 512;  // measured on Monster_II node batches (tools/wg_shape_sweep.sh): 512 > 1024 > 256
+        if (v != 256 && v != 1024) v = 512;
+    }
+    return v;
+}
+static int group_max() {  // nodes per group of a batch (= tableau copies alive at once)
+    static int v = -1;
+    if (v < 0) {
+        const char* t = getenv("JSLP_GROUP_MAX");  // tuning knob
+        v = t ? atoi(t) : 1024;
+        if (v < 1) v = 1024;
+    }
+    return v;
+}
+static long long wg_cells_child() {  // a single B&B child (few repair pivots) stays in one workgroup up to this
+    static long long v = -1;
+    if (v < 0) {
+        const char* t = getenv("JSLP_WG_CELLS_CHILD");  // tuning knob (tools/child_path_times.py)
+        v = t ? atoll(t) : 1536LL * 1024;
+    }
+    return v;
+}
 static const size_t HIST_CAP_MAIN = 1u << 20;
 static const size_t HIST_CAP_SLOT = 1u << 16;
 static const long long TRACE_CAP = 1LL << 20;
@@ -131,7 +156,7 @@ static void free_slots(jslp_engine* e) {
     e->slot_arena = nullptr;
     e->s.dirty = nullptr; e->s.oo = nullptr;
     e->s.A = nullptr; e->s.vibr = e->s.vibc = e->s.rbv = e->s.cbv = nullptr;
-    e->s.prow = e->s.pcol = nullptr; e->s.st = nullptr; e->s.hist = nullptr;
+    e->s.prow = e->s.pcol = nullptr; e->s.rhs = nullptr; e->s.st = nullptr; e->s.hist = nullptr;
 }
 
 static void carve_slots(Slots& s, Carver& cv, int n) {
@@ -143,6 +168,7 @@ static void carve_slots(Slots& s, Carver& cv, int n) {
     s.prow = cv.take<double>((size_t)s.prow_stride * n);
     s.pcol = cv.take<double>((size_t)s.pcol_stride * n);
     s.dirty = cv.take<uint8_t>((size_t)s.pcol_stride * n);
+    s.rhs = cv.take<double>((size_t)s.pcol_stride * n);
     s.st = cv.take<DevState>((size_t)n);
     s.hist = cv.take<int2>((size_t)s.hist_cap * n);
 }
@@ -187,6 +213,7 @@ static int ensure_slots(jslp_engine* e, int n) {
         HIPC(hipMemcpyAsync(s.cbv, o.cbv, sizeof(int32_t) * o.idx_stride, hipMemcpyDeviceToDevice, e->stream));
         HIPC(hipMemcpyAsync(s.st, o.st, sizeof(DevState), hipMemcpyDeviceToDevice, e->stream));
         HIPC(hipMemcpyAsync(s.dirty, o.dirty, (size_t)o.pcol_stride, hipMemcpyDeviceToDevice, e->stream));
+        HIPC(hipMemcpyAsync(s.rhs, o.rhs, sizeof(double) * (size_t)o.pcol_stride, hipMemcpyDeviceToDevice, e->stream));
         if (e->n_opt > 0 && o.oo) HIPC(hipMemcpyAsync(s.oo, o.oo, sizeof(double) * (size_t)o.oo_stride, hipMemcpyDeviceToDevice, e->stream));
         HIPC(hipStreamSynchronize(e->stream));
         hipFree(old_arena);
@@ -247,6 +274,7 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
                 e->d_unr = cv.take<uint8_t>((size_t)e->n_idx);
                 e->d_isint = cv.take<uint8_t>((size_t)e->n_idx);
                 e->snap_A = cv.take<double>(cells);
+                e->snap_rhs = cv.take<double>((size_t)e->cap_rows);
                 e->snap_vibr = cv.take<int32_t>((size_t)e->cap_rows);
                 e->snap_vibc = cv.take<int32_t>((size_t)e->W);
                 e->snap_rbv = cv.take<int32_t>((size_t)e->n_idx);
@@ -387,7 +415,7 @@ extern "C" int jslp_engine_get_optional_objectives(jslp_engine* e, double* rows,
 static Ctx host_ctx(const jslp_engine* e, int check_cycles) {
     Ctx c;
     c.A = e->s.A; c.vibr = e->s.vibr; c.vibc = e->s.vibc; c.rbv = e->s.rbv; c.cbv = e->s.cbv; c.unr = e->s.unr;
-    c.prow = e->s.prow; c.pcol = e->s.pcol; c.dirty = e->s.dirty; c.oo = e->s.oo; c.n_opt = e->n_opt; c.st = e->s.st; c.hist = e->s.hist; c.hist_cap = e->s.hist_cap;
+    c.prow = e->s.prow; c.pcol = e->s.pcol; c.dirty = e->s.dirty; c.rhs = nullptr; c.oo = e->s.oo; c.n_opt = e->n_opt; c.st = e->s.st; c.hist = e->s.hist; c.hist_cap = e->s.hist_cap;
     c.trace = e->s.trace; c.trace_cap = e->s.trace_cap; c.ld = e->ld; c.W = e->W; c.check_cycles = check_cycles;
     c.batch = e->batch; c.use_partial = e->use_partial; c.precision = e->precision; c.stop_at_phase2 = 0;
     c.has_unr = e->n_unr > 0 ? 1 : 0;
@@ -525,7 +553,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
     HIPC(hipEventRecord(e->ev_begin, s));
     if (use_wg_single(e)) {
         e->last_path = "workgroup";
-        hipLaunchKernelGGL(k_simplex_wg, dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
+        hipLaunchKernelGGL((k_simplex_wg<JSLP_WG_THREADS, 4096>), dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
         HIPC(hipGetLastError());
         HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
         HIPC(hipEventRecord(e->ev_end, s));
@@ -722,7 +750,7 @@ static dim3 copy_grid(const jslp_engine* e, int slots) {
 extern "C" int jslp_engine_save(jslp_engine* e) {
     if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "save before upload");
     HIPC(hipSetDevice(e->device));
-    SnapshotW w{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo};
+    SnapshotW w{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, e->snap_rhs};
     hipLaunchKernelGGL(k_save, dim3(copy_grid(e, 1).x), dim3(256), 0, e->stream, e->s, w);
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(e->stream));
@@ -734,11 +762,11 @@ extern "C" int jslp_engine_save(jslp_engine* e) {
 static int enqueue_restore(jslp_engine* e, int first_slot, int n, int checkpoint = -1) {
     if (checkpoint < 0) {
         if (!e->has_save) return JSLP_OK;  // backup.ts:54-56
-        Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0};
+        Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs};
         hipLaunchKernelGGL(k_restore, copy_grid(e, n), dim3(256), 0, e->stream, e->s, sn, first_slot);
     } else {
         const jslp_engine::Ckpt& c = e->ckpts[checkpoint];
-        Snapshot sn{c.A, c.vibr, c.vibc, c.rbv, c.cbv, e->n_idx, nullptr, c.H, c.last_element_index};
+        Snapshot sn{c.A, c.vibr, c.vibc, c.rbv, c.cbv, e->n_idx, nullptr, c.H, c.last_element_index, c.rhs};
         hipLaunchKernelGGL(k_restore, copy_grid(e, n), dim3(256), 0, e->stream, e->s, sn, first_slot);
     }
     hipLaunchKernelGGL(k_restore_commit, dim3(n), dim3(1), 0, e->stream, e->s, first_slot, checkpoint < 0 ? 1 : 0);
@@ -763,6 +791,7 @@ extern "C" int jslp_engine_checkpoint_create(jslp_engine* e, int32_t* id_out) {
     for (int pass = 0; pass < 2; pass++) {  // every buffer is sized for the row capacity, so freed ones fit any later checkpoint
         Carver cv{pass ? c.mem : nullptr, 0};
         c.A = cv.take<double>((size_t)e->cap_rows * e->ld);
+        c.rhs = cv.take<double>((size_t)e->cap_rows);
         c.vibr = cv.take<int32_t>((size_t)e->cap_rows);
         c.vibc = cv.take<int32_t>((size_t)e->W);
         c.rbv = cv.take<int32_t>((size_t)e->n_idx);
@@ -781,7 +810,7 @@ extern "C" int jslp_engine_checkpoint_create(jslp_engine* e, int32_t* id_out) {
     c.last_element_index = e->h_state->last_element_index;
     c.evaluation = e->evaluation;
     c.live = 1;
-    SnapshotW w{c.A, c.vibr, c.vibc, c.rbv, c.cbv, e->n_idx, nullptr};
+    SnapshotW w{c.A, c.vibr, c.vibc, c.rbv, c.cbv, e->n_idx, nullptr, c.rhs};
     hipLaunchKernelGGL(k_checkpoint, dim3(copy_grid(e, 1).x), dim3(256), 0, e->stream, e->s, w, (int)c.H);
     HIPC(hipGetLastError());
     int32_t id = -1;
@@ -951,6 +980,7 @@ static int ensure_f32(jslp_engine* e) {
     s.hist_cap = (int32_t)HIST_CAP_SLOT;
     s.ld = e->ld; s.W = e->W; s.batch = e->batch; s.use_partial = e->use_partial;
     s.oo = nullptr; s.oo_stride = 0; s.n_opt = 0;
+    s.rhs = nullptr;
     s.trace = nullptr; s.trace_cap = 0;
     for (int pass = 0; pass < 2; pass++) {
         Carver cv{pass ? e->arena32 : nullptr, 0};
@@ -994,7 +1024,7 @@ extern "C" int jslp_engine_simplex_f32(jslp_engine* e, double precision, int che
     const int H = e->h_state->H;
     f32::Ctx c;
     c.A = d.A; c.vibr = d.vibr; c.vibc = d.vibc; c.rbv = d.rbv; c.cbv = d.cbv; c.unr = d.unr;
-    c.prow = d.prow; c.pcol = d.pcol; c.dirty = d.dirty; c.oo = nullptr; c.n_opt = 0; c.st = d.st; c.hist = d.hist;
+    c.prow = d.prow; c.pcol = d.pcol; c.dirty = d.dirty; c.rhs = nullptr; c.oo = nullptr; c.n_opt = 0; c.st = d.st; c.hist = d.hist;
     c.hist_cap = d.hist_cap; c.trace = nullptr; c.trace_cap = 0; c.ld = e->ld; c.W = e->W; c.check_cycles = check_cycles;
     c.batch = e->batch; c.use_partial = e->use_partial; c.precision = (float)precision; c.stop_at_phase2 = 0;
     c.has_unr = d.has_unr;
@@ -1072,15 +1102,15 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     // branch-and-bound children (a saved root exists) need a handful of repair pivots each: one workgroup, one launch,
     // no host round trip.  A first solve / plain LP goes through the chip-wide path unless the tableau is tiny.
     const bool wg = e->force_path == 1 ||
-                    (e->force_path == 0 && (((e->has_save || checkpoint >= 0) && cells <= (n_nodes > 1 ? WG_CELLS_BATCH : WG_CELLS_CHILD)) || use_wg_single(e)));
+                    (e->force_path == 0 && (((e->has_save || checkpoint >= 0) && cells <= (n_nodes > 1 ? WG_CELLS_BATCH : wg_cells_child())) || use_wg_single(e)));
     // a node that does not reach an optimum keeps the evaluation it started with: the checkpoint's (restoreCheckpoint,
     // incremental-branch-and-cut.ts:105) or the live one (restore() leaves it alone)
     const double prev_eval = checkpoint >= 0 ? e->ckpts[checkpoint].evaluation : e->evaluation;
-    // group size: bounded by memory (<= 8 GiB of tableau copies) and by what fills the chip twice over
+    // group size: bounded by memory (<= 16 GiB of the 288 GB for tableau copies) and by what keeps every CU busy with several nodes
     int group = 1;
     if (wg) {
-        const long long max_slots = std::max<long long>(1, (8LL << 30) / (cells * 8));
-        group = (int)std::min<long long>(std::min<long long>(n_nodes, 512), max_slots);
+        const long long max_slots = std::max<long long>(1, (16LL << 30) / (cells * 8));
+        group = (int)std::min<long long>(std::min<long long>(n_nodes, group_max()), max_slots);
         rc = ensure_slots(e, group);
         if (rc) return rc;
     }
@@ -1095,7 +1125,14 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         HIPC(hipGetLastError());
         if (wg) {
             e->last_path = "workgroup";
-            hipLaunchKernelGGL(k_simplex_wg, dim3(g), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
+            // one node: the 1024-thread latency shape; a batch: smaller workgroups, more nodes in flight per CU
+            const int shape = g == 1 ? 1024 : wg_batch_threads();
+            if (shape == 256)
+                hipLaunchKernelGGL((k_simplex_wg<256, 1024>), dim3(g), dim3(256), 0, s, e->s, 0, check_cycles, cap);
+            else if (shape == 512)
+                hipLaunchKernelGGL((k_simplex_wg<512, 2048>), dim3(g), dim3(512), 0, s, e->s, 0, check_cycles, cap);
+            else
+                hipLaunchKernelGGL((k_simplex_wg<JSLP_WG_THREADS, 4096>), dim3(g), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
             HIPC(hipGetLastError());
         } else {
             // big tableau: the chip-wide kernels on slot 0 (g == 1)

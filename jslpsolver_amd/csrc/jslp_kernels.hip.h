@@ -57,6 +57,7 @@ struct DevState {
     int32_t f_pc;         // entering column chosen for the NEXT launch's pivot
     int32_t f_final_buf;  // which ping-pong buffer holds the tableau when the pipeline stopped
     int32_t mir_added;    // rows appended by the last k_mir_cuts
+    int32_t rhs_valid;    // the slot's contiguous RHS mirror (Ctx::rhs) equals column 0 (kept by the per-node kernel only)
 };
 
 // ---- the simplex core, compiled for both scalar types (see jslp_core.inc.h) -------------------------------------
@@ -82,6 +83,7 @@ struct SnapshotW {
     int32_t *vibr, *vibc, *rbv, *cbv;
     int32_t n_idx;
     double* oo;
+    double* rhs;  // contiguous copy of column 0
 };
 // restore (backup.ts:53-105): snapshot -> slots [first_slot, first_slot+gridDim.y).  Grid-stride copy.
 struct Snapshot {
@@ -92,6 +94,7 @@ struct Snapshot {
     // H < 0: the saved root (scalars in slot 0's DevState).  Otherwise a checkpoint (incremental-branch-and-cut.ts:72-107)
     // with its own scalars; the dirty-row shortcut does not apply to it.
     int32_t H, last_element_index;
+    const double* rhs;  // contiguous copy of column 0
 };
 __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int first_slot) {
     const int slot = first_slot + blockIdx.y;
@@ -104,10 +107,12 @@ __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int fir
     const double2* src = reinterpret_cast<const double2*>(snap.A);
     double2* dst = reinterpret_cast<double2*>(s.A + (long long)slot * s.A_stride);
     uint8_t* dirty = s.dirty + (long long)slot * s.pcol_stride;
+    double* rhs = s.rhs + (long long)slot * s.pcol_stride;
     if (!incremental) {
         const long long n2 = (long long)H * s.ld / 2;
         for (long long i = tid; i < n2; i += nt) dst[i] = src[i];
         for (long long i = tid; i < s.pcol_stride; i += nt) dirty[i] = 0;
+        for (long long i = tid; i < H; i += nt) rhs[i] = snap.rhs[i];
     } else {
         // one wave per dirty row: rows are found by a strided scan of the byte flags
         const int lane = threadIdx.x & 63;
@@ -118,7 +123,7 @@ __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int fir
             const double2* a = src + r * ld2;
             double2* b = dst + r * ld2;
             for (int i = lane; i < ld2; i += 64) b[i] = a[i];
-            if (lane == 0) dirty[r] = 0;
+            if (lane == 0) { dirty[r] = 0; rhs[r] = snap.rhs[r]; }
         }
     }
     int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
@@ -136,6 +141,7 @@ __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int fir
         st->H = H;
         st->last_element_index = root ? s.st[0].s_last_element_index : snap.last_element_index;
         st->err = ERR_NONE;
+        if (!incremental) st->rhs_valid = 1;  // (an incremental restore keeps whatever the mirror's state was)
     }
 }
 // second half of restore(): record that the slots are in sync with the saved root (a separate tiny launch: k_restore's
@@ -216,6 +222,7 @@ __global__ void __launch_bounds__(256) k_mir_cuts(Slots s, const uint8_t* is_int
                 out = cut - a;  // :128-130
             }
             dst[c] = out;
+            if (c == 0) s.rhs[H + k] = out;
         }
     }
     if (threadIdx.x == 0) {
@@ -242,6 +249,7 @@ __global__ void __launch_bounds__(256) k_checkpoint(Slots s, SnapshotW ck, int H
     for (long long i = tid; i < H; i += nt) ck.vibr[i] = s.vibr[i];
     for (long long i = tid; i < s.W; i += nt) ck.vibc[i] = s.vibc[i];
     for (long long i = tid; i < ck.n_idx; i += nt) { ck.rbv[i] = s.rbv[i]; ck.cbv[i] = s.cbv[i]; }
+    for (long long i = tid; i < H; i += nt) ck.rhs[i] = s.A[i * s.ld];
 }
 
 // save (backup.ts:13-51): slot 0 -> snapshot
@@ -256,6 +264,7 @@ __global__ void __launch_bounds__(256) k_save(Slots s, SnapshotW snap) {
     for (long long i = tid; i < H; i += nt) snap.vibr[i] = s.vibr[i];
     for (long long i = tid; i < s.W; i += nt) snap.vibc[i] = s.vibc[i];
     for (long long i = tid; i < snap.n_idx; i += nt) { snap.rbv[i] = s.rbv[i]; snap.cbv[i] = s.cbv[i]; }
+    for (long long i = tid; i < H; i += nt) snap.rhs[i] = s.A[i * s.ld];
     if (s.n_opt > 0)  // backup.ts:37-43
         for (long long i = tid; i < s.oo_stride; i += nt) snap.oo[i] = s.oo[i];
     if (tid == 0) {
@@ -278,6 +287,7 @@ __global__ void __launch_bounds__(256) k_add_cuts(Slots s, Cuts cuts, int first_
     const int slot = first_slot + blockIdx.x, node = first_node + blockIdx.x;
     DevState* st = s.st + slot;
     double* A = s.A + (long long)slot * s.A_stride;
+    double* rhs = s.rhs + (long long)slot * s.pcol_stride;
     int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
     int32_t* rbv = s.rbv + (long long)slot * s.idx_stride;
     int32_t* cbv = s.cbv + (long long)slot * s.idx_stride;
@@ -301,7 +311,7 @@ __global__ void __launch_bounds__(256) k_add_cuts(Slots s, Cuts cuts, int first_
         if (var_row == -1) {  // non-basic variable: unit row (:46-53)
             for (int col = threadIdx.x; col < ld; col += blockDim.x) {
                 double v = 0.0;
-                if (col == 0) v = sign * value;
+                if (col == 0) { v = sign * value; rhs[H + h] = v; }
                 else if (col == var_col) v = sign;
                 cut[col] = v;
             }
@@ -309,7 +319,7 @@ __global__ void __launch_bounds__(256) k_add_cuts(Slots s, Cuts cuts, int first_
             const double* src = A + (long long)var_row * ld;
             for (int col = threadIdx.x; col < ld; col += blockDim.x) {
                 double v = 0.0;
-                if (col == 0) v = sign * (value - src[0]);
+                if (col == 0) { v = sign * (value - src[0]); rhs[H + h] = v; }
                 else if (col < W) v = -sign * src[col];
                 cut[col] = v;
             }
@@ -334,10 +344,12 @@ __global__ void __launch_bounds__(256) k_gather(Slots s, int first_slot, double*
     const int slot = first_slot + blockIdx.x, o = first_out + blockIdx.x;
     const DevState* st = s.st + slot;
     const double* A = s.A + (long long)slot * s.A_stride;
+    const double* mirror = s.rhs + (long long)slot * s.pcol_stride;
+    const bool mirrored = st->rhs_valid != 0;
     const int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
     const int H = st->H;
     for (int r = threadIdx.x; r < H; r += blockDim.x) {
-        if (rhs) rhs[(long long)o * out_stride + r] = A[(long long)r * s.ld];
+        if (rhs) rhs[(long long)o * out_stride + r] = mirrored ? mirror[r] : A[(long long)r * s.ld];
         if (rows) rows[(long long)o * out_stride + r] = vibr[r];
     }
     if (threadIdx.x == 0) states[o] = *st;

@@ -180,6 +180,17 @@ def test_relax_batch_equals_sequential_relax(hip_lib, oracle_lib):
     t.close()
 
 
+@pytest.mark.parametrize("threads,group", [(256, 64), (512, 200), (1024, 1024), (256, 2048)])
+def test_batch_launch_shapes(hip_lib, threads, group):
+    """every workgroup shape of the per-node kernel and several group sizes give the reference's per-node outcomes"""
+    import subprocess
+    import sys
+    env = dict(os.environ, JSLP_WG_BATCH_THREADS=str(threads), JSLP_GROUP_MAX=str(group))
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "batch_shape_worker.py")],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-1500:] + out.stderr[-1500:]
+
+
 def test_pivot_entry_point(hip_lib, oracle_lib):
     rng = np.random.default_rng(5)
     A = rng.integers(-5, 9, (9, 12)).astype(np.float64)
