@@ -8,6 +8,8 @@ with LIFO ties (src/tableau/min-heap.ts:43-49), most-fractional branching (src/t
 import math
 import time
 
+import numpy as np
+
 
 def js_round(x):
     """Math.round: nearest integer, ties toward +Infinity"""
@@ -68,32 +70,63 @@ class BranchMinHeap:
         return top
 
 
+class _RowMap:
+    """rowByVarIndex as the host tree reads it: variable index -> row of the final tableau (-1 = not basic)"""
+    __slots__ = ("row_of",)
+
+    def __init__(self, vibr):
+        v = np.asarray(vibr[1:], dtype=np.int64)
+        self.row_of = np.full(int(v.max()) + 2 if v.size else 1, -1, dtype=np.int64)
+        self.row_of[v] = np.arange(1, v.size + 1)
+
+    def get(self, index, default=-1):
+        if 0 <= index < self.row_of.shape[0]:
+            r = int(self.row_of[index])
+            return r if r != -1 else default
+        return default
+
+    def rows(self, indexes):
+        """rows of several variable indexes at once (-1 = not basic)"""
+        out = np.full(indexes.shape[0], -1, dtype=np.int64)
+        ok = indexes < self.row_of.shape[0]
+        out[ok] = self.row_of[indexes[ok]]
+        return out
+
+
 def _rows_by_var(vibr):
-    return {int(v): r for r, v in enumerate(vibr) if r > 0}
+    return _RowMap(vibr)
+
+
+def _js_round_vec(x):
+    f = np.floor(x)
+    return np.where(x - f >= 0.5, f + 1.0, f)
+
+
+def _integer_values(model, rhs, rows):
+    """(variable indexes, values) of the integer variables that are basic, in model.integerVariables order"""
+    idx = model.integer_index_array
+    r = rows.rows(idx)
+    basic = r != -1
+    return idx[basic], np.asarray(rhs, dtype=np.float64)[r[basic]]
 
 
 def is_integral(model, rhs, rows, precision):
     """mip-utils.ts:43-61"""
-    for var in model.integerVariables:
-        r = rows.get(var["index"], -1)
-        if r != -1:
-            value = float(rhs[r])
-            if abs(value - js_round(value)) > precision:
-                return False
-    return True
+    _idx, values = _integer_values(model, rhs, rows)
+    return not bool((np.abs(values - _js_round_vec(values)) > precision).any())
 
 
 def most_fractional_var(model, rhs, rows):
     """mip-utils.ts:100-126: first variable with the strictly biggest |v - round(v)|"""
-    biggest, sel_index, sel_value = 0.0, None, 0.0
-    for var in model.integerVariables:
-        r = rows.get(var["index"], -1)
-        if r != -1:
-            value = float(rhs[r])
-            fraction = abs(value - js_round(value))
-            if fraction > biggest:
-                biggest, sel_index, sel_value = fraction, var["index"], value
-    return sel_index, sel_value
+    idx, values = _integer_values(model, rhs, rows)
+    if values.size == 0:
+        return None, 0.0
+    fraction = np.abs(values - _js_round_vec(values))
+    fraction = np.where(np.isnan(fraction), -1.0, fraction)  # `fraction > biggest` is false for NaN
+    k = int(np.argmax(fraction))  # first index of the maximum
+    if not fraction[k] > 0.0:
+        return None, 0.0
+    return int(idx[k]), float(values[k])
 
 
 def fractional_volume(model, rhs, vibr, precision):

@@ -608,11 +608,8 @@ __global__ void k_begin(Slots s, int first_slot, int iters_cap) {
 // THREADS = workgroup size the launch uses, CAP = capacity of the LDS list of gated-in rows (more rows than that: every
 // row is walked).  <1024, 4096> is the latency shape for ONE tableau; batches of nodes trade per-node latency for nodes
 // in flight per CU with smaller workgroups (chosen by the host, jslp_hip.hip).
-template <int THREADS, int CAP>
-__global__ void __launch_bounds__(THREADS) k_simplex_wg(Slots s, int first_slot, int check_cycles, int iters_cap) {
-    __shared__ Smem sm;
-    __shared__ ActSmem<CAP> act;
-    const Ctx c = slot_ctx(s, first_slot + blockIdx.x, check_cycles);
+template <int CAP>
+__device__ __forceinline__ void simplex_wg(const Ctx& c, Smem& sm, ActSmem<CAP>& act, int iters_cap) {
     if (threadIdx.x == 0) begin_simplex(c.st, iters_cap);
     __syncthreads();
     if (c.rhs && !c.st->rhs_valid) {  // first use after a chip-wide solve / an upload: one strided gather, then contiguous
@@ -632,4 +629,11 @@ __global__ void __launch_bounds__(THREADS) k_simplex_wg(Slots s, int first_slot,
         update_rows_wg(c, act);
         __syncthreads();
     }
+}
+template <int THREADS, int CAP>
+__global__ void __launch_bounds__(THREADS) k_simplex_wg(Slots s, int first_slot, int check_cycles, int iters_cap) {
+    __shared__ Smem sm;
+    __shared__ ActSmem<CAP> act;
+    const Ctx c = slot_ctx(s, first_slot + blockIdx.x, check_cycles);
+    simplex_wg(c, sm, act, iters_cap);
 }

@@ -37,6 +37,7 @@ struct jslp_engine {
     double precision = 1e-8;
     int32_t batch = 50, use_partial = 0;
     int uploaded = 0, has_save = 0;
+    int slot0_synced = 0;  // slot 0 = current snapshot except for its dirty rows (st.gen == st.s_gen): k_node_wg may be used
     double evaluation = 0;
     // slots (slot 0 = the live tableau).  All per-slot arrays live in ONE device allocation (slot_arena), the
     // snapshot / flags / trace in another (static_arena): hipMalloc / hipFree cost ~0.1 ms apiece, and a Solve of a
@@ -87,6 +88,7 @@ struct jslp_engine {
     u64_t* r_gran = nullptr;  // [2][G][8] granules then [2][G] row flags (one allocation, zeroed per launch)
     u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr;
     int no_resident = 0;
+    int one_launch_nodes = 1;  // JSLP_NO_NODE_KERNEL=1: single children go through the five-launch sequence
     const char* last_path = "none";
     // timing
     int timing = 0;
@@ -262,6 +264,8 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     if (fp && !strcmp(fp, "resident")) e->force_path = 3;
     const char* nr = getenv("JSLP_NO_RESIDENT");
     if (nr && nr[0] == '1') e->no_resident = 1;
+    const char* nk = getenv("JSLP_NO_NODE_KERNEL");
+    if (nk && nk[0] == '1') e->one_launch_nodes = 0;
     const char* nt = getenv("JSLP_NT");
     e->nt = (nt && nt[0] == '1') ? 1 : 0;
     int rc = JSLP_OK;
@@ -368,6 +372,7 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
     HIPC(hipStreamSynchronize(s));  // the host vectors die here
     e->uploaded = 1;
     e->has_save = 0;
+    e->slot0_synced = 0;
     drop_checkpoints(e, 0);
     e->evaluation = 0;
     e->n_unr = n_unrestricted;
@@ -502,6 +507,7 @@ static int state_error(const DevState& st) {
         case ERR_CUT_ARG: return fail(JSLP_ERR_ARG, "add_cuts: variable index out of range or neither basic nor non-basic");
         case ERR_CAPACITY: return fail(JSLP_ERR_CAPACITY, "add_cuts: row / element-index capacity exceeded");
         case ERR_BARRIER: return fail(JSLP_ERR_DEVICE, "resident simplex kernel: grid barrier timed out (workgroups not co-resident?)");
+        case ERR_NOT_SYNCED: return fail(JSLP_ERR_STATE, "internal: one-launch node kernel used on a slot that is not in sync with the snapshot");
     }
     return fail(JSLP_ERR_DEVICE, "unknown device error code");
 }
@@ -549,6 +555,7 @@ static int ensure_events(jslp_engine* e, size_t n) {
 // simplex() of the live tableau (slot 0), leaving the final DevState in e->h_state
 static int run_simplex(jslp_engine* e, int check_cycles) {
     hipStream_t s = e->stream;
+    e->slot0_synced = 0;  // the chip-wide kernels do not maintain the dirty-row flags (k_begin zeroes st.gen)
     const int cap = iters_cap(e);
     HIPC(hipEventRecord(e->ev_begin, s));
     if (use_wg_single(e)) {
@@ -731,6 +738,7 @@ extern "C" int jslp_engine_pivot(jslp_engine* e, int32_t row, int32_t col) {
     HIPC(hipStreamSynchronize(s));
     const int H = e->h_state->H;
     if (row < 0 || row >= H || col < 0 || col >= e->W) return fail(JSLP_ERR_ARG, "pivot: index out of range");
+    e->slot0_synced = 0;  // k_prepare zeroes st.gen
     const Ctx c = host_ctx(e, 0);
     hipLaunchKernelGGL(k_prepare, dim3(1), dim3(JSLP_WG_THREADS), 0, s, c, (int)row, (int)col);
     hipLaunchKernelGGL(k_update, update_grid(e, H), dim3(JSLP_UPD_THREADS), 0, s, c);
@@ -751,6 +759,7 @@ extern "C" int jslp_engine_save(jslp_engine* e) {
     if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "save before upload");
     HIPC(hipSetDevice(e->device));
     SnapshotW w{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, e->snap_rhs};
+    e->slot0_synced = 0;  // new snapshot generation
     hipLaunchKernelGGL(k_save, dim3(copy_grid(e, 1).x), dim3(256), 0, e->stream, e->s, w);
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(e->stream));
@@ -760,6 +769,7 @@ extern "C" int jslp_engine_save(jslp_engine* e) {
 
 // restore slots [first_slot, first_slot + n) from the saved root (checkpoint < 0) or from a checkpoint
 static int enqueue_restore(jslp_engine* e, int first_slot, int n, int checkpoint = -1) {
+    if (first_slot == 0) e->slot0_synced = (checkpoint < 0 && e->has_save) ? 1 : 0;
     if (checkpoint < 0) {
         if (!e->has_save) return JSLP_OK;  // backup.ts:54-56
         Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs};
@@ -854,7 +864,7 @@ extern "C" int jslp_engine_restore(jslp_engine* e) {
 // stage the cut lists of n_nodes nodes on the device: packed into one pinned buffer, one async copy, no sync
 // (the pinned buffer is reused only after the call's final stream synchronisation)
 static int upload_cuts(jslp_engine* e, int32_t n_nodes, const int32_t* offs, const int8_t* type, const int32_t* var,
-                       const double* value) {
+                       const double* value, bool to_device = true) {
     const size_t C = (size_t)offs[n_nodes], N1 = (size_t)n_nodes + 1;
     if (C > 0 && (!type || !var || !value)) return fail(JSLP_ERR_ARG, "cuts: null pointer");
     const size_t off_offs = 8 * C, off_var = off_offs + 4 * N1, off_type = off_var + 4 * C, total = off_type + C;
@@ -868,11 +878,19 @@ static int upload_cuts(jslp_engine* e, int32_t n_nodes, const int32_t* offs, con
     if (C) memcpy(e->h_cuts, value, 8 * C);
     memcpy(e->h_cuts + off_offs, offs, 4 * N1);
     if (C) { memcpy(e->h_cuts + off_var, var, 4 * C); memcpy(e->h_cuts + off_type, type, C); }
-    HIPC(hipMemcpyAsync(e->d_cuts, e->h_cuts, total, hipMemcpyHostToDevice, e->stream));
-    e->d_cut_val = reinterpret_cast<double*>(e->d_cuts);
-    e->d_cut_offs = reinterpret_cast<int32_t*>(e->d_cuts + off_offs);
-    e->d_cut_var = reinterpret_cast<int32_t*>(e->d_cuts + off_var);
-    e->d_cut_type = reinterpret_cast<int8_t*>(e->d_cuts + off_type);
+    // to_device == false: the one-launch node kernel reads the (tiny) cut list straight from the pinned buffer
+    char* base = e->d_cuts;
+    if (to_device) {
+        HIPC(hipMemcpyAsync(e->d_cuts, e->h_cuts, total, hipMemcpyHostToDevice, e->stream));
+    } else {
+        void* dev = nullptr;
+        HIPC(hipHostGetDevicePointer(&dev, e->h_cuts, 0));
+        base = static_cast<char*>(dev);
+    }
+    e->d_cut_val = reinterpret_cast<double*>(base);
+    e->d_cut_offs = reinterpret_cast<int32_t*>(base + off_offs);
+    e->d_cut_var = reinterpret_cast<int32_t*>(base + off_var);
+    e->d_cut_type = reinterpret_cast<int8_t*>(base + off_type);
     return JSLP_OK;
 }
 
@@ -1093,12 +1111,46 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     if (n_nodes > 1 && !e->has_save && checkpoint < 0)
         return fail(JSLP_ERR_STATE, "relax_batch: several nodes need a saved root (save() first)");
     HIPC(hipSetDevice(e->device));
-    int rc = upload_cuts(e, n_nodes, cut_offsets, type, var_index, value);
-    if (rc) return rc;
     hipStream_t s = e->stream;
-    Cuts cu{e->d_cut_offs, e->d_cut_type, e->d_cut_var, e->d_cut_val};
     const int cap = iters_cap(e);
     const long long cells = (long long)e->cap_rows * e->ld;
+    int rc;
+    // ---- ONE child of the saved root, slot 0 already in sync with the snapshot: one launch, one synchronisation ----------
+    if (n_nodes == 1 && checkpoint < 0 && e->has_save && e->slot0_synced && !e->timing && e->force_path <= 1 &&
+        e->one_launch_nodes && cells <= wg_cells_child()) {
+        rc = upload_cuts(e, 1, cut_offsets, type, var_index, value, false);
+        if (rc) return rc;
+        rc = ensure_out(e, 1);
+        if (rc) return rc;
+        void* out_dev = nullptr;
+        HIPC(hipHostGetDevicePointer(&out_dev, e->h_out, 0));
+        char* ob = static_cast<char*>(out_dev);
+        DevState* o_state = reinterpret_cast<DevState*>(ob);
+        double* o_rhs = want_rhs ? reinterpret_cast<double*>(ob + ((char*)e->h_rhs - e->h_out)) : nullptr;
+        int32_t* o_rows = want_rows ? reinterpret_cast<int32_t*>(ob + ((char*)e->h_rows - e->h_out)) : nullptr;
+        Cuts cu{e->d_cut_offs, e->d_cut_type, e->d_cut_var, e->d_cut_val};
+        Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs};
+        e->last_path = "workgroup";
+        hipLaunchKernelGGL(k_node_wg, dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, sn, cu, check_cycles, cap, (int)e->cap_rows,
+                           o_rhs, o_rows, o_state);
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(s));
+        const DevState st = e->h_states[0];
+        rc = state_error(st);
+        if (rc) { e->slot0_synced = 0; return rc; }
+        double ev;
+        rc = fill_result(e, st, 0, e->evaluation, &out[0], &ev);
+        if (rc) return rc;
+        e->evaluation = ev;
+        if (!pinned) {
+            if (rhs) memcpy(rhs, e->h_rhs, sizeof(double) * st.H);
+            if (var_index_by_row) memcpy(var_index_by_row, e->h_rows, sizeof(int32_t) * st.H);
+        }
+        return JSLP_OK;
+    }
+    rc = upload_cuts(e, n_nodes, cut_offsets, type, var_index, value);
+    if (rc) return rc;
+    Cuts cu{e->d_cut_offs, e->d_cut_type, e->d_cut_var, e->d_cut_val};
     // branch-and-bound children (a saved root exists) need a handful of repair pivots each: one workgroup, one launch,
     // no host round trip.  A first solve / plain LP goes through the chip-wide path unless the tableau is tiny.
     const bool wg = e->force_path == 1 ||

@@ -29,7 +29,7 @@
 #define JSLP_UPD_COLS (JSLP_UPD_THREADS * 2)
 
 enum { ST_RUNNING = 0, ST_DONE = 1, ST_PHASE1_DONE = 2 };
-enum { ERR_NONE = 0, ERR_HIST_FULL = 1, ERR_ITER_LIMIT = 2, ERR_CUT_ARG = 3, ERR_CAPACITY = 4, ERR_BARRIER = 5 };
+enum { ERR_NONE = 0, ERR_HIST_FULL = 1, ERR_ITER_LIMIT = 2, ERR_CUT_ARG = 3, ERR_CAPACITY = 4, ERR_BARRIER = 5, ERR_NOT_SYNCED = 6 };
 
 // Per-tableau device state (one per slot).  Plain ints so the host can read it back with one copy.
 struct DevState {
@@ -283,8 +283,7 @@ struct Cuts {
     const int32_t* var;
     const double* value;
 };
-__global__ void __launch_bounds__(256) k_add_cuts(Slots s, Cuts cuts, int first_slot, int first_node, int cap_rows) {
-    const int slot = first_slot + blockIdx.x, node = first_node + blockIdx.x;
+__device__ __forceinline__ void add_cuts_slot(const Slots& s, const Cuts& cuts, int slot, int node, int cap_rows) {
     DevState* st = s.st + slot;
     double* A = s.A + (long long)slot * s.A_stride;
     double* rhs = s.rhs + (long long)slot * s.pcol_stride;
@@ -337,11 +336,13 @@ __global__ void __launch_bounds__(256) k_add_cuts(Slots s, Cuts cuts, int first_
         st->H = H + n;
     }
 }
+__global__ void __launch_bounds__(256) k_add_cuts(Slots s, Cuts cuts, int first_slot, int first_node, int cap_rows) {
+    add_cuts_slot(s, cuts, first_slot + blockIdx.x, first_node + blockIdx.x, cap_rows);
+}
 
 // Read-back for the host tree: RHS column + varIndexByRow of each slot, and the slot's state.
-__global__ void __launch_bounds__(256) k_gather(Slots s, int first_slot, double* rhs, int32_t* rows, DevState* states,
-                                                int out_stride, int first_out) {
-    const int slot = first_slot + blockIdx.x, o = first_out + blockIdx.x;
+__device__ __forceinline__ void gather_slot(const Slots& s, int slot, double* rhs, int32_t* rows, DevState* states,
+                                            int out_stride, int o) {
     const DevState* st = s.st + slot;
     const double* A = s.A + (long long)slot * s.A_stride;
     const double* mirror = s.rhs + (long long)slot * s.pcol_stride;
@@ -353,6 +354,72 @@ __global__ void __launch_bounds__(256) k_gather(Slots s, int first_slot, double*
         if (rows) rows[(long long)o * out_stride + r] = vibr[r];
     }
     if (threadIdx.x == 0) states[o] = *st;
+}
+__global__ void __launch_bounds__(256) k_gather(Slots s, int first_slot, double* rhs, int32_t* rows, DevState* states,
+                                                int out_stride, int first_out) {
+    gather_slot(s, first_slot + blockIdx.x, rhs, rows, states, out_stride, first_out + blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ONE branch-and-bound child in ONE launch (slot 0, from the saved root): the restore of the rows the previous node
+// dirtied, the commit, addCutConstraints, the whole simplex() and the read-back, which goes straight into the pinned
+// host buffer (and the cut list is read straight from one) -- a sequential tree walk pays one launch and one stream
+// synchronisation per node instead of five launches and two copies.  Only valid when slot 0 is in sync with the current
+// snapshot generation (the host tracks that and otherwise uses k_restore / k_add_cuts / k_simplex_wg / k_gather once).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(JSLP_WG_THREADS) k_node_wg(Slots s, Snapshot snap, Cuts cuts, int check_cycles, int iters_cap,
+                                                             int cap_rows, double* rhs_out, int32_t* rows_out, DevState* state_out) {
+    __shared__ Smem sm;
+    __shared__ ActSmem<4096> act;
+    DevState* st = s.st;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int gen = st->s_gen, H = st->s_H, ld2 = s.ld / 2;
+    if (gen == 0 || st->gen != gen) {  // must not happen (host bookkeeping): refuse rather than restore wrongly
+        if (tid == 0) { st->err = ERR_NOT_SYNCED; st->status = ST_DONE; *state_out = *st; }
+        return;
+    }
+    // restore(): the dirty rows, found by all threads at once and compacted into the LDS list the update uses later
+    if (tid == 0) act.n = 0;
+    __syncthreads();
+    for (int r = tid; r < H; r += blockDim.x)
+        if (s.dirty[r]) {
+            const int idx = atomicAdd(&act.n, 1);
+            if (idx < 4096) act.row[idx] = r;
+        }
+    __syncthreads();
+    const int n = act.n;
+    const double2* src = reinterpret_cast<const double2*>(snap.A);
+    double2* dst = reinterpret_cast<double2*>(s.A);
+    if (n <= 4096) {
+        for (int i = w; i < n; i += nw) {
+            const int r = act.row[i];
+            for (int k = lane; k < ld2; k += 64) dst[(long long)r * ld2 + k] = src[(long long)r * ld2 + k];
+            if (lane == 0) { s.dirty[r] = 0; s.rhs[r] = snap.rhs[r]; }
+        }
+    } else {
+        for (int r = w; r < H; r += nw) {
+            if (!s.dirty[r]) continue;
+            for (int k = lane; k < ld2; k += 64) dst[(long long)r * ld2 + k] = src[(long long)r * ld2 + k];
+            if (lane == 0) { s.dirty[r] = 0; s.rhs[r] = snap.rhs[r]; }
+        }
+    }
+    for (int i = tid; i < H; i += blockDim.x) s.vibr[i] = snap.vibr[i];
+    for (int i = tid; i < s.W; i += blockDim.x) s.vibc[i] = snap.vibc[i];
+    for (int i = tid; i < snap.n_idx; i += blockDim.x) { s.rbv[i] = snap.rbv[i]; s.cbv[i] = snap.cbv[i]; }
+    if (s.n_opt > 0 && snap.oo)
+        for (long long i = tid; i < s.oo_stride; i += blockDim.x) s.oo[i] = snap.oo[i];
+    if (tid == 0) {
+        st->H = H;
+        st->last_element_index = st->s_last_element_index;
+        st->err = ERR_NONE;
+    }
+    __syncthreads();
+    add_cuts_slot(s, cuts, 0, 0, cap_rows);
+    __syncthreads();
+    const Ctx c = slot_ctx(s, 0, check_cycles);
+    simplex_wg(c, sm, act, iters_cap);
+    __syncthreads();
+    gather_slot(s, 0, rhs_out, rows_out, state_out, 0, 0);
 }
 
 // ---- fp32 twin (jslp_engine_simplex_f32): narrow the live fp64 tableau into an fp32 slot / widen the read-back ----------

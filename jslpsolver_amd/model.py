@@ -129,6 +129,7 @@ class Model:
                     cons_max[name]["terms"].append((pos, coefficient))
 
         self.integer_index_set = frozenset(v["index"] for v in self.integerVariables)
+        self.integer_index_array = np.array([v["index"] for v in self.integerVariables], dtype=np.int64)
 
     _PRIORITIES = {"required": 0, "strong": 1, "medium": 2, "weak": 3}
 

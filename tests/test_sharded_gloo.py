@@ -59,5 +59,5 @@ def test_bench_multi_rank_code_path_on_one_gpu(hip_lib):
     assert line["n_gpus"] == 2 and line["unit"] == "pivots/s" and line["value"] > 0
     assert line["config"]["pivot_digest"] == "1cda2607"  # the reference's digest for n = 500
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - 2 * 657) < 1e-6 * 2 * 657
-    assert line["relaxations"]["nodes"] == 2 * 8 * 151
+    assert line["relaxations"]["nodes"] == 2 * 16 * 151
     assert "cpu_baseline" not in line
