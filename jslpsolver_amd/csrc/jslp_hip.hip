@@ -33,6 +33,8 @@ static int fail(int code, const char* fmt, const char* a = "", const char* b = "
 struct jslp_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // read-back of a finished group of nodes while the next group computes
+    hipEvent_t ev_group = nullptr;
     int32_t H0 = 0, W = 0, ld = 0, cap_rows = 0, n_idx = 0;
     double precision = 1e-8;
     int32_t batch = 50, use_partial = 0;
@@ -271,6 +273,8 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     int rc = JSLP_OK;
     auto init = [&]() -> int {
         HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        HIPC(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        HIPC(hipEventCreateWithFlags(&e->ev_group, hipEventDisableTiming));
         {   // snapshot, unrestricted flags and pivot trace: one allocation
             const size_t cells = (size_t)e->cap_rows * e->ld;
             for (int pass = 0; pass < 2; pass++) {
@@ -320,6 +324,8 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     if (e->ev_begin) hipEventDestroy(e->ev_begin);
     if (e->ev_end) hipEventDestroy(e->ev_end);
+    if (e->ev_group) hipEventDestroy(e->ev_group);
+    if (e->copy_stream) hipStreamDestroy(e->copy_stream);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1198,12 +1204,20 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         hipLaunchKernelGGL(k_gather, dim3(g), dim3(256), 0, s, e->s, 0, want_rhs ? e->d_rhs : nullptr,
                            want_rows ? e->d_rows : nullptr, e->d_states, (int)e->cap_rows, first);
         HIPC(hipGetLastError());
+        // this group's outcomes cross PCIe on the copy stream while the next group computes (the three regions of the
+        // read-back buffer are laid out for all nodes, so a group is one contiguous slice of each)
+        HIPC(hipEventRecord(e->ev_group, s));
+        HIPC(hipStreamWaitEvent(e->copy_stream, e->ev_group, 0));
+        HIPC(hipMemcpyAsync(e->h_states + first, e->d_states + first, sizeof(DevState) * (size_t)g, hipMemcpyDeviceToHost, e->copy_stream));
+        if (want_rhs)
+            HIPC(hipMemcpyAsync(e->h_rhs + (size_t)first * e->cap_rows, e->d_rhs + (size_t)first * e->cap_rows,
+                                sizeof(double) * (size_t)g * e->cap_rows, hipMemcpyDeviceToHost, e->copy_stream));
+        if (want_rows)
+            HIPC(hipMemcpyAsync(e->h_rows + (size_t)first * e->cap_rows, e->d_rows + (size_t)first * e->cap_rows,
+                                sizeof(int32_t) * (size_t)g * e->cap_rows, hipMemcpyDeviceToHost, e->copy_stream));
     }
     if (e->timing && wg) HIPC(hipEventRecord(e->ev_end, s));
-    // states come first in the buffer: copy only as far as the caller needs
-    const size_t need = want_rows ? out_bytes(e, (size_t)n_nodes)
-                                  : (want_rhs ? (size_t)n_nodes * (sizeof(DevState) + (size_t)e->cap_rows * 8) : (size_t)n_nodes * sizeof(DevState));
-    HIPC(hipMemcpyAsync(e->h_out, e->d_out, need, hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(e->copy_stream));
     HIPC(hipStreamSynchronize(s));
     if (wg && e->timing) {
         float ms = 0;
