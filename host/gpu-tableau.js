@@ -247,8 +247,18 @@ function install(Tableau, options) {
     // checkpoints; without the solver such a Solve must be kept on the reference's own path (guardIncremental).
     let hadOwnSelect = false;
     let origSelect = null;
+    let origSolve = null;
     if (opts.solver) {
         const solver = opts.solver;
+        // a simplified-result Solve() is done with its tableau when it returns: hand the engine back right away (its
+        // stream / arenas go to the library's resource pool for the next Solve) instead of waiting for the garbage
+        // collector.  Solve(model, precision, full = true) keeps it for sync() / the post-solve API.
+        origSolve = solver.Solve;
+        solver.Solve = function (model, precision, full) {
+            const result = origSolve.apply(this, arguments);
+            if (!full && this.lastSolvedModel && this.lastSolvedModel.tableau) release(this.lastSolvedModel.tableau);
+            return result;
+        };
         const service = require("./gpu-incremental-service.js");
         hadOwnSelect = Object.prototype.hasOwnProperty.call(solver, "selectBranchAndCutService");
         origSelect = solver.selectBranchAndCutService;
@@ -271,6 +281,7 @@ function install(Tableau, options) {
         if (opts.solver) {
             if (hadOwnSelect) opts.solver.selectBranchAndCutService = origSelect;
             else delete opts.solver.selectBranchAndCutService;
+            opts.solver.Solve = origSolve;
         }
     };
 }

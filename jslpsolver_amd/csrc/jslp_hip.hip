@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 static thread_local char g_err[512];
@@ -46,8 +47,9 @@ struct jslp_engine {
     // small model creates and destroys an engine
     int n_slots = 0;
     Slots s{};
-    char* slot_arena = nullptr;
-    char* static_arena = nullptr;
+    char* slot_arena = nullptr; size_t slot_bytes = 0;
+    char* static_arena = nullptr; size_t static_bytes = 0;
+    char* spare_slot_arena = nullptr; size_t spare_slot_bytes = 0;  // handed over by the resource pool at create()
     // snapshot
     double* snap_A = nullptr; double* snap_rhs = nullptr;
     int32_t *snap_vibr = nullptr, *snap_vibc = nullptr, *snap_rbv = nullptr, *snap_cbv = nullptr;
@@ -63,7 +65,7 @@ struct jslp_engine {
     char* d_out = nullptr; char* h_out = nullptr;
     double* d_rhs = nullptr; int32_t* d_rows = nullptr; DevState* d_states = nullptr;
     double* h_rhs = nullptr; int32_t* h_rows = nullptr; DevState* h_states = nullptr;
-    size_t out_cap = 0;  // nodes
+    size_t out_bytes_cap = 0;
     DevState* h_state = nullptr;  // pinned, 1 entry
     // checkpoints (incremental-branch-and-cut.ts:31-44): equally sized device buffers, recycled through a free list
     struct Ckpt {
@@ -154,8 +156,53 @@ struct Carver {  // hands out 256-byte aligned pieces of one allocation; first p
     }
 };
 
-static void free_slots(jslp_engine* e) {
-    hipFree(e->slot_arena);
+// ---- resource pool ---------------------------------------------------------------------------------------------------
+// A Solve() of a small model creates and destroys an engine; stream / event / pinned-memory creation and the two device
+// arenas cost ~4 ms per engine on this stack -- more than every pivot of the reference's fixtures.  Destroyed engines
+// therefore park those resources here (a handful of entries, arenas up to 1 GiB each) and the next create() on the same
+// device takes them over, re-carving the arenas when they are large enough.
+struct PooledRes {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    DevState* h_state = nullptr;
+    char* static_arena = nullptr; size_t static_bytes = 0;
+    char* slot_arena = nullptr; size_t slot_bytes = 0;
+    char* d_cuts = nullptr; char* h_cuts = nullptr; size_t cuts_bytes = 0;  // staging of the cut lists
+    char* d_out = nullptr; char* h_out = nullptr; size_t out_bytes = 0;     // read-back staging
+};
+static std::mutex g_pool_mu;
+static std::vector<PooledRes> g_pool;
+static const size_t POOL_MAX_ENTRIES = 4;
+static const size_t POOL_MAX_ARENA = (size_t)1 << 30;
+
+static bool pool_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* t = getenv("JSLP_NO_POOL"); v = (t && t[0] == '1') ? 0 : 1; }
+    return v == 1;
+}
+static bool pool_take(int device, PooledRes* out) {
+    if (!pool_enabled()) return false;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++)
+        if (g_pool[i].device == device) {
+            *out = g_pool[i];
+            g_pool.erase(g_pool.begin() + (long)i);
+            return true;
+        }
+    return false;
+}
+static bool pool_give(const PooledRes& r) {
+    if (!pool_enabled() || r.static_bytes > POOL_MAX_ARENA || r.slot_bytes > POOL_MAX_ARENA || r.out_bytes > POOL_MAX_ARENA / 4)
+        return false;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool.size() >= POOL_MAX_ENTRIES) return false;
+    g_pool.push_back(r);
+    return true;
+}
+
+static void free_slots(jslp_engine* e, bool keep_arena = false) {
+    if (!keep_arena) { hipFree(e->slot_arena); e->slot_bytes = 0; }
     hipFree(e->s.oo);
     e->slot_arena = nullptr;
     e->s.dirty = nullptr; e->s.oo = nullptr;
@@ -196,7 +243,14 @@ static int ensure_slots(jslp_engine* e, int n) {
     Carver sizing{nullptr, 0};
     carve_slots(s, sizing, n);
     char* arena = nullptr;
-    HIPC(hipMalloc(&arena, sizing.off + 256));
+    size_t arena_bytes = sizing.off + 256;
+    if (e->spare_slot_arena && e->spare_slot_bytes >= arena_bytes) {  // from the resource pool
+        arena = e->spare_slot_arena;
+        arena_bytes = e->spare_slot_bytes;
+        e->spare_slot_arena = nullptr;
+    } else {
+        HIPC(hipMalloc(&arena, arena_bytes));
+    }
     Carver cv{arena, 0};
     carve_slots(s, cv, n);
     // slot 0's matrix is zero-filled by upload(); other slots are filled by their first (full) restore
@@ -225,7 +279,9 @@ static int ensure_slots(jslp_engine* e, int n) {
     }
     e->s = s;
     e->slot_arena = arena;
+    e->slot_bytes = arena_bytes;
     e->n_slots = n;
+    if (e->spare_slot_arena) { hipFree(e->spare_slot_arena); e->spare_slot_arena = nullptr; }  // too small: not needed any more
     return JSLP_OK;
 }
 
@@ -271,10 +327,17 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     const char* nt = getenv("JSLP_NT");
     e->nt = (nt && nt[0] == '1') ? 1 : 0;
     int rc = JSLP_OK;
+    PooledRes pooled;
+    const bool have = pool_take(device, &pooled);
     auto init = [&]() -> int {
-        HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        HIPC(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-        HIPC(hipEventCreateWithFlags(&e->ev_group, hipEventDisableTiming));
+        if (have) {
+            e->stream = pooled.stream; e->ev_begin = pooled.ev_begin; e->ev_end = pooled.ev_end; e->h_state = pooled.h_state;
+            e->spare_slot_arena = pooled.slot_arena; e->spare_slot_bytes = pooled.slot_bytes;
+            e->d_cuts = pooled.d_cuts; e->h_cuts = pooled.h_cuts; e->cuts_bytes = pooled.cuts_bytes;
+            e->d_out = pooled.d_out; e->h_out = pooled.h_out; e->out_bytes_cap = pooled.out_bytes;
+        } else {
+            HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        }
         {   // snapshot, unrestricted flags and pivot trace: one allocation
             const size_t cells = (size_t)e->cap_rows * e->ld;
             for (int pass = 0; pass < 2; pass++) {
@@ -288,16 +351,27 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
                 e->snap_rbv = cv.take<int32_t>((size_t)e->n_idx);
                 e->snap_cbv = cv.take<int32_t>((size_t)e->n_idx);
                 e->s.trace = cv.take<int2>((size_t)TRACE_CAP);
-                if (!pass) HIPC(hipMalloc(&e->static_arena, cv.off + 256));
+                if (!pass) {
+                    e->static_bytes = cv.off + 256;
+                    if (have && pooled.static_bytes >= e->static_bytes) {
+                        e->static_arena = pooled.static_arena;
+                        e->static_bytes = pooled.static_bytes;
+                    } else {
+                        if (have) hipFree(pooled.static_arena);
+                        HIPC(hipMalloc(&e->static_arena, e->static_bytes));
+                    }
+                }
             }
             e->s.trace_cap = TRACE_CAP;
         }
         HIPC(hipMemsetAsync(e->d_unr, 0, e->n_idx, e->stream));
         int r = ensure_slots(e, 1);
         if (r) return r;
-        HIPC(hipHostMalloc(&e->h_state, sizeof(DevState)));
-        HIPC(hipEventCreate(&e->ev_begin));
-        HIPC(hipEventCreate(&e->ev_end));
+        if (!have) {
+            HIPC(hipHostMalloc(&e->h_state, sizeof(DevState)));
+            HIPC(hipEventCreate(&e->ev_begin));
+            HIPC(hipEventCreate(&e->ev_end));
+        }
         HIPC(hipStreamSynchronize(e->stream));
         return JSLP_OK;
     };
@@ -311,7 +385,23 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
-    free_slots(e);
+    if (e->copy_stream) hipStreamSynchronize(e->copy_stream);
+    if (e->spare_slot_arena) hipFree(e->spare_slot_arena);
+    bool parked = false;
+    if (e->stream && e->ev_begin && e->ev_end && e->h_state && e->static_arena && e->slot_arena) {
+        PooledRes r;
+        r.device = e->device; r.stream = e->stream; r.ev_begin = e->ev_begin; r.ev_end = e->ev_end; r.h_state = e->h_state;
+        r.static_arena = e->static_arena; r.static_bytes = e->static_bytes;
+        r.slot_arena = e->slot_arena; r.slot_bytes = e->slot_bytes;
+        r.d_cuts = e->d_cuts; r.h_cuts = e->h_cuts; r.cuts_bytes = e->cuts_bytes;
+        r.d_out = e->d_out; r.h_out = e->h_out; r.out_bytes = e->out_bytes_cap;
+        parked = pool_give(r);
+    }
+    free_slots(e, parked);
+    if (parked) {
+        e->static_arena = nullptr; e->h_state = nullptr; e->ev_begin = e->ev_end = nullptr; e->stream = nullptr;
+        e->d_cuts = e->h_cuts = nullptr; e->d_out = e->h_out = nullptr;
+    }
     hipFree(e->static_arena); hipFree(e->snap_oo);
     drop_checkpoints(e, 1);
     hipFree(e->arena32);
@@ -930,12 +1020,15 @@ static void out_layout(jslp_engine* e, size_t nodes) {
     e->h_rows = reinterpret_cast<int32_t*>(e->h_out + o_rows);
 }
 static int ensure_out(jslp_engine* e, size_t nodes) {
-    if (nodes > e->out_cap) {
+    if (out_bytes(e, nodes) > e->out_bytes_cap) {
         hipFree(e->d_out);
         if (e->h_out) hipHostFree(e->h_out);
-        e->out_cap = std::max<size_t>(nodes, 16);
-        HIPC(hipMalloc(&e->d_out, out_bytes(e, e->out_cap)));
-        HIPC(hipHostMalloc(&e->h_out, out_bytes(e, e->out_cap)));
+        e->d_out = e->h_out = nullptr;
+        e->out_bytes_cap = 0;
+        const size_t bytes = out_bytes(e, std::max<size_t>(nodes, 16));
+        HIPC(hipMalloc(&e->d_out, bytes));
+        HIPC(hipHostMalloc(&e->h_out, bytes));
+        e->out_bytes_cap = bytes;
     }
     out_layout(e, nodes);
     return JSLP_OK;
@@ -1174,6 +1267,10 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     }
     rc = ensure_out(e, (size_t)n_nodes);  // laid out for ALL nodes: [states | rhs | rows]
     if (rc) return rc;
+    if (!e->copy_stream) {  // created on first use: a stream costs a Solve of a tiny model more than its pivots do
+        HIPC(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        HIPC(hipEventCreateWithFlags(&e->ev_group, hipEventDisableTiming));
+    }
     if (e->timing) HIPC(hipEventRecord(e->ev_begin, s));
     for (int first = 0; first < n_nodes; first += group) {
         const int g = std::min(group, n_nodes - first);

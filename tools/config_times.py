@@ -19,7 +19,7 @@ const root=process.argv[1], mode=process.argv[2], file=process.argv[3];
 const solver=require(path.join(root,'oracle/_ref/src/solver.js')).default;
 if(mode==='gpu'){const T=require(path.join(root,'oracle/_ref/src/tableau/tableau.js')).default;
  const {SlackVariable}=require(path.join(root,'oracle/_ref/src/expressions.js'));
- const gpu=require(path.join(root,'host/gpu-tableau.js'));gpu.loadEngine({});gpu.install(T,{SlackVariable});}
+ const gpu=require(path.join(root,'host/gpu-tableau.js'));gpu.loadEngine({});gpu.install(T,{SlackVariable,solver});}
 const g=JSON.parse(zlib.gunzipSync(fs.readFileSync(file)).toString());
 const run=()=>{const t0=process.hrtime.bigint();const r=solver.Solve(JSON.parse(JSON.stringify(g.model)));return [Number(process.hrtime.bigint()-t0)/1e6,r.result];};
 run();const a=[run(),run(),run()].map(x=>x[0]).sort((x,y)=>x-y);console.log(JSON.stringify({ms:a[1],result:run()[1]}));
