@@ -92,6 +92,7 @@ struct jslp_engine {
     u64_t* r_gran = nullptr;  // [2][G][8] granules then [2][G] row flags (one allocation, zeroed per launch)
     u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr;
     int no_resident = 0;
+    int res_cpt = 2;  // columns per lane of the resident kernel (JSLP_RES_CPT=2|4)
     int one_launch_nodes = 1;  // JSLP_NO_NODE_KERNEL=1: single children go through the five-launch sequence
     const char* last_path = "none";
     // timing
@@ -322,6 +323,9 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     if (fp && !strcmp(fp, "resident")) e->force_path = 3;
     const char* nr = getenv("JSLP_NO_RESIDENT");
     if (nr && nr[0] == '1') e->no_resident = 1;
+    const char* rcpt = getenv("JSLP_RES_CPT");
+    if (rcpt && rcpt[0] == '4') e->res_cpt = 4;
+    if (rcpt && rcpt[0] == '2') e->res_cpt = 2;
     const char* nk = getenv("JSLP_NO_NODE_KERNEL");
     if (nk && nk[0] == '1') e->one_launch_nodes = 0;
     const char* nt = getenv("JSLP_NT");
@@ -707,7 +711,10 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             hipEvent_t k0 = nullptr, k1 = nullptr;
             if (e->timing) { r = ensure_events(e, 2); if (r) return r; k0 = e->ev_pool[0]; k1 = e->ev_pool[1]; HIPC(hipEventRecord(k0, s)); }
             void* args[] = {&rc};
-            hipError_t le = hipLaunchCooperativeKernel((const void*)k_simplex_resident, dim3(rc.G), dim3(JSLP_F_THREADS), args, 0, s);
+            // lane geometry: 1024 lanes x 2 columns, or 512 lanes x 4 columns (half the waves per workgroup barrier)
+            hipError_t le = e->res_cpt == 4
+                ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 4>, dim3(rc.G), dim3(512), args, 0, s)
+                : hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2>, dim3(rc.G), dim3(1024), args, 0, s);
             if (le == hipSuccess) {
                 if (e->timing) HIPC(hipEventRecord(k1, s));
                 const int it_before = 0;  // k_begin zeroed the pivot counters

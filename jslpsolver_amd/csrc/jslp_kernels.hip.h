@@ -949,18 +949,20 @@ __device__ __forceinline__ bool sweep_summary(const ResCtx& f, int par, unsigned
 // holds, reduced with three LDS atomics: first batch holding a candidate, best value in it, first column with
 // that value.  Positive doubles order like their bit patterns.  Returns the column (0 = none) and its value.
 // `sm.p_*` must have been reset (p_batch = INT_MAX, p_val = 0, p_col = INT_MAX) before a preceding barrier.
-__device__ __forceinline__ int price_row_lds(double x0, double x1, int c0, int b0, int b1, const Ctx& c, RSmem& sm,
+template <int CPT>
+__device__ __forceinline__ int price_row_lds(const double (&x)[CPT], int c0, const int (&pb)[CPT], const Ctx& c, RSmem& sm,
                                              double* value) {
-    const int col1 = c0 + 1;
-    const bool ok0 = c0 >= 1 && c0 < c.W && x0 > c.precision;
-    const bool ok1 = col1 < c.W && x1 > c.precision;
     double bv = c.precision;
     int bi = 0, bb = 0;
-    if (ok0) { bv = x0; bi = c0; bb = b0; }
-    const bool take1 = ok1 && (bi == 0 || b1 < bb || (b1 == bb && x1 > bv));
-    bv = take1 ? x1 : bv;
-    bi = take1 ? col1 : bi;
-    bb = take1 ? b1 : bb;
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {  // my columns in order: earlier batch first, bigger value inside a batch, first index on ties
+        const int col = c0 + j;
+        const bool ok = col >= 1 && col < c.W && x[j] > c.precision;
+        const bool take = ok && (bi == 0 || pb[j] < bb || (pb[j] == bb && x[j] > bv));
+        bv = take ? x[j] : bv;
+        bi = take ? col : bi;
+        bb = take ? pb[j] : bb;
+    }
     {   // batch ids grow with the lane index: the wave's earliest batch is that of its first candidate lane
         const unsigned long long m = __ballot(bi != 0);
         if (m != 0ull) {
@@ -1016,9 +1018,10 @@ __device__ __forceinline__ int global_or(const ResCtx& f, int par, unsigned tag,
 }
 
 // Loop-carried state of the resident kernel (kept in registers: every member is a scalar or a fully unrolled array)
+template <int CPT>
 struct ResRegs {
-    double2 a[JSLP_R_ROWS];
-    double2 r0;
+    double a[JSLP_R_ROWS][CPT];  // my rows: CPT adjacent columns per lane
+    double r0[CPT];              // my copy of the cost row
     double k0;
     int pc, end_code, unbounded_col, hist_n, it1, it2;
     unsigned epoch;
@@ -1032,19 +1035,20 @@ struct ResRegs {
 // One phase of the solve.  PHASE is a compile-time constant so that the phase-2 loop -- the hot one -- carries none of
 // the phase-1 branches; returns when the solve ends (R.end_code != 0) or, for PHASE == 1, when phase 1 is over
 // (end_code stays 0 and the caller starts phase 2).
-template <int PHASE>
-__device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRegs& R, int it1_start, int it2_start,
-                                               int pb0, int pb1) {
+template <int PHASE, int CPT>
+__device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRegs<CPT>& R, int it1_start, int it2_start,
+                                               const int (&pb)[CPT]) {
     const Ctx& c = f.c;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int ld = c.ld, W = c.W, H = f.H;
     const double precision = c.precision;
-    const int c0 = tid * 2;
+    const int c0 = tid * CPT;
     const bool colok = c0 < ld;
     const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
+    const int sweep0 = (int)blockDim.x - JSLP_SWEEP_LANES;  // the leader's last four waves sweep
     constexpr int phase = PHASE;
-    double2 (&a)[JSLP_R_ROWS] = R.a;
-    double2& r0 = R.r0;
+    double (&a)[JSLP_R_ROWS][CPT] = R.a;
+    double (&r0)[CPT] = R.r0;
     double& k0 = R.k0;
     int& pc = R.pc;
     int& end_code = R.end_code;
@@ -1058,7 +1062,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
     u64_t (&rt_acc)[8] = R.rt_acc;
     u64_t& rt_prev = R.rt_prev;
 #endif
-    (void)H; (void)pb0; (void)pb1;
+    (void)H;
     while (end_code == 0) {
         if ((it1 - it1_start) + (it2 - it2_start) >= f.iters_cap) { end_code = 4; break; }
         const int par = epoch & 1;
@@ -1066,14 +1070,18 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         RT_MARK(7);
         // ---- A: my rows' summary: phase 2 = ratio test for column pc (simplex.ts:276-296); phase 1 = most negative RHS
         //         below -precision (simplex.ts:39-49) -------------------------------------------------------------------
-        bool has_pc = phase == 2 && colok && ((pc == c0) || (pc == c0 + 1));
-        if (has_pc) {
+        bool has_pc = phase == 2 && colok && pc >= c0 && pc < c0 + CPT;
+        if (has_pc) {  // (conditional stores, not selects among register-array elements: those end up in scratch)
 #pragma unroll
-            for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.col[i] = (pc == c0) ? a[i].x : a[i].y;
+            for (int j = 0; j < CPT; j++)
+                if (pc == c0 + j) {
+#pragma unroll
+                    for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.col[i] = a[i][j];
+                }
         }
         if (tid == 0) {
 #pragma unroll
-            for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.rhs[i] = a[i].x;
+            for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.rhs[i] = a[i][0];
             reset_reductions(sm);
         }
         __syncthreads();
@@ -1128,13 +1136,13 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         // ---- B: publish that row (write-through 8-byte agent stores); its own flag follows the drain ---------------
         const int pubrow = sm.pubrow;
         if (pubrow != 0 && colok) {
-            double2 v = make_double2(0, 0);
+            u64_t* rp = f.rows_pub[par] + (long long)b * ld + c0;
 #pragma unroll
             for (int i = 0; i < JSLP_R_ROWS; i++)
-                if (r_begin + i == pubrow) v = a[i];
-            u64_t* rp = f.rows_pub[par] + (long long)b * ld + c0;
-            AG_STORE(rp, (u64_t)__double_as_longlong(v.x));
-            AG_STORE(rp + 1, (u64_t)__double_as_longlong(v.y));
+                if (r_begin + i == pubrow) {  // uniform
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) AG_STORE(rp + j, (u64_t)__double_as_longlong(a[i][j]));
+                }
         }
         RT_MARK(1);
         // ---- C: workgroup 0 is the LEADER: its last four waves gather everybody's tagged summaries (data = flag)
@@ -1142,8 +1150,8 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         bool swept = true;
         SweptCand sc;
         sc.qbits = ~0ull; sc.kq = 0; sc.kdeg = 0; sc.r = 0; sc.rdeg = 0x7fffffff;
-        const bool sweeper = b == 0 && tid >= JSLP_F_THREADS - JSLP_SWEEP_LANES;
-        if (sweeper) swept = sweep_summary(f, par, tag, tid - (JSLP_F_THREADS - JSLP_SWEEP_LANES), sc);
+        const bool sweeper = b == 0 && tid >= sweep0;
+        if (sweeper) swept = sweep_summary(f, par, tag, tid - sweep0, sc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { end_code = 5; break; }
@@ -1169,7 +1177,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                     rdeg = rd2 < rdeg ? rd2 : rdeg;
                 }
                 if ((tid & 63) == 0) {
-                    const int wv = (tid - (JSLP_F_THREADS - JSLP_SWEEP_LANES)) >> 6;
+                    const int wv = (tid - sweep0) >> 6;
                     sm.w_q[wv] = q; sm.w_r[wv] = r; sm.w_rdeg[wv] = rdeg;
                 }
             }
@@ -1189,7 +1197,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             if (wrdeg != 0x7fffffff) pr = wrdeg;
             else if (wr != 0) pr = wr;
             else stop = phase == 1 ? 4 : 3;  // phase 1: no violated row -> feasible (:51-54); phase 2: unbounded (:298-303)
-            if (!stop && sweeper && tid - (JSLP_F_THREADS - JSLP_SWEEP_LANES) == pr / f.rpb)
+            if (!stop && sweeper && tid - sweep0 == pr / f.rpb)
                 sm.l_k = wrdeg != 0x7fffffff ? sc.kdeg : sc.kq;  // the owner of row pr published both entries
             __syncthreads();
             quot = stop ? 0.0 : sm.l_k;
@@ -1244,13 +1252,15 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         //         (which follows the winner's drain) was not up yet ------------------------------------------------------
         const int bw = pr / f.rpb;
         const u64_t* rp_in = f.rows_pub[par] + (long long)bw * ld + c0;
-        double pvx = 0.0, pvy = 0.0;
+        double pv[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; j++) pv[j] = 0.0;
         for (;;) {
             u64_t flag = 0;
             if (tid == 0) flag = AG_LOAD(f.rowflag[par] + bw);
             if (colok) {
-                pvx = __longlong_as_double((long long)AG_LOAD(rp_in));
-                pvy = __longlong_as_double((long long)AG_LOAD(rp_in + 1));
+#pragma unroll
+                for (int j = 0; j < CPT; j++) pv[j] = __longlong_as_double((long long)AG_LOAD(rp_in + j));
             }
             if (tid == 0) {
                 int ok = 1;
@@ -1280,11 +1290,11 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             // entering column: max -cost/coef over coef < -precision (simplex.ts:56-71; no unrestricted variables here)
             Cand best; best.v = -INFINITY; best.i = 0; best.b = 0;
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < CPT; j++) {
                 const int col = c0 + j;
-                const double coef = j ? pvy : pvx;
+                const double coef = pv[j];
                 if (col >= 1 && col < W && coef < -precision) {
-                    const double quo = -(j ? r0.y : r0.x) / coef;
+                    const double quo = -r0[j] / coef;
                     const bool take = best.v < quo;
                     best.v = take ? quo : best.v;
                     best.i = take ? col : best.i;
@@ -1293,12 +1303,16 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             best = block_reduce(best, MaxFirst(), sm.f.red);
             if (best.i == 0) { end_code = 7; break; }  // infeasible (simplex.ts:73-76), uniform
             pc = best.i;
-            has_pc = colok && ((pc == c0) || (pc == c0 + 1));
+            has_pc = colok && pc >= c0 && pc < c0 + CPT;
             if (has_pc) {
 #pragma unroll
-                for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.col[i] = (pc == c0) ? a[i].x : a[i].y;
-                sm.xq[0] = (pc == c0) ? pvx : pvy;    // quot = A[pr, pc]
-                sm.xq[1] = (pc == c0) ? r0.x : r0.y;  // k0 = A[0, pc]
+                for (int j = 0; j < CPT; j++)
+                    if (pc == c0 + j) {
+#pragma unroll
+                        for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.col[i] = a[i][j];
+                        sm.xq[0] = pv[j];  // quot = A[pr, pc]
+                        sm.xq[1] = r0[j];  // k0 = A[0, pc]
+                    }
             }
             __syncthreads();
             quot = sm.xq[0];
@@ -1339,13 +1353,15 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                 if (stop == 2) { end_code = 6; break; }
             }
         }
-        double2 p = make_double2(0, 0);  // normalised pivot row (simplex.ts:352-364)
-        int tiny = 0;                    // entries simplex.ts:381-383 zeroes as soon as ANY other row is eliminated
+        double p[CPT];  // normalised pivot row (simplex.ts:352-364)
+#pragma unroll
+        for (int j = 0; j < CPT; j++) p[j] = 0.0;
+        int tiny = 0;   // entries simplex.ts:381-383 zeroes as soon as ANY other row is eliminated
         if (colok) {
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < CPT; j++) {
                 const int col = c0 + j;
-                const double val = j ? pvy : pvx;
+                const double val = pv[j];
                 double v = 0.0;
                 if (col < W) {
                     const bool innz = nonzero16(val);
@@ -1353,7 +1369,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                     if (col == pc) v = 1.0 / quot;
                     if (innz && !nonzero16(v) && v != 0.0) tiny |= 1 << j;
                 }
-                if (j) p.y = v; else p.x = v;
+                p[j] = v;
             }
         }
         if (phase == 1 && __syncthreads_or(tiny)) {
@@ -1368,29 +1384,50 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             if (g < 0) { end_code = 5; break; }
             anyrow = g != 0;
         }
-        if (anyrow) {
-            if (tiny & 1) p.x = 0.0;
-            if (tiny & 2) p.y = 0.0;
+        bool nz[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            if (anyrow && (tiny & (1 << j))) p[j] = 0.0;
+            nz[j] = nonzero16(p[j]);
         }
-        const bool v0 = nonzero16(p.x), v1 = nonzero16(p.y);
         RT_MARK(5);
         // ---- F: update registers: cost row (every workgroup the same), then my rows ------------------------------------
         if (nonzero16(k0)) {
-            if (v0) r0.x = eliminate(r0.x, k0, p.x);
-            if (v1) r0.y = eliminate(r0.y, k0, p.y);
-            if (has_pc) { const double nv = -k0 / quot; if (pc == c0) r0.x = nv; else r0.y = nv; }
+#pragma unroll
+            for (int j = 0; j < CPT; j++)
+                if (nz[j]) r0[j] = eliminate(r0[j], k0, p[j]);
+            if (has_pc) {
+                const double nv = -k0 / quot;
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if (pc == c0 + j) r0[j] = nv;
+            }
         }
 #pragma unroll
         for (int i = 0; i < JSLP_R_ROWS; i++) {
             const int r = r_begin + i;
             if (r >= r_end) continue;
-            if (r == 0) { a[i] = r0; continue; }  // workgroup 0 owns the cost row
-            if (r == pr) { a[i] = p; continue; }
+            if (r == 0) {  // workgroup 0 owns the cost row
+#pragma unroll
+                for (int j = 0; j < CPT; j++) a[i][j] = r0[j];
+                continue;
+            }
+            if (r == pr) {
+#pragma unroll
+                for (int j = 0; j < CPT; j++) a[i][j] = p[j];
+                continue;
+            }
             const double ki = sm.f.col[i];  // pivot-column entry of row i (still in LDS from step A)
             if (nonzero16(ki)) {
-                if (v0) a[i].x = eliminate(a[i].x, ki, p.x);
-                if (v1) a[i].y = eliminate(a[i].y, ki, p.y);
-                if (has_pc) { const double nv = -ki / quot; if (pc == c0) a[i].x = nv; else a[i].y = nv; }
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if (nz[j]) a[i][j] = eliminate(a[i][j], ki, p[j]);
+                if (has_pc) {
+                    const double nv = -ki / quot;
+#pragma unroll
+                    for (int j = 0; j < CPT; j++)
+                        if (pc == c0 + j) a[i][j] = nv;
+                }
             }
         }
         // workgroup 0 commits the basis change (simplex.ts:339-349)
@@ -1410,15 +1447,18 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         RT_MARK(6);
         // ---- G: phase 2: price the new cost row -> entering column of the next pivot -----------------------------------
         if (phase == 2) {
-            pc = price_row_lds(r0.x, r0.y, c0, pb0, pb1, c, sm, &k0);
+            pc = price_row_lds<CPT>(r0, c0, pb, c, sm, &k0);
             if (pc == 0) end_code = 1;
         }
     }
 }
 
-__global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
+// THREADS x CPT >= ld: <1024, 2> = lane pairs of columns, 4 waves per SIMD; <512, 4> = half the waves to synchronise,
+// twice the independent work per lane (and 256 VGPRs per lane).
+template <int THREADS, int CPT>
+__global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     __shared__ RSmem sm;
-    ResRegs R;
+    ResRegs<CPT> R;
 #ifdef JSLP_DEBUG_RESIDENT
     for (int i = 0; i < 8; i++) R.rt_acc[i] = 0;
     R.rt_prev = __builtin_amdgcn_s_memtime();
@@ -1427,21 +1467,31 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
     const int tid = threadIdx.x, b = blockIdx.x;
     const int ld = c.ld, W = c.W, H = f.H;
     const double precision = c.precision;
-    const int c0 = tid * 2;
+    const int c0 = tid * CPT;
     const bool colok = c0 < ld;
     const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
     DevState* st = c.st;
+    static_assert(CPT % 2 == 0, "lanes load and store their columns as 16-byte pairs");
 
     // ---- load my rows and the cost row into registers ---------------------------------------------------
-    double2 (&a)[JSLP_R_ROWS] = R.a;
-    double2& r0 = R.r0;
-    r0 = make_double2(0, 0);
-    if (colok) r0 = *reinterpret_cast<const double2*>(c.A + c0);
+    double (&a)[JSLP_R_ROWS][CPT] = R.a;
+    double (&r0)[CPT] = R.r0;
+#pragma unroll
+    for (int j = 0; j < CPT; j += 2) {
+        double2 t = make_double2(0, 0);
+        if (colok) t = *reinterpret_cast<const double2*>(c.A + c0 + j);
+        r0[j] = t.x; r0[j + 1] = t.y;
+    }
 #pragma unroll
     for (int i = 0; i < JSLP_R_ROWS; i++) {
         const int r = r_begin + i;
-        a[i] = make_double2(0, 0);
-        if (i < f.rpb && r < r_end && colok) a[i] = *reinterpret_cast<const double2*>(c.A + (long long)r * ld + c0);
+        const bool mine = i < f.rpb && r < r_end && colok;
+#pragma unroll
+        for (int j = 0; j < CPT; j += 2) {
+            double2 t = make_double2(0, 0);
+            if (mine) t = *reinterpret_cast<const double2*>(c.A + (long long)r * ld + c0 + j);
+            a[i][j] = t.x; a[i][j + 1] = t.y;
+        }
     }
     const int status0 = st->status;
     R.hist_n = st->hist_n;
@@ -1475,22 +1525,23 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
 #endif
     if (tid == 0) reset_reductions(sm);
     __syncthreads();
-    // pricing batch of my two columns (simplex.ts:118-127): fixed for the whole solve
-    const int pb0 = c.use_partial && c0 >= 1 ? (c0 - 1) / c.batch : 0;
-    const int pb1 = c.use_partial ? c0 / c.batch : 0;
+    // pricing batch of my columns (simplex.ts:118-127): fixed for the whole solve
+    int pb[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; j++) pb[j] = c.use_partial && c0 + j >= 1 ? (c0 + j - 1) / c.batch : 0;
     R.k0 = 0.0;  // reduced cost of the entering column = cost-row entry of column pc
     R.pc = 0;
     R.end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted hand-off, 6 history full, 7 infeasible
     R.unbounded_col = 0;
     R.epoch = 0;
     if (phase == 1) {
-        resident_phase<1>(f, sm, R, it1_start, it2_start, pb0, pb1);
+        resident_phase<1, CPT>(f, sm, R, it1_start, it2_start, pb);
         if (R.end_code == 0) phase = 2;
     }
     if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
-        R.pc = price_row_lds(r0.x, r0.y, c0, pb0, pb1, c, sm, &R.k0);
+        R.pc = price_row_lds<CPT>(r0, c0, pb, c, sm, &R.k0);
         if (R.pc == 0) R.end_code = 1;
-        else resident_phase<2>(f, sm, R, it1_start, it2_start, pb0, pb1);
+        else resident_phase<2, CPT>(f, sm, R, it1_start, it2_start, pb);
     }
     const int end_code = R.end_code, unbounded_col = R.unbounded_col, hist_n = R.hist_n, it1 = R.it1, it2 = R.it2;
     const unsigned epoch = R.epoch;
@@ -1510,7 +1561,11 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
 #pragma unroll
         for (int i = 0; i < JSLP_R_ROWS; i++) {
             const int r = r_begin + i;
-            if (i < f.rpb && r < r_end && colok) *reinterpret_cast<double2*>(c.A + (long long)r * ld + c0) = a[i];
+            if (i < f.rpb && r < r_end && colok) {
+#pragma unroll
+                for (int j = 0; j < CPT; j += 2)
+                    *reinterpret_cast<double2*>(c.A + (long long)r * ld + c0 + j) = make_double2(a[i][j], a[i][j + 1]);
+            }
         }
     }
     if (b == 0 && tid == 0) {
@@ -1523,7 +1578,7 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_simplex_resident(ResCtx f) {
         st->status = ST_DONE;
         st->phase = phase;
         if (phase == 2) { st->entered_phase2 = 1; st->feasible = 1; }  // phase 1 found no violated row (simplex.ts:51-54)
-        st->obj_cell = r0.x;  // column 0 of the cost row
+        st->obj_cell = r0[0];  // column 0 of the cost row
         if (end_code == 1) st->optimal = 1;
         if (end_code == 2) { st->bounded = 0; st->unbounded_var = c.vibc[unbounded_col]; }
         if (end_code == 3) { st->cycle_phase = phase; st->feasible = 0; }

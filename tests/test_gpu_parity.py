@@ -16,17 +16,24 @@ from test_oracle_golden import replay, usable
 
 pytestmark = pytest.mark.gpu
 
-PATHS = ["auto", "wg", "sp", "fused", "resident"]
+PATHS = ["auto", "wg", "sp", "fused", "resident", "resident4"]  # resident4: 512 lanes x 4 columns (JSLP_RES_CPT=4)
+
+
+def set_path(mode):
+    os.environ.pop("JSLP_FORCE_PATH", None)
+    os.environ.pop("JSLP_RES_CPT", None)
+    if mode == "resident4":
+        os.environ["JSLP_FORCE_PATH"] = "resident"
+        os.environ["JSLP_RES_CPT"] = "4"
+    elif mode != "auto":
+        os.environ["JSLP_FORCE_PATH"] = mode
 
 
 @pytest.fixture(params=PATHS)
 def path_mode(request):
-    if request.param == "auto":
-        os.environ.pop("JSLP_FORCE_PATH", None)
-    else:
-        os.environ["JSLP_FORCE_PATH"] = request.param
+    set_path(request.param)
     yield request.param
-    os.environ.pop("JSLP_FORCE_PATH", None)
+    set_path("auto")
 
 
 def test_backend_is_hip(hip_lib):
@@ -54,12 +61,12 @@ def test_big_fixture_replay(hip_lib, name):
 @pytest.mark.parametrize("name", ["Monster_Problem", "Monster_II"])
 def test_big_fixture_replay_other_paths(hip_lib, name):
     g = G.load(os.path.join(G.GOLDEN, "fixtures", name + ".json.gz"))
-    for mode in ("wg", "sp", "fused", "resident"):
-        os.environ["JSLP_FORCE_PATH"] = mode
+    for mode in ("wg", "sp", "fused", "resident", "resident4"):
+        set_path(mode)
         try:
             replay(hip_lib, g)
         finally:
-            os.environ.pop("JSLP_FORCE_PATH", None)
+            set_path("auto")
 
 
 @pytest.mark.parametrize("path", [p for p in G.synthetic_paths() if "_1000x" not in p and "_2000x" not in p], ids=G.ident)
