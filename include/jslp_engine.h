@@ -68,6 +68,15 @@ const char* jslp_last_error(void);
 int jslp_device_count(void);
 
 /*
+ * Threading: an engine belongs to one host thread at a time (the reference is single-threaded); different engines may
+ * be driven from different threads.  destroy() parks the engine's stream, events, pinned staging buffers and device
+ * arenas in a small per-process pool that the next create() on the same device takes over (a Solve of a small model
+ * is otherwise dominated by ~4 ms of resource set-up and tear-down); jslp_release_pooled_resources() frees whatever is
+ * parked, e.g. before unloading the library.
+ */
+void jslp_release_pooled_resources(void);
+
+/*
  * new Tableau(precision) + Tableau.initialize(width, height, ...) (tableau.ts:94-99, 292-317).
  * row_capacity >= height bounds how many cut rows add_cuts may append (the reference reallocates in
  * cutting-strategies.ts:24-30; device memory is sized once instead).  device = HIP device ordinal.

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.environ.get("JSLP_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libjslp_hip.so")  # env: debug builds only
 
 JSLP_OK = 0
+JSLP_ERR_ARG, JSLP_ERR_DEVICE, JSLP_ERR_NOMEM, JSLP_ERR_STATE, JSLP_ERR_CAPACITY, JSLP_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 JSLP_CUT_MIN = 0
 JSLP_CUT_MAX = 1
 
@@ -51,6 +52,7 @@ SYMBOLS = {
     "jslp_backend_name": (C.c_char_p, []),
     "jslp_last_error": (C.c_char_p, []),
     "jslp_device_count": (C.c_int, []),
+    "jslp_release_pooled_resources": (None, []),
     "jslp_engine_create": (C.c_int, [_P(C.c_void_p), C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
     "jslp_engine_destroy": (None, [C.c_void_p]),
     "jslp_engine_upload": (C.c_int, [C.c_void_p, _f64p, _i32p, _i32p, _i32p, C.c_int32]),

@@ -202,6 +202,24 @@ static bool pool_give(const PooledRes& r) {
     return true;
 }
 
+extern "C" void jslp_release_pooled_resources(void) {
+    std::vector<PooledRes> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        drop.swap(g_pool);
+    }
+    for (auto& r : drop) {
+        hipSetDevice(r.device);
+        hipFree(r.static_arena); hipFree(r.slot_arena); hipFree(r.d_cuts); hipFree(r.d_out);
+        if (r.h_cuts) hipHostFree(r.h_cuts);
+        if (r.h_out) hipHostFree(r.h_out);
+        if (r.h_state) hipHostFree(r.h_state);
+        if (r.ev_begin) hipEventDestroy(r.ev_begin);
+        if (r.ev_end) hipEventDestroy(r.ev_end);
+        if (r.stream) hipStreamDestroy(r.stream);
+    }
+}
+
 static void free_slots(jslp_engine* e, bool keep_arena = false) {
     if (!keep_arena) { hipFree(e->slot_arena); e->slot_bytes = 0; }
     hipFree(e->s.oo);

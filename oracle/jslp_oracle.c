@@ -80,6 +80,7 @@ static int fail(int code, const char* msg) {
 }
 
 const char* jslp_backend_name(void) { return "oracle-c"; }
+void jslp_release_pooled_resources(void) {} /* nothing is pooled on the CPU */
 const char* jslp_last_error(void) { return g_err; }
 int jslp_device_count(void) { return 0; }
 
