@@ -36,6 +36,7 @@ static struct {
     int (*relax)(jslp_engine*, int32_t, const int8_t*, const int32_t*, const double*, int, jslp_simplex_result*, double*, int32_t*);
     int (*relax_batch)(jslp_engine*, int32_t, const int32_t*, const int8_t*, const int32_t*, const double*, int,
                        jslp_simplex_result*, double*, int32_t*, int32_t);
+    void (*release_pooled)(void);
     int (*set_integer_variables)(jslp_engine*, const int32_t*, int32_t);
     int (*apply_mir_cuts)(jslp_engine*, int32_t*);
     int (*checkpoint_create)(jslp_engine*, int32_t*);
@@ -166,6 +167,7 @@ static napi_value fn_load(napi_env env, napi_callback_info info) {
     SYM(restore, "jslp_engine_restore"); SYM(add_cuts, "jslp_engine_add_cuts"); SYM(relax, "jslp_engine_relax");
     SYM(relax_batch, "jslp_engine_relax_batch"); SYM(dims, "jslp_engine_dims"); SYM(read_rhs, "jslp_engine_read_rhs");
     SYM(download, "jslp_engine_download"); SYM(pivot_trace, "jslp_engine_pivot_trace");
+    SYM(release_pooled, "jslp_release_pooled_resources");
     SYM(set_integer_variables, "jslp_engine_set_integer_variables"); SYM(apply_mir_cuts, "jslp_engine_apply_mir_cuts");
     SYM(checkpoint_create, "jslp_engine_checkpoint_create"); SYM(checkpoint_restore, "jslp_engine_checkpoint_restore");
     SYM(checkpoint_release, "jslp_engine_checkpoint_release"); SYM(relax_from, "jslp_engine_relax_from");
@@ -351,6 +353,14 @@ static napi_value fn_relax(napi_env env, napi_callback_info info) {
     ENGINE_OK(env, L.relax(e, (int32_t)nt, (const int8_t*)t, (const int32_t*)v, (const double*)x, check ? 1 : 0, &r,
                            (double*)rhs, (int32_t*)rows), "jslp_engine_relax");
     return result_object(env, &r);
+}
+
+/* releasePooledResources(): free the engine resources parked by destroyed engines (jslp_release_pooled_resources) */
+static napi_value fn_release_pooled(napi_env env, napi_callback_info info) {
+    (void)info;
+    NEED_LIB(env);
+    L.release_pooled();
+    return NULL;
 }
 
 /* setIntegerVariables(h, Int32Array varIndexes): variable.isInteger for the MIR cuts (cutting-strategies.ts:82-85) */
@@ -546,7 +556,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"simplex", fn_simplex}, {"pivot", fn_pivot}, {"save", fn_save}, {"restore", fn_restore},
         {"addCuts", fn_add_cuts}, {"relax", fn_relax}, {"relaxBatch", fn_relax_batch}, {"dims", fn_dims},
         {"readRhs", fn_read_rhs}, {"download", fn_download}, {"pivotTrace", fn_pivot_trace},
-        {"setIntegerVariables", fn_set_integer_variables}, {"applyMirCuts", fn_apply_mir_cuts},
+        {"releasePooledResources", fn_release_pooled}, {"setIntegerVariables", fn_set_integer_variables}, {"applyMirCuts", fn_apply_mir_cuts},
         {"checkpointCreate", fn_checkpoint_create}, {"checkpointRestore", fn_checkpoint_restore},
         {"checkpointRelease", fn_checkpoint_release}, {"relaxFrom", fn_relax_from},
     };

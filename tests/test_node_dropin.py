@@ -40,7 +40,7 @@ def test_addon_exports_the_abi():
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip() == ("addCuts,applyMirCuts,checkpointCreate,checkpointRelease,checkpointRestore,create,destroy,"
                                   "deviceCount,dims,download,getOptionalObjectives,load,pivot,pivotTrace,readRhs,relax,"
-                                  "relaxBatch,relaxFrom,restore,save,setIntegerVariables,setOptionalObjectives,simplex,upload")
+                                  "relaxBatch,relaxFrom,releasePooledResources,restore,save,setIntegerVariables,setOptionalObjectives,simplex,upload")
 
 
 def test_reference_host_with_oracle_engine(oracle_lib):
