@@ -71,9 +71,19 @@ function activate(t, opts) {
         }
         addon.setOptionalObjectives(h, nOpt, optional);
     }
+    // which variable indexes the branch-and-bound tree reads between relaxations (integer variables only:
+    // isIntegral / getMostFractionalVar / computeFractionalVolume / the services' branching rules)
+    let isInt = null;
+    if (nInts > 0) {
+        isInt = new Uint8Array(t.width + 2 * rowCapacity + 2);
+        for (const v of t.model.integerVariables) isInt[v.index] = 1;
+    }
     t.__gpu = {
         nOpt,
         optional,
+        isInt,
+        stale: false, // true while only the integer variables' rows of the host copy are up to date
+        lastHeight: 0,
         active: true,
         h,
         rowCapacity,
@@ -129,8 +139,46 @@ function absorb(t, st, res) {
             for (let c = 0; c < t.width; c++) rc[c] = st.optional[o * t.width + c];
         }
     }
-    // read-back: RHS column + row map (and the inverse map the host tree indexes with)
+    // read-back: RHS column + row map (and the inverse map the host tree indexes with).  While a tree is being walked
+    // only the integer variables' rows are read on the host, so only those cells of the (large, strided) host matrix
+    // are written per relaxation; flush() completes the picture before anything reads the other rows.
     const H = res.height;
+    st.lastHeight = H;
+    const width = t.width;
+    const rhsColumn = t.rhsColumn;
+    const matrix = t.matrix;
+    const rowByVarIndex = t.rowByVarIndex;
+    const varIndexByRow = t.varIndexByRow;
+    const isInt = st.isInt;
+    if (isInt === null) {
+        for (let v = 0; v < rowByVarIndex.length; v++) rowByVarIndex[v] = -1;
+        for (let r = 0; r < H; r++) {
+            matrix[r * width + rhsColumn] = st.rhs[r];
+            const v = st.rows[r];
+            varIndexByRow[r] = v;
+            if (v >= 0) rowByVarIndex[v] = r;
+        }
+        st.stale = false;
+        return;
+    }
+    const ints = t.model.integerVariables;
+    for (let i = 0; i < ints.length; i++) rowByVarIndex[ints[i].index] = -1;
+    for (let r = 0; r < H; r++) {
+        const v = st.rows[r];
+        varIndexByRow[r] = v;
+        if (v >= 0 && isInt[v] === 1) {
+            rowByVarIndex[v] = r;
+            matrix[r * width + rhsColumn] = st.rhs[r];
+        }
+    }
+    st.stale = true;
+}
+
+// complete the host copy (every row's RHS, the whole rowByVarIndex) from the last read-back
+function flush(t) {
+    const st = t.__gpu;
+    if (!st || !st.active || !st.stale) return;
+    const H = st.lastHeight;
     const width = t.width;
     const rhsColumn = t.rhsColumn;
     const matrix = t.matrix;
@@ -139,9 +187,9 @@ function absorb(t, st, res) {
     for (let r = 0; r < H; r++) {
         matrix[r * width + rhsColumn] = st.rhs[r];
         const v = st.rows[r];
-        t.varIndexByRow[r] = v;
         if (v >= 0) rowByVarIndex[v] = r;
     }
+    st.stale = false;
 }
 
 function install(Tableau, options) {
@@ -149,7 +197,17 @@ function install(Tableau, options) {
     if (!addon) loadEngine(opts);
     const P = Tableau.prototype;
     const orig = { simplex: P.simplex, save: P.save, restore: P.restore, addCutConstraints: P.addCutConstraints,
-        applyMIRCuts: P.applyMIRCuts };
+        applyMIRCuts: P.applyMIRCuts, updateVariableValues: P.updateVariableValues, getSolution: P.getSolution };
+
+    // the two readers of EVERY row's value (tableau.ts:256-257; keep_solutions inside the services): complete the host copy first
+    P.updateVariableValues = function () {
+        flush(this);
+        return orig.updateVariableValues.call(this);
+    };
+    P.getSolution = function () {
+        flush(this);
+        return orig.getSolution.call(this);
+    };
 
     // slack bookkeeping of one appended row (cutting-strategies.ts:64-71 / :104-109); the row itself is built on the device
     function newSlackRow(t, row) {
@@ -278,6 +336,8 @@ function install(Tableau, options) {
         P.restore = orig.restore;
         P.addCutConstraints = orig.addCutConstraints;
         P.applyMIRCuts = orig.applyMIRCuts;
+        P.updateVariableValues = orig.updateVariableValues;
+        P.getSolution = orig.getSolution;
         if (opts.solver) {
             if (hadOwnSelect) opts.solver.selectBranchAndCutService = origSelect;
             else delete opts.solver.selectBranchAndCutService;
@@ -368,6 +428,7 @@ function sync(t) {
         t.rowByVarIndex[v] = rbv[v];
         t.colByVarIndex[v] = cbv[v];
     }
+    st.stale = false;
     return t;
 }
 
