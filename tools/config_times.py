@@ -21,8 +21,8 @@ if(mode==='gpu'){const T=require(path.join(root,'oracle/_ref/src/tableau/tableau
  const {SlackVariable}=require(path.join(root,'oracle/_ref/src/expressions.js'));
  const gpu=require(path.join(root,'host/gpu-tableau.js'));gpu.loadEngine({});gpu.install(T,{SlackVariable,solver});}
 const g=JSON.parse(zlib.gunzipSync(fs.readFileSync(file)).toString());
-const run=()=>{const t0=process.hrtime.bigint();const r=solver.Solve(JSON.parse(JSON.stringify(g.model)));return [Number(process.hrtime.bigint()-t0)/1e6,r.result];};
-run();const a=[run(),run(),run()].map(x=>x[0]).sort((x,y)=>x-y);console.log(JSON.stringify({ms:a[1],result:run()[1]}));
+const run=()=>{const m=JSON.parse(JSON.stringify(g.model));const t0=process.hrtime.bigint();const r=solver.Solve(m);return [Number(process.hrtime.bigint()-t0)/1e6,r.result];};
+run();run();run();const a=[run(),run(),run(),run(),run()].map(x=>x[0]).sort((x,y)=>x-y);console.log(JSON.stringify({ms:a[2],result:run()[1]}));
 """
 
 
@@ -47,11 +47,11 @@ def main(out_path=None):
         for spec in (1, 16):
             Solve(model, lib=lib, speculate=spec)
             ts = []
-            for _ in range(3):
+            for _ in range(5):
                 t0 = time.perf_counter()
                 r = Solve(model, lib=lib, speculate=spec)
                 ts.append(1e3 * (time.perf_counter() - t0))
-            times[spec] = (sorted(ts)[1], r["result"])
+            times[spec] = (sorted(ts)[2], r["result"])
         ref = node("cpu", path)
         shim = node("gpu", path)
         rows.append((label, g["tableau"]["height"], g["tableau"]["width"], g["nPivots"], len(g["simplexCalls"]), times[1], times[16], shim, ref))

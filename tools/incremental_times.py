@@ -27,7 +27,7 @@ const run=()=>{const m=JSON.parse(JSON.stringify(g.model));m.options=Object.assi
  const it=r._tableau.branchAndCutIterations;const res=solver.buildSimplifiedResult(r).result;
  if(mode==='gpu'){require(path.join(root,'host/gpu-tableau.js')).release(r._tableau);}
  return [ms,res,it];};
-run();const a=[run(),run(),run()].sort((x,y)=>x[0]-y[0]);console.log(JSON.stringify({ms:a[1][0],result:a[1][1],iterations:a[1][2]}));
+run();run();run();const a=[run(),run(),run(),run(),run()].sort((x,y)=>x[0]-y[0]);console.log(JSON.stringify({ms:a[2][0],result:a[2][1],iterations:a[2][2]}));
 """
 
 POLICIES = [
@@ -61,14 +61,14 @@ def main(out_path=None):
             model["options"].pop("timeout", None)
             Solve(model, lib=lib)
             ts = []
-            for _ in range(3):
+            for _ in range(5):
                 t0 = time.perf_counter()
                 out = Solve(model, lib=lib, full=True)
                 ts.append(1e3 * (time.perf_counter() - t0))
             shim = node("gpu", path, options)
             ref = node("cpu", path, options)
             lines.append("| %s | %s | %d | %d | %d | %.1f | %s | %s | %s / %s / %s |" % (
-                name, label, out["iter"], len(out["pivots"]), out["checkpoints"], sorted(ts)[1],
+                name, label, out["iter"], len(out["pivots"]), out["checkpoints"], sorted(ts)[2],
                 "%.1f" % shim["ms"] if shim["ms"] else "n/a", "%.1f" % ref["ms"] if ref["ms"] else "n/a",
                 out["result"]["result"], shim["result"], ref["result"]))
             if shim["iterations"] is not None and (shim["iterations"] != out["iter"] or ref["iterations"] != out["iter"]):

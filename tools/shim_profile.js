@@ -1,0 +1,32 @@
+// Where does a Solve() through the reference host + N-API binding spend its time?  (wall clock inside the addon vs
+// inside Model.solve vs the whole Solve; V8 CPU profile of the rest when run with --cpu-prof)
+//   node tools/shim_profile.js <fixture name> [engine library]
+"use strict";
+const fs = require("fs"), path = require("path"), zlib = require("zlib");
+const root = path.join(__dirname, "..");
+const solver = require(path.join(root, "oracle/_ref/src/solver.js")).default;
+const T = require(path.join(root, "oracle/_ref/src/tableau/tableau.js")).default;
+const { SlackVariable } = require(path.join(root, "oracle/_ref/src/expressions.js"));
+const M = require(path.join(root, "oracle/_ref/src/model.js")).default;
+const gpu = require(path.join(root, "host/gpu-tableau.js"));
+gpu.loadEngine(process.argv[3] ? { library: path.resolve(process.argv[3]) } : {});
+const addon = require(path.join(root, "addon/jslp_napi.node"));
+let inAddon = 0, calls = 0;
+for (const k of Object.keys(addon)) {
+    const f = addon[k];
+    if (typeof f !== "function") continue;
+    addon[k] = function () { const t0 = process.hrtime.bigint(); try { return f.apply(this, arguments); } finally { inAddon += Number(process.hrtime.bigint() - t0) / 1e6; calls += 1; } };
+}
+gpu.install(T, { SlackVariable, solver });
+const g = JSON.parse(zlib.gunzipSync(fs.readFileSync(path.join(root, "tests/golden/fixtures", process.argv[2] + ".json.gz"))).toString());
+const origSolve = M.prototype.solve;
+let tSolve = 0;
+M.prototype.solve = function () { const t0 = process.hrtime.bigint(); try { return origSolve.apply(this, arguments); } finally { tSolve += Number(process.hrtime.bigint() - t0) / 1e6; } };
+for (let i = 0; i < 8; i++) {
+    inAddon = 0; tSolve = 0; calls = 0;
+    const m = JSON.parse(JSON.stringify(g.model));
+    const t0 = process.hrtime.bigint();
+    solver.Solve(m);
+    const ms = Number(process.hrtime.bigint() - t0) / 1e6;
+    console.log("total", ms.toFixed(1), "ms; Model.solve", tSolve.toFixed(1), "; inside the addon", inAddon.toFixed(1), "over", calls, "calls");
+}
