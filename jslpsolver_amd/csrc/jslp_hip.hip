@@ -41,6 +41,7 @@ struct jslp_engine {
     int32_t batch = 50, use_partial = 0;
     int uploaded = 0, has_save = 0;
     int slot0_synced = 0;  // slot 0 = current snapshot except for its dirty rows (st.gen == st.s_gen): k_node_wg may be used
+    int slots_synced = 0;  // slots 1 .. slots_synced-1 are in that state too (only slot 0 ever leaves it on its own)
     double evaluation = 0;
     // slots (slot 0 = the live tableau).  All per-slot arrays live in ONE device allocation (slot_arena), the
     // snapshot / flags / trace in another (static_arena): hipMalloc / hipFree cost ~0.1 ms apiece, and a Solve of a
@@ -300,6 +301,7 @@ static int ensure_slots(jslp_engine* e, int n) {
     e->slot_arena = arena;
     e->slot_bytes = arena_bytes;
     e->n_slots = n;
+    e->slots_synced = std::min(e->slots_synced, 1);  // only slot 0 was carried over
     if (e->spare_slot_arena) { hipFree(e->spare_slot_arena); e->spare_slot_arena = nullptr; }  // too small: not needed any more
     return JSLP_OK;
 }
@@ -491,6 +493,7 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
     e->uploaded = 1;
     e->has_save = 0;
     e->slot0_synced = 0;
+    e->slots_synced = 0;
     drop_checkpoints(e, 0);
     e->evaluation = 0;
     e->n_unr = n_unrestricted;
@@ -881,6 +884,7 @@ extern "C" int jslp_engine_save(jslp_engine* e) {
     HIPC(hipSetDevice(e->device));
     SnapshotW w{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, e->snap_rhs};
     e->slot0_synced = 0;  // new snapshot generation
+    e->slots_synced = 0;
     hipLaunchKernelGGL(k_save, dim3(copy_grid(e, 1).x), dim3(256), 0, e->stream, e->s, w);
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(e->stream));
@@ -890,7 +894,15 @@ extern "C" int jslp_engine_save(jslp_engine* e) {
 
 // restore slots [first_slot, first_slot + n) from the saved root (checkpoint < 0) or from a checkpoint
 static int enqueue_restore(jslp_engine* e, int first_slot, int n, int checkpoint = -1) {
-    if (first_slot == 0) e->slot0_synced = (checkpoint < 0 && e->has_save) ? 1 : 0;
+    if (first_slot == 0) {
+        if (checkpoint < 0 && e->has_save) {
+            e->slot0_synced = 1;
+            e->slots_synced = std::max(e->slots_synced, n);
+        } else {
+            e->slot0_synced = 0;
+            if (checkpoint >= 0) e->slots_synced = 0;  // these slots now hold a checkpoint, not the snapshot
+        }
+    }
     if (checkpoint < 0) {
         if (!e->has_save) return JSLP_OK;  // backup.ts:54-56
         Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs};
@@ -1255,8 +1267,8 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         Cuts cu{e->d_cut_offs, e->d_cut_type, e->d_cut_var, e->d_cut_val};
         Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs};
         e->last_path = "workgroup";
-        hipLaunchKernelGGL(k_node_wg, dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, sn, cu, check_cycles, cap, (int)e->cap_rows,
-                           o_rhs, o_rows, o_state);
+        hipLaunchKernelGGL((k_node_wg<JSLP_WG_THREADS, 4096>), dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, sn, cu, 0, check_cycles,
+                           cap, (int)e->cap_rows, o_rhs, o_rows, o_state, 0, 0);
         HIPC(hipGetLastError());
         HIPC(hipStreamSynchronize(s));
         const DevState st = e->h_states[0];
@@ -1299,6 +1311,18 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     if (e->timing) HIPC(hipEventRecord(e->ev_begin, s));
     for (int first = 0; first < n_nodes; first += group) {
         const int g = std::min(group, n_nodes - first);
+        // slots already in sync with the snapshot: restore of the dirty rows, cuts, simplex and gather in ONE launch per
+        // group (what a workgroup restores and cuts stays in its XCD's L2 for its own pivots)
+        const bool one_launch = wg && g > 1 && checkpoint < 0 && e->has_save && e->slot0_synced && g <= e->slots_synced &&
+                                !e->timing && e->one_launch_nodes && wg_batch_threads() == 512;
+        if (one_launch) {
+            Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs};
+            e->last_path = "workgroup";
+            hipLaunchKernelGGL((k_node_wg<512, 2048>), dim3(g), dim3(512), 0, s, e->s, sn, cu, first, check_cycles, cap,
+                               (int)e->cap_rows, want_rhs ? e->d_rhs : nullptr, want_rows ? e->d_rows : nullptr, e->d_states,
+                               (int)e->cap_rows, first);
+            HIPC(hipGetLastError());
+        } else {
         rc = enqueue_restore(e, 0, g, checkpoint);
         if (rc) return rc;
         hipLaunchKernelGGL(k_add_cuts, dim3(g), dim3(256), 0, s, e->s, cu, 0, first, (int)e->cap_rows);
@@ -1326,6 +1350,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         hipLaunchKernelGGL(k_gather, dim3(g), dim3(256), 0, s, e->s, 0, want_rhs ? e->d_rhs : nullptr,
                            want_rows ? e->d_rows : nullptr, e->d_states, (int)e->cap_rows, first);
         HIPC(hipGetLastError());
+        }  // !one_launch
         // this group's outcomes cross PCIe on the copy stream while the next group computes (the three regions of the
         // read-back buffer are laid out for all nodes, so a group is one contiguous slice of each)
         HIPC(hipEventRecord(e->ev_group, s));
@@ -1348,7 +1373,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     for (int i = 0; i < n_nodes; i++) {
         DevState st = e->h_states[i];
         rc = state_error(st);
-        if (rc) return rc;
+        if (rc) { e->slot0_synced = 0; e->slots_synced = 0; return rc; }
         if (st.cycle_phase && wg && n_nodes > group) {
             // the cycle message is rebuilt from the slot's history, which later groups have reused: report the hit
             // (flags are exact) without the [start, length] detail

@@ -367,59 +367,73 @@ __global__ void __launch_bounds__(256) k_gather(Slots s, int first_slot, double*
 // synchronisation per node instead of five launches and two copies.  Only valid when slot 0 is in sync with the current
 // snapshot generation (the host tracks that and otherwise uses k_restore / k_add_cuts / k_simplex_wg / k_gather once).
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(JSLP_WG_THREADS) k_node_wg(Slots s, Snapshot snap, Cuts cuts, int check_cycles, int iters_cap,
-                                                             int cap_rows, double* rhs_out, int32_t* rows_out, DevState* state_out) {
+// Workgroup blockIdx.x evaluates node (first_node + blockIdx.x) on slot blockIdx.x and writes outcome (first_out +
+// blockIdx.x).  <1024, 4096> for one node (outputs may point into pinned host memory), <512, 2048> for batches.
+template <int THREADS, int CAP>
+__global__ void __launch_bounds__(THREADS) k_node_wg(Slots s, Snapshot snap, Cuts cuts, int first_node, int check_cycles,
+                                                     int iters_cap, int cap_rows, double* rhs_out, int32_t* rows_out,
+                                                     DevState* state_out, int out_stride, int first_out) {
     __shared__ Smem sm;
-    __shared__ ActSmem<4096> act;
-    DevState* st = s.st;
+    __shared__ ActSmem<CAP> act;
+    const int slot = blockIdx.x, node = first_node + blockIdx.x, o = first_out + blockIdx.x;
+    DevState* st = s.st + slot;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
-    const int gen = st->s_gen, H = st->s_H, ld2 = s.ld / 2;
+    const int gen = s.st[0].s_gen, H = s.st[0].s_H, ld2 = s.ld / 2;  // every slot shares slot 0's snapshot scalars
     if (gen == 0 || st->gen != gen) {  // must not happen (host bookkeeping): refuse rather than restore wrongly
-        if (tid == 0) { st->err = ERR_NOT_SYNCED; st->status = ST_DONE; *state_out = *st; }
+        if (tid == 0) { st->err = ERR_NOT_SYNCED; st->status = ST_DONE; state_out[o] = *st; }
         return;
     }
+    double* A = s.A + (long long)slot * s.A_stride;
+    uint8_t* dirty = s.dirty + (long long)slot * s.pcol_stride;
+    double* rhs = s.rhs + (long long)slot * s.pcol_stride;
     // restore(): the dirty rows, found by all threads at once and compacted into the LDS list the update uses later
     if (tid == 0) act.n = 0;
     __syncthreads();
     for (int r = tid; r < H; r += blockDim.x)
-        if (s.dirty[r]) {
+        if (dirty[r]) {
             const int idx = atomicAdd(&act.n, 1);
-            if (idx < 4096) act.row[idx] = r;
+            if (idx < CAP) act.row[idx] = r;
         }
     __syncthreads();
     const int n = act.n;
     const double2* src = reinterpret_cast<const double2*>(snap.A);
-    double2* dst = reinterpret_cast<double2*>(s.A);
-    if (n <= 4096) {
+    double2* dst = reinterpret_cast<double2*>(A);
+    if (n <= CAP) {
         for (int i = w; i < n; i += nw) {
             const int r = act.row[i];
             for (int k = lane; k < ld2; k += 64) dst[(long long)r * ld2 + k] = src[(long long)r * ld2 + k];
-            if (lane == 0) { s.dirty[r] = 0; s.rhs[r] = snap.rhs[r]; }
+            if (lane == 0) { dirty[r] = 0; rhs[r] = snap.rhs[r]; }
         }
     } else {
         for (int r = w; r < H; r += nw) {
-            if (!s.dirty[r]) continue;
+            if (!dirty[r]) continue;
             for (int k = lane; k < ld2; k += 64) dst[(long long)r * ld2 + k] = src[(long long)r * ld2 + k];
-            if (lane == 0) { s.dirty[r] = 0; s.rhs[r] = snap.rhs[r]; }
+            if (lane == 0) { dirty[r] = 0; rhs[r] = snap.rhs[r]; }
         }
     }
-    for (int i = tid; i < H; i += blockDim.x) s.vibr[i] = snap.vibr[i];
-    for (int i = tid; i < s.W; i += blockDim.x) s.vibc[i] = snap.vibc[i];
-    for (int i = tid; i < snap.n_idx; i += blockDim.x) { s.rbv[i] = snap.rbv[i]; s.cbv[i] = snap.cbv[i]; }
-    if (s.n_opt > 0 && snap.oo)
-        for (long long i = tid; i < s.oo_stride; i += blockDim.x) s.oo[i] = snap.oo[i];
+    int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
+    int32_t* vibc = s.vibc + (long long)slot * s.vibc_stride;
+    int32_t* rbv = s.rbv + (long long)slot * s.idx_stride;
+    int32_t* cbv = s.cbv + (long long)slot * s.idx_stride;
+    for (int i = tid; i < H; i += blockDim.x) vibr[i] = snap.vibr[i];
+    for (int i = tid; i < s.W; i += blockDim.x) vibc[i] = snap.vibc[i];
+    for (int i = tid; i < snap.n_idx; i += blockDim.x) { rbv[i] = snap.rbv[i]; cbv[i] = snap.cbv[i]; }
+    if (s.n_opt > 0 && snap.oo) {
+        double* oo = s.oo + (long long)slot * s.oo_stride;
+        for (long long i = tid; i < s.oo_stride; i += blockDim.x) oo[i] = snap.oo[i];
+    }
     if (tid == 0) {
         st->H = H;
-        st->last_element_index = st->s_last_element_index;
+        st->last_element_index = s.st[0].s_last_element_index;
         st->err = ERR_NONE;
     }
     __syncthreads();
-    add_cuts_slot(s, cuts, 0, 0, cap_rows);
+    add_cuts_slot(s, cuts, slot, node, cap_rows);
     __syncthreads();
-    const Ctx c = slot_ctx(s, 0, check_cycles);
+    const Ctx c = slot_ctx(s, slot, check_cycles);
     simplex_wg(c, sm, act, iters_cap);
     __syncthreads();
-    gather_slot(s, 0, rhs_out, rows_out, state_out, 0, 0);
+    gather_slot(s, slot, rhs_out, rows_out, state_out, out_stride, o);
 }
 
 // ---- fp32 twin (jslp_engine_simplex_f32): narrow the live fp64 tableau into an fp32 slot / widen the read-back ----------
