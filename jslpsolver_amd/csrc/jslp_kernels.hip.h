@@ -369,8 +369,9 @@ __global__ void __launch_bounds__(256) k_gather(Slots s, int first_slot, double*
 // ---------------------------------------------------------------------------------------------------
 // Workgroup blockIdx.x evaluates node (first_node + blockIdx.x) on slot blockIdx.x and writes outcome (first_out +
 // blockIdx.x).  <1024, 4096> for one node (outputs may point into pinned host memory), <512, 2048> for batches.
+// (second launch bound = waves per SIMD to fit: 512-thread workgroups are meant to run FOUR per CU, i.e. <= 64 VGPRs)
 template <int THREADS, int CAP>
-__global__ void __launch_bounds__(THREADS) k_node_wg(Slots s, Snapshot snap, Cuts cuts, int first_node, int check_cycles,
+__global__ void __launch_bounds__(THREADS, THREADS == 512 ? 8 : 4) k_node_wg(Slots s, Snapshot snap, Cuts cuts, int first_node, int check_cycles,
                                                      int iters_cap, int cap_rows, double* rhs_out, int32_t* rows_out,
                                                      DevState* state_out, int out_stride, int first_out) {
     __shared__ Smem sm;
