@@ -132,6 +132,9 @@ def main():
     res = None
     for _ in range(args.warmup):
         res = step()
+    import gc
+    gc.collect()
+    gc.disable()  # keep CPython's cyclic collector out of the timed region (re-enabled right after it)
     barrier()
     t0 = time.perf_counter()
     pivots = 0
@@ -140,6 +143,7 @@ def main():
         pivots += res.pivots_phase1 + max(res.pivots_phase2, 0)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    gc.enable()
     total_pivots = sum_over_ranks(float(pivots))
     value = total_pivots / elapsed
     digest = pivot_digest(t.pivot_trace()[-(res.pivots_phase1 + max(res.pivots_phase2, 0)):])
@@ -242,14 +246,26 @@ def relaxation_throughput(lib, device, rank, world, barrier, max_over_ranks, sum
     # the cut lists are flattened once (host-side input preparation, like the tableau build); the timed call is the
     # engine entry point itself: restore + add cuts + simplex + RHS / row-map read-back for every node
     packed = t.pack_cut_lists(mine)
-    t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)  # warm-up (allocates the slots)
-    calls = 5
+    per_call = []
+    # warm-up: the first call allocates the slots and restores them in full; and the GPU has been idle while the host
+    # built the model: ~10-15 ms into a new burst of work one call stalls for ~6 ms (clock ramp), so warm up past that
+    for _ in range(25):
+        t0 = time.perf_counter()
+        t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+        per_call.append(time.perf_counter() - t0)
+    calls = 10
+    import gc
+    gc.collect()
+    gc.disable()  # a generation-2 pass of CPython's collector (~6 ms over the model's dicts) otherwise lands in a random call
     barrier()
     t0 = time.perf_counter()
     for _ in range(calls):
+        t1 = time.perf_counter()
         results, rhs, rows = t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+        per_call.append(time.perf_counter() - t1)
     barrier()
     el = max_over_ranks(time.perf_counter() - t0) / calls
+    gc.enable()
     total = sum_over_ranks(float(len(mine)))
     my_pivots = [results[i].pivots_phase1 + max(results[i].pivots_phase2, 0) for i in range(len(mine))]
     piv = sum_over_ranks(float(sum(my_pivots)))
@@ -259,7 +275,7 @@ def relaxation_throughput(lib, device, rank, world, barrier, max_over_ranks, sum
     alg_bytes = sum_over_ranks(float(my_bytes))
     t.close()
     return {"value": total / el, "unit": "LP relaxations/s", "nodes": int(total), "pivots": int(piv), "seconds": el,
-            "calls_averaged": calls,
+            "calls_averaged": calls, "per_call_us": [round(1e6 * x) for x in per_call[-calls:]],
             "roofline": {"bound": "latency (per-node kernel); hbm for reference", "achieved": alg_bytes / el / 1e9 / world,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s per GPU", "frac": alg_bytes / el / world / HBM_PEAK,
                          "note": "algorithmic bytes per relaxation = 16*H*W (restore) + pivots * 16*H'*W as SURVEY.md 8d defines "
