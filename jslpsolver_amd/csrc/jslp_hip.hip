@@ -448,6 +448,7 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
                                   const int32_t* var_index_by_col, const int32_t* unrestricted_var_indexes,
                                   int32_t n_unrestricted) {
     if (!e || !matrix || !var_index_by_row || !var_index_by_col) return fail(JSLP_ERR_ARG, "upload: null pointer");
+    if (n_unrestricted < 0 || (n_unrestricted > 0 && !unrestricted_var_indexes)) return fail(JSLP_ERR_ARG, "upload: bad unrestricted list");
     HIPC(hipSetDevice(e->device));
     const int32_t H = e->H0, W = e->W;
     std::vector<int32_t> rbv(e->n_idx, -1), cbv(e->n_idx, -1), vibr(e->cap_rows, -1), vibc(W, -1);
@@ -998,6 +999,9 @@ extern "C" int jslp_engine_restore(jslp_engine* e) {
 // (the pinned buffer is reused only after the call's final stream synchronisation)
 static int upload_cuts(jslp_engine* e, int32_t n_nodes, const int32_t* offs, const int8_t* type, const int32_t* var,
                        const double* value, bool to_device = true) {
+    if (offs[0] != 0) return fail(JSLP_ERR_ARG, "cuts: cut_offsets[0] must be 0");
+    for (int32_t i = 0; i < n_nodes; i++)
+        if (offs[i + 1] < offs[i]) return fail(JSLP_ERR_ARG, "cuts: cut_offsets must not decrease");
     const size_t C = (size_t)offs[n_nodes], N1 = (size_t)n_nodes + 1;
     if (C > 0 && (!type || !var || !value)) return fail(JSLP_ERR_ARG, "cuts: null pointer");
     const size_t off_offs = 8 * C, off_var = off_offs + 4 * N1, off_type = off_var + 4 * C, total = off_type + C;
