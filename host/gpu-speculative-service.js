@@ -1,0 +1,171 @@
+// host/gpu-speculative-service.js -- the DEFAULT branch-and-bound policy with speculative, batched evaluation.
+//
+// Same contract and the same tree policy as the reference's createBranchAndCutService (src/tableau/branch-and-cut.ts:32-199:
+// best-first on the relaxed evaluation with LIFO ties, src/tableau/min-heap.ts:43-49; most-fractional branching,
+// src/tableau/mip-utils.ts:100-126; tolerance / timeout / optional-objective tie-break / keep_solutions), injected
+// through the same seam (src/main.ts:62-83) when install() is given `speculate > 1`.  What changes is WHEN nodes are
+// evaluated: every node is a pure function of the saved root and its cut list (applyCuts always restores the root,
+// :33-37), so whenever the loop needs a node that has not been evaluated yet, that node and the next `speculate - 1`
+// entries the heap would hand out are evaluated as ONE batch of independent relaxations on the MI355X
+// (jslp_engine_relax_batch: one workgroup per node).  The loop itself still pops, prunes and commits in the reference's
+// order (speculation with in-order commit), so the incumbent, the iteration count and the result are those of the
+// sequential run (host/test/dropin.js checks that against the goldens).
+"use strict";
+
+function Heap() {
+    this.items = [];
+    this.stamp = 0;
+}
+Heap.prototype.before = function (a, b) {
+    return a.key !== b.key ? a.key < b.key : a.stamp > b.stamp;
+};
+Heap.prototype.push = function (key, cuts) {
+    const it = { key, stamp: this.stamp++, cuts };
+    const h = this.items;
+    let i = h.length;
+    h.push(it);
+    while (i > 0) {
+        const p = (i - 1) >> 1;
+        if (!this.before(it, h[p])) break;
+        h[i] = h[p];
+        i = p;
+    }
+    h[i] = it;
+};
+Heap.prototype.pop = function () {
+    const h = this.items;
+    const top = h[0];
+    const last = h.pop();
+    const n = h.length;
+    if (n > 0) {
+        let i = 0;
+        for (;;) {
+            let c = 2 * i + 1;
+            if (c >= n) break;
+            if (c + 1 < n && this.before(h[c + 1], h[c])) c += 1;
+            if (!this.before(h[c], last)) break;
+            h[i] = h[c];
+            i = c;
+        }
+        h[i] = last;
+    }
+    return top;
+};
+
+function createGpuSpeculativeService(gpu, options) {
+    const width = Math.max(1, (options && options.speculate) || 16);
+
+    function applyCuts(t, cuts) { // :33-37 (MIR models never get this service)
+        t.restore();
+        t.addCutConstraints(cuts);
+        t.simplex();
+    }
+
+    function branchAndCut(t) {
+        const model = t.model;
+        const heap = new Heap();
+        const cache = new Map(); // heap stamp -> outcome of that node
+        let iterations = 0;
+        const tolerance = model && model.tolerance ? model.tolerance : 0;
+        let withinTolerance = true;
+        const deadline = model && model.timeout ? Date.now() + model.timeout : 1e99;
+        let bestEvaluation = Infinity;
+        let bestCuts = null;
+        let lastCuts = null;
+        let saved = false;
+        const nOpt = t.optionalObjectives.length;
+        const bestOptional = new Array(nOpt).fill(Infinity);
+        // the tie-break below reads the live optional-objective cells: evaluate such models in order
+        const speculate = nOpt > 0 ? 1 : width;
+
+        heap.push(-Infinity, []);
+        while (heap.items.length > 0 && withinTolerance && Date.now() < deadline) {
+            const acceptable = model && model.isMinimization
+                ? t.bestPossibleEval * (1 + tolerance)
+                : t.bestPossibleEval * (1 - tolerance);
+            if (tolerance > 0 && bestEvaluation < acceptable) withinTolerance = false;
+
+            const node = heap.pop();
+            if (node.key > bestEvaluation) continue;
+            const cuts = node.cuts;
+            if (speculate > 1 && saved) {
+                if (!cache.has(node.stamp)) {
+                    // this node + what the heap would hand out next (best first, LIFO ties) that is not pruned already
+                    const ahead = heap.items.slice().sort((a, b) => (a.key !== b.key ? a.key - b.key : b.stamp - a.stamp));
+                    const batch = [node];
+                    for (let i = 0; i < ahead.length && batch.length < speculate; i++)
+                        if (!cache.has(ahead[i].stamp) && ahead[i].key <= bestEvaluation) batch.push(ahead[i]);
+                    const outcomes = gpu.relaxBatch(t, batch.map((b) => b.cuts));
+                    for (let i = 0; i < batch.length; i++) cache.set(batch[i].stamp, outcomes[i]);
+                }
+                const outcome = cache.get(node.stamp);
+                cache.delete(node.stamp);
+                gpu.commitOutcome(t, cuts, outcome); // restore() + addCutConstraints(cuts) bookkeeping + the cached simplex()
+            } else {
+                applyCuts(t, cuts);
+            }
+            lastCuts = cuts;
+            iterations += 1;
+            if (t.feasible === false) continue;
+            const evaluation = t.evaluation;
+            if (evaluation > bestEvaluation) continue;
+            if (evaluation === bestEvaluation) {
+                let worse = true; // :107-127
+                for (let k = 0; k < nOpt; k++) {
+                    const cell = t.optionalObjectives[k].reducedCosts[0];
+                    if (cell > bestOptional[k]) break;
+                    if (cell < bestOptional[k]) {
+                        worse = false;
+                        break;
+                    }
+                }
+                if (worse) continue;
+            }
+            if (t.isIntegral() === true) {
+                t.__isIntegral = true;
+                if (iterations === 1) {
+                    t.branchAndCutIterations = iterations;
+                    return;
+                }
+                bestCuts = cuts;
+                bestEvaluation = evaluation;
+                for (let k = 0; k < nOpt; k++) bestOptional[k] = t.optionalObjectives[k].reducedCosts[0];
+                if (model && model.keep_solutions) {
+                    const now = model.tableau.getSolution();
+                    const store = now.generateSolutionSet();
+                    store.result = now.evaluation;
+                    if (!model.solutions) model.solutions = [];
+                    model.solutions.push(store);
+                }
+            } else {
+                if (iterations === 1) {
+                    t.save();
+                    saved = true;
+                }
+                const variable = t.getMostFractionalVar();
+                const varIndex = variable.index;
+                const high = [];
+                const low = [];
+                for (let k = 0; k < cuts.length; k++) {
+                    const cut = cuts[k];
+                    if (cut.varIndex !== varIndex) {
+                        high.push(cut);
+                        low.push(cut);
+                    } else if (cut.type === "min") low.push(cut);
+                    else high.push(cut);
+                }
+                high.push({ type: "min", varIndex, value: Math.ceil(variable.value) });
+                low.push({ type: "max", varIndex, value: Math.floor(variable.value) });
+                heap.push(evaluation, high);
+                heap.push(evaluation, low);
+            }
+        }
+        if (bestCuts !== null) applyCuts(t, bestCuts); // :194-196
+        else if (speculate > 1 && saved && lastCuts !== null) applyCuts(t, lastCuts); // no incumbent: end where the sequential run ends
+        t.branchAndCutIterations = iterations;
+    }
+
+    return { applyCuts, branchAndCut, __gpuSpeculative: true };
+}
+
+module.exports = { createGpuSpeculativeService };

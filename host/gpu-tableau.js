@@ -325,6 +325,11 @@ function install(Tableau, options) {
             if (o && o.useIncremental === true) {
                 return service.createGpuIncrementalService(api, { nodeSelection: o.nodeSelection, branching: o.branching });
             }
+            // install(..., { speculate: n > 1 }): the default policy with n-node speculative batches (in-order commit);
+            // models that ask for another policy or for MIR cuts keep the reference's own services
+            if (opts.speculate > 1 && !(o && (o.nodeSelection || o.branching || o.useMIRCuts))) {
+                return require("./gpu-speculative-service.js").createGpuSpeculativeService(api, { speculate: opts.speculate });
+            }
             return origSelect.call(this, model);
         };
     }
@@ -401,6 +406,59 @@ function relaxFromCheckpoint(t, cp, cuts) {
     return t;
 }
 
+// ---- batches of independent nodes (host/gpu-speculative-service.js) ----------------------------------------------------
+// every node = restore() + addCutConstraints(cuts) + simplex() from the saved root, all nodes in ONE engine call
+function relaxBatch(t, cutLists) {
+    const st = t.__gpu;
+    if (!st || !st.active) throw new Error("[gpu-tableau] relaxBatch: tableau is not on the engine");
+    const n = cutLists.length;
+    const offsets = new Int32Array(n + 1);
+    let total = 0;
+    for (let i = 0; i < n; i++) {
+        total += cutLists[i].length;
+        offsets[i + 1] = total;
+    }
+    const type = new Int8Array(total);
+    const varIndex = new Int32Array(total);
+    const value = new Float64Array(total);
+    for (let i = 0, k = 0; i < n; i++) {
+        const cuts = cutLists[i];
+        for (let j = 0; j < cuts.length; j++, k++) {
+            type[k] = cuts[j].type === "min" ? 0 : 1;
+            varIndex[k] = cuts[j].varIndex;
+            value[k] = cuts[j].value;
+        }
+    }
+    const stride = st.rowCapacity;
+    if (!st.batchRhs || st.batchRhs.length < n * stride) {
+        st.batchRhs = new Float64Array(n * stride);
+        st.batchRows = new Int32Array(n * stride);
+    }
+    const check = t.model ? t.model.checkForCycles === true : false;
+    const results = addon.relaxBatch(st.h, offsets, type, varIndex, value, check, st.batchRhs, st.batchRows, stride);
+    const out = new Array(n);
+    for (let i = 0; i < n; i++) {
+        const H = results[i].height;
+        // copies: outcomes are cached across batches, the staging arrays are not
+        out[i] = { res: results[i], rhs: st.batchRhs.slice(i * stride, i * stride + H), rows: st.batchRows.slice(i * stride, i * stride + H) };
+    }
+    return out;
+}
+
+// make `t` the tableau of a node evaluated earlier by relaxBatch: the host bookkeeping of restore() + addCutConstraints(cuts)
+// and then the cached outcome in place of simplex()
+function commitOutcome(t, cuts, outcome) {
+    const st = t.__gpu;
+    t.restore();
+    t.addCutConstraints(cuts);
+    st.pendingRestore = false;
+    st.pendingCuts = null;
+    st.rhs.set(outcome.rhs);
+    st.rows.set(outcome.rows);
+    absorb(t, st, outcome.res);
+    return t;
+}
+
 function releaseCheckpoint(t, cp) {
     const st = t.__gpu;
     if (st && st.active && cp && cp.id >= 0) {
@@ -447,6 +505,7 @@ function release(t) {
 
 const api = {
     loadEngine, install, sync, pivotTrace, release, guardIncremental, createCheckpoint, relaxFromCheckpoint, releaseCheckpoint,
+    relaxBatch, commitOutcome,
     backend: () => backend,
 };
 module.exports = api;

@@ -32,7 +32,7 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
         strategyBase[f + JSON.stringify(v)] = JSON.stringify(solver.Solve(m));
     }
 }
-gpu.install(Tableau, { SlackVariable, solver });
+let uninstall = gpu.install(Tableau, { SlackVariable, solver });
 
 function num(x) {
     if (typeof x !== "number") return x;
@@ -140,6 +140,32 @@ if (!filter && dir.indexOf("fixtures") >= 0 && fs.existsSync(mirFile)) {
         else mirOk += 1;
     }
 }
+// install(..., { speculate: 16 }): the default policy with 16-node speculative batches (host/gpu-speculative-service.js)
+// must return the sequential run's result object and relaxation count on every integer fixture
+let speculativeOk = 0;
+if (!filter && dir.indexOf("fixtures") >= 0) {
+    uninstall();
+    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16 });
+    for (const f of fs.readdirSync(dir).filter((x) => x.endsWith(".json.gz")).sort()) {
+        const g = loadGolden(dir, f);
+        if (!g.model || !g.tableau || g.tableau.integerVarIndexes.length === 0) continue;
+        const o = g.model.options || {};
+        if (o.nodeSelection || o.branching || o.useMIRCuts || o.useIncremental) continue;
+        const m = JSON.parse(JSON.stringify(g.model));
+        if (m.options) delete m.options.timeout; // wall-clock limits are not replayable
+        const solution = solver.Solve(m, undefined, true);
+        const res = solver.buildSimplifiedResult(solution);
+        const got = {};
+        for (const k of Object.keys(res)) got[k] = num(res[k]);
+        const bad = [];
+        if (!(solution._tableau.branchAndCutService && solution._tableau.branchAndCutService.__gpuSpeculative)) bad.push("service not injected");
+        if (JSON.stringify(Object.keys(res)) !== JSON.stringify(g.resultKeys)) bad.push("keys");
+        if (JSON.stringify(got) !== JSON.stringify(g.result)) bad.push("values");
+        if (solution._tableau.branchAndCutIterations !== g.final.branchAndCutIterations) bad.push("B&B iterations " + solution._tableau.branchAndCutIterations + " != " + g.final.branchAndCutIterations);
+        gpu.release(solution._tableau);
+        if (bad.length) { fail += 1; console.log("FAIL speculative", f, bad.join("; ")); } else speculativeOk += 1;
+    }
+}
 console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk,
-    incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk }));
+    incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);

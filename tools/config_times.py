@@ -17,9 +17,9 @@ NODE_SCRIPT = r"""
 const fs=require('fs'),path=require('path'),zlib=require('zlib');
 const root=process.argv[1], mode=process.argv[2], file=process.argv[3];
 const solver=require(path.join(root,'oracle/_ref/src/solver.js')).default;
-if(mode==='gpu'){const T=require(path.join(root,'oracle/_ref/src/tableau/tableau.js')).default;
+if(mode!=='cpu'){const T=require(path.join(root,'oracle/_ref/src/tableau/tableau.js')).default;
  const {SlackVariable}=require(path.join(root,'oracle/_ref/src/expressions.js'));
- const gpu=require(path.join(root,'host/gpu-tableau.js'));gpu.loadEngine({});gpu.install(T,{SlackVariable,solver});}
+ const gpu=require(path.join(root,'host/gpu-tableau.js'));gpu.loadEngine({});gpu.install(T,{SlackVariable,solver,speculate:mode==='gpu16'?16:1});}
 const g=JSON.parse(zlib.gunzipSync(fs.readFileSync(file)).toString());
 const run=()=>{const m=JSON.parse(JSON.stringify(g.model));const t0=process.hrtime.bigint();const r=solver.Solve(m);return [Number(process.hrtime.bigint()-t0)/1e6,r.result];};
 run();run();run();const a=[run(),run(),run(),run(),run()].map(x=>x[0]).sort((x,y)=>x-y);console.log(JSON.stringify({ms:a[2],result:run()[1]}));
@@ -54,13 +54,14 @@ def main(out_path=None):
             times[spec] = (sorted(ts)[2], r["result"])
         ref = node("cpu", path)
         shim = node("gpu", path)
-        rows.append((label, g["tableau"]["height"], g["tableau"]["width"], g["nPivots"], len(g["simplexCalls"]), times[1], times[16], shim, ref))
-    lines = ["| config | tableau | pivots | LP relaxations | Python host + HIP (ms) | same, 16-node speculative batches (ms) | reference host + N-API + HIP (ms) | reference TS on CPU, node 12 (ms) | result |",
-             "|---|---|---|---|---|---|---|---|---|"]
-    for label, h, w, p, n, t1, t16, shim, ref in rows:
-        lines.append("| %s | %dx%d | %d | %d | %.1f | %.1f | %s | %s | %s / %s / %s |" % (
-            label, h, w, p, n, t1[0], t16[0], "%.1f" % shim["ms"] if shim["ms"] else "n/a", "%.1f" % ref["ms"] if ref["ms"] else "n/a",
-            t1[1], shim["result"], ref["result"]))
+        shim16 = node("gpu16", path)
+        rows.append((label, g["tableau"]["height"], g["tableau"]["width"], g["nPivots"], len(g["simplexCalls"]), times[1], times[16], shim, shim16, ref))
+    lines = ["| config | tableau | pivots | LP relaxations | Python host + HIP (ms) | same, 16-node speculative batches (ms) | reference host + N-API + HIP (ms) | same, install(..., {speculate: 16}) (ms) | reference TS on CPU, node 12 (ms) | result |",
+             "|---|---|---|---|---|---|---|---|---|---|"]
+    fmt = lambda x: "%.1f" % x["ms"] if x["ms"] else "n/a"
+    for label, h, w, p, n, t1, t16, shim, shim16, ref in rows:
+        lines.append("| %s | %dx%d | %d | %d | %.1f | %.1f | %s | %s | %s | %s / %s / %s / %s |" % (
+            label, h, w, p, n, t1[0], t16[0], fmt(shim), fmt(shim16), fmt(ref), t1[1], shim["result"], shim16["result"], ref["result"]))
     text = "\n".join(lines) + "\n"
     print(text)
     if out_path:
