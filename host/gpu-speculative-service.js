@@ -75,8 +75,10 @@ function createGpuSpeculativeService(gpu, options) {
         let saved = false;
         const nOpt = t.optionalObjectives.length;
         const bestOptional = new Array(nOpt).fill(Infinity);
-        // the tie-break below reads the live optional-objective cells: evaluate such models in order
-        const speculate = nOpt > 0 ? 1 : width;
+        // the tie-break below reads the live optional-objective cells: evaluate such models in order; and a batch runs one
+        // workgroup per node, which only pays while a node's tableau is small next to the chip (a single child of a
+        // 20 MB tableau is faster through the chip-wide kernels, one node at a time)
+        const speculate = nOpt > 0 || t.width * t.height > 1536 * 1024 ? 1 : width;
 
         heap.push(-Infinity, []);
         while (heap.items.length > 0 && withinTolerance && Date.now() < deadline) {

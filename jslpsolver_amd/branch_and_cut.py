@@ -195,6 +195,8 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
     best_optional = [math.inf] * n_opt  # bestOptionalObjectivesEvaluations (:66-69)
     if n_opt > 0 or model.useMIRCuts:
         speculate = 1  # the tie-break below reads the live optional-objective cells / the MIR loop is driven per node
+    if evaluate_batch is None and tableau.width * tableau.height0 > 1536 * 1024:
+        speculate = 1  # one workgroup per node only pays for small tableaus; big ones go node by node through the chip-wide kernels
     cache = {}          # heap sequence number -> _NodeEval
     saved = False
     last_cuts = None    # cuts of the node the sequential run evaluated last
