@@ -130,6 +130,7 @@ function createGpuIncrementalService(gpu, options) {
     }
 
     function branchAndCut(t) {
+        if (o.fallback && !gpu.isOnEngine(t)) return o.fallback.branchAndCut(t); // kept off the engine by the host's size policy
         const model = t.model;
         const heap = new Heap();
         const stack = [];

@@ -61,7 +61,10 @@ function createGpuSpeculativeService(gpu, options) {
         t.simplex();
     }
 
+    const fallback = options && options.fallback;
+
     function branchAndCut(t) {
+        if (fallback && !gpu.isOnEngine(t)) return fallback.branchAndCut(t); // kept off the engine by the host's size policy
         const model = t.model;
         const heap = new Heap();
         const cache = new Map(); // heap stamp -> outcome of that node

@@ -37,12 +37,15 @@ function loadEngine(options) {
     return backend;
 }
 
-function eligible() {
-    return bypass === 0;
+// opts.minCells (default 0 = everything runs on the engine): tableaus with fewer cells stay on the reference's own
+// TypeScript path -- a host policy for models so small that one launch + synchronisation per simplex() (~0.1 ms) costs
+// more than the reference's whole pivot loop (LargeFarmMIP: 36 x 101, 0.02 ms per relaxation on the CPU)
+function eligible(t, opts) {
+    return bypass === 0 && !(opts.minCells > 0 && t.width * t.height < opts.minCells);
 }
 
 function activate(t, opts) {
-    if (!eligible()) {
+    if (!eligible(t, opts)) {
         t.__gpu = { active: false };
         return t.__gpu;
     }
@@ -96,8 +99,13 @@ function activate(t, opts) {
     return t.__gpu;
 }
 
+let installedOpts = {};
 function state(t, opts) {
-    return t.__gpu || activate(t, opts);
+    return t.__gpu || activate(t, opts || installedOpts);
+}
+// does this tableau live on the engine?  (decides it on first use: size policy, bypass)
+function isOnEngine(t) {
+    return state(t, installedOpts).active === true;
 }
 
 function packCuts(cuts) {
@@ -194,6 +202,7 @@ function flush(t) {
 
 function install(Tableau, options) {
     const opts = options || {};
+    installedOpts = opts;
     if (!addon) loadEngine(opts);
     const P = Tableau.prototype;
     const orig = { simplex: P.simplex, save: P.save, restore: P.restore, addCutConstraints: P.addCutConstraints,
@@ -322,13 +331,16 @@ function install(Tableau, options) {
         origSelect = solver.selectBranchAndCutService;
         solver.selectBranchAndCutService = function (model) {
             const o = model && model.options;
+            // (each injected service falls back to the reference's own choice for tableaus the size policy keeps off the engine)
             if (o && o.useIncremental === true) {
-                return service.createGpuIncrementalService(api, { nodeSelection: o.nodeSelection, branching: o.branching });
+                return service.createGpuIncrementalService(api, { nodeSelection: o.nodeSelection, branching: o.branching,
+                    fallback: origSelect.call(this, model) });
             }
             // install(..., { speculate: n > 1 }): the default policy with n-node speculative batches (in-order commit);
             // models that ask for another policy or for MIR cuts keep the reference's own services
             if (opts.speculate > 1 && !(o && (o.nodeSelection || o.branching || o.useMIRCuts))) {
-                return require("./gpu-speculative-service.js").createGpuSpeculativeService(api, { speculate: opts.speculate });
+                return require("./gpu-speculative-service.js").createGpuSpeculativeService(api, { speculate: opts.speculate,
+                    fallback: origSelect.call(this, model) });
             }
             return origSelect.call(this, model);
         };
@@ -505,7 +517,7 @@ function release(t) {
 
 const api = {
     loadEngine, install, sync, pivotTrace, release, guardIncremental, createCheckpoint, relaxFromCheckpoint, releaseCheckpoint,
-    relaxBatch, commitOutcome,
+    relaxBatch, commitOutcome, isOnEngine,
     backend: () => backend,
 };
 module.exports = api;

@@ -166,6 +166,28 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
         if (bad.length) { fail += 1; console.log("FAIL speculative", f, bad.join("; ")); } else speculativeOk += 1;
     }
 }
+// install(..., { minCells }): a host policy that leaves small tableaus on the reference's own path -- also under the injected services
+let policyOk = 0;
+if (!filter && dir.indexOf("fixtures") >= 0) {
+    uninstall();
+    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16, minCells: 100000 });
+    for (const [f, expectOnEngine] of [["Knapsack_1", false], ["LargeFarmMIP", false], ["Monster_II", true], ["Monster_Problem", true]]) {
+        for (const extra of [{}, { useIncremental: true }]) {
+            const g = loadGolden(dir, f + ".json.gz");
+            const m = JSON.parse(JSON.stringify(g.model));
+            m.options = Object.assign({}, m.options || {}, extra);
+            delete m.options.timeout;
+            const solution = solver.Solve(m, undefined, true);
+            const onEngine = gpu.pivotTrace(solution._tableau) !== null;
+            gpu.release(solution._tableau);
+            const sameResult = extra.useIncremental ? solution.feasible === g.final.feasible
+                : JSON.stringify(solver.buildSimplifiedResult(solution).result) === JSON.stringify(g.result.result);
+            if (onEngine === expectOnEngine && sameResult) policyOk += 1;
+            else { fail += 1; console.log("FAIL size policy", f, JSON.stringify(extra), "on engine:", onEngine); }
+        }
+    }
+}
 console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk,
-    incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk }));
+    incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk,
+    size_policy_ok: policyOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);

@@ -52,6 +52,7 @@ def test_reference_host_with_oracle_engine(oracle_lib):
     assert r["incremental_ok"] >= 100 and r["device_checkpoints"] > 300
     assert r["mir_ok"] >= 60  # options.useMIRCuts under the default, enhanced and incremental services
     assert r["speculative_ok"] >= 12  # install(..., {speculate: 16}): same results and relaxation counts as the sequential run
+    assert r["size_policy_ok"] == 8  # install(..., {minCells}): small tableaus stay on the reference's own path
     r = _run(oracle_lib.path, "synthetic", "40x")
     assert r["fail"] == 0 and r["pass"] >= 12
 
