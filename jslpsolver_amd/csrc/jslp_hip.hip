@@ -569,7 +569,7 @@ static bool fused_eligible(const jslp_engine* e) {
 }
 
 static bool resident_eligible(const jslp_engine* e, int H) {
-    return !e->no_resident && fused_eligible(e) && H <= JSLP_R_ROWS * JSLP_F_MAXG;
+    return !e->no_resident && fused_eligible(e) && H <= JSLP_R_MAXROWS * JSLP_F_MAXG;  // tall geometry above 8 rows per workgroup
 }
 
 static int ensure_resident(jslp_engine* e) {
@@ -734,9 +734,15 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             if (e->timing) { r = ensure_events(e, 2); if (r) return r; k0 = e->ev_pool[0]; k1 = e->ev_pool[1]; HIPC(hipEventRecord(k0, s)); }
             void* args[] = {&rc};
             // lane geometry: 1024 lanes x 2 columns, or 512 lanes x 4 columns (half the waves per workgroup barrier)
-            hipError_t le = e->res_cpt == 4
-                ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 4>, dim3(rc.G), dim3(512), args, 0, s)
-                : hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2>, dim3(rc.G), dim3(1024), args, 0, s);
+            // up to 8 rows per workgroup: 1024 lanes x 2 columns (or 512 x 4, measured slower); 9..16 rows (2048 < H <= 4096):
+            // 512 lanes x 4 columns x 16 rows -- 2 waves per SIMD leave 256 VGPRs per lane for the 64 MB of tableau
+            hipError_t le;
+            if (rc.rpb > JSLP_R_ROWS)
+                le = hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 4, 16>, dim3(rc.G), dim3(512), args, 0, s);
+            else if (e->res_cpt == 4)
+                le = hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 4, 8>, dim3(rc.G), dim3(512), args, 0, s);
+            else
+                le = hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2, 8>, dim3(rc.G), dim3(1024), args, 0, s);
             if (le == hipSuccess) {
                 if (e->timing) HIPC(hipEventRecord(k1, s));
                 const int it_before = 0;  // k_begin zeroed the pivot counters

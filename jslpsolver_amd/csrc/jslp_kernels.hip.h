@@ -877,7 +877,8 @@ __global__ void __launch_bounds__(256) k_fused_finish(FusedCtx f, int last_launc
 // Preconditions (host): those of the fused pipeline, plus H <= 8 * G (register residency) and a successful
 // hipLaunchCooperativeKernel (all workgroups co-resident).
 // ===================================================================================================
-#define JSLP_R_ROWS 8
+#define JSLP_R_ROWS 8       // rows per workgroup of the default geometry (H <= 8 * 256)
+#define JSLP_R_MAXROWS 16   // ... of the tall geometry (512 lanes x 4 columns x 16 rows: H <= 16 * 256)
 #define JSLP_R_GRAN 8        // 8-byte granules per workgroup summary (7 used)
 typedef unsigned long long u64_t;
 
@@ -917,8 +918,10 @@ struct RSmem {
     int32_t pubrow;
     unsigned dec[4];
     double xq[2];   // phase 1: quot and k0 broadcast by the lane pair owning column pc
-    double quo[JSLP_R_ROWS];
-    int32_t kind[JSLP_R_ROWS];
+    double quo[JSLP_R_MAXROWS];
+    int32_t kind[JSLP_R_MAXROWS];
+    double col[JSLP_R_MAXROWS];  // my rows' entries in the pivot column / in column 0
+    double rhs[JSLP_R_MAXROWS];
 };
 
 // The leader's last FOUR waves gather every workgroup's summary of this epoch (all-gather with the data as the flag,
@@ -1033,9 +1036,9 @@ __device__ __forceinline__ int global_or(const ResCtx& f, int par, unsigned tag,
 }
 
 // Loop-carried state of the resident kernel (kept in registers: every member is a scalar or a fully unrolled array)
-template <int CPT>
+template <int CPT, int ROWS>
 struct ResRegs {
-    double a[JSLP_R_ROWS][CPT];  // my rows: CPT adjacent columns per lane
+    double a[ROWS][CPT];  // my rows: CPT adjacent columns per lane
     double r0[CPT];              // my copy of the cost row
     double k0;
     int pc, end_code, unbounded_col, hist_n, it1, it2;
@@ -1050,8 +1053,8 @@ struct ResRegs {
 // One phase of the solve.  PHASE is a compile-time constant so that the phase-2 loop -- the hot one -- carries none of
 // the phase-1 branches; returns when the solve ends (R.end_code != 0) or, for PHASE == 1, when phase 1 is over
 // (end_code stays 0 and the caller starts phase 2).
-template <int PHASE, int CPT>
-__device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRegs<CPT>& R, int it1_start, int it2_start,
+template <int PHASE, int CPT, int ROWS>
+__device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start,
                                                const int (&pb)[CPT]) {
     const Ctx& c = f.c;
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -1062,7 +1065,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
     const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
     const int sweep0 = (int)blockDim.x - JSLP_SWEEP_LANES;  // the leader's last four waves sweep
     constexpr int phase = PHASE;
-    double (&a)[JSLP_R_ROWS][CPT] = R.a;
+    double (&a)[ROWS][CPT] = R.a;
     double (&r0)[CPT] = R.r0;
     double& k0 = R.k0;
     int& pc = R.pc;
@@ -1091,21 +1094,21 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             for (int j = 0; j < CPT; j++)
                 if (pc == c0 + j) {
 #pragma unroll
-                    for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.col[i] = a[i][j];
+                    for (int i = 0; i < ROWS; i++) sm.col[i] = a[i][j];
                 }
         }
         if (tid == 0) {
 #pragma unroll
-            for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.rhs[i] = a[i][0];
+            for (int i = 0; i < ROWS; i++) sm.rhs[i] = a[i][0];
             reset_reductions(sm);
         }
         __syncthreads();
         if (tid < 64) {
             // lanes 0..7 classify one row each (the division runs in parallel), then every lane of wave 0 merges the
             // eight verdicts in row order: same result in all lanes, no shuffles
-            if (tid < JSLP_R_ROWS) {
+            if (tid < ROWS) {
                 const int r = r_begin + tid;
-                const double colv = sm.f.col[tid], rhs = sm.f.rhs[tid];
+                const double colv = sm.col[tid], rhs = sm.rhs[tid];
                 int kind = 0;  // 0 skip, 1 degenerate winner, 2 quotient candidate (phase 1: RHS candidate)
                 double quo = 0.0;
                 if (phase == 1) {
@@ -1122,9 +1125,9 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
             FCand mine = fcand_none();
 #pragma unroll
-            for (int i = 0; i < JSLP_R_ROWS; i++) {
+            for (int i = 0; i < ROWS; i++) {
                 const int kind = sm.kind[i];
-                const double quo = sm.quo[i], colv = sm.f.col[i];
+                const double quo = sm.quo[i], colv = sm.col[i];
                 const int r = r_begin + i;
                 if (kind == 1) { if (r < mine.rdeg) { mine.rdeg = r; mine.kdeg = colv; } }
                 else if (kind == 2 && mine.q > quo) { mine.q = quo; mine.r = r; mine.kq = colv; }
@@ -1153,7 +1156,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         if (pubrow != 0 && colok) {
             u64_t* rp = f.rows_pub[par] + (long long)b * ld + c0;
 #pragma unroll
-            for (int i = 0; i < JSLP_R_ROWS; i++)
+            for (int i = 0; i < ROWS; i++)
                 if (r_begin + i == pubrow) {  // uniform
 #pragma unroll
                     for (int j = 0; j < CPT; j++) AG_STORE(rp + j, (u64_t)__double_as_longlong(a[i][j]));
@@ -1324,7 +1327,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                 for (int j = 0; j < CPT; j++)
                     if (pc == c0 + j) {
 #pragma unroll
-                        for (int i = 0; i < JSLP_R_ROWS; i++) sm.f.col[i] = a[i][j];
+                        for (int i = 0; i < ROWS; i++) sm.col[i] = a[i][j];
                         sm.xq[0] = pv[j];  // quot = A[pr, pc]
                         sm.xq[1] = r0[j];  // k0 = A[0, pc]
                     }
@@ -1391,9 +1394,9 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             // rare: the stored pivot row depends on whether any OTHER row has a non-zero entry in column pc
             int local_any = 0;
 #pragma unroll
-            for (int i = 0; i < JSLP_R_ROWS; i++) {
+            for (int i = 0; i < ROWS; i++) {
                 const int r = r_begin + i;
-                if (r < r_end && r != pr && nonzero16(sm.f.col[i])) local_any = 1;
+                if (r < r_end && r != pr && nonzero16(sm.col[i])) local_any = 1;
             }
             const int g = global_or(f, par, tag, local_any, sm);
             if (g < 0) { end_code = 5; break; }
@@ -1419,7 +1422,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             }
         }
 #pragma unroll
-        for (int i = 0; i < JSLP_R_ROWS; i++) {
+        for (int i = 0; i < ROWS; i++) {
             const int r = r_begin + i;
             if (r >= r_end) continue;
             if (r == 0) {  // workgroup 0 owns the cost row
@@ -1432,7 +1435,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                 for (int j = 0; j < CPT; j++) a[i][j] = p[j];
                 continue;
             }
-            const double ki = sm.f.col[i];  // pivot-column entry of row i (still in LDS from step A)
+            const double ki = sm.col[i];  // pivot-column entry of row i (still in LDS from step A)
             if (nonzero16(ki)) {
 #pragma unroll
                 for (int j = 0; j < CPT; j++)
@@ -1470,10 +1473,11 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
 
 // THREADS x CPT >= ld: <1024, 2> = lane pairs of columns, 4 waves per SIMD; <512, 4> = half the waves to synchronise,
 // twice the independent work per lane (and 256 VGPRs per lane).
-template <int THREADS, int CPT>
+template <int THREADS, int CPT, int ROWS>
 __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
+    static_assert(ROWS <= JSLP_R_MAXROWS, "RSmem holds one entry per row of the workgroup");
     __shared__ RSmem sm;
-    ResRegs<CPT> R;
+    ResRegs<CPT, ROWS> R;
 #ifdef JSLP_DEBUG_RESIDENT
     for (int i = 0; i < 8; i++) R.rt_acc[i] = 0;
     R.rt_prev = __builtin_amdgcn_s_memtime();
@@ -1489,7 +1493,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     static_assert(CPT % 2 == 0, "lanes load and store their columns as 16-byte pairs");
 
     // ---- load my rows and the cost row into registers ---------------------------------------------------
-    double (&a)[JSLP_R_ROWS][CPT] = R.a;
+    double (&a)[ROWS][CPT] = R.a;
     double (&r0)[CPT] = R.r0;
 #pragma unroll
     for (int j = 0; j < CPT; j += 2) {
@@ -1498,7 +1502,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
         r0[j] = t.x; r0[j + 1] = t.y;
     }
 #pragma unroll
-    for (int i = 0; i < JSLP_R_ROWS; i++) {
+    for (int i = 0; i < ROWS; i++) {
         const int r = r_begin + i;
         const bool mine = i < f.rpb && r < r_end && colok;
 #pragma unroll
@@ -1550,13 +1554,13 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     R.unbounded_col = 0;
     R.epoch = 0;
     if (phase == 1) {
-        resident_phase<1, CPT>(f, sm, R, it1_start, it2_start, pb);
+        resident_phase<1, CPT, ROWS>(f, sm, R, it1_start, it2_start, pb);
         if (R.end_code == 0) phase = 2;
     }
     if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
         R.pc = price_row_lds<CPT>(r0, c0, pb, c, sm, &R.k0);
         if (R.pc == 0) R.end_code = 1;
-        else resident_phase<2, CPT>(f, sm, R, it1_start, it2_start, pb);
+        else resident_phase<2, CPT, ROWS>(f, sm, R, it1_start, it2_start, pb);
     }
     const int end_code = R.end_code, unbounded_col = R.unbounded_col, hist_n = R.hist_n, it1 = R.it1, it2 = R.it2;
     const unsigned epoch = R.epoch;
@@ -1574,7 +1578,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     // ---- epilogue: registers -> tableau, workgroup 0 -> state -----------------------------------------------------------
     if (end_code != 5) {
 #pragma unroll
-        for (int i = 0; i < JSLP_R_ROWS; i++) {
+        for (int i = 0; i < ROWS; i++) {
             const int r = r_begin + i;
             if (i < f.rpb && r < r_end && colok) {
 #pragma unroll
