@@ -1,0 +1,400 @@
+// jslp_fused.hip.h -- the fused phase-2 pipeline (one launch per pivot) for tableaus that do not fit the registers.
+// Included by jslp_kernels.hip.h (needs the simplex core, DevState and the launch constants defined there).
+#pragma once
+
+// ===================================================================================================
+// Fused phase-2 pipeline for one LARGE tableau: ONE launch per pivot.
+//
+// Launch t (a) finishes the selection of pivot t from what launch t-1 left behind -- the entering column
+// f_pc, the per-workgroup ratio-test candidates cands[] and the pivot column pcol[] -- (b) streams the whole
+// tableau once, out of place (read buf[in], write buf[in^1]: no workgroup ever reads a cell another one is
+// writing, so any workgroup may read the pivot row and the cost row straight from the input), and (c) while
+// the updated rows are still in registers prepares pivot t+1: every workgroup re-derives the updated cost row
+// and prices it (same result everywhere), then its rows' ratio-test candidates and pivot-column entries.
+// Workgroup w owns `rpb` consecutive rows; lane pairs own two adjacent columns (16-byte accesses).
+// Preconditions checked by the host: phase 2, no unrestricted variables, ld <= 2048, H <= 64 * 256,
+// precision >= 1e-15 (then the entering cost is never "tiny" and simplex.ts:381-383 always fires).
+// The cycle check is done by workgroup 0 alone; the other workgroups pivot speculatively into the OTHER
+// buffer, which is simply not adopted when the check (or unboundedness) stops the solve.
+// ===================================================================================================
+__device__ __forceinline__ void copy_state(DevState* dst, const DevState* src) {
+    static_assert(sizeof(DevState) % 8 == 0, "DevState is copied as 8-byte words");
+    const unsigned long long* a = reinterpret_cast<const unsigned long long*>(src);
+    unsigned long long* b = reinterpret_cast<unsigned long long*>(dst);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(DevState) / 8; i++) b[i] = a[i];
+}
+
+struct FCand {       // per-workgroup ratio-test summary
+    double q;        // smallest accepted quotient among its rows (first index on ties)
+    double kq;       // pivot-column entry of that row (becomes `quot` if it wins)
+    double kdeg;     // pivot-column entry of row rdeg
+    int32_t r;       // row of q, 0 = none
+    int32_t rdeg;    // first row passing the degenerate test (simplex.ts:285-289), 0x7fffffff = none
+};
+#define JSLP_F_THREADS 1024
+#define JSLP_F_RG 8          // rows processed per group (kept in registers)
+#define JSLP_F_MAXG 256      // workgroups (= CUs)
+
+struct FusedCtx {
+    Ctx c;               // slot 0 (maps, history, trace, canonical state)
+    double* buf[2];      // buf[0] = c.A
+    FCand* cands[2];
+    double* pcol[2];
+    DevState* fst[2];
+    int32_t G, rpb;
+    int32_t H;   // height is fixed during a simplex() call: known to the host, so no load gates the prefetch
+    int32_t nt;  // non-temporal hints on the streamed tableau cells
+};
+
+__device__ __forceinline__ void fcand_consider(FCand& best, int r, double colv, double rhs, double precision) {
+    // one row of the ratio test (simplex.ts:276-296), rows visited in ascending order
+    if (-precision < colv && colv < precision) return;
+    if (colv > 0 && precision > rhs && rhs > -precision) {
+        if (r < best.rdeg) { best.rdeg = r; best.kdeg = colv; }
+        return;
+    }
+    const double quo = rhs / colv;  // isReducedCostNegative is false without unrestricted variables
+    if (quo > precision && best.q > quo) { best.q = quo; best.r = r; best.kq = colv; }
+}
+
+__device__ __forceinline__ bool fcand_better(const FCand& a, const FCand& b) {  // MinFirst on (q, r)
+    if (a.r == 0) return false;
+    if (b.r == 0) return true;
+    return a.q < b.q || (a.q == b.q && a.r < b.r);
+}
+
+// reduce FCands held by the lanes of ONE wave (lanes >= n hold "none")
+__device__ __forceinline__ FCand fcand_wave_reduce(FCand x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        FCand y;
+        y.q = __shfl_down(x.q, off, 64);
+        y.kq = __shfl_down(x.kq, off, 64);
+        y.kdeg = __shfl_down(x.kdeg, off, 64);
+        y.r = __shfl_down(x.r, off, 64);
+        y.rdeg = __shfl_down(x.rdeg, off, 64);
+        if (fcand_better(y, x)) { x.q = y.q; x.r = y.r; x.kq = y.kq; }
+        if (y.rdeg < x.rdeg) { x.rdeg = y.rdeg; x.kdeg = y.kdeg; }
+    }
+    return x;
+}
+
+struct FSmem {
+    Smem red;
+    FCand wave[JSLP_F_THREADS / 64];
+    FCand win;
+    double col[JSLP_F_RG];
+    double rhs[JSLP_F_RG];
+};
+
+__device__ __forceinline__ FCand fcand_none() {
+    FCand x; x.q = INFINITY; x.kq = 0; x.kdeg = 0; x.r = 0; x.rdeg = 0x7fffffff;
+    return x;
+}
+
+__device__ __forceinline__ FCand fcand_block_reduce(FCand x, FSmem& sm) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    x = fcand_wave_reduce(x);
+    __syncthreads();
+    if (lane == 0) sm.wave[w] = x;
+    __syncthreads();
+    if (w == 0) {
+        FCand y = lane < nw ? sm.wave[lane] : fcand_none();
+        y = fcand_wave_reduce(y);
+        if (lane == 0) sm.win = y;
+    }
+    __syncthreads();
+    return sm.win;
+}
+
+// pricing of a cost-row pair held in registers (columns c0, c0+1): simplex.ts:118-219 without unrestricted vars
+__device__ __forceinline__ int price_row(double x0, double x1, int c0, const Ctx& c, Smem& sm, unsigned long long* dbg = nullptr) {
+    // the lane's two columns, written out field by field (no struct select: a `Cand e = cand` inside an unrolled
+    // loop was observed to keep the FIRST column's index with the SECOND column's value on gfx950 / ROCm 7.2)
+    const int col1 = c0 + 1;
+    const bool ok0 = c0 >= 1 && c0 < c.W && x0 > c.precision;
+    const bool ok1 = col1 < c.W && x1 > c.precision;   // col1 >= 1 always
+    const int b0 = c.use_partial ? (c0 - 1) / c.batch : 0;
+    const int b1 = c.use_partial ? (col1 - 1) / c.batch : 0;
+    double bv = c.precision;
+    int bi = 0, bb = 0;
+    if (ok0) { bv = x0; bi = c0; bb = b0; }
+    // column c0+1 replaces column c0 only when strictly better in (batch asc, value desc); ties keep c0
+    const bool take1 = ok1 && (bi == 0 || b1 < bb || (b1 == bb && x1 > bv));
+    bv = take1 ? x1 : bv;
+    bi = take1 ? col1 : bi;
+    bb = take1 ? b1 : bb;
+    Cand e;
+    e.v = bv; e.i = bi; e.b = bb;
+    if (dbg) {
+        dbg[threadIdx.x * 4] = (unsigned long long)__double_as_longlong(e.v);
+        dbg[threadIdx.x * 4 + 1] = (unsigned long long)(unsigned)e.i | ((unsigned long long)(unsigned)e.b << 32);
+        dbg[threadIdx.x * 4 + 2] = (unsigned long long)__double_as_longlong(x0);
+        dbg[threadIdx.x * 4 + 3] = (unsigned long long)__double_as_longlong(x1);
+    }
+    e = block_reduce(e, PriceFirst(), sm);
+    if (dbg && threadIdx.x == 0) dbg[4096] = (unsigned long long)(unsigned)e.i;
+    return e.i;
+}
+
+// streamed tableau cells: every cell is read once and written once per launch, so optionally bypass the
+// cache retention policy (non-temporal) to keep L2 for the small shared vectors
+__device__ __forceinline__ double2 ld_stream(const double* p, int nt) {
+    const double2* q = reinterpret_cast<const double2*>(p);
+    if (nt) {
+        double2 v;
+        v.x = __builtin_nontemporal_load(&q->x);
+        v.y = __builtin_nontemporal_load(&q->y);
+        return v;
+    }
+    return *q;
+}
+__device__ __forceinline__ void st_stream(double* p, double2 v, int nt) {
+    double2* q = reinterpret_cast<double2*>(p);
+    if (nt) {
+        __builtin_nontemporal_store(v.x, &q->x);
+        __builtin_nontemporal_store(v.y, &q->y);
+    } else {
+        *q = v;
+    }
+}
+
+__global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int launch) {
+    __shared__ FSmem sm;
+    const Ctx& c = f.c;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const bool init = launch == 0;
+    const DevState* sin = init ? c.st : f.fst[launch & 1];
+    DevState* sout = f.fst[(launch + 1) & 1];
+    const int in_buf = init ? 0 : ((launch - 1) & 1);
+    const double* Min = f.buf[in_buf];
+    double* Mout = f.buf[in_buf ^ 1];
+    const FCand* cin = f.cands[launch & 1];
+    FCand* cout = f.cands[(launch + 1) & 1];
+    const double* pin = f.pcol[launch & 1];
+    double* pout = f.pcol[(launch + 1) & 1];
+    const int ld = c.ld, W = c.W;
+    const double precision = c.precision;
+
+    const int H = f.H;
+    const int c0 = tid * 2;
+    const bool colok = c0 < ld;
+    const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
+    // Everything whose address does not depend on the selection is requested FIRST, before any barrier: the
+    // workgroup's first row group (8 rows x 16 B per lane), its pivot-column entries, the cost row, the
+    // candidates and the state.  The selection below then runs while these loads are in flight.
+    double2 a[JSLP_F_RG];
+    double k[JSLP_F_RG];
+    double2 row0 = make_double2(0, 0);
+    double k0 = 0.0;
+    FCand mine = fcand_none();
+    // (vmcnt retires in order: the selection's own inputs go first so that waiting for them leaves the bulk
+    // row loads in flight)
+    const int status = sin->status;
+    const int pc_in = sin->f_pc;
+    const int iters_left_in = sin->iters_left;
+    if (!init) {
+        if (tid < f.G) mine = cin[tid];
+        k0 = pin[0];
+        if (colok) row0 = *reinterpret_cast<const double2*>(Min + c0);
+#pragma unroll
+        for (int i = 0; i < JSLP_F_RG; i++) {
+            const int r = r_begin + i;
+            k[i] = r < r_end ? pin[r] : 0.0;
+            a[i] = make_double2(0, 0);
+            if (r < r_end && colok) a[i] = ld_stream(Min + (long long)r * ld + c0, f.nt);
+        }
+    }
+    const bool live = init ? (status == ST_PHASE1_DONE) : (status == ST_RUNNING);
+    if (!live) {  // the solve already ended (or never reached phase 2): carry the state forward
+        if (b == 0 && tid == 0) { copy_state(sout, sin); if (init) sout->f_final_buf = 0; }
+        return;
+    }
+    if (init) {
+        // first phase-2 step: price the current cost row, then scan the entering column for candidates
+        double2 r0 = make_double2(0, 0);
+        if (colok) r0 = *reinterpret_cast<const double2*>(Min + c0);
+        const int cn = price_row(r0.x, r0.y, c0, c, sm.red);
+        if (cn == 0) {  // already optimal (simplex.ts:265-269)
+            if (b == 0 && tid == 0) {
+                copy_state(sout, sin); DevState& s = *sout;
+                s.status = ST_DONE; s.optimal = 1; s.do_pivot = 0; s.obj_cell = Min[0]; s.f_final_buf = 0;
+            }
+            return;
+        }
+        FCand best = fcand_none();
+        if (tid < 64) {
+            for (int r = r_begin + tid; r < r_end; r += 64) {
+                const double colv = Min[(long long)r * ld + cn];
+                pout[r] = colv;
+                if (r >= 1) fcand_consider(best, r, colv, Min[(long long)r * ld], precision);
+            }
+            // lanes hold rows in interleaved order: the reduction's (q, r) / min-rdeg orders are total
+            best = fcand_wave_reduce(best);
+            if (tid == 0) cout[b] = best;
+        }
+        if (b == 0 && tid == 0) {
+            copy_state(sout, sin); DevState& s = *sout;
+            s.status = ST_RUNNING; s.f_pc = cn; s.f_final_buf = 0; s.do_pivot = 0;
+        }
+        return;
+    }
+
+    // ---- STEP: pivot t ---------------------------------------------------------------------------
+    const int pc = pc_in;
+    if (iters_left_in <= 0) {
+        if (b == 0 && tid == 0) {
+            copy_state(sout, sin); DevState& s = *sout;
+            s.err = ERR_ITER_LIMIT; s.status = ST_DONE; s.do_pivot = 0; s.obj_cell = Min[0]; s.f_final_buf = in_buf;
+        }
+        return;
+    }
+    const FCand win = fcand_block_reduce(mine, sm);
+    int pr; double quot;
+    if (win.rdeg != 0x7fffffff) { pr = win.rdeg; quot = win.kdeg; }
+    else if (win.r != 0) { pr = win.r; quot = win.kq; }
+    else {  // unbounded (simplex.ts:298-303): nothing is pivoted, the input buffer is final
+        if (b == 0 && tid == 0) {
+            copy_state(sout, sin); DevState& s = *sout;
+            s.bounded = 0; s.unbounded_var = c.vibc[pc]; s.status = ST_DONE; s.do_pivot = 0;
+            s.obj_cell = Min[0]; s.f_final_buf = in_buf;
+        }
+        return;
+    }
+    // workgroup 0: cycle check before anything is committed (simplex.ts:305-320)
+    if (b == 0 && c.check_cycles) {
+        const int n = sin->hist_n;
+        if (n >= c.hist_cap) {
+            if (tid == 0) {
+                copy_state(sout, sin); DevState& s = *sout;
+                s.err = ERR_HIST_FULL; s.status = ST_DONE; s.do_pivot = 0; s.obj_cell = Min[0]; s.f_final_buf = in_buf;
+            }
+            return;
+        }
+        if (tid == 0) c.hist[n] = make_int2(c.vibr[pr], c.vibc[pc]);
+        __syncthreads();
+        if (suffix_is_square(c.hist, n + 1, sm.red)) {
+            if (tid == 0) {
+                copy_state(sout, sin); DevState& s = *sout;
+                s.hist_n = n + 1; s.cycle_phase = 2; s.feasible = 0; s.status = ST_DONE; s.do_pivot = 0;
+                s.obj_cell = Min[0]; s.f_final_buf = in_buf;
+            }
+            return;  // the other workgroups write the other buffer, which nobody adopts
+        }
+    }
+    // normalised pivot row in registers (simplex.ts:352-364; anyrow is true in phase 2, see header)
+    double2 p = make_double2(0, 0);
+    if (colok) {
+        const double2 pv = *reinterpret_cast<const double2*>(Min + (long long)pr * ld + c0);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int col = c0 + j;
+            const double val = j ? pv.y : pv.x;
+            double v = 0.0;
+            if (col < W) {
+                const bool innz = nonzero16(val);
+                v = innz ? val / quot : 0.0;
+                if (col == pc) v = 1.0 / quot;
+                if (innz && !nonzero16(v) && v != 0.0) v = 0.0;
+            }
+            if (j) p.y = v; else p.x = v;
+        }
+    }
+    const bool v0 = nonzero16(p.x), v1 = nonzero16(p.y);
+    const bool has_pc = colok && ((pc == c0) || (pc == c0 + 1));
+    // updated cost row (every workgroup derives the same values), priced for pivot t+1
+    double2 n0 = row0;
+    if (nonzero16(k0)) {
+        if (v0) n0.x = eliminate(n0.x, k0, p.x);
+        if (v1) n0.y = eliminate(n0.y, k0, p.y);
+        if (has_pc) { const double nv = -k0 / quot; if (pc == c0) n0.x = nv; else n0.y = nv; }
+    }
+    const int cn = price_row(n0.x, n0.y, c0, c, sm.red);  // 0 => optimal after this pivot
+
+    // ---- stream my rows ---------------------------------------------------------------------------
+    FCand best = fcand_none();  // kept by lanes 0..7 of wave 0: lane i sees rows r_begin+i, +8, ... in order
+    for (int g0 = r_begin; g0 < r_end; g0 += JSLP_F_RG) {
+        if (g0 != r_begin) {  // the first group was prefetched at the top
+#pragma unroll
+            for (int i = 0; i < JSLP_F_RG; i++) {
+                const int r = g0 + i;
+                k[i] = r < r_end ? pin[r] : 0.0;
+                a[i] = make_double2(0, 0);
+                if (r < r_end && colok) a[i] = ld_stream(Min + (long long)r * ld + c0, f.nt);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < JSLP_F_RG; i++) {
+            const int r = g0 + i;
+            if (r >= r_end) break;
+            double2 x = a[i];
+            if (r == pr) {
+                x = p;
+            } else if (nonzero16(k[i])) {
+                if (v0) x.x = eliminate(x.x, k[i], p.x);
+                if (v1) x.y = eliminate(x.y, k[i], p.y);
+                if (has_pc) { const double nv = -k[i] / quot; if (pc == c0) x.x = nv; else x.y = nv; }
+            }
+            if (colok) st_stream(Mout + (long long)r * ld + c0, x, f.nt);
+            if (cn != 0) {
+                if (cn == c0) sm.col[i] = x.x; else if (cn == c0 + 1) sm.col[i] = x.y;
+                if (tid == 0) sm.rhs[i] = x.x;
+            }
+        }
+        if (cn != 0) {
+            __syncthreads();
+            if (tid < JSLP_F_RG && g0 + tid < r_end) {
+                const int r = g0 + tid;
+                const double colv = sm.col[tid];
+                pout[r] = colv;
+                if (r >= 1) fcand_consider(best, r, colv, sm.rhs[tid], precision);
+            }
+            __syncthreads();
+        }
+    }
+    if (cn != 0 && tid < 64) {
+        best = fcand_wave_reduce(best);
+        if (tid == 0) cout[b] = best;
+    }
+    // ---- workgroup 0 commits the pivot (simplex.ts:339-349) and publishes the next state -----------------
+    if (b == 0 && tid == 0) {
+        copy_state(sout, sin); DevState& s = *sout;
+        const int leaving = c.vibr[pr], entering = c.vibc[pc];
+        c.vibr[pr] = entering;
+        c.vibc[pc] = leaving;
+        c.rbv[entering] = pr;
+        c.rbv[leaving] = -1;
+        c.cbv[entering] = -1;
+        c.cbv[leaving] = pc;
+        if (s.trace_n < c.trace_cap) c.trace[s.trace_n] = make_int2(pr, pc);
+        s.trace_n += 1;
+        if (c.check_cycles) s.hist_n += 1;
+        s.it2 += 1;
+        s.iters_left -= 1;
+        s.pr = pr; s.pc = pc; s.quot = quot;
+        s.f_pc = cn;
+        s.f_final_buf = in_buf ^ 1;
+        if (cn == 0) {  // optimal after this pivot
+            s.status = ST_DONE; s.optimal = 1; s.do_pivot = 0;
+            s.obj_cell = n0.x;  // thread 0 owns column 0 of the updated cost row
+        }
+    }
+}
+
+// End of the fused pipeline: adopt the final state and make buf[0] hold the final tableau.
+__global__ void __launch_bounds__(256) k_fused_finish(FusedCtx f, int last_launch) {
+    const DevState* fin = f.fst[(last_launch + 1) & 1];
+    const int H = f.H;
+    if (fin->f_final_buf == 1) {
+        const long long n2 = (long long)H * f.c.ld / 2;
+        const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long long)gridDim.x * blockDim.x;
+        const double2* src = reinterpret_cast<const double2*>(f.buf[1]);
+        double2* dst = reinterpret_cast<double2*>(f.buf[0]);
+        for (long long i = tid; i < n2; i += nt) dst[i] = src[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        copy_state(f.c.st, fin);
+    }
+}
+

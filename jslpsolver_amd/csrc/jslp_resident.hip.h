@@ -1,0 +1,751 @@
+// jslp_resident.hip.h -- the register-resident whole-solve kernel (one cooperative launch per simplex()).
+// Included by jslp_kernels.hip.h after jslp_fused.hip.h (shares FCand / FSmem and the launch constants with it).
+#pragma once
+
+// ===================================================================================================
+// Register-resident phase 2: the whole tableau lives in the VGPRs of the chip for the whole solve.
+//
+// 256 CUs x 512 KB of vector registers = 128 MB; a 2001 x 2016 fp64 tableau is 32 MB.  Workgroup w keeps its
+// (<= 8) rows in registers -- lane pair (c0, c0+1) of each row -- together with a private copy of the cost row,
+// so a pivot moves NO tableau bytes through HBM: per pivot each workgroup publishes 32 bytes of ratio-test
+// summary plus the one row that would become the pivot row if it wins (16 KB), all workgroups meet at ONE
+// grid barrier, read the <= 256 summaries and the winning row back, and update their registers.
+// One cooperative launch runs the entire phase 2 (no host round trip, no kernel boundary per pivot).
+//
+// Inter-workgroup hand-off follows cdna_hip_programming.md Guideline 16: every shared word is written and read
+// with 8-byte agent-scope relaxed atomics (sc1, write-through / L1-bypassing), every storing wave drains its
+// stores (s_waitcnt vmcnt(0)) before the workgroup's leader arrives at the barrier counter, one lane polls with
+// s_sleep, buffers alternate by pivot parity, every spin is bounded and raises a device-wide abort flag.
+// Preconditions (host): those of the fused pipeline, plus H <= 8 * G (register residency) and a successful
+// hipLaunchCooperativeKernel (all workgroups co-resident).
+// ===================================================================================================
+#define JSLP_R_ROWS 8       // rows per workgroup of the default geometry (H <= 8 * 256)
+#define JSLP_R_MAXROWS 16   // ... of the tall geometry (512 lanes x 4 columns x 16 rows: H <= 16 * 256)
+#define JSLP_R_GRAN 8        // 8-byte granules per workgroup summary (7 used)
+typedef unsigned long long u64_t;
+
+struct ResCtx {
+    Ctx c;
+    u64_t* gran[2];       // [G][8] data-tagged granules {tag = epoch + 1 : 32 | payload : 32}: q, kq, kdeg halves, rows
+    u64_t* rows_pub[2];   // [G][ld] candidate rows (doubles as 8-byte words)
+    u64_t* rowflag[2];    // [G] epoch tag: the workgroup's candidate row of that epoch is fully written through
+    unsigned* abort_flag; // set when any spin gives up
+    u64_t* decision[2];   // leader's per-pivot decision: 3 tagged granules {pr | stop << 16}, {quot lo}, {quot hi}
+    u64_t* verdict[2];    // phase 1 only: leader's cycle-check verdict {tag | stop} (the entering column is known late there)
+    u64_t* gor[2];        // [G] rare slow path: tagged per-workgroup flags for a chip-wide OR
+    int32_t G, rpb, H;
+    int32_t iters_cap;
+    u64_t* dbg;  // JSLP_DEBUG_RESIDENT builds only
+};
+
+#define AG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define AG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define JSLP_SPIN_LIMIT (1u << 22)
+#ifndef JSLP_POLL_SLEEP
+#define JSLP_POLL_SLEEP 6
+#endif
+
+struct RSmem {
+    FSmem f;
+    u64_t w_q[4];        // leader: per sweep wave, bits of its smallest quotient / its row / its first degenerate row
+    int32_t w_r[4], w_rdeg[4];
+    // LDS-atomic reductions (a handful of participants each; far cheaper than 12 ds_bpermute stages)
+    u64_t p_val;      // pricing: bits of the best value in the winning batch
+    int32_t p_batch;  // pricing: first batch holding a candidate
+    int32_t p_col;    // pricing: first column with that value
+    u64_t l_q;        // leader: bits of the smallest accepted quotient
+    double l_k;       // leader: pivot-column entry of the winning row
+    int32_t l_rdeg, l_r;
+    int32_t ok;
+    int32_t pubrow;
+    unsigned dec[4];
+    double xq[2];   // phase 1: quot and k0 broadcast by the lane pair owning column pc
+    double quo[JSLP_R_MAXROWS];
+    int32_t kind[JSLP_R_MAXROWS];
+    double col[JSLP_R_MAXROWS];  // my rows' entries in the pivot column / in column 0
+    double rhs[JSLP_R_MAXROWS];
+};
+
+// The leader's last FOUR waves gather every workgroup's summary of this epoch (all-gather with the data as the flag,
+// Guideline 16 R2): lane w of the 256 owns workgroup w and re-reads its 7 granules -- all in flight per pass -- until
+// every tag matches, so the complete summary ends up in that lane's registers.  Returns false on abort (per wave).
+#define JSLP_SWEEP_LANES 256
+struct SweptCand {
+    u64_t qbits;   // bits of the smallest accepted quotient (positive doubles order like their bits); ~0 when none
+    double kq, kdeg;
+    int32_t r, rdeg;
+};
+__device__ __forceinline__ bool sweep_summary(const ResCtx& f, int par, unsigned tag, int w, SweptCand& out) {
+    const bool used = w < f.G;
+    const u64_t* g = f.gran[par] + (long long)(used ? w : 0) * JSLP_R_GRAN;
+    unsigned spins = 0;
+    u64_t x[JSLP_R_GRAN - 1];
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < JSLP_R_GRAN - 1; j++) x[j] = used ? AG_LOAD(g + j) : ((u64_t)tag << 32);
+#pragma unroll
+        for (int j = 0; j < JSLP_R_GRAN - 1; j++) ok = ok && (unsigned)(x[j] >> 32) == tag;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+        if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) return false;
+        if (spins > JSLP_SPIN_LIMIT) { if ((w & 63) == 0) AG_STORE(f.abort_flag, 1u); return false; }
+    }
+    const u64_t qb = (x[0] & 0xffffffffull) | (x[1] << 32);
+    const u64_t kqb = (x[2] & 0xffffffffull) | (x[3] << 32);
+    const u64_t kdb = (x[4] & 0xffffffffull) | (x[5] << 32);
+    const unsigned rr = (unsigned)x[6];
+    out.r = used ? (int32_t)(rr & 0xffffu) : 0;
+    const unsigned rd = rr >> 16;
+    out.rdeg = (!used || rd == 0xffffu) ? 0x7fffffff : (int32_t)rd;
+    out.qbits = out.r != 0 ? qb : ~0ull;
+    out.kq = __longlong_as_double((long long)kqb);
+    out.kdeg = __longlong_as_double((long long)kdb);
+    return true;
+}
+
+// Pricing (simplex.ts:118-219, no unrestricted variables) of the cost-row pair (columns c0, c0+1) each lane
+// holds, reduced with three LDS atomics: first batch holding a candidate, best value in it, first column with
+// that value.  Positive doubles order like their bit patterns.  Returns the column (0 = none) and its value.
+// `sm.p_*` must have been reset (p_batch = INT_MAX, p_val = 0, p_col = INT_MAX) before a preceding barrier.
+template <int CPT>
+__device__ __forceinline__ int price_row_lds(const double (&x)[CPT], int c0, const int (&pb)[CPT], const Ctx& c, RSmem& sm,
+                                             double* value) {
+    double bv = c.precision;
+    int bi = 0, bb = 0;
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {  // my columns in order: earlier batch first, bigger value inside a batch, first index on ties
+        const int col = c0 + j;
+        const bool ok = col >= 1 && col < c.W && x[j] > c.precision;
+        const bool take = ok && (bi == 0 || pb[j] < bb || (pb[j] == bb && x[j] > bv));
+        bv = take ? x[j] : bv;
+        bi = take ? col : bi;
+        bb = take ? pb[j] : bb;
+    }
+    {   // batch ids grow with the lane index: the wave's earliest batch is that of its first candidate lane
+        const unsigned long long m = __ballot(bi != 0);
+        if (m != 0ull) {
+            const int first = __ffsll((long long)m) - 1;
+            const int wave_b = __builtin_amdgcn_readlane(bb, first);
+            if ((threadIdx.x & 63) == 0) atomicMin(&sm.p_batch, wave_b);
+        }
+    }
+    __syncthreads();
+    const int wb = sm.p_batch;
+    if (wb == 0x7fffffff) return 0;  // uniform: no candidate anywhere -> optimal
+    const u64_t bits = (u64_t)__double_as_longlong(bv);
+    if (bi != 0 && bb == wb) atomicMax(&sm.p_val, bits);
+    __syncthreads();
+    const u64_t wv = sm.p_val;
+    if (bi != 0 && bb == wb && bits == wv) atomicMin(&sm.p_col, bi);
+    __syncthreads();
+    *value = __longlong_as_double((long long)wv);
+    return sm.p_col;
+}
+
+#ifdef JSLP_DEBUG_RESIDENT
+#define RT_MARK(i) do { const u64_t _now = __builtin_amdgcn_s_memtime(); rt_acc[i] += _now - rt_prev; rt_prev = _now; } while (0)
+#else
+#define RT_MARK(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ void reset_reductions(RSmem& sm) {  // one thread, before a barrier
+    sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff;
+    sm.l_rdeg = 0x7fffffff; sm.l_q = ~0ull; sm.l_r = 0x7fffffff;
+}
+
+// Chip-wide OR of one flag per workgroup (rare slow path of phase 1, see the lazily-zeroed pivot-row entries):
+// every workgroup publishes a tagged granule and polls everybody else's.  Returns -1 on abort.
+__device__ __forceinline__ int global_or(const ResCtx& f, int par, unsigned tag, int flag, RSmem& sm) {
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (tid == 0) AG_STORE(f.gor[par] + b, ((u64_t)tag << 32) | (unsigned)(flag ? 1 : 0));
+    int mine = 0, ok = 1;
+    if (tid < f.G) {
+        unsigned spins = 0;
+        for (;;) {
+            const u64_t x = AG_LOAD(f.gor[par] + tid);
+            if ((unsigned)(x >> 32) == tag) { mine = (int)(x & 1u); break; }
+            __builtin_amdgcn_s_sleep(JSLP_POLL_SLEEP);
+            ++spins;
+            if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
+            if (spins > JSLP_SPIN_LIMIT) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+        }
+    }
+    const int bad = __syncthreads_or(ok ? 0 : 1);
+    const int any = __syncthreads_or(mine);
+    return bad ? -1 : (any ? 1 : 0);
+}
+
+// Loop-carried state of the resident kernel (kept in registers: every member is a scalar or a fully unrolled array)
+template <int CPT, int ROWS>
+struct ResRegs {
+    double a[ROWS][CPT];  // my rows: CPT adjacent columns per lane
+    double r0[CPT];              // my copy of the cost row
+    double k0;
+    int pc, end_code, unbounded_col, hist_n, it1, it2;
+    unsigned epoch;
+    long long trace_n;
+#ifdef JSLP_DEBUG_RESIDENT
+    u64_t rt_acc[8];
+    u64_t rt_prev;
+#endif
+};
+
+// One phase of the solve.  PHASE is a compile-time constant so that the phase-2 loop -- the hot one -- carries none of
+// the phase-1 branches; returns when the solve ends (R.end_code != 0) or, for PHASE == 1, when phase 1 is over
+// (end_code stays 0 and the caller starts phase 2).
+template <int PHASE, int CPT, int ROWS>
+__device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start,
+                                               const int (&pb)[CPT]) {
+    const Ctx& c = f.c;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int ld = c.ld, W = c.W, H = f.H;
+    const double precision = c.precision;
+    const int c0 = tid * CPT;
+    const bool colok = c0 < ld;
+    const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
+    const int sweep0 = (int)blockDim.x - JSLP_SWEEP_LANES;  // the leader's last four waves sweep
+    constexpr int phase = PHASE;
+    double (&a)[ROWS][CPT] = R.a;
+    double (&r0)[CPT] = R.r0;
+    double& k0 = R.k0;
+    int& pc = R.pc;
+    int& end_code = R.end_code;
+    int& unbounded_col = R.unbounded_col;
+    int& hist_n = R.hist_n;
+    int& it1 = R.it1;
+    int& it2 = R.it2;
+    unsigned& epoch = R.epoch;
+    long long& trace_n = R.trace_n;
+#ifdef JSLP_DEBUG_RESIDENT
+    u64_t (&rt_acc)[8] = R.rt_acc;
+    u64_t& rt_prev = R.rt_prev;
+#endif
+    (void)H;
+    while (end_code == 0) {
+        if ((it1 - it1_start) + (it2 - it2_start) >= f.iters_cap) { end_code = 4; break; }
+        const int par = epoch & 1;
+        const unsigned tag = epoch + 1;
+        RT_MARK(7);
+        // ---- A: my rows' summary: phase 2 = ratio test for column pc (simplex.ts:276-296); phase 1 = most negative RHS
+        //         below -precision (simplex.ts:39-49) -------------------------------------------------------------------
+        bool has_pc = phase == 2 && colok && pc >= c0 && pc < c0 + CPT;
+        if (has_pc) {  // (conditional stores, not selects among register-array elements: those end up in scratch)
+#pragma unroll
+            for (int j = 0; j < CPT; j++)
+                if (pc == c0 + j) {
+#pragma unroll
+                    for (int i = 0; i < ROWS; i++) sm.col[i] = a[i][j];
+                }
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) sm.rhs[i] = a[i][0];
+            reset_reductions(sm);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lanes 0..7 classify one row each (the division runs in parallel), then every lane of wave 0 merges the
+            // eight verdicts in row order: same result in all lanes, no shuffles
+            if (tid < ROWS) {
+                const int r = r_begin + tid;
+                const double colv = sm.col[tid], rhs = sm.rhs[tid];
+                int kind = 0;  // 0 skip, 1 degenerate winner, 2 quotient candidate (phase 1: RHS candidate)
+                double quo = 0.0;
+                if (phase == 1) {
+                    if (r >= 1 && r < r_end && rhs < -precision) { quo = rhs; kind = 2; }
+                } else if (r >= 1 && r < r_end && !(-precision < colv && colv < precision)) {
+                    if (colv > 0 && precision > rhs && rhs > -precision) kind = 1;
+                    else { quo = rhs / colv; kind = quo > precision ? 2 : 0; }
+                }
+                sm.quo[tid] = quo;
+                sm.kind[tid] = kind;
+            }
+            // (wave 0 only: LDS writes above are visible to the same wave after the wave-level sync below)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            FCand mine = fcand_none();
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) {
+                const int kind = sm.kind[i];
+                const double quo = sm.quo[i], colv = sm.col[i];
+                const int r = r_begin + i;
+                if (kind == 1) { if (r < mine.rdeg) { mine.rdeg = r; mine.kdeg = colv; } }
+                else if (kind == 2 && mine.q > quo) { mine.q = quo; mine.r = r; mine.kq = colv; }
+            }
+            if (tid < JSLP_R_GRAN - 1) {  // lanes 0..6 publish one tagged granule each
+                const u64_t qb = (u64_t)__double_as_longlong(mine.q), kqb = (u64_t)__double_as_longlong(mine.kq),
+                            kdb = (u64_t)__double_as_longlong(mine.kdeg);
+                unsigned payload;
+                switch (tid) {
+                    case 0: payload = (unsigned)qb; break;
+                    case 1: payload = (unsigned)(qb >> 32); break;
+                    case 2: payload = (unsigned)kqb; break;
+                    case 3: payload = (unsigned)(kqb >> 32); break;
+                    case 4: payload = (unsigned)kdb; break;
+                    case 5: payload = (unsigned)(kdb >> 32); break;
+                    default: payload = (unsigned)mine.r | ((mine.rdeg == 0x7fffffff ? 0xffffu : (unsigned)mine.rdeg) << 16); break;
+                }
+                AG_STORE(f.gran[par] + (long long)b * JSLP_R_GRAN + tid, ((u64_t)tag << 32) | payload);
+            }
+            if (tid == 0) sm.pubrow = mine.rdeg != 0x7fffffff ? mine.rdeg : mine.r;  // the only row of mine that can win
+        }
+        __syncthreads();
+        RT_MARK(0);
+        // ---- B: publish that row (write-through 8-byte agent stores); its own flag follows the drain ---------------
+        const int pubrow = sm.pubrow;
+        if (pubrow != 0 && colok) {
+            u64_t* rp = f.rows_pub[par] + (long long)b * ld + c0;
+#pragma unroll
+            for (int i = 0; i < ROWS; i++)
+                if (r_begin + i == pubrow) {  // uniform
+#pragma unroll
+                    for (int j = 0; j < CPT; j++) AG_STORE(rp + j, (u64_t)__double_as_longlong(a[i][j]));
+                }
+        }
+        RT_MARK(1);
+        // ---- C: workgroup 0 is the LEADER: its last four waves gather everybody's tagged summaries (data = flag)
+        //         while all other waves, everywhere, drain their row stores -----------------------------------------------
+        bool swept = true;
+        SweptCand sc;
+        sc.qbits = ~0ull; sc.kq = 0; sc.kdeg = 0; sc.r = 0; sc.rdeg = 0x7fffffff;
+        const bool sweeper = b == 0 && tid >= sweep0;
+        if (sweeper) swept = sweep_summary(f, par, tag, tid - sweep0, sc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int all_swept = __syncthreads_and(swept ? 1 : 0);
+        if (!all_swept) { end_code = 5; break; }
+        if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: row is visible
+        RT_MARK(2);
+        // ---- D: the leader decides (winner, unboundedness, cycle check) and broadcasts three tagged granules -----------
+        int pr = 0, stop = 0;
+        double quot = 0.0;
+        if (b == 0) {
+            // (min rdeg) else (min q, then min r): each sweep wave reduces its 64 summaries with shuffles on the keys
+            // only, the four wave results meet in LDS, the lane that holds the winner supplies its pivot-column entry
+            if (sweeper) {
+                u64_t q = sc.qbits;
+                int r = sc.r, rdeg = sc.rdeg;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const u64_t q2 = __shfl_xor(q, off, 64);
+                    const int r2 = __shfl_xor(r, off, 64), rd2 = __shfl_xor(rdeg, off, 64);
+                    const double d2 = __longlong_as_double((long long)q2), d1 = __longlong_as_double((long long)q);
+                    const bool take = r2 != 0 && (r == 0 || d2 < d1 || (d2 == d1 && r2 < r));  // smallest value, first row
+                    q = take ? q2 : q;
+                    r = take ? r2 : r;
+                    rdeg = rd2 < rdeg ? rd2 : rdeg;
+                }
+                if ((tid & 63) == 0) {
+                    const int wv = (tid - sweep0) >> 6;
+                    sm.w_q[wv] = q; sm.w_r[wv] = r; sm.w_rdeg[wv] = rdeg;
+                }
+            }
+            __syncthreads();
+            u64_t wq = ~0ull;
+            int wr = 0, wrdeg = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u64_t q2 = sm.w_q[i];
+                const int r2 = sm.w_r[i], rd2 = sm.w_rdeg[i];
+                const double d2 = __longlong_as_double((long long)q2), d1 = __longlong_as_double((long long)wq);
+                const bool take = r2 != 0 && (wr == 0 || d2 < d1 || (d2 == d1 && r2 < wr));
+                wq = take ? q2 : wq;
+                wr = take ? r2 : wr;
+                wrdeg = rd2 < wrdeg ? rd2 : wrdeg;
+            }
+            if (wrdeg != 0x7fffffff) pr = wrdeg;
+            else if (wr != 0) pr = wr;
+            else stop = phase == 1 ? 4 : 3;  // phase 1: no violated row -> feasible (:51-54); phase 2: unbounded (:298-303)
+            if (!stop && sweeper && tid - sweep0 == pr / f.rpb)
+                sm.l_k = wrdeg != 0x7fffffff ? sc.kdeg : sc.kq;  // the owner of row pr published both entries
+            __syncthreads();
+            quot = stop ? 0.0 : sm.l_k;
+            if (!stop && phase == 2 && c.check_cycles) {  // simplex.ts:305-320, before anything is committed
+                if (hist_n >= c.hist_cap) {
+                    stop = 2;
+                } else {
+                    if (tid == 0) c.hist[hist_n] = make_int2(c.vibr[pr], c.vibc[pc]);
+                    __syncthreads();
+                    hist_n += 1;
+                    if (suffix_is_square(c.hist, hist_n, sm.f.red)) stop = 1;
+                }
+            }
+            if (tid < 3) {
+                const u64_t qb = (u64_t)__double_as_longlong(quot);
+                const unsigned payload = tid == 0 ? ((unsigned)pr | ((unsigned)stop << 16)) : (tid == 1 ? (unsigned)qb : (unsigned)(qb >> 32));
+                AG_STORE(f.decision[par] + tid, ((u64_t)tag << 32) | payload);
+            }
+        } else {
+            if (tid < 64) {
+                unsigned spins = 0;
+                int ok = 1;
+                u64_t x = 0;
+                for (;;) {
+                    bool have = true;
+                    if (tid < 3) { x = AG_LOAD(f.decision[par] + tid); have = (unsigned)(x >> 32) == tag; }
+                    if (__all(have)) break;
+                    __builtin_amdgcn_s_sleep(JSLP_POLL_SLEEP);  // 250 workgroups poll this one line: keep the load on it light
+                    ++spins;
+                    if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
+                    if (spins > JSLP_SPIN_LIMIT) { if (tid == 0) AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+                }
+                if (tid < 3) sm.dec[tid] = (unsigned)x;
+                if (tid == 0) sm.ok = ok;
+            }
+            __syncthreads();
+            if (!sm.ok) { end_code = 5; break; }
+            pr = (int)(sm.dec[0] & 0xffffu);
+            stop = (int)(sm.dec[0] >> 16);
+            quot = __longlong_as_double((long long)((u64_t)sm.dec[1] | ((u64_t)sm.dec[2] << 32)));
+        }
+        RT_MARK(3);
+        if (stop == 3) { end_code = 2; unbounded_col = pc; break; }
+        if (stop == 1) { end_code = 3; break; }
+        if (stop == 2) { end_code = 6; break; }
+        if (stop == 4) {  // phase 1 is over: the caller starts phase 2 with a fresh history (simplex.ts:14-23, 102)
+            hist_n = 0;
+            epoch += 1;
+            return;
+        }
+        // ---- E: the winning row: loaded speculatively together with its flag; re-loaded in the rare case the flag
+        //         (which follows the winner's drain) was not up yet ------------------------------------------------------
+        const int bw = pr / f.rpb;
+        const u64_t* rp_in = f.rows_pub[par] + (long long)bw * ld + c0;
+        double pv[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; j++) pv[j] = 0.0;
+        for (;;) {
+            u64_t flag = 0;
+            if (tid == 0) flag = AG_LOAD(f.rowflag[par] + bw);
+            if (colok) {
+#pragma unroll
+                for (int j = 0; j < CPT; j++) pv[j] = __longlong_as_double((long long)AG_LOAD(rp_in + j));
+            }
+            if (tid == 0) {
+                int ok = 1;
+                if ((unsigned)flag != tag) {
+                    unsigned spins = 0;
+                    ok = 2;  // row must be re-read once the flag is up
+                    while ((unsigned)AG_LOAD(f.rowflag[par] + bw) != tag) {
+                        __builtin_amdgcn_s_sleep(1);
+                        ++spins;
+                        if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
+                        if (spins > JSLP_SPIN_LIMIT) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+                    }
+                }
+                sm.ok = ok;
+            }
+            __syncthreads();
+            const int okv = sm.ok;
+            __syncthreads();
+            if (okv == 2) continue;
+            if (okv == 0) end_code = 5;
+            break;
+        }
+        if (end_code == 5) break;
+        RT_MARK(4);
+        bool anyrow = true;  // phase 2: the entering cost is > precision, so some row always runs simplex.ts:381-383
+        if (phase == 1) {
+            // entering column: max -cost/coef over coef < -precision (simplex.ts:56-71; no unrestricted variables here)
+            Cand best; best.v = -INFINITY; best.i = 0; best.b = 0;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const int col = c0 + j;
+                const double coef = pv[j];
+                if (col >= 1 && col < W && coef < -precision) {
+                    const double quo = -r0[j] / coef;
+                    const bool take = best.v < quo;
+                    best.v = take ? quo : best.v;
+                    best.i = take ? col : best.i;
+                }
+            }
+            best = block_reduce(best, MaxFirst(), sm.f.red);
+            if (best.i == 0) { end_code = 7; break; }  // infeasible (simplex.ts:73-76), uniform
+            pc = best.i;
+            has_pc = colok && pc >= c0 && pc < c0 + CPT;
+            if (has_pc) {
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if (pc == c0 + j) {
+#pragma unroll
+                        for (int i = 0; i < ROWS; i++) sm.col[i] = a[i][j];
+                        sm.xq[0] = pv[j];  // quot = A[pr, pc]
+                        sm.xq[1] = r0[j];  // k0 = A[0, pc]
+                    }
+            }
+            __syncthreads();
+            quot = sm.xq[0];
+            k0 = sm.xq[1];
+            if (c.check_cycles) {  // simplex.ts:78-93: only now is the (leaving, entering) pair known
+                if (b == 0) {
+                    int cstop = 0;
+                    if (hist_n >= c.hist_cap) {
+                        cstop = 2;
+                    } else {
+                        if (tid == 0) c.hist[hist_n] = make_int2(c.vibr[pr], c.vibc[pc]);
+                        __syncthreads();
+                        hist_n += 1;
+                        if (suffix_is_square(c.hist, hist_n, sm.f.red)) cstop = 1;
+                    }
+                    if (tid == 0) AG_STORE(f.verdict[par], ((u64_t)tag << 32) | (unsigned)cstop);
+                    stop = cstop;
+                } else {
+                    if (tid == 0) {
+                        unsigned spins = 0;
+                        int v = -1;
+                        for (;;) {
+                            const u64_t x = AG_LOAD(f.verdict[par]);
+                            if ((unsigned)(x >> 32) == tag) { v = (int)(x & 3u); break; }
+                            __builtin_amdgcn_s_sleep(JSLP_POLL_SLEEP);
+                            ++spins;
+                            if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) break;
+                            if (spins > JSLP_SPIN_LIMIT) { AG_STORE(f.abort_flag, 1u); break; }
+                        }
+                        sm.ok = v;
+                    }
+                    __syncthreads();
+                    stop = sm.ok;
+                    __syncthreads();
+                }
+                if (stop < 0) { end_code = 5; break; }
+                if (stop == 1) { end_code = 3; break; }
+                if (stop == 2) { end_code = 6; break; }
+            }
+        }
+        double p[CPT];  // normalised pivot row (simplex.ts:352-364)
+#pragma unroll
+        for (int j = 0; j < CPT; j++) p[j] = 0.0;
+        int tiny = 0;   // entries simplex.ts:381-383 zeroes as soon as ANY other row is eliminated
+        if (colok) {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const int col = c0 + j;
+                const double val = pv[j];
+                double v = 0.0;
+                if (col < W) {
+                    const bool innz = nonzero16(val);
+                    v = innz ? val / quot : 0.0;
+                    if (col == pc) v = 1.0 / quot;
+                    if (innz && !nonzero16(v) && v != 0.0) tiny |= 1 << j;
+                }
+                p[j] = v;
+            }
+        }
+        if (phase == 1 && __syncthreads_or(tiny)) {
+            // rare: the stored pivot row depends on whether any OTHER row has a non-zero entry in column pc
+            int local_any = 0;
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) {
+                const int r = r_begin + i;
+                if (r < r_end && r != pr && nonzero16(sm.col[i])) local_any = 1;
+            }
+            const int g = global_or(f, par, tag, local_any, sm);
+            if (g < 0) { end_code = 5; break; }
+            anyrow = g != 0;
+        }
+        bool nz[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            if (anyrow && (tiny & (1 << j))) p[j] = 0.0;
+            nz[j] = nonzero16(p[j]);
+        }
+        RT_MARK(5);
+        // ---- F: update registers: cost row (every workgroup the same), then my rows ------------------------------------
+        if (nonzero16(k0)) {
+#pragma unroll
+            for (int j = 0; j < CPT; j++)
+                if (nz[j]) r0[j] = eliminate(r0[j], k0, p[j]);
+            if (has_pc) {
+                const double nv = -k0 / quot;
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if (pc == c0 + j) r0[j] = nv;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ROWS; i++) {
+            const int r = r_begin + i;
+            if (r >= r_end) continue;
+            if (r == 0) {  // workgroup 0 owns the cost row
+#pragma unroll
+                for (int j = 0; j < CPT; j++) a[i][j] = r0[j];
+                continue;
+            }
+            if (r == pr) {
+#pragma unroll
+                for (int j = 0; j < CPT; j++) a[i][j] = p[j];
+                continue;
+            }
+            const double ki = sm.col[i];  // pivot-column entry of row i (still in LDS from step A)
+            if (nonzero16(ki)) {
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if (nz[j]) a[i][j] = eliminate(a[i][j], ki, p[j]);
+                if (has_pc) {
+                    const double nv = -ki / quot;
+#pragma unroll
+                    for (int j = 0; j < CPT; j++)
+                        if (pc == c0 + j) a[i][j] = nv;
+                }
+            }
+        }
+        // workgroup 0 commits the basis change (simplex.ts:339-349)
+        if (b == 0 && tid == 0) {
+            const int leaving = c.vibr[pr], entering = c.vibc[pc];
+            c.vibr[pr] = entering;
+            c.vibc[pc] = leaving;
+            c.rbv[entering] = pr;
+            c.rbv[leaving] = -1;
+            c.cbv[entering] = -1;
+            c.cbv[leaving] = pc;
+            if (trace_n < c.trace_cap) c.trace[trace_n] = make_int2(pr, pc);
+        }
+        trace_n += 1;
+        if (phase == 1) it1 += 1; else it2 += 1;
+        epoch += 1;
+        RT_MARK(6);
+        // ---- G: phase 2: price the new cost row -> entering column of the next pivot -----------------------------------
+        if (phase == 2) {
+            pc = price_row_lds<CPT>(r0, c0, pb, c, sm, &k0);
+            if (pc == 0) end_code = 1;
+        }
+    }
+}
+
+// THREADS x CPT >= ld: <1024, 2> = lane pairs of columns, 4 waves per SIMD; <512, 4> = half the waves to synchronise,
+// twice the independent work per lane (and 256 VGPRs per lane).
+template <int THREADS, int CPT, int ROWS>
+__global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
+    static_assert(ROWS <= JSLP_R_MAXROWS, "RSmem holds one entry per row of the workgroup");
+    __shared__ RSmem sm;
+    ResRegs<CPT, ROWS> R;
+#ifdef JSLP_DEBUG_RESIDENT
+    for (int i = 0; i < 8; i++) R.rt_acc[i] = 0;
+    R.rt_prev = __builtin_amdgcn_s_memtime();
+#endif
+    const Ctx& c = f.c;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int ld = c.ld, W = c.W, H = f.H;
+    const double precision = c.precision;
+    const int c0 = tid * CPT;
+    const bool colok = c0 < ld;
+    const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
+    DevState* st = c.st;
+    static_assert(CPT % 2 == 0, "lanes load and store their columns as 16-byte pairs");
+
+    // ---- load my rows and the cost row into registers ---------------------------------------------------
+    double (&a)[ROWS][CPT] = R.a;
+    double (&r0)[CPT] = R.r0;
+#pragma unroll
+    for (int j = 0; j < CPT; j += 2) {
+        double2 t = make_double2(0, 0);
+        if (colok) t = *reinterpret_cast<const double2*>(c.A + c0 + j);
+        r0[j] = t.x; r0[j + 1] = t.y;
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; i++) {
+        const int r = r_begin + i;
+        const bool mine = i < f.rpb && r < r_end && colok;
+#pragma unroll
+        for (int j = 0; j < CPT; j += 2) {
+            double2 t = make_double2(0, 0);
+            if (mine) t = *reinterpret_cast<const double2*>(c.A + (long long)r * ld + c0 + j);
+            a[i][j] = t.x; a[i][j + 1] = t.y;
+        }
+    }
+    const int status0 = st->status;
+    R.hist_n = st->hist_n;
+    const int it1_start = st->it1, it2_start = st->it2;
+    R.it1 = it1_start; R.it2 = it2_start;
+    R.trace_n = st->trace_n;
+    // fresh simplex() (k_begin ran: phase 1 first) or a hand-over after a phase 1 done elsewhere
+    if (status0 != ST_RUNNING && status0 != ST_PHASE1_DONE) return;  // uniform
+    int phase = status0 == ST_PHASE1_DONE ? 2 : 1;
+
+#ifdef JSLP_DEBUG_RESIDENT
+    if (f.dbg) {  // micro-costs in this kernel's own geometry
+        u64_t t0 = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 64; i++) __syncthreads();
+        u64_t t1 = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 64; i++) { atomicMin(&sm.p_batch, tid + i); }
+        __syncthreads();
+        u64_t t2 = __builtin_amdgcn_s_memtime();
+        u64_t acc = 0;
+        for (int i = 0; i < 16; i++) { acc += AG_LOAD(f.rowflag[0] + ((acc + i) & 63)); }
+        u64_t t3 = __builtin_amdgcn_s_memtime();
+        double dv = 1.0 + (double)tid;
+        for (int i = 0; i < 16; i++) dv = 3.0 / dv + 1.0;
+        u64_t t4 = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && b == 1) {
+            u64_t* o = f.dbg + (long long)512 * f.G * 2 + 12288 + 64;
+            o[0] = (t1 - t0) / 64; o[1] = (t2 - t1) / 64; o[2] = (t3 - t2) / 16; o[3] = (t4 - t3) / 16; o[4] = acc + (u64_t)dv;
+        }
+        __syncthreads();
+    }
+#endif
+    if (tid == 0) reset_reductions(sm);
+    __syncthreads();
+    // pricing batch of my columns (simplex.ts:118-127): fixed for the whole solve
+    int pb[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; j++) pb[j] = c.use_partial && c0 + j >= 1 ? (c0 + j - 1) / c.batch : 0;
+    R.k0 = 0.0;  // reduced cost of the entering column = cost-row entry of column pc
+    R.pc = 0;
+    R.end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted hand-off, 6 history full, 7 infeasible
+    R.unbounded_col = 0;
+    R.epoch = 0;
+    if (phase == 1) {
+        resident_phase<1, CPT, ROWS>(f, sm, R, it1_start, it2_start, pb);
+        if (R.end_code == 0) phase = 2;
+    }
+    if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
+        R.pc = price_row_lds<CPT>(r0, c0, pb, c, sm, &R.k0);
+        if (R.pc == 0) R.end_code = 1;
+        else resident_phase<2, CPT, ROWS>(f, sm, R, it1_start, it2_start, pb);
+    }
+    const int end_code = R.end_code, unbounded_col = R.unbounded_col, hist_n = R.hist_n, it1 = R.it1, it2 = R.it2;
+    const unsigned epoch = R.epoch;
+    const long long trace_n = R.trace_n;
+    (void)epoch;
+
+
+#ifdef JSLP_DEBUG_RESIDENT
+    if (f.dbg && tid == 0 && (b == 0 || b == 100 || b == f.G - 1)) {
+        u64_t* o = f.dbg + (long long)512 * f.G * 2 + 12288 + (b == 0 ? 0 : (b == 100 ? 16 : 32));
+        for (int i = 0; i < 8; i++) o[i] = R.rt_acc[i];
+        o[8] = epoch;
+    }
+#endif
+    // ---- epilogue: registers -> tableau, workgroup 0 -> state -----------------------------------------------------------
+    if (end_code != 5) {
+#pragma unroll
+        for (int i = 0; i < ROWS; i++) {
+            const int r = r_begin + i;
+            if (i < f.rpb && r < r_end && colok) {
+#pragma unroll
+                for (int j = 0; j < CPT; j += 2)
+                    *reinterpret_cast<double2*>(c.A + (long long)r * ld + c0 + j) = make_double2(a[i][j], a[i][j + 1]);
+            }
+        }
+    }
+    if (b == 0 && tid == 0) {
+        st->it1 = it1;
+        st->it2 = it2;
+        st->trace_n = trace_n;
+        st->hist_n = hist_n;
+        st->iters_left -= (it1 - it1_start) + (it2 - it2_start);
+        st->do_pivot = 0;
+        st->status = ST_DONE;
+        st->phase = phase;
+        if (phase == 2) { st->entered_phase2 = 1; st->feasible = 1; }  // phase 1 found no violated row (simplex.ts:51-54)
+        st->obj_cell = r0[0];  // column 0 of the cost row
+        if (end_code == 1) st->optimal = 1;
+        if (end_code == 2) { st->bounded = 0; st->unbounded_var = c.vibc[unbounded_col]; }
+        if (end_code == 3) { st->cycle_phase = phase; st->feasible = 0; }
+        if (end_code == 7) st->feasible = 0;
+        if (end_code == 4) st->err = ERR_ITER_LIMIT;
+        if (end_code == 5) st->err = ERR_BARRIER;
+        if (end_code == 6) st->err = ERR_HIST_FULL;
+    }
+}
