@@ -55,8 +55,9 @@ class _PseudoCosts:
         return max(up * (1 - fraction), 1e-6) * max(down * fraction, 1e-6)
 
 
-def _select_branching_variable(model, rhs, rows, precision, branching, pseudo):
-    """selectBranchingVariable (:176-221): (varIndex, value) or None"""
+def _select_branching_variable(model, rhs, rows, precision, branching, pseudo, strong_candidates=5):
+    """selectBranchingVariable (incremental-branch-and-cut.ts:176-221; enhanced-branch-and-cut.ts:112-196, which adds the
+    "strong" rule): (varIndex, value) or None"""
     candidates = []
     for var in model.integerVariables:
         r = rows.get(var["index"], -1)
@@ -73,6 +74,16 @@ def _select_branching_variable(model, rhs, rows, precision, branching, pseudo):
             if c[2] > best[2]:
                 best = c
         return best[0], best[1]
+    if branching == "strong":  # enhanced-branch-and-cut.ts:161-193: the 5 most fractional, scored by pseudocosts once both
+        # directions of a variable have been seen twice, by fraction * (1 - fraction) until then
+        ranked = sorted(candidates, key=lambda c: -c[2])[:strong_candidates]  # stable, like Array.prototype.sort
+        best_score, best = -math.inf, ranked[0]
+        for c in ranked:
+            d = pseudo._get(c[0])
+            score = pseudo.score(c[0], c[2]) if d[1] >= 2 and d[3] >= 2 else c[2] * (1 - c[2])
+            if score > best_score:
+                best_score, best = score, c
+        return best[0], best[1]
     best_score, best = -math.inf, candidates[0]
     for c in candidates:
         score = pseudo.score(c[0], c[2])
@@ -81,10 +92,20 @@ def _select_branching_variable(model, rhs, rows, precision, branching, pseudo):
     return best[0], best[1]
 
 
-def incremental_branch_and_cut(tableau, model, node_selection="hybrid", branching="pseudocost", max_checkpoints=50):
+def enhanced_branch_and_cut(tableau, model, node_selection="hybrid", branching="pseudocost"):
+    """createEnhancedBranchAndCutService (src/tableau/enhanced-branch-and-cut.ts:58-437), the service `Solve` picks for
+    `options.nodeSelection` / `options.branching` (src/main.ts:74-80): the same tree walk as the incremental service
+    with every node evaluated from the saved root (no checkpoints) and the "strong" branching rule."""
+    return incremental_branch_and_cut(tableau, model, node_selection=node_selection, branching=branching, max_checkpoints=0,
+                                      incremental_rules=False)
+
+
+def incremental_branch_and_cut(tableau, model, node_selection="hybrid", branching="pseudocost", max_checkpoints=50,
+                               incremental_rules=True):
     """branchAndCut (:283-495).  Leaves `tableau` holding the incumbent; returns (iterations, found_integral).
     `tableau.checkpoints_used` / `tableau.incremental_nodes` report how many checkpoints were taken and how many
-    nodes started from one."""
+    nodes started from one.  incremental_rules=False: the enhanced service's variant of the two places where the
+    services differ (which branching rules exist; both update pseudocosts from the node's last cut)."""
     heap = BranchMinHeap()     # entries carry the _Branch in the `cuts` position
     stack = []
     iterations = 0
@@ -143,8 +164,11 @@ def incremental_branch_and_cut(tableau, model, node_selection="hybrid", branchin
         evaluation = tableau.evaluation
         if evaluation > best_evaluation:
             continue
-        if branch.new_cut is not None and parent_eval != 0:  # :354-365
-            pseudo.update(branch.new_cut["varIndex"], branch.new_cut["type"] == "min", abs(evaluation - parent_eval), 0.5)
+        # :354-365; the enhanced service takes the node's LAST cut instead (enhanced-branch-and-cut.ts:299-311), which also
+        # exists for nodes that came through the best-first heap
+        observed = branch.new_cut if incremental_rules else (branch.cuts[-1] if branch.cuts else None)
+        if observed is not None and parent_eval != 0:
+            pseudo.update(observed["varIndex"], observed["type"] == "min", abs(evaluation - parent_eval), 0.5)
         optional_cells = None
         if evaluation == best_evaluation:  # :367-388
             worse = True
@@ -179,7 +203,8 @@ def incremental_branch_and_cut(tableau, model, node_selection="hybrid", branchin
         else:
             if iterations == 1:
                 tableau.save()
-            sel = _select_branching_variable(model, rhs, rows, precision, branching, pseudo)
+            rule = branching if (not incremental_rules or branching == "most-fractional") else "pseudocost"  # (:203-221)
+            sel = _select_branching_variable(model, rhs, rows, precision, rule, pseudo)
             if sel is None:
                 continue
             var_index, var_value = sel

@@ -62,6 +62,11 @@ def Solve(model, precision=None, full=False, validate=False, lib=None, device=0,
             iterations, integral = incremental_branch_and_cut(
                 t, m, node_selection=m.options.get("nodeSelection") or "hybrid",
                 branching=m.options.get("branching") or "pseudocost")
+        elif m.options.get("nodeSelection") or m.options.get("branching"):  # main.ts:74-80
+            from .incremental_branch_and_cut import enhanced_branch_and_cut
+            iterations, integral = enhanced_branch_and_cut(
+                t, m, node_selection=m.options.get("nodeSelection") or "hybrid",
+                branching=m.options.get("branching") or "pseudocost")
         else:
             iterations, integral = branch_and_cut(t, m, speculate=speculate, evaluate_batch=evaluate)
     else:

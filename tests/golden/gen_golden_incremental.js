@@ -79,13 +79,27 @@ function run(model) {
     };
 }
 
-const policies = [
-    {}, // the defaults: hybrid + pseudocost
-    { nodeSelection: "depth-first" },
-    { nodeSelection: "best-first" },
-    { branching: "most-fractional" },
-    { nodeSelection: "depth-first", branching: "most-fractional" },
-];
+// node tests/golden/gen_golden_incremental.js            -> incremental.json.gz (options.useIncremental = true)
+// node tests/golden/gen_golden_incremental.js enhanced   -> enhanced.json.gz (options.nodeSelection / branching alone:
+//                                                           src/tableau/enhanced-branch-and-cut.ts, src/main.ts:74-80)
+const enhanced = process.argv[2] === "enhanced";
+const policies = enhanced
+    ? [
+        { nodeSelection: "hybrid" }, // + the default branching of that service: pseudocost
+        { nodeSelection: "depth-first" },
+        { nodeSelection: "best-first" },
+        { branching: "most-fractional" },
+        { branching: "strong" },
+        { nodeSelection: "best-first", branching: "strong" },
+        { nodeSelection: "depth-first", branching: "most-fractional" },
+    ]
+    : [
+        {}, // the defaults: hybrid + pseudocost
+        { nodeSelection: "depth-first" },
+        { nodeSelection: "best-first" },
+        { branching: "most-fractional" },
+        { nodeSelection: "depth-first", branching: "most-fractional" },
+    ];
 
 const cases = [];
 for (const dir of ["fixtures", "synthetic"]) {
@@ -96,7 +110,7 @@ for (const dir of ["fixtures", "synthetic"]) {
         if (g.tableau.useMIRCuts) continue;
         for (const pol of policies) {
             const model = JSON.parse(JSON.stringify(g.model));
-            model.options = Object.assign({}, model.options || {}, pol, { useIncremental: true });
+            model.options = Object.assign({}, model.options || {}, pol, enhanced ? {} : { useIncremental: true });
             const out = run(model);
             out.file = dir + "/" + f;
             out.options = model.options;
@@ -107,5 +121,5 @@ for (const dir of ["fixtures", "synthetic"]) {
         }
     }
 }
-fs.writeFileSync(path.join(__dirname, "incremental.json.gz"), zlib.gzipSync(Buffer.from(JSON.stringify(cases)), { level: 9 }));
+fs.writeFileSync(path.join(__dirname, enhanced ? "enhanced.json.gz" : "incremental.json.gz"), zlib.gzipSync(Buffer.from(JSON.stringify(cases)), { level: 9 }));
 console.log(cases.length, "cases");
