@@ -1,4 +1,4 @@
-"""630 reference runs on random small MILPs (the reference's own generators, seeds 100..129, seven service policies each;
+"""Reference runs on random models: 630 on small MILPs (the reference's own generators, seeds 100..129, seven service policies each;
 tests/golden/gen_golden_fuzz.js): the Python host + engine must take the same pivots in the same order, the same number
 of relaxations and return the same result object.  CPU: oracle engine; `-m gpu`: the HIP engine."""
 import gzip
@@ -11,9 +11,16 @@ import pytest
 import golden_util as G
 from jslpsolver_amd import Solve, UnsupportedModel, pivot_digest
 
-with gzip.open(os.path.join(G.GOLDEN, "fuzz_services.jsonl.gz"), "rt") as fh:
-    CASES = [json.loads(line) for line in fh]
-REPLAYABLE = [c for c in CASES if c["fixed"] == 0 and not c["infeasPre"]]  # the rest needs the reference's presolve pre-pass
+def _load(name):
+    with gzip.open(os.path.join(G.GOLDEN, name), "rt") as fh:
+        cases = [json.loads(line) for line in fh if line.startswith("{")]
+    return [c for c in cases if c["fixed"] == 0 and not c["infeasPre"]]  # the rest needs the reference's presolve pre-pass
+
+
+REPLAYABLE = _load("fuzz_services.jsonl.gz")
+# random models with soft constraints (weight / priority -> optional objectives), equalities, ranges, unrestricted
+# variables, a third of them with integers under three service policies (tests/golden/gen_golden_fuzz_soft.js)
+SOFT = _load("fuzz_soft.jsonl.gz")
 
 
 def replay(lib, cases):
@@ -23,7 +30,7 @@ def replay(lib, cases):
             out = Solve(c["model"], full=True, lib=lib)
         except UnsupportedModel:
             continue
-        where = (c["gen"], c["seed"], c["model"]["options"])
+        where = (c["gen"], c["seed"], c["model"].get("options"))
         assert len(out["pivots"]) == c["nPivots"], where
         assert pivot_digest(out["pivots"]) == c["digest"], where
         assert c["iter"] is None or out["iter"] == c["iter"], where
@@ -41,6 +48,15 @@ def test_fuzz_through_oracle_engine(oracle_lib):
     assert replay(oracle_lib, REPLAYABLE) > 500
 
 
+def test_soft_constraint_fuzz_through_oracle_engine(oracle_lib):
+    assert replay(oracle_lib, SOFT) > 300
+
+
 @pytest.mark.gpu
 def test_fuzz_on_gpu(hip_lib):
     assert replay(hip_lib, REPLAYABLE) > 500
+
+
+@pytest.mark.gpu
+def test_soft_constraint_fuzz_on_gpu(hip_lib):
+    assert replay(hip_lib, SOFT) > 300
