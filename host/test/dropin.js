@@ -166,6 +166,38 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
         if (bad.length) { fail += 1; console.log("FAIL speculative", f, bad.join("; ")); } else speculativeOk += 1;
     }
 }
+// random models (tests/golden/fuzz_*.jsonl.gz: the reference's generators under seven service policies; soft constraints,
+// equalities, ranges, unrestricted variables) through the reference host + binding, INCLUDING the ones the reference's
+// presolve touches: result object, pivot count / digest, relaxation count
+let fuzzOk = 0;
+if (!filter && dir.indexOf("fixtures") >= 0) {
+    uninstall();
+    uninstall = gpu.install(Tableau, { SlackVariable, solver });
+    for (const name of ["fuzz_services.jsonl.gz", "fuzz_soft.jsonl.gz"]) {
+        const file = path.join(root, "tests", "golden", name);
+        if (!fs.existsSync(file)) continue;
+        for (const line of zlib.gunzipSync(fs.readFileSync(file)).toString().split("\n")) {
+            if (!line.startsWith("{")) continue;
+            const c = JSON.parse(line);
+            const solution = solver.Solve(JSON.parse(JSON.stringify(c.model)), undefined, true);
+            const res = solver.buildSimplifiedResult(solution);
+            const got = {};
+            for (const k of Object.keys(res)) got[k] = num(res[k]);
+            const bad = [];
+            if (JSON.stringify(Object.keys(res)) !== JSON.stringify(c.keys)) bad.push("keys");
+            if (JSON.stringify(got) !== JSON.stringify(c.result)) bad.push("values");
+            const trace = solution._tableau ? gpu.pivotTrace(solution._tableau) : null;
+            if (trace) {
+                if (trace.length / 2 !== c.nPivots) bad.push("pivot count " + trace.length / 2 + " != " + c.nPivots);
+                else if (digest(trace) !== c.digest) bad.push("pivot digest");
+                if (c.iter !== null && solution._tableau.branchAndCutIterations !== undefined && solution._tableau.branchAndCutIterations !== c.iter) bad.push("B&B iterations");
+                gpu.release(solution._tableau);
+            }
+            if (bad.length) { fail += 1; console.log("FAIL fuzz", name, c.gen, c.seed, JSON.stringify(c.model.options || {}), bad.join("; ")); }
+            else fuzzOk += 1;
+        }
+    }
+}
 // install(..., { minCells }): a host policy that leaves small tableaus on the reference's own path -- also under the injected services
 let policyOk = 0;
 if (!filter && dir.indexOf("fixtures") >= 0) {
@@ -189,5 +221,5 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
 }
 console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk,
     incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk,
-    size_policy_ok: policyOk }));
+    size_policy_ok: policyOk, fuzz_ok: fuzzOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);

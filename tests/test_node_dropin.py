@@ -53,6 +53,7 @@ def test_reference_host_with_oracle_engine(oracle_lib):
     assert r["mir_ok"] >= 60  # options.useMIRCuts under the default, enhanced and incremental services
     assert r["speculative_ok"] >= 12  # install(..., {speculate: 16}): same results and relaxation counts as the sequential run
     assert r["size_policy_ok"] == 8  # install(..., {minCells}): small tableaus stay on the reference's own path
+    assert r["fuzz_ok"] >= 1000  # random MILPs / soft-constraint models incl. the ones the reference's presolve touches
     r = _run(oracle_lib.path, "synthetic", "40x")
     assert r["fail"] == 0 and r["pass"] >= 12
 
@@ -64,6 +65,6 @@ def test_reference_host_with_hip_engine(hip_lib):
     assert r["backend"] == "hip-gfx950" and r["fail"] == 0 and r["pass"] == 47 and r["solved_on_engine"] >= 43
     assert r["strategy_variants_ok"] == 30
     assert r["incremental_ok"] >= 100 and r["device_checkpoints"] > 300
-    assert r["mir_ok"] >= 60 and r["speculative_ok"] >= 12
+    assert r["mir_ok"] >= 60 and r["speculative_ok"] >= 12 and r["fuzz_ok"] >= 1000
     r = _run(hip_lib.path, "synthetic", "_")
     assert r["fail"] == 0 and r["pass"] >= 40
