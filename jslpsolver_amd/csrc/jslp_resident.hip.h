@@ -626,8 +626,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
 #endif
     const Ctx& c = f.c;
     const int tid = threadIdx.x, b = blockIdx.x;
-    const int ld = c.ld, W = c.W, H = f.H;
-    const double precision = c.precision;
+    const int ld = c.ld, H = f.H;
     const int c0 = tid * CPT;
     const bool colok = c0 < ld;
     const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
