@@ -204,6 +204,76 @@ int jslp_engine_relax_from(jslp_engine* e, int32_t checkpoint, int32_t n_nodes, 
                            const int8_t* type, const int32_t* var_index, const double* value, int check_cycles,
                            jslp_simplex_result* out, double* rhs, int32_t* var_index_by_row, int32_t out_stride);
 
+/*
+ * Host-side build straight into pinned memory (model.ts:278-419 + tableau.ts:319-380 write the dense
+ * tableau cell by cell).  host_matrix hands the host a zero-filled height x width fp64 buffer in pinned (DMA-able) memory
+ * owned by the engine -- the binding makes it the `Float64Array` behind `tableau.matrix` before _resetMatrix runs
+ * (tableau.ts:304 allocates that array; a fresh Float64Array is zero-filled, so is this buffer on every call).  Passing
+ * that very pointer to jslp_engine_upload() turns the upload into one DMA from pinned memory (no pageable staging copy).
+ * The buffer stays valid until destroy(); *n_doubles receives height * width.
+ */
+int jslp_engine_host_matrix(jslp_engine* e, double** matrix, int64_t* n_doubles);
+
+/*
+ * Compact read-back for the branch-and-bound tree.  Between relaxations the host reads only the integer variables
+ * (isIntegral / getMostFractionalVar, mip-utils.ts:43-61, 100-126: `rowByVarIndex[v]` then `matrix[row * width + rhsColumn]`).
+ * set_watched_variables lists those variable indexes once; relax_watched = jslp_engine_relax whose read-back is, per
+ * watched variable i, watched_row[i] (rowByVarIndex, -1 when not basic) and watched_value[i] (its RHS cell; 0 when not
+ * basic) -- n_watched x 12 bytes instead of height x 12.  jslp_engine_read_rhs completes the picture when the tree is done.
+ */
+int jslp_engine_set_watched_variables(jslp_engine* e, const int32_t* var_indexes, int32_t n);
+int jslp_engine_relax_watched(jslp_engine* e, int32_t n_cuts, const int8_t* type, const int32_t* var_index,
+                              const double* value, int check_cycles, jslp_simplex_result* out, int32_t* watched_row,
+                              double* watched_value);
+
+/*
+ * Work counters (bench.py's roofline of the relaxation path): what the calls since the last reset really had
+ * to touch, counted by the kernels themselves when counting is on (off by default: it costs a reduction per pivot).
+ * gated_cells = sum over pivots of (rows passing the reference's gate |A[r,c*]| > 1e-16, simplex.ts:370-375) x (columns of
+ * the normalised pivot row that are non-zero, plus c*): the cells simplex.ts:376-387 reads and writes.
+ */
+typedef struct jslp_work_counters {
+    int64_t relaxations;    /* restore + addCutConstraints + simplex units (relax / relax_batch / relax_from nodes)   */
+    int64_t simplex_calls;  /* all simplex() runs, including plain jslp_engine_simplex                                */
+    int64_t pivots;
+    int64_t gated_cells;
+    int64_t gated_rows;     /* sum over pivots of the rows passing the gate                                          */
+    int64_t restored_rows;  /* rows copied back from the saved root / a checkpoint by restore()                      */
+    int64_t cut_rows;       /* rows appended by addCutConstraints                                                    */
+    int64_t height_sum;     /* sum over simplex calls of the tableau height (selection traffic = 8 x (W + 2H) per pivot) */
+} jslp_work_counters;
+int jslp_engine_set_counting(jslp_engine* e, int enabled); /* also resets the counters */
+int jslp_engine_get_counters(jslp_engine* e, jslp_work_counters* out);
+
+/*
+ * Device pool: branch-and-bound shards at node granularity -- every relaxation is a pure function of the
+ * saved root and its cut list (branch-and-cut.ts:33-37) -- so a pool is `primary` (the engine behind the host's Tableau)
+ * plus one engine per further entry of devices[], each holding a copy of the primary's saved root.  devices[0] must be the
+ * primary's device; an ordinal may repeat ("virtual devices": several engines, streams and host threads on one GPU).
+ * sync_root fans the saved root out to every member (hipMemcpyPeerAsync over xGMI: the snapshot, its index maps, the
+ * unrestricted / integer flags and the optional objectives; 6.9 - 22.6 MB for BASELINE.json's configs); relax_batch does
+ * it by itself when the primary's root changed since the last fan-out.  relax_batch = jslp_engine_relax_batch with the
+ * nodes split into one contiguous range per member, every member driven by its own host thread and stream, outcomes
+ * landing in ONE pinned buffer (the _pinned variant hands that buffer out, valid until the next call on the pool).
+ * The caller stays single-threaded and synchronous: the threads live inside the pool.  The primary's
+ * live tableau is left holding the last node of ITS range.  destroy() frees the members it created, never the primary.
+ */
+typedef struct jslp_pool jslp_pool;
+int jslp_pool_create(jslp_pool** out, jslp_engine* primary, const int32_t* devices, int32_t n_devices);
+void jslp_pool_destroy(jslp_pool* p);
+int jslp_pool_size(const jslp_pool* p);
+int jslp_pool_sync_root(jslp_pool* p);
+int jslp_pool_relax_batch(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                          const int32_t* var_index, const double* value, int check_cycles, jslp_simplex_result* out,
+                          double* rhs, int32_t* var_index_by_row, int32_t out_stride);
+int jslp_pool_relax_batch_pinned(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                 const int32_t* var_index, const double* value, int check_cycles,
+                                 jslp_simplex_result* out, const double** rhs, const int32_t** var_index_by_row,
+                                 int32_t* out_stride);
+/* Counters of all members added up (see jslp_work_counters); set_counting applies to every member. */
+int jslp_pool_set_counting(jslp_pool* p, int enabled);
+int jslp_pool_get_counters(jslp_pool* p, jslp_work_counters* out);
+
 /* Current dimensions (height grows with cuts, restore() puts it back). */
 int jslp_engine_dims(const jslp_engine* e, int32_t* height, int32_t* width, int32_t* n_var_indexes);
 
@@ -222,6 +292,8 @@ int jslp_engine_download(jslp_engine* e, double* matrix, int32_t* var_index_by_r
  * Diagnostics used by the parity tests: the (row, col) arguments of every pivot() since the last upload
  * in order.  Returns the total count in *n_pivots and copies at most max_pairs pairs into row_col
  * (interleaved r0,c0,r1,c1,...).  The FNV-1a digest of SURVEY.md Appendix C is computed by the caller.
+ * The trace holds 2^20 pivots; asking for the pairs of a longer run fails with JSLP_ERR_CAPACITY (the count is still
+ * returned) instead of handing out a truncated trace.
  */
 int jslp_engine_pivot_trace(jslp_engine* e, int32_t* row_col, int64_t max_pairs, int64_t* n_pivots);
 

@@ -42,6 +42,16 @@ class SimplexResult(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class WorkCounters(C.Structure):
+    """struct jslp_work_counters (include/jslp_engine.h)"""
+
+    _fields_ = [(name, C.c_int64) for name in ("relaxations", "simplex_calls", "pivots", "gated_cells", "gated_rows",
+                                              "restored_rows", "cut_rows", "height_sum")]
+
+    def as_dict(self):
+        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
 _P = C.POINTER
 _i32p = _P(C.c_int32)
 _f64p = _P(C.c_double)
@@ -77,6 +87,21 @@ SYMBOLS = {
     "jslp_engine_checkpoint_release": (C.c_int, [C.c_void_p, C.c_int32]),
     "jslp_engine_relax_from": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i8p, _i32p, _f64p, C.c_int,
                                          _P(SimplexResult), _f64p, _i32p, C.c_int32]),
+    "jslp_engine_host_matrix": (C.c_int, [C.c_void_p, _P(_f64p), _P(C.c_int64)]),
+    "jslp_engine_set_watched_variables": (C.c_int, [C.c_void_p, _i32p, C.c_int32]),
+    "jslp_engine_relax_watched": (C.c_int, [C.c_void_p, C.c_int32, _i8p, _i32p, _f64p, C.c_int, _P(SimplexResult), _i32p, _f64p]),
+    "jslp_engine_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
+    "jslp_engine_get_counters": (C.c_int, [C.c_void_p, _P(WorkCounters)]),
+    "jslp_pool_create": (C.c_int, [_P(C.c_void_p), C.c_void_p, _i32p, C.c_int32]),
+    "jslp_pool_destroy": (None, [C.c_void_p]),
+    "jslp_pool_size": (C.c_int, [C.c_void_p]),
+    "jslp_pool_sync_root": (C.c_int, [C.c_void_p]),
+    "jslp_pool_relax_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p, _i32p, _f64p, C.c_int,
+                                        _P(SimplexResult), _f64p, _i32p, C.c_int32]),
+    "jslp_pool_relax_batch_pinned": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p, _i32p, _f64p, C.c_int,
+                                               _P(SimplexResult), _P(_f64p), _P(_i32p), _i32p]),
+    "jslp_pool_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
+    "jslp_pool_get_counters": (C.c_int, [C.c_void_p, _P(WorkCounters)]),
     "jslp_engine_dims": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p]),
     "jslp_engine_read_rhs": (C.c_int, [C.c_void_p, _f64p, _i32p]),
     "jslp_engine_download": (C.c_int, [C.c_void_p, _f64p, _i32p, _i32p, _i32p, _i32p]),

@@ -33,6 +33,7 @@ struct Ctx {
     int32_t stop_at_phase2;  // hand phase 2 to the fused pipeline instead of continuing here
     int32_t has_unr;         // any unrestricted variable at all (else the per-column map lookups are skipped)
     real_t precision;
+    cnt_t* cnt;              // work counters (nullptr = counting off)
 };
 
 // Base pointers + per-slot strides: slot s of a batch owns the s-th tableau copy.
@@ -56,6 +57,9 @@ struct Slots {
     int32_t batch, use_partial;
     int32_t has_unr;
     real_t precision;
+    cnt_t* cnt;              // see Ctx::cnt
+    const int32_t* watch;    // watched variable indexes (compact read-back), n_watch entries
+    int32_t n_watch;
 };
 
 __device__ __forceinline__ Ctx slot_ctx(const Slots& s, int slot, int check_cycles) {
@@ -85,6 +89,7 @@ __device__ __forceinline__ Ctx slot_ctx(const Slots& s, int slot, int check_cycl
     c.stop_at_phase2 = 0;
     c.has_unr = s.has_unr;
     c.precision = s.precision;
+    c.cnt = s.cnt;
     return c;
 }
 
@@ -182,7 +187,7 @@ __device__ __forceinline__ void prepare_pivot(const Ctx& c, int pr, int pc, bool
     const int tid = threadIdx.x, nt = blockDim.x;
     real_t* A = c.A;
     const real_t quot = A[(long long)pr * ld + pc];  // simplex.ts:335
-    int any = 0;
+    int any = 0, n_gated = 0;
     for (int r = tid; r < H; r += nt) {
         real_t k;
         if (pcol_ready && r > 0) {
@@ -191,11 +196,14 @@ __device__ __forceinline__ void prepare_pivot(const Ctx& c, int pr, int pc, bool
             k = A[(long long)r * ld + pc];
             c.pcol[r] = k;
         }
-        any |= (r != pr && nonzero16(k));
+        const int gated = (r != pr && nonzero16(k));
+        any |= gated;
+        n_gated += gated;
     }
     // any row that will execute the inner loop of simplex.ts:367-391 lazily zeroes the tiny pivot-row entries
     const int anyrow = __syncthreads_or(any);  // also orders the quot read above against the row write below
     real_t* prow_A = A + (long long)pr * ld;
+    int n_cols = 0;
     for (int col = tid; col < ld; col += nt) {
         real_t v = 0.0;
         if (col < W) {
@@ -207,8 +215,21 @@ __device__ __forceinline__ void prepare_pivot(const Ctx& c, int pr, int pc, bool
             if (in_list && anyrow && !nonzero16(v) && v != 0.0) v = 0.0;  // :381-383
             prow_A[col] = v;
             if (col == 0 && c.rhs) c.rhs[pr] = v;
+            n_cols += (nonzero16(v) || col == pc) ? 1 : 0;
         }
         c.prow[col] = v;
+    }
+    if (c.cnt) {  // work counters (uniform branch): cells simplex.ts:376-387 touches = gated rows x live pivot-row columns
+        __syncthreads();  // sm.flag / sm.flag2 are free here
+        if (tid == 0) { sm.flag = 0; sm.flag2 = 0; }
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) { n_gated += __shfl_down(n_gated, off, 64); n_cols += __shfl_down(n_cols, off, 64); }
+        if ((tid & 63) == 0) { atomicAdd(&sm.flag, n_gated); atomicAdd(&sm.flag2, n_cols); }
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(c.cnt + CNT_CELLS, (cnt_t)sm.flag * (cnt_t)sm.flag2);
+            atomicAdd(c.cnt + CNT_ROWS, (cnt_t)sm.flag);
+        }
     }
     // optional objectives (simplex.ts:394-412): same elimination with exact `!== 0` tests, on the final pivot row
     for (int o = 0; o < c.n_opt; o++) {

@@ -17,7 +17,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 static thread_local char g_err[512];
@@ -68,6 +71,27 @@ struct jslp_engine {
     double* h_rhs = nullptr; int32_t* h_rows = nullptr; DevState* h_states = nullptr;
     size_t out_bytes_cap = 0;
     DevState* h_state = nullptr;  // pinned, 1 entry
+    // upload staging (pinned): [matrix, row stride W | vibr | vibc | unrestricted list]; the matrix part is what
+    // jslp_engine_host_matrix hands to the host to build the tableau in; d_up = device twin of the blob
+    // (and of the matrix when it needs the W -> ld repack)
+    char* h_up = nullptr; size_t h_up_bytes = 0;
+    char* d_up = nullptr; size_t d_up_bytes = 0;
+    int host_matrix_out = 0;  // the host holds a pointer into h_up
+    // the one-call-only redirection of the read-back (device pool: every member copies straight into the pool's buffer)
+    DevState* ext_states = nullptr; double* ext_rhs = nullptr; int32_t* ext_rows = nullptr;
+    // compact read-back (jslp_engine_relax_watched)
+    int32_t* d_watch = nullptr; int32_t n_watch = 0;
+    // work counters
+    int counting = 0;
+    cnt_t* d_cnt = nullptr;
+    jslp_work_counters wc{};
+    // snapshot generation as the device pool sees it: bumped by save() and upload()
+    unsigned long long root_seq = 0;
+    // safety net of the register-resident kernel: copy of slot 0 taken before the cooperative launch
+    char* r_backup = nullptr; DevState* r_backup_st = nullptr;
+    double* rb_A = nullptr; int32_t *rb_vibr = nullptr, *rb_vibc = nullptr, *rb_rbv = nullptr, *rb_cbv = nullptr;
+    unsigned spin_limit = 0; int test_abort_epoch = -1;
+    int resident_fallbacks = 0;  // solves that were rolled back and re-run through the streaming kernels
     // checkpoints (incremental-branch-and-cut.ts:31-44): equally sized device buffers, recycled through a free list
     struct Ckpt {
         char* mem = nullptr;
@@ -145,6 +169,7 @@ extern "C" int jslp_device_count(void) {
 }
 
 static int32_t round_up(int32_t x, int32_t m) { return (x + m - 1) / m * m; }
+static dim3 copy_grid(const jslp_engine* e, int slots);
 
 struct Carver {  // hands out 256-byte aligned pieces of one allocation; first pass (base == nullptr) just sizes it
     char* base;
@@ -172,6 +197,7 @@ struct PooledRes {
     char* slot_arena = nullptr; size_t slot_bytes = 0;
     char* d_cuts = nullptr; char* h_cuts = nullptr; size_t cuts_bytes = 0;  // staging of the cut lists
     char* d_out = nullptr; char* h_out = nullptr; size_t out_bytes = 0;     // read-back staging
+    char* h_up = nullptr; size_t h_up_bytes = 0; char* d_up = nullptr; size_t d_up_bytes = 0;  // upload staging
 };
 static std::mutex g_pool_mu;
 static std::vector<PooledRes> g_pool;
@@ -195,7 +221,8 @@ static bool pool_take(int device, PooledRes* out) {
     return false;
 }
 static bool pool_give(const PooledRes& r) {
-    if (!pool_enabled() || r.static_bytes > POOL_MAX_ARENA || r.slot_bytes > POOL_MAX_ARENA || r.out_bytes > POOL_MAX_ARENA / 4)
+    if (!pool_enabled() || r.static_bytes > POOL_MAX_ARENA || r.slot_bytes > POOL_MAX_ARENA || r.out_bytes > POOL_MAX_ARENA / 4 ||
+        r.h_up_bytes > POOL_MAX_ARENA / 4)
         return false;
     std::lock_guard<std::mutex> lk(g_pool_mu);
     if (g_pool.size() >= POOL_MAX_ENTRIES) return false;
@@ -214,6 +241,8 @@ extern "C" void jslp_release_pooled_resources(void) {
         hipFree(r.static_arena); hipFree(r.slot_arena); hipFree(r.d_cuts); hipFree(r.d_out);
         if (r.h_cuts) hipHostFree(r.h_cuts);
         if (r.h_out) hipHostFree(r.h_out);
+        if (r.h_up) hipHostFree(r.h_up);
+        hipFree(r.d_up);
         if (r.h_state) hipHostFree(r.h_state);
         if (r.ev_begin) hipEventDestroy(r.ev_begin);
         if (r.ev_end) hipEventDestroy(r.ev_end);
@@ -350,6 +379,10 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     if (nk && nk[0] == '1') e->one_launch_nodes = 0;
     const char* nt = getenv("JSLP_NT");
     e->nt = (nt && nt[0] == '1') ? 1 : 0;
+    const char* sl = getenv("JSLP_SPIN_LIMIT");  // polls before a hand-off of the resident kernel gives up (tests shorten it)
+    e->spin_limit = sl ? (unsigned)std::max(1LL, atoll(sl)) : JSLP_SPIN_LIMIT_DEFAULT;
+    const char* ta = getenv("JSLP_TEST_RESIDENT_ABORT");  // tests only: abort the resident kernel's hand-off at this pivot
+    e->test_abort_epoch = ta ? atoi(ta) : -1;
     int rc = JSLP_OK;
     PooledRes pooled;
     const bool have = pool_take(device, &pooled);
@@ -359,6 +392,7 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
             e->spare_slot_arena = pooled.slot_arena; e->spare_slot_bytes = pooled.slot_bytes;
             e->d_cuts = pooled.d_cuts; e->h_cuts = pooled.h_cuts; e->cuts_bytes = pooled.cuts_bytes;
             e->d_out = pooled.d_out; e->h_out = pooled.h_out; e->out_bytes_cap = pooled.out_bytes;
+            e->h_up = pooled.h_up; e->h_up_bytes = pooled.h_up_bytes; e->d_up = pooled.d_up; e->d_up_bytes = pooled.d_up_bytes;
         } else {
             HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         }
@@ -419,13 +453,16 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
         r.slot_arena = e->slot_arena; r.slot_bytes = e->slot_bytes;
         r.d_cuts = e->d_cuts; r.h_cuts = e->h_cuts; r.cuts_bytes = e->cuts_bytes;
         r.d_out = e->d_out; r.h_out = e->h_out; r.out_bytes = e->out_bytes_cap;
+        r.h_up = e->h_up; r.h_up_bytes = e->h_up_bytes; r.d_up = e->d_up; r.d_up_bytes = e->d_up_bytes;
         parked = pool_give(r);
     }
     free_slots(e, parked);
     if (parked) {
         e->static_arena = nullptr; e->h_state = nullptr; e->ev_begin = e->ev_end = nullptr; e->stream = nullptr;
-        e->d_cuts = e->h_cuts = nullptr; e->d_out = e->h_out = nullptr;
+        e->d_cuts = e->h_cuts = nullptr; e->d_out = e->h_out = nullptr; e->h_up = e->d_up = nullptr;
     }
+    if (e->h_up) hipHostFree(e->h_up);
+    hipFree(e->d_up); hipFree(e->d_watch); hipFree(e->d_cnt); hipFree(e->r_backup);
     hipFree(e->static_arena); hipFree(e->snap_oo);
     drop_checkpoints(e, 1);
     hipFree(e->arena32);
@@ -444,55 +481,94 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     delete e;
 }
 
+// upload staging: pinned [matrix H0 x W | vibr | vibc | unrestricted list] and its device twin
+static size_t up_matrix_bytes(const jslp_engine* e) { return ((sizeof(double) * (size_t)e->H0 * e->W) + 255) & ~(size_t)255; }
+static size_t up_blob_bytes(const jslp_engine* e) { return sizeof(int32_t) * ((size_t)e->H0 + e->W + e->n_idx); }
+static int ensure_up(jslp_engine* e) {
+    const size_t total = up_matrix_bytes(e) + up_blob_bytes(e);
+    if (e->h_up_bytes < total) {
+        if (e->h_up) hipHostFree(e->h_up);
+        e->h_up = nullptr; e->h_up_bytes = 0;
+        HIPC(hipHostMalloc(&e->h_up, total));
+        e->h_up_bytes = total;
+    }
+    if (e->d_up_bytes < total) {
+        hipFree(e->d_up);
+        e->d_up = nullptr; e->d_up_bytes = 0;
+        HIPC(hipMalloc(&e->d_up, total));
+        e->d_up_bytes = total;
+    }
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_host_matrix(jslp_engine* e, double** matrix, int64_t* n_doubles) {
+    if (!e || !matrix) return fail(JSLP_ERR_ARG, "host_matrix: null pointer");
+    HIPC(hipSetDevice(e->device));
+    int rc = ensure_up(e);
+    if (rc) return rc;
+    memset(e->h_up, 0, sizeof(double) * (size_t)e->H0 * e->W);  // a fresh Float64Array is zero-filled (tableau.ts:304)
+    e->host_matrix_out = 1;
+    *matrix = reinterpret_cast<double*>(e->h_up);
+    if (n_doubles) *n_doubles = (int64_t)e->H0 * e->W;
+    return JSLP_OK;
+}
+
 extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const int32_t* var_index_by_row,
                                   const int32_t* var_index_by_col, const int32_t* unrestricted_var_indexes,
                                   int32_t n_unrestricted) {
     if (!e || !matrix || !var_index_by_row || !var_index_by_col) return fail(JSLP_ERR_ARG, "upload: null pointer");
     if (n_unrestricted < 0 || (n_unrestricted > 0 && !unrestricted_var_indexes)) return fail(JSLP_ERR_ARG, "upload: bad unrestricted list");
+    if (n_unrestricted > e->n_idx) return fail(JSLP_ERR_ARG, "upload: more unrestricted variables than variable indexes");
     HIPC(hipSetDevice(e->device));
     const int32_t H = e->H0, W = e->W;
-    std::vector<int32_t> rbv(e->n_idx, -1), cbv(e->n_idx, -1), vibr(e->cap_rows, -1), vibc(W, -1);
-    std::vector<uint8_t> unr(e->n_idx, 0);
+    int rc = ensure_up(e);
+    if (rc) return rc;
+    // everything crosses PCIe from pinned memory: the matrix as ONE DMA (straight from the buffer the host built it in when
+    // it used jslp_engine_host_matrix), the maps as one small blob; the inverse maps, flags and state are built on the device
+    const size_t mat = sizeof(double) * (size_t)H * W, mat_pad = up_matrix_bytes(e);
+    int32_t* b_vibr = reinterpret_cast<int32_t*>(e->h_up + mat_pad);
+    int32_t* b_vibc = b_vibr + H;
+    int32_t* b_unr = b_vibc + W;
+    b_vibr[0] = -1; b_vibc[0] = -1;
     for (int32_t r = 1; r < H; r++) {
         const int32_t v = var_index_by_row[r];
         if (v < 0 || v >= e->n_idx) return fail(JSLP_ERR_ARG, "upload: row variable index out of range");
-        vibr[r] = v; rbv[v] = r;
+        b_vibr[r] = v;
     }
     for (int32_t c = 1; c < W; c++) {
         const int32_t v = var_index_by_col[c];
         if (v < 0 || v >= e->n_idx) return fail(JSLP_ERR_ARG, "upload: column variable index out of range");
-        vibc[c] = v; cbv[v] = c;
+        b_vibc[c] = v;
     }
     for (int32_t i = 0; i < n_unrestricted; i++) {
         const int32_t v = unrestricted_var_indexes[i];
         if (v < 0 || v >= e->n_idx) return fail(JSLP_ERR_ARG, "upload: unrestricted variable index out of range");
-        unr[v] = 1;
+        b_unr[i] = v;
     }
-    DevState st;
-    memset(&st, 0, sizeof st);
-    st.H = H;
-    st.last_element_index = W + H - 2;  // tableau.ts:312-316
-    st.status = ST_DONE;
-    st.phase = 1;
-    st.feasible = 1;
-    st.bounded = 1;
-    st.unbounded_var = -1;
-    st.gen = 0;
-    st.s_gen = 0;
+    if (matrix != reinterpret_cast<const double*>(e->h_up)) memcpy(e->h_up, matrix, mat);  // pageable caller memory: stage it once
     hipStream_t s = e->stream;
-    HIPC(hipMemsetAsync(e->s.A, 0, sizeof(double) * e->s.A_stride, s));
-    HIPC(hipMemcpy2DAsync(e->s.A, sizeof(double) * e->ld, matrix, sizeof(double) * W, sizeof(double) * W, H,
-                          hipMemcpyHostToDevice, s));
-    HIPC(hipMemcpyAsync(e->s.vibr, vibr.data(), sizeof(int32_t) * e->cap_rows, hipMemcpyHostToDevice, s));
-    HIPC(hipMemcpyAsync(e->s.vibc, vibc.data(), sizeof(int32_t) * W, hipMemcpyHostToDevice, s));
-    HIPC(hipMemcpyAsync(e->s.rbv, rbv.data(), sizeof(int32_t) * e->n_idx, hipMemcpyHostToDevice, s));
-    HIPC(hipMemcpyAsync(e->s.cbv, cbv.data(), sizeof(int32_t) * e->n_idx, hipMemcpyHostToDevice, s));
-    HIPC(hipMemcpyAsync(e->d_unr, unr.data(), e->n_idx, hipMemcpyHostToDevice, s));
-    HIPC(hipMemsetAsync(e->d_isint, 0, e->n_idx, s));
-    HIPC(hipMemcpyAsync(e->s.st, &st, sizeof st, hipMemcpyHostToDevice, s));
-    HIPC(hipStreamSynchronize(s));  // the host vectors die here
+    const size_t blob = sizeof(int32_t) * ((size_t)H + W + (size_t)n_unrestricted);
+    char* d_blob = e->d_up + mat_pad;
+    if (W == e->ld) {
+        HIPC(hipMemcpyAsync(e->s.A, e->h_up, mat, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(d_blob, e->h_up + mat_pad, blob, hipMemcpyHostToDevice, s));
+    } else {  // one DMA for matrix + blob, then the W -> ld repack on the device (padding columns become 0)
+        HIPC(hipMemcpyAsync(e->d_up, e->h_up, mat_pad + blob, hipMemcpyHostToDevice, s));
+        const long long cells = (long long)H * e->ld;
+        hipLaunchKernelGGL(k_repack, dim3((unsigned)std::min<long long>(2048, (cells + 255) / 256)), dim3(256), 0, s, e->s.A,
+                           reinterpret_cast<const double*>(e->d_up), (int)H, (int)W, (int)e->ld);
+    }
+    UploadBlob ub;
+    ub.vibr = reinterpret_cast<const int32_t*>(d_blob);
+    ub.vibc = ub.vibr + H;
+    ub.unr = ub.vibc + W;
+    ub.H = H; ub.n_unr = n_unrestricted; ub.n_idx = e->n_idx; ub.cap_rows = e->cap_rows;
+    hipLaunchKernelGGL(k_upload_finish, dim3(1), dim3(1024), 0, s, e->s, ub, e->d_unr, e->d_isint);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(s));  // the staging buffer (and the host's view of it) is free again
     e->uploaded = 1;
     e->has_save = 0;
+    e->root_seq += 1;
     e->slot0_synced = 0;
     e->slots_synced = 0;
     drop_checkpoints(e, 0);
@@ -546,6 +622,7 @@ static Ctx host_ctx(const jslp_engine* e, int check_cycles) {
     c.trace = e->s.trace; c.trace_cap = e->s.trace_cap; c.ld = e->ld; c.W = e->W; c.check_cycles = check_cycles;
     c.batch = e->batch; c.use_partial = e->use_partial; c.precision = e->precision; c.stop_at_phase2 = 0;
     c.has_unr = e->n_unr > 0 ? 1 : 0;
+    c.cnt = e->s.cnt;
     return c;
 }
 
@@ -577,6 +654,16 @@ static int ensure_resident(jslp_engine* e) {
     HIPC(hipMalloc(&e->r_gran, sizeof(u64_t) * (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32)));
     for (int i = 0; i < 2; i++) HIPC(hipMalloc(&e->r_rows[i], sizeof(u64_t) * (size_t)JSLP_F_MAXG * e->ld));
     HIPC(hipMalloc(&e->r_sync, sizeof(unsigned) * 16));
+    for (int pass = 0; pass < 2; pass++) {  // the safety net: a copy of slot 0 (matrix, maps, state)
+        Carver cv{pass ? e->r_backup : nullptr, 0};
+        e->rb_A = cv.take<double>((size_t)e->cap_rows * e->ld);
+        e->rb_vibr = cv.take<int32_t>((size_t)e->cap_rows);
+        e->rb_vibc = cv.take<int32_t>((size_t)e->W);
+        e->rb_rbv = cv.take<int32_t>((size_t)e->n_idx);
+        e->rb_cbv = cv.take<int32_t>((size_t)e->n_idx);
+        e->r_backup_st = cv.take<DevState>(1);
+        if (!pass) HIPC(hipMalloc(&e->r_backup, cv.off + 256));
+    }
     return JSLP_OK;
 }
 
@@ -674,6 +761,15 @@ static int ensure_events(jslp_engine* e, size_t n) {
     return JSLP_OK;
 }
 
+// host half of the work counters: one finished simplex() (a relaxation when it came with restore + cuts)
+static void account(jslp_engine* e, const DevState& st, int is_relaxation) {
+    if (!e->counting) return;
+    e->wc.simplex_calls += 1;
+    e->wc.relaxations += is_relaxation ? 1 : 0;
+    e->wc.pivots += (long long)st.it1 + st.it2;
+    e->wc.height_sum += st.H;
+}
+
 // simplex() of the live tableau (slot 0), leaving the final DevState in e->h_state
 static int run_simplex(jslp_engine* e, int check_cycles) {
     hipStream_t s = e->stream;
@@ -722,6 +818,8 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             rc.G = (H + rc.rpb - 1) / rc.rpb;
             rc.H = H;
             rc.iters_cap = cap;
+            rc.spin_limit = e->spin_limit;
+            rc.test_abort_epoch = e->test_abort_epoch;
             rc.dbg = nullptr;
 #ifdef JSLP_DEBUG_RESIDENT
             static u64_t* dbg_buf = nullptr;
@@ -730,6 +828,11 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             rc.dbg = dbg_buf;
 #endif
             HIPC(hipMemsetAsync(e->r_sync, 0, sizeof(unsigned) * 16, s));
+            // Safety net.  The kernel commits every pivot's index-map swap as it goes but writes the matrix back only in
+            // its epilogue, and a timed-out hand-off (workgroups not co-resident, a stalled GPU) skips that epilogue: keep a
+            // copy of slot 0 (one pass over the matrix, ~15 us at 2001 x 2001 against a ~100 ms solve) to roll back to.
+            SnapshotW bk{e->rb_A, e->rb_vibr, e->rb_vibc, e->rb_rbv, e->rb_cbv, e->n_idx, nullptr, nullptr};
+            hipLaunchKernelGGL(k_res_backup, dim3(copy_grid(e, 1).x), dim3(256), 0, s, e->s, bk, e->r_backup_st, H, 1);
             hipEvent_t k0 = nullptr, k1 = nullptr;
             if (e->timing) { r = ensure_events(e, 2); if (r) return r; k0 = e->ev_pool[0]; k1 = e->ev_pool[1]; HIPC(hipEventRecord(k0, s)); }
             void* args[] = {&rc};
@@ -753,8 +856,19 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                     if (hipEventElapsedTime(&ms, k0, k1) == hipSuccess) e->upd_ms += ms;
                     e->upd_launches += e->h_state->it1 + e->h_state->it2 - it_before;  // unit = one pivot (16*H*W algorithmic bytes)
                 }
+                if (e->h_state->err == ERR_BARRIER) {
+                    // roll slot 0 back to its state before the launch and solve through the streaming kernels instead
+                    hipLaunchKernelGGL(k_res_backup, dim3(copy_grid(e, 1).x), dim3(256), 0, s, e->s, bk, e->r_backup_st, H, 0);
+                    HIPC(hipGetLastError());
+                    e->resident_fallbacks += 1;
+                } else {
                 resident_done = true;
                 e->last_path = "resident";
+                if (e->counting) {  // a dense streaming update touches every cell: rows x columns per pivot
+                    const long long piv = (long long)e->h_state->it1 + e->h_state->it2;
+                    e->wc.gated_cells += piv * (long long)(H - 1) * e->W;
+                    e->wc.gated_rows += piv * (long long)(H - 1);
+                }
 #ifdef JSLP_DEBUG_RESIDENT
                 {   // phase timing + micro-costs of the debug build (tools/resident_phase_timing.py reads this file)
                     std::vector<u64_t> d(16384);
@@ -763,6 +877,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                     if (fb) { fwrite(d.data(), 8, 16384, fb); fclose(fb); }
                 }
 #endif
+                }  // !ERR_BARRIER
             } else {
                 (void)hipGetLastError();  // not co-resident on this device: use one launch per pivot instead
             }
@@ -842,6 +957,10 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             hipLaunchKernelGGL(k_fused_finish, dim3(512), dim3(256), 0, s, f, launch - 1);
             HIPC(hipGetLastError());
             HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+            if (e->counting) {  // the fused launches stream every cell (phase 1 went through k_select: counted on the device)
+                e->wc.gated_cells += (long long)e->h_state->it2 * (long long)(H - 1) * e->W;
+                e->wc.gated_rows += (long long)e->h_state->it2 * (long long)(H - 1);
+            }
         }
         }  // !resident_done
         HIPC(hipEventRecord(e->ev_end, s));
@@ -858,6 +977,7 @@ extern "C" int jslp_engine_simplex(jslp_engine* e, int check_cycles, jslp_simple
     HIPC(hipSetDevice(e->device));
     int rc = run_simplex(e, check_cycles);
     if (rc) return rc;
+    account(e, *e->h_state, 0);
     return fill_result(e, *e->h_state, 0, e->evaluation, out, &e->evaluation);
 }
 
@@ -896,6 +1016,7 @@ extern "C" int jslp_engine_save(jslp_engine* e) {
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(e->stream));
     e->has_save = 1;
+    e->root_seq += 1;
     return JSLP_OK;
 }
 
@@ -1011,12 +1132,15 @@ static int upload_cuts(jslp_engine* e, int32_t n_nodes, const int32_t* offs, con
     const size_t C = (size_t)offs[n_nodes], N1 = (size_t)n_nodes + 1;
     if (C > 0 && (!type || !var || !value)) return fail(JSLP_ERR_ARG, "cuts: null pointer");
     const size_t off_offs = 8 * C, off_var = off_offs + 4 * N1, off_type = off_var + 4 * C, total = off_type + C;
-    if (total > e->cuts_bytes) {
+    if (total > e->cuts_bytes) {  // grow: allocate the new pair first, swap only when both exist
+        const size_t bytes = std::max<size_t>(2 * total, 4096);
+        char* nd = nullptr; char* nh = nullptr;
+        if (hipMalloc(&nd, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(JSLP_ERR_NOMEM, "cuts: out of device memory"); }
+        if (hipHostMalloc(&nh, bytes) != hipSuccess) { (void)hipGetLastError(); hipFree(nd); return fail(JSLP_ERR_NOMEM, "cuts: out of pinned memory"); }
+        HIPC(hipStreamSynchronize(e->stream));  // nothing in flight may still read the old pair
         hipFree(e->d_cuts);
         if (e->h_cuts) hipHostFree(e->h_cuts);
-        e->cuts_bytes = std::max<size_t>(2 * total, 4096);
-        HIPC(hipMalloc(&e->d_cuts, e->cuts_bytes));
-        HIPC(hipHostMalloc(&e->h_cuts, e->cuts_bytes));
+        e->d_cuts = nd; e->h_cuts = nh; e->cuts_bytes = bytes;
     }
     if (C) memcpy(e->h_cuts, value, 8 * C);
     memcpy(e->h_cuts + off_offs, offs, 4 * N1);
@@ -1045,6 +1169,7 @@ extern "C" int jslp_engine_add_cuts(jslp_engine* e, int32_t n, const int8_t* typ
     const int32_t offs[2] = {0, n};
     int rc = upload_cuts(e, 1, offs, type, var_index, value);
     if (rc) return rc;
+    if (e->counting) e->wc.cut_rows += n;
     Cuts cu{e->d_cut_offs, e->d_cut_type, e->d_cut_var, e->d_cut_val};
     hipLaunchKernelGGL(k_add_cuts, dim3(1), dim3(256), 0, e->stream, e->s, cu, 0, 0, (int)e->cap_rows);
     HIPC(hipGetLastError());
@@ -1065,6 +1190,9 @@ static void out_layout(jslp_engine* e, size_t nodes) {
     e->h_states = reinterpret_cast<DevState*>(e->h_out);
     e->h_rhs = reinterpret_cast<double*>(e->h_out + o_rhs);
     e->h_rows = reinterpret_cast<int32_t*>(e->h_out + o_rows);
+    if (e->ext_states) {  // device pool: this call's outcomes go straight into the pool's pinned buffer
+        e->h_states = e->ext_states; e->h_rhs = e->ext_rhs; e->h_rows = e->ext_rows;
+    }
 }
 static int ensure_out(jslp_engine* e, size_t nodes) {
     if (out_bytes(e, nodes) > e->out_bytes_cap) {
@@ -1244,9 +1372,13 @@ extern "C" int jslp_engine_simplex_f32(jslp_engine* e, double precision, int che
 static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
                             const int32_t* var_index, const double* value, int check_cycles, jslp_simplex_result* out,
                             double* rhs, int32_t* var_index_by_row, int32_t out_stride, int pinned, int want_rhs,
-                            int want_rows, int checkpoint = -1) {
+                            int want_rows, int checkpoint = -1, int compact = 0) {
     if (!e || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "relax_batch: null pointer");
     if (!e->uploaded) return fail(JSLP_ERR_STATE, "relax before upload");
+    if (compact && (n_nodes != 1 || e->n_watch <= 0 || e->n_watch > e->cap_rows))
+        return fail(JSLP_ERR_ARG, "relax_watched: one node at a time, after set_watched_variables (at most row_capacity of them)");
+    // gather mode: >= 0 = the whole RHS column / row map with this row stride; < 0 = the watched variables only
+    const int g_stride = compact ? -e->n_watch : (int)e->cap_rows;
     if (checkpoint >= 0) {
         int rc0 = checkpoint_check(e, checkpoint, "relax_from");
         if (rc0) return rc0;
@@ -1263,7 +1395,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     int rc;
     // ---- ONE child of the saved root, slot 0 already in sync with the snapshot: one launch, one synchronisation ----------
     if (n_nodes == 1 && checkpoint < 0 && e->has_save && e->slot0_synced && !e->timing && e->force_path <= 1 &&
-        e->one_launch_nodes && cells <= wg_cells_child()) {
+        e->one_launch_nodes && cells <= wg_cells_child() && !e->ext_states) {
         rc = upload_cuts(e, 1, cut_offsets, type, var_index, value, false);
         if (rc) return rc;
         rc = ensure_out(e, 1);
@@ -1278,19 +1410,22 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs};
         e->last_path = "workgroup";
         hipLaunchKernelGGL((k_node_wg<JSLP_WG_THREADS, 4096>), dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, sn, cu, 0, check_cycles,
-                           cap, (int)e->cap_rows, o_rhs, o_rows, o_state, 0, 0);
+                           cap, (int)e->cap_rows, o_rhs, o_rows, o_state, compact ? g_stride : 0, 0);
         HIPC(hipGetLastError());
         HIPC(hipStreamSynchronize(s));
         const DevState st = e->h_states[0];
         rc = state_error(st);
         if (rc) { e->slot0_synced = 0; return rc; }
+        account(e, st, 1);
+        if (e->counting) e->wc.cut_rows += cut_offsets[1];
         double ev;
         rc = fill_result(e, st, 0, e->evaluation, &out[0], &ev);
         if (rc) return rc;
         e->evaluation = ev;
         if (!pinned) {
-            if (rhs) memcpy(rhs, e->h_rhs, sizeof(double) * st.H);
-            if (var_index_by_row) memcpy(var_index_by_row, e->h_rows, sizeof(int32_t) * st.H);
+            const size_t n_out = compact ? (size_t)e->n_watch : (size_t)st.H;
+            if (rhs) memcpy(rhs, e->h_rhs, sizeof(double) * n_out);
+            if (var_index_by_row) memcpy(var_index_by_row, e->h_rows, sizeof(int32_t) * n_out);
         }
         return JSLP_OK;
     }
@@ -1330,7 +1465,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
             e->last_path = "workgroup";
             hipLaunchKernelGGL((k_node_wg<512, 2048>), dim3(g), dim3(512), 0, s, e->s, sn, cu, first, check_cycles, cap,
                                (int)e->cap_rows, want_rhs ? e->d_rhs : nullptr, want_rows ? e->d_rows : nullptr, e->d_states,
-                               (int)e->cap_rows, first);
+                               g_stride, first);
             HIPC(hipGetLastError());
         } else {
         rc = enqueue_restore(e, 0, g, checkpoint);
@@ -1358,7 +1493,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
             if (rc) return rc;
         }
         hipLaunchKernelGGL(k_gather, dim3(g), dim3(256), 0, s, e->s, 0, want_rhs ? e->d_rhs : nullptr,
-                           want_rows ? e->d_rows : nullptr, e->d_states, (int)e->cap_rows, first);
+                           want_rows ? e->d_rows : nullptr, e->d_states, g_stride, first);
         HIPC(hipGetLastError());
         }  // !one_launch
         // this group's outcomes cross PCIe on the copy stream while the next group computes (the three regions of the
@@ -1380,10 +1515,12 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         float ms = 0;
         if (hipEventElapsedTime(&ms, e->ev_begin, e->ev_end) == hipSuccess) e->total_ms += ms;
     }
+    if (e->counting) e->wc.cut_rows += cut_offsets[n_nodes];
     for (int i = 0; i < n_nodes; i++) {
         DevState st = e->h_states[i];
         rc = state_error(st);
         if (rc) { e->slot0_synced = 0; e->slots_synced = 0; return rc; }
+        account(e, st, 1);
         if (st.cycle_phase && wg && n_nodes > group) {
             // the cycle message is rebuilt from the slot's history, which later groups have reused: report the hit
             // (flags are exact) without the [start, length] detail
@@ -1394,9 +1531,10 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         if (rc) return rc;
         if (i == n_nodes - 1) e->evaluation = ev;
         if (!pinned) {
-            if (rhs) memcpy(rhs + (size_t)i * out_stride, e->h_rhs + (size_t)i * e->cap_rows, sizeof(double) * st.H);
+            const size_t n_out = compact ? (size_t)e->n_watch : (size_t)st.H;
+            if (rhs) memcpy(rhs + (size_t)i * out_stride, e->h_rhs + (size_t)i * e->cap_rows, sizeof(double) * n_out);
             if (var_index_by_row)
-                memcpy(var_index_by_row + (size_t)i * out_stride, e->h_rows + (size_t)i * e->cap_rows, sizeof(int32_t) * st.H);
+                memcpy(var_index_by_row + (size_t)i * out_stride, e->h_rows + (size_t)i * e->cap_rows, sizeof(int32_t) * n_out);
         }
     }
     return JSLP_OK;
@@ -1442,6 +1580,347 @@ extern "C" int jslp_engine_relax(jslp_engine* e, int32_t n_cuts, const int8_t* t
                                    e->cap_rows);
 }
 
+// ---- compact read-back -----------------------------------------------------------------------------------------------
+extern "C" int jslp_engine_set_watched_variables(jslp_engine* e, const int32_t* var_indexes, int32_t n) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "set_watched_variables before upload");
+    if (n < 0 || (n > 0 && !var_indexes)) return fail(JSLP_ERR_ARG, "set_watched_variables: bad arguments");
+    for (int32_t i = 0; i < n; i++)
+        if (var_indexes[i] < 0 || var_indexes[i] >= e->n_idx) return fail(JSLP_ERR_ARG, "set_watched_variables: index out of range");
+    HIPC(hipSetDevice(e->device));
+    HIPC(hipStreamSynchronize(e->stream));
+    hipFree(e->d_watch);
+    e->d_watch = nullptr; e->n_watch = 0; e->s.watch = nullptr; e->s.n_watch = 0;
+    if (n > 0) {
+        HIPC(hipMalloc(&e->d_watch, sizeof(int32_t) * (size_t)n));
+        HIPC(hipMemcpy(e->d_watch, var_indexes, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+        e->n_watch = n; e->s.watch = e->d_watch; e->s.n_watch = n;
+    }
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_relax_watched(jslp_engine* e, int32_t n_cuts, const int8_t* type, const int32_t* var_index,
+                                         const double* value, int check_cycles, jslp_simplex_result* out,
+                                         int32_t* watched_row, double* watched_value) {
+    if (!e) return fail(JSLP_ERR_ARG, "relax_watched: null engine");
+    if (n_cuts < 0) return fail(JSLP_ERR_ARG, "relax_watched: negative cut count");
+    const int32_t offs[2] = {0, n_cuts};
+    return relax_batch_impl(e, 1, offs, type, var_index, value, check_cycles, out, watched_value, watched_row, e->cap_rows, 0,
+                            watched_value != nullptr, watched_row != nullptr, -1, 1);
+}
+
+// ---- work counters ---------------------------------------------------------------------------------------------------
+extern "C" int jslp_engine_set_counting(jslp_engine* e, int enabled) {
+    if (!e) return fail(JSLP_ERR_ARG, "set_counting: null engine");
+    HIPC(hipSetDevice(e->device));
+    HIPC(hipStreamSynchronize(e->stream));
+    if (!e->d_cnt) HIPC(hipMalloc(&e->d_cnt, sizeof(cnt_t) * CNT_N));
+    HIPC(hipMemset(e->d_cnt, 0, sizeof(cnt_t) * CNT_N));
+    e->counting = enabled ? 1 : 0;
+    e->s.cnt = enabled ? e->d_cnt : nullptr;
+    e->wc = jslp_work_counters{};
+    return JSLP_OK;
+}
+
+extern "C" int jslp_engine_get_counters(jslp_engine* e, jslp_work_counters* out) {
+    if (!e || !out) return fail(JSLP_ERR_ARG, "get_counters: null pointer");
+    *out = e->wc;
+    if (e->d_cnt) {
+        HIPC(hipSetDevice(e->device));
+        HIPC(hipStreamSynchronize(e->stream));
+        cnt_t c[CNT_N];
+        HIPC(hipMemcpy(c, e->d_cnt, sizeof c, hipMemcpyDeviceToHost));
+        out->gated_cells += (int64_t)c[CNT_CELLS];
+        out->gated_rows += (int64_t)c[CNT_ROWS];
+        out->restored_rows += (int64_t)c[CNT_RESTORED];
+    }
+    return JSLP_OK;
+}
+
+// ---- device pool -------------------------------------------------------------------------------------------
+// One host thread per additional member: the caller stays single-threaded and synchronous, the fan-out lives in here.
+struct PoolWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool pending = false, quit = false;
+    int rc = 0;
+    char err[512] = {0};
+    void loop() {
+        for (;;) {
+            std::function<int()> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return pending || quit; });
+                if (quit) return;
+                j = job;
+            }
+            g_err[0] = 0;
+            const int r = j();
+            std::lock_guard<std::mutex> lk(mu);
+            rc = r;
+            snprintf(err, sizeof err, "%s", g_err);
+            pending = false;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<int()> j) {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(j);
+        pending = true;
+        cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !pending; });
+        return rc;
+    }
+};
+
+struct jslp_pool {
+    std::vector<jslp_engine*> members;  // members[0] = the primary (not owned)
+    std::vector<PoolWorker*> workers;   // workers[i] drives members[i] (i >= 1); the primary runs on the calling thread
+    unsigned long long synced_seq = ~0ull;
+    int synced = 0;
+    char* h_out = nullptr; size_t h_out_bytes = 0;  // ONE pinned (portable) read-back buffer: [states | rhs | rows] for all nodes
+    std::vector<std::vector<int32_t>> offs;         // per member: its cut offsets rebased to 0
+};
+
+extern "C" int jslp_pool_size(const jslp_pool* p) { return p ? (int)p->members.size() : 0; }
+
+extern "C" void jslp_pool_destroy(jslp_pool* p) {
+    if (!p) return;
+    for (size_t i = 1; i < p->workers.size(); i++) {
+        PoolWorker* w = p->workers[i];
+        if (!w) continue;
+        w->wait();
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->quit = true;
+            w->cv.notify_all();
+        }
+        if (w->th.joinable()) w->th.join();
+        delete w;
+    }
+    for (size_t i = 1; i < p->members.size(); i++) jslp_engine_destroy(p->members[i]);
+    if (p->h_out) hipHostFree(p->h_out);
+    delete p;
+}
+
+extern "C" int jslp_pool_create(jslp_pool** out, jslp_engine* primary, const int32_t* devices, int32_t n_devices) {
+    if (!out || !primary || !devices || n_devices < 1) return fail(JSLP_ERR_ARG, "pool_create: bad arguments");
+    if (devices[0] != primary->device) return fail(JSLP_ERR_ARG, "pool_create: devices[0] must be the primary engine's device");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(JSLP_ERR_DEVICE, "pool_create: no HIP device visible");
+    for (int32_t i = 0; i < n_devices; i++)
+        if (devices[i] < 0 || devices[i] >= ndev) return fail(JSLP_ERR_ARG, "pool_create: device ordinal out of range");
+    jslp_pool* p = new jslp_pool();
+    p->members.push_back(primary);
+    p->workers.push_back(nullptr);
+    for (int32_t i = 1; i < n_devices; i++) {
+        jslp_engine* m = nullptr;
+        int rc = jslp_engine_create(&m, devices[i], primary->H0, primary->W, primary->cap_rows, primary->precision);
+        if (rc) { jslp_pool_destroy(p); return rc; }
+        p->members.push_back(m);
+        if (devices[i] != primary->device) {  // direct xGMI copies where the platform allows them (else staged by the runtime)
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], primary->device) == hipSuccess && can) {
+                hipSetDevice(devices[i]);
+                if (hipDeviceEnablePeerAccess(primary->device, 0) != hipSuccess) (void)hipGetLastError();
+            }
+            (void)hipGetLastError();
+        }
+        PoolWorker* w = new PoolWorker();
+        w->th = std::thread([w] { w->loop(); });
+        p->workers.push_back(w);
+    }
+    hipSetDevice(primary->device);
+    p->offs.resize(p->members.size());
+    *out = p;
+    return JSLP_OK;
+}
+
+// one member adopts the primary's saved root: peer copies of the snapshot + a state fix-up + restore()
+static int pool_adopt_root(jslp_engine* m, const jslp_engine* src, int s_H, int s_lei) {
+    HIPC(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    if (m->n_opt != src->n_opt) {  // optional objectives travel with the root (backup.ts:37-43)
+        HIPC(hipStreamSynchronize(s));
+        hipFree(m->s.oo); hipFree(m->snap_oo);
+        m->s.oo = nullptr; m->snap_oo = nullptr;
+        m->n_opt = src->n_opt; m->s.n_opt = src->n_opt; m->s.oo_stride = (long long)src->n_opt * m->ld;
+        if (src->n_opt > 0) {
+            const size_t per = (size_t)m->s.oo_stride;
+            HIPC(hipMalloc(&m->s.oo, sizeof(double) * per * std::max(1, m->n_slots)));
+            HIPC(hipMalloc(&m->snap_oo, sizeof(double) * per));
+            HIPC(hipMemsetAsync(m->s.oo, 0, sizeof(double) * per * std::max(1, m->n_slots), s));
+        }
+    }
+    const int sd = src->device, dd = m->device;
+    HIPC(hipMemcpyPeerAsync(m->snap_A, dd, src->snap_A, sd, sizeof(double) * (size_t)s_H * m->ld, s));
+    HIPC(hipMemcpyPeerAsync(m->snap_rhs, dd, src->snap_rhs, sd, sizeof(double) * (size_t)s_H, s));
+    HIPC(hipMemcpyPeerAsync(m->snap_vibr, dd, src->snap_vibr, sd, sizeof(int32_t) * (size_t)s_H, s));
+    HIPC(hipMemcpyPeerAsync(m->snap_vibc, dd, src->snap_vibc, sd, sizeof(int32_t) * (size_t)m->W, s));
+    HIPC(hipMemcpyPeerAsync(m->snap_rbv, dd, src->snap_rbv, sd, sizeof(int32_t) * (size_t)m->n_idx, s));
+    HIPC(hipMemcpyPeerAsync(m->snap_cbv, dd, src->snap_cbv, sd, sizeof(int32_t) * (size_t)m->n_idx, s));
+    HIPC(hipMemcpyPeerAsync(m->d_unr, dd, src->d_unr, sd, (size_t)m->n_idx, s));
+    HIPC(hipMemcpyPeerAsync(m->d_isint, dd, src->d_isint, sd, (size_t)m->n_idx, s));
+    if (src->n_opt > 0) HIPC(hipMemcpyPeerAsync(m->snap_oo, dd, src->snap_oo, sd, sizeof(double) * (size_t)m->s.oo_stride, s));
+    hipLaunchKernelGGL(k_adopt_root, dim3(1), dim3(1), 0, s, m->s, s_H, s_lei);
+    HIPC(hipGetLastError());
+    m->uploaded = 1;
+    m->has_save = 1;
+    m->root_seq += 1;
+    m->n_unr = src->n_unr;
+    m->s.has_unr = src->n_unr > 0 ? 1 : 0;
+    m->evaluation = src->evaluation;
+    m->slot0_synced = 0;
+    m->slots_synced = 0;
+    drop_checkpoints(m, 0);
+    int rc = enqueue_restore(m, 0, 1);  // the member's live tableau = the root
+    if (rc) return rc;
+    HIPC(hipStreamSynchronize(s));
+    return JSLP_OK;
+}
+
+static int pool_join(jslp_pool* p, int rc0) {  // wait for every worker; the first failure wins (its text becomes ours)
+    int rc = rc0;
+    for (size_t i = 1; i < p->workers.size(); i++) {
+        const int r = p->workers[i]->wait();
+        if (r && !rc) { rc = r; snprintf(g_err, sizeof g_err, "%s", p->workers[i]->err); }
+    }
+    return rc;
+}
+
+extern "C" int jslp_pool_sync_root(jslp_pool* p) {
+    if (!p) return fail(JSLP_ERR_ARG, "pool_sync_root: null pool");
+    jslp_engine* e = p->members[0];
+    if (!e->uploaded || !e->has_save) return fail(JSLP_ERR_STATE, "pool_sync_root: the primary has no saved root (save() first)");
+    HIPC(hipSetDevice(e->device));
+    HIPC(hipStreamSynchronize(e->stream));
+    DevState st;
+    HIPC(hipMemcpy(&st, e->s.st, sizeof st, hipMemcpyDeviceToHost));
+    const int s_H = st.s_H, s_lei = st.s_last_element_index;
+    for (size_t i = 1; i < p->members.size(); i++) {
+        jslp_engine* m = p->members[i];
+        p->workers[i]->submit([m, e, s_H, s_lei] { return pool_adopt_root(m, e, s_H, s_lei); });
+    }
+    int rc = pool_join(p, JSLP_OK);
+    hipSetDevice(e->device);
+    if (rc) return rc;
+    p->synced_seq = e->root_seq;
+    p->synced = 1;
+    return JSLP_OK;
+}
+
+static int pool_relax(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type, const int32_t* var_index,
+                      const double* value, int check_cycles, jslp_simplex_result* out, double* rhs, int32_t* vibr,
+                      int32_t out_stride, int want_rhs, int want_rows) {
+    if (!p || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "pool_relax_batch: null pointer");
+    jslp_engine* e = p->members[0];
+    if (!e->uploaded || !e->has_save) return fail(JSLP_ERR_STATE, "pool_relax_batch: the primary has no saved root (save() first)");
+    if ((rhs || vibr) && out_stride < e->cap_rows) return fail(JSLP_ERR_ARG, "pool_relax_batch: out_stride < row capacity");
+    if (n_nodes == 0) return JSLP_OK;
+    if (cut_offsets[0] != 0) return fail(JSLP_ERR_ARG, "cuts: cut_offsets[0] must be 0");
+    for (int32_t i = 0; i < n_nodes; i++)
+        if (cut_offsets[i + 1] < cut_offsets[i]) return fail(JSLP_ERR_ARG, "cuts: cut_offsets must not decrease");
+    int rc;
+    if (!p->synced || p->synced_seq != e->root_seq) {  // the primary saved a new root since the last fan-out
+        rc = jslp_pool_sync_root(p);
+        if (rc) return rc;
+    }
+    // ONE pinned buffer for every member's outcomes, laid out for all nodes: [states | rhs | rows]
+    const size_t cap = (size_t)e->cap_rows;
+    const size_t need = (size_t)n_nodes * (sizeof(DevState) + cap * 12);
+    if (need > p->h_out_bytes) {
+        if (p->h_out) hipHostFree(p->h_out);
+        p->h_out = nullptr; p->h_out_bytes = 0;
+        const size_t bytes = std::max<size_t>(need, (size_t)16 * (sizeof(DevState) + cap * 12));
+        HIPC(hipHostMalloc(&p->h_out, bytes, hipHostMallocPortable));
+        p->h_out_bytes = bytes;
+    }
+    DevState* g_states = reinterpret_cast<DevState*>(p->h_out);
+    double* g_rhs = reinterpret_cast<double*>(p->h_out + (size_t)n_nodes * sizeof(DevState));
+    int32_t* g_rows = reinterpret_cast<int32_t*>(p->h_out + (size_t)n_nodes * (sizeof(DevState) + cap * 8));
+    const int M = (int)p->members.size();
+    auto job = [=](int mi) -> int {
+        jslp_engine* m = p->members[mi];
+        const int first = (int)((long long)n_nodes * mi / M), last = (int)((long long)n_nodes * (mi + 1) / M), cnt = last - first;
+        if (cnt <= 0) return JSLP_OK;
+        std::vector<int32_t>& o = p->offs[mi];
+        o.resize((size_t)cnt + 1);
+        const int32_t base = cut_offsets[first];
+        for (int i = 0; i <= cnt; i++) o[i] = cut_offsets[first + i] - base;
+        m->ext_states = g_states + first;
+        m->ext_rhs = g_rhs + (size_t)first * cap;
+        m->ext_rows = g_rows + (size_t)first * cap;
+        const int r = relax_batch_impl(m, cnt, o.data(), type ? type + base : nullptr, var_index ? var_index + base : nullptr,
+                                       value ? value + base : nullptr, check_cycles, out + first, nullptr, nullptr, 0, 1,
+                                       want_rhs, want_rows);
+        m->ext_states = nullptr; m->ext_rhs = nullptr; m->ext_rows = nullptr;
+        if (r) return r;
+        for (int i = first; i < last && (rhs || vibr); i++) {  // caller-owned arrays: every member copies its own range
+            const size_t H = (size_t)out[i].height;
+            if (rhs) memcpy(rhs + (size_t)i * out_stride, g_rhs + (size_t)i * cap, sizeof(double) * H);
+            if (vibr) memcpy(vibr + (size_t)i * out_stride, g_rows + (size_t)i * cap, sizeof(int32_t) * H);
+        }
+        return JSLP_OK;
+    };
+    for (int mi = 1; mi < M; mi++) p->workers[mi]->submit([job, mi] { return job(mi); });
+    rc = job(0);
+    rc = pool_join(p, rc);
+    hipSetDevice(e->device);
+    return rc;
+}
+
+extern "C" int jslp_pool_relax_batch(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                     const int32_t* var_index, const double* value, int check_cycles,
+                                     jslp_simplex_result* out, double* rhs, int32_t* var_index_by_row, int32_t out_stride) {
+    return pool_relax(p, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, rhs, var_index_by_row, out_stride,
+                      rhs != nullptr, var_index_by_row != nullptr);
+}
+
+extern "C" int jslp_pool_relax_batch_pinned(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                            const int32_t* var_index, const double* value, int check_cycles,
+                                            jslp_simplex_result* out, const double** rhs, const int32_t** var_index_by_row,
+                                            int32_t* out_stride) {
+    int rc = pool_relax(p, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, nullptr, nullptr, 0, rhs != nullptr,
+                        var_index_by_row != nullptr);
+    if (rc) return rc;
+    const size_t cap = (size_t)p->members[0]->cap_rows;
+    if (rhs) *rhs = n_nodes > 0 ? reinterpret_cast<const double*>(p->h_out + (size_t)n_nodes * sizeof(DevState)) : nullptr;
+    if (var_index_by_row)
+        *var_index_by_row = n_nodes > 0 ? reinterpret_cast<const int32_t*>(p->h_out + (size_t)n_nodes * (sizeof(DevState) + cap * 8)) : nullptr;
+    if (out_stride) *out_stride = (int32_t)cap;
+    return JSLP_OK;
+}
+
+extern "C" int jslp_pool_set_counting(jslp_pool* p, int enabled) {
+    if (!p) return fail(JSLP_ERR_ARG, "pool_set_counting: null pool");
+    for (jslp_engine* m : p->members) {
+        int rc = jslp_engine_set_counting(m, enabled);
+        if (rc) return rc;
+    }
+    hipSetDevice(p->members[0]->device);
+    return JSLP_OK;
+}
+
+extern "C" int jslp_pool_get_counters(jslp_pool* p, jslp_work_counters* out) {
+    if (!p || !out) return fail(JSLP_ERR_ARG, "pool_get_counters: null pointer");
+    jslp_work_counters sum{};
+    for (jslp_engine* m : p->members) {
+        jslp_work_counters c;
+        int rc = jslp_engine_get_counters(m, &c);
+        if (rc) return rc;
+        sum.relaxations += c.relaxations; sum.simplex_calls += c.simplex_calls; sum.pivots += c.pivots;
+        sum.gated_cells += c.gated_cells; sum.gated_rows += c.gated_rows; sum.restored_rows += c.restored_rows;
+        sum.cut_rows += c.cut_rows; sum.height_sum += c.height_sum;
+    }
+    hipSetDevice(p->members[0]->device);
+    *out = sum;
+    return JSLP_OK;
+}
+
 extern "C" int jslp_engine_dims(const jslp_engine* e, int32_t* height, int32_t* width, int32_t* n_var_indexes) {
     if (!e) return fail(JSLP_ERR_ARG, "dims: null engine");
     if (height) {
@@ -1480,6 +1959,8 @@ extern "C" int jslp_engine_pivot_trace(jslp_engine* e, int32_t* row_col, int64_t
     DevState st;
     HIPC(hipMemcpy(&st, e->s.st, sizeof st, hipMemcpyDeviceToHost));
     *n_pivots = st.trace_n;
+    if (row_col && max_pairs > 0 && st.trace_n > e->s.trace_cap)
+        return fail(JSLP_ERR_CAPACITY, "pivot_trace: more pivots since upload than the trace holds (2^20): the recorded prefix is not handed out as if it were complete");
     if (row_col && max_pairs > 0) {
         const long long n = std::min<long long>(std::min<long long>(st.trace_n, max_pairs), e->s.trace_cap);
         if (n > 0) HIPC(hipMemcpy(row_col, e->s.trace, sizeof(int2) * n, hipMemcpyDeviceToHost));

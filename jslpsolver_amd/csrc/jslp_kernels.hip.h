@@ -59,6 +59,9 @@ struct DevState {
     int32_t mir_added;    // rows appended by the last k_mir_cuts
     int32_t rhs_valid;    // the slot's contiguous RHS mirror (Ctx::rhs) equals column 0 (kept by the per-node kernel only)
 };
+// Work counters (jslp_work_counters), one block per engine, advanced with device-scope atomics only while counting is on
+enum { CNT_CELLS = 0, CNT_ROWS = 1, CNT_RESTORED = 2, CNT_N = 4 };
+typedef unsigned long long cnt_t;
 
 // ---- the simplex core, compiled for both scalar types (see jslp_core.inc.h) -------------------------------------
 __device__ __forceinline__ double rmul_rn(double a, double b) { return __dmul_rn(a, b); }
@@ -113,6 +116,7 @@ __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int fir
         for (long long i = tid; i < n2; i += nt) dst[i] = src[i];
         for (long long i = tid; i < s.pcol_stride; i += nt) dirty[i] = 0;
         for (long long i = tid; i < H; i += nt) rhs[i] = snap.rhs[i];
+        if (s.cnt && tid == 0) atomicAdd(s.cnt + CNT_RESTORED, (cnt_t)H);
     } else {
         // one wave per dirty row: rows are found by a strided scan of the byte flags
         const int lane = threadIdx.x & 63;
@@ -123,7 +127,7 @@ __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int fir
             const double2* a = src + r * ld2;
             double2* b = dst + r * ld2;
             for (int i = lane; i < ld2; i += 64) b[i] = a[i];
-            if (lane == 0) { dirty[r] = 0; rhs[r] = snap.rhs[r]; }
+            if (lane == 0) { dirty[r] = 0; rhs[r] = snap.rhs[r]; if (s.cnt) atomicAdd(s.cnt + CNT_RESTORED, (cnt_t)1); }
         }
     }
     int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
@@ -341,6 +345,8 @@ __global__ void __launch_bounds__(256) k_add_cuts(Slots s, Cuts cuts, int first_
 }
 
 // Read-back for the host tree: RHS column + varIndexByRow of each slot, and the slot's state.
+// out_stride < 0: compact read-back (jslp_engine_relax_watched) -- per watched variable its row (rowByVarIndex) and its RHS
+// cell, -out_stride entries per node
 __device__ __forceinline__ void gather_slot(const Slots& s, int slot, double* rhs, int32_t* rows, DevState* states,
                                             int out_stride, int o) {
     const DevState* st = s.st + slot;
@@ -349,6 +355,18 @@ __device__ __forceinline__ void gather_slot(const Slots& s, int slot, double* rh
     const bool mirrored = st->rhs_valid != 0;
     const int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
     const int H = st->H;
+    if (out_stride < 0) {
+        const int32_t* rbv = s.rbv + (long long)slot * s.idx_stride;
+        const int n = -out_stride;
+        for (int i = threadIdx.x; i < n && i < s.n_watch; i += blockDim.x) {
+            const int r = rbv[s.watch[i]];
+            const bool basic = r > 0 && r < H;
+            if (rows) rows[(long long)o * n + i] = basic ? r : -1;
+            if (rhs) rhs[(long long)o * n + i] = basic ? (mirrored ? mirror[r] : A[(long long)r * s.ld]) : 0.0;
+        }
+        if (threadIdx.x == 0) states[o] = *st;
+        return;
+    }
     for (int r = threadIdx.x; r < H; r += blockDim.x) {
         if (rhs) rhs[(long long)o * out_stride + r] = mirrored ? mirror[r] : A[(long long)r * s.ld];
         if (rows) rows[(long long)o * out_stride + r] = vibr[r];
@@ -397,6 +415,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 8 : 4) k_node_wg(Slo
         }
     __syncthreads();
     const int n = act.n;
+    if (s.cnt && tid == 0) atomicAdd(s.cnt + CNT_RESTORED, (cnt_t)n);
     const double2* src = reinterpret_cast<const double2*>(snap.A);
     double2* dst = reinterpret_cast<double2*>(A);
     if (n <= CAP) {
@@ -435,6 +454,84 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 8 : 4) k_node_wg(Slo
     simplex_wg(c, sm, act, iters_cap);
     __syncthreads();
     gather_slot(s, slot, rhs_out, rows_out, state_out, out_stride, o);
+}
+
+// ---- upload (tableau.ts:292-380 hand-over): the matrix arrives by DMA; ONE blob brings [vibr | vibc | unrestricted list]
+// and this kernel builds the inverse maps, the flags and the state on the device (one workgroup) -----------------------------
+struct UploadBlob {
+    const int32_t* vibr;  // H entries
+    const int32_t* vibc;  // W entries
+    const int32_t* unr;   // n_unr variable indexes
+    int32_t H, n_unr, n_idx, cap_rows;
+};
+__global__ void __launch_bounds__(1024) k_upload_finish(Slots s, UploadBlob b, uint8_t* unr_flags, uint8_t* isint_flags) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < b.n_idx; i += nt) { s.rbv[i] = -1; s.cbv[i] = -1; unr_flags[i] = 0; isint_flags[i] = 0; }
+    for (int i = tid; i < b.cap_rows; i += nt) { s.vibr[i] = i < b.H && i > 0 ? b.vibr[i] : -1; s.dirty[i] = 0; }
+    for (int i = tid; i < s.W; i += nt) s.vibc[i] = i > 0 ? b.vibc[i] : -1;
+    __syncthreads();
+    for (int r = 1 + tid; r < b.H; r += nt) s.rbv[b.vibr[r]] = r;
+    for (int c = 1 + tid; c < s.W; c += nt) s.cbv[b.vibc[c]] = c;
+    for (int i = tid; i < b.n_unr; i += nt) unr_flags[b.unr[i]] = 1;
+    if (tid == 0) {
+        DevState st;
+        memset(&st, 0, sizeof st);
+        st.H = b.H;
+        st.last_element_index = s.W + b.H - 2;  // tableau.ts:312-316
+        st.status = ST_DONE;
+        st.phase = 1;
+        st.feasible = 1;
+        st.bounded = 1;
+        st.unbounded_var = -1;
+        *s.st = st;
+    }
+}
+// strided host layout (row stride W) -> device layout (row stride ld) for a tableau that arrived as ONE contiguous DMA
+__global__ void __launch_bounds__(256) k_repack(double* A, const double* packed, int H, int W, int ld) {
+    const long long n = (long long)H * ld;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / ld), c = (int)(i - (long long)r * ld);
+        A[i] = c < W ? packed[(long long)r * W + c] : 0.0;
+    }
+}
+
+// ---- resident kernel safety net: slot 0 (matrix rows [0, H), maps, state) <-> a backup taken before the cooperative launch
+__global__ void __launch_bounds__(256) k_res_backup(Slots s, SnapshotW bk, DevState* st_bk, int H, int to_backup) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long long)gridDim.x * blockDim.x;
+    const long long n2 = (long long)H * s.ld / 2;
+    double2* live = reinterpret_cast<double2*>(s.A);
+    double2* back = reinterpret_cast<double2*>(bk.A);
+    if (to_backup) {
+        for (long long i = tid; i < n2; i += nt) back[i] = live[i];
+        for (long long i = tid; i < H; i += nt) bk.vibr[i] = s.vibr[i];
+        for (long long i = tid; i < s.W; i += nt) bk.vibc[i] = s.vibc[i];
+        for (long long i = tid; i < bk.n_idx; i += nt) { bk.rbv[i] = s.rbv[i]; bk.cbv[i] = s.cbv[i]; }
+        if (tid == 0) *st_bk = *s.st;
+    } else {
+        for (long long i = tid; i < n2; i += nt) live[i] = back[i];
+        for (long long i = tid; i < H; i += nt) s.vibr[i] = bk.vibr[i];
+        for (long long i = tid; i < s.W; i += nt) s.vibc[i] = bk.vibc[i];
+        for (long long i = tid; i < bk.n_idx; i += nt) { s.rbv[i] = bk.rbv[i]; s.cbv[i] = bk.cbv[i]; }
+        if (tid == 0) *s.st = *st_bk;
+    }
+}
+
+// ---- device pool: a member that just received the primary's saved root by peer copy adopts it as ITS saved root ------------
+__global__ void k_adopt_root(Slots s, int s_H, int s_last_element_index) {
+    DevState* st = s.st;
+    st->s_H = s_H;
+    st->s_last_element_index = s_last_element_index;
+    st->s_gen += 1;
+    st->gen = 0;
+    st->H = s_H;
+    st->last_element_index = s_last_element_index;
+    st->status = ST_DONE;
+    st->phase = 2;
+    st->feasible = 1;
+    st->bounded = 1;
+    st->unbounded_var = -1;
+    st->err = ERR_NONE;
+    st->rhs_valid = 0;
 }
 
 // ---- fp32 twin (jslp_engine_simplex_f32): narrow the live fp64 tableau into an fp32 slot / widen the read-back ----------

@@ -35,12 +35,14 @@ struct ResCtx {
     u64_t* gor[2];        // [G] rare slow path: tagged per-workgroup flags for a chip-wide OR
     int32_t G, rpb, H;
     int32_t iters_cap;
+    uint32_t spin_limit;       // bound of every poll loop (polls, not cycles); reaching it raises the device-wide abort flag
+    int32_t test_abort_epoch;  // tests only (JSLP_TEST_RESIDENT_ABORT): the last workgroup aborts the hand-off at this pivot; -1 = never
     u64_t* dbg;  // JSLP_DEBUG_RESIDENT builds only
 };
 
 #define AG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define AG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define JSLP_SPIN_LIMIT (1u << 22)
+#define JSLP_SPIN_LIMIT_DEFAULT (1u << 22)
 #ifndef JSLP_POLL_SLEEP
 #define JSLP_POLL_SLEEP 6
 #endif
@@ -90,7 +92,7 @@ __device__ __forceinline__ bool sweep_summary(const ResCtx& f, int par, unsigned
         __builtin_amdgcn_s_sleep(1);
         ++spins;
         if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) return false;
-        if (spins > JSLP_SPIN_LIMIT) { if ((w & 63) == 0) AG_STORE(f.abort_flag, 1u); return false; }
+        if (spins > f.spin_limit) { if ((w & 63) == 0) AG_STORE(f.abort_flag, 1u); return false; }
     }
     const u64_t qb = (x[0] & 0xffffffffull) | (x[1] << 32);
     const u64_t kqb = (x[2] & 0xffffffffull) | (x[3] << 32);
@@ -169,7 +171,7 @@ __device__ __forceinline__ int global_or(const ResCtx& f, int par, unsigned tag,
             __builtin_amdgcn_s_sleep(JSLP_POLL_SLEEP);
             ++spins;
             if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
-            if (spins > JSLP_SPIN_LIMIT) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+            if (spins > f.spin_limit) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
         }
     }
     const int bad = __syncthreads_or(ok ? 0 : 1);
@@ -227,6 +229,11 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         if ((it1 - it1_start) + (it2 - it2_start) >= f.iters_cap) { end_code = 4; break; }
         const int par = epoch & 1;
         const unsigned tag = epoch + 1;
+        if (f.test_abort_epoch >= 0 && (int)epoch == f.test_abort_epoch && b == f.G - 1) {  // tests: a workgroup gives up
+            if (tid == 0) AG_STORE(f.abort_flag, 1u);
+            end_code = 5;
+            break;
+        }
         RT_MARK(7);
         // ---- A: my rows' summary: phase 2 = ratio test for column pc (simplex.ts:276-296); phase 1 = most negative RHS
         //         below -precision (simplex.ts:39-49) -------------------------------------------------------------------
@@ -388,7 +395,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                     __builtin_amdgcn_s_sleep(JSLP_POLL_SLEEP);  // 250 workgroups poll this one line: keep the load on it light
                     ++spins;
                     if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
-                    if (spins > JSLP_SPIN_LIMIT) { if (tid == 0) AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+                    if (spins > f.spin_limit) { if (tid == 0) AG_STORE(f.abort_flag, 1u); ok = 0; break; }
                 }
                 if (tid < 3) sm.dec[tid] = (unsigned)x;
                 if (tid == 0) sm.ok = ok;
@@ -431,7 +438,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                         __builtin_amdgcn_s_sleep(1);
                         ++spins;
                         if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
-                        if (spins > JSLP_SPIN_LIMIT) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+                        if (spins > f.spin_limit) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
                     }
                 }
                 sm.ok = ok;
@@ -500,7 +507,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                             __builtin_amdgcn_s_sleep(JSLP_POLL_SLEEP);
                             ++spins;
                             if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) break;
-                            if (spins > JSLP_SPIN_LIMIT) { AG_STORE(f.abort_flag, 1u); break; }
+                            if (spins > f.spin_limit) { AG_STORE(f.abort_flag, 1u); break; }
                         }
                         sm.ok = v;
                     }

@@ -168,6 +168,51 @@ class Tableau:
         vibr = np.ctypeslib.as_array(p_rows, shape=shape) if want_rows else None
         return out, rhs, vibr
 
+    # ---- compact read-back, work counters, pinned host build --------------------------------------------------
+    def set_watched_variables(self, var_indexes):
+        """the variable indexes the branch-and-bound tree reads between relaxations (the integer variables)"""
+        w = _capi.as_i32(list(var_indexes))
+        self.lib.check(self.lib.jslp_engine_set_watched_variables(self._h, _capi.ptr_i32(w), int(w.shape[0])),
+                       "jslp_engine_set_watched_variables")
+        self.n_watched = int(w.shape[0])
+
+    def applyCutsWatched(self, cuts, check_cycles=True):
+        """applyCuts whose read-back is only rowByVarIndex / the RHS cell of the watched variables"""
+        n, t, v, x = self._pack_cuts(cuts)
+        res = SimplexResult()
+        rows = np.empty(self.n_watched, dtype=np.int32)
+        vals = np.empty(self.n_watched, dtype=np.float64)
+        self.lib.check(self.lib.jslp_engine_relax_watched(self._h, n, _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x),
+                                                          int(bool(check_cycles)), _capi.C.byref(res), _capi.ptr_i32(rows),
+                                                          _capi.ptr_f64(vals)), "jslp_engine_relax_watched")
+        self._absorb(res)
+        return res, rows, vals
+
+    def set_counting(self, enabled):
+        self.lib.check(self.lib.jslp_engine_set_counting(self._h, int(bool(enabled))), "jslp_engine_set_counting")
+
+    def get_counters(self):
+        c = _capi.WorkCounters()
+        self.lib.check(self.lib.jslp_engine_get_counters(self._h, _capi.C.byref(c)), "jslp_engine_get_counters")
+        return c.as_dict()
+
+    def host_matrix(self):
+        """height x width float64 view of the engine's pinned build buffer (zero-filled on every call); fill it and pass
+        it to upload_host_matrix()"""
+        p = _capi._f64p()
+        n = _capi.C.c_int64()
+        self.lib.check(self.lib.jslp_engine_host_matrix(self._h, _capi.C.byref(p), _capi.C.byref(n)), "jslp_engine_host_matrix")
+        return np.ctypeslib.as_array(p, shape=(self.height0, self.width))
+
+    def upload(self, matrix, var_index_by_row, var_index_by_col, unrestricted=()):
+        """Tableau hand-over again (a new model of the same shape, or the buffer of host_matrix())"""
+        vibr = _capi.as_i32(var_index_by_row)
+        vibc = _capi.as_i32(var_index_by_col)
+        unr = _capi.as_i32(list(unrestricted))
+        m = np.ascontiguousarray(matrix, dtype=np.float64)
+        self.lib.check(self.lib.jslp_engine_upload(self._h, _capi.ptr_f64(m), _capi.ptr_i32(vibr), _capi.ptr_i32(vibc),
+                                                   _capi.ptr_i32(unr), int(unr.shape[0])), "jslp_engine_upload")
+
     # ---- fp32 experiment ------------------------------------------------------------------------------------
     def simplex_f32(self, precision, check_cycles=True):
         """simplex() on an fp32 copy of the live tableau with tolerance `precision` (SURVEY.md 8d, config 5's fp32-vs-fp64
@@ -291,6 +336,70 @@ class Tableau:
         self.lib.check(self.lib.jslp_engine_get_timing(self._h, _capi.C.byref(ms), _capi.C.byref(n), _capi.C.byref(tot)),
                        "jslp_engine_get_timing")
         return ms.value, n.value, tot.value
+
+
+class DevicePool:
+    """jslp_pool: `tableau` (the primary) plus one engine per further device ordinal, each holding the primary's saved
+    root; batches of independent nodes are split over the members.  devices[0] must be the primary's."""
+
+    def __init__(self, tableau, devices):
+        self.t = tableau
+        self.lib = tableau.lib
+        d = _capi.as_i32(list(devices))
+        self._p = _capi.C.c_void_p()
+        self.lib.check(self.lib.jslp_pool_create(_capi.C.byref(self._p), tableau._h, _capi.ptr_i32(d), int(d.shape[0])),
+                       "jslp_pool_create")
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self.lib.jslp_pool_destroy(self._p)
+            self._p = _capi.C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return self.lib.jslp_pool_size(self._p)
+
+    def sync_root(self):
+        self.lib.check(self.lib.jslp_pool_sync_root(self._p), "jslp_pool_sync_root")
+
+    def applyCutsBatch(self, cut_lists, check_cycles=True, packed=None, want_rows=True, copy=True):
+        """Tableau.applyCutsBatch over every member of the pool"""
+        t = self.t
+        n_nodes, offs, ty, v, x = packed if packed is not None else t.pack_cut_lists(cut_lists)
+        out = (SimplexResult * max(n_nodes, 1))()
+        stride = t.row_capacity
+        if copy:
+            rhs = np.empty((max(n_nodes, 1), stride), dtype=np.float64)
+            vibr = np.empty((max(n_nodes, 1), stride), dtype=np.int32) if want_rows else None
+            self.lib.check(self.lib.jslp_pool_relax_batch(self._p, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(ty), _capi.ptr_i32(v),
+                                                          _capi.ptr_f64(x), int(bool(check_cycles)), out, _capi.ptr_f64(rhs),
+                                                          _capi.ptr_i32(vibr), stride), "jslp_pool_relax_batch")
+            return [out[i] for i in range(n_nodes)], rhs, vibr
+        p_rhs = _capi._f64p()
+        p_rows = _capi._i32p()
+        c_stride = _capi.C.c_int32()
+        self.lib.check(self.lib.jslp_pool_relax_batch_pinned(
+            self._p, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(ty), _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)),
+            out, _capi.C.byref(p_rhs), _capi.C.byref(p_rows) if want_rows else None, _capi.C.byref(c_stride)),
+            "jslp_pool_relax_batch_pinned")
+        shape = (max(n_nodes, 1), c_stride.value)
+        rhs = np.ctypeslib.as_array(p_rhs, shape=shape)
+        vibr = np.ctypeslib.as_array(p_rows, shape=shape) if want_rows else None
+        return out, rhs, vibr
+
+    def set_counting(self, enabled):
+        self.lib.check(self.lib.jslp_pool_set_counting(self._p, int(bool(enabled))), "jslp_pool_set_counting")
+
+    def get_counters(self):
+        c = _capi.WorkCounters()
+        self.lib.check(self.lib.jslp_pool_get_counters(self._p, _capi.C.byref(c)), "jslp_pool_get_counters")
+        return c.as_dict()
 
 
 def pivot_digest(pairs):

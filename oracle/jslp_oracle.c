@@ -52,6 +52,13 @@ struct jslp_engine {
     /* StateCheckpoint list (incremental-branch-and-cut.ts:31-44) */
     struct checkpoint* ck;
     int32_t n_ck;
+    /* ABI extras mirrored so that host code written against the product library runs against this one */
+    double* host_matrix;    /* jslp_engine_host_matrix */
+    int32_t* watch;         /* jslp_engine_set_watched_variables */
+    int32_t n_watch;
+    int counting;
+    jslp_work_counters wc;
+    unsigned long long root_seq;
 };
 
 struct checkpoint {
@@ -129,6 +136,8 @@ void jslp_engine_destroy(jslp_engine* e) {
     free(e->oo); free(e->s_oo); free(e->defer);
     checkpoints_clear(e);
     free(e->is_int);
+    free(e->host_matrix);
+    free(e->watch);
     free(e);
 }
 
@@ -171,6 +180,7 @@ int jslp_engine_upload(jslp_engine* e, const double* matrix, const int32_t* var_
     e->n_trace = 0;
     e->uploaded = 1;
     e->n_opt = 0;
+    e->root_seq += 1;
     return JSLP_OK;
 }
 
@@ -237,11 +247,13 @@ static void pivot(jslp_engine* e, int32_t pr, int32_t pc) {
     }
     m[pro + pc] = 1 / quotient; /* :364 */
 
+    int64_t gated_rows = 0; /* work counters only */
     for (int32_t r = 0; r < height; r++) { /* :367-392 */
         if (r == pr) continue;
         const size_t ro = (size_t)r * width;
         const double pcv = m[ro + pc];
         if (nonzero16(pcv)) {
+            gated_rows += 1;
             const double coefficient = pcv;
             for (int32_t i = 0; i < nnz; i++) {
                 const int32_t c = e->nz[i];
@@ -256,6 +268,12 @@ static void pivot(jslp_engine* e, int32_t pr, int32_t pc) {
         }
         /* the reference's inner `else if (coefficient !== 0) matrix[...] = 0` (:388-390) is unreachable: it sits
            inside `if (!(pivotColVal tiny))` with coefficient === pivotColVal, so tiny entries stay untouched */
+    }
+    if (e->counting) { /* jslp_work_counters: gated rows x live columns of the final pivot row (plus c*) */
+        int64_t cols = 0;
+        for (int32_t c = 0; c < width; c++) cols += (nonzero16(m[pro + c]) || c == pc) ? 1 : 0;
+        e->wc.gated_rows += gated_rows;
+        e->wc.gated_cells += gated_rows * cols;
     }
     /* optional objectives (:394-412): exact `!== 0` tests instead of the 1e-16 band */
     for (int32_t o = 0; o < e->n_opt; o++) {
@@ -554,6 +572,11 @@ int jslp_engine_simplex(jslp_engine* e, int check_cycles, jslp_simplex_result* o
     out->height = e->height;
     out->obj_cell = e->matrix[0];
     out->evaluation = e->evaluation;
+    if (e->counting) {
+        e->wc.simplex_calls += 1;
+        e->wc.pivots += out->pivots_phase1 + (out->pivots_phase2 > 0 ? out->pivots_phase2 : 0);
+        e->wc.height_sum += e->height;
+    }
     return JSLP_OK;
 }
 
@@ -576,6 +599,7 @@ int jslp_engine_save(jslp_engine* e) {
     e->s_height = e->height;
     e->s_last_element_index = e->last_element_index;
     e->has_save = 1;
+    e->root_seq += 1;
     return JSLP_OK;
 }
 
@@ -593,6 +617,7 @@ int jslp_engine_restore(jslp_engine* e) {
     memcpy(e->rbv, e->s_rbv, (size_t)e->n_idx_cap * sizeof(int32_t));
     memcpy(e->cbv, e->s_cbv, (size_t)e->n_idx_cap * sizeof(int32_t));
     if (e->n_opt > 0) memcpy(e->oo, e->s_oo, (size_t)e->n_opt * e->width * sizeof(double)); /* backup.ts:94-104 */
+    if (e->counting) e->wc.restored_rows += e->height; /* the reference copies every row; the product only the changed ones */
     return JSLP_OK;
 }
 
@@ -629,6 +654,7 @@ int jslp_engine_add_cuts(jslp_engine* e, int32_t n, const int8_t* type, const in
         e->cbv[slack] = -1;
     }
     e->height = height + n;
+    if (e->counting) e->wc.cut_rows += n;
     return JSLP_OK;
 }
 
@@ -651,6 +677,7 @@ int jslp_engine_relax(jslp_engine* e, int32_t n_cuts, const int8_t* type, const 
     if (rc) return rc;
     rc = jslp_engine_simplex(e, check_cycles, out);
     if (rc) return rc;
+    if (e->counting) e->wc.relaxations += 1;
     return jslp_engine_read_rhs(e, rhs, var_index_by_row);
 }
 
@@ -859,6 +886,208 @@ int jslp_engine_relax_from(jslp_engine* e, int32_t checkpoint, int32_t n_nodes, 
         rc = jslp_engine_read_rhs(e, rhs ? rhs + (size_t)i * out_stride : 0,
                                   var_index_by_row ? var_index_by_row + (size_t)i * out_stride : 0);
         if (rc) return rc;
+    }
+    return JSLP_OK;
+}
+
+/* ---- ABI extras (host build buffer, compact read-back, work counters, device pool), mirrored sequentially ------------- */
+int jslp_engine_host_matrix(jslp_engine* e, double** matrix, int64_t* n_doubles) {
+    if (!e || !matrix) return fail(JSLP_ERR_ARG, "host_matrix: null");
+    const size_t n = (size_t)e->height0 * e->width;
+    if (!e->host_matrix) e->host_matrix = (double*)malloc(n * sizeof(double));
+    if (!e->host_matrix) return fail(JSLP_ERR_NOMEM, "host_matrix: oom");
+    memset(e->host_matrix, 0, n * sizeof(double));
+    *matrix = e->host_matrix;
+    if (n_doubles) *n_doubles = (int64_t)n;
+    return JSLP_OK;
+}
+
+int jslp_engine_set_watched_variables(jslp_engine* e, const int32_t* var_indexes, int32_t n) {
+    if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "set_watched_variables before upload");
+    if (n < 0 || (n > 0 && !var_indexes)) return fail(JSLP_ERR_ARG, "set_watched_variables: bad arguments");
+    for (int32_t i = 0; i < n; i++)
+        if (var_indexes[i] < 0 || var_indexes[i] >= e->n_idx_cap) return fail(JSLP_ERR_ARG, "set_watched_variables: index out of range");
+    free(e->watch);
+    e->watch = 0;
+    e->n_watch = 0;
+    if (n > 0) {
+        e->watch = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+        if (!e->watch) return fail(JSLP_ERR_NOMEM, "set_watched_variables: oom");
+        memcpy(e->watch, var_indexes, (size_t)n * sizeof(int32_t));
+        e->n_watch = n;
+    }
+    return JSLP_OK;
+}
+
+int jslp_engine_relax_watched(jslp_engine* e, int32_t n_cuts, const int8_t* type, const int32_t* var_index,
+                              const double* value, int check_cycles, jslp_simplex_result* out, int32_t* watched_row,
+                              double* watched_value) {
+    if (!e) return fail(JSLP_ERR_ARG, "relax_watched: null");
+    if (e->n_watch <= 0 || e->n_watch > e->cap_rows)
+        return fail(JSLP_ERR_ARG, "relax_watched: one node at a time, after set_watched_variables (at most row_capacity of them)");
+    int rc = jslp_engine_relax(e, n_cuts, type, var_index, value, check_cycles, out, 0, 0);
+    if (rc) return rc;
+    for (int32_t i = 0; i < e->n_watch; i++) { /* rowByVarIndex[v], then matrix[row * width + rhsColumn] (mip-utils.ts:43-61) */
+        const int32_t r = e->rbv[e->watch[i]];
+        const int basic = r > 0 && r < e->height;
+        if (watched_row) watched_row[i] = basic ? r : -1;
+        if (watched_value) watched_value[i] = basic ? e->matrix[(size_t)r * e->width] : 0.0;
+    }
+    return JSLP_OK;
+}
+
+int jslp_engine_set_counting(jslp_engine* e, int enabled) {
+    if (!e) return fail(JSLP_ERR_ARG, "set_counting: null");
+    e->counting = enabled ? 1 : 0;
+    memset(&e->wc, 0, sizeof e->wc);
+    return JSLP_OK;
+}
+
+int jslp_engine_get_counters(jslp_engine* e, jslp_work_counters* out) {
+    if (!e || !out) return fail(JSLP_ERR_ARG, "get_counters: null");
+    *out = e->wc;
+    return JSLP_OK;
+}
+
+struct jslp_pool {
+    int32_t n;
+    jslp_engine** members; /* members[0] = the primary (not owned) */
+    unsigned long long synced_seq;
+    int synced;
+    double* b_rhs;
+    int32_t* b_rows;
+    size_t b_cap;
+};
+
+int jslp_pool_size(const jslp_pool* p) { return p ? p->n : 0; }
+
+void jslp_pool_destroy(jslp_pool* p) {
+    if (!p) return;
+    for (int32_t i = 1; i < p->n; i++) jslp_engine_destroy(p->members[i]);
+    free(p->members); free(p->b_rhs); free(p->b_rows);
+    free(p);
+}
+
+int jslp_pool_create(jslp_pool** out, jslp_engine* primary, const int32_t* devices, int32_t n_devices) {
+    if (!out || !primary || !devices || n_devices < 1) return fail(JSLP_ERR_ARG, "pool_create: bad arguments");
+    jslp_pool* p = (jslp_pool*)calloc(1, sizeof *p);
+    if (!p) return fail(JSLP_ERR_NOMEM, "pool_create: oom");
+    p->members = (jslp_engine**)calloc((size_t)n_devices, sizeof(jslp_engine*));
+    if (!p->members) { free(p); return fail(JSLP_ERR_NOMEM, "pool_create: oom"); }
+    p->members[0] = primary;
+    p->n = 1;
+    for (int32_t i = 1; i < n_devices; i++) {
+        int rc = jslp_engine_create(&p->members[i], devices[i], primary->height0, primary->width, primary->cap_rows, primary->precision);
+        if (rc) { jslp_pool_destroy(p); return rc; }
+        p->n = i + 1;
+    }
+    *out = p;
+    return JSLP_OK;
+}
+
+/* every member receives the primary's saved root (savedState, backup.ts:13-51) and restores it */
+int jslp_pool_sync_root(jslp_pool* p) {
+    if (!p) return fail(JSLP_ERR_ARG, "pool_sync_root: null");
+    jslp_engine* e = p->members[0];
+    if (!e->uploaded || !e->has_save) return fail(JSLP_ERR_STATE, "pool_sync_root: the primary has no saved root (save() first)");
+    for (int32_t i = 1; i < p->n; i++) {
+        jslp_engine* m = p->members[i];
+        const size_t cells = (size_t)e->s_height * e->width;
+        memcpy(m->s_matrix, e->s_matrix, cells * sizeof(double));
+        memcpy(m->s_vibr, e->s_vibr, (size_t)e->s_height * sizeof(int32_t));
+        memcpy(m->s_vibc, e->s_vibc, (size_t)e->width * sizeof(int32_t));
+        memcpy(m->s_rbv, e->s_rbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+        memcpy(m->s_cbv, e->s_cbv, (size_t)e->n_idx_cap * sizeof(int32_t));
+        memcpy(m->unrestricted, e->unrestricted, (size_t)e->n_idx_cap);
+        if (e->is_int) {
+            if (!m->is_int) m->is_int = (uint8_t*)calloc((size_t)e->n_idx_cap, 1);
+            if (!m->is_int) return fail(JSLP_ERR_NOMEM, "pool_sync_root: oom");
+            memcpy(m->is_int, e->is_int, (size_t)e->n_idx_cap);
+        }
+        if (e->n_opt > 0) {
+            const size_t nb = (size_t)e->n_opt * e->width * sizeof(double);
+            free(m->oo); free(m->s_oo); free(m->defer);
+            m->oo = (double*)malloc(nb);
+            m->s_oo = (double*)malloc(nb);
+            m->defer = (int32_t*)calloc((size_t)e->width * 2, sizeof(int32_t));
+            if (!m->oo || !m->s_oo || !m->defer) return fail(JSLP_ERR_NOMEM, "pool_sync_root: oom");
+            memcpy(m->s_oo, e->s_oo, nb);
+        }
+        m->n_opt = e->n_opt;
+        m->s_height = e->s_height;
+        m->s_last_element_index = e->s_last_element_index;
+        m->has_save = 1;
+        m->uploaded = 1;
+        m->evaluation = e->evaluation;
+        m->feasible = 1;
+        m->bounded = 1;
+        checkpoints_clear(m);
+        int rc = jslp_engine_restore(m);
+        if (rc) return rc;
+    }
+    p->synced_seq = e->root_seq;
+    p->synced = 1;
+    return JSLP_OK;
+}
+
+int jslp_pool_relax_batch(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                          const int32_t* var_index, const double* value, int check_cycles, jslp_simplex_result* out,
+                          double* rhs, int32_t* var_index_by_row, int32_t out_stride) {
+    if (!p || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "pool_relax_batch: null");
+    jslp_engine* e = p->members[0];
+    if (!e->uploaded || !e->has_save) return fail(JSLP_ERR_STATE, "pool_relax_batch: the primary has no saved root (save() first)");
+    if ((rhs || var_index_by_row) && out_stride < e->cap_rows) return fail(JSLP_ERR_ARG, "pool_relax_batch: out_stride < row capacity");
+    if (!p->synced || p->synced_seq != e->root_seq) {
+        int rc = jslp_pool_sync_root(p);
+        if (rc) return rc;
+    }
+    for (int32_t mi = 0; mi < p->n; mi++) { /* the same contiguous ranges the product hands its members */
+        const int32_t first = (int32_t)((int64_t)n_nodes * mi / p->n), last = (int32_t)((int64_t)n_nodes * (mi + 1) / p->n);
+        for (int32_t i = first; i < last; i++) {
+            const int32_t a = cut_offsets[i], n = cut_offsets[i + 1] - a;
+            int rc = jslp_engine_relax(p->members[mi], n, type ? type + a : 0, var_index ? var_index + a : 0, value ? value + a : 0,
+                                       check_cycles, &out[i], rhs ? rhs + (size_t)i * out_stride : 0,
+                                       var_index_by_row ? var_index_by_row + (size_t)i * out_stride : 0);
+            if (rc) return rc;
+        }
+    }
+    return JSLP_OK;
+}
+
+int jslp_pool_relax_batch_pinned(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                 const int32_t* var_index, const double* value, int check_cycles,
+                                 jslp_simplex_result* out, const double** rhs, const int32_t** var_index_by_row,
+                                 int32_t* out_stride) {
+    if (!p) return fail(JSLP_ERR_ARG, "pool_relax_batch_pinned: null");
+    const int32_t cap = p->members[0]->cap_rows;
+    const size_t need = (size_t)(n_nodes > 0 ? n_nodes : 1) * cap;
+    if (need > p->b_cap) {
+        p->b_rhs = (double*)realloc(p->b_rhs, need * sizeof(double));
+        p->b_rows = (int32_t*)realloc(p->b_rows, need * sizeof(int32_t));
+        p->b_cap = need;
+    }
+    int rc = jslp_pool_relax_batch(p, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, p->b_rhs, p->b_rows, cap);
+    if (rc) return rc;
+    if (rhs) *rhs = p->b_rhs;
+    if (var_index_by_row) *var_index_by_row = p->b_rows;
+    if (out_stride) *out_stride = cap;
+    return JSLP_OK;
+}
+
+int jslp_pool_set_counting(jslp_pool* p, int enabled) {
+    if (!p) return fail(JSLP_ERR_ARG, "pool_set_counting: null");
+    for (int32_t i = 0; i < p->n; i++) jslp_engine_set_counting(p->members[i], enabled);
+    return JSLP_OK;
+}
+
+int jslp_pool_get_counters(jslp_pool* p, jslp_work_counters* out) {
+    if (!p || !out) return fail(JSLP_ERR_ARG, "pool_get_counters: null");
+    memset(out, 0, sizeof *out);
+    for (int32_t i = 0; i < p->n; i++) {
+        const jslp_work_counters* c = &p->members[i]->wc;
+        out->relaxations += c->relaxations; out->simplex_calls += c->simplex_calls; out->pivots += c->pivots;
+        out->gated_cells += c->gated_cells; out->gated_rows += c->gated_rows; out->restored_rows += c->restored_rows;
+        out->cut_rows += c->cut_rows; out->height_sum += c->height_sum;
     }
     return JSLP_OK;
 }

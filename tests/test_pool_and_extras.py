@@ -1,0 +1,192 @@
+"""Round-2 additions of the C ABI: the device pool, the compact read-back, the work counters, the pinned
+host-build buffer (8f.4) and the resident kernel's roll-back.  CPU: the test-only oracle library behind the same ABI;
+-m gpu: the HIP library, with "virtual devices" (several pool members on the one visible MI355X)."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as G
+from jslpsolver_amd import generators
+from jslpsolver_amd.engine import DevicePool, Tableau, pivot_digest
+
+MONSTER_II = os.path.join(G.GOLDEN, "fixtures", "Monster_II.json.gz")
+
+
+def _root(lib, g, extra_rows=0):
+    tab = g["tableau"]
+    m, vibr, vibc = G.dense_tableau(tab)
+    calls = g["simplexCalls"]
+    t = Tableau(m, vibr, vibc, tab["unrestricted"], precision=tab["precision"],
+                row_capacity=tab["height"] + max(len(c["cuts"] or []) for c in calls) + extra_rows, lib=lib)
+    res, rhs, rows = t.applyCuts([], check_cycles=True)
+    assert G.sha_rhs(rhs, rows) == calls[0]["rhsSha"]
+    t.save()
+    return t, calls
+
+
+def _check_pool(lib, n_members, reps):
+    """a pool of n members reproduces the reference's outcome (sha256 of RHS column + row map) of every node Monster_II's
+    branch-and-bound visits, `reps` times over, in both read-back flavours"""
+    g = G.load(MONSTER_II)
+    t, calls = _root(lib, g)
+    nodes = [c["cuts"] or [] for c in calls[1:]] * reps
+    want = [c for c in calls[1:]] * reps
+    pool = DevicePool(t, [0] * n_members)
+    assert pool.size == n_members
+    for copy in (True, False):
+        results, rhs, rows = pool.applyCutsBatch(nodes, check_cycles=True, copy=copy)
+        assert len(nodes) == 151 * reps
+        for i, call in enumerate(want):
+            h = results[i].height
+            assert bool(results[i].feasible) == call["feasible"] and h == call["height"]
+            assert G.sha_rhs(rhs[i, :h], rows[i, :h]) == call["rhsSha"], (copy, i)
+    # a new root (here: the same tableau saved again after one more relaxation) is fanned out again by itself
+    first = nodes[0]
+    t.applyCuts(first, check_cycles=True)
+    t.save()
+    results, rhs, rows = pool.applyCutsBatch([[], []] * n_members, check_cycles=True)
+    ref_res, ref_rhs, ref_rows = t.applyCuts([], check_cycles=True)
+    for i in range(2 * n_members):
+        h = results[i].height
+        assert h == ref_res.height and G.sha_rhs(rhs[i, :h], rows[i, :h]) == G.sha_rhs(ref_rhs, ref_rows)
+    pool.close()
+    t.close()
+
+
+def test_pool_reproduces_monster_ii_nodes_oracle(oracle_lib):
+    _check_pool(oracle_lib, 3, 1)
+
+
+@pytest.mark.gpu
+def test_pool_of_four_virtual_devices_reproduces_monster_ii_nodes(hip_lib):
+    _check_pool(hip_lib, 4, 3)  # 453 nodes over 4 engines / streams / host threads on the one GPU
+
+
+def _check_watched(lib):
+    g = G.load(MONSTER_II)
+    t, calls = _root(lib, g)
+    from jslpsolver_amd import Model
+    ints = [int(v) for v in Model(g["model"]).integer_index_array]  # model.integerVariables' indexes, as the host has them
+    t.set_watched_variables(ints)
+    for call in calls[1:40]:
+        cuts = call["cuts"] or []
+        res_w, rows_w, vals_w = t.applyCutsWatched(cuts, check_cycles=True)
+        res, rhs, vibr = t.applyCuts(cuts, check_cycles=True)
+        assert res_w.as_dict() == res.as_dict()
+        row_of = {int(v): r for r, v in enumerate(vibr) if r > 0}
+        for i, v in enumerate(ints):
+            r = row_of.get(v, -1)
+            assert rows_w[i] == r
+            assert vals_w[i] == (rhs[r] if r > 0 else 0.0)
+    t.close()
+
+
+def test_watched_read_back_equals_full_read_back_oracle(oracle_lib):
+    _check_watched(oracle_lib)
+
+
+@pytest.mark.gpu
+def test_watched_read_back_equals_full_read_back_hip(hip_lib):
+    _check_watched(hip_lib)
+
+
+def _counted_batch(lib, n_nodes=60):
+    g = G.load(MONSTER_II)
+    t, calls = _root(lib, g)
+    t.set_counting(True)
+    nodes = [c["cuts"] or [] for c in calls[1:1 + n_nodes]]
+    t.applyCutsBatch(nodes, check_cycles=True)
+    c = t.get_counters()
+    t.set_counting(False)
+    t.close()
+    want_pivots = sum(c2["p1"] + max(c2["p2"], 0) for c2 in calls[1:1 + n_nodes])
+    return c, want_pivots
+
+
+def test_work_counters_oracle(oracle_lib):
+    c, want_pivots = _counted_batch(oracle_lib)
+    assert c["relaxations"] == 60 and c["simplex_calls"] == 60 and c["pivots"] == want_pivots > 0
+    assert c["gated_cells"] >= c["gated_rows"] > 0 and c["cut_rows"] > 0
+    assert c["restored_rows"] >= 60 * 935  # the reference restores every row of the root
+
+
+@pytest.mark.gpu
+def test_work_counters_hip_equal_the_oracles(hip_lib, oracle_lib):
+    """the kernels' own count of the cells simplex.ts:376-387 touches equals the sequential restatement's; only the
+    restore differs by design (dirty rows instead of the whole matrix)"""
+    a, _ = _counted_batch(hip_lib)
+    b, _ = _counted_batch(oracle_lib)
+    for k in ("relaxations", "simplex_calls", "pivots", "gated_cells", "gated_rows", "cut_rows", "height_sum"):
+        assert a[k] == b[k], (k, a, b)
+    assert 0 < a["restored_rows"] < b["restored_rows"]
+
+
+def _check_host_matrix(lib):
+    m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, 100, 100)
+    t = Tableau(m, vibr, vibc, lib=lib)
+    ref = t.simplex(check_cycles=True)
+    ref_final = t.download()[0]
+    buf = t.host_matrix()  # pinned build buffer: zero-filled, the host writes the tableau cell by cell
+    assert buf.shape == m.shape and not buf.any()
+    buf[:, :] = m
+    t.upload(buf, vibr, vibc)
+    res = t.simplex(check_cycles=True)
+    assert res.as_dict() == ref.as_dict() and t.download()[0].tobytes() == ref_final.tobytes()
+    assert pivot_digest(t.pivot_trace()[-20:]) == "b5dedd09"  # the reference's digest for N = 100
+    assert not t.host_matrix().any()  # zero-filled again
+    t.close()
+
+
+def test_host_matrix_oracle(oracle_lib):
+    _check_host_matrix(oracle_lib)
+
+
+@pytest.mark.gpu
+def test_host_matrix_hip(hip_lib):
+    _check_host_matrix(hip_lib)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("abort_at", [0, 7, 150])
+def test_resident_abort_rolls_back_and_resolves(hip_lib, abort_at, monkeypatch):
+    """a timed-out hand-off inside the register-resident kernel (forced: the last workgroup gives up at pivot `abort_at`)
+    must not leave the engine with advanced index maps over the old matrix: the solve is rolled back and re-run through
+    the streaming kernels, pivot for pivot the reference's"""
+    monkeypatch.setenv("JSLP_TEST_RESIDENT_ABORT", str(abort_at))
+    monkeypatch.setenv("JSLP_FORCE_PATH", "resident")
+    m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, 200, 200)
+    t = Tableau(m, vibr, vibc, lib=hip_lib)
+    res = t.simplex(check_cycles=True)
+    assert t.last_path() in ("fused", "select+update")
+    assert res.feasible and res.optimal and res.pivots_phase2 == 242
+    assert pivot_digest(t.pivot_trace()) == "27aaaa0b"
+    monkeypatch.delenv("JSLP_TEST_RESIDENT_ABORT")
+    t2 = Tableau(m, vibr, vibc, lib=hip_lib)
+    t2.simplex(check_cycles=True)
+    assert t2.last_path() == "resident"
+    a, b = t.download(), t2.download()
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+    t.close()
+    t2.close()
+
+
+@pytest.mark.gpu
+def test_pivot_trace_overflow_is_an_error(hip_lib):
+    """the trace holds 2^20 pivots since upload(); past that the pairs are refused instead of handed out truncated"""
+    from jslpsolver_amd._capi import EngineError
+    m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, 500, 500)
+    t = Tableau(m, vibr, vibc, lib=hip_lib)
+    t.save()
+    solves = (1 << 20) // 657 + 1
+    for _ in range(solves):
+        t.restore()
+        res = t.simplex(check_cycles=False)
+    assert res.pivots_phase2 == 657
+    with pytest.raises(EngineError, match="pivot_trace"):
+        t.pivot_trace()
+    t.upload(m, vibr, vibc)  # a new hand-over starts a new trace
+    t.simplex(check_cycles=False)
+    assert pivot_digest(t.pivot_trace()) == "1cda2607"
+    t.close()
