@@ -48,7 +48,22 @@ static struct {
     int (*read_rhs)(jslp_engine*, double*, int32_t*);
     int (*download)(jslp_engine*, double*, int32_t*, int32_t*, int32_t*, int32_t*);
     int (*pivot_trace)(jslp_engine*, int32_t*, int64_t, int64_t*);
+    int (*host_matrix)(jslp_engine*, double**, int64_t*);
+    int (*set_watched)(jslp_engine*, const int32_t*, int32_t);
+    int (*relax_watched)(jslp_engine*, int32_t, const int8_t*, const int32_t*, const double*, int, jslp_simplex_result*, int32_t*, double*);
+    int (*set_counting)(jslp_engine*, int);
+    int (*get_counters)(jslp_engine*, jslp_work_counters*);
+    int (*pool_create)(jslp_pool**, jslp_engine*, const int32_t*, int32_t);
+    void (*pool_destroy)(jslp_pool*);
+    int (*pool_size)(const jslp_pool*);
+    int (*pool_sync_root)(jslp_pool*);
+    int (*pool_relax_batch)(jslp_pool*, int32_t, const int32_t*, const int8_t*, const int32_t*, const double*, int,
+                            jslp_simplex_result*, double*, int32_t*, int32_t);
 } L;
+
+/* what a JS engine handle points at: the engine plus the dimensions it was created with (argument checks without a
+   device round trip) */
+typedef struct { jslp_engine* e; int32_t h0, w, cap; } ebox;
 
 #define THROW(env, msg)                       \
     do {                                      \
@@ -107,15 +122,20 @@ static jslp_engine* handle(napi_env env, napi_value v) {
         napi_throw_type_error(env, "JSLP", "engine handle expected");
         return NULL;
     }
-    jslp_engine* e = *(jslp_engine**)p;
+    jslp_engine* e = ((ebox*)p)->e;
     if (!e) napi_throw_error(env, "JSLP", "engine already destroyed");
     return e;
+}
+static const ebox* box_of(napi_env env, napi_value v) {
+    void* p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) return NULL;
+    return (const ebox*)p;
 }
 
 static void finalize_handle(napi_env env, void* data, void* hint) {
     (void)env; (void)hint;
-    jslp_engine** box = (jslp_engine**)data;
-    if (*box && L.destroy) L.destroy(*box);
+    ebox* box = (ebox*)data;
+    if (box->e && L.destroy) L.destroy(box->e);
     free(box);
 }
 
@@ -171,6 +191,10 @@ static napi_value fn_load(napi_env env, napi_callback_info info) {
     SYM(set_integer_variables, "jslp_engine_set_integer_variables"); SYM(apply_mir_cuts, "jslp_engine_apply_mir_cuts");
     SYM(checkpoint_create, "jslp_engine_checkpoint_create"); SYM(checkpoint_restore, "jslp_engine_checkpoint_restore");
     SYM(checkpoint_release, "jslp_engine_checkpoint_release"); SYM(relax_from, "jslp_engine_relax_from");
+    SYM(host_matrix, "jslp_engine_host_matrix"); SYM(set_watched, "jslp_engine_set_watched_variables");
+    SYM(relax_watched, "jslp_engine_relax_watched"); SYM(set_counting, "jslp_engine_set_counting");
+    SYM(get_counters, "jslp_engine_get_counters"); SYM(pool_create, "jslp_pool_create"); SYM(pool_destroy, "jslp_pool_destroy");
+    SYM(pool_size, "jslp_pool_size"); SYM(pool_sync_root, "jslp_pool_sync_root"); SYM(pool_relax_batch, "jslp_pool_relax_batch");
     napi_value s;
     NAPI_OK(env, napi_create_string_utf8(env, L.backend_name(), NAPI_AUTO_LENGTH, &s));
     return s;
@@ -198,8 +222,9 @@ static napi_value fn_create(napi_env env, napi_callback_info info) {
     NAPI_OK(env, napi_get_value_int32(env, argv[2], &cap));
     NAPI_OK(env, napi_get_value_double(env, argv[3], &precision));
     NAPI_OK(env, napi_get_value_int32(env, argv[4], &dev));
-    jslp_engine** box = (jslp_engine**)calloc(1, sizeof *box);
-    int rc = L.create(box, dev, h, w, cap, precision);
+    ebox* box = (ebox*)calloc(1, sizeof *box);
+    int rc = L.create(&box->e, dev, h, w, cap, precision);
+    box->h0 = h; box->w = w; box->cap = cap;
     if (rc != JSLP_OK) free(box);
     ENGINE_OK(env, rc, "jslp_engine_create");
     napi_value ext;
@@ -212,8 +237,8 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 1, argv)) return NULL;
     void* p = NULL;
     if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
-        jslp_engine** box = (jslp_engine**)p;
-        if (*box) { L.destroy(*box); *box = NULL; }
+        ebox* box = (ebox*)p;
+        if (box->e) { L.destroy(box->e); box->e = NULL; }
     }
     return NULL;
 }
@@ -229,10 +254,10 @@ static napi_value fn_upload(napi_env env, napi_callback_info info) {
     if (!typed(env, argv[1], napi_float64_array, &m, &nm) || !typed(env, argv[2], napi_int32_array, &r, &nr) ||
         !typed(env, argv[3], napi_int32_array, &c, &nc) || !typed(env, argv[4], napi_int32_array, &u, &nu))
         return NULL;
-    int32_t H, W;
-    ENGINE_OK(env, L.dims(e, NULL, &W, NULL), "jslp_engine_dims");
-    (void)H;
-    if (nc < (size_t)W || nm < (size_t)W) THROW(env, "upload: arrays shorter than the tableau");
+    const ebox* b = box_of(env, argv[0]);
+    if (!m || !r || !c) THROW(env, "upload: matrix, varIndexByRow and varIndexByCol are required");
+    if (nm < (size_t)b->h0 * (size_t)b->w || nr < (size_t)b->h0 || nc < (size_t)b->w)
+        THROW(env, "upload: arrays shorter than the tableau (height x width cells, height rows, width columns)");
     ENGINE_OK(env, L.upload(e, (const double*)m, (const int32_t*)r, (const int32_t*)c, (const int32_t*)u, (int32_t)nu),
               "jslp_engine_upload");
     return NULL;
@@ -347,6 +372,10 @@ static napi_value fn_relax(napi_env env, napi_callback_info info) {
     NAPI_OK(env, napi_get_value_bool(env, argv[4], &check));
     if (!typed(env, argv[5], napi_float64_array, &rhs, &nrhs) || !typed(env, argv[6], napi_int32_array, &rows, &nrows)) return NULL;
     if (nt != nv || nv != nx) THROW(env, "relax: array lengths differ");
+    {   /* the engine writes `height after the cuts` entries, at most the row capacity */
+        const ebox* b = box_of(env, argv[0]);
+        if ((rhs && nrhs < (size_t)b->cap) || (rows && nrows < (size_t)b->cap)) THROW(env, "relax: output arrays shorter than the row capacity");
+    }
     /* the engine writes `height after the cuts` entries: bounded by the created row capacity, which the host passed
        to create() and sized its output arrays by */
     jslp_simplex_result r;
@@ -435,6 +464,10 @@ static napi_value fn_relax_from(napi_env env, napi_callback_info info) {
     NAPI_OK(env, napi_get_value_bool(env, argv[5], &check));
     if (!typed(env, argv[6], napi_float64_array, &rhs, &nrhs) || !typed(env, argv[7], napi_int32_array, &rows, &nrows)) return NULL;
     if (nt != nv || nv != nx) THROW(env, "relaxFrom: array lengths differ");
+    {
+        const ebox* b = box_of(env, argv[0]);
+        if (!rhs || !rows || nrhs < (size_t)b->cap || nrows < (size_t)b->cap) THROW(env, "relaxFrom: output arrays shorter than the row capacity");
+    }
     const int32_t offs[2] = {0, (int32_t)nt};
     /* one node: the stride only has to cover the row capacity, which is what the host sized its arrays by */
     const int32_t stride = (int32_t)(nrhs < nrows ? nrhs : nrows);
@@ -462,6 +495,8 @@ static napi_value fn_relax_batch(napi_env env, napi_callback_info info) {
     NAPI_OK(env, napi_get_value_int32(env, argv[8], &stride));
     if (no < 1) THROW(env, "relaxBatch: offsets must hold n_nodes + 1 entries");
     const int32_t n_nodes = (int32_t)no - 1;
+    if (nt != nv || nv != nx || (size_t)((const int32_t*)o)[n_nodes] != nt) THROW(env, "relaxBatch: offsets[n_nodes] must equal the length of the cut arrays");
+    if (stride < box_of(env, argv[0])->cap) THROW(env, "relaxBatch: stride below the row capacity");
     if ((rhs && nrhs < (size_t)n_nodes * (size_t)stride) || (rows && nrows < (size_t)n_nodes * (size_t)stride))
         THROW(env, "relaxBatch: output arrays shorter than n_nodes * stride");
     jslp_simplex_result* res = (jslp_simplex_result*)calloc((size_t)(n_nodes > 0 ? n_nodes : 1), sizeof *res);
@@ -505,9 +540,12 @@ static napi_value fn_read_rhs(napi_env env, napi_callback_info info) {
     void *rhs, *rows;
     size_t n1, n2;
     if (!typed(env, argv[1], napi_float64_array, &rhs, &n1) || !typed(env, argv[2], napi_int32_array, &rows, &n2)) return NULL;
-    int32_t H;
-    ENGINE_OK(env, L.dims(e, &H, NULL, NULL), "jslp_engine_dims");
-    if ((rhs && n1 < (size_t)H) || (rows && n2 < (size_t)H)) THROW(env, "readRhs: output arrays shorter than the height");
+    const ebox* b = box_of(env, argv[0]);
+    if ((rhs && n1 < (size_t)b->cap) || (rows && n2 < (size_t)b->cap)) {  /* shorter than the capacity: check the live height */
+        int32_t H;
+        ENGINE_OK(env, L.dims(e, &H, NULL, NULL), "jslp_engine_dims");
+        if ((rhs && n1 < (size_t)H) || (rows && n2 < (size_t)H)) THROW(env, "readRhs: output arrays shorter than the height");
+    }
     ENGINE_OK(env, L.read_rhs(e, (double*)rhs, (int32_t*)rows), "jslp_engine_read_rhs");
     return NULL;
 }
@@ -549,6 +587,206 @@ static napi_value fn_pivot_trace(napi_env env, napi_callback_info info) {
     return ta;
 }
 
+/* hostMatrix(h) -> Float64Array (height x width) over the engine's PINNED build buffer (jslp_engine_host_matrix): the host
+   builds the tableau straight into DMA-able memory and passes the very array to upload().  The engine owns
+   the memory: the binding detaches the array (detach()) before it destroys the engine. */
+static void release_keep(napi_env env, void* data, void* hint) {
+    (void)data;
+    if (hint) napi_delete_reference(env, (napi_ref)hint);
+}
+static napi_value fn_host_matrix(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    double* m = NULL;
+    int64_t n = 0;
+    ENGINE_OK(env, L.host_matrix(e, &m, &n), "jslp_engine_host_matrix");
+    napi_value ab, ta;
+    /* the view keeps the engine handle alive: a garbage-collected handle destroys the engine (finalize_handle), which must
+       not happen while JS can still reach the engine's memory through this array */
+    napi_ref keep = NULL;
+    NAPI_OK(env, napi_create_reference(env, argv[0], 1, &keep));
+    NAPI_OK(env, napi_create_external_arraybuffer(env, m, (size_t)n * sizeof(double), release_keep, keep, &ab));
+    NAPI_OK(env, napi_create_typedarray(env, napi_float64_array, (size_t)n, ab, 0, &ta));
+    return ta;
+}
+
+/* detach(typedArray): the array (a hostMatrix() view) becomes zero-length, its memory goes back to the engine */
+static napi_value fn_detach(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    bool is = false;
+    if (napi_is_typedarray(env, argv[0], &is) != napi_ok || !is) THROW(env, "detach: typed array expected");
+    napi_typedarray_type ty; size_t len, off; void* data; napi_value ab;
+    NAPI_OK(env, napi_get_typedarray_info(env, argv[0], &ty, &len, &data, &ab, &off));
+    NAPI_OK(env, napi_detach_arraybuffer(env, ab));
+    return NULL;
+}
+
+/* setWatchedVariables(h, Int32Array varIndexes) */
+static napi_value fn_set_watched(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    void* v; size_t n;
+    if (!typed(env, argv[1], napi_int32_array, &v, &n)) return NULL;
+    ENGINE_OK(env, L.set_watched(e, (const int32_t*)v, (int32_t)n), "jslp_engine_set_watched_variables");
+    return NULL;
+}
+
+/* relaxWatched(h, type, varIndex, value, checkCycles, Int32Array watchedRow, Float64Array watchedValue) -> result */
+static napi_value fn_relax_watched(napi_env env, napi_callback_info info) {
+    napi_value argv[7];
+    if (!get_args(env, info, 7, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    void *t, *v, *x, *wr, *wv;
+    size_t nt, nv, nx, nwr, nwv;
+    bool check;
+    if (!typed(env, argv[1], napi_int8_array, &t, &nt) || !typed(env, argv[2], napi_int32_array, &v, &nv) ||
+        !typed(env, argv[3], napi_float64_array, &x, &nx))
+        return NULL;
+    NAPI_OK(env, napi_get_value_bool(env, argv[4], &check));
+    if (!typed(env, argv[5], napi_int32_array, &wr, &nwr) || !typed(env, argv[6], napi_float64_array, &wv, &nwv)) return NULL;
+    if (nt != nv || nv != nx) THROW(env, "relaxWatched: array lengths differ");
+    /* the engine writes one entry per watched variable: the host sized both arrays by the list it registered, and the
+       engine refuses lists longer than the row capacity */
+    if (!wr || !wv || nwr != nwv) THROW(env, "relaxWatched: watchedRow and watchedValue must have one entry per watched variable");
+    jslp_simplex_result r;
+    ENGINE_OK(env, L.relax_watched(e, (int32_t)nt, (const int8_t*)t, (const int32_t*)v, (const double*)x, check ? 1 : 0, &r,
+                                   (int32_t*)wr, (double*)wv), "jslp_engine_relax_watched");
+    return result_object(env, &r);
+}
+
+/* setCounting(h, on) / getCounters(h) -> {relaxations, simplexCalls, pivots, gatedCells, gatedRows, restoredRows, cutRows, heightSum} */
+static napi_value fn_set_counting(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    bool on;
+    NAPI_OK(env, napi_get_value_bool(env, argv[1], &on));
+    ENGINE_OK(env, L.set_counting(e, on ? 1 : 0), "jslp_engine_set_counting");
+    return NULL;
+}
+static napi_value fn_get_counters(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    jslp_work_counters c;
+    ENGINE_OK(env, L.get_counters(e, &c), "jslp_engine_get_counters");
+    napi_value o, v;
+    NAPI_OK(env, napi_create_object(env, &o));
+    SET_D("relaxations", (double)c.relaxations); SET_D("simplexCalls", (double)c.simplex_calls); SET_D("pivots", (double)c.pivots);
+    SET_D("gatedCells", (double)c.gated_cells); SET_D("gatedRows", (double)c.gated_rows); SET_D("restoredRows", (double)c.restored_rows);
+    SET_D("cutRows", (double)c.cut_rows); SET_D("heightSum", (double)c.height_sum);
+    return o;
+}
+
+/* ---- device pool (jslp_pool_*) ---- */
+typedef struct { jslp_pool* p; int32_t cap; } pbox;
+static void finalize_pool(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    /* NOT destroyed here: the pool's members must go before the primary engine does, and finalisers run in no particular
+       order -- the binding destroys its pools explicitly (poolDestroy) before it destroys the primary */
+    free(data);
+}
+static jslp_pool* pool_handle(napi_env env, napi_value v, int32_t* cap) {
+    void* p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((pbox*)p)->p) {
+        napi_throw_type_error(env, "JSLP", "pool handle expected (or pool already destroyed)");
+        return NULL;
+    }
+    if (cap) *cap = ((pbox*)p)->cap;
+    return ((pbox*)p)->p;
+}
+/* poolCreate(h, Int32Array devices) -> pool handle; devices[0] = the primary's device, ordinals may repeat */
+static napi_value fn_pool_create(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    void* d; size_t n;
+    if (!typed(env, argv[1], napi_int32_array, &d, &n)) return NULL;
+    if (!d || n < 1) THROW(env, "poolCreate: at least one device ordinal");
+    pbox* box = (pbox*)calloc(1, sizeof *box);
+    box->cap = box_of(env, argv[0])->cap;
+    int rc = L.pool_create(&box->p, e, (const int32_t*)d, (int32_t)n);
+    if (rc != JSLP_OK) free(box);
+    ENGINE_OK(env, rc, "jslp_pool_create");
+    napi_value ext;
+    NAPI_OK(env, napi_create_external(env, box, finalize_pool, NULL, &ext));
+    return ext;
+}
+static napi_value fn_pool_destroy(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    void* p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+        pbox* box = (pbox*)p;
+        if (box->p) { L.pool_destroy(box->p); box->p = NULL; }
+    }
+    return NULL;
+}
+static napi_value fn_pool_size(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    jslp_pool* p = pool_handle(env, argv[0], NULL);
+    if (!p) return NULL;
+    napi_value v;
+    NAPI_OK(env, napi_create_int32(env, L.pool_size(p), &v));
+    return v;
+}
+static napi_value fn_pool_sync_root(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    jslp_pool* p = pool_handle(env, argv[0], NULL);
+    if (!p) return NULL;
+    ENGINE_OK(env, L.pool_sync_root(p), "jslp_pool_sync_root");
+    return NULL;
+}
+/* poolRelaxBatch(pool, Int32Array offsets, type, varIndex, value, checkCycles, rhsOut|null, rowsOut|null, stride) -> [result] */
+static napi_value fn_pool_relax_batch(napi_env env, napi_callback_info info) {
+    napi_value argv[9];
+    if (!get_args(env, info, 9, argv)) return NULL;
+    int32_t cap = 0;
+    jslp_pool* p = pool_handle(env, argv[0], &cap);
+    if (!p) return NULL;
+    void *o, *t, *v, *x, *rhs, *rows;
+    size_t no, nt, nv, nx, nrhs, nrows;
+    bool check;
+    int32_t stride;
+    if (!typed(env, argv[1], napi_int32_array, &o, &no) || !typed(env, argv[2], napi_int8_array, &t, &nt) ||
+        !typed(env, argv[3], napi_int32_array, &v, &nv) || !typed(env, argv[4], napi_float64_array, &x, &nx))
+        return NULL;
+    NAPI_OK(env, napi_get_value_bool(env, argv[5], &check));
+    if (!typed(env, argv[6], napi_float64_array, &rhs, &nrhs) || !typed(env, argv[7], napi_int32_array, &rows, &nrows)) return NULL;
+    NAPI_OK(env, napi_get_value_int32(env, argv[8], &stride));
+    if (no < 1) THROW(env, "poolRelaxBatch: offsets must hold n_nodes + 1 entries");
+    const int32_t n_nodes = (int32_t)no - 1;
+    if (nt != nv || nv != nx || (size_t)((const int32_t*)o)[n_nodes] != nt) THROW(env, "poolRelaxBatch: offsets[n_nodes] must equal the length of the cut arrays");
+    if (stride < cap) THROW(env, "poolRelaxBatch: stride below the row capacity");
+    if ((rhs && nrhs < (size_t)n_nodes * (size_t)stride) || (rows && nrows < (size_t)n_nodes * (size_t)stride))
+        THROW(env, "poolRelaxBatch: output arrays shorter than n_nodes * stride");
+    jslp_simplex_result* res = (jslp_simplex_result*)calloc((size_t)(n_nodes > 0 ? n_nodes : 1), sizeof *res);
+    int rc = L.pool_relax_batch(p, n_nodes, (const int32_t*)o, (const int8_t*)t, (const int32_t*)v, (const double*)x,
+                                check ? 1 : 0, res, (double*)rhs, (int32_t*)rows, stride);
+    if (rc != JSLP_OK) free(res);
+    ENGINE_OK(env, rc, "jslp_pool_relax_batch");
+    napi_value arr;
+    if (napi_create_array_with_length(env, (size_t)n_nodes, &arr) != napi_ok) { free(res); THROW(env, "array"); }
+    for (int32_t i = 0; i < n_nodes; i++) {
+        napi_value ro = result_object(env, &res[i]);
+        if (!ro) { free(res); return NULL; }
+        napi_set_element(env, arr, (uint32_t)i, ro);
+    }
+    free(res);
+    return arr;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"load", fn_load}, {"deviceCount", fn_device_count}, {"create", fn_create}, {"destroy", fn_destroy},
@@ -559,6 +797,10 @@ static napi_value init(napi_env env, napi_value exports) {
         {"releasePooledResources", fn_release_pooled}, {"setIntegerVariables", fn_set_integer_variables}, {"applyMirCuts", fn_apply_mir_cuts},
         {"checkpointCreate", fn_checkpoint_create}, {"checkpointRestore", fn_checkpoint_restore},
         {"checkpointRelease", fn_checkpoint_release}, {"relaxFrom", fn_relax_from},
+        {"hostMatrix", fn_host_matrix}, {"detach", fn_detach}, {"setWatchedVariables", fn_set_watched}, {"relaxWatched", fn_relax_watched},
+        {"setCounting", fn_set_counting}, {"getCounters", fn_get_counters},
+        {"poolCreate", fn_pool_create}, {"poolDestroy", fn_pool_destroy}, {"poolSize", fn_pool_size},
+        {"poolSyncRoot", fn_pool_sync_root}, {"poolRelaxBatch", fn_pool_relax_batch},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

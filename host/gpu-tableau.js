@@ -44,17 +44,33 @@ function eligible(t, opts) {
     return bypass === 0 && !(opts.minCells > 0 && t.width * t.height < opts.minCells);
 }
 
-function activate(t, opts) {
-    if (!eligible(t, opts)) {
-        t.__gpu = { active: false };
-        return t.__gpu;
-    }
+// the engine of a tableau whose dimensions are known (Tableau.initialize ran); the upload follows in activate()
+function createEngine(t, opts) {
     const nInts = t.model ? t.model.getNumberOfIntegerVariables() : 0;
     const incremental = !!(t.branchAndCutService && t.branchAndCutService.__gpuIncremental);
     // <= one "min" and one "max" cut per integer variable for the services that start every node from the root
     const useMir = !!(t.model && t.model.useMIRCuts);
     const rowCapacity = t.height + 2 * nInts + 8 + (incremental ? INCREMENTAL_EXTRA_ROWS : 0) + (useMir ? MIR_EXTRA_ROWS : 0);
     const h = addon.create(t.height, t.width, rowCapacity, t.precision, opts.device || 0);
+    return { h, rowCapacity, height: t.height, width: t.width, nInts, useMir, pinnedMatrix: null };
+}
+
+function activate(t, opts) {
+    if (t.__gpuReleased) throw new Error("[gpu-tableau] this tableau's engine was released when Solve() returned; " +
+        "use Solve(model, precision, true) (or model.solve()) to keep working with the tableau");
+    if (!eligible(t, opts)) {
+        t.__gpu = { active: false };
+        return t.__gpu;
+    }
+    // built in the engine's pinned buffer by the initialize() override?  (same dimensions, nothing appended since)
+    let pre = t.__gpuEngine || null;
+    t.__gpuEngine = null;
+    if (pre && (pre.height !== t.height || pre.width !== t.width)) {
+        addon.destroy(pre.h);
+        pre = null;
+    }
+    const made = pre || createEngine(t, opts);
+    const h = made.h, rowCapacity = made.rowCapacity, nInts = made.nInts, useMir = made.useMir;
     const rows = Int32Array.from(t.varIndexByRow);
     const cols = Int32Array.from(t.varIndexByCol);
     rows[0] = -1;
@@ -95,8 +111,27 @@ function activate(t, opts) {
         pendingRestore: false,
         pendingCuts: null,
         saved: null,
+        pinnedMatrix: made.pinnedMatrix,
+        pool: null,
     };
     return t.__gpu;
+}
+
+// drop the device side of a tableau: pools first (their members hold copies of this engine's root), the pinned view of
+// the build buffer is detached (the memory belongs to the engine), then the engine itself
+function dropEngine(t, st, keepMatrix) {
+    if (st.pool) {
+        addon.poolDestroy(st.pool);
+        st.pool = null;
+    }
+    if (st.pinnedMatrix) {
+        // (a finished tableau -- release() -- is not worth a copy of its stale host matrix: detaching leaves it zero-length)
+        if (t.matrix === st.pinnedMatrix && keepMatrix) t.matrix = new Float64Array(st.pinnedMatrix);
+        addon.detach(st.pinnedMatrix);
+        st.pinnedMatrix = null;
+    }
+    addon.destroy(st.h);
+    st.active = false;
 }
 
 let installedOpts = {};
@@ -207,6 +242,45 @@ function install(Tableau, options) {
     const P = Tableau.prototype;
     const orig = { simplex: P.simplex, save: P.save, restore: P.restore, addCutConstraints: P.addCutConstraints,
         applyMIRCuts: P.applyMIRCuts, updateVariableValues: P.updateVariableValues, getSolution: P.getSolution };
+
+    // SURVEY.md 8f.4: Tableau.initialize (tableau.ts:292-317) allocates `matrix`, _resetMatrix (:319-380) fills it cell by
+    // cell.  For tableaus that go to the engine the array is a view of the engine's PINNED build buffer, so the upload that
+    // follows is one DMA straight from where the host built the tableau (no pageable staging copy).
+    const origInitialize = P.initialize;
+    P.initialize = function (width, height, variables, unrestrictedVars) {
+        origInitialize.call(this, width, height, variables, unrestrictedVars);
+        if (this.__gpu) { // a tableau that is set up again (setModel twice): start over
+            if (this.__gpu.active) dropEngine(this, this.__gpu, false);
+            this.__gpu = undefined;
+        }
+        if (opts.pinnedBuild === false || !eligible(this, opts)) return;
+        const made = createEngine(this, opts);
+        made.pinnedMatrix = addon.hostMatrix(made.h); // zero-filled like the Float64Array it replaces (tableau.ts:304)
+        this.matrix = made.pinnedMatrix;
+        this.__gpuEngine = made;
+    };
+
+    // The post-solve editing API (dynamic-modification.ts: updateRightHandSide, updateConstraintCoefficient, updateCost,
+    // addConstraint, removeConstraint, addVariable, removeVariable, putInBase / takeOutOfBase -> pivot) and copy() work on the
+    // HOST matrix and maps, which are stale while the tableau lives on the device (only the RHS column is mirrored).  They
+    // first bring the tableau home -- full read-back, engine dropped -- and the next simplex() uploads the edited tableau.
+    const editing = ["updateRightHandSide", "updateConstraintCoefficient", "updateCost", "addConstraint", "removeConstraint",
+        "addVariable", "removeVariable", "putInBase", "takeOutOfBase", "pivot"];
+    const origEditing = {};
+    for (const name of editing) {
+        if (typeof P[name] !== "function") continue;
+        origEditing[name] = P[name];
+        P[name] = function () {
+            bringHome(this);
+            return origEditing[name].apply(this, arguments);
+        };
+    }
+    const origCopy = P.copy;
+    P.copy = function () {
+        const st = this.__gpu;
+        if (st && st.active) { flush(this); sync(this); }
+        return origCopy.call(this);
+    };
 
     // the two readers of EVERY row's value (tableau.ts:256-257; keep_solutions inside the services): complete the host copy first
     P.updateVariableValues = function () {
@@ -355,6 +429,9 @@ function install(Tableau, options) {
         P.applyMIRCuts = orig.applyMIRCuts;
         P.updateVariableValues = orig.updateVariableValues;
         P.getSolution = orig.getSolution;
+        P.initialize = origInitialize;
+        P.copy = origCopy;
+        for (const name of Object.keys(origEditing)) P[name] = origEditing[name];
         if (opts.solver) {
             if (hadOwnSelect) opts.solver.selectBranchAndCutService = origSelect;
             else delete opts.solver.selectBranchAndCutService;
@@ -447,7 +524,13 @@ function relaxBatch(t, cutLists) {
         st.batchRows = new Int32Array(n * stride);
     }
     const check = t.model ? t.model.checkForCycles === true : false;
-    const results = addon.relaxBatch(st.h, offsets, type, varIndex, value, check, st.batchRhs, st.batchRows, stride);
+    // install(..., { devices: [0, 1, ...] }): the batch is split over one engine per listed device (jslp_pool_*: the saved
+    // root is fanned out over xGMI once per save(), every member has its own host thread and stream inside the library)
+    const devices = installedOpts.devices;
+    if (devices && devices.length > 1 && !st.pool) st.pool = addon.poolCreate(st.h, Int32Array.from(devices));
+    const results = st.pool
+        ? addon.poolRelaxBatch(st.pool, offsets, type, varIndex, value, check, st.batchRhs, st.batchRows, stride)
+        : addon.relaxBatch(st.h, offsets, type, varIndex, value, check, st.batchRhs, st.batchRows, stride);
     const out = new Array(n);
     for (let i = 0; i < n; i++) {
         const H = results[i].height;
@@ -490,7 +573,7 @@ function sync(t) {
     const rbv = new Int32Array(d.nVarIndexes);
     const cbv = new Int32Array(d.nVarIndexes);
     addon.download(st.h, m, rows, cols, rbv, cbv);
-    if (t.matrix.length < m.length) t.matrix = new Float64Array(m.length);
+    if (t.matrix.length < m.length || t.matrix === st.pinnedMatrix) t.matrix = new Float64Array(Math.max(m.length, st.rowCapacity * d.width));
     t.matrix.set(m);
     for (let r = 0; r < d.height; r++) t.varIndexByRow[r] = rows[r];
     for (let c = 0; c < d.width; c++) t.varIndexByCol[c] = cols[c];
@@ -507,17 +590,46 @@ function pivotTrace(t) {
     return st && st.active ? addon.pivotTrace(st.h) : null;
 }
 
+// Solve() returned a simplified result: the engine goes back to the library's resource pool.  The tableau is finished --
+// its host matrix was never kept in step with the device -- so any later simplex() on it throws instead of silently
+// solving a stale copy; Solve(model, precision, true) / model.solve() keep the engine for the post-solve API.
 function release(t) {
     const st = t.__gpu;
-    if (st && st.active) {
-        addon.destroy(st.h);
-        st.active = false;
+    if (t.__gpuEngine) { // built in pinned memory but never solved (e.g. presolve decided the model)
+        const made = t.__gpuEngine;
+        t.__gpuEngine = null;
+        addon.detach(made.pinnedMatrix);
+        addon.destroy(made.h);
+        t.__gpuReleased = true;
     }
+    if (st && st.active) {
+        dropEngine(t, st, false);
+        t.__gpuReleased = true;
+        t.__gpu = undefined;
+    }
+}
+
+// full read-back, then the tableau is an ordinary host tableau again (the next simplex() uploads it afresh)
+function bringHome(t) {
+    if (t.__gpuEngine) { // still being built in the pinned buffer: keep the contents, give the buffer back
+        const made = t.__gpuEngine;
+        t.__gpuEngine = null;
+        t.matrix = new Float64Array(made.pinnedMatrix);
+        addon.detach(made.pinnedMatrix);
+        addon.destroy(made.h);
+    }
+    const st = t.__gpu;
+    if (!st || !st.active) return;
+    if (st.pendingRestore || st.pendingCuts) throw new Error("[gpu-tableau] tableau edited between restore()/addCutConstraints() and simplex()");
+    flush(t);
+    sync(t);
+    dropEngine(t, st, true);
+    t.__gpu = undefined;
 }
 
 const api = {
     loadEngine, install, sync, pivotTrace, release, guardIncremental, createCheckpoint, relaxFromCheckpoint, releaseCheckpoint,
-    relaxBatch, commitOutcome, isOnEngine,
+    relaxBatch, commitOutcome, isOnEngine, bringHome,
     backend: () => backend,
 };
 module.exports = api;

@@ -32,6 +32,33 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
         strategyBase[f + JSON.stringify(v)] = JSON.stringify(solver.Solve(m));
     }
 }
+// the post-solve editing API (dynamic-modification.ts through Model.updateRightHandSide / updateCost /
+// updateConstraintCoefficient / smallerThan / removeConstraint, then model.solve() again): same sequence on the unpatched
+// reference first, then under the binding, where every edit brings the tableau home and the next solve uploads it again
+function editScript(file) {
+    const out = [];
+    const snap = (sol) => JSON.stringify([sol.feasible, sol.bounded, num(sol.evaluation), sol.generateSolutionSet()]);
+    solver.Solve(JSON.parse(JSON.stringify(loadGolden(strategyDir, file + ".json.gz").model)), undefined, true);
+    const model = solver.lastSolvedModel;
+    const c0 = model.constraints[0], c1 = model.constraints[model.constraints.length - 1];
+    const v0 = model.variables[0], v1 = model.variables[model.variables.length - 1];
+    model.updateRightHandSide(c0, c0.isUpperBound ? 3 : -3);
+    out.push(snap(model.solve()));
+    model.setCost(v1.cost + 1.5, v1);
+    out.push(snap(model.solve()));
+    model.updateConstraintCoefficient(c1, v0, 0.25);
+    out.push(snap(model.solve()));
+    const extra = model.smallerThan(1e6);
+    extra.addTerm(1, v0);
+    extra.addTerm(2, v1);
+    out.push(snap(model.solve()));
+    model.removeConstraint(extra);
+    out.push(snap(model.solve()));
+    return out;
+}
+const editFiles = ["Berlin_Air_Lift_Problem", "Wiki_1", "Monster_Problem", "Shift_Work_Problem"];
+const editBase = {};
+if (!filter && dir.indexOf("fixtures") >= 0) for (const f of editFiles) editBase[f] = editScript(f);
 let uninstall = gpu.install(Tableau, { SlackVariable, solver });
 
 function num(x) {
@@ -198,6 +225,53 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
         }
     }
 }
+// the editing API under the binding (see editScript above)
+let editOk = 0;
+for (const f of Object.keys(editBase)) {
+    const got = editScript(f);
+    for (let i = 0; i < got.length; i++) {
+        if (got[i] === editBase[f][i]) editOk += 1;
+        else { fail += 1; console.log("FAIL edit", f, "step", i); }
+    }
+    gpu.bringHome(solver.lastSolvedModel.tableau);
+}
+// a tableau whose engine went back to the pool when Solve() returned must refuse further solves (never a stale host copy)
+let releasedOk = 0;
+if (!filter && dir.indexOf("fixtures") >= 0) {
+    solver.Solve(JSON.parse(JSON.stringify(loadGolden(strategyDir, "Monster_Problem.json.gz").model)));
+    try {
+        solver.lastSolvedModel.tableau.simplex();
+        fail += 1; console.log("FAIL released tableau solved again");
+    } catch (e) {
+        if (/released/.test(String(e.message))) releasedOk += 1; else { fail += 1; console.log("FAIL released:", e.message); }
+    }
+}
+// install(..., { speculate: 16, devices: [0, 0, 0, 0] }): the speculative batches split over a device pool (jslp_pool_*;
+// here four engines on device 0 -- "virtual devices" -- each with its own stream and host thread inside the library)
+let poolOk = 0;
+if (!filter && dir.indexOf("fixtures") >= 0) {
+    uninstall();
+    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16, devices: [0, 0, 0, 0] });
+    for (const f of fs.readdirSync(dir).filter((x) => x.endsWith(".json.gz")).sort()) {
+        const g = loadGolden(dir, f);
+        if (!g.model || !g.tableau || g.tableau.integerVarIndexes.length === 0) continue;
+        const o = g.model.options || {};
+        if (o.nodeSelection || o.branching || o.useMIRCuts || o.useIncremental) continue;
+        const m = JSON.parse(JSON.stringify(g.model));
+        if (m.options) delete m.options.timeout;
+        const solution = solver.Solve(m, undefined, true);
+        const res = solver.buildSimplifiedResult(solution);
+        const got = {};
+        for (const k of Object.keys(res)) got[k] = num(res[k]);
+        const bad = [];
+        if (JSON.stringify(Object.keys(res)) !== JSON.stringify(g.resultKeys)) bad.push("keys");
+        if (JSON.stringify(got) !== JSON.stringify(g.result)) bad.push("values");
+        if (solution._tableau.branchAndCutIterations !== g.final.branchAndCutIterations) bad.push("B&B iterations");
+        const usedPool = !!(solution._tableau.__gpu && solution._tableau.__gpu.pool);
+        gpu.release(solution._tableau);
+        if (bad.length) { fail += 1; console.log("FAIL pool", f, bad.join("; ")); } else poolOk += usedPool ? 1 : 0;
+    }
+}
 // install(..., { minCells }): a host policy that leaves small tableaus on the reference's own path -- also under the injected services
 let policyOk = 0;
 if (!filter && dir.indexOf("fixtures") >= 0) {
@@ -221,5 +295,5 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
 }
 console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk,
     incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk,
-    size_policy_ok: policyOk, fuzz_ok: fuzzOk }));
+    size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, pool_ok: poolOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);

@@ -38,33 +38,37 @@ def test_addon_exports_the_abi():
     out = subprocess.run(["node", "-e", "console.log(Object.keys(require(%r)).sort().join(','))" % ADDON],
                          capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
-    assert out.stdout.strip() == ("addCuts,applyMirCuts,checkpointCreate,checkpointRelease,checkpointRestore,create,destroy,"
-                                  "deviceCount,dims,download,getOptionalObjectives,load,pivot,pivotTrace,readRhs,relax,"
-                                  "relaxBatch,relaxFrom,releasePooledResources,restore,save,setIntegerVariables,setOptionalObjectives,simplex,upload")
+    assert out.stdout.strip() == ("addCuts,applyMirCuts,checkpointCreate,checkpointRelease,checkpointRestore,create,destroy,detach,"
+                                  "deviceCount,dims,download,getCounters,getOptionalObjectives,hostMatrix,load,pivot,pivotTrace,"
+                                  "poolCreate,poolDestroy,poolRelaxBatch,poolSize,poolSyncRoot,readRhs,relax,relaxBatch,relaxFrom,"
+                                  "relaxWatched,releasePooledResources,restore,save,setCounting,setIntegerVariables,"
+                                  "setOptionalObjectives,setWatchedVariables,simplex,upload")
+
+
+# exact counts (not lower bounds): a regression that turns cases into skips must fail
+FIXTURE_COUNTS = {"fail": 0, "pass": 47, "solved_on_engine": 43, "strategy_variants_ok": 30, "incremental_ok": 114,
+                  "device_checkpoints": 577, "mir_ok": 67, "speculative_ok": 15, "size_policy_ok": 8, "fuzz_ok": 1063,
+                  "edit_ok": 20, "released_ok": 1, "pool_ok": 13}
+
+
+def _check_fixture_counts(r, backend):
+    assert r["backend"] == backend
+    assert {k: r[k] for k in FIXTURE_COUNTS} == FIXTURE_COUNTS
 
 
 def test_reference_host_with_oracle_engine(oracle_lib):
     _prepare()
-    r = _run(oracle_lib.path, "fixtures")
-    assert r["backend"] == "oracle-c" and r["fail"] == 0 and r["pass"] == 47 and r["solved_on_engine"] >= 43
-    assert r["strategy_variants_ok"] == 30  # enhanced B&B services over the same seam
-    # options.useIncremental: the reference's policy over device checkpoints (host/gpu-incremental-service.js)
-    assert r["incremental_ok"] >= 100 and r["device_checkpoints"] > 300
-    assert r["mir_ok"] >= 60  # options.useMIRCuts under the default, enhanced and incremental services
-    assert r["speculative_ok"] >= 12  # install(..., {speculate: 16}): same results and relaxation counts as the sequential run
-    assert r["size_policy_ok"] == 8  # install(..., {minCells}): small tableaus stay on the reference's own path
-    assert r["fuzz_ok"] >= 1000  # random MILPs / soft-constraint models incl. the ones the reference's presolve touches
+    # 47 reference fixtures; 30 enhanced-service variants; the incremental service over device checkpoints; MIR cuts;
+    # 16-node speculative batches; minCells size policy; 1063 random models incl. the ones the reference's presolve touches;
+    # the post-solve editing API (5 edits x 4 models); a released tableau refuses to solve; speculative batches over a pool
+    _check_fixture_counts(_run(oracle_lib.path, "fixtures"), "oracle-c")
     r = _run(oracle_lib.path, "synthetic", "40x")
-    assert r["fail"] == 0 and r["pass"] >= 12
+    assert r["fail"] == 0 and r["pass"] == 18
 
 
 @pytest.mark.gpu
 def test_reference_host_with_hip_engine(hip_lib):
     _prepare()
-    r = _run(hip_lib.path, "fixtures")
-    assert r["backend"] == "hip-gfx950" and r["fail"] == 0 and r["pass"] == 47 and r["solved_on_engine"] >= 43
-    assert r["strategy_variants_ok"] == 30
-    assert r["incremental_ok"] >= 100 and r["device_checkpoints"] > 300
-    assert r["mir_ok"] >= 60 and r["speculative_ok"] >= 12 and r["fuzz_ok"] >= 1000
+    _check_fixture_counts(_run(hip_lib.path, "fixtures"), "hip-gfx950")
     r = _run(hip_lib.path, "synthetic", "_")
-    assert r["fail"] == 0 and r["pass"] >= 40
+    assert r["fail"] == 0 and r["pass"] == 40  # every synthetic golden that stores its model
