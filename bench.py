@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- headline measurement (BASELINE.json): simplex pivots/sec on the synthetic dense LP
 generateResourceAllocation({seed:12345, numVariables:2000, numConstraints:2000, density:1.0}) (config 3a:
-2001 x 2001 fp64 tableau, 9726 pivots, cycle check off -- the FASTER reference setting), 1 GPU; with
---gpus N every rank solves its own replica (a single LP does not shard: SURVEY.md 8e "replicas only"), and
-the LP-relaxation throughput of the sharded branch-and-bound workload (config 4, Monster_II node batch,
-nodes split across ranks, no data-path collective) rides along in "relaxations".
+2001 x 2001 fp64 tableau, 9726 pivots, cycle check off -- the FASTER reference setting), 1 GPU; with --gpus N every
+rank solves its own replica (a single LP does not shard: SURVEY.md 8e "replicas only").  Riding along in the same JSON
+line: the same LP with the reference's DEFAULT cycle check on, the all-phase-1 instance 3b, and config 4's LP
+relaxations/sec (Monster_II): an independent node batch sharded over the ranks (weak scaling) and ONE real
+branch-and-bound tree sharded over the ranks with RCCL as the exchange step (strong scaling).
 
-A "step" = one complete simplex() of the workload with the tableau already resident in HBM (restored from
-the device-side snapshot; the 32 MB host upload happens once, outside the timed region).
+A "step" = one complete simplex() of the workload with the tableau already resident in HBM (restored from the
+device-side snapshot; the 32 MB host upload happens once, outside the timed region).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: spawns N ranks itself, one per GPU, RCCL)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Every result that has a reference answer is CHECKED (pivot digests of SURVEY.md
+Appendix C, the reference's per-node outcomes and final result of Monster_II): a wrong answer exits non-zero instead
+of printing a number.  GPU legs run back to back first; the CPU baselines (the reference itself under node) last.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -25,6 +30,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
+# pivot digests of the reference itself (options.exitOnCycles = false and the default give the same
+# pivots on these instances: no cycle is ever detected)
+DIGEST_3A = {100: "b5dedd09", 200: "27aaaa0b", 500: "1cda2607", 1000: "77bfa35c", 2000: "e8cab46c"}
+DIGEST_3B = {100: "7f16dba0", 200: "d9715450", 500: "1ff155dd", 1000: "854e8f4", 2000: "5dd32458"}
+PIVOTS_3A = {100: 20, 200: 242, 500: 657, 1000: 2833, 2000: 9726}
+
+
+class WrongAnswer(SystemExit):
+    def __init__(self, what):
+        super().__init__("bench.py: WRONG ANSWER -- %s" % what)
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside a torchrun world: launch N ranks (one per GPU, RCCL) and relay rank 0's line"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(n, sample_pivots):
@@ -41,24 +67,24 @@ def cpu_baseline(n, sample_pivots):
         return {"value": r["pivots_per_sec"], "unit": "pivots/s", "cores": 1, "kind": "reference",
                 "sample": "first %d of the %d pivots of the same %dx%d instance, reference TS (type-erased) under node %s, "
                           "options.exitOnCycles=false, simplex() time only; host has %d cores"
-                          % (r["pivots"], 9726 if n == 2000 else -1, n + 1, n + 1, r["node"], os.cpu_count())}
+                          % (r["pivots"], PIVOTS_3A.get(n, -1), n + 1, n + 1, r["node"], os.cpu_count())}
     except Exception as e:  # the baseline is reported, never required
         return {"value": None, "unit": "pivots/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
 
 
-def pmc_traffic(H, W, kernel):
-    """HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    separate runs, gfx950 FETCH_SIZE x2 correction): counters cannot be read from inside this process, so the
-    committed summary of the latest pass on this workload is reported, with its provenance."""
+def pmc_traffic(key, kernel, alg_bytes):
+    """HBM bytes per unit of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    runs, gfx950 FETCH_SIZE x2 correction): counters cannot be read from inside this process, so the committed summary of
+    the latest pass on this workload is reported with its provenance (tools/gpu_round.sh pmc regenerates it)."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as fh:
-            d = json.load(fh)
-        if abs(d["algorithmic_bytes_per_launch"] - 16.0 * H * W) > 1 or d["kernel"] != kernel:
-            return None, "profiles/pmc_latest.json is for another workload / kernel (%s)" % d["kernel"]
-        return d["traffic_bytes_per_launch"], "profiles/pmc_latest.json (%s; %s)" % (d["kernel"], d["source"])
+            d = json.load(fh)[key]
+        if d["kernel"] != kernel or abs(d["algorithmic_bytes_per_unit"] - alg_bytes) > 1e-3 * alg_bytes:
+            return None, "profiles/pmc_latest.json[%s] is for another workload / kernel (%s)" % (key, d["kernel"])
+        return d["traffic_bytes_per_unit"], "profiles/pmc_latest.json[%s] (%s; %s)" % (key, d["kernel"], d["source"])
     except Exception:
-        return None, "no PMC summary committed"
+        return None, "no PMC summary committed for %s" % key
 
 
 def main():
@@ -68,9 +94,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--lp-size", dest="n", type=int, default=2000, help="variables = constraints of the dense LP (2000 = config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-pivots", type=int, default=1200)
+    ap.add_argument("--cpu-sample-pivots", type=int, default=3000)
     ap.add_argument("--no-relaxations", action="store_true")
+    ap.add_argument("--only-relaxations", action="store_true", help="profiling runs: skip the dense-LP legs")
+    ap.add_argument("--no-extras", action="store_true", help="profiling runs: only the timed headline steps")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -81,6 +112,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     # one rank per GPU over RCCL.  JSLP_BENCH_BACKEND=gloo (tests only) lets several ranks share the one GPU of the
     # test box so that the N > 1 code path of this file can be exercised there.
     backend = os.environ.get("JSLP_BENCH_BACKEND", "nccl")
@@ -104,109 +137,151 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def max_over_ranks(x):
+    def reduce_ranks(x, op):
         if world == 1:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=red_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=op)
         return float(t.item())
 
-    def sum_over_ranks(x):
-        if world == 1:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=red_device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return float(t.item())
+    max_over_ranks = lambda x: reduce_ranks(x, dist.ReduceOp.MAX)
+    sum_over_ranks = lambda x: reduce_ranks(x, dist.ReduceOp.SUM)
+    ctx = {"lib": lib, "device": device_index, "rank": rank, "world": world, "barrier": barrier, "max": max_over_ranks,
+           "sum": sum_over_ranks, "group": dist.group.WORLD if world > 1 else None}
 
-    # ---- workload: config 3a ------------------------------------------------------------------------
+    line = None
     n = args.n
-    m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
-    H, W = m.shape
-    t = Tableau(m, vibr, vibc, device=device_index, lib=lib)
-    t.save()  # device-resident copy of the initial tableau: every step restarts from it without touching PCIe
+    if not args.only_relaxations:
+        # ---- workload: config 3a ------------------------------------------------------------------------
+        m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
+        H, W = m.shape
+        t = Tableau(m, vibr, vibc, device=device_index, lib=lib)
+        t.save()  # device-resident copy of the initial tableau: every step restarts from it without touching PCIe
 
-    def step():
-        t.restore()
-        return t.simplex(check_cycles=False)
+        def timed_steps(check_cycles, warmup, steps):
+            """W untimed + K timed steps bracketed by barrier + synchronize, max over ranks; the dominant kernel is
+            event-timed inside the SAME steps (HIP events on the engine's stream)"""
+            import gc
+            res = None
+            for _ in range(warmup):
+                t.restore()
+                res = t.simplex(check_cycles=check_cycles)
+            gc.collect()
+            gc.disable()  # keep CPython's cyclic collector out of the timed region (re-enabled right after it)
+            t.set_timing(True)
+            barrier()
+            t0 = time.perf_counter()
+            pivots = 0
+            for _ in range(steps):
+                t.restore()
+                res = t.simplex(check_cycles=check_cycles)
+                pivots += res.pivots_phase1 + max(res.pivots_phase2, 0)
+            barrier()
+            elapsed = max_over_ranks(time.perf_counter() - t0)
+            kern_ms, launches, _total_ms = t.get_timing()
+            t.set_timing(False)
+            gc.enable()
+            return res, pivots, elapsed, kern_ms, launches
 
-    res = None
-    for _ in range(args.warmup):
-        res = step()
-    import gc
-    gc.collect()
-    gc.disable()  # keep CPython's cyclic collector out of the timed region (re-enabled right after it)
-    barrier()
-    t0 = time.perf_counter()
-    pivots = 0
-    for _ in range(args.steps):
-        res = step()
-        pivots += res.pivots_phase1 + max(res.pivots_phase2, 0)
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    gc.enable()
-    total_pivots = sum_over_ranks(float(pivots))
-    value = total_pivots / elapsed
-    digest = pivot_digest(t.pivot_trace()[-(res.pivots_phase1 + max(res.pivots_phase2, 0)):])
-    pivots_per_solve = res.pivots_phase1 + max(res.pivots_phase2, 0)
+        res, pivots, elapsed, kern_ms, launches = timed_steps(False, args.warmup, args.steps)
+        total_pivots = sum_over_ranks(float(pivots))
+        value = total_pivots / elapsed
+        pivots_per_solve = res.pivots_phase1 + max(res.pivots_phase2, 0)
+        path_used = t.last_path()
+        evaluation = t.evaluation
 
-    # ---- roofline of the dominant kernel (k_update), measured live with HIP events on the engine's stream ---
-    roofline = None
-    if rank == 0:
-        t.set_timing(True)
-        step()
-        upd_ms, launches, total_ms = t.get_timing()
-        t.set_timing(False)
-        bytes_per_launch = 16.0 * H * W  # read + write every fp64 cell of the H x W tableau
-        avg_s = (upd_ms / 1e3) / max(launches, 1)
-        achieved = bytes_per_launch / avg_s if launches else 0.0
-        # the register-resident kernel runs ALL pivots of phase 2 in one launch; its unit of work stays one pivot
-        # (16*H*W algorithmic bytes), so "launch" below means "pivot" for it
+        def verify(check_cycles, want_digest, what):
+            """the answer of the path that was just timed: a fresh hand-over (new pivot trace), one solve, the digest"""
+            t.upload(m, vibr, vibc)
+            t.save()
+            r = t.simplex(check_cycles=check_cycles)
+            got = pivot_digest(t.pivot_trace())
+            if want_digest is not None and got != want_digest:
+                raise WrongAnswer("%s: pivot digest %s, the reference's is %s" % (what, got, want_digest))
+            if not (r.feasible and r.optimal):
+                raise WrongAnswer("%s: not solved to optimality" % what)
+            return got
+
+        digest = verify(False, DIGEST_3A.get(n), "config 3a (%d x %d), cycle check off" % (H, W))
+
+        # ---- roofline of the dominant kernel, from the timed steps themselves ---------------------------------------
+        # unit of work = one pivot = 16*H*W algorithmic bytes (SURVEY.md 8d); the register-resident kernel runs all pivots of
+        # a solve in ONE launch, so its per-unit time is (event-timed launch duration) / pivots
+        bytes_per_unit = 16.0 * H * W
         kernel_name = {"resident": "k_simplex_resident", "fused": "k_pivot_fused", "select+update": "k_update",
-                       "workgroup": "k_simplex_wg"}.get(t.last_path(), t.last_path())
-        traffic, traffic_note = pmc_traffic(H, W, kernel_name)
-        roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_note,
-                    "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches": launches,
-                    "whole_pivot_frac": (bytes_per_launch * value / max(world, 1)) / HBM_PEAK}
-    t.close()
+                       "workgroup": "k_simplex_wg"}.get(path_used, path_used)
+        roofline = None
+        if rank == 0:
+            avg_s = (kern_ms / 1e3) / max(launches, 1)
+            achieved = bytes_per_unit / avg_s if launches else 0.0
+            traffic, traffic_note = pmc_traffic("pivots", kernel_name, bytes_per_unit)
+            roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_note,
+                        "bytes_per_unit": bytes_per_unit, "unit_of_work": "one pivot (16*H*W algorithmic bytes)",
+                        "avg_unit_us": avg_s * 1e6, "units": launches, "timed_in": "the %d timed steps (HIP events on the engine's stream)" % args.steps,
+                        "whole_step_frac": (bytes_per_unit * value / max(world, 1)) / HBM_PEAK,
+                        "rocprof_hbm_gb_s": (traffic / avg_s / 1e9) if traffic else None}
 
-    # ---- the other config-3 instance (3b: generateRandomLP, every pivot is a phase-1 pivot; ends infeasible) ------------
-    phase1 = None
-    if rank == 0:
-        m1, vibr1, vibc1, _op = generators.dense_random_lp_tableau(12345, n, n)
-        t1 = Tableau(m1, vibr1, vibc1, device=device_index, lib=lib)
-        t1.save()
-        t1.simplex(check_cycles=False)
-        t1.restore()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        r1 = t1.simplex(check_cycles=False)
-        dt = time.perf_counter() - t0
-        phase1 = {"workload": "config 3b: generateRandomLP(seed 12345, %d x %d, density 1.0), phase 1 only" % (n, n),
-                  "pivots": r1.pivots_phase1, "feasible": bool(r1.feasible), "pivots_per_s": r1.pivots_phase1 / dt,
-                  "pivot_digest": pivot_digest(t1.pivot_trace()[-r1.pivots_phase1:]), "kernel": t1.last_path()}
-        t1.close()
+        extras = {}
+        if not args.no_extras:
+            # ---- the reference's DEFAULT: checkForCycles on (model.ts:73; simplex.ts:415-440 after every selection) ----------
+            # (every rank runs it: the timed region is bracketed by the same barriers; rank 0 reports its own replica)
+            k2 = max(1, min(args.steps, 3))
+            r2, piv2, el2, km2, ln2 = timed_steps(True, 1, k2)
+            d2 = verify(True, DIGEST_3A.get(n), "config 3a, cycle check on (the reference's default)")
+            extras["cycle_check_on"] = {"workload": "config 3a with options.exitOnCycles = true (the reference's default, src/model.ts:73)",
+                                        "value": sum_over_ranks(float(piv2)) / el2, "unit": "pivots/s", "steps": k2, "ms_per_step": 1e3 * el2 / k2,
+                                        "pivot_digest": d2, "kernel": t.last_path(),
+                                        "roofline_frac": (bytes_per_unit / ((km2 / 1e3) / max(ln2, 1))) / HBM_PEAK if ln2 else None}
+        t.close()
 
-    # ---- LP relaxations/sec: Monster_II node batch sharded over ranks (config 4, throughput variant) -----
+        # ---- the other config-3 instance (3b: generateRandomLP, every pivot is a phase-1 pivot; ends infeasible) -------------
+        if rank == 0 and not args.no_extras:
+            m1, vibr1, vibc1, _op = generators.dense_random_lp_tableau(12345, n, n)
+            t1 = Tableau(m1, vibr1, vibc1, device=device_index, lib=lib)
+            t1.save()
+            t1.simplex(check_cycles=False)
+            reps1 = max(1, min(args.steps, 3))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps1):
+                t1.restore()
+                r1 = t1.simplex(check_cycles=False)
+            dt = (time.perf_counter() - t0) / reps1
+            d1 = pivot_digest(t1.pivot_trace()[-r1.pivots_phase1:])
+            if DIGEST_3B.get(n) is not None and (d1 != DIGEST_3B[n] or r1.feasible):
+                raise WrongAnswer("config 3b: digest %s feasible %s, the reference: %s infeasible" % (d1, bool(r1.feasible), DIGEST_3B[n]))
+            extras["phase1_instance"] = {"workload": "config 3b: generateRandomLP(seed 12345, %d x %d, density 1.0), phase 1 only" % (n, n),
+                                         "pivots": r1.pivots_phase1, "feasible": bool(r1.feasible), "pivots_per_s": r1.pivots_phase1 / dt,
+                                         "pivot_digest": d1, "kernel": t1.last_path()}
+            t1.close()
+
+        if rank == 0:
+            line = {
+                "metric": "simplex pivots/sec", "value": value, "unit": "pivots/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "config 3a: generateResourceAllocation(seed 12345, %d vars x %d constraints, density 1.0), "
+                                       "%dx%d fp64 tableau, %d pivots per solve, cycle check off; one replica per GPU"
+                                       % (n, n, H, W, pivots_per_solve),
+                           "pivot_digest": digest, "pivot_digest_checked_against": DIGEST_3A.get(n) and "SURVEY.md Appendix C (the reference's own trace)",
+                           "result_evaluation": evaluation, "parallelism": "replicas%d" % world,
+                           "rccl_ranks": world if (world > 1 and backend == "nccl") else 0},
+                "roofline": roofline,
+            }
+            line.update(extras)
+
+    # ---- LP relaxations/sec: Monster_II (config 4) ----------------------------------------------------------------------
     relax = None
     if not args.no_relaxations:
-        relax = relaxation_throughput(lib, device_index, rank, world, barrier, max_over_ranks, sum_over_ranks)
-
-    if rank == 0:
-        line = {
-            "metric": "simplex pivots/sec", "value": value, "unit": "pivots/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "config 3a: generateResourceAllocation(seed 12345, %d vars x %d constraints, density 1.0), "
-                                   "%dx%d fp64 tableau, %d pivots per solve, cycle check off; one replica per GPU"
-                                   % (n, n, H, W, pivots_per_solve),
-                       "pivot_digest": digest, "result_evaluation": t.evaluation, "parallelism": "replicas%d" % world},
-            "roofline": roofline,
-        }
-        if relax is not None:
+        relax = relaxation_legs(ctx, args)
+        if line is not None and relax is not None:
             line["relaxations"] = relax
-        if phase1 is not None:
-            line["phase1_instance"] = phase1
+        elif rank == 0 and relax is not None:
+            line = {"metric": "LP relaxations/sec", "value": relax["value"], "unit": relax["unit"], "n_gpus": world, "relaxations": relax}
+
+    # ---- CPU baselines last: the GPU legs above ran back to back -----------------------------------------------------
+    if rank == 0 and line is not None:
         if not args.no_cpu_baseline and world == 1:
             if relax is not None:
                 relax["cpu_baseline"] = cpu_relaxation_baseline()
@@ -214,21 +289,40 @@ def main():
                     relax["speedup_vs_cpu_1_thread"] = relax["value"] / relax["cpu_baseline"]["value"]
                     if relax["cpu_baseline"].get("aggregate_value"):
                         relax["speedup_vs_cpu_all_cores"] = relax["value"] / relax["cpu_baseline"]["aggregate_value"]
-            line["cpu_baseline"] = cpu_baseline(n, args.cpu_sample_pivots)
-            if line["cpu_baseline"] and line["cpu_baseline"].get("value"):
-                line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+            if not args.only_relaxations:
+                line["cpu_baseline"] = cpu_baseline(n, args.cpu_sample_pivots)
+                if line["cpu_baseline"] and line["cpu_baseline"].get("value"):
+                    line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 
 
-def relaxation_throughput(lib, device, rank, world, barrier, max_over_ranks, sum_over_ranks, reps=16):
-    """Config 4 throughput variant: the 151 cut lists the reference visits on Monster_II,
-    replicated `reps` times, evaluated as independent nodes; rank r takes nodes r, r+world, ... (no collective
-    in the data path).  Needs the committed golden fixture for the cut lists only."""
+def gated_bytes(c, W, n_idx, H_root):
+    """Algorithmic bytes of the counted relaxations: what restore + addCutConstraints + simplex + read-back have
+    to move given what the reference's loops touch -- rows restored / appended (read + write a row), per pivot the
+    selection reads (cost row, pivot column, RHS column), the pivot row (read + write) and the gated cells
+    (simplex.ts:370-387: read + write), the index maps restored per relaxation, the read-back."""
+    row = 16.0 * W
+    return (row * (c["restored_rows"] + c["cut_rows"]) + c["pivots"] * (row + 8.0 * W) + 16.0 * c["height_sum"] * c["pivots"] / max(c["simplex_calls"], 1)
+            + 16.0 * c["gated_cells"] + c["relaxations"] * 8.0 * (H_root + W + 2 * n_idx) + 12.0 * c["height_sum"])
+
+
+def relaxation_legs(ctx, args, reps=16):
+    """Config 4.
+    (i)  throughput variant: the 151 cut lists the reference visits on Monster_II x reps, evaluated as independent nodes;
+         rank r takes nodes r, r+world, ... (weak scaling: reps x 151 per rank, no collective in the data path);
+    (ii) the same batch once more with the kernels' work counters on -> gated algorithmic bytes -> roofline fraction;
+    (iii) ONE real tree: Solve(Monster_II) with speculative batches of 8 x world nodes sharded over the ranks, outcomes
+         all-gathered (RCCL) -- strong scaling of the tree itself (SURVEY.md 8e: ~3.5x at 4, ~5.3x at 8 GPUs);
+    (iv) N = 1 only: the batch of (i) through the engine's own device pool with 4 virtual devices on the one GPU."""
     import gzip
-    from jslpsolver_amd import Model
-    from jslpsolver_amd.engine import Tableau
+    import gc
+    import numpy as np
+    from jslpsolver_amd import Model, Solve
+    from jslpsolver_amd.engine import DevicePool, Tableau
+    lib, device, rank, world = ctx["lib"], ctx["device"], ctx["rank"], ctx["world"]
+    barrier, max_over_ranks, sum_over_ranks = ctx["barrier"], ctx["max"], ctx["sum"]
     path = os.path.join(ROOT, "tests", "golden", "fixtures", "Monster_II.json.gz")
     if not os.path.exists(path):
         return None
@@ -236,54 +330,107 @@ def relaxation_throughput(lib, device, rank, world, barrier, max_over_ranks, sum
         g = json.load(fh)
     model = Model(g["model"])
     m, vibr, vibc = model.build_tableau()
-    # weak scaling: every rank evaluates reps x 151 nodes whatever the world size
-    nodes = [c["cuts"] or [] for c in g["simplexCalls"][1:]] * (reps * world)
+    H, W = m.shape
+    calls = g["simplexCalls"][1:]
+    nodes = [c["cuts"] or [] for c in calls] * (reps * world)
     mine = nodes[rank::world]
-    t = Tableau(m, vibr, vibc, model.unrestricted, precision=model.precision,
-                row_capacity=m.shape[0] + 2 * len(model.integerVariables), device=device, lib=lib)
+    cap = H + 2 * len(model.integerVariables)
+    t = Tableau(m, vibr, vibc, model.unrestricted, precision=model.precision, row_capacity=cap, device=device, lib=lib)
     t.applyCuts([], check_cycles=True)  # root relaxation
     t.save()
-    # the cut lists are flattened once (host-side input preparation, like the tableau build); the timed call is the
-    # engine entry point itself: restore + add cuts + simplex + RHS / row-map read-back for every node
     packed = t.pack_cut_lists(mine)
-    per_call = []
-    # warm-up: the first call allocates the slots and restores them in full; and the GPU has been idle while the host
-    # built the model: ~10-15 ms into a new burst of work one call stalls for ~6 ms (clock ramp), so warm up past that
-    for _ in range(25):
+
+    def check_outcomes(results, rhs, rows, which, what):
+        """every node's outcome against the reference's own (sha256 of RHS column + row map per relaxation)"""
+        for i, k in enumerate(which):
+            call = calls[k % len(calls)]
+            h = results[i].height
+            sha = hashlib.sha256(np.ascontiguousarray(rhs[i, :h]).tobytes() + np.ascontiguousarray(rows[i, :h]).tobytes()).hexdigest()
+            if h != call["height"] or bool(results[i].feasible) != call["feasible"] or sha != call["rhsSha"]:
+                raise WrongAnswer("%s: node %d differs from the reference's relaxation outcome" % (what, k))
+
+    def timed_calls(fn, warm, calls_n):
+        per_call = []
+        for _ in range(warm):
+            fn()
+        gc.collect()
+        gc.disable()  # a generation-2 pass of CPython's collector (~6 ms over the model's dicts) otherwise lands in a random call
+        barrier()
         t0 = time.perf_counter()
-        t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
-        per_call.append(time.perf_counter() - t0)
-    calls = 10
-    import gc
-    gc.collect()
-    gc.disable()  # a generation-2 pass of CPython's collector (~6 ms over the model's dicts) otherwise lands in a random call
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(calls):
-        t1 = time.perf_counter()
-        results, rhs, rows = t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
-        per_call.append(time.perf_counter() - t1)
-    barrier()
-    el = max_over_ranks(time.perf_counter() - t0) / calls
-    gc.enable()
+        out = None
+        for _ in range(calls_n):
+            t1 = time.perf_counter()
+            out = fn()
+            per_call.append(time.perf_counter() - t1)
+        barrier()
+        el = max_over_ranks(time.perf_counter() - t0) / calls_n
+        gc.enable()
+        return out, el, per_call
+
+    # (i) the first call allocates the slots and restores them in full; ~10-15 ms into a new burst of work one call stalls
+    # for ~6 ms (clock ramp): warm up past that
+    fn = lambda: t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+    (results, rhs, rows), el, per_call = timed_calls(fn, 25, 10)
+    if rank == 0:
+        check_outcomes(results, rhs, rows, list(range(rank, len(nodes), world)), "relaxation batch")
     total = sum_over_ranks(float(len(mine)))
-    my_pivots = [results[i].pivots_phase1 + max(results[i].pivots_phase2, 0) for i in range(len(mine))]
-    piv = sum_over_ranks(float(sum(my_pivots)))
-    # algorithmic bytes of one relaxation: restore = 16*H*W, then p pivots of 16*H'*W with H' = H + #cuts
-    H, W = m.shape
-    my_bytes = sum(16.0 * H * W + p * 16.0 * results[i].height * W for i, p in enumerate(my_pivots))
-    alg_bytes = sum_over_ranks(float(my_bytes))
+    piv = sum_over_ranks(float(sum(results[i].pivots_phase1 + max(results[i].pivots_phase2, 0) for i in range(len(mine)))))
+    out = {"value": total / el, "unit": "LP relaxations/s", "nodes": int(total), "pivots": int(piv), "seconds": el,
+           "calls_averaged": 10, "per_call_us": [round(1e6 * x) for x in per_call], "scaling": "weak",
+           "outcomes_checked": "sha256(RHS column + row map) of every node of the last call == the reference's (rank 0's share)",
+           "workload": "config 4: Monster_II (935x925 root, 112 ints), the reference's 151 visited cut lists x%d as one batch of "
+                       "independent nodes per rank, sharded round-robin over %d rank(s)" % (reps, world)}
+    # (ii) gated algorithmic bytes from the kernels' own counters (a separate, untimed pass over the same batch)
+    if rank == 0:
+        t.set_counting(True)
+        fn()
+        c = t.get_counters()
+        t.set_counting(False)
+        n_idx = W + 2 * cap + 2
+        alg = gated_bytes(c, W, n_idx, H)
+        per_node = alg / max(c["relaxations"], 1)
+        traffic, note = pmc_traffic("relaxations", "k_node_wg", per_node)
+        dense = 16.0 * H * W * (c["relaxations"] + c["pivots"])  # SURVEY.md 8d's dense figure, for reference only
+        rate_rank0 = len(mine) / el
+        out["roofline"] = {"bound": "hbm", "kernel": "k_node_wg", "achieved": per_node * rate_rank0 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                           "frac": per_node * rate_rank0 / HBM_PEAK, "bytes_per_unit": per_node, "unit_of_work": "one LP relaxation",
+                           "traffic": traffic, "traffic_source": note,
+                           "traffic_over_algorithmic": (traffic / per_node) if traffic else None,
+                           "counters": c, "dense_bytes_per_unit_survey_8d": dense / max(c["relaxations"], 1),
+                           "note": "algorithmic bytes = what restore + addCutConstraints + simplex + read-back must move for the cells the "
+                                   "reference's own loops touch (gated rows x live pivot-row columns, counted by the kernels: "
+                                   "jslp_work_counters); SURVEY.md 8d's dense 16*H*W per restore and per pivot would be %.1fx that"
+                                   % (dense / max(alg, 1.0))}
+    # (iv) the engine's own device pool (single process): 4 virtual devices on this GPU
+    if world == 1:
+        pool = DevicePool(t, [device] * 4)
+        fnp = lambda: pool.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+        (r4, rhs4, rows4), el4, per4 = timed_calls(fnp, 10, 10)
+        check_outcomes(r4, rhs4, rows4, list(range(len(nodes))), "device pool batch")
+        out["pool_virtual4"] = {"value": len(mine) / el4, "unit": "LP relaxations/s", "members": pool.size,
+                                "note": "jslp_pool_relax_batch_pinned: the same batch split over 4 engines (own stream + host thread each) on "
+                                        "the one visible GPU; on a multi-GPU node the members sit on different devices and the root is "
+                                        "fanned out with hipMemcpyPeerAsync", "per_call_us": [round(1e6 * x) for x in per4]}
+        pool.close()
     t.close()
-    return {"value": total / el, "unit": "LP relaxations/s", "nodes": int(total), "pivots": int(piv), "seconds": el,
-            "calls_averaged": calls, "per_call_us": [round(1e6 * x) for x in per_call[-calls:]],
-            "roofline": {"bound": "latency (per-node kernel); hbm for reference", "achieved": alg_bytes / el / 1e9 / world,
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s per GPU", "frac": alg_bytes / el / world / HBM_PEAK,
-                         "note": "algorithmic bytes per relaxation = 16*H*W (restore) + pivots * 16*H'*W as SURVEY.md 8d defines "
-                                 "them (dense update of every cell); the per-node kernel restores only dirty rows and updates "
-                                 "only the rows/columns the reference's zero gate touches, so its real HBM traffic is far "
-                                 "below this figure and the fraction can exceed 1"},
-            "workload": "config 4: Monster_II (935x925 root, 112 ints), the reference's 151 visited cut lists x%d as one "
-                        "batch of independent nodes per rank, sharded round-robin over %d rank(s) (weak scaling)" % (reps, world)}
+    # (iii) strong scaling: one real branch-and-bound tree, speculative batches of 8 x world nodes sharded over the ranks
+    group = ctx["group"]
+    spec = 8 * world
+    want = {k: (float(v) if isinstance(v, (int, float)) and not isinstance(v, bool) else v) for k, v in g["result"].items()}
+
+    def solve_tree():
+        return Solve(g["model"], full=True, lib=lib, device=device, speculate=spec, group=group)
+
+    sol, el_tree, per_tree = timed_calls(solve_tree, 3, 5)
+    if sol["iter"] != g["final"]["branchAndCutIterations"] or sol["result"].get("result") != want.get("result"):
+        raise WrongAnswer("Monster_II tree: result %r after %d relaxations, the reference: %r after %d"
+                          % (sol["result"].get("result"), sol["iter"], want.get("result"), g["final"]["branchAndCutIterations"]))
+    out["tree"] = {"workload": "one solver.Solve(Monster_II): %d committed relaxations, speculative batches of %d nodes sharded over %d rank(s), "
+                               "outcomes all-gathered (%s)" % (sol["iter"], spec, world, "RCCL" if (world > 1 and os.environ.get("JSLP_BENCH_BACKEND", "nccl") == "nccl") else ("gloo" if world > 1 else "no exchange at N = 1")),
+                   "scaling": "strong", "ms_per_solve": 1e3 * el_tree, "solves_per_s": 1.0 / el_tree, "committed_relaxations_per_s": sol["iter"] / el_tree,
+                   "result": sol["result"].get("result"), "result_checked": "result and relaxation count == the reference's (%s, %d)" % (want.get("result"), g["final"]["branchAndCutIterations"]),
+                   "per_solve_ms": [round(1e3 * x, 2) for x in per_tree], "includes": "model parsing, upload, root LP, the whole tree and the read-back (host logic in Python)"}
+    return out if rank == 0 else None
 
 
 def cpu_relaxation_baseline(seconds=4.0):

@@ -1,20 +1,28 @@
-"""Multi-GPU sharding of the hot path: independent LP relaxations (branch-and-bound nodes) over ranks.
+"""Multi-GPU sharding of the hot path across PROCESSES: independent LP relaxations (branch-and-bound nodes) over ranks.
 
-One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the MI355X node, "gloo" in the CPU
-tests).  A node's relaxation is a pure function of (saved root tableau, cut list) (branch-and-cut.ts:33-37
-always restores the root), so the unit of sharding is the node: every rank owns an engine holding the SAME
-saved root -- each rank solves the root itself, which is cheaper than broadcasting a 7-23 MB tableau and keeps
-the data path free of collectives -- and evaluates nodes rank, rank+world, ... of a batch.  The only exchange
-step is the all-gather of the per-node outcomes (flags, evaluation, RHS column, row map: ~12 bytes per row per
-node); afterwards every rank holds every outcome and replays the same deterministic tree, so the incumbent is
-agreed on without a separate broadcast.
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the MI355X node, "gloo" in the CPU tests).
+A node's relaxation is a pure function of (saved root tableau, cut list) (branch-and-cut.ts:33-37 always restores the
+root), so the unit of sharding is the node: every rank owns an engine holding the SAME saved root and evaluates nodes
+rank, rank + world, ... of a batch with one engine call.  The one exchange step is the all-gather of the outcomes --
+per node the result struct (flags, evaluation = the bound the tree prunes with, pivot counts), the RHS column and the
+row map, ~12 bytes per row -- after which every rank holds every outcome and replays the same deterministic tree
+(speculation with in-order commit), so the incumbent is agreed on without a further broadcast.
+
+(Inside ONE process the same split over several GPUs is the engine's own device pool, jslp_pool_* in
+include/jslp_engine.h: host threads and peer copies instead of ranks and collectives.)
+
+The payload is assembled and taken apart with whole-array copies: the engine call leaves results, RHS columns and row
+maps in three contiguous arrays (jslp_engine_relax_batch_pinned), which are laid side by side into one byte matrix
+[node, RES | rhs | rows]; nothing here loops over nodes.
 """
+import ctypes
+
 import numpy as np
 
 from ._capi import SimplexResult
 from .branch_and_cut import _NodeEval
 
-_FIELDS = [name for name, _ in SimplexResult._fields_]
+RES_BYTES = ctypes.sizeof(SimplexResult)
 
 
 def shard(items, rank, world):
@@ -22,57 +30,95 @@ def shard(items, rank, world):
     return items[rank::world]
 
 
-def _pack(results, rhs, vibr, stride):
-    """[n, len(_FIELDS) + 2 * stride] float64: result fields, RHS row, row map (exact in a double)"""
-    n = len(results)
-    out = np.zeros((n, len(_FIELDS) + 2 * stride), dtype=np.float64)
-    for i, r in enumerate(results):
-        out[i, :len(_FIELDS)] = [float(getattr(r, f)) for f in _FIELDS]
-        h = r.height
-        out[i, len(_FIELDS):len(_FIELDS) + h] = rhs[i, :h]
-        out[i, len(_FIELDS) + stride:len(_FIELDS) + stride + h] = vibr[i, :h]
-    return out
+def node_bytes(stride):
+    """bytes of one node's outcome in the exchange payload (8-byte aligned)"""
+    return RES_BYTES + 8 * stride + 4 * stride + (4 * stride) % 8
 
 
-def _unpack(row, stride):
-    r = SimplexResult()
-    for j, (name, ctype) in enumerate(SimplexResult._fields_):
-        v = row[j]
-        setattr(r, name, float(v) if name in ("obj_cell", "evaluation") else int(v))
-    h = r.height
-    rhs = row[len(_FIELDS):len(_FIELDS) + h].copy()
-    vibr = row[len(_FIELDS) + stride:len(_FIELDS) + stride + h].astype(np.int32)
-    return _NodeEval(r, rhs, vibr)
+class ShardedOutcomes:
+    """every node's outcome after the all-gather; node i sits in rank (i % world)'s block at slot i // world"""
+
+    def __init__(self, blocks, n, world, stride):
+        self.blocks, self.n, self.world, self.stride = blocks, n, world, stride  # blocks: [world, per, node_bytes] uint8
+
+    def __len__(self):
+        return self.n
+
+    def _row(self, i):
+        return self.blocks[i % self.world, i // self.world]
+
+    def result(self, i):
+        return SimplexResult.from_buffer_copy(self._row(i)[:RES_BYTES].tobytes())
+
+    def rhs(self, i, height):
+        return self._row(i)[RES_BYTES:RES_BYTES + 8 * height].view(np.float64)
+
+    def rows(self, i, height):
+        o = RES_BYTES + 8 * self.stride
+        return self._row(i)[o:o + 4 * height].view(np.int32)
+
+    def node(self, i):
+        r = self.result(i)
+        return _NodeEval(r, self.rhs(i, r.height).copy(), self.rows(i, r.height).copy())
+
+    def heights(self):
+        """height of every node, vectorised (offset of `height` inside the result struct)"""
+        off = SimplexResult.height.offset
+        h = self.blocks[:, :, off:off + 4].copy().view(np.int32)[:, :, 0]  # [world, per]
+        idx = np.arange(self.n)
+        return h[idx % self.world, idx // self.world]
 
 
-def evaluate_nodes_sharded(tableau, cut_lists, check_cycles, group):
-    """Every rank calls this with the same `cut_lists`; returns the outcomes of ALL nodes on every rank."""
+def exchange_outcomes(local, n, group):
+    """all-gather of the per-rank payloads ([per, node_bytes] uint8, padded to equal size) -> ShardedOutcomes"""
     import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    per, nb = local.shape
+    t = torch.from_numpy(local)
+    if dist.get_backend(group) == "nccl":  # RCCL moves device memory: one H2D, the collective, one D2H
+        t = t.cuda(non_blocking=True)
+    out = torch.empty((world, per, nb), dtype=torch.uint8, device=t.device)
+    dist.all_gather_into_tensor(out.view(-1), t.view(-1), group=group)
+    return out.cpu().numpy() if out.is_cuda else out.numpy()
+
+
+def pack_local(results, rhs, rows, n_mine, per, stride):
+    """[per, node_bytes] uint8 from the engine's three output arrays (whole-array copies)"""
+    nb = node_bytes(stride)
+    local = np.zeros((per, nb), dtype=np.uint8)
+    if n_mine:
+        res = np.frombuffer(results, dtype=np.uint8, count=n_mine * RES_BYTES).reshape(n_mine, RES_BYTES)
+        local[:n_mine, :RES_BYTES] = res
+        local[:n_mine, RES_BYTES:RES_BYTES + 8 * stride] = np.ascontiguousarray(rhs[:n_mine]).view(np.uint8).reshape(n_mine, 8 * stride)
+        o = RES_BYTES + 8 * stride
+        local[:n_mine, o:o + 4 * stride] = np.ascontiguousarray(rows[:n_mine]).view(np.uint8).reshape(n_mine, 4 * stride)
+    return local
+
+
+def evaluate_nodes_sharded(tableau, cut_lists, check_cycles, group, packed_mine=None):
+    """Every rank calls this with the same `cut_lists`; returns the outcomes of ALL nodes on every rank
+    (ShardedOutcomes).  `packed_mine`: this rank's share already flattened by Tableau.pack_cut_lists."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n = len(cut_lists)
     stride = tableau.row_capacity
-    per = (n + world - 1) // world  # equal-sized contributions (padded) for all_gather
-    mine = shard(cut_lists, rank, world)
-    width = len(_FIELDS) + 2 * stride
-    local = np.zeros((per, width), dtype=np.float64)
-    if mine:
-        results, rhs, vibr = tableau.applyCutsBatch(mine, check_cycles=check_cycles)
-        local[:len(mine)] = _pack(results, rhs, vibr, stride)
-    use_cuda = dist.get_backend(group) == "nccl"
-    t = torch.from_numpy(local)
-    if use_cuda:
-        t = t.cuda()
-    gathered = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(gathered, t, group=group)  # the one exchange step of the sharded path
-    parts = [g.cpu().numpy() for g in gathered]
-    out = []
-    for i in range(n):
-        out.append(_unpack(parts[i % world][i // world], stride))
-    return out
+    per = (n + world - 1) // world  # equal-sized contributions (padded) for the all-gather
+    n_mine = len(range(rank, n, world))
+    results = rhs = rows = None
+    if n_mine:
+        packed = packed_mine if packed_mine is not None else tableau.pack_cut_lists(shard(cut_lists, rank, world))
+        results, rhs, rows = tableau.applyCutsBatch(None, check_cycles=check_cycles, packed=packed, copy=False)
+    local = pack_local(results, rhs, rows, n_mine, per, stride)
+    blocks = exchange_outcomes(local, n, group)  # the one exchange step of the sharded path
+    return ShardedOutcomes(blocks, n, world, stride)
 
 
 def make_sharded_evaluator(tableau, check_cycles, group):
-    return lambda cut_lists: evaluate_nodes_sharded(tableau, cut_lists, check_cycles, group)
+    def evaluate(cut_lists):
+        out = evaluate_nodes_sharded(tableau, cut_lists, check_cycles, group)
+        return [out.node(i) for i in range(len(out))]  # a speculative batch: a handful of nodes
+    return evaluate

@@ -44,9 +44,9 @@ def main():
     t.applyCuts([], check_cycles=True)
     t.save()
     nodes = [c["cuts"] or [] for c in calls[1:]]
-    evs = evaluate_nodes_sharded(t, nodes, True, dist.group.WORLD)
-    ok = len(evs) == len(nodes)
-    for ev, call in zip(evs, calls[1:]):
+    out = evaluate_nodes_sharded(t, nodes, True, dist.group.WORLD)
+    ok = len(out) == len(nodes) and [int(h) for h in out.heights()] == [c["height"] for c in calls[1:]]
+    for ev, call in zip([out.node(i) for i in range(len(out))], calls[1:]):
         ok = ok and bool(ev.res.feasible) == call["feasible"] and ev.res.height == call["height"]
         ok = ok and G.sha_rhs(ev.rhs, ev.vibr) == call["rhsSha"]
     report["cases"].append({"name": "Monster_II node batch", "ok": bool(ok)})

@@ -50,9 +50,11 @@ def test_bench_multi_rank_code_path_on_one_gpu(hip_lib):
     """bench.py's N > 1 branch (process group, barrier, max / sum over ranks, replica + sharded-relaxation accounting)
     with 2 ranks sharing the one GPU of the test box (gloo instead of RCCL): the JSON line must be well formed and the
     aggregate must count both ranks' pivots"""
+    # `python bench.py --gpus 2` as the driver types it for N = 1: bench.py spawns the two ranks itself
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", JSLP_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--lp-size", "500"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--lp-size", "500"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -60,4 +62,6 @@ def test_bench_multi_rank_code_path_on_one_gpu(hip_lib):
     assert line["config"]["pivot_digest"] == "1cda2607"  # the reference's digest for n = 500
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - 2 * 657) < 1e-6 * 2 * 657
     assert line["relaxations"]["nodes"] == 2 * 16 * 151
+    assert line["relaxations"]["tree"]["scaling"] == "strong" and line["relaxations"]["tree"]["result"] == 20631
+    assert line["cycle_check_on"]["pivot_digest"] == "1cda2607"
     assert "cpu_baseline" not in line

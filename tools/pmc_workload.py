@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""The two workloads of bench.py in a form whose units of work can be matched to kernel dispatches exactly, for the
+rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs: tools/gpu_round.sh pmc).
+  tools/pmc_workload.py pivots [n]   -> K solves of config 3a (k_simplex_resident: one dispatch per solve)
+  tools/pmc_workload.py relax        -> the 2416-node Monster_II batch, K one-launch calls (k_node_wg: 3 dispatches per call)
+Prints one JSON line: which kernel, how many dispatches of it to expect, how many units (pivots / relaxations) they did."""
+import gzip
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from jslpsolver_amd import Model, _capi, generators  # noqa: E402
+from jslpsolver_amd.engine import Tableau  # noqa: E402
+
+
+def pivots(n=2000, solves=2):
+    lib = _capi.load_hip()
+    m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
+    t = Tableau(m, vibr, vibc, lib=lib)
+    t.save()
+    total = 0
+    for _ in range(solves):
+        t.restore()
+        r = t.simplex(check_cycles=False)
+        total += r.pivots_phase1 + max(r.pivots_phase2, 0)
+    path = t.last_path()
+    t.close()
+    H, W = m.shape
+    print(json.dumps({"key": "pivots", "kernel": "k_simplex_resident" if path == "resident" else path, "dispatches": solves,
+                      "units": total, "unit": "pivot", "algorithmic_bytes_per_unit": 16.0 * H * W,
+                      "workload": "config 3a %dx%d fp64, %d solves" % (H, W, solves)}))
+
+
+def relax(calls=12, reps=16):
+    lib = _capi.load_hip()
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "fixtures", "Monster_II.json.gz"), "rt") as fh:
+        g = json.load(fh)
+    model = Model(g["model"])
+    m, vibr, vibc = model.build_tableau()
+    H, W = m.shape
+    cap = H + 2 * len(model.integerVariables)
+    t = Tableau(m, vibr, vibc, model.unrestricted, precision=model.precision, row_capacity=cap, lib=lib)
+    t.applyCuts([], check_cycles=True)
+    t.save()
+    nodes = [c["cuts"] or [] for c in g["simplexCalls"][1:]] * reps
+    packed = t.pack_cut_lists(nodes)
+    t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)  # first call: slots allocated + restored in full (other kernels)
+    for _ in range(calls):
+        t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+    # the same batch once more with the work counters on (host-side only here: the counting pass is not profiled separately)
+    t.set_counting(True)
+    t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+    c = t.get_counters()
+    t.set_counting(False)
+    t.close()
+    sys.path.insert(0, ROOT)
+    import bench
+    per_node = bench.gated_bytes(c, W, W + 2 * cap + 2, H) / c["relaxations"]
+    groups = (len(nodes) + 1023) // 1024
+    print(json.dumps({"key": "relaxations", "kernel": "k_node_wg", "dispatches": groups * (calls + 1), "units": len(nodes) * (calls + 1),
+                      "unit": "LP relaxation", "algorithmic_bytes_per_unit": per_node,
+                      "workload": "Monster_II %d-node batch, %d one-launch calls" % (len(nodes), calls + 1)}))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "pivots":
+        pivots(int(sys.argv[2]) if len(sys.argv) > 2 else 2000)
+    else:
+        relax()

@@ -12,10 +12,19 @@ const gpu = require(path.join(root, "host/gpu-tableau.js"));
 gpu.loadEngine(process.argv[3] ? { library: path.resolve(process.argv[3]) } : {});
 const addon = require(path.join(root, "addon/jslp_napi.node"));
 let inAddon = 0, calls = 0;
+let perFn = {};
 for (const k of Object.keys(addon)) {
     const f = addon[k];
     if (typeof f !== "function") continue;
-    addon[k] = function () { const t0 = process.hrtime.bigint(); try { return f.apply(this, arguments); } finally { inAddon += Number(process.hrtime.bigint() - t0) / 1e6; calls += 1; } };
+    addon[k] = function () {
+        const t0 = process.hrtime.bigint();
+        try { return f.apply(this, arguments); } finally {
+            const ms = Number(process.hrtime.bigint() - t0) / 1e6;
+            inAddon += ms; calls += 1;
+            const e = perFn[k] || (perFn[k] = [0, 0]);
+            e[0] += ms; e[1] += 1;
+        }
+    };
 }
 gpu.install(T, { SlackVariable, solver });
 const g = JSON.parse(zlib.gunzipSync(fs.readFileSync(path.join(root, "tests/golden/fixtures", process.argv[2] + ".json.gz"))).toString());
@@ -23,10 +32,11 @@ const origSolve = M.prototype.solve;
 let tSolve = 0;
 M.prototype.solve = function () { const t0 = process.hrtime.bigint(); try { return origSolve.apply(this, arguments); } finally { tSolve += Number(process.hrtime.bigint() - t0) / 1e6; } };
 for (let i = 0; i < 8; i++) {
-    inAddon = 0; tSolve = 0; calls = 0;
+    inAddon = 0; tSolve = 0; calls = 0; perFn = {};
     const m = JSON.parse(JSON.stringify(g.model));
     const t0 = process.hrtime.bigint();
     solver.Solve(m);
     const ms = Number(process.hrtime.bigint() - t0) / 1e6;
-    console.log("total", ms.toFixed(1), "ms; Model.solve", tSolve.toFixed(1), "; inside the addon", inAddon.toFixed(1), "over", calls, "calls");
+    console.log("total", ms.toFixed(2), "ms; Model.solve", tSolve.toFixed(2), "; inside the addon", inAddon.toFixed(2), "over", calls, "calls;",
+        Object.keys(perFn).map((k) => k + " " + perFn[k][0].toFixed(3) + "/" + perFn[k][1]).join(", "));
 }
