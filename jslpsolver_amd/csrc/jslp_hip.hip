@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -70,7 +71,8 @@ struct jslp_engine {
     double* d_rhs = nullptr; int32_t* d_rows = nullptr; DevState* d_states = nullptr;
     double* h_rhs = nullptr; int32_t* h_rows = nullptr; DevState* h_states = nullptr;
     size_t out_bytes_cap = 0;
-    DevState* h_state = nullptr;  // pinned, 1 entry
+    DevState* h_state = nullptr;  // pinned, 1 entry, followed by the completion flag of the one-launch node kernel
+    unsigned done_seq = 0;
     // upload staging (pinned): [matrix, row stride W | vibr | vibc | unrestricted list]; the matrix part is what
     // jslp_engine_host_matrix hands to the host to build the tableau in; d_up = device twin of the blob
     // (and of the matrix when it needs the W -> ld repack)
@@ -88,7 +90,8 @@ struct jslp_engine {
     // snapshot generation as the device pool sees it: bumped by save() and upload()
     unsigned long long root_seq = 0;
     // safety net of the register-resident kernel: copy of slot 0 taken before the cooperative launch
-    char* r_backup = nullptr; DevState* r_backup_st = nullptr;
+    char* r_arena = nullptr; size_t r_arena_bytes = 0;  // hand-off buffers + this backup in ONE allocation (parked in the resource pool)
+    DevState* r_backup_st = nullptr;
     double* rb_A = nullptr; int32_t *rb_vibr = nullptr, *rb_vibc = nullptr, *rb_rbv = nullptr, *rb_cbv = nullptr;
     unsigned spin_limit = 0; int test_abort_epoch = -1;
     int resident_fallbacks = 0;  // solves that were rolled back and re-run through the streaming kernels
@@ -119,6 +122,7 @@ struct jslp_engine {
     int no_resident = 0;
     int res_cpt = 2;  // columns per lane of the resident kernel (JSLP_RES_CPT=2|4)
     int one_launch_nodes = 1;  // JSLP_NO_NODE_KERNEL=1: single children go through the five-launch sequence
+    int use_wglds = 1;         // JSLP_NO_WGLDS=1: the generic one-workgroup kernels (global-memory selection state) only
     const char* last_path = "none";
     // timing
     int timing = 0;
@@ -198,6 +202,8 @@ struct PooledRes {
     char* d_cuts = nullptr; char* h_cuts = nullptr; size_t cuts_bytes = 0;  // staging of the cut lists
     char* d_out = nullptr; char* h_out = nullptr; size_t out_bytes = 0;     // read-back staging
     char* h_up = nullptr; size_t h_up_bytes = 0; char* d_up = nullptr; size_t d_up_bytes = 0;  // upload staging
+    char* r_arena = nullptr; size_t r_arena_bytes = 0;  // the resident kernel's hand-off buffers + backup
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_group = nullptr;  // read-back overlap of node batches
 };
 static std::mutex g_pool_mu;
 static std::vector<PooledRes> g_pool;
@@ -222,7 +228,7 @@ static bool pool_take(int device, PooledRes* out) {
 }
 static bool pool_give(const PooledRes& r) {
     if (!pool_enabled() || r.static_bytes > POOL_MAX_ARENA || r.slot_bytes > POOL_MAX_ARENA || r.out_bytes > POOL_MAX_ARENA / 4 ||
-        r.h_up_bytes > POOL_MAX_ARENA / 4)
+        r.h_up_bytes > POOL_MAX_ARENA / 4 || r.r_arena_bytes > POOL_MAX_ARENA)
         return false;
     std::lock_guard<std::mutex> lk(g_pool_mu);
     if (g_pool.size() >= POOL_MAX_ENTRIES) return false;
@@ -242,7 +248,9 @@ extern "C" void jslp_release_pooled_resources(void) {
         if (r.h_cuts) hipHostFree(r.h_cuts);
         if (r.h_out) hipHostFree(r.h_out);
         if (r.h_up) hipHostFree(r.h_up);
-        hipFree(r.d_up);
+        hipFree(r.d_up); hipFree(r.r_arena);
+        if (r.ev_group) hipEventDestroy(r.ev_group);
+        if (r.copy_stream) hipStreamDestroy(r.copy_stream);
         if (r.h_state) hipHostFree(r.h_state);
         if (r.ev_begin) hipEventDestroy(r.ev_begin);
         if (r.ev_end) hipEventDestroy(r.ev_end);
@@ -377,6 +385,8 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     if (rcpt && rcpt[0] == '2') e->res_cpt = 2;
     const char* nk = getenv("JSLP_NO_NODE_KERNEL");
     if (nk && nk[0] == '1') e->one_launch_nodes = 0;
+    const char* nl = getenv("JSLP_NO_WGLDS");
+    if (nl && nl[0] == '1') e->use_wglds = 0;
     const char* nt = getenv("JSLP_NT");
     e->nt = (nt && nt[0] == '1') ? 1 : 0;
     const char* sl = getenv("JSLP_SPIN_LIMIT");  // polls before a hand-off of the resident kernel gives up (tests shorten it)
@@ -393,6 +403,8 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
             e->d_cuts = pooled.d_cuts; e->h_cuts = pooled.h_cuts; e->cuts_bytes = pooled.cuts_bytes;
             e->d_out = pooled.d_out; e->h_out = pooled.h_out; e->out_bytes_cap = pooled.out_bytes;
             e->h_up = pooled.h_up; e->h_up_bytes = pooled.h_up_bytes; e->d_up = pooled.d_up; e->d_up_bytes = pooled.d_up_bytes;
+            e->r_arena = pooled.r_arena; e->r_arena_bytes = pooled.r_arena_bytes;
+            e->copy_stream = pooled.copy_stream; e->ev_group = pooled.ev_group;
         } else {
             HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         }
@@ -426,7 +438,8 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
         int r = ensure_slots(e, 1);
         if (r) return r;
         if (!have) {
-            HIPC(hipHostMalloc(&e->h_state, sizeof(DevState)));
+            HIPC(hipHostMalloc(&e->h_state, sizeof(DevState) + 64));
+            memset(e->h_state, 0, sizeof(DevState) + 64);
             HIPC(hipEventCreate(&e->ev_begin));
             HIPC(hipEventCreate(&e->ev_end));
         }
@@ -454,21 +467,23 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
         r.d_cuts = e->d_cuts; r.h_cuts = e->h_cuts; r.cuts_bytes = e->cuts_bytes;
         r.d_out = e->d_out; r.h_out = e->h_out; r.out_bytes = e->out_bytes_cap;
         r.h_up = e->h_up; r.h_up_bytes = e->h_up_bytes; r.d_up = e->d_up; r.d_up_bytes = e->d_up_bytes;
+        r.r_arena = e->r_arena; r.r_arena_bytes = e->r_arena_bytes;
+        r.copy_stream = e->copy_stream; r.ev_group = e->ev_group;
         parked = pool_give(r);
     }
     free_slots(e, parked);
     if (parked) {
         e->static_arena = nullptr; e->h_state = nullptr; e->ev_begin = e->ev_end = nullptr; e->stream = nullptr;
-        e->d_cuts = e->h_cuts = nullptr; e->d_out = e->h_out = nullptr; e->h_up = e->d_up = nullptr;
+        e->d_cuts = e->h_cuts = nullptr; e->d_out = e->h_out = nullptr; e->h_up = e->d_up = nullptr; e->r_arena = nullptr;
+        e->copy_stream = nullptr; e->ev_group = nullptr;
     }
     if (e->h_up) hipHostFree(e->h_up);
-    hipFree(e->d_up); hipFree(e->d_watch); hipFree(e->d_cnt); hipFree(e->r_backup);
+    hipFree(e->d_up); hipFree(e->d_watch); hipFree(e->d_cnt); hipFree(e->r_arena);
     hipFree(e->static_arena); hipFree(e->snap_oo);
     drop_checkpoints(e, 1);
     hipFree(e->arena32);
     hipFree(e->f_buf1); hipFree(e->f_cands[0]); hipFree(e->f_cands[1]); hipFree(e->f_pcol[0]); hipFree(e->f_pcol[1]);
     hipFree(e->f_st[0]); hipFree(e->f_st[1]);
-    hipFree(e->r_gran); hipFree(e->r_rows[0]); hipFree(e->r_rows[1]); hipFree(e->r_sync);
     hipFree(e->d_cuts); if (e->h_cuts) hipHostFree(e->h_cuts);
     hipFree(e->d_out); if (e->h_out) hipHostFree(e->h_out);
     if (e->h_state) hipHostFree(e->h_state);
@@ -616,7 +631,7 @@ extern "C" int jslp_engine_get_optional_objectives(jslp_engine* e, double* rows,
 }
 
 static Ctx host_ctx(const jslp_engine* e, int check_cycles) {
-    Ctx c;
+    Ctx c{};
     c.A = e->s.A; c.vibr = e->s.vibr; c.vibc = e->s.vibc; c.rbv = e->s.rbv; c.cbv = e->s.cbv; c.unr = e->s.unr;
     c.prow = e->s.prow; c.pcol = e->s.pcol; c.dirty = e->s.dirty; c.rhs = nullptr; c.oo = e->s.oo; c.n_opt = e->n_opt; c.st = e->s.st; c.hist = e->s.hist; c.hist_cap = e->s.hist_cap;
     c.trace = e->s.trace; c.trace_cap = e->s.trace_cap; c.ld = e->ld; c.W = e->W; c.check_cycles = check_cycles;
@@ -631,6 +646,13 @@ static int iters_cap(const jslp_engine* e) {
     // an error instead of a hung GPU
     long long cap = 2000000LL + 200LL * ((long long)e->cap_rows + e->W);
     return (int)std::min<long long>(cap, 2000000000LL);
+}
+
+// dynamic LDS of the LDS-resident one-workgroup kernels (jslp_wglds.hip.h); 0 = use the generic kernels
+static size_t wglds_smem(const jslp_engine* e) {
+    if (!e->use_wglds || e->n_opt > 0) return 0;
+    const size_t b = wglds_bytes(e->ld, e->cap_rows);
+    return b <= 64 * 1024 ? b : 0;
 }
 
 static bool use_wg_single(const jslp_engine* e) {
@@ -651,18 +673,25 @@ static bool resident_eligible(const jslp_engine* e, int H) {
 
 static int ensure_resident(jslp_engine* e) {
     if (e->r_sync) return JSLP_OK;
-    HIPC(hipMalloc(&e->r_gran, sizeof(u64_t) * (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32)));
-    for (int i = 0; i < 2; i++) HIPC(hipMalloc(&e->r_rows[i], sizeof(u64_t) * (size_t)JSLP_F_MAXG * e->ld));
-    HIPC(hipMalloc(&e->r_sync, sizeof(unsigned) * 16));
-    for (int pass = 0; pass < 2; pass++) {  // the safety net: a copy of slot 0 (matrix, maps, state)
-        Carver cv{pass ? e->r_backup : nullptr, 0};
+    // hand-off buffers and the safety-net copy of slot 0 (matrix, maps, state) carved from ONE allocation, which the
+    // resource pool hands from engine to engine (hipMalloc / hipFree of these cost a small Solve more than its pivots)
+    for (int pass = 0; pass < 2; pass++) {
+        Carver cv{pass ? e->r_arena : nullptr, 0};
+        e->r_gran = cv.take<u64_t>(2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32);
+        for (int i = 0; i < 2; i++) e->r_rows[i] = cv.take<u64_t>((size_t)JSLP_F_MAXG * e->ld);
+        e->r_sync = cv.take<unsigned>(16);
         e->rb_A = cv.take<double>((size_t)e->cap_rows * e->ld);
         e->rb_vibr = cv.take<int32_t>((size_t)e->cap_rows);
         e->rb_vibc = cv.take<int32_t>((size_t)e->W);
         e->rb_rbv = cv.take<int32_t>((size_t)e->n_idx);
         e->rb_cbv = cv.take<int32_t>((size_t)e->n_idx);
         e->r_backup_st = cv.take<DevState>(1);
-        if (!pass) HIPC(hipMalloc(&e->r_backup, cv.off + 256));
+        if (!pass && e->r_arena_bytes < cv.off + 256) {
+            hipFree(e->r_arena);
+            e->r_arena = nullptr; e->r_arena_bytes = 0; e->r_sync = nullptr;
+            HIPC(hipMalloc(&e->r_arena, cv.off + 256));
+            e->r_arena_bytes = cv.off + 256;
+        }
     }
     return JSLP_OK;
 }
@@ -778,7 +807,10 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
     HIPC(hipEventRecord(e->ev_begin, s));
     if (use_wg_single(e)) {
         e->last_path = "workgroup";
-        hipLaunchKernelGGL((k_simplex_wg<JSLP_WG_THREADS, 4096>), dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
+        if (const size_t lds = wglds_smem(e))
+            hipLaunchKernelGGL((k_simplex_lds<JSLP_WG_THREADS>), dim3(1), dim3(JSLP_WG_THREADS), lds, s, e->s, 0, check_cycles, cap, (int)e->cap_rows);
+        else
+            hipLaunchKernelGGL((k_simplex_wg<JSLP_WG_THREADS, 4096>), dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
         HIPC(hipGetLastError());
         HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
         HIPC(hipEventRecord(e->ev_end, s));
@@ -1314,7 +1346,7 @@ extern "C" int jslp_engine_simplex_f32(jslp_engine* e, double precision, int che
     HIPC(hipMemcpyAsync(e->h_state, d.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
     const int H = e->h_state->H;
-    f32::Ctx c;
+    f32::Ctx c{};  // (cnt = nullptr: the fp32 experiment is not counted)
     c.A = d.A; c.vibr = d.vibr; c.vibc = d.vibc; c.rbv = d.rbv; c.cbv = d.cbv; c.unr = d.unr;
     c.prow = d.prow; c.pcol = d.pcol; c.dirty = d.dirty; c.rhs = nullptr; c.oo = nullptr; c.n_opt = 0; c.st = d.st; c.hist = d.hist;
     c.hist_cap = d.hist_cap; c.trace = nullptr; c.trace_cap = 0; c.ld = e->ld; c.W = e->W; c.check_cycles = check_cycles;
@@ -1409,10 +1441,33 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         Cuts cu{e->d_cut_offs, e->d_cut_type, e->d_cut_var, e->d_cut_val};
         Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs};
         e->last_path = "workgroup";
-        hipLaunchKernelGGL((k_node_wg<JSLP_WG_THREADS, 4096>), dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, sn, cu, 0, check_cycles,
-                           cap, (int)e->cap_rows, o_rhs, o_rows, o_state, compact ? g_stride : 0, 0);
+        unsigned* h_flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e->h_state) + sizeof(DevState));
+        void* flag_dev = nullptr;
+        HIPC(hipHostGetDevicePointer(&flag_dev, h_flag, 0));
+        unsigned* d_flag = static_cast<unsigned*>(flag_dev);
+        const unsigned seq = ++e->done_seq ? e->done_seq : ++e->done_seq;  // never 0 (the flag's initial value)
+        if (const size_t lds = wglds_smem(e))
+            hipLaunchKernelGGL((k_node_lds<JSLP_WG_THREADS>), dim3(1), dim3(JSLP_WG_THREADS), lds, s, e->s, sn, cu, 0, check_cycles,
+                               cap, (int)e->cap_rows, o_rhs, o_rows, o_state, compact ? g_stride : 0, 0, d_flag, seq);
+        else
+            hipLaunchKernelGGL((k_node_wg<JSLP_WG_THREADS, 4096>), dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, sn, cu, 0, check_cycles,
+                               cap, (int)e->cap_rows, o_rhs, o_rows, o_state, compact ? g_stride : 0, 0, d_flag, seq);
         HIPC(hipGetLastError());
-        HIPC(hipStreamSynchronize(s));
+        // the kernel's last act is a system-scope release store of `seq` into pinned memory: poll it (a stream
+        // synchronisation costs tens of microseconds of wake-up latency per node of a sequential tree walk)
+        {
+            unsigned spins = 0;
+            const auto t_begin = std::chrono::steady_clock::now();
+            bool arrived = false;
+            while (!(arrived = (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == seq))) {
+                if ((++spins & 0x3fffu) == 0 &&
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 5.0) break;
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            if (!arrived) HIPC(hipStreamSynchronize(s));  // a fault or a hang: let the runtime report it
+        }
         const DevState st = e->h_states[0];
         rc = state_error(st);
         if (rc) { e->slot0_synced = 0; return rc; }
@@ -1463,9 +1518,14 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         if (one_launch) {
             Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs};
             e->last_path = "workgroup";
-            hipLaunchKernelGGL((k_node_wg<512, 2048>), dim3(g), dim3(512), 0, s, e->s, sn, cu, first, check_cycles, cap,
-                               (int)e->cap_rows, want_rhs ? e->d_rhs : nullptr, want_rows ? e->d_rows : nullptr, e->d_states,
-                               g_stride, first);
+            if (const size_t lds = wglds_smem(e))
+                hipLaunchKernelGGL((k_node_lds<512>), dim3(g), dim3(512), lds, s, e->s, sn, cu, first, check_cycles, cap,
+                                   (int)e->cap_rows, want_rhs ? e->d_rhs : nullptr, want_rows ? e->d_rows : nullptr, e->d_states,
+                                   g_stride, first, (unsigned*)nullptr, 0u);
+            else
+                hipLaunchKernelGGL((k_node_wg<512, 2048>), dim3(g), dim3(512), 0, s, e->s, sn, cu, first, check_cycles, cap,
+                                   (int)e->cap_rows, want_rhs ? e->d_rhs : nullptr, want_rows ? e->d_rows : nullptr, e->d_states,
+                                   g_stride, first, (unsigned*)nullptr, 0u);
             HIPC(hipGetLastError());
         } else {
         rc = enqueue_restore(e, 0, g, checkpoint);
@@ -1476,7 +1536,12 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
             e->last_path = "workgroup";
             // one node: the 1024-thread latency shape; a batch: smaller workgroups, more nodes in flight per CU
             const int shape = g == 1 ? 1024 : wg_batch_threads();
-            if (shape == 256)
+            const size_t lds = wglds_smem(e);
+            if (lds && shape == 1024)
+                hipLaunchKernelGGL((k_simplex_lds<JSLP_WG_THREADS>), dim3(g), dim3(JSLP_WG_THREADS), lds, s, e->s, 0, check_cycles, cap, (int)e->cap_rows);
+            else if (lds && shape == 512)
+                hipLaunchKernelGGL((k_simplex_lds<512>), dim3(g), dim3(512), lds, s, e->s, 0, check_cycles, cap, (int)e->cap_rows);
+            else if (shape == 256)
                 hipLaunchKernelGGL((k_simplex_wg<256, 1024>), dim3(g), dim3(256), 0, s, e->s, 0, check_cycles, cap);
             else if (shape == 512)
                 hipLaunchKernelGGL((k_simplex_wg<512, 2048>), dim3(g), dim3(512), 0, s, e->s, 0, check_cycles, cap);
@@ -1925,6 +1990,7 @@ extern "C" int jslp_engine_dims(const jslp_engine* e, int32_t* height, int32_t* 
     if (!e) return fail(JSLP_ERR_ARG, "dims: null engine");
     if (height) {
         if (hipSetDevice(e->device) != hipSuccess) return fail(JSLP_ERR_DEVICE, "dims: hipSetDevice failed");
+        if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(JSLP_ERR_DEVICE, "dims: stream synchronisation failed");
         DevState st;
         if (hipMemcpy(&st, e->s.st, sizeof st, hipMemcpyDeviceToHost) != hipSuccess)
             return fail(JSLP_ERR_DEVICE, "dims: state read-back failed");

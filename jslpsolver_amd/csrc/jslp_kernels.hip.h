@@ -391,7 +391,8 @@ __global__ void __launch_bounds__(256) k_gather(Slots s, int first_slot, double*
 template <int THREADS, int CAP>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 8 : 4) k_node_wg(Slots s, Snapshot snap, Cuts cuts, int first_node, int check_cycles,
                                                      int iters_cap, int cap_rows, double* rhs_out, int32_t* rows_out,
-                                                     DevState* state_out, int out_stride, int first_out) {
+                                                     DevState* state_out, int out_stride, int first_out,
+                                                     unsigned* done_flag, unsigned done_seq) {
     __shared__ Smem sm;
     __shared__ ActSmem<CAP> act;
     const int slot = blockIdx.x, node = first_node + blockIdx.x, o = first_out + blockIdx.x;
@@ -399,7 +400,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 8 : 4) k_node_wg(Slo
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const int gen = s.st[0].s_gen, H = s.st[0].s_H, ld2 = s.ld / 2;  // every slot shares slot 0's snapshot scalars
     if (gen == 0 || st->gen != gen) {  // must not happen (host bookkeeping): refuse rather than restore wrongly
-        if (tid == 0) { st->err = ERR_NOT_SYNCED; st->status = ST_DONE; state_out[o] = *st; }
+        if (tid == 0) {
+            st->err = ERR_NOT_SYNCED; st->status = ST_DONE; state_out[o] = *st;
+            if (done_flag) { __threadfence_system(); __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        }
         return;
     }
     double* A = s.A + (long long)slot * s.A_stride;
@@ -454,6 +458,13 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 8 : 4) k_node_wg(Slo
     simplex_wg(c, sm, act, iters_cap);
     __syncthreads();
     gather_slot(s, slot, rhs_out, rows_out, state_out, out_stride, o);
+    if (done_flag) {
+        // one node, outcome written straight into pinned host memory: the host polls this flag instead of paying a stream
+        // synchronisation (every thread makes its own writes visible system-wide, then ONE release store of the sequence number)
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---- upload (tableau.ts:292-380 hand-over): the matrix arrives by DMA; ONE blob brings [vibr | vibc | unrestricted list]
@@ -533,6 +544,8 @@ __global__ void k_adopt_root(Slots s, int s_H, int s_last_element_index) {
     st->err = ERR_NONE;
     st->rhs_valid = 0;
 }
+
+#include "jslp_wglds.hip.h"
 
 // ---- fp32 twin (jslp_engine_simplex_f32): narrow the live fp64 tableau into an fp32 slot / widen the read-back ----------
 __global__ void __launch_bounds__(256) k32_convert(Slots s, f32::Slots d, int iters_unused) {

@@ -93,11 +93,15 @@ def test_argument_and_capacity_errors(oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["auto", "wg", "sp", "fused", "resident"])
+@pytest.mark.parametrize("mode", ["auto", "wg", "wggen", "sp", "fused", "resident"])
 @pytest.mark.parametrize("name,A", _cases(), ids=[c[0] for c in _cases()])
 def test_hip_equals_oracle_on_edge_shapes(hip_lib, oracle_lib, mode, name, A):
+    os.environ.pop("JSLP_NO_WGLDS", None)
     if mode == "auto":
         os.environ.pop("JSLP_FORCE_PATH", None)
+    elif mode == "wggen":  # the generic one-workgroup kernels ("wg": their LDS-resident twins)
+        os.environ["JSLP_FORCE_PATH"] = "wg"
+        os.environ["JSLP_NO_WGLDS"] = "1"
     else:
         os.environ["JSLP_FORCE_PATH"] = mode
     try:
@@ -106,6 +110,7 @@ def test_hip_equals_oracle_on_edge_shapes(hip_lib, oracle_lib, mode, name, A):
             _same(_run(hip_lib, A, unr=[A.shape[0] - 1 + 1]), _run(oracle_lib, A, unr=[A.shape[0] - 1 + 1]))
     finally:
         os.environ.pop("JSLP_FORCE_PATH", None)
+        os.environ.pop("JSLP_NO_WGLDS", None)
 
 
 @pytest.mark.gpu

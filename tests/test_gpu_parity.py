@@ -16,13 +16,19 @@ from test_oracle_golden import replay, usable
 
 pytestmark = pytest.mark.gpu
 
-PATHS = ["auto", "wg", "sp", "fused", "resident", "resident4"]  # resident4: 512 lanes x 4 columns (JSLP_RES_CPT=4)
+# resident4: 512 lanes x 4 columns (JSLP_RES_CPT=4); wggen: the generic one-workgroup kernels (selection state in global
+# memory, JSLP_NO_WGLDS=1) -- "wg" and "auto" use their LDS-resident twins wherever the tableau's vectors fit
+PATHS = ["auto", "wg", "wggen", "sp", "fused", "resident", "resident4"]
 
 
 def set_path(mode):
     os.environ.pop("JSLP_FORCE_PATH", None)
     os.environ.pop("JSLP_RES_CPT", None)
-    if mode == "resident4":
+    os.environ.pop("JSLP_NO_WGLDS", None)
+    if mode == "wggen":
+        os.environ["JSLP_FORCE_PATH"] = "wg"
+        os.environ["JSLP_NO_WGLDS"] = "1"
+    elif mode == "resident4":
         os.environ["JSLP_FORCE_PATH"] = "resident"
         os.environ["JSLP_RES_CPT"] = "4"
     elif mode != "auto":
@@ -61,7 +67,7 @@ def test_big_fixture_replay(hip_lib, name):
 @pytest.mark.parametrize("name", ["Monster_Problem", "Monster_II"])
 def test_big_fixture_replay_other_paths(hip_lib, name):
     g = G.load(os.path.join(G.GOLDEN, "fixtures", name + ".json.gz"))
-    for mode in ("wg", "sp", "fused", "resident", "resident4"):
+    for mode in ("wg", "wggen", "sp", "fused", "resident", "resident4"):
         set_path(mode)
         try:
             replay(hip_lib, g)
@@ -99,7 +105,7 @@ def _dense_case(lib, kind, n, check_cycles):
 
 @pytest.mark.parametrize("kind,n", [("ra", 200), ("lp", 200), ("ra", 500), ("lp", 500), ("ra", 1000), ("lp", 1000)])
 def test_dense_synthetic_against_reference_golden(hip_lib, path_mode, kind, n):
-    if path_mode == "wg" and n > 500:
+    if path_mode in ("wg", "wggen") and n > 500:
         pytest.skip("one workgroup on a 1000x1000 dense tableau: correct but slow")
     name = ("generateResourceAllocation" if kind == "ra" else "generateRandomLP") + "_%dx%d_seed12345" % (n, n)
     g = G.load(os.path.join(G.GOLDEN, "synthetic", name + ".json.gz"))
