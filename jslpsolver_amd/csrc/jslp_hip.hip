@@ -444,6 +444,9 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
             HIPC(hipEventCreate(&e->ev_end));
         }
         HIPC(hipStreamSynchronize(e->stream));
+        // the completion flag lives behind the pinned state and travels with it through the resource pool: continue the
+        // previous owner's sequence (a fresh counter would meet the old owner's numbers again)
+        e->done_seq = *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e->h_state) + sizeof(DevState));
         return JSLP_OK;
     };
     rc = init();
@@ -1678,8 +1681,8 @@ extern "C" int jslp_engine_set_counting(jslp_engine* e, int enabled) {
     if (!e) return fail(JSLP_ERR_ARG, "set_counting: null engine");
     HIPC(hipSetDevice(e->device));
     HIPC(hipStreamSynchronize(e->stream));
-    if (!e->d_cnt) HIPC(hipMalloc(&e->d_cnt, sizeof(cnt_t) * CNT_N));
-    HIPC(hipMemset(e->d_cnt, 0, sizeof(cnt_t) * CNT_N));
+    if (!e->d_cnt) HIPC(hipMalloc(&e->d_cnt, sizeof(cnt_t) * CNT_ALLOC));
+    HIPC(hipMemset(e->d_cnt, 0, sizeof(cnt_t) * CNT_ALLOC));
     e->counting = enabled ? 1 : 0;
     e->s.cnt = enabled ? e->d_cnt : nullptr;
     e->wc = jslp_work_counters{};
@@ -1692,8 +1695,24 @@ extern "C" int jslp_engine_get_counters(jslp_engine* e, jslp_work_counters* out)
     if (e->d_cnt) {
         HIPC(hipSetDevice(e->device));
         HIPC(hipStreamSynchronize(e->stream));
-        cnt_t c[CNT_N];
+        cnt_t c[CNT_ALLOC];
         HIPC(hipMemcpy(c, e->d_cnt, sizeof c, hipMemcpyDeviceToHost));
+#ifdef JSLP_DEBUG_WGLDS
+        {   // cycle accumulators of the LDS one-workgroup kernels (thread 0 of every workgroup, s_memtime), per section
+            static const char* names[] = {"restore rows", "restore maps", "cuts", "begin + LDS load", "phase-1 row", "pricing", "column gather + ratio test",
+                                          "cycle check", "gate + pivot row", "map swap + compaction", "row updates", "epilogue", "read-back", "phase-1 column"};
+            const double piv = (double)std::max<long long>(1, out->pivots), nodes = (double)std::max<long long>(1, out->simplex_calls);
+            fprintf(stderr, "[wglds cycles] per node (%lld nodes, %lld pivots):", (long long)out->simplex_calls, (long long)out->pivots);
+            double tot = 0;
+            for (int i = 0; i < 14; i++) tot += (double)c[CNT_DBG + i];
+            for (int i = 0; i < 14; i++)
+                fprintf(stderr, "\n  %-28s %10.0f cycles/node %9.0f cycles/pivot %5.1f %%", names[i], c[CNT_DBG + i] / nodes, c[CNT_DBG + i] / piv, 100.0 * c[CNT_DBG + i] / std::max(1.0, tot));
+            fprintf(stderr, "\n  total %.0f cycles/node\n", tot / nodes);
+            static const char* micro[] = {"block_min_ki", "__syncthreads", "LDS scan of H + barrier", "strided column gather + barrier", "coalesced row load + barrier",
+                                          "coalesced row store + barrier"};
+            for (int i = 0; i < 6; i++) fprintf(stderr, "  micro: %-34s %8.0f cycles each\n", micro[i], c[CNT_DBG + 14 + i] / nodes / 16.0);
+        }
+#endif
         out->gated_cells += (int64_t)c[CNT_CELLS];
         out->gated_rows += (int64_t)c[CNT_ROWS];
         out->restored_rows += (int64_t)c[CNT_RESTORED];

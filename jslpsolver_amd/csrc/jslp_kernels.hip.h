@@ -60,7 +60,7 @@ struct DevState {
     int32_t rhs_valid;    // the slot's contiguous RHS mirror (Ctx::rhs) equals column 0 (kept by the per-node kernel only)
 };
 // Work counters (jslp_work_counters), one block per engine, advanced with device-scope atomics only while counting is on
-enum { CNT_CELLS = 0, CNT_ROWS = 1, CNT_RESTORED = 2, CNT_N = 4 };
+enum { CNT_CELLS = 0, CNT_ROWS = 1, CNT_RESTORED = 2, CNT_N = 4, CNT_DBG = 8, CNT_ALLOC = 40 };  // CNT_DBG..: cycle accumulators of debug builds
 typedef unsigned long long cnt_t;
 
 // ---- the simplex core, compiled for both scalar types (see jslp_core.inc.h) -------------------------------------

@@ -16,6 +16,14 @@
 // Not handled here (the host launches the generic kernel instead): optional objectives, tableaus whose four vectors
 // exceed the dynamic LDS budget.
 // ===================================================================================================
+#ifdef JSLP_DEBUG_WGLDS
+#define WL_MARK(i) do { if (wl_dbg && threadIdx.x == 0) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); atomicAdd(wl_dbg + CNT_DBG + (i), _n - wl_prev); wl_prev = _n; } } while (0)
+#define WL_BEGIN(cntp) cnt_t* wl_dbg = (cntp); unsigned long long wl_prev = __builtin_amdgcn_s_memtime()
+#else
+#define WL_MARK(i) do { } while (0)
+#define WL_BEGIN(cntp) do { } while (0)
+#endif
+
 struct WgLds {
     double* r0;     // [ld]   cost row (row 0), kept in step with A by the row update
     double* prow;   // [ld]   normalised pivot row of the current pivot
@@ -38,32 +46,145 @@ __device__ __forceinline__ WgLds wglds_carve(double* base, int ld, int cap_rows)
     return L;
 }
 
-// one gated row, one wave: row <- row - k * prow on the live columns (simplex.ts:376-387); column 0 and row 0 are mirrored in LDS
+// ---- (key, index) minimum over a workgroup in ONE barrier ---------------------------------------------------------------
+// The generic kernels reduce (value, index, batch) triples with 12 dependent ds_bpermute stages and three barriers
+// (block_reduce, ~4-5 k cycles per reduction at 16 waves: measured with s_memtime, profiles/r02_wglds_sections.md).  Here a
+// candidate is a 64-bit key whose unsigned order IS the selection order plus the index that breaks ties (first index), the
+// wave stage is four DPP exchanges inside the 16-lane rows + readlanes across the four rows, and the waves meet in a
+// double-buffered LDS array every thread scans itself.
+struct KI {
+    unsigned long long k;
+    int32_t i;
+    int32_t pad;
+};
+#define KI_NONE_KEY (~0ull)
+__device__ __forceinline__ KI ki_none() { KI x; x.k = KI_NONE_KEY; x.i = 0x7fffffff; x.pad = 0; return x; }
+__device__ __forceinline__ KI ki_min(KI a, KI b) {
+    const bool t = b.k < a.k || (b.k == a.k && b.i < a.i);
+    KI r; r.k = t ? b.k : a.k; r.i = t ? b.i : a.i; r.pad = 0;
+    return r;
+}
+// doubles -> keys: unsigned order == numeric order (-0 is folded into +0 first: the reference compares them equal and lets
+// the first index win); NaN never becomes a candidate (every candidate passed a strict comparison)
+__device__ __forceinline__ unsigned long long key_asc(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v + 0.0);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ unsigned long long key_desc(double v) { return ~key_asc(v); }
+
+template <int CTRL>
+__device__ __forceinline__ KI ki_dpp(KI x) {
+    const int lo = (int)(unsigned)x.k, hi = (int)(unsigned)(x.k >> 32);
+    KI y;
+    y.k = ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false) << 32) |
+          (unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    y.i = __builtin_amdgcn_update_dpp(x.i, x.i, CTRL, 0xf, 0xf, false);
+    y.pad = 0;
+    return y;
+}
+__device__ __forceinline__ KI ki_readlane(KI x, int lane) {
+    KI y;
+    y.k = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x.k >> 32), lane) << 32) |
+          (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)x.k, lane);
+    y.i = __builtin_amdgcn_readlane(x.i, lane);
+    y.pad = 0;
+    return y;
+}
+__device__ __forceinline__ KI ki_wave_min(KI x) {  // result in every lane
+    x = ki_min(x, ki_dpp<0xB1>(x));    // quad_perm [1,0,3,2]: lane ^ 1
+    x = ki_min(x, ki_dpp<0x4E>(x));    // quad_perm [2,3,0,1]: lane ^ 2
+    x = ki_min(x, ki_dpp<0x141>(x));   // row_half_mirror: the other quad of the 8-lane half
+    x = ki_min(x, ki_dpp<0x140>(x));   // row_mirror: the other half of the 16-lane row
+    KI r = ki_readlane(x, 0);
+    r = ki_min(r, ki_readlane(x, 16));
+    r = ki_min(r, ki_readlane(x, 32));
+    r = ki_min(r, ki_readlane(x, 48));
+    return r;
+}
+
+#define WGL_HIST 128
+struct SmemL {
+    Smem g;                 // what suffix_is_square / the counters use
+    unsigned long long red_k[2][16];  // cross-wave stage of the reductions (keys / indexes), double-buffered by call parity
+    int32_t red_i[2][16];
+    int2 hist[WGL_HIST];    // first entries of the cycle-check history (simplex.ts:415-440): the suffix test runs on them
+    int32_t n_list;         // length of the gated-row list
+};
+// Only the first WGL_SEL threads (four waves, one per SIMD) take part in a selection: a wave-level reduction costs every
+// wave its ~60 instructions whether it holds candidates or not, and at 16 waves per workgroup that issue time -- not memory --
+// was the pivot's largest cost (block reductions: 6.0 k cycles each at 1024 threads, profiles/r02_wglds_sections.md).
+#define WGL_SEL 256
+__device__ __forceinline__ KI block_min_ki(KI x, SmemL& sm, int& par) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (w < WGL_SEL / 64) {
+        x = ki_wave_min(x);
+        if (lane == 0) { sm.red_k[par][w] = x.k; sm.red_i[par][w] = x.i; }
+    }
+    __syncthreads();
+    unsigned long long rk = sm.red_k[par][0];
+    int ri = sm.red_i[par][0];
+#pragma unroll
+    for (int i = 1; i < WGL_SEL / 64; i++) {  // (scalars, not structs through references: those end up in scratch behind flat pointers)
+        const unsigned long long k = sm.red_k[par][i];
+        const int ii = sm.red_i[par][i];
+        const bool t = k < rk || (k == rk && ii < ri);
+        rk = t ? k : rk;
+        ri = t ? ii : ri;
+    }
+    par ^= 1;  // the next call writes the other buffer: one barrier per reduction is enough
+    KI r; r.k = rk; r.i = ri; r.pad = 0;
+    return r;
+}
+
+// the gated rows of one pivot, one wave per row: row <- row - k * prow on the live columns (simplex.ts:376-387).  The loads
+// of UN column pairs are in flight together (a row of Monster_II: two dependent trips instead of eight); column 0 and row 0
+// are mirrored in LDS.
+template <int UN>
 __device__ __forceinline__ void wglds_update_row(const Ctx& c, const WgLds& L, int r, double k, int pc, double quot, int lane) {
     const int ld = c.ld;
     double* row = c.A + (long long)r * ld;
-    for (int c0 = lane * 2; c0 < ld; c0 += 128) {
-        const double2 p = *reinterpret_cast<const double2*>(L.prow + c0);
-        const bool v0 = nonzero16(p.x), v1 = nonzero16(p.y);
-        const bool has_pc = (pc == c0) || (pc == c0 + 1);
-        if (!v0 && !v1 && !has_pc) continue;
-        double2 x = *reinterpret_cast<const double2*>(row + c0);
-        if (v0) x.x = eliminate(x.x, k, p.x);
-        if (v1) x.y = eliminate(x.y, k, p.y);
-        if (has_pc) {
-            const double nv = -k / quot;
-            if (pc == c0) x.x = nv; else x.y = nv;
+    for (int base = lane * 2; base < ld; base += 128 * UN) {
+        double2 a[UN];
+        unsigned live = 0;
+#pragma unroll
+        for (int j = 0; j < UN; j++) {
+            const int c0 = base + 128 * j;
+            a[j] = make_double2(0.0, 0.0);
+            if (c0 < ld) {
+                const double2 p = *reinterpret_cast<const double2*>(L.prow + c0);
+                if (nonzero16(p.x) || nonzero16(p.y) || pc == c0 || pc == c0 + 1) {
+                    live |= 1u << j;
+                    a[j] = *reinterpret_cast<const double2*>(row + c0);
+                }
+            }
         }
-        *reinterpret_cast<double2*>(row + c0) = x;
-        if (c0 == 0) L.rhs[r] = x.x;
-        if (r == 0) *reinterpret_cast<double2*>(L.r0 + c0) = x;
+#pragma unroll
+        for (int j = 0; j < UN; j++) {
+            if (!(live & (1u << j))) continue;
+            const int c0 = base + 128 * j;
+            const double2 p = *reinterpret_cast<const double2*>(L.prow + c0);
+            double2 x = a[j];
+            if (nonzero16(p.x)) x.x = eliminate(x.x, k, p.x);
+            if (nonzero16(p.y)) x.y = eliminate(x.y, k, p.y);
+            if (pc == c0 || pc == c0 + 1) {
+                const double nv = -k / quot;
+                if (pc == c0) x.x = nv; else x.y = nv;
+            }
+            *reinterpret_cast<double2*>(row + c0) = x;
+            if (c0 == 0) L.rhs[r] = x.x;
+            if (r == 0) *reinterpret_cast<double2*>(L.r0 + c0) = x;
+        }
     }
 }
 
-__device__ void simplex_wg_lds(const Ctx& c, Smem& sm, const WgLds& L, int iters_cap) {
+#define WGL_KP 2  // pivot-row values a thread keeps in registers across the cycle check (ld <= WGL_KP * threads)
+
+template <int UN>
+__device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iters_cap) {
+    WL_BEGIN(c.cnt);
     DevState* st = c.st;
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6, nw = nt >> 6;
-    if (tid == 0) begin_simplex(st, iters_cap);
+    if (tid == 0) { begin_simplex(st, iters_cap); sm.n_list = 0; }
     __syncthreads();
     const int H = st->H, W = c.W, ld = c.ld;  // the height is fixed during a simplex() call
     const double precision = c.precision;
@@ -80,73 +201,134 @@ __device__ void simplex_wg_lds(const Ctx& c, Smem& sm, const WgLds& L, int iters
         if (tid == 0) finish(c);
         return;
     }
-    int phase = 1, it1 = 0, it2 = 0, hist_n = 0, iters_left = iters_cap, entered2 = 0;
+    WL_MARK(3);
+#ifdef JSLP_DEBUG_WGLDS
+    if (wl_dbg) {  // micro-costs in this kernel's own geometry (thread 0's clock), 16 repetitions each
+        int par0 = 0;
+        KI acc = ki_none();
+        for (int i = 0; i < 16; i++) { KI x = ki_none(); x.k = key_asc(L.rhs[(tid + i) % H]); x.i = tid; acc = ki_min(acc, block_min_ki(x, sm, par0)); }
+        WL_MARK(14);
+        for (int i = 0; i < 16; i++) __syncthreads();
+        WL_MARK(15);
+        double sacc = 0;
+        for (int i = 0; i < 16; i++) { for (int r = 1 + tid; r < H; r += nt) sacc += L.rhs[r]; __syncthreads(); }
+        WL_MARK(16);
+        for (int i = 0; i < 16; i++) { for (int r = tid; r < H; r += nt) L.pcol[r] = A[(long long)r * ld + 1 + i]; __syncthreads(); }
+        WL_MARK(17);
+        for (int i = 0; i < 16; i++) { for (int col = tid; col < ld; col += nt) L.prow[col] = A[(long long)(1 + i) * ld + col]; __syncthreads(); }
+        WL_MARK(18);
+        for (int i = 0; i < 16; i++) { for (int col = tid; col < ld; col += nt) c.prow[col] = L.prow[col] + i; __syncthreads(); }
+        WL_MARK(19);
+        if (acc.k == 1234567 && sacc == 1.5) L.pcol[0] = 1.0;  // keep the loops alive
+        __syncthreads();
+        for (int r = tid; r < H; r += nt) L.pcol[r] = 0.0;
+        __syncthreads();
+        WL_MARK(20);
+    }
+#endif
+    const bool row_in_regs = ld <= WGL_KP * nt;
+    int phase = 1, it1 = 0, it2 = 0, hist_n = 0, iters_left = iters_cap, entered2 = 0, par = 0;
     // outcome: 0 running, 1 optimal, 2 unbounded, 3 cycle, 4 infeasible, 5 iteration cap, 6 history full
     int outcome = 0, unbounded_col = 0;
     while (outcome == 0) {
         if (iters_left <= 0) { outcome = 5; break; }
         int pr = 0, pc = 0, neg_flag = 0;
+        double pv0 = 0.0, pv1 = 0.0;  // my two columns of the pivot row (raw), loaded as early as the row is known
+        bool have_pv = false;
         if (phase == 1) {
             // leaving row: most negative RHS below -precision, first index on ties (simplex.ts:39-49)
-            Cand best; best.v = -precision; best.i = 0; best.b = 0;
-            for (int r = 1 + tid; r < H; r += nt) {
-                const double v = L.rhs[r];
-                if (v < best.v) { best.v = v; best.i = r; }
-            }
-            best = block_reduce(best, MinFirst(), sm);
-            if (best.i == 0) {  // :51-54 feasible: phase 2 starts in this same iteration with a fresh history (:102)
+            double bv = -precision;
+            int bi = 0;
+            if (tid < WGL_SEL)
+                for (int r = 1 + tid; r < H; r += WGL_SEL) {
+                    const double v = L.rhs[r];
+                    if (v < bv) { bv = v; bi = r; }
+                }
+            KI x = ki_none();
+            if (bi != 0) { x.k = key_asc(bv); x.i = bi; }
+            x = block_min_ki(x, sm, par);
+            WL_MARK(4);
+            if (x.k == KI_NONE_KEY) {  // :51-54 feasible: phase 2 starts in this same iteration with a fresh history (:102)
                 phase = 2; entered2 = 1; hist_n = 0;
             } else {
-                pr = best.i;
-                // entering column: max -cost/coef over unrestricted or coef < -precision (simplex.ts:56-71)
+                pr = x.i;
+                // entering column: max -cost/coef over unrestricted or coef < -precision (simplex.ts:56-71).  Row pr is the
+                // pivot row of this pivot: what is read for the search stays in registers for the normalisation below.
                 const double* row = A + (long long)pr * ld;
-                Cand q; q.v = -INFINITY; q.i = 0; q.b = 0;
-                for (int col = 1 + tid; col < W; col += nt) {
-                    const double coef = row[col];
-                    const bool un = c.has_unr && c.unr[c.vibc[col]] != 0;
-                    if (un || coef < -precision) {
-                        const double quo = -L.r0[col] / coef;
-                        if (q.v < quo) { q.v = quo; q.i = col; }
-                    }
+                double qv = -INFINITY;
+                int qi = 0;
+                if (row_in_regs) {
+                    pv0 = tid < ld ? row[tid] : 0.0;
+                    pv1 = tid + nt < ld ? row[tid + nt] : 0.0;
+                    have_pv = true;
+                    if (tid < ld) L.prow[tid] = pv0;          // (raw: the normalisation below overwrites it)
+                    if (tid + nt < ld) L.prow[tid + nt] = pv1;
+                } else {
+                    for (int col = tid; col < ld; col += nt) L.prow[col] = row[col];
                 }
-                q = block_reduce(q, MaxFirst(), sm);
-                if (q.i == 0) { outcome = 4; break; }  // :73-76 infeasible
+                __syncthreads();
+                if (tid < WGL_SEL)
+                    for (int col = 1 + tid; col < W; col += WGL_SEL) {
+                        const double coef = L.prow[col];
+                        const bool un = c.has_unr && c.unr[c.vibc[col]] != 0;
+                        if (un || coef < -precision) {
+                            const double quo = -L.r0[col] / coef;
+                            if (qv < quo) { qv = quo; qi = col; }
+                        }
+                    }
+                KI q = ki_none();
+                if (qi != 0) { q.k = key_desc(qv); q.i = qi; }
+                q = block_min_ki(q, sm, par);
+                if (q.k == KI_NONE_KEY) { outcome = 4; break; }  // :73-76 infeasible
                 pc = q.i;
                 for (int r = tid; r < H; r += nt) L.pcol[r] = A[(long long)r * ld + pc];
                 __syncthreads();
+                WL_MARK(13);
             }
         }
         if (phase == 2) {
-            // Dantzig pricing with the reference's batch rule (simplex.ts:118-219) on the LDS cost row
-            Cand e; e.v = precision; e.i = 0; e.b = 0;
-            for (int col = 1 + tid; col < W; col += nt) {
+            // Dantzig pricing with the reference's batch rule (simplex.ts:118-219) on the LDS cost row: the first
+            // batch holding a candidate wins, inside it the largest value, first index on ties
+            double ev = precision;
+            int ei = 0, eb = 0;
+            for (int col = 1 + tid; col < W && tid < WGL_SEL; col += WGL_SEL) {
                 const double rc = L.r0[col];
                 const bool un = c.has_unr && c.unr[c.vibc[col]] != 0;
                 const int b = c.use_partial ? (col - 1) / c.batch : 0;
                 const double val = (un && rc < 0) ? -rc : rc;
                 if (val > precision) {
-                    Cand cand; cand.v = val; cand.i = col; cand.b = b;
-                    const bool take = PriceFirst()(cand, e);
-                    e.v = take ? cand.v : e.v;
-                    e.i = take ? cand.i : e.i;
-                    e.b = take ? cand.b : e.b;
+                    const bool take = ei == 0 || b < eb || (b == eb && val > ev);  // my columns ascend: ties keep the earlier one
+                    ev = take ? val : ev;
+                    ei = take ? col : ei;
+                    eb = take ? b : eb;
                 }
             }
-            e = block_reduce(e, PriceFirst(), sm);
-            if (e.i == 0) { outcome = 1; break; }  // optimal (simplex.ts:265-269)
+            if (c.use_partial) {  // which batch?
+                KI b = ki_none();
+                if (ei != 0) { b.k = (unsigned long long)eb; b.i = 0; }
+                b = block_min_ki(b, sm, par);
+                if (b.k == KI_NONE_KEY) ei = 0;
+                else if (ei != 0 && (unsigned long long)eb != b.k) ei = 0;  // my best sits in a later batch
+            }
+            KI e = ki_none();
+            if (ei != 0) { e.k = key_desc(ev); e.i = ei; }
+            e = block_min_ki(e, sm, par);
+            WL_MARK(5);
+            if (e.k == KI_NONE_KEY) { outcome = 1; break; }  // optimal (simplex.ts:265-269)
             pc = e.i;
             {
                 const double rc = L.r0[pc];
                 const bool un = c.has_unr && c.unr[c.vibc[pc]] != 0;
                 neg_flag = (un && rc < 0) ? 1 : 0;
             }
-            // ratio test (simplex.ts:271-296) in its order-free form; the strided column gather is the pivot's first global trip
-            Cand m; m.v = INFINITY; m.i = 0; m.b = 0;
-            int rdeg = 0x7fffffff;
-            for (int r = tid; r < H; r += nt) {
-                const double colv = A[(long long)r * ld + pc];
-                L.pcol[r] = colv;
-                if (r == 0) continue;
+            // ratio test (simplex.ts:271-296) in its order-free form: the first degenerate row wins outright (key 0), else the
+            // first-index argmin of the accepted quotients; the strided column gather is the pivot's first global trip
+            double mv = INFINITY;
+            int mi = 0, rdeg = 0x7fffffff;
+            for (int r = tid; r < H; r += nt) L.pcol[r] = A[(long long)r * ld + pc];
+            __syncthreads();
+            for (int r = 1 + tid; r < H && tid < WGL_SEL; r += WGL_SEL) {
+                const double colv = L.pcol[r];
                 const double rhs = L.rhs[r];
                 if (-precision < colv && colv < precision) continue;
                 if (colv > 0 && precision > rhs && rhs > -precision) {
@@ -154,57 +336,92 @@ __device__ void simplex_wg_lds(const Ctx& c, Smem& sm, const WgLds& L, int iters
                     continue;
                 }
                 const double quo = neg_flag ? -rhs / colv : rhs / colv;
-                if (quo > precision && m.v > quo) { m.v = quo; m.i = r; }
+                if (quo > precision && mv > quo) { mv = quo; mi = r; }
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                const int o = __shfl_down(rdeg, off, 64);
-                rdeg = o < rdeg ? o : rdeg;
+            KI m = ki_none();
+            if (rdeg != 0x7fffffff) { m.k = 0; m.i = rdeg; }
+            else if (mi != 0) { m.k = key_asc(mv); m.i = mi; }
+            m = block_min_ki(m, sm, par);
+            WL_MARK(6);
+            if (m.k == KI_NONE_KEY) { outcome = 2; unbounded_col = pc; break; }  // unbounded (simplex.ts:298-303)
+            pr = m.i;
+        }
+        // ---- the pivot (pr, pc) is chosen.  Start its global reads now: my columns of the pivot row, and (thread 0) the two
+        //      map entries the pivot swaps; the cycle check and the row-gate compaction run while they are in flight ---------
+        if (row_in_regs && !have_pv) {
+            const double* row = A + (long long)pr * ld;
+            pv0 = tid < ld ? row[tid] : 0.0;
+            pv1 = tid + nt < ld ? row[tid + nt] : 0.0;
+            have_pv = true;
+        }
+        int leaving = 0, entering = 0;
+        if (tid == 0) { leaving = c.vibr[pr]; entering = c.vibc[pc]; }
+        // the rows that pass the reference's gate (simplex.ts:370-375), compacted into the LDS list (a Monster_II pivot: ~10 of
+        // 945); "any row at all" is what decides the lazy zeroing of tiny pivot-row entries (:381-383)
+        int n_gated = 0;
+        for (int r = tid; r < H; r += nt) {
+            if (r != pr && nonzero16(L.pcol[r])) {
+                L.list[atomicAdd(&sm.n_list, 1)] = r;  // the list holds every row: it cannot overflow
+                c.dirty[r] = 1;
+                n_gated += 1;
             }
-            __syncthreads();
-            if (tid == 0) sm.flag = 0x7fffffff;
-            __syncthreads();
-            if (lane == 0 && rdeg != 0x7fffffff) atomicMin(&sm.flag, rdeg);
-            m = block_reduce(m, MinFirst(), sm);  // contains the barriers that publish sm.flag and L.pcol
-            rdeg = sm.flag;
-            if (rdeg != 0x7fffffff) pr = rdeg;
-            else if (m.i != 0) pr = m.i;
-            else { outcome = 2; unbounded_col = pc; break; }  // unbounded (simplex.ts:298-303)
         }
         // cycle check (simplex.ts:78-93 / 305-320): append first, test, stop WITHOUT pivoting on a hit
         if (c.check_cycles) {
             if (hist_n >= c.hist_cap) { outcome = 6; break; }
-            if (tid == 0) c.hist[hist_n] = make_int2(c.vibr[pr], c.vibc[pc]);
+            if (tid == 0) {
+                const int2 pair = make_int2(leaving, entering);
+                c.hist[hist_n] = pair;  // the host rebuilds the reference's [start, length] message from the global copy
+                if (hist_n < WGL_HIST) sm.hist[hist_n] = pair;
+            }
             __syncthreads();
             hist_n += 1;
-            if (suffix_is_square(c.hist, hist_n, sm)) { outcome = 3; break; }
+            if (suffix_is_square(hist_n <= WGL_HIST ? sm.hist : c.hist, hist_n, sm.g)) { outcome = 3; break; }
+        } else {
+            __syncthreads();  // the list is complete
         }
-        // ---- pivot (simplex.ts:330-413): maps, normalised pivot row (second global trip), then the gated rows (third) ----
+        WL_MARK(7);
+        const int n = sm.n_list;
+        const bool anyrow = n > 0;
+        // ---- pivot row (simplex.ts:352-364) from the registers (or from memory when the row is wider than they hold) -----------
         const double quot = L.pcol[pr];  // = A[pr, pc] (:335)
-        int any = 0, n_gated = 0;
-        for (int r = tid; r < H; r += nt) {
-            const int gated = (r != pr && nonzero16(L.pcol[r]));
-            any |= gated;
-            n_gated += gated;
-        }
-        const int anyrow = __syncthreads_or(any);
         double* prow_A = A + (long long)pr * ld;
         int n_cols = 0;
-        for (int col = tid; col < ld; col += nt) {
-            double v = 0.0;
-            if (col < W) {
-                const double val = prow_A[col];
-                const bool innz = nonzero16(val);       // :356
-                v = innz ? val / quot : 0.0;            // :357 / :361
-                if (col == pc) v = 1.0 / quot;          // :364
-                if (innz && anyrow && !nonzero16(v) && v != 0.0) v = 0.0;  // :381-383
-                prow_A[col] = v;
-                if (col == 0) L.rhs[pr] = v;
-                n_cols += (nonzero16(v) || col == pc) ? 1 : 0;
+        if (have_pv) {
+            auto normalise = [&](int col, double val) {
+                if (col < ld) {
+                    double v = 0.0;
+                    if (col < W) {
+                        const bool innz = nonzero16(val);       // :356
+                        v = innz ? val / quot : 0.0;            // :357 / :361
+                        if (col == pc) v = 1.0 / quot;          // :364
+                        if (innz && anyrow && !nonzero16(v) && v != 0.0) v = 0.0;  // :381-383
+                        prow_A[col] = v;
+                        if (col == 0) L.rhs[pr] = v;
+                        n_cols += (nonzero16(v) || col == pc) ? 1 : 0;
+                    }
+                    L.prow[col] = v;
+                }
+            };
+            normalise(tid, pv0);
+            normalise(tid + nt, pv1);
+        } else {
+            for (int col = tid; col < ld; col += nt) {
+                double v = 0.0;
+                if (col < W) {
+                    const double val = prow_A[col];
+                    const bool innz = nonzero16(val);
+                    v = innz ? val / quot : 0.0;
+                    if (col == pc) v = 1.0 / quot;
+                    if (innz && anyrow && !nonzero16(v) && v != 0.0) v = 0.0;
+                    prow_A[col] = v;
+                    if (col == 0) L.rhs[pr] = v;
+                    n_cols += (nonzero16(v) || col == pc) ? 1 : 0;
+                }
+                L.prow[col] = v;
             }
-            L.prow[col] = v;
         }
-        if (tid == 0) {
-            const int leaving = c.vibr[pr], entering = c.vibc[pc];  // :339-349
+        if (tid == 0) {  // :339-349
             c.vibr[pr] = entering;
             c.vibc[pc] = leaving;
             c.rbv[entering] = pr;
@@ -212,40 +429,33 @@ __device__ void simplex_wg_lds(const Ctx& c, Smem& sm, const WgLds& L, int iters
             c.cbv[entering] = -1;
             c.cbv[leaving] = pc;
             if (trace_n < c.trace_cap) c.trace[trace_n] = make_int2(pr, pc);
-            sm.flag2 = 0;  // length of the gated-row list
             c.dirty[pr] = 1;
         }
         trace_n += 1;
         if (phase == 1) it1 += 1; else it2 += 1;
         iters_left -= 1;
-        if (c.cnt) {  // work counters (uniform branch)
-            for (int off = 32; off > 0; off >>= 1) { n_gated += __shfl_down(n_gated, off, 64); n_cols += __shfl_down(n_cols, off, 64); }
+        if (c.cnt) {  // work counters (uniform branch): cells simplex.ts:376-387 touches = gated rows x live pivot-row columns
+            for (int off = 32; off > 0; off >>= 1) n_cols += __shfl_down(n_cols, off, 64);
             __syncthreads();
-            if (tid == 0) { sm.flag = 0; sm.wave[0].i = 0; }
+            if (tid == 0) sm.g.flag = 0;
             __syncthreads();
-            if (lane == 0) { atomicAdd(&sm.flag, n_gated); atomicAdd(&sm.wave[0].i, n_cols); }
+            if (lane == 0) atomicAdd(&sm.g.flag, n_cols);
             __syncthreads();
             if (tid == 0) {
-                atomicAdd(c.cnt + CNT_CELLS, (cnt_t)sm.flag * (cnt_t)sm.wave[0].i);
-                atomicAdd(c.cnt + CNT_ROWS, (cnt_t)sm.flag);
+                atomicAdd(c.cnt + CNT_CELLS, (cnt_t)n * (cnt_t)sm.g.flag);
+                atomicAdd(c.cnt + CNT_ROWS, (cnt_t)n);
             }
         }
-        __syncthreads();  // L.prow complete, sm.flag2 reset
-        // the rows that pass the reference's gate, compacted into the LDS list (a Monster_II pivot: ~10 of 945)
-        for (int r = tid; r < H; r += nt) {
-            if (r != pr && nonzero16(L.pcol[r])) {
-                const int idx = atomicAdd(&sm.flag2, 1);
-                L.list[idx] = r;  // the list holds every row: it cannot overflow
-                c.dirty[r] = 1;
-            }
-        }
-        __syncthreads();
-        const int n = sm.flag2;
+        (void)n_gated;
+        __syncthreads();  // L.prow complete
+        WL_MARK(8);
         for (int i = w; i < n; i += nw) {
             const int r = L.list[i];
-            wglds_update_row(c, L, r, L.pcol[r], pc, quot, lane);
+            wglds_update_row<UN>(c, L, r, L.pcol[r], pc, quot, lane);
         }
+        if (tid == 0) sm.n_list = 0;  // for the next pivot (several barriers away from its first use)
         __syncthreads();
+        WL_MARK(10);
     }
     // ---- epilogue: scalars back into the state, column 0 back into the slot's mirror ---------------------------------------
     if (c.rhs)
@@ -271,27 +481,92 @@ __device__ void simplex_wg_lds(const Ctx& c, Smem& sm, const WgLds& L, int iters
         st->obj_cell = L.r0[0];
     }
     __syncthreads();
+    WL_MARK(11);
+}
+
+// addCutConstraints (cutting-strategies.ts:16-72) with one WAVE per cut row (add_cuts_slot builds them one after the other:
+// five dependent global trips per node of a Monster_II tree); the slack bookkeeping stays sequential (getNewElementIndex)
+__device__ __forceinline__ void add_cuts_waves(const Slots& s, const Cuts& cuts, int slot, int node, int cap_rows) {
+    DevState* st = s.st + slot;
+    double* A = s.A + (long long)slot * s.A_stride;
+    double* rhs = s.rhs + (long long)slot * s.pcol_stride;
+    int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
+    int32_t* rbv = s.rbv + (long long)slot * s.idx_stride;
+    int32_t* cbv = s.cbv + (long long)slot * s.idx_stride;
+    const int a = cuts.offs[node], n = cuts.offs[node + 1] - a;
+    const int H = st->H, W = s.W, ld = s.ld;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (H + n > cap_rows) {
+        if (threadIdx.x == 0) st->err = ERR_CAPACITY;
+        return;
+    }
+    for (int h = w; h < n; h += nw) {
+        const int vi = cuts.var[a + h];
+        const double sign = cuts.type[a + h] == 0 ? -1.0 : 1.0;  // "min" -> -1 (:41)
+        const double value = cuts.value[a + h];
+        double* cut = A + (long long)(H + h) * ld;
+        const int var_row = (vi >= 0 && vi < s.idx_stride) ? rbv[vi] : -2;
+        const int var_col = (vi >= 0 && vi < s.idx_stride) ? cbv[vi] : -1;
+        if (var_row == -2 || (var_row == -1 && var_col < 0)) {
+            if (lane == 0) st->err = ERR_CUT_ARG;
+            continue;
+        }
+        if (var_row == -1) {  // non-basic variable: unit row (:46-53)
+            for (int col = lane; col < ld; col += 64) {
+                double v = 0.0;
+                if (col == 0) { v = sign * value; rhs[H + h] = v; }
+                else if (col == var_col) v = sign;
+                cut[col] = v;
+            }
+        } else {  // basic variable: negated copy of its row (:54-62)
+            const double* src = A + (long long)var_row * ld;
+            for (int col = lane; col < ld; col += 64) {
+                double v = 0.0;
+                if (col == 0) { v = sign * (value - src[0]); rhs[H + h] = v; }
+                else if (col < W) v = -sign * src[col];
+                cut[col] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && st->err != ERR_CUT_ARG) {
+        for (int h = 0; h < n; h++) {  // getNewElementIndex + map updates (:64-69)
+            const int slack = st->last_element_index++;
+            if (slack >= s.idx_stride) { st->err = ERR_CAPACITY; break; }
+            vibr[H + h] = slack;
+            rbv[slack] = H + h;
+            cbv[slack] = -1;
+        }
+        st->H = H + n;
+    }
 }
 
 // simplex() of slots [first_slot, first_slot + gridDim.x): the LDS twin of k_simplex_wg
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) k_simplex_lds(Slots s, int first_slot, int check_cycles, int iters_cap, int cap_rows) {
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
-    __shared__ Smem sm;
+    __shared__ SmemL sm;
     const Ctx c = slot_ctx(s, first_slot + blockIdx.x, check_cycles);
     const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
-    simplex_wg_lds(c, sm, L, iters_cap);
+    simplex_wg_lds<(THREADS >= 1024 ? 8 : 4)>(c, sm, L, iters_cap);
 }
 
 // The LDS twin of k_node_wg: ONE branch-and-bound child per workgroup in ONE launch -- restore of the rows the previous node
 // dirtied, the index maps, addCutConstraints, simplex() and the read-back (see k_node_wg for the contract).
+#ifndef JSLP_NODE512_WAVES
+// waves per SIMD the 512-thread batch shape is compiled for.  6 = three workgroups per CU, 80 VGPRs, no spills: measured
+// 1.87 M relaxations/s on the Monster_II batch against 1.79 M for 8 (64 VGPRs, 36 bytes of scratch per lane); with the LDS
+// this kernel declares (40 KB per workgroup) a fourth workgroup does not fit a CU anyway
+#define JSLP_NODE512_WAVES 6
+#endif
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS, THREADS == 512 ? 8 : 4) k_node_lds(Slots s, Snapshot snap, Cuts cuts, int first_node, int check_cycles,
+__global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES : 4) k_node_lds(Slots s, Snapshot snap, Cuts cuts, int first_node, int check_cycles,
                                                       int iters_cap, int cap_rows, double* rhs_out, int32_t* rows_out,
                                                       DevState* state_out, int out_stride, int first_out,
                                                       unsigned* done_flag, unsigned done_seq) {
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
-    __shared__ Smem sm;
+    __shared__ SmemL sm;
+    WL_BEGIN(s.cnt);
     const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
     const int slot = blockIdx.x, node = first_node + blockIdx.x, o = first_out + blockIdx.x;
     DevState* st = s.st + slot;
@@ -308,12 +583,12 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 8 : 4) k_node_lds(Sl
     uint8_t* dirty = s.dirty + (long long)slot * s.pcol_stride;
     double* rhs = s.rhs + (long long)slot * s.pcol_stride;
     // restore(): the dirty rows, found by all threads at once and compacted into the LDS list
-    if (tid == 0) sm.flag2 = 0;
+    if (tid == 0) sm.n_list = 0;
     __syncthreads();
     for (int r = tid; r < H; r += blockDim.x)
-        if (dirty[r]) L.list[atomicAdd(&sm.flag2, 1)] = r;
+        if (dirty[r]) L.list[atomicAdd(&sm.n_list, 1)] = r;
     __syncthreads();
-    const int n = sm.flag2;
+    const int n = sm.n_list;
     if (s.cnt && tid == 0) atomicAdd(s.cnt + CNT_RESTORED, (cnt_t)n);
     const double2* src = reinterpret_cast<const double2*>(snap.A);
     double2* dst = reinterpret_cast<double2*>(A);
@@ -322,6 +597,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 8 : 4) k_node_lds(Sl
         for (int k = lane; k < ld2; k += 64) dst[(long long)r * ld2 + k] = src[(long long)r * ld2 + k];
         if (lane == 0) { dirty[r] = 0; rhs[r] = snap.rhs[r]; }
     }
+    __syncthreads();
+    WL_MARK(0);
     int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
     int32_t* vibc = s.vibc + (long long)slot * s.vibc_stride;
     int32_t* rbv = s.rbv + (long long)slot * s.idx_stride;
@@ -335,11 +612,18 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 8 : 4) k_node_lds(Sl
         st->err = ERR_NONE;
     }
     __syncthreads();
-    add_cuts_slot(s, cuts, slot, node, cap_rows);
+    WL_MARK(1);
+    add_cuts_waves(s, cuts, slot, node, cap_rows);
     __syncthreads();
+    WL_MARK(2);
     const Ctx c = slot_ctx(s, slot, check_cycles);
-    simplex_wg_lds(c, sm, L, iters_cap);
+    simplex_wg_lds<(THREADS >= 1024 ? 8 : 4)>(c, sm, L, iters_cap);
+#ifdef JSLP_DEBUG_WGLDS
+    wl_prev = __builtin_amdgcn_s_memtime();
+#endif
     gather_slot(s, slot, rhs_out, rows_out, state_out, out_stride, o);
+    __syncthreads();
+    WL_MARK(12);
     if (done_flag) {
         __threadfence_system();
         __syncthreads();

@@ -94,8 +94,9 @@ def test_watched_read_back_equals_full_read_back_hip(hip_lib):
 def _counted_batch(lib, n_nodes=60):
     g = G.load(MONSTER_II)
     t, calls = _root(lib, g)
-    t.set_counting(True)
     nodes = [c["cuts"] or [] for c in calls[1:1 + n_nodes]]
+    t.applyCutsBatch(nodes, check_cycles=True)  # the first batch after save() fills every tableau copy in full
+    t.set_counting(True)
     t.applyCutsBatch(nodes, check_cycles=True)
     c = t.get_counters()
     t.set_counting(False)
@@ -189,4 +190,23 @@ def test_pivot_trace_overflow_is_an_error(hip_lib):
     t.upload(m, vibr, vibc)  # a new hand-over starts a new trace
     t.simplex(check_cycles=False)
     assert pivot_digest(t.pivot_trace()) == "1cda2607"
+    t.close()
+
+
+@pytest.mark.gpu
+def test_large_batch_repeated(hip_lib):
+    """bench.py's relaxation workload as a test: 2416 independent nodes (three groups of tableau copies), a dozen calls in a
+    row on the same engine, every node's outcome checked against the reference's on the first and on the last call"""
+    g = G.load(MONSTER_II)
+    t, calls = _root(hip_lib, g, extra_rows=2 * 112)
+    nodes = [c["cuts"] or [] for c in calls[1:]] * 16
+    packed = t.pack_cut_lists(nodes)
+    for k in range(12):
+        results, rhs, rows = t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+        if k in (0, 11):
+            for i in range(len(nodes)):
+                call = calls[1 + i % 151]
+                h = results[i].height
+                assert h == call["height"] and bool(results[i].feasible) == call["feasible"]
+                assert G.sha_rhs(rhs[i, :h], rows[i, :h]) == call["rhsSha"], (k, i)
     t.close()

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Where does a branch-and-bound node spend its time inside the one-workgroup kernel?  (debug build: -DJSLP_DEBUG_WGLDS,
+JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so; the library prints the per-section cycle table on get_counters)
+  tools/wglds_timing.py single|batch|rate"""
+import gzip, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from jslpsolver_amd import Model, _capi
+from jslpsolver_amd.engine import Tableau
+lib = _capi.load_hip()
+with gzip.open(os.path.join(ROOT, "tests", "golden", "fixtures", "Monster_II.json.gz"), "rt") as fh:
+    g = json.load(fh)
+model = Model(g["model"])
+m, vibr, vibc = model.build_tableau()
+base = [c["cuts"] or [] for c in g["simplexCalls"][1:]]
+t = Tableau(m, vibr, vibc, model.unrestricted, precision=model.precision, row_capacity=m.shape[0] + 2 * len(model.integerVariables), lib=lib)
+t.applyCuts([], check_cycles=True)
+t.save()
+mode = sys.argv[1]
+if mode == "single":
+    for cuts in base[:20]:
+        t.applyCuts(cuts, check_cycles=True)
+    t.set_counting(True)
+    t0 = time.perf_counter()
+    for cuts in base:
+        t.applyCuts(cuts, check_cycles=True)
+    dt = time.perf_counter() - t0
+    print("single nodes: %.1f us per relaxation (host wall, counting on)" % (1e6 * dt / len(base)), flush=True)
+    print(t.get_counters(), flush=True)
+    t.set_counting(False)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        for cuts in base:
+            t.applyCuts(cuts, check_cycles=True)
+    dt = time.perf_counter() - t0
+    print("single nodes: %.1f us per relaxation (host wall, counting off)" % (1e6 * dt / (3 * len(base))), flush=True)
+else:
+    nodes = base * 16
+    packed = t.pack_cut_lists(nodes)
+    for _ in range(5):
+        t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+    if mode == "batch":
+        t.set_counting(True)
+        t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+        print(t.get_counters(), flush=True)
+        t.set_counting(False)
+    best = 1e9
+    for _ in range(8):
+        t0 = time.perf_counter()
+        t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+        best = min(best, time.perf_counter() - t0)
+    print("batch %d nodes: %.0f us, %.0f relaxations/s  [threads %s group %s wglds %s]" % (
+        len(nodes), best * 1e6, len(nodes) / best, os.environ.get("JSLP_WG_BATCH_THREADS", "512"), os.environ.get("JSLP_GROUP_MAX", "1024"),
+        "off" if os.environ.get("JSLP_NO_WGLDS") == "1" else "on"), flush=True)
