@@ -670,9 +670,21 @@ static bool fused_eligible(const jslp_engine* e) {
     return e->n_unr == 0 && e->n_opt == 0 && e->ld <= 2 * JSLP_F_THREADS && e->cap_rows <= 64 * JSLP_F_MAXG && e->precision >= 1e-15;
 }
 
-static bool resident_eligible(const jslp_engine* e, int H) {
-    return !e->no_resident && fused_eligible(e) && H <= JSLP_R_MAXROWS * JSLP_F_MAXG;  // tall geometry above 8 rows per workgroup
+// Geometry of the register-resident kernel for this tableau: lanes x columns per lane must cover a row (ld), rows per
+// workgroup x 256 workgroups the height, and rows x columns per lane must fit the lane's registers.  0 = does not fit.
+//   1: <1024, 2, 8>   ld <= 2048, H <= 2048 (the headline shape)      2: <512, 4, 8>  (JSLP_RES_CPT=4, measured slower)
+//   3: <512, 4, 16>   ld <= 2048, H <= 4096                            4: <512, 6, 12> ld <= 3072, H <= 3072 (3001 x 3001: 72 MB)
+//   5: <512, 8, 8>    ld <= 4096, H <= 2048
+static int resident_geometry(const jslp_engine* e, int H) {
+    if (e->no_resident || e->n_opt > 0 || e->precision < 1e-15) return 0;  // (see k_pivot_fused for the precision condition)
+    const int rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
+    if (e->ld <= 2048 && rpb <= 8) return e->res_cpt == 4 ? 2 : 1;
+    if (e->ld <= 2048 && rpb <= 16) return 3;
+    if (e->ld <= 3072 && rpb <= 12) return 4;
+    if (e->ld <= 4096 && rpb <= 8) return 5;
+    return 0;
 }
+static bool resident_eligible(const jslp_engine* e, int H) { return resident_geometry(e, H) != 0; }
 
 static int ensure_resident(jslp_engine* e) {
     if (e->r_sync) return JSLP_OK;
@@ -874,13 +886,19 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             // lane geometry: 1024 lanes x 2 columns, or 512 lanes x 4 columns (half the waves per workgroup barrier)
             // up to 8 rows per workgroup: 1024 lanes x 2 columns (or 512 x 4, measured slower); 9..16 rows (2048 < H <= 4096):
             // 512 lanes x 4 columns x 16 rows -- 2 waves per SIMD leave 256 VGPRs per lane for the 64 MB of tableau
-            hipError_t le;
-            if (rc.rpb > JSLP_R_ROWS)
-                le = hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 4, 16>, dim3(rc.G), dim3(512), args, 0, s);
-            else if (e->res_cpt == 4)
-                le = hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 4, 8>, dim3(rc.G), dim3(512), args, 0, s);
-            else
-                le = hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2, 8>, dim3(rc.G), dim3(1024), args, 0, s);
+            hipError_t le = hipErrorInvalidValue;
+            const bool unr = e->n_unr > 0;  // unrestricted variables: the UNR build threads the per-column flags through
+#define JSLP_RES_LAUNCH(T, C, R)                                                                                             \
+    le = unr ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, true>, dim3(rc.G), dim3(T), args, 0, s)    \
+             : hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false>, dim3(rc.G), dim3(T), args, 0, s)
+            switch (resident_geometry(e, H)) {
+                case 1: JSLP_RES_LAUNCH(1024, 2, 8); break;
+                case 2: JSLP_RES_LAUNCH(512, 4, 8); break;
+                case 3: JSLP_RES_LAUNCH(512, 4, 16); break;
+                case 4: JSLP_RES_LAUNCH(512, 6, 12); break;
+                case 5: JSLP_RES_LAUNCH(512, 8, 8); break;
+            }
+#undef JSLP_RES_LAUNCH
             if (le == hipSuccess) {
                 if (e->timing) HIPC(hipEventRecord(k1, s));
                 const int it_before = 0;  // k_begin zeroed the pivot counters

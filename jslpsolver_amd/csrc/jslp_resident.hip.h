@@ -59,6 +59,7 @@ struct RSmem {
     double l_k;       // leader: pivot-column entry of the winning row
     int32_t l_rdeg, l_r;
     int32_t ok;
+    int32_t p_neg;    // pricing: isReducedCostNegative of the winning column (unrestricted variables only, simplex.ts:164-177)
     int32_t pubrow;
     unsigned dec[4];
     double xq[2];   // phase 1: quot and k0 broadcast by the lane pair owning column pc
@@ -111,17 +112,20 @@ __device__ __forceinline__ bool sweep_summary(const ResCtx& f, int par, unsigned
 // holds, reduced with three LDS atomics: first batch holding a candidate, best value in it, first column with
 // that value.  Positive doubles order like their bit patterns.  Returns the column (0 = none) and its value.
 // `sm.p_*` must have been reset (p_batch = INT_MAX, p_val = 0, p_col = INT_MAX) before a preceding barrier.
-template <int CPT>
+// UNR: columns whose variable is unrestricted (bit j of `unr`) price with |rc| and hand isReducedCostNegative to the ratio
+// test (simplex.ts:164-177, 282); *value receives the signed reduced cost of the winner, *neg the flag.
+template <int CPT, bool UNR>
 __device__ __forceinline__ int price_row_lds(const double (&x)[CPT], int c0, const int (&pb)[CPT], const Ctx& c, RSmem& sm,
-                                             double* value) {
+                                             double* value, unsigned unr, int* neg) {
     double bv = c.precision;
     int bi = 0, bb = 0;
 #pragma unroll
     for (int j = 0; j < CPT; j++) {  // my columns in order: earlier batch first, bigger value inside a batch, first index on ties
         const int col = c0 + j;
-        const bool ok = col >= 1 && col < c.W && x[j] > c.precision;
-        const bool take = ok && (bi == 0 || pb[j] < bb || (pb[j] == bb && x[j] > bv));
-        bv = take ? x[j] : bv;
+        const double val = (UNR && ((unr >> j) & 1u) && x[j] < 0) ? -x[j] : x[j];
+        const bool ok = col >= 1 && col < c.W && val > c.precision;
+        const bool take = ok && (bi == 0 || pb[j] < bb || (pb[j] == bb && val > bv));
+        bv = take ? val : bv;
         bi = take ? col : bi;
         bb = take ? pb[j] : bb;
     }
@@ -142,8 +146,18 @@ __device__ __forceinline__ int price_row_lds(const double (&x)[CPT], int c0, con
     const u64_t wv = sm.p_val;
     if (bi != 0 && bb == wb && bits == wv) atomicMin(&sm.p_col, bi);
     __syncthreads();
-    *value = __longlong_as_double((long long)wv);
-    return sm.p_col;
+    const int pcol = sm.p_col;
+    double v = __longlong_as_double((long long)wv);
+    if (UNR) {  // the lane holding the winner knows the sign of its reduced cost
+#pragma unroll
+        for (int j = 0; j < CPT; j++)
+            if (pcol == c0 + j) sm.p_neg = (((unr >> j) & 1u) && x[j] < 0) ? 1 : 0;
+        __syncthreads();
+        *neg = sm.p_neg;
+        if (*neg) v = -v;
+    }
+    *value = v;
+    return pcol;
 }
 
 #ifdef JSLP_DEBUG_RESIDENT
@@ -185,6 +199,8 @@ struct ResRegs {
     double a[ROWS][CPT];  // my rows: CPT adjacent columns per lane
     double r0[CPT];              // my copy of the cost row
     double k0;
+    unsigned unr;  // bit j: the variable of my column j is unrestricted (UNR builds)
+    int neg;       // isReducedCostNegative of the entering column (phase 2, UNR builds)
     int pc, end_code, unbounded_col, hist_n, it1, it2;
     unsigned epoch;
     long long trace_n;
@@ -197,7 +213,7 @@ struct ResRegs {
 // One phase of the solve.  PHASE is a compile-time constant so that the phase-2 loop -- the hot one -- carries none of
 // the phase-1 branches; returns when the solve ends (R.end_code != 0) or, for PHASE == 1, when phase 1 is over
 // (end_code stays 0 and the caller starts phase 2).
-template <int PHASE, int CPT, int ROWS>
+template <int PHASE, int CPT, int ROWS, bool UNR>
 __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start,
                                                const int (&pb)[CPT]) {
     const Ctx& c = f.c;
@@ -264,7 +280,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                     if (r >= 1 && r < r_end && rhs < -precision) { quo = rhs; kind = 2; }
                 } else if (r >= 1 && r < r_end && !(-precision < colv && colv < precision)) {
                     if (colv > 0 && precision > rhs && rhs > -precision) kind = 1;
-                    else { quo = rhs / colv; kind = quo > precision ? 2 : 0; }
+                    else { quo = (UNR && R.neg) ? -rhs / colv : rhs / colv; kind = quo > precision ? 2 : 0; }
                 }
                 sm.quo[tid] = quo;
                 sm.kind[tid] = kind;
@@ -380,9 +396,15 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             }
             if (tid < 3) {
                 const u64_t qb = (u64_t)__double_as_longlong(quot);
-                const unsigned payload = tid == 0 ? ((unsigned)pr | ((unsigned)stop << 16)) : (tid == 1 ? (unsigned)qb : (unsigned)(qb >> 32));
+                unsigned lead = (unsigned)pr | ((unsigned)stop << 16);
+                // the entering column inherits the LEAVING variable (simplex.ts:339-349): every workgroup needs to know whether
+                // that variable is unrestricted; only this workgroup sees the row map
+                if (UNR && tid == 0 && !stop && c.unr[c.vibr[pr]] != 0) lead |= 1u << 24;
+                const unsigned payload = tid == 0 ? lead : (tid == 1 ? (unsigned)qb : (unsigned)(qb >> 32));
                 AG_STORE(f.decision[par] + tid, ((u64_t)tag << 32) | payload);
+                if (UNR && tid == 0) sm.dec[0] = lead;
             }
+            if (UNR) __syncthreads();
         } else {
             if (tid < 64) {
                 unsigned spins = 0;
@@ -403,9 +425,10 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             __syncthreads();
             if (!sm.ok) { end_code = 5; break; }
             pr = (int)(sm.dec[0] & 0xffffu);
-            stop = (int)(sm.dec[0] >> 16);
+            stop = (int)((sm.dec[0] >> 16) & 0xffu);
             quot = __longlong_as_double((long long)((u64_t)sm.dec[1] | ((u64_t)sm.dec[2] << 32)));
         }
+        const bool leaving_unr = UNR && ((sm.dec[0] >> 24) & 1u);
         RT_MARK(3);
         if (stop == 3) { end_code = 2; unbounded_col = pc; break; }
         if (stop == 1) { end_code = 3; break; }
@@ -460,7 +483,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             for (int j = 0; j < CPT; j++) {
                 const int col = c0 + j;
                 const double coef = pv[j];
-                if (col >= 1 && col < W && coef < -precision) {
+                if (col >= 1 && col < W && ((UNR && ((R.unr >> j) & 1u)) || coef < -precision)) {
                     const double quo = -r0[j] / coef;
                     const bool take = best.v < quo;
                     best.v = take ? quo : best.v;
@@ -608,13 +631,18 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             c.cbv[leaving] = pc;
             if (trace_n < c.trace_cap) c.trace[trace_n] = make_int2(pr, pc);
         }
+        if (UNR && has_pc) {
+#pragma unroll
+            for (int j = 0; j < CPT; j++)
+                if (pc == c0 + j) R.unr = (R.unr & ~(1u << j)) | ((leaving_unr ? 1u : 0u) << j);
+        }
         trace_n += 1;
         if (phase == 1) it1 += 1; else it2 += 1;
         epoch += 1;
         RT_MARK(6);
         // ---- G: phase 2: price the new cost row -> entering column of the next pivot -----------------------------------
         if (phase == 2) {
-            pc = price_row_lds<CPT>(r0, c0, pb, c, sm, &k0);
+            pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &k0, R.unr, &R.neg);
             if (pc == 0) end_code = 1;
         }
     }
@@ -622,7 +650,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
 
 // THREADS x CPT >= ld: <1024, 2> = lane pairs of columns, 4 waves per SIMD; <512, 4> = half the waves to synchronise,
 // twice the independent work per lane (and 256 VGPRs per lane).
-template <int THREADS, int CPT, int ROWS>
+template <int THREADS, int CPT, int ROWS, bool UNR>
 __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     static_assert(ROWS <= JSLP_R_MAXROWS, "RSmem holds one entry per row of the workgroup");
     __shared__ RSmem sm;
@@ -697,18 +725,25 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
 #pragma unroll
     for (int j = 0; j < CPT; j++) pb[j] = c.use_partial && c0 + j >= 1 ? (c0 + j - 1) / c.batch : 0;
     R.k0 = 0.0;  // reduced cost of the entering column = cost-row entry of column pc
+    R.unr = 0;
+    R.neg = 0;
+    if (UNR) {  // which of my columns carry an unrestricted variable (model.unrestrictedVariables, tableau.ts:57)
+#pragma unroll
+        for (int j = 0; j < CPT; j++)
+            if (c0 + j >= 1 && c0 + j < c.W && c.unr[c.vibc[c0 + j]] != 0) R.unr |= 1u << j;
+    }
     R.pc = 0;
     R.end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted hand-off, 6 history full, 7 infeasible
     R.unbounded_col = 0;
     R.epoch = 0;
     if (phase == 1) {
-        resident_phase<1, CPT, ROWS>(f, sm, R, it1_start, it2_start, pb);
+        resident_phase<1, CPT, ROWS, UNR>(f, sm, R, it1_start, it2_start, pb);
         if (R.end_code == 0) phase = 2;
     }
     if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
-        R.pc = price_row_lds<CPT>(r0, c0, pb, c, sm, &R.k0);
+        R.pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg);
         if (R.pc == 0) R.end_code = 1;
-        else resident_phase<2, CPT, ROWS>(f, sm, R, it1_start, it2_start, pb);
+        else resident_phase<2, CPT, ROWS, UNR>(f, sm, R, it1_start, it2_start, pb);
     }
     const int end_code = R.end_code, unbounded_col = R.unbounded_col, hist_n = R.hist_n, it1 = R.it1, it2 = R.it2;
     const unsigned epoch = R.epoch;

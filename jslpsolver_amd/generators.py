@@ -97,6 +97,23 @@ def dense_resource_allocation_tableau(seed, n, m):
     return matrix, vibr, vibc
 
 
+def unrestricted_resource_allocation_tableau(seed, n, m, k):
+    """generateResourceAllocation({seed, numVariables: n, numConstraints: m, density: 1.0}) whose first k activities are
+    declared `unrestricted`, get their profit negated and a lower bound `lower<i>: {min: -(1 + i % 7)}` each -- the model
+    tests/golden/gen_golden_wide.js hands to the reference.  Tableau (m + k + 1) x (n + 1); returns (matrix,
+    varIndexByRow, varIndexByCol, unrestricted variable indexes)."""
+    base, _, _ = dense_resource_allocation_tableau(seed, n, m)
+    matrix = np.zeros((m + k + 1, n + 1), dtype=np.float64)
+    matrix[:m + 1] = base
+    matrix[0, 1:k + 1] = -base[0, 1:k + 1]          # negated profit, "max" => cost row = +cost
+    for i in range(k):                               # "min" rows are negated, RHS included (tableau.ts:371-378)
+        matrix[m + 1 + i, 1 + i] = -1.0
+        matrix[m + 1 + i, 0] = float(1 + i % 7)
+    vibr = np.concatenate(([-1], np.arange(m + k))).astype(np.int32)   # constraints are created first
+    vibc = np.concatenate(([-1], m + k + np.arange(n))).astype(np.int32)
+    return matrix, vibr, vibc, [m + k + i for i in range(k)]
+
+
 def dense_random_lp_tableau(seed, n, m):
     """Same for generateRandomLP({seed, numVariables: n, numConstraints: m, density: 1.0}) -- config 3b.
     Returns (matrix, varIndexByRow, varIndexByCol, opType)."""

@@ -2,6 +2,7 @@
 hot path running on the MI355X engine.  Model parsing and the branch-and-bound tree stay on the CPU.
 """
 import math
+import warnings
 
 from . import _capi
 from .branch_and_cut import branch_and_cut, js_round
@@ -9,6 +10,7 @@ from .engine import Tableau
 from .model import Model, js_keys
 
 EPSILON = 2.220446049250313e-16
+_presolve_warned = False
 
 
 def _round_value(v, rounding_coeff):
@@ -27,10 +29,25 @@ def Solve(model, precision=None, full=False, validate=False, lib=None, device=0,
     `lib` selects the engine library (default: the HIP product library; tests pass the CPU oracle to exercise
     the host logic without a GPU).  Returns the simplified result dict, or -- with full=True -- a dict that
     also carries the final tableau read-back.
+
+    Differences from the reference host, by design (this Python host exists for pytest and bench.py; the drop-in host
+    is the reference's own code under host/gpu-tableau.js): the presolve pre-pass (src/tableau/presolve.ts, on by
+    default for models with integer variables) is NOT run -- it can fix variables or declare infeasibility before any
+    simplex, so results may differ on models it touches (a UserWarning says so once); `options.keep_solutions` is
+    rejected (UnsupportedModel).
     """
+    global _presolve_warned
     if model is None:
         raise ValueError("Solver requires a model to operate on")  # main.ts:110-112
     m = Model(model, precision)
+    if m.keep_solutions:
+        from .model import UnsupportedModel
+        raise UnsupportedModel("options.keep_solutions is not collected by the Python host (use the reference host + binding)")
+    if m.usePresolve and len(m.integerVariables) > 0 and not _presolve_warned:
+        _presolve_warned = True
+        warnings.warn("jslpsolver_amd.Solve does not run the reference's presolve pre-pass (src/tableau/presolve.ts): on models "
+                      "where presolve fixes variables or proves infeasibility the result can differ from solver.Solve(); "
+                      "pass options.presolve = false to compare like with like, or use the reference host + binding", stacklevel=2)
     matrix, vibr, vibc = m.build_tableau()
     n_int = len(m.integerVariables)
     # cut rows: at most one "min" and one "max" cut per integer variable (branch-and-cut.ts:166-179)
@@ -50,6 +67,13 @@ def Solve(model, precision=None, full=False, validate=False, lib=None, device=0,
     t = Tableau(matrix, vibr, vibc, m.unrestricted, precision=m.precision, row_capacity=matrix.shape[0] + extra,
                 device=device, lib=lib, optional_objectives=optional_rows,
                 integer_variables=[v["index"] for v in m.integerVariables] if m.useMIRCuts else None)
+    try:
+        return _solve_on(t, m, n_int, incremental, speculate, group, full)
+    finally:
+        t.close()  # also on errors (JSLP_ERR_CAPACITY ...): the engine goes back to the library's resource pool
+
+
+def _solve_on(t, m, n_int, incremental, speculate, group, full):
     iterations = 0
     integral = False
     if n_int > 0:  # tableau.ts:250-258
@@ -94,5 +118,4 @@ def Solve(model, precision=None, full=False, validate=False, lib=None, device=0,
         result = {"result": result, "solutionSet": solution_set, "matrix": fm, "varIndexByRow": fvibr,
                   "varIndexByCol": fvibc, "iter": iterations, "pivots": t.pivot_trace(), "model": m,
                   "checkpoints": getattr(t, "checkpoints_used", 0), "incrementalNodes": getattr(t, "incremental_nodes", 0)}
-    t.close()
     return result

@@ -63,7 +63,7 @@ P.solve = function () {
         const t = this;
         const model = t.model;
         const rows = [], cols = [], vals = [];
-        for (let r = 0; r < t.height; r++) {
+        for (let r = 0; r < t.height && !rec.lite; r++) {  // (lite: dense instances are pinned by matrixSha alone)
             for (let c = 0; c < t.width; c++) {
                 const v = t.matrix[r * t.width + c];
                 if (v !== 0 || Object.is(v, -0)) {
@@ -131,8 +131,8 @@ P.simplex = function () {
     return this;
 };
 
-function run(model, keepPivots) {
-    rec = { pivots: [], h: 2166136261 | 0, simplexCalls: [], pendingCuts: null, cur: null, tableau: null, savedAfterCall: -1 };
+function run(model, keepPivots, lite) {
+    rec = { pivots: [], h: 2166136261 | 0, simplexCalls: [], pendingCuts: null, cur: null, tableau: null, savedAfterCall: -1, lite: !!lite };
     const t0 = process.hrtime.bigint();
     const solution = solver.Solve(JSON.parse(JSON.stringify(model)), undefined, true);
     const ms = Number(process.hrtime.bigint() - t0) / 1e6;
@@ -174,6 +174,10 @@ function write(dir, name, obj) {
     return file;
 }
 
+module.exports = { run, write, gen };
+if (require.main === module) main();
+
+function main() {
 const only = process.argv[2];
 
 // ---- 1. the reference's known-answer fixtures --------------------------------------------------
@@ -232,4 +236,5 @@ for (const s of synth) {
     index.synthetic.push({ file: path.basename(file), gen: s.gen, opts: s.opts, pivots: out.nPivots, digest: out.pivotDigest,
         feasible: out.final.feasible, bounded: out.final.bounded, result: out.result.result, refWallMs: out.refWallMs });
     console.log("synthetic", name, out.nPivots, out.pivotDigest, out.final.feasible, out.result.result, out.refWallMs.toFixed(0) + "ms");
+}
 }

@@ -1,0 +1,52 @@
+// Golden vectors for the tableau shapes beyond the headline 2001 x 2001 (TEST INFRASTRUCTURE; build container only):
+//   node --max-old-space-size=12000 tests/golden/gen_golden_wide.js [name filter]
+// The reference itself (oracle/_ref) solves
+//   * wide dense LPs: generateResourceAllocation / generateRandomLP at 3000 x 3000 (tableau 3001 x 3001, 72 MB: the
+//     column-wider register-resident geometry) -- options.exitOnCycles = false like every dense golden with N >= 100;
+//   * dense LPs with UNRESTRICTED variables (simplex.ts:56-71, 164-177, 282): generateResourceAllocation whose first K
+//     activities are declared unrestricted, get a NEGATIVE profit (so that they price out through the negative-reduced-cost
+//     branch and enter downwards) and a lower bound `lower<i>: {min: -(1 + i % 7)}` that keeps the LP bounded;
+//   * config 3a once more with the reference's DEFAULT cycle check on (model.ts:73) at full size.
+// and every pivot (row, col), the flags and the sha256 of the initial and final tableau are recorded.  The models are
+// rebuilt at test time by jslpsolver_amd.generators (checked against matrixSha), so only the traces are stored.
+"use strict";
+const path = require("path");
+const { run, write, gen } = require("./gen_golden.js");
+
+function unrestrictedRA(n, m, k, seed) {
+    const model = gen.generateResourceAllocation({ seed, numVariables: n, numConstraints: m, density: 1.0 });
+    model.unrestricted = {};
+    for (let i = 0; i < k; i++) {
+        const id = "activity" + i;
+        model.unrestricted[id] = 1;
+        model.variables[id].profit = -model.variables[id].profit;
+        model.variables[id]["lower" + i] = 1;
+        model.constraints["lower" + i] = { min: -(1 + (i % 7)) };
+    }
+    return model;
+}
+
+const cases = [
+    { name: "unrestricted_RA_300x250_k20", build: () => unrestrictedRA(300, 250, 20, 12345), exit: false, meta: { kind: "unrestricted", n: 300, m: 250, k: 20 } },
+    { name: "unrestricted_RA_1000x950_k50", build: () => unrestrictedRA(1000, 950, 50, 12345), exit: false, meta: { kind: "unrestricted", n: 1000, m: 950, k: 50 } },
+    { name: "unrestricted_RA_2000x3950_k50", build: () => unrestrictedRA(2000, 3950, 50, 12345), exit: false, meta: { kind: "unrestricted", n: 2000, m: 3950, k: 50 } },
+    { name: "cyclecheck_RA_2000x2000", build: () => gen.generateResourceAllocation({ seed: 12345, numVariables: 2000, numConstraints: 2000, density: 1.0 }), exit: true, meta: { kind: "ra", n: 2000, m: 2000 } },
+    { name: "wide_RandomLP_3000x3000", build: () => gen.generateRandomLP({ seed: 12345, numVariables: 3000, numConstraints: 3000, density: 1.0 }), exit: false, meta: { kind: "lp", n: 3000, m: 3000 } },
+    { name: "wide_RA_3000x3000", build: () => gen.generateResourceAllocation({ seed: 12345, numVariables: 3000, numConstraints: 3000, density: 1.0 }), exit: false, meta: { kind: "ra", n: 3000, m: 3000 } },
+];
+const filter = process.argv[2] || "";
+for (const c of cases) {
+    if (!c.name.includes(filter)) continue;
+    const model = c.build();
+    if (!c.exit) model.options = { exitOnCycles: false };
+    const out = run(model, true, true);
+    out.model = null;
+    out.meta = c.meta;
+    out.exitOnCycles = c.exit;
+    out.tableau.rows = out.tableau.cols = out.tableau.vals = null;
+    out.tableau.variableIds = null;
+    out.final.rhs = null;
+    write(path.join(__dirname, "wide"), c.name, out);
+    console.log(c.name, out.tableau.height + "x" + out.tableau.width, out.nPivots, out.pivotDigest, out.final.feasible, out.final.bounded,
+        out.result.result, out.refWallMs.toFixed(0) + "ms");
+}
