@@ -37,11 +37,25 @@ function loadEngine(options) {
     return backend;
 }
 
-// opts.minCells (default 0 = everything runs on the engine): tableaus with fewer cells stay on the reference's own
-// TypeScript path -- a host policy for models so small that one launch + synchronisation per simplex() (~0.1 ms) costs
-// more than the reference's whole pivot loop (LargeFarmMIP: 36 x 101, 0.02 ms per relaxation on the CPU)
+// Size policy: which tableaus go to the engine.  Measured on the MI355X box (tools/mincells_sweep.js, tools/shim_profile.js;
+// profiles/r02_mincells_sweep.md): an LP pays from ~10 k cells (one launch + synchronisation per simplex(), ~0.1 ms, against
+// the reference's whole pivot loop); a branch-and-bound tree walked node by node costs ~50-80 us per relaxation on the engine
+// whatever the size, which the reference's CPU path undercuts until a relaxation touches a few hundred thousand cells
+// (LargeFarmMIP, 36 x 101: 0.017 ms per relaxation on the CPU); batched speculative evaluation (install(..., {speculate}))
+// amortises that latency over the batch.  opts.minCells overrides all three defaults (0 = everything runs on the engine).
+const DEFAULT_MIN_CELLS_LP = 8192;
+const DEFAULT_MIN_CELLS_INTEGER = 262144;
+const DEFAULT_MIN_CELLS_INTEGER_BATCHED = 32768;
+function minCellsFor(t, opts) {
+    if (opts.minCells !== undefined) return opts.minCells;
+    const nInts = t.model ? t.model.getNumberOfIntegerVariables() : 0;
+    if (nInts === 0) return DEFAULT_MIN_CELLS_LP;
+    return opts.speculate > 1 ? DEFAULT_MIN_CELLS_INTEGER_BATCHED : DEFAULT_MIN_CELLS_INTEGER;
+}
 function eligible(t, opts) {
-    return bypass === 0 && !(opts.minCells > 0 && t.width * t.height < opts.minCells);
+    if (bypass !== 0) return false;
+    const min = minCellsFor(t, opts);
+    return !(min > 0 && t.width * t.height < min);
 }
 
 // the engine of a tableau whose dimensions are known (Tableau.initialize ran); the upload follows in activate()

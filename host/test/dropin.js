@@ -59,7 +59,7 @@ function editScript(file) {
 const editFiles = ["Berlin_Air_Lift_Problem", "Wiki_1", "Monster_Problem", "Shift_Work_Problem"];
 const editBase = {};
 if (!filter && dir.indexOf("fixtures") >= 0) for (const f of editFiles) editBase[f] = editScript(f);
-let uninstall = gpu.install(Tableau, { SlackVariable, solver });
+let uninstall = gpu.install(Tableau, { SlackVariable, solver, minCells: 0 }); // parity runs: EVERY tableau on the engine
 
 function num(x) {
     if (typeof x !== "number") return x;
@@ -172,7 +172,7 @@ if (!filter && dir.indexOf("fixtures") >= 0 && fs.existsSync(mirFile)) {
 let speculativeOk = 0;
 if (!filter && dir.indexOf("fixtures") >= 0) {
     uninstall();
-    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16 });
+    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16, minCells: 0 });
     for (const f of fs.readdirSync(dir).filter((x) => x.endsWith(".json.gz")).sort()) {
         const g = loadGolden(dir, f);
         if (!g.model || !g.tableau || g.tableau.integerVarIndexes.length === 0) continue;
@@ -199,7 +199,7 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
 let fuzzOk = 0;
 if (!filter && dir.indexOf("fixtures") >= 0) {
     uninstall();
-    uninstall = gpu.install(Tableau, { SlackVariable, solver });
+    uninstall = gpu.install(Tableau, { SlackVariable, solver, minCells: 0 });
     for (const name of ["fuzz_services.jsonl.gz", "fuzz_soft.jsonl.gz"]) {
         const file = path.join(root, "tests", "golden", name);
         if (!fs.existsSync(file)) continue;
@@ -251,7 +251,7 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
 let poolOk = 0;
 if (!filter && dir.indexOf("fixtures") >= 0) {
     uninstall();
-    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16, devices: [0, 0, 0, 0] });
+    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16, devices: [0, 0, 0, 0], minCells: 0 });
     for (const f of fs.readdirSync(dir).filter((x) => x.endsWith(".json.gz")).sort()) {
         const g = loadGolden(dir, f);
         if (!g.model || !g.tableau || g.tableau.integerVarIndexes.length === 0) continue;
@@ -272,11 +272,11 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
         if (bad.length) { fail += 1; console.log("FAIL pool", f, bad.join("; ")); } else poolOk += usedPool ? 1 : 0;
     }
 }
-// install(..., { minCells }): a host policy that leaves small tableaus on the reference's own path -- also under the injected services
+// the DEFAULT size policy (no minCells given): small tableaus stay on the reference's own path -- also under the injected services
 let policyOk = 0;
 if (!filter && dir.indexOf("fixtures") >= 0) {
     uninstall();
-    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16, minCells: 100000 });
+    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16 });
     for (const [f, expectOnEngine] of [["Knapsack_1", false], ["LargeFarmMIP", false], ["Monster_II", true], ["Monster_Problem", true]]) {
         for (const extra of [{}, { useIncremental: true }]) {
             const g = loadGolden(dir, f + ".json.gz");

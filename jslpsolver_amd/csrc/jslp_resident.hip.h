@@ -241,6 +241,13 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
     u64_t& rt_prev = R.rt_prev;
 #endif
     (void)H;
+    // candidate rows travel as 16-byte write-through (sc1) buffer stores / loads: a lane holds its columns as adjacent pairs,
+    // and the same bytes issued as 8-byte agent atomics cost one fabric write each (cdna_hip_programming.md, Guideline 16 R1
+    // and pitfall 7: narrow sc1 stores are 2.7x the time per byte) -- half the stores, half the counted write traffic
+    typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+    const int pub_bytes = f.G * ld * 8;
+    const auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_bytes, 0x00020000);
+    const auto rsrc1 = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[1], 0, pub_bytes, 0x00020000);
     while (end_code == 0) {
         if ((it1 - it1_start) + (it2 - it2_start) >= f.iters_cap) { end_code = 4; break; }
         const int par = epoch & 1;
@@ -319,12 +326,19 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         // ---- B: publish that row (write-through 8-byte agent stores); its own flag follows the drain ---------------
         const int pubrow = sm.pubrow;
         if (pubrow != 0 && colok) {
-            u64_t* rp = f.rows_pub[par] + (long long)b * ld + c0;
+            const int off = (b * ld + c0) * 8;
 #pragma unroll
             for (int i = 0; i < ROWS; i++)
                 if (r_begin + i == pubrow) {  // uniform
 #pragma unroll
-                    for (int j = 0; j < CPT; j++) AG_STORE(rp + j, (u64_t)__double_as_longlong(a[i][j]));
+                    for (int j = 0; j < CPT; j += 2) {
+                        if (c0 + j >= ld) continue;  // (a lane's last pairs may lie beyond the row when CPT does not divide 16)
+                        const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
+                        v4u_t v;
+                        v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
+                        if (par) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc1, off + j * 8, 0, 16);  // aux 16 = sc1
+                        else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc0, off + j * 8, 0, 16);
+                    }
                 }
         }
         RT_MARK(1);
@@ -441,7 +455,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         // ---- E: the winning row: loaded speculatively together with its flag; re-loaded in the rare case the flag
         //         (which follows the winner's drain) was not up yet ------------------------------------------------------
         const int bw = pr / f.rpb;
-        const u64_t* rp_in = f.rows_pub[par] + (long long)bw * ld + c0;
+        const int off_in = (bw * ld + c0) * 8;
         double pv[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; j++) pv[j] = 0.0;
@@ -450,7 +464,13 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             if (tid == 0) flag = AG_LOAD(f.rowflag[par] + bw);
             if (colok) {
 #pragma unroll
-                for (int j = 0; j < CPT; j++) pv[j] = __longlong_as_double((long long)AG_LOAD(rp_in + j));
+                for (int j = 0; j < CPT; j += 2) {
+                    if (c0 + j >= ld) continue;
+                    const v4u_t v = par ? __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off_in + j * 8, 0, 16)
+                                        : __builtin_amdgcn_raw_buffer_load_b128(rsrc0, off_in + j * 8, 0, 16);
+                    pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
+                    pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
+                }
             }
             if (tid == 0) {
                 int ok = 1;
@@ -674,7 +694,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
 #pragma unroll
     for (int j = 0; j < CPT; j += 2) {
         double2 t = make_double2(0, 0);
-        if (colok) t = *reinterpret_cast<const double2*>(c.A + c0 + j);
+        if (c0 + j < ld) t = *reinterpret_cast<const double2*>(c.A + c0 + j);
         r0[j] = t.x; r0[j + 1] = t.y;
     }
 #pragma unroll
@@ -684,7 +704,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
 #pragma unroll
         for (int j = 0; j < CPT; j += 2) {
             double2 t = make_double2(0, 0);
-            if (mine) t = *reinterpret_cast<const double2*>(c.A + (long long)r * ld + c0 + j);
+            if (mine && c0 + j < ld) t = *reinterpret_cast<const double2*>(c.A + (long long)r * ld + c0 + j);
             a[i][j] = t.x; a[i][j + 1] = t.y;
         }
     }
@@ -766,7 +786,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
             if (i < f.rpb && r < r_end && colok) {
 #pragma unroll
                 for (int j = 0; j < CPT; j += 2)
-                    *reinterpret_cast<double2*>(c.A + (long long)r * ld + c0 + j) = make_double2(a[i][j], a[i][j + 1]);
+                    if (c0 + j < ld) *reinterpret_cast<double2*>(c.A + (long long)r * ld + c0 + j) = make_double2(a[i][j], a[i][j + 1]);
             }
         }
     }

@@ -17,7 +17,11 @@ from jslpsolver_amd.sharding import evaluate_nodes_sharded  # noqa: E402
 
 
 def main():
-    dist.init_process_group("gloo")
+    backend = os.environ.get("JSLP_TEST_BACKEND", "gloo")
+    if backend == "nccl":  # RCCL: one rank per GPU (the test box has one: world_size 1 still runs the real collectives)
+        import torch
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     # CPU run: the test-only oracle stands in for the GPUs; GPU run ("virtual shards"): every rank drives the HIP engine
     # on the one visible MI355X, the exchange still goes over gloo

@@ -10,8 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import pytest
 
 
-def _run(engine, nproc, port):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", JSLP_TEST_ENGINE=engine)
+def _run(engine, nproc, port, backend="gloo"):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", JSLP_TEST_ENGINE=engine, JSLP_TEST_BACKEND=backend)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
@@ -29,6 +29,15 @@ def test_virtual_shards_on_one_gpu(hip_lib):
     for rep in reports:
         assert rep["backend"] == "hip-gfx950" and rep["world"] == 4
         assert all(c["ok"] for c in rep["cases"]), rep
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_on_one_gpu(hip_lib):
+    """the exchange step over RCCL itself (backend "nccl"): the box has one GPU, so one rank -- the process group, the
+    device-side all-gather of the outcome payload and the tree replay are the code the 8-GPU run executes"""
+    reports = _run("hip", 1, 29551, backend="nccl")
+    assert len(reports) == 1 and reports[0]["backend"] == "hip-gfx950" and reports[0]["world"] == 1
+    assert all(c["ok"] for c in reports[0]["cases"]), reports
 
 
 def test_two_ranks_shard_nodes_and_agree(oracle_lib):

@@ -30,6 +30,7 @@ for s in $steps; do
         timeout 120 python tools/rocpd_pmc.py $out $out/pmc_sq_summary.json < /dev/null | grep -A40 "k_node_lds" | head -120 ;;
     wgm) (JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py single; JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py batch) 2>&1 | grep -i "micro\|total\|single\|batch" > $out/wglds_micro.log; cat $out/wglds_micro.log ;;
     stress) for i in 1 2 3; do timeout 120 python tools/wglds_timing.py rate; done > $out/stress.log 2>&1 < /dev/null; echo "stress rc=$?"; grep -c relaxations $out/stress.log; tail -3 $out/stress.log ;;
+    sweep) timeout 600 node tools/mincells_sweep.js > $out/mincells_sweep.md 2> $out/mincells_sweep.err < /dev/null; echo "sweep rc=$?"; cat $out/mincells_sweep.md ;;
   esac
 done
 # keep the merge-back small: databases can be large
