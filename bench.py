@@ -389,10 +389,11 @@ def relaxation_legs(ctx, args, reps=16):
         n_idx = W + 2 * cap + 2
         alg = gated_bytes(c, W, n_idx, H)
         per_node = alg / max(c["relaxations"], 1)
-        traffic, note = pmc_traffic("relaxations", "k_node_wg", per_node)
+        node_kernel = "k_node_wg" if os.environ.get("JSLP_NO_WGLDS") == "1" else "k_node_lds"
+        traffic, note = pmc_traffic("relaxations", node_kernel, per_node)
         dense = 16.0 * H * W * (c["relaxations"] + c["pivots"])  # SURVEY.md 8d's dense figure, for reference only
         rate_rank0 = len(mine) / el
-        out["roofline"] = {"bound": "hbm", "kernel": "k_node_wg", "achieved": per_node * rate_rank0 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+        out["roofline"] = {"bound": "hbm", "kernel": node_kernel, "achieved": per_node * rate_rank0 / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                            "frac": per_node * rate_rank0 / HBM_PEAK, "bytes_per_unit": per_node, "unit_of_work": "one LP relaxation",
                            "traffic": traffic, "traffic_source": note,
                            "traffic_over_algorithmic": (traffic / per_node) if traffic else None,

@@ -93,6 +93,7 @@ struct jslp_engine {
     char* r_arena = nullptr; size_t r_arena_bytes = 0;  // hand-off buffers + this backup in ONE allocation (parked in the resource pool)
     DevState* r_backup_st = nullptr;
     double* rb_A = nullptr; int32_t *rb_vibr = nullptr, *rb_vibc = nullptr, *rb_rbv = nullptr, *rb_cbv = nullptr;
+    unsigned long long* d_nnz = nullptr; long long nnz = -1;  // non-zero cells of the uploaded tableau (counted on the device)
     unsigned spin_limit = 0; int test_abort_epoch = -1;
     int resident_fallbacks = 0;  // solves that were rolled back and re-run through the streaming kernels
     // checkpoints (incremental-branch-and-cut.ts:31-44): equally sized device buffers, recycled through a free list
@@ -421,6 +422,7 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
                 e->snap_rbv = cv.take<int32_t>((size_t)e->n_idx);
                 e->snap_cbv = cv.take<int32_t>((size_t)e->n_idx);
                 e->s.trace = cv.take<int2>((size_t)TRACE_CAP);
+                e->d_nnz = cv.take<unsigned long long>(1);
                 if (!pass) {
                     e->static_bytes = cv.off + 256;
                     if (have && pooled.static_bytes >= e->static_bytes) {
@@ -576,6 +578,8 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
         hipLaunchKernelGGL(k_repack, dim3((unsigned)std::min<long long>(2048, (cells + 255) / 256)), dim3(256), 0, s, e->s.A,
                            reinterpret_cast<const double*>(e->d_up), (int)H, (int)W, (int)e->ld);
     }
+    HIPC(hipMemsetAsync(e->d_nnz, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_count_nnz, dim3(256), dim3(256), 0, s, e->s.A, (int)H, (int)e->ld, e->d_nnz);
     UploadBlob ub;
     ub.vibr = reinterpret_cast<const int32_t*>(d_blob);
     ub.vibc = ub.vibr + H;
@@ -583,7 +587,9 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
     ub.H = H; ub.n_unr = n_unrestricted; ub.n_idx = e->n_idx; ub.cap_rows = e->cap_rows;
     hipLaunchKernelGGL(k_upload_finish, dim3(1), dim3(1024), 0, s, e->s, ub, e->d_unr, e->d_isint);
     HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(e->h_state, e->d_nnz, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));  // the staging buffer (and the host's view of it) is free again
+    e->nnz = (long long)*reinterpret_cast<unsigned long long*>(e->h_state);
     e->uploaded = 1;
     e->has_save = 0;
     e->root_seq += 1;
@@ -658,10 +664,19 @@ static size_t wglds_smem(const jslp_engine* e) {
     return b <= 64 * 1024 ? b : 0;
 }
 
+// one workgroup for the whole simplex(): tiny tableaus, and SPARSE ones up to a few million cells -- a pivot of the
+// LDS-resident one-workgroup kernel touches only the rows and columns the reference's gates let through (Monster LP, 1 %
+// dense: ~5 us per pivot against ~12 for the chip-wide register-resident kernel, whose hand-off latency does not shrink with
+// the work); dense tableaus of that size belong to the chip
+static const long long WG_CELLS_SPARSE = 1024LL * 1024;  // (Vendor Selection, 2.8 M cells, 0.3 % dense: 38.7 ms in one workgroup against 9.0 ms register-resident -- fill-in makes its pivots touch hundreds of rows)
+static const double WG_SPARSE_DENSITY = 0.05;
 static bool use_wg_single(const jslp_engine* e) {
     if (e->force_path == 1) return true;
     if (e->force_path == 2 || e->force_path == 3) return false;
-    return (long long)e->cap_rows * e->ld <= WG_CELLS_SINGLE;
+    const long long cells = (long long)e->cap_rows * e->ld;
+    if (cells <= WG_CELLS_SINGLE) return true;
+    return wglds_smem(e) != 0 && cells <= WG_CELLS_SPARSE && e->nnz >= 0 &&
+           (double)e->nnz <= WG_SPARSE_DENSITY * (double)e->H0 * (double)e->W;
 }
 
 // the fused one-launch-per-pivot phase 2 (see k_pivot_fused for the preconditions)
@@ -676,7 +691,7 @@ static bool fused_eligible(const jslp_engine* e) {
 //   3: <512, 4, 16>   ld <= 2048, H <= 4096                            4: <512, 6, 12> ld <= 3072, H <= 3072 (3001 x 3001: 72 MB)
 //   5: <512, 8, 8>    ld <= 4096, H <= 2048
 static int resident_geometry(const jslp_engine* e, int H) {
-    if (e->no_resident || e->n_opt > 0 || e->precision < 1e-15) return 0;  // (see k_pivot_fused for the precision condition)
+    if (e->no_resident || e->force_path == 2 || e->n_opt > 0 || e->precision < 1e-15) return 0;  // (see k_pivot_fused for the precision condition)
     const int rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
     if (e->ld <= 2048 && rpb <= 8) return e->res_cpt == 4 ? 2 : 1;
     if (e->ld <= 2048 && rpb <= 16) return 3;
@@ -1876,6 +1891,7 @@ static int pool_adopt_root(jslp_engine* m, const jslp_engine* src, int s_H, int 
     m->n_unr = src->n_unr;
     m->s.has_unr = src->n_unr > 0 ? 1 : 0;
     m->evaluation = src->evaluation;
+    m->nnz = src->nnz;
     m->slot0_synced = 0;
     m->slots_synced = 0;
     drop_checkpoints(m, 0);

@@ -497,6 +497,16 @@ __global__ void __launch_bounds__(1024) k_upload_finish(Slots s, UploadBlob b, u
         *s.st = st;
     }
 }
+// non-zero cells of the uploaded tableau (the host picks the launch shape by density: see use_wg_single); *out zeroed by the host
+__global__ void __launch_bounds__(256) k_count_nnz(const double* A, int H, int ld, unsigned long long* out) {
+    const long long n = (long long)H * ld;
+    unsigned long long mine = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        mine += A[i] != 0.0 ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+
 // strided host layout (row stride W) -> device layout (row stride ld) for a tableau that arrived as ONE contiguous DMA
 __global__ void __launch_bounds__(256) k_repack(double* A, const double* packed, int H, int W, int ld) {
     const long long n = (long long)H * ld;

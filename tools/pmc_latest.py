@@ -15,18 +15,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def counter_sum(run_dir, sub, counter, kernel):
-    tot, n = 0.0, 0
+    tot, n, wgs = 0.0, 0, 0
     for db in glob.glob(os.path.join(run_dir, sub, "**", "*.db"), recursive=True):
         cur = sqlite3.connect(db).cursor()
         cols = [d[0] for d in cur.execute("select * from counters_collection limit 1").description]
         name_col = "kernel_name" if "kernel_name" in cols else "name"
         cnt_col = "counter_name" if "counter_name" in cols else "pmc_name"
         val_col = "value" if "value" in cols else "counter_value"
-        q = "select count(*), sum(%s) from counters_collection where %s like ? and %s = ?" % (val_col, name_col, cnt_col)
-        c, s = cur.execute(q, ("%" + kernel + "%", counter)).fetchone()
+        q = "select count(*), sum(%s), sum(grid_size / workgroup_size) from counters_collection where %s like ? and %s = ?" % (val_col, name_col, cnt_col)
+        c, s, g = cur.execute(q, ("%" + kernel + "%", counter)).fetchone()
         tot += s or 0.0
         n += c or 0
-    return tot, n
+        wgs += g or 0
+    return tot, n, int(wgs)
 
 
 def workload_line(path):
@@ -38,8 +39,11 @@ def main(run_dir, key, source):
     w = workload_line(os.path.join(run_dir, "pmc_%s_fetch.log" % key))
     w2 = workload_line(os.path.join(run_dir, "pmc_%s_write.log" % key))
     assert w["units"] == w2["units"] and w["kernel"] == w2["kernel"]
-    fetch_kib, nf = counter_sum(run_dir, "pmc_%s_fetch" % key, "FETCH_SIZE", w["kernel"])
-    write_kib, nw = counter_sum(run_dir, "pmc_%s_write" % key, "WRITE_SIZE", w["kernel"])
+    fetch_kib, nf, gf = counter_sum(run_dir, "pmc_%s_fetch" % key, "FETCH_SIZE", w["kernel"])
+    write_kib, nw, gw = counter_sum(run_dir, "pmc_%s_write" % key, "WRITE_SIZE", w["kernel"])
+    if key == "relax":  # one workgroup = one node: count the units from the dispatches themselves (grid size / workgroup size)
+        assert gf == gw, (gf, gw)
+        w["units"] = gf
     wide = key == "relax"  # k_node_wg streams rows with 16 B per lane; the resident kernel issues 8-byte agent-scope loads
     fetch = fetch_kib * 1024.0 * (2.0 if wide else 1.0) / w["units"]
     write = write_kib * 1024.0 / w["units"]

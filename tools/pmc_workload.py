@@ -59,7 +59,7 @@ def relax(calls=12, reps=16):
     import bench
     per_node = bench.gated_bytes(c, W, W + 2 * cap + 2, H) / c["relaxations"]
     groups = (len(nodes) + 1023) // 1024
-    print(json.dumps({"key": "relaxations", "kernel": "k_node_wg", "dispatches": groups * (calls + 1), "units": len(nodes) * (calls + 1),
+    print(json.dumps({"key": "relaxations", "kernel": "k_node_lds" if os.environ.get("JSLP_NO_WGLDS") != "1" else "k_node_wg", "dispatches": groups * (calls + 1), "units": len(nodes) * (calls + 1),
                       "unit": "LP relaxation", "algorithmic_bytes_per_unit": per_node,
                       "workload": "Monster_II %d-node batch, %d one-launch calls" % (len(nodes), calls + 1)}))
 
