@@ -31,6 +31,8 @@ for s in $steps; do
     wgm) (JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py single; JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py batch) 2>&1 | grep -i "micro\|total\|single\|batch" > $out/wglds_micro.log; cat $out/wglds_micro.log ;;
     stress) for i in 1 2 3; do timeout 120 python tools/wglds_timing.py rate; done > $out/stress.log 2>&1 < /dev/null; echo "stress rc=$?"; grep -c relaxations $out/stress.log; tail -3 $out/stress.log ;;
     sweep) timeout 600 node tools/mincells_sweep.js > $out/mincells_sweep.md 2> $out/mincells_sweep.err < /dev/null; echo "sweep rc=$?"; cat $out/mincells_sweep.md ;;
+    dense) (timeout 300 python tools/dense_lp_times.py; JSLP_HIP_LIBRARY=build/libjslp_hip_nodefer.so timeout 300 python tools/dense_lp_times.py) > $out/dense_lp_times.log 2>&1 < /dev/null; echo "dense rc=$?"; cat $out/dense_lp_times.log ;;
+    wide) timeout 900 python -m pytest tests/test_wide_goldens.py -m gpu -q > $out/wide.log 2>&1 < /dev/null; echo "wide rc=$?"; tail -15 $out/wide.log ;;
   esac
 done
 # keep the merge-back small: databases can be large
