@@ -30,10 +30,12 @@ struct WgLds {
     double* pcol;   // [Hc]   pivot column of the current pivot
     double* rhs;    // [Hc]   column 0 (the authoritative copy during the solve; written back to the slot's mirror at the end)
     int32_t* list;  // [Hc]   rows passing the gate / rows to restore
+    int32_t* vibr;  // [Hc]   varIndexByRow / [ld] varIndexByCol: what a pivot swaps and the cycle check records; mirrored to the
+    int32_t* vibc;  //        slot's global copies with fire-and-forget stores (a global read here was a full trip per pivot)
 };
 __host__ __device__ __forceinline__ size_t wglds_bytes(int ld, int cap_rows) {
     const size_t hc = ((size_t)cap_rows + 1) & ~(size_t)1;
-    return 8 * (2 * (size_t)ld + 2 * hc) + 4 * hc;
+    return 8 * (2 * (size_t)ld + 2 * hc) + 4 * hc + 4 * hc + 4 * (size_t)ld;
 }
 __device__ __forceinline__ WgLds wglds_carve(double* base, int ld, int cap_rows) {
     const int hc = (cap_rows + 1) & ~1;
@@ -43,6 +45,8 @@ __device__ __forceinline__ WgLds wglds_carve(double* base, int ld, int cap_rows)
     L.pcol = base + 2 * ld;
     L.rhs = base + 2 * ld + hc;
     L.list = reinterpret_cast<int32_t*>(base + 2 * ld + 2 * hc);
+    L.vibr = L.list + hc;
+    L.vibc = L.vibr + hc;
     return L;
 }
 
@@ -136,6 +140,18 @@ __device__ __forceinline__ KI block_min_ki(KI x, SmemL& sm, int& par) {
     return r;
 }
 
+// copy one row of ld doubles (a wave; 16 bytes per lane) with four loads in flight per lane instead of a load -> store chain
+__device__ __forceinline__ void wglds_copy_row(double2* dst, const double2* src, int ld2, int lane) {
+    for (int k0 = lane; k0 < ld2; k0 += 256) {
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = (k0 + 64 * u < ld2) ? src[k0 + 64 * u] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (k0 + 64 * u < ld2) dst[k0 + 64 * u] = v[u];
+    }
+}
+
 // the gated rows of one pivot, one wave per row: row <- row - k * prow on the live columns (simplex.ts:376-387).  The loads
 // of UN column pairs are in flight together (a row of Monster_II: two dependent trips instead of eight); column 0 and row 0
 // are mirrored in LDS.
@@ -193,6 +209,8 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
         const bool mirrored = c.rhs && st->rhs_valid;
         for (int r = tid; r < H; r += nt) L.rhs[r] = mirrored ? c.rhs[r] : A[(long long)r * ld];
         for (int col = tid; col < ld; col += nt) L.r0[col] = A[col];
+        for (int r = tid; r < H; r += nt) L.vibr[r] = c.vibr[r];
+        for (int col = tid; col < W; col += nt) L.vibc[col] = c.vibc[col];
     }
     const int err0 = st->err;
     long long trace_n = st->trace_n;
@@ -270,7 +288,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
                 if (tid < WGL_SEL)
                     for (int col = 1 + tid; col < W; col += WGL_SEL) {
                         const double coef = L.prow[col];
-                        const bool un = c.has_unr && c.unr[c.vibc[col]] != 0;
+                        const bool un = c.has_unr && c.unr[L.vibc[col]] != 0;
                         if (un || coef < -precision) {
                             const double quo = -L.r0[col] / coef;
                             if (qv < quo) { qv = quo; qi = col; }
@@ -293,7 +311,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
             int ei = 0, eb = 0;
             for (int col = 1 + tid; col < W && tid < WGL_SEL; col += WGL_SEL) {
                 const double rc = L.r0[col];
-                const bool un = c.has_unr && c.unr[c.vibc[col]] != 0;
+                const bool un = c.has_unr && c.unr[L.vibc[col]] != 0;
                 const int b = c.use_partial ? (col - 1) / c.batch : 0;
                 const double val = (un && rc < 0) ? -rc : rc;
                 if (val > precision) {
@@ -318,7 +336,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
             pc = e.i;
             {
                 const double rc = L.r0[pc];
-                const bool un = c.has_unr && c.unr[c.vibc[pc]] != 0;
+                const bool un = c.has_unr && c.unr[L.vibc[pc]] != 0;
                 neg_flag = (un && rc < 0) ? 1 : 0;
             }
             // ratio test (simplex.ts:271-296) in its order-free form: the first degenerate row wins outright (key 0), else the
@@ -355,7 +373,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
             have_pv = true;
         }
         int leaving = 0, entering = 0;
-        if (tid == 0) { leaving = c.vibr[pr]; entering = c.vibc[pc]; }
+        if (tid == 0) { leaving = L.vibr[pr]; entering = L.vibc[pc]; }
         // the rows that pass the reference's gate (simplex.ts:370-375), compacted into the LDS list (a Monster_II pivot: ~10 of
         // 945); "any row at all" is what decides the lazy zeroing of tiny pivot-row entries (:381-383)
         int n_gated = 0;
@@ -424,6 +442,8 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
         if (tid == 0) {  // :339-349
             c.vibr[pr] = entering;
             c.vibc[pc] = leaving;
+            L.vibr[pr] = entering;
+            L.vibc[pc] = leaving;
             c.rbv[entering] = pr;
             c.rbv[leaving] = -1;
             c.cbv[entering] = -1;
@@ -471,7 +491,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
         if (entered2) st->feasible = 1;
         if (c.rhs) st->rhs_valid = 1;
         if (outcome == 1) st->optimal = 1;
-        if (outcome == 2) { st->bounded = 0; st->unbounded_var = c.vibc[unbounded_col]; }
+        if (outcome == 2) { st->bounded = 0; st->unbounded_var = L.vibc[unbounded_col]; }
         if (outcome == 3) { st->cycle_phase = phase; st->feasible = 0; }
         if (outcome == 4) st->feasible = 0;
         if (outcome == 5) st->err = ERR_ITER_LIMIT;
@@ -520,11 +540,19 @@ __device__ __forceinline__ void add_cuts_waves(const Slots& s, const Cuts& cuts,
             }
         } else {  // basic variable: negated copy of its row (:54-62)
             const double* src = A + (long long)var_row * ld;
-            for (int col = lane; col < ld; col += 64) {
-                double v = 0.0;
-                if (col == 0) { v = sign * (value - src[0]); rhs[H + h] = v; }
-                else if (col < W) v = -sign * src[col];
-                cut[col] = v;
+            for (int col0 = lane; col0 < ld; col0 += 256) {  // four loads in flight per lane
+                double x[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int col = col0 + 64 * u; x[u] = col < W ? src[col] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int col = col0 + 64 * u;
+                    if (col >= ld) continue;
+                    double v = 0.0;
+                    if (col == 0) { v = sign * (value - x[u]); rhs[H + h] = v; }
+                    else if (col < W) v = -sign * x[u];
+                    cut[col] = v;
+                }
             }
         }
     }
@@ -594,7 +622,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
     double2* dst = reinterpret_cast<double2*>(A);
     for (int i = w; i < n; i += nw) {
         const int r = L.list[i];
-        for (int k = lane; k < ld2; k += 64) dst[(long long)r * ld2 + k] = src[(long long)r * ld2 + k];
+        wglds_copy_row(dst + (long long)r * ld2, src + (long long)r * ld2, ld2, lane);
         if (lane == 0) { dirty[r] = 0; rhs[r] = snap.rhs[r]; }
     }
     __syncthreads();
@@ -603,9 +631,23 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
     int32_t* vibc = s.vibc + (long long)slot * s.vibc_stride;
     int32_t* rbv = s.rbv + (long long)slot * s.idx_stride;
     int32_t* cbv = s.cbv + (long long)slot * s.idx_stride;
-    for (int i = tid; i < H; i += blockDim.x) vibr[i] = snap.vibr[i];
-    for (int i = tid; i < s.W; i += blockDim.x) vibc[i] = snap.vibc[i];
-    for (int i = tid; i < snap.n_idx; i += blockDim.x) { rbv[i] = snap.rbv[i]; cbv[i] = snap.cbv[i]; }
+    {   // the index maps: all loads of a pass issued before its stores
+        const int nt4 = blockDim.x * 4;
+        for (int i0 = tid; i0 < snap.n_idx; i0 += nt4) {
+            int32_t x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; x[u] = i < snap.n_idx ? snap.rbv[i] : 0; y[u] = i < snap.n_idx ? snap.cbv[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; if (i < snap.n_idx) { rbv[i] = x[u]; cbv[i] = y[u]; } }
+        }
+        for (int i0 = tid; i0 < H || i0 < s.W; i0 += nt4) {
+            int32_t x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; x[u] = i < H ? snap.vibr[i] : 0; y[u] = i < s.W ? snap.vibc[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; if (i < H) vibr[i] = x[u]; if (i < s.W) vibc[i] = y[u]; }
+        }
+    }
     if (tid == 0) {
         st->H = H;
         st->last_element_index = s.st[0].s_last_element_index;

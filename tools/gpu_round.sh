@@ -21,10 +21,7 @@ for s in $steps; do
     shim) for f in Monster_Problem Monster_II LargeFarmMIP Knapsack_1 Vendor_Selection; do echo "== $f" >> $out/shim_profile.log; timeout 300 node tools/shim_profile.js $f >> $out/shim_profile.log 2>&1 < /dev/null; done; echo "shim rc=$?"; cat $out/shim_profile.log | cut -c1-400 ;;
     config) timeout 900 python tools/config_times.py $out/config_times.md > $out/config_times.log 2>&1 < /dev/null; echo "config rc=$?"; cat $out/config_times.md ;;
     wgt) (JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py single; JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py batch
-          for g in 256 512 768 1024 2048; do JSLP_GROUP_MAX=$g timeout 120 python tools/wglds_timing.py rate; done
-          JSLP_NO_WGLDS=1 timeout 120 python tools/wglds_timing.py rate; JSLP_WG_BATCH_THREADS=1024 timeout 120 python tools/wglds_timing.py rate
-          JSLP_WG_BATCH_THREADS=1024 JSLP_GROUP_MAX=512 timeout 120 python tools/wglds_timing.py rate
-          for g in 768 1024; do JSLP_HIP_LIBRARY=build/libjslp_hip_w6.so JSLP_GROUP_MAX=$g timeout 120 python tools/wglds_timing.py rate; done) > $out/wglds_timing.log 2>&1 < /dev/null; echo "wgt rc=$?"; cat $out/wglds_timing.log ;;
+          timeout 120 python tools/wglds_timing.py rate; JSLP_GROUP_MAX=768 timeout 120 python tools/wglds_timing.py rate; timeout 120 python tools/wglds_timing.py single) > $out/wglds_timing.log 2>&1 < /dev/null; echo "wgt rc=$?"; grep -v "^{" $out/wglds_timing.log ;;
     sq) (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $GRAFT_REPO_ROOT/$out/pmc_sq -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py relax > $GRAFT_REPO_ROOT/$out/pmc_sq.log 2>&1 < /dev/null); echo "sq rc=$?"
         (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT -d $GRAFT_REPO_ROOT/$out/pmc_sq2 -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py relax > $GRAFT_REPO_ROOT/$out/pmc_sq2.log 2>&1 < /dev/null); echo "sq2 rc=$?"
         timeout 120 python tools/rocpd_pmc.py $out $out/pmc_sq_summary.json < /dev/null | grep -A40 "k_node_lds" | head -120 ;;
