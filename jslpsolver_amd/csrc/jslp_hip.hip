@@ -35,6 +35,7 @@ static int fail(int code, const char* fmt, const char* a = "", const char* b = "
         if (_e != hipSuccess) return fail(JSLP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
+static const size_t WGLDS_MAX_BYTES = 64 * 1024;  // largest dynamic LDS the LDS-resident one-workgroup kernels are launched with
 struct jslp_engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -57,6 +58,7 @@ struct jslp_engine {
     char* spare_slot_arena = nullptr; size_t spare_slot_bytes = 0;  // handed over by the resource pool at create()
     // snapshot
     double* snap_A = nullptr; double* snap_rhs = nullptr;
+    double* snap_AT = nullptr; int snap_ldT = 0;  // the saved root transposed (tableaus the LDS node kernels take; else nullptr)
     int32_t *snap_vibr = nullptr, *snap_vibc = nullptr, *snap_rbv = nullptr, *snap_cbv = nullptr;
     uint8_t* d_unr = nullptr;
     uint8_t* d_isint = nullptr;  // variable.isInteger per variable index (MIR cuts)
@@ -65,6 +67,9 @@ struct jslp_engine {
     // cuts staging: ONE pinned host buffer -> ONE device buffer per call: [value | offs | var | type]
     char* d_cuts = nullptr; char* h_cuts = nullptr; size_t cuts_bytes = 0;
     int32_t* d_cut_offs = nullptr; int8_t* d_cut_type = nullptr; int32_t* d_cut_var = nullptr; double* d_cut_val = nullptr;
+    int32_t* d_cut_order = nullptr; int* d_queue = nullptr;  // batch hand-out order (most cuts first) + queue counter, uploaded with the cuts
+    std::vector<int32_t> order_scratch;
+    int queue_wgs = 0; size_t queue_wgs_lds = 0;             // resident workgroups of k_node_queue<512> for this LDS size
     // read-back staging (device + pinned host)
     // read-back staging: ONE device buffer -> ONE pinned buffer per group: [states | rhs | rows]
     char* d_out = nullptr; char* h_out = nullptr;
@@ -150,6 +155,30 @@ static int group_max() {  // nodes per group of a batch (= tableau copies alive 
         const char* t = getenv("JSLP_GROUP_MAX");  // tuning knob
         v = t ? atoi(t) : 1024;
         if (v < 1) v = 1024;
+    }
+    return v;
+}
+static int zero_copy() {  // batch outcomes written by the kernels straight into the pinned read-back buffer (no copy stream)
+    static int v = -1;
+    if (v < 0) {
+        const char* t = getenv("JSLP_ZERO_COPY");  // tuning knob
+        v = t ? atoi(t) : 1;
+    }
+    return v;
+}
+static int snapshot_transpose_on() {  // pivot-column reads of untouched rows from the transposed root
+    static int v = -1;
+    if (v < 0) {
+        const char* t = getenv("JSLP_SNAPSHOT_TRANSPOSE");  // tuning knob
+        v = t ? atoi(t) : 1;
+    }
+    return v;
+}
+static int node_queue() {  // a batch in one launch of resident workgroups pulling nodes from a queue
+    static int v = -1;
+    if (v < 0) {
+        const char* t = getenv("JSLP_NODE_QUEUE");  // tuning knob: 0 = one launch per group, 2 = hand the nodes out most-cuts-first
+        v = t ? atoi(t) : 1;                        // (measured slower on the Monster_II batch: 2.73 M/s against 2.94 M/s in call order)
     }
     return v;
 }
@@ -417,6 +446,8 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
                 e->d_isint = cv.take<uint8_t>((size_t)e->n_idx);
                 e->snap_A = cv.take<double>(cells);
                 e->snap_rhs = cv.take<double>((size_t)e->cap_rows);
+                e->snap_ldT = (e->cap_rows + 1) & ~1;
+                e->snap_AT = wglds_bytes(e->ld, e->cap_rows) <= WGLDS_MAX_BYTES ? cv.take<double>((size_t)e->snap_ldT * e->W) : nullptr;
                 e->snap_vibr = cv.take<int32_t>((size_t)e->cap_rows);
                 e->snap_vibc = cv.take<int32_t>((size_t)e->W);
                 e->snap_rbv = cv.take<int32_t>((size_t)e->n_idx);
@@ -661,7 +692,7 @@ static int iters_cap(const jslp_engine* e) {
 static size_t wglds_smem(const jslp_engine* e) {
     if (!e->use_wglds || e->n_opt > 0) return 0;
     const size_t b = wglds_bytes(e->ld, e->cap_rows);
-    return b <= 64 * 1024 ? b : 0;
+    return b <= WGLDS_MAX_BYTES ? b : 0;
 }
 
 // one workgroup for the whole simplex(): tiny tableaus, and SPARSE ones up to a few million cells -- a pivot of the
@@ -1074,6 +1105,17 @@ static dim3 copy_grid(const jslp_engine* e, int slots) {
     return dim3((unsigned)std::max<long long>(bx, 1), slots, 1);
 }
 
+// the saved root once more, column-major, for the node kernels' pivot-column reads (WgLds::snapT)
+static void launch_snapshot_transpose(jslp_engine* e) {
+    if (!e->snap_AT) return;
+    hipLaunchKernelGGL(k_snapshot_transpose, dim3((e->W + 31) / 32, (e->cap_rows + 31) / 32), dim3(256), 0, e->stream, e->s.st, e->snap_A,
+                       (int)e->ld, (int)e->W, e->snap_AT, e->snap_ldT);
+}
+static Snapshot root_snapshot(const jslp_engine* e) {
+    return Snapshot{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs,
+                    snapshot_transpose_on() ? e->snap_AT : nullptr, e->snap_ldT};
+}
+
 extern "C" int jslp_engine_save(jslp_engine* e) {
     if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "save before upload");
     HIPC(hipSetDevice(e->device));
@@ -1081,6 +1123,7 @@ extern "C" int jslp_engine_save(jslp_engine* e) {
     e->slot0_synced = 0;  // new snapshot generation
     e->slots_synced = 0;
     hipLaunchKernelGGL(k_save, dim3(copy_grid(e, 1).x), dim3(256), 0, e->stream, e->s, w);
+    launch_snapshot_transpose(e);
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(e->stream));
     e->has_save = 1;
@@ -1101,7 +1144,7 @@ static int enqueue_restore(jslp_engine* e, int first_slot, int n, int checkpoint
     }
     if (checkpoint < 0) {
         if (!e->has_save) return JSLP_OK;  // backup.ts:54-56
-        Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs};
+        Snapshot sn = root_snapshot(e);
         hipLaunchKernelGGL(k_restore, copy_grid(e, n), dim3(256), 0, e->stream, e->s, sn, first_slot);
     } else {
         const jslp_engine::Ckpt& c = e->ckpts[checkpoint];
@@ -1199,7 +1242,9 @@ static int upload_cuts(jslp_engine* e, int32_t n_nodes, const int32_t* offs, con
         if (offs[i + 1] < offs[i]) return fail(JSLP_ERR_ARG, "cuts: cut_offsets must not decrease");
     const size_t C = (size_t)offs[n_nodes], N1 = (size_t)n_nodes + 1;
     if (C > 0 && (!type || !var || !value)) return fail(JSLP_ERR_ARG, "cuts: null pointer");
-    const size_t off_offs = 8 * C, off_var = off_offs + 4 * N1, off_type = off_var + 4 * C, total = off_type + C;
+    // [values | offsets | variables | types | hand-out order of a batch | its queue counter (0)]
+    const size_t off_offs = 8 * C, off_var = off_offs + 4 * N1, off_type = off_var + 4 * C, off_order = (off_type + C + 3) & ~(size_t)3,
+                 off_queue = off_order + 4 * (size_t)n_nodes, total = off_queue + 4;
     if (total > e->cuts_bytes) {  // grow: allocate the new pair first, swap only when both exist
         const size_t bytes = std::max<size_t>(2 * total, 4096);
         char* nd = nullptr; char* nh = nullptr;
@@ -1213,6 +1258,17 @@ static int upload_cuts(jslp_engine* e, int32_t n_nodes, const int32_t* offs, con
     if (C) memcpy(e->h_cuts, value, 8 * C);
     memcpy(e->h_cuts + off_offs, offs, 4 * N1);
     if (C) { memcpy(e->h_cuts + off_var, var, 4 * C); memcpy(e->h_cuts + off_type, type, C); }
+    if (node_queue() == 2) {  // most cuts first (a counting sort, stable): k_node_queue hands the nodes out in this order
+        int32_t* order = reinterpret_cast<int32_t*>(e->h_cuts + off_order);
+        int most = 0;
+        for (int32_t i = 0; i < n_nodes; i++) most = std::max(most, (int)(offs[i + 1] - offs[i]));
+        std::vector<int32_t>& start = e->order_scratch;
+        start.assign((size_t)most + 2, 0);
+        for (int32_t i = 0; i < n_nodes; i++) start[(size_t)(most - (offs[i + 1] - offs[i])) + 1]++;
+        for (int c = 0; c <= most; c++) start[(size_t)c + 1] += start[c];
+        for (int32_t i = 0; i < n_nodes; i++) order[start[(size_t)(most - (offs[i + 1] - offs[i]))]++] = i;
+    }
+    *reinterpret_cast<int32_t*>(e->h_cuts + off_queue) = 0;
     // to_device == false: the one-launch node kernel reads the (tiny) cut list straight from the pinned buffer
     char* base = e->d_cuts;
     if (to_device) {
@@ -1226,6 +1282,8 @@ static int upload_cuts(jslp_engine* e, int32_t n_nodes, const int32_t* offs, con
     e->d_cut_offs = reinterpret_cast<int32_t*>(base + off_offs);
     e->d_cut_var = reinterpret_cast<int32_t*>(base + off_var);
     e->d_cut_type = reinterpret_cast<int8_t*>(base + off_type);
+    e->d_cut_order = reinterpret_cast<int32_t*>(base + off_order);
+    e->d_queue = reinterpret_cast<int*>(base + off_queue);
     return JSLP_OK;
 }
 
@@ -1475,7 +1533,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         double* o_rhs = want_rhs ? reinterpret_cast<double*>(ob + ((char*)e->h_rhs - e->h_out)) : nullptr;
         int32_t* o_rows = want_rows ? reinterpret_cast<int32_t*>(ob + ((char*)e->h_rows - e->h_out)) : nullptr;
         Cuts cu{e->d_cut_offs, e->d_cut_type, e->d_cut_var, e->d_cut_val};
-        Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs};
+        Snapshot sn = root_snapshot(e);
         e->last_path = "workgroup";
         unsigned* h_flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e->h_state) + sizeof(DevState));
         void* flag_dev = nullptr;
@@ -1535,6 +1593,18 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     if (wg) {
         const long long max_slots = std::max<long long>(1, (16LL << 30) / (cells * 8));
         group = (int)std::min<long long>(std::min<long long>(n_nodes, group_max()), max_slots);
+        if (const size_t lds = wglds_smem(e); lds && node_queue() && wg_batch_threads() == 512 && n_nodes > 1) {
+            // the queue kernel wants exactly as many slots as the chip keeps workgroups resident
+            if (e->queue_wgs == 0 || e->queue_wgs_lds != lds) {
+                int per_cu = 0, cus = 0;
+                HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_node_queue<512>, 512, lds));
+                HIPC(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+                e->queue_wgs = std::max(1, per_cu * cus);
+                e->queue_wgs_lds = lds;
+            }
+            const char* t = getenv("JSLP_GROUP_MAX");
+            group = (int)std::min<long long>(std::min<long long>(n_nodes, t ? group_max() : e->queue_wgs), max_slots);
+        }
         rc = ensure_slots(e, group);
         if (rc) return rc;
     }
@@ -1545,6 +1615,34 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         HIPC(hipEventCreateWithFlags(&e->ev_group, hipEventDisableTiming));
     }
     if (e->timing) HIPC(hipEventRecord(e->ev_begin, s));
+    // where the kernels leave the outcomes: the device staging buffer (copied group by group on the copy stream) or, zero-copy,
+    // the pinned host buffer itself - the stores cross PCIe while the other workgroups compute
+    DevState* o_states = e->d_states; double* o_rhs = e->d_rhs; int32_t* o_rows = e->d_rows;
+    bool zc = zero_copy() != 0;
+    if (zc) {
+        void *ps = nullptr, *pr = nullptr, *pw = nullptr;
+        if (hipHostGetDevicePointer(&ps, e->h_states, 0) == hipSuccess && hipHostGetDevicePointer(&pr, e->h_rhs, 0) == hipSuccess &&
+            hipHostGetDevicePointer(&pw, e->h_rows, 0) == hipSuccess) {
+            o_states = static_cast<DevState*>(ps); o_rhs = static_cast<double*>(pr); o_rows = static_cast<int32_t*>(pw);
+        } else {
+            (void)hipGetLastError();
+            zc = false;
+        }
+    }
+    if (const size_t lds = wglds_smem(e); wg && lds && node_queue() && n_nodes > group && checkpoint < 0 && e->has_save && e->slot0_synced &&
+        group <= e->slots_synced && !e->timing && e->one_launch_nodes && wg_batch_threads() == 512) {
+        Snapshot sn = root_snapshot(e);
+        e->last_path = "workgroup";
+        hipLaunchKernelGGL((k_node_queue<512>), dim3(group), dim3(512), lds, s, e->s, sn, cu, (int)n_nodes,
+                           node_queue() == 2 ? e->d_cut_order : (const int32_t*)nullptr, e->d_queue, check_cycles, cap, (int)e->cap_rows,
+                           want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states, g_stride);
+        HIPC(hipGetLastError());
+        if (!zc) {
+            HIPC(hipMemcpyAsync(e->h_states, e->d_states, sizeof(DevState) * (size_t)n_nodes, hipMemcpyDeviceToHost, s));
+            if (want_rhs) HIPC(hipMemcpyAsync(e->h_rhs, e->d_rhs, sizeof(double) * (size_t)n_nodes * e->cap_rows, hipMemcpyDeviceToHost, s));
+            if (want_rows) HIPC(hipMemcpyAsync(e->h_rows, e->d_rows, sizeof(int32_t) * (size_t)n_nodes * e->cap_rows, hipMemcpyDeviceToHost, s));
+        }
+    } else
     for (int first = 0; first < n_nodes; first += group) {
         const int g = std::min(group, n_nodes - first);
         // slots already in sync with the snapshot: restore of the dirty rows, cuts, simplex and gather in ONE launch per
@@ -1552,15 +1650,15 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         const bool one_launch = wg && g > 1 && checkpoint < 0 && e->has_save && e->slot0_synced && g <= e->slots_synced &&
                                 !e->timing && e->one_launch_nodes && wg_batch_threads() == 512;
         if (one_launch) {
-            Snapshot sn{e->snap_A, e->snap_vibr, e->snap_vibc, e->snap_rbv, e->snap_cbv, e->n_idx, e->snap_oo, -1, 0, e->snap_rhs};
+            Snapshot sn = root_snapshot(e);
             e->last_path = "workgroup";
             if (const size_t lds = wglds_smem(e))
                 hipLaunchKernelGGL((k_node_lds<512>), dim3(g), dim3(512), lds, s, e->s, sn, cu, first, check_cycles, cap,
-                                   (int)e->cap_rows, want_rhs ? e->d_rhs : nullptr, want_rows ? e->d_rows : nullptr, e->d_states,
+                                   (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states,
                                    g_stride, first, (unsigned*)nullptr, 0u);
             else
                 hipLaunchKernelGGL((k_node_wg<512, 2048>), dim3(g), dim3(512), 0, s, e->s, sn, cu, first, check_cycles, cap,
-                                   (int)e->cap_rows, want_rhs ? e->d_rhs : nullptr, want_rows ? e->d_rows : nullptr, e->d_states,
+                                   (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states,
                                    g_stride, first, (unsigned*)nullptr, 0u);
             HIPC(hipGetLastError());
         } else {
@@ -1593,12 +1691,13 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
             rc = run_simplex(e, check_cycles);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_gather, dim3(g), dim3(256), 0, s, e->s, 0, want_rhs ? e->d_rhs : nullptr,
-                           want_rows ? e->d_rows : nullptr, e->d_states, g_stride, first);
+        hipLaunchKernelGGL(k_gather, dim3(g), dim3(256), 0, s, e->s, 0, want_rhs ? o_rhs : nullptr,
+                           want_rows ? o_rows : nullptr, o_states, g_stride, first);
         HIPC(hipGetLastError());
         }  // !one_launch
         // this group's outcomes cross PCIe on the copy stream while the next group computes (the three regions of the
         // read-back buffer are laid out for all nodes, so a group is one contiguous slice of each)
+        if (zc) continue;
         HIPC(hipEventRecord(e->ev_group, s));
         HIPC(hipStreamWaitEvent(e->copy_stream, e->ev_group, 0));
         HIPC(hipMemcpyAsync(e->h_states + first, e->d_states + first, sizeof(DevState) * (size_t)g, hipMemcpyDeviceToHost, e->copy_stream));
@@ -1884,6 +1983,7 @@ static int pool_adopt_root(jslp_engine* m, const jslp_engine* src, int s_H, int 
     HIPC(hipMemcpyPeerAsync(m->d_isint, dd, src->d_isint, sd, (size_t)m->n_idx, s));
     if (src->n_opt > 0) HIPC(hipMemcpyPeerAsync(m->snap_oo, dd, src->snap_oo, sd, sizeof(double) * (size_t)m->s.oo_stride, s));
     hipLaunchKernelGGL(k_adopt_root, dim3(1), dim3(1), 0, s, m->s, s_H, s_lei);
+    launch_snapshot_transpose(m);
     HIPC(hipGetLastError());
     m->uploaded = 1;
     m->has_save = 1;

@@ -98,7 +98,26 @@ struct Snapshot {
     // with its own scalars; the dirty-row shortcut does not apply to it.
     int32_t H, last_element_index;
     const double* rhs;  // contiguous copy of column 0
+    const double* AT;   // the saved root transposed (column stride ldT), or nullptr: see WgLds::snapT
+    int32_t ldT;
 };
+// snapshot -> its transpose (32 x 32 tiles through LDS, both sides coalesced); rows = the saved root's height
+__global__ void __launch_bounds__(256) k_snapshot_transpose(const DevState* st0, const double* A, int ld, int W, double* AT, int ldT) {
+    __shared__ double tile[32][33];
+    const int H = st0->s_H;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    if (r0 >= H) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < H && c < W) ? A[(long long)r * ld + c] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < W && r < H) AT[(long long)c * ldT + r] = tile[tx][j];
+    }
+}
 __global__ void __launch_bounds__(256) k_restore(Slots s, Snapshot snap, int first_slot) {
     const int slot = first_slot + blockIdx.y;
     DevState* st = s.st + slot;

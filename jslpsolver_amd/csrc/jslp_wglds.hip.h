@@ -32,10 +32,16 @@ struct WgLds {
     int32_t* list;  // [Hc]   rows passing the gate / rows to restore
     int32_t* vibr;  // [Hc]   varIndexByRow / [ld] varIndexByCol: what a pivot swaps and the cycle check records; mirrored to the
     int32_t* vibc;  //        slot's global copies with fire-and-forget stores (a global read here was a full trip per pivot)
+    // Branch-and-bound nodes only (k_node_lds / k_node_queue; snapT == nullptr otherwise): a row the node has not written yet
+    // still equals the saved root's, so its pivot-column entry comes from the root's TRANSPOSE -- one contiguous column
+    // (7.5 KB on Monster_II) shared by every workgroup of the batch instead of H cache lines of the slot, one per row
+    uint8_t* cur;         // [Hc] row written by this node (the slot holds its current version)
+    const double* snapT;  // column-major copy of the saved root, column stride ldT
+    int ldT, Hs;          // Hs = rows of the saved root
 };
 __host__ __device__ __forceinline__ size_t wglds_bytes(int ld, int cap_rows) {
     const size_t hc = ((size_t)cap_rows + 1) & ~(size_t)1;
-    return 8 * (2 * (size_t)ld + 2 * hc) + 4 * hc + 4 * hc + 4 * (size_t)ld;
+    return 8 * (2 * (size_t)ld + 2 * hc) + 4 * hc + 4 * hc + 4 * (size_t)ld + hc;
 }
 __device__ __forceinline__ WgLds wglds_carve(double* base, int ld, int cap_rows) {
     const int hc = (cap_rows + 1) & ~1;
@@ -47,6 +53,8 @@ __device__ __forceinline__ WgLds wglds_carve(double* base, int ld, int cap_rows)
     L.list = reinterpret_cast<int32_t*>(base + 2 * ld + 2 * hc);
     L.vibr = L.list + hc;
     L.vibc = L.vibr + hc;
+    L.cur = reinterpret_cast<uint8_t*>(L.vibc + ld);
+    L.snapT = nullptr; L.ldT = 0; L.Hs = 0;
     return L;
 }
 
@@ -245,6 +253,14 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
     }
 #endif
     const bool row_in_regs = ld <= WGL_KP * nt;
+    auto gather_column = [&](int col) {  // the pivot column into LDS
+        if (L.snapT) {
+            const double* colT = L.snapT + (long long)col * L.ldT;
+            for (int r = tid; r < H; r += nt) L.pcol[r] = (r < L.Hs && !L.cur[r]) ? colT[r] : A[(long long)r * ld + col];
+        } else {
+            for (int r = tid; r < H; r += nt) L.pcol[r] = A[(long long)r * ld + col];
+        }
+    };
     int phase = 1, it1 = 0, it2 = 0, hist_n = 0, iters_left = iters_cap, entered2 = 0, par = 0;
     // outcome: 0 running, 1 optimal, 2 unbounded, 3 cycle, 4 infeasible, 5 iteration cap, 6 history full
     int outcome = 0, unbounded_col = 0;
@@ -299,7 +315,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
                 q = block_min_ki(q, sm, par);
                 if (q.k == KI_NONE_KEY) { outcome = 4; break; }  // :73-76 infeasible
                 pc = q.i;
-                for (int r = tid; r < H; r += nt) L.pcol[r] = A[(long long)r * ld + pc];
+                gather_column(pc);
                 __syncthreads();
                 WL_MARK(13);
             }
@@ -343,7 +359,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
             // first-index argmin of the accepted quotients; the strided column gather is the pivot's first global trip
             double mv = INFINITY;
             int mi = 0, rdeg = 0x7fffffff;
-            for (int r = tid; r < H; r += nt) L.pcol[r] = A[(long long)r * ld + pc];
+            gather_column(pc);
             __syncthreads();
             for (int r = 1 + tid; r < H && tid < WGL_SEL; r += WGL_SEL) {
                 const double colv = L.pcol[r];
@@ -381,6 +397,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
             if (r != pr && nonzero16(L.pcol[r])) {
                 L.list[atomicAdd(&sm.n_list, 1)] = r;  // the list holds every row: it cannot overflow
                 c.dirty[r] = 1;
+                L.cur[r] = 1;
                 n_gated += 1;
             }
         }
@@ -450,6 +467,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
             c.cbv[leaving] = pc;
             if (trace_n < c.trace_cap) c.trace[trace_n] = make_int2(pr, pc);
             c.dirty[pr] = 1;
+            L.cur[pr] = 1;
         }
         trace_n += 1;
         if (phase == 1) it1 += 1; else it2 += 1;
@@ -587,25 +605,18 @@ __global__ void __launch_bounds__(THREADS) k_simplex_lds(Slots s, int first_slot
 // this kernel declares (40 KB per workgroup) a fourth workgroup does not fit a CU anyway
 #define JSLP_NODE512_WAVES 6
 #endif
+// one node (= restore + cuts + simplex + read-back) of slot `slot`; false = the slot is not in sync with the snapshot
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES : 4) k_node_lds(Slots s, Snapshot snap, Cuts cuts, int first_node, int check_cycles,
-                                                      int iters_cap, int cap_rows, double* rhs_out, int32_t* rows_out,
-                                                      DevState* state_out, int out_stride, int first_out,
-                                                      unsigned* done_flag, unsigned done_seq) {
-    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
-    __shared__ SmemL sm;
+__device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& snap, const Cuts& cuts, SmemL& sm, const WgLds& L, int slot, int node, int o,
+                                             int check_cycles, int iters_cap, int cap_rows, double* rhs_out, int32_t* rows_out,
+                                             DevState* state_out, int out_stride) {
     WL_BEGIN(s.cnt);
-    const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
-    const int slot = blockIdx.x, node = first_node + blockIdx.x, o = first_out + blockIdx.x;
     DevState* st = s.st + slot;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const int gen = s.st[0].s_gen, H = s.st[0].s_H, ld2 = s.ld / 2;  // every slot shares slot 0's snapshot scalars
     if (gen == 0 || st->gen != gen) {  // must not happen (host bookkeeping): refuse rather than restore wrongly
-        if (tid == 0) {
-            st->err = ERR_NOT_SYNCED; st->status = ST_DONE; state_out[o] = *st;
-            if (done_flag) { __threadfence_system(); __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-        }
-        return;
+        if (tid == 0) { st->err = ERR_NOT_SYNCED; st->status = ST_DONE; state_out[o] = *st; }
+        return false;
     }
     double* A = s.A + (long long)slot * s.A_stride;
     uint8_t* dirty = s.dirty + (long long)slot * s.pcol_stride;
@@ -648,6 +659,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
             for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; if (i < H) vibr[i] = x[u]; if (i < s.W) vibc[i] = y[u]; }
         }
     }
+    for (int r = tid; r < H; r += blockDim.x) L.cur[r] = 0;  // every row of the root is as saved
     if (tid == 0) {
         st->H = H;
         st->last_element_index = s.st[0].s_last_element_index;
@@ -659,16 +671,57 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
     __syncthreads();
     WL_MARK(2);
     const Ctx c = slot_ctx(s, slot, check_cycles);
-    simplex_wg_lds<(THREADS >= 1024 ? 8 : 4)>(c, sm, L, iters_cap);
+    WgLds Ln = L;
+    if (snap.AT) { Ln.snapT = snap.AT; Ln.ldT = snap.ldT; Ln.Hs = H; }
+    simplex_wg_lds<(THREADS >= 1024 ? 8 : 4)>(c, sm, Ln, iters_cap);
 #ifdef JSLP_DEBUG_WGLDS
     wl_prev = __builtin_amdgcn_s_memtime();
 #endif
     gather_slot(s, slot, rhs_out, rows_out, state_out, out_stride, o);
     __syncthreads();
     WL_MARK(12);
+    return true;
+}
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES : 4) k_node_lds(Slots s, Snapshot snap, Cuts cuts, int first_node, int check_cycles,
+                                                      int iters_cap, int cap_rows, double* rhs_out, int32_t* rows_out,
+                                                      DevState* state_out, int out_stride, int first_out,
+                                                      unsigned* done_flag, unsigned done_seq) {
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    __shared__ SmemL sm;
+    const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
+    node_lds_run<THREADS>(s, snap, cuts, sm, L, blockIdx.x, first_node + blockIdx.x, first_out + blockIdx.x, check_cycles, iters_cap, cap_rows,
+                          rhs_out, rows_out, state_out, out_stride);
     if (done_flag) {
         __threadfence_system();
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// A whole batch in ONE launch: as many workgroups as the chip keeps resident, each on its own slot, each pulling the next node
+// from a queue (an atomic counter) until the batch is empty -- no group boundaries, hence no idle tail per group; `order`
+// hands the nodes out most-cuts-first (the cut count predicts the repair pivots: longest-processing-time-first keeps the
+// last workgroups to finish on the cheap nodes).  Node k's outcome goes to index k whatever workgroup / slot evaluated it.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES : 4) k_node_queue(Slots s, Snapshot snap, Cuts cuts, int n_nodes, const int32_t* order,
+                                                      int* queue, int check_cycles, int iters_cap, int cap_rows, double* rhs_out,
+                                                      int32_t* rows_out, DevState* state_out, int out_stride) {
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    __shared__ SmemL sm;
+    __shared__ int q_next;
+    const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
+    for (;;) {
+        if (threadIdx.x == 0) q_next = atomicAdd(queue, 1);
+        __syncthreads();
+        const int k = q_next;
+        __syncthreads();
+        if (k >= n_nodes) break;
+        const int node = order ? order[k] : k;
+        int slot = blockIdx.x;
+        asm volatile("" : "+s"(slot));  // opaque per iteration: nothing derived from the slot is hoisted and kept live across nodes
+        node_lds_run<THREADS>(s, snap, cuts, sm, L, slot, node, node, check_cycles, iters_cap, cap_rows, rhs_out, rows_out, state_out, out_stride);
+        __syncthreads();
     }
 }
