@@ -225,6 +225,20 @@ int jslp_engine_set_watched_variables(jslp_engine* e, const int32_t* var_indexes
 int jslp_engine_relax_watched(jslp_engine* e, int32_t n_cuts, const int8_t* type, const int32_t* var_index,
                               const double* value, int check_cycles, jslp_simplex_result* out, int32_t* watched_row,
                               double* watched_value);
+/*
+ * relax_batch with the compact read-back: node i's watched variables at watched_row / watched_value [i * n_watched ..
+ * (i + 1) * n_watched).  A large batch of full read-backs is bound by the PCIe link (height x 12 bytes per node: 27.8 MB for
+ * the 2416 Monster_II nodes), not by the GPU; this is what a host that walks the tree itself needs per node (the full
+ * RHS column of an incumbent is one jslp_engine_relax away).  Both outputs may be NULL.  Same preconditions as relax_batch.
+ */
+int jslp_engine_relax_batch_watched(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                    const int32_t* var_index, const double* value, int check_cycles,
+                                    jslp_simplex_result* out, int32_t* watched_row, double* watched_value);
+/* the same without the copy: *watched_row / *watched_value point into the engine's pinned read-back buffer (n_nodes x
+ * n_watched each), valid until the next call on this engine */
+int jslp_engine_relax_batch_watched_pinned(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                           const int32_t* var_index, const double* value, int check_cycles,
+                                           jslp_simplex_result* out, const int32_t** watched_row, const double** watched_value);
 
 /*
  * Work counters (bench.py's roofline of the relaxation path): what the calls since the last reset really had

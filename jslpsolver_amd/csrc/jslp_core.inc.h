@@ -60,6 +60,7 @@ struct Slots {
     cnt_t* cnt;              // see Ctx::cnt
     const int32_t* watch;    // watched variable indexes (compact read-back), n_watch entries
     int32_t n_watch;
+    const int32_t* watch_pos;  // variable index -> its position in `watch` (-1 elsewhere); nullptr when a variable is listed twice
 };
 
 __device__ __forceinline__ Ctx slot_ctx(const Slots& s, int slot, int check_cycles) {

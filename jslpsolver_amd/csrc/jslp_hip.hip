@@ -174,6 +174,14 @@ static int snapshot_transpose_on() {  // pivot-column reads of untouched rows fr
     }
     return v;
 }
+static int node_cow() {  // queue kernel: copy-on-write slots (no restore between nodes)
+    static int v = -1;
+    if (v < 0) {
+        const char* t = getenv("JSLP_NODE_COW");  // tuning knob
+        v = t ? atoi(t) : 1;
+    }
+    return v;
+}
 static int node_queue() {  // a batch in one launch of resident workgroups pulling nodes from a queue
     static int v = -1;
     if (v < 0) {
@@ -1306,10 +1314,17 @@ extern "C" int jslp_engine_add_cuts(jslp_engine* e, int32_t n, const int8_t* typ
 
 // read-back buffers for `nodes` nodes laid out [states | rhs | rows] so that one copy brings a group back
 static size_t out_bytes(const jslp_engine* e, size_t nodes) {
-    return nodes * (sizeof(DevState) + (size_t)e->cap_rows * 12);
+    return nodes * (sizeof(DevState) + (((size_t)e->cap_rows + 3) & ~(size_t)3) * 12) + 192;
+}
+// rows per node in the engine's own read-back buffers: a multiple of 4, so that every node's slice starts 16-byte aligned and
+// the kernels write it with 8/16-byte stores per lane (4-byte stores into pinned host memory cost the Monster_II batch a
+// quarter of its time); the device pool lays its shared buffer out itself, with the plain row capacity
+static size_t out_stride_of(const jslp_engine* e) {
+    return e->ext_states ? (size_t)e->cap_rows : (((size_t)e->cap_rows + 3) & ~(size_t)3);
 }
 static void out_layout(jslp_engine* e, size_t nodes) {
-    const size_t o_rhs = nodes * sizeof(DevState), o_rows = o_rhs + nodes * (size_t)e->cap_rows * 8;
+    const size_t stride = out_stride_of(e);
+    const size_t o_rhs = (nodes * sizeof(DevState) + 63) & ~(size_t)63, o_rows = (o_rhs + nodes * stride * 8 + 63) & ~(size_t)63;
     e->d_states = reinterpret_cast<DevState*>(e->d_out);
     e->d_rhs = reinterpret_cast<double*>(e->d_out + o_rhs);
     e->d_rows = reinterpret_cast<int32_t*>(e->d_out + o_rows);
@@ -1501,10 +1516,11 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
                             int want_rows, int checkpoint = -1, int compact = 0) {
     if (!e || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "relax_batch: null pointer");
     if (!e->uploaded) return fail(JSLP_ERR_STATE, "relax before upload");
-    if (compact && (n_nodes != 1 || e->n_watch <= 0 || e->n_watch > e->cap_rows))
-        return fail(JSLP_ERR_ARG, "relax_watched: one node at a time, after set_watched_variables (at most row_capacity of them)");
+    if (compact && (e->n_watch <= 0 || e->n_watch > e->cap_rows))
+        return fail(JSLP_ERR_ARG, "relax_watched: after set_watched_variables (at most row_capacity of them)");
     // gather mode: >= 0 = the whole RHS column / row map with this row stride; < 0 = the watched variables only
-    const int g_stride = compact ? -e->n_watch : (int)e->cap_rows;
+    const int g_stride = compact ? -e->n_watch : (int)out_stride_of(e);
+    const size_t row_stride = compact ? (size_t)e->n_watch : out_stride_of(e);  // entries per node in the read-back buffers
     if (checkpoint >= 0) {
         int rc0 = checkpoint_check(e, checkpoint, "relax_from");
         if (rc0) return rc0;
@@ -1597,7 +1613,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
             // the queue kernel wants exactly as many slots as the chip keeps workgroups resident
             if (e->queue_wgs == 0 || e->queue_wgs_lds != lds) {
                 int per_cu = 0, cus = 0;
-                HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_node_queue<512>, 512, lds));
+                HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_node_queue<512, true>, 512, lds));
                 HIPC(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
                 e->queue_wgs = std::max(1, per_cu * cus);
                 e->queue_wgs_lds = lds;
@@ -1633,14 +1649,18 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         group <= e->slots_synced && !e->timing && e->one_launch_nodes && wg_batch_threads() == 512) {
         Snapshot sn = root_snapshot(e);
         e->last_path = "workgroup";
-        hipLaunchKernelGGL((k_node_queue<512>), dim3(group), dim3(512), lds, s, e->s, sn, cu, (int)n_nodes,
-                           node_queue() == 2 ? e->d_cut_order : (const int32_t*)nullptr, e->d_queue, check_cycles, cap, (int)e->cap_rows,
-                           want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states, g_stride);
+        const int32_t* order = node_queue() == 2 ? e->d_cut_order : (const int32_t*)nullptr;
+        if (node_cow())
+            hipLaunchKernelGGL((k_node_queue<512, true>), dim3(group), dim3(512), lds, s, e->s, sn, cu, (int)n_nodes, order, e->d_queue, check_cycles,
+                               cap, (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states, g_stride);
+        else
+            hipLaunchKernelGGL((k_node_queue<512, false>), dim3(group), dim3(512), lds, s, e->s, sn, cu, (int)n_nodes, order, e->d_queue, check_cycles,
+                               cap, (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states, g_stride);
         HIPC(hipGetLastError());
         if (!zc) {
             HIPC(hipMemcpyAsync(e->h_states, e->d_states, sizeof(DevState) * (size_t)n_nodes, hipMemcpyDeviceToHost, s));
-            if (want_rhs) HIPC(hipMemcpyAsync(e->h_rhs, e->d_rhs, sizeof(double) * (size_t)n_nodes * e->cap_rows, hipMemcpyDeviceToHost, s));
-            if (want_rows) HIPC(hipMemcpyAsync(e->h_rows, e->d_rows, sizeof(int32_t) * (size_t)n_nodes * e->cap_rows, hipMemcpyDeviceToHost, s));
+            if (want_rhs) HIPC(hipMemcpyAsync(e->h_rhs, e->d_rhs, sizeof(double) * (size_t)n_nodes * row_stride, hipMemcpyDeviceToHost, s));
+            if (want_rows) HIPC(hipMemcpyAsync(e->h_rows, e->d_rows, sizeof(int32_t) * (size_t)n_nodes * row_stride, hipMemcpyDeviceToHost, s));
         }
     } else
     for (int first = 0; first < n_nodes; first += group) {
@@ -1702,11 +1722,11 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         HIPC(hipStreamWaitEvent(e->copy_stream, e->ev_group, 0));
         HIPC(hipMemcpyAsync(e->h_states + first, e->d_states + first, sizeof(DevState) * (size_t)g, hipMemcpyDeviceToHost, e->copy_stream));
         if (want_rhs)
-            HIPC(hipMemcpyAsync(e->h_rhs + (size_t)first * e->cap_rows, e->d_rhs + (size_t)first * e->cap_rows,
-                                sizeof(double) * (size_t)g * e->cap_rows, hipMemcpyDeviceToHost, e->copy_stream));
+            HIPC(hipMemcpyAsync(e->h_rhs + (size_t)first * row_stride, e->d_rhs + (size_t)first * row_stride,
+                                sizeof(double) * (size_t)g * row_stride, hipMemcpyDeviceToHost, e->copy_stream));
         if (want_rows)
-            HIPC(hipMemcpyAsync(e->h_rows + (size_t)first * e->cap_rows, e->d_rows + (size_t)first * e->cap_rows,
-                                sizeof(int32_t) * (size_t)g * e->cap_rows, hipMemcpyDeviceToHost, e->copy_stream));
+            HIPC(hipMemcpyAsync(e->h_rows + (size_t)first * row_stride, e->d_rows + (size_t)first * row_stride,
+                                sizeof(int32_t) * (size_t)g * row_stride, hipMemcpyDeviceToHost, e->copy_stream));
     }
     if (e->timing && wg) HIPC(hipEventRecord(e->ev_end, s));
     HIPC(hipStreamSynchronize(e->copy_stream));
@@ -1730,12 +1750,16 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         rc = fill_result(e, st, wg ? i % group : 0, prev_eval, &out[i], &ev);
         if (rc) return rc;
         if (i == n_nodes - 1) e->evaluation = ev;
-        if (!pinned) {
-            const size_t n_out = compact ? (size_t)e->n_watch : (size_t)st.H;
-            if (rhs) memcpy(rhs + (size_t)i * out_stride, e->h_rhs + (size_t)i * e->cap_rows, sizeof(double) * n_out);
+        if (!pinned && !compact) {
+            const size_t n_out = (size_t)st.H;
+            if (rhs) memcpy(rhs + (size_t)i * out_stride, e->h_rhs + (size_t)i * row_stride, sizeof(double) * n_out);
             if (var_index_by_row)
-                memcpy(var_index_by_row + (size_t)i * out_stride, e->h_rows + (size_t)i * e->cap_rows, sizeof(int32_t) * n_out);
+                memcpy(var_index_by_row + (size_t)i * out_stride, e->h_rows + (size_t)i * row_stride, sizeof(int32_t) * n_out);
         }
+    }
+    if (!pinned && compact) {  // same layout on both sides: one copy each (per-node copies cost more than the kernel's share of a node)
+        if (rhs) memcpy(rhs, e->h_rhs, sizeof(double) * (size_t)n_nodes * row_stride);
+        if (var_index_by_row) memcpy(var_index_by_row, e->h_rows, sizeof(int32_t) * (size_t)n_nodes * row_stride);
     }
     return JSLP_OK;
 }
@@ -1758,7 +1782,7 @@ extern "C" int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, c
     if (rc) return rc;
     if (rhs) *rhs = n_nodes > 0 ? e->h_rhs : nullptr;
     if (var_index_by_row) *var_index_by_row = n_nodes > 0 ? e->h_rows : nullptr;
-    if (out_stride) *out_stride = e->cap_rows;
+    if (out_stride) *out_stride = (int32_t)out_stride_of(e);
     return JSLP_OK;
 }
 
@@ -1789,11 +1813,20 @@ extern "C" int jslp_engine_set_watched_variables(jslp_engine* e, const int32_t* 
     HIPC(hipSetDevice(e->device));
     HIPC(hipStreamSynchronize(e->stream));
     hipFree(e->d_watch);
-    e->d_watch = nullptr; e->n_watch = 0; e->s.watch = nullptr; e->s.n_watch = 0;
+    e->d_watch = nullptr; e->n_watch = 0; e->s.watch = nullptr; e->s.n_watch = 0; e->s.watch_pos = nullptr;
     if (n > 0) {
-        HIPC(hipMalloc(&e->d_watch, sizeof(int32_t) * (size_t)n));
+        // [the list | variable index -> position in the list] (the second half only when no variable is listed twice)
+        std::vector<int32_t> pos((size_t)e->n_idx, -1);
+        bool unique = true;
+        for (int32_t i = 0; i < n; i++) {
+            if (pos[var_indexes[i]] >= 0) unique = false;
+            pos[var_indexes[i]] = i;
+        }
+        HIPC(hipMalloc(&e->d_watch, sizeof(int32_t) * ((size_t)n + (size_t)e->n_idx)));
         HIPC(hipMemcpy(e->d_watch, var_indexes, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(e->d_watch + n, pos.data(), sizeof(int32_t) * (size_t)e->n_idx, hipMemcpyHostToDevice));
         e->n_watch = n; e->s.watch = e->d_watch; e->s.n_watch = n;
+        e->s.watch_pos = unique ? e->d_watch + n : nullptr;
     }
     return JSLP_OK;
 }
@@ -1806,6 +1839,27 @@ extern "C" int jslp_engine_relax_watched(jslp_engine* e, int32_t n_cuts, const i
     const int32_t offs[2] = {0, n_cuts};
     return relax_batch_impl(e, 1, offs, type, var_index, value, check_cycles, out, watched_value, watched_row, e->cap_rows, 0,
                             watched_value != nullptr, watched_row != nullptr, -1, 1);
+}
+
+extern "C" int jslp_engine_relax_batch_watched(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                               const int32_t* var_index, const double* value, int check_cycles,
+                                               jslp_simplex_result* out, int32_t* watched_row, double* watched_value) {
+    if (!e) return fail(JSLP_ERR_ARG, "relax_batch_watched: null engine");
+    return relax_batch_impl(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, watched_value, watched_row, e->cap_rows, 0,
+                            watched_value != nullptr, watched_row != nullptr, -1, 1);
+}
+
+extern "C" int jslp_engine_relax_batch_watched_pinned(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                                      const int32_t* var_index, const double* value, int check_cycles,
+                                                      jslp_simplex_result* out, const int32_t** watched_row,
+                                                      const double** watched_value) {
+    if (!e) return fail(JSLP_ERR_ARG, "relax_batch_watched_pinned: null engine");
+    int rc = relax_batch_impl(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, nullptr, nullptr, 0, 1,
+                              watched_value != nullptr, watched_row != nullptr, -1, 1);
+    if (rc) return rc;
+    if (watched_row) *watched_row = n_nodes > 0 ? e->h_rows : nullptr;
+    if (watched_value) *watched_value = n_nodes > 0 ? e->h_rhs : nullptr;
+    return JSLP_OK;
 }
 
 // ---- work counters ---------------------------------------------------------------------------------------------------

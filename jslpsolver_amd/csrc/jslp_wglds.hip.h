@@ -38,6 +38,11 @@ struct WgLds {
     uint8_t* cur;         // [Hc] row written by this node (the slot holds its current version)
     const double* snapT;  // column-major copy of the saved root, column stride ldT
     int ldT, Hs;          // Hs = rows of the saved root
+    // Copy-on-write nodes (k_node_queue): nothing is restored between nodes -- a row the node has not written yet is READ from
+    // the saved root (row-major copy, shared by the whole batch, cache-resident) and written to the slot on its first update;
+    // the slot's copy of a row an earlier node wrote and this one did not is stale and never read (dirty flag 2)
+    const double* snapA;
+    bool cow;
 };
 __host__ __device__ __forceinline__ size_t wglds_bytes(int ld, int cap_rows) {
     const size_t hc = ((size_t)cap_rows + 1) & ~(size_t)1;
@@ -54,7 +59,7 @@ __device__ __forceinline__ WgLds wglds_carve(double* base, int ld, int cap_rows)
     L.vibr = L.list + hc;
     L.vibc = L.vibr + hc;
     L.cur = reinterpret_cast<uint8_t*>(L.vibc + ld);
-    L.snapT = nullptr; L.ldT = 0; L.Hs = 0;
+    L.snapT = nullptr; L.ldT = 0; L.Hs = 0; L.snapA = nullptr; L.cow = false;
     return L;
 }
 
@@ -163,10 +168,13 @@ __device__ __forceinline__ void wglds_copy_row(double2* dst, const double2* src,
 // the gated rows of one pivot, one wave per row: row <- row - k * prow on the live columns (simplex.ts:376-387).  The loads
 // of UN column pairs are in flight together (a row of Monster_II: two dependent trips instead of eight); column 0 and row 0
 // are mirrored in LDS.
+// `first`: the node's first write of this row (copy-on-write): every column is read from root_row (the saved root's row) and
+// written to the slot, not only the live ones
 template <int UN>
-__device__ __forceinline__ void wglds_update_row(const Ctx& c, const WgLds& L, int r, double k, int pc, double quot, int lane) {
+__device__ __forceinline__ void wglds_update_row(const Ctx& c, const WgLds& L, int r, double k, int pc, double quot, int lane, bool first, const double* root_row) {
     const int ld = c.ld;
     double* row = c.A + (long long)r * ld;
+    const double* src = first ? root_row : row;
     for (int base = lane * 2; base < ld; base += 128 * UN) {
         double2 a[UN];
         unsigned live = 0;
@@ -176,9 +184,9 @@ __device__ __forceinline__ void wglds_update_row(const Ctx& c, const WgLds& L, i
             a[j] = make_double2(0.0, 0.0);
             if (c0 < ld) {
                 const double2 p = *reinterpret_cast<const double2*>(L.prow + c0);
-                if (nonzero16(p.x) || nonzero16(p.y) || pc == c0 || pc == c0 + 1) {
+                if (first || nonzero16(p.x) || nonzero16(p.y) || pc == c0 || pc == c0 + 1) {
                     live |= 1u << j;
-                    a[j] = *reinterpret_cast<const double2*>(row + c0);
+                    a[j] = *reinterpret_cast<const double2*>(src + c0);
                 }
             }
         }
@@ -216,7 +224,10 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
     {   // column 0 and row 0 into LDS (the slot's contiguous RHS mirror when it is valid, else one strided gather)
         const bool mirrored = c.rhs && st->rhs_valid;
         for (int r = tid; r < H; r += nt) L.rhs[r] = mirrored ? c.rhs[r] : A[(long long)r * ld];
-        for (int col = tid; col < ld; col += nt) L.r0[col] = A[col];
+        {
+            const double* row0 = (L.cow && !L.cur[0]) ? L.snapA : A;
+            for (int col = tid; col < ld; col += nt) L.r0[col] = row0[col];
+        }
         for (int r = tid; r < H; r += nt) L.vibr[r] = c.vibr[r];
         for (int col = tid; col < W; col += nt) L.vibc[col] = c.vibc[col];
     }
@@ -253,12 +264,17 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
     }
 #endif
     const bool row_in_regs = ld <= WGL_KP * nt;
+    const double* rootA = L.cow ? L.snapA : A;
+    auto rowsrc = [&](int r) -> const double* {  // where row r is read from
+        const bool from_root = L.cow && r < L.Hs && !L.cur[r];
+        return (from_root ? rootA : A) + (long long)r * ld;
+    };
     auto gather_column = [&](int col) {  // the pivot column into LDS
         if (L.snapT) {
             const double* colT = L.snapT + (long long)col * L.ldT;
             for (int r = tid; r < H; r += nt) L.pcol[r] = (r < L.Hs && !L.cur[r]) ? colT[r] : A[(long long)r * ld + col];
         } else {
-            for (int r = tid; r < H; r += nt) L.pcol[r] = A[(long long)r * ld + col];
+            for (int r = tid; r < H; r += nt) L.pcol[r] = rowsrc(r)[col];
         }
     };
     int phase = 1, it1 = 0, it2 = 0, hist_n = 0, iters_left = iters_cap, entered2 = 0, par = 0;
@@ -288,7 +304,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
                 pr = x.i;
                 // entering column: max -cost/coef over unrestricted or coef < -precision (simplex.ts:56-71).  Row pr is the
                 // pivot row of this pivot: what is read for the search stays in registers for the normalisation below.
-                const double* row = A + (long long)pr * ld;
+                const double* row = rowsrc(pr);
                 double qv = -INFINITY;
                 int qi = 0;
                 if (row_in_regs) {
@@ -382,8 +398,9 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
         }
         // ---- the pivot (pr, pc) is chosen.  Start its global reads now: my columns of the pivot row, and (thread 0) the two
         //      map entries the pivot swaps; the cycle check and the row-gate compaction run while they are in flight ---------
+        const double* prow_src = rowsrc(pr);  // (read before anyone marks the row as written)
         if (row_in_regs && !have_pv) {
-            const double* row = A + (long long)pr * ld;
+            const double* row = prow_src;
             pv0 = tid < ld ? row[tid] : 0.0;
             pv1 = tid + nt < ld ? row[tid + nt] : 0.0;
             have_pv = true;
@@ -395,7 +412,8 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
         int n_gated = 0;
         for (int r = tid; r < H; r += nt) {
             if (r != pr && nonzero16(L.pcol[r])) {
-                L.list[atomicAdd(&sm.n_list, 1)] = r;  // the list holds every row: it cannot overflow
+                const bool first = L.cow && r < L.Hs && !L.cur[r];  // copy-on-write: this pivot brings the row into the slot
+                L.list[atomicAdd(&sm.n_list, 1)] = r | (first ? 0x40000000 : 0);  // the list holds every row: it cannot overflow
                 c.dirty[r] = 1;
                 L.cur[r] = 1;
                 n_gated += 1;
@@ -444,7 +462,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
             for (int col = tid; col < ld; col += nt) {
                 double v = 0.0;
                 if (col < W) {
-                    const double val = prow_A[col];
+                    const double val = prow_src[col];
                     const bool innz = nonzero16(val);
                     v = innz ? val / quot : 0.0;
                     if (col == pc) v = 1.0 / quot;
@@ -488,8 +506,8 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
         __syncthreads();  // L.prow complete
         WL_MARK(8);
         for (int i = w; i < n; i += nw) {
-            const int r = L.list[i];
-            wglds_update_row<UN>(c, L, r, L.pcol[r], pc, quot, lane);
+            const int entry = L.list[i], r = entry & 0x3fffffff;
+            wglds_update_row<UN>(c, L, r, L.pcol[r], pc, quot, lane, (entry & 0x40000000) != 0, rootA + (long long)r * ld);
         }
         if (tid == 0) sm.n_list = 0;  // for the next pivot (several barriers away from its first use)
         __syncthreads();
@@ -524,7 +542,8 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
 
 // addCutConstraints (cutting-strategies.ts:16-72) with one WAVE per cut row (add_cuts_slot builds them one after the other:
 // five dependent global trips per node of a Monster_II tree); the slack bookkeeping stays sequential (getNewElementIndex)
-__device__ __forceinline__ void add_cuts_waves(const Slots& s, const Cuts& cuts, int slot, int node, int cap_rows) {
+// (rows_src: where the rows of the root are read from -- the slot, or the saved root itself for copy-on-write nodes)
+__device__ __forceinline__ void add_cuts_waves(const Slots& s, const Cuts& cuts, int slot, int node, int cap_rows, const double* rows_src = nullptr) {
     DevState* st = s.st + slot;
     double* A = s.A + (long long)slot * s.A_stride;
     double* rhs = s.rhs + (long long)slot * s.pcol_stride;
@@ -557,7 +576,7 @@ __device__ __forceinline__ void add_cuts_waves(const Slots& s, const Cuts& cuts,
                 cut[col] = v;
             }
         } else {  // basic variable: negated copy of its row (:54-62)
-            const double* src = A + (long long)var_row * ld;
+            const double* src = (rows_src ? rows_src : A) + (long long)var_row * ld;
             for (int col0 = lane; col0 < ld; col0 += 256) {  // four loads in flight per lane
                 double x[4];
 #pragma unroll
@@ -605,8 +624,60 @@ __global__ void __launch_bounds__(THREADS) k_simplex_lds(Slots s, int first_slot
 // this kernel declares (40 KB per workgroup) a fourth workgroup does not fit a CU anyway
 #define JSLP_NODE512_WAVES 6
 #endif
+// Read-back of a node the LDS kernel just solved: column 0 and the row map are still in LDS (no load of what this workgroup
+// stored a moment ago).  Compact form (out_stride < 0): the row of each watched variable is found by scattering the rows
+// through watch_pos (variable index -> position in the watched list, -1 elsewhere) into the LDS list.
+__device__ __forceinline__ void gather_slot_lds(const Slots& s, const WgLds& L, int slot, double* rhs, int32_t* rows, DevState* states,
+                                                int out_stride, int o) {
+    const DevState* st = s.st + slot;
+    const int H = st->H;
+    if (out_stride < 0) {
+        const int n = -out_stride < s.n_watch ? -out_stride : s.n_watch;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) L.list[i] = -1;
+        __syncthreads();
+        for (int r = 1 + threadIdx.x; r < H; r += blockDim.x) {
+            const int v = L.vibr[r];
+            const int p = (v >= 0 && v < s.idx_stride) ? s.watch_pos[v] : -1;
+            if (p >= 0 && p < n) L.list[p] = r;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int r = L.list[i];
+            if (rows) rows[(long long)o * (-out_stride) + i] = r;
+            if (rhs) rhs[(long long)o * (-out_stride) + i] = r > 0 ? L.rhs[r] : 0.0;
+        }
+    } else if ((out_stride & 3) == 0) {
+        // the node's slices start 16-byte aligned: 16-byte stores of the RHS column, 8-byte stores of the row map (4-byte stores
+        // into pinned host memory are several times slower per byte)
+        if (rhs) {
+            double2* dst = reinterpret_cast<double2*>(rhs + (long long)o * out_stride);
+            const double2* src = reinterpret_cast<const double2*>(L.rhs);
+            for (int k = threadIdx.x; 2 * k < H; k += blockDim.x) {
+                double2 v = src[k];
+                if (2 * k + 1 >= H) v.y = 0.0;
+                dst[k] = v;
+            }
+        }
+        if (rows) {
+            int2* dst = reinterpret_cast<int2*>(rows + (long long)o * out_stride);
+            const int2* src = reinterpret_cast<const int2*>(L.vibr);
+            for (int k = threadIdx.x; 2 * k < H; k += blockDim.x) {
+                int2 v = src[k];
+                if (2 * k + 1 >= H) v.y = -1;
+                dst[k] = v;
+            }
+        }
+    } else {
+        for (int r = threadIdx.x; r < H; r += blockDim.x) {
+            if (rhs) rhs[(long long)o * out_stride + r] = L.rhs[r];
+            if (rows) rows[(long long)o * out_stride + r] = L.vibr[r];
+        }
+    }
+    if (threadIdx.x == 0) states[o] = *st;
+}
+
 // one node (= restore + cuts + simplex + read-back) of slot `slot`; false = the slot is not in sync with the snapshot
-template <int THREADS>
+template <int THREADS, bool COW = false>
 __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& snap, const Cuts& cuts, SmemL& sm, const WgLds& L, int slot, int node, int o,
                                              int check_cycles, int iters_cap, int cap_rows, double* rhs_out, int32_t* rows_out,
                                              DevState* state_out, int out_stride) {
@@ -621,6 +692,17 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
     double* A = s.A + (long long)slot * s.A_stride;
     uint8_t* dirty = s.dirty + (long long)slot * s.pcol_stride;
     double* rhs = s.rhs + (long long)slot * s.pcol_stride;
+    if (COW) {
+        // restore() without moving a row: what the previous node wrote becomes stale (2: never read, copied back only by whoever
+        // needs the slot whole again -- k_restore, the other node kernels, the end of this launch for slot 0); its column 0 comes back
+        int n_mine = 0;
+        for (int r = tid; r < H; r += blockDim.x)
+            if (dirty[r] == 1) { dirty[r] = 2; rhs[r] = snap.rhs[r]; n_mine += 1; }
+        if (s.cnt) {
+            for (int off = 32; off > 0; off >>= 1) n_mine += __shfl_down(n_mine, off, 64);
+            if (lane == 0 && n_mine) atomicAdd(s.cnt + CNT_RESTORED, (cnt_t)n_mine);
+        }
+    } else {
     // restore(): the dirty rows, found by all threads at once and compacted into the LDS list
     if (tid == 0) sm.n_list = 0;
     __syncthreads();
@@ -637,6 +719,7 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
         if (lane == 0) { dirty[r] = 0; rhs[r] = snap.rhs[r]; }
     }
     __syncthreads();
+    }
     WL_MARK(0);
     int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
     int32_t* vibc = s.vibc + (long long)slot * s.vibc_stride;
@@ -667,17 +750,19 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
     }
     __syncthreads();
     WL_MARK(1);
-    add_cuts_waves(s, cuts, slot, node, cap_rows);
+    add_cuts_waves(s, cuts, slot, node, cap_rows, COW ? snap.A : nullptr);
     __syncthreads();
     WL_MARK(2);
     const Ctx c = slot_ctx(s, slot, check_cycles);
     WgLds Ln = L;
     if (snap.AT) { Ln.snapT = snap.AT; Ln.ldT = snap.ldT; Ln.Hs = H; }
+    if (COW) { Ln.snapA = snap.A; Ln.Hs = H; Ln.cow = true; }
     simplex_wg_lds<(THREADS >= 1024 ? 8 : 4)>(c, sm, Ln, iters_cap);
 #ifdef JSLP_DEBUG_WGLDS
     wl_prev = __builtin_amdgcn_s_memtime();
 #endif
-    gather_slot(s, slot, rhs_out, rows_out, state_out, out_stride, o);
+    if (st->err == ERR_NONE && (out_stride >= 0 || s.watch_pos)) gather_slot_lds(s, Ln, slot, rhs_out, rows_out, state_out, out_stride, o);
+    else gather_slot(s, slot, rhs_out, rows_out, state_out, out_stride, o);
     __syncthreads();
     WL_MARK(12);
     return true;
@@ -704,7 +789,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
 // from a queue (an atomic counter) until the batch is empty -- no group boundaries, hence no idle tail per group; `order`
 // hands the nodes out most-cuts-first (the cut count predicts the repair pivots: longest-processing-time-first keeps the
 // last workgroups to finish on the cheap nodes).  Node k's outcome goes to index k whatever workgroup / slot evaluated it.
-template <int THREADS>
+template <int THREADS, bool COW>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES : 4) k_node_queue(Slots s, Snapshot snap, Cuts cuts, int n_nodes, const int32_t* order,
                                                       int* queue, int check_cycles, int iters_cap, int cap_rows, double* rhs_out,
                                                       int32_t* rows_out, DevState* state_out, int out_stride) {
@@ -721,7 +806,20 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
         const int node = order ? order[k] : k;
         int slot = blockIdx.x;
         asm volatile("" : "+s"(slot));  // opaque per iteration: nothing derived from the slot is hoisted and kept live across nodes
-        node_lds_run<THREADS>(s, snap, cuts, sm, L, slot, node, node, check_cycles, iters_cap, cap_rows, rhs_out, rows_out, state_out, out_stride);
+        node_lds_run<THREADS, COW>(s, snap, cuts, sm, L, slot, node, node, check_cycles, iters_cap, cap_rows, rhs_out, rows_out, state_out, out_stride);
         __syncthreads();
+    }
+    if (COW && blockIdx.x == 0) {
+        // slot 0 is also the engine's live tableau: leave it whole (the last node this workgroup evaluated), as the other
+        // batch shapes do -- its stale rows come back from the saved root.  The other slots keep theirs until someone restores them.
+        const int H = s.st[0].s_H, ld2 = s.ld / 2, lane = threadIdx.x & 63;
+        uint8_t* dirty = s.dirty;
+        const double2* src = reinterpret_cast<const double2*>(snap.A);
+        double2* dst = reinterpret_cast<double2*>(s.A);
+        for (int r = threadIdx.x >> 6; r < H; r += blockDim.x >> 6)
+            if (dirty[r] == 2) {
+                wglds_copy_row(dst + (long long)r * ld2, src + (long long)r * ld2, ld2, lane);
+                if (lane == 0) dirty[r] = 0;
+            }
     }
 }

@@ -188,6 +188,27 @@ class Tableau:
         self._absorb(res)
         return res, rows, vals
 
+    def applyCutsBatchWatched(self, cut_lists, check_cycles=True, packed=None, copy=True):
+        """applyCutsBatch whose read-back is, per node, rowByVarIndex / the RHS cell of the watched variables only: what a host
+        that walks the tree itself reads per node, and ~10x fewer bytes over PCIe than the full RHS columns + row maps.
+        copy=False returns views of the engine's pinned buffer (valid until the next call on this tableau)."""
+        n_nodes, offs, t, v, x = packed if packed is not None else self.pack_cut_lists(cut_lists)
+        out = (SimplexResult * max(n_nodes, 1))()
+        if not copy:
+            p_rows = _capi._i32p()
+            p_vals = _capi._f64p()
+            self.lib.check(self.lib.jslp_engine_relax_batch_watched_pinned(
+                self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)), out,
+                _capi.C.byref(p_rows), _capi.C.byref(p_vals)), "jslp_engine_relax_batch_watched_pinned")
+            shape = (max(n_nodes, 1), self.n_watched)
+            return out, np.ctypeslib.as_array(p_rows, shape=shape), np.ctypeslib.as_array(p_vals, shape=shape)
+        rows = np.empty((max(n_nodes, 1), self.n_watched), dtype=np.int32)
+        vals = np.empty((max(n_nodes, 1), self.n_watched), dtype=np.float64)
+        self.lib.check(self.lib.jslp_engine_relax_batch_watched(self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t), _capi.ptr_i32(v),
+                                                                _capi.ptr_f64(x), int(bool(check_cycles)), out, _capi.ptr_i32(rows),
+                                                                _capi.ptr_f64(vals)), "jslp_engine_relax_batch_watched")
+        return out, rows, vals
+
     def set_counting(self, enabled):
         self.lib.check(self.lib.jslp_engine_set_counting(self._h, int(bool(enabled))), "jslp_engine_set_counting")
 

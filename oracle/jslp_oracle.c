@@ -936,6 +936,43 @@ int jslp_engine_relax_watched(jslp_engine* e, int32_t n_cuts, const int8_t* type
     return JSLP_OK;
 }
 
+int jslp_engine_relax_batch_watched(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                    const int32_t* var_index, const double* value, int check_cycles,
+                                    jslp_simplex_result* out, int32_t* watched_row, double* watched_value) {
+    if (!e || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "relax_batch_watched: null");
+    if (e->n_watch <= 0 || e->n_watch > e->cap_rows)
+        return fail(JSLP_ERR_ARG, "relax_batch_watched: after set_watched_variables (at most row_capacity of them)");
+    for (int32_t i = 0; i < n_nodes; i++) {
+        const int32_t a = cut_offsets[i], n = cut_offsets[i + 1] - a;
+        int rc = jslp_engine_relax_watched(e, n, type ? type + a : 0, var_index ? var_index + a : 0, value ? value + a : 0, check_cycles,
+                                           &out[i], watched_row ? watched_row + (size_t)i * e->n_watch : 0,
+                                           watched_value ? watched_value + (size_t)i * e->n_watch : 0);
+        if (rc) return rc;
+    }
+    return JSLP_OK;
+}
+
+/* zero-copy variant of the ABI: here backed by heap buffers */
+int jslp_engine_relax_batch_watched_pinned(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                           const int32_t* var_index, const double* value, int check_cycles,
+                                           jslp_simplex_result* out, const int32_t** watched_row, const double** watched_value) {
+    if (!e) return fail(JSLP_ERR_ARG, "relax_batch_watched_pinned: null");
+    static __thread double* b_val = 0;
+    static __thread int32_t* b_row = 0;
+    static __thread size_t b_cap = 0;
+    const size_t need = (size_t)(n_nodes > 0 ? n_nodes : 1) * (size_t)(e->n_watch > 0 ? e->n_watch : 1);
+    if (need > b_cap) {
+        b_val = (double*)realloc(b_val, need * sizeof(double));
+        b_row = (int32_t*)realloc(b_row, need * sizeof(int32_t));
+        b_cap = need;
+    }
+    int rc = jslp_engine_relax_batch_watched(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, b_row, b_val);
+    if (rc) return rc;
+    if (watched_row) *watched_row = b_row;
+    if (watched_value) *watched_value = b_val;
+    return JSLP_OK;
+}
+
 int jslp_engine_set_counting(jslp_engine* e, int enabled) {
     if (!e) return fail(JSLP_ERR_ARG, "set_counting: null");
     e->counting = enabled ? 1 : 0;

@@ -82,6 +82,45 @@ def _check_watched(lib):
     t.close()
 
 
+def _check_watched_batch(lib, reps):
+    """the compact read-back of a whole batch (jslp_engine_relax_batch_watched) against the full one, node by node; reps > 1 makes
+    the batch larger than the resident workgroups of the HIP engine's queue kernel (several nodes per slot, copy-on-write)"""
+    g = G.load(MONSTER_II)
+    t, calls = _root(lib, g)
+    from jslpsolver_amd import Model
+    ints = [int(v) for v in Model(g["model"]).integer_index_array]
+    t.set_watched_variables(ints)
+    nodes = [c["cuts"] or [] for c in calls[1:]] * reps
+    packed = t.pack_cut_lists(nodes)
+    for _ in range(2):  # (the first batch of an engine goes through the separate restore / cut / simplex launches)
+        out_w, rows_w, vals_w = t.applyCutsBatchWatched(None, check_cycles=True, packed=packed)
+        out_p, rows_p, vals_p = t.applyCutsBatchWatched(None, check_cycles=True, packed=packed, copy=False)
+        assert np.array_equal(rows_p, rows_w) and np.array_equal(vals_p.view(np.int64), vals_w.view(np.int64))
+        out, rhs, vibr = t.applyCutsBatch(None, check_cycles=True, packed=packed)
+        ints_a = np.asarray(ints)
+        for i in range(len(nodes)):
+            assert (out_w[i].feasible, out_w[i].bounded, out_w[i].pivots_phase1, out_w[i].pivots_phase2, out_w[i].height) == \
+                   (out[i].feasible, out[i].bounded, out[i].pivots_phase1, out[i].pivots_phase2, out[i].height)
+            h = out[i].height
+            row_of = np.full(int(max(vibr[i, :h].max(), ints_a.max())) + 1, -1, dtype=np.int64)
+            row_of[vibr[i, 1:h]] = np.arange(1, h)
+            r = row_of[ints_a]
+            assert np.array_equal(rows_w[i], r.astype(np.int32)), i
+            want = np.where(r > 0, rhs[i, np.maximum(r, 0)], 0.0)
+            assert np.array_equal(vals_w[i].view(np.int64), want.view(np.int64)), i
+    t.close()
+
+
+def test_watched_batch_equals_full_batch_oracle(oracle_lib):
+    _check_watched_batch(oracle_lib, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reps", [1, 8])
+def test_watched_batch_equals_full_batch_hip(hip_lib, reps):
+    _check_watched_batch(hip_lib, reps)
+
+
 def test_watched_read_back_equals_full_read_back_oracle(oracle_lib):
     _check_watched(oracle_lib)
 

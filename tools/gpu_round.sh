@@ -29,9 +29,13 @@ for s in $steps; do
     stress) for i in 1 2 3; do timeout 120 python tools/wglds_timing.py rate; done > $out/stress.log 2>&1 < /dev/null; echo "stress rc=$?"; grep -c relaxations $out/stress.log; tail -3 $out/stress.log ;;
     sweep) timeout 600 node tools/mincells_sweep.js > $out/mincells_sweep.md 2> $out/mincells_sweep.err < /dev/null; echo "sweep rc=$?"; cat $out/mincells_sweep.md ;;
     dense) (timeout 300 python tools/dense_lp_times.py; JSLP_HIP_LIBRARY=build/libjslp_hip_nodefer.so timeout 300 python tools/dense_lp_times.py) > $out/dense_lp_times.log 2>&1 < /dev/null; echo "dense rc=$?"; cat $out/dense_lp_times.log ;;
-    zc) (for t in 0 1; do echo "snapshot_transpose=$t"; JSLP_SNAPSHOT_TRANSPOSE=$t timeout 120 python tools/wglds_timing.py rate; JSLP_SNAPSHOT_TRANSPOSE=$t timeout 120 python tools/wglds_timing.py single | grep "counting off"; done
-         JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py batch) > $out/zero_copy.log 2>&1 < /dev/null; echo "zc rc=$?"; cat $out/zero_copy.log ;;
-    qcheck) (for cfg in "JSLP_NODE_QUEUE=0 JSLP_SNAPSHOT_TRANSPOSE=0" "JSLP_NODE_QUEUE=1 JSLP_SNAPSHOT_TRANSPOSE=0" "JSLP_NODE_QUEUE=0 JSLP_SNAPSHOT_TRANSPOSE=1" "JSLP_NODE_QUEUE=1 JSLP_SNAPSHOT_TRANSPOSE=1" "JSLP_NODE_QUEUE=2" "JSLP_ZERO_COPY=0" "JSLP_NO_WGLDS=1"; do echo "== $cfg"; env $cfg timeout 120 python tools/queue_check.py; done) > $out/queue_check.log 2>&1 < /dev/null; echo "qcheck rc=$?"; cat $out/queue_check.log ;;
+    zc) (for t in 0 1; do echo "node_cow=$t"; JSLP_NODE_COW=$t timeout 120 python tools/wglds_timing.py rate; done
+         JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py batch) > $out/zero_copy.log 2>&1 < /dev/null; echo "zc rc=$?"; grep -v micro $out/zero_copy.log ;;
+    pmcrelax) for cow in 0 1; do for c in fetch write; do
+           C=FETCH_SIZE; [ $c = write ] && C=WRITE_SIZE
+           (cd /tmp && JSLP_NODE_COW=$cow timeout 600 rocprofv3 --pmc $C -d $GRAFT_REPO_ROOT/$out/pmc_relax_$c -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py relax > $GRAFT_REPO_ROOT/$out/pmc_relax_$c.log 2>&1 < /dev/null); echo "pmc relax cow=$cow $c rc=$?"
+         done; timeout 120 python tools/pmc_latest.py $out relax "gpurun_out/$tag (tools/gpu_round.sh pmcrelax, JSLP_NODE_COW=$cow), round 2" < /dev/null | grep "bytes_per_unit\|traffic_over"; rm -rf $out/pmc_relax_fetch $out/pmc_relax_write; done ;;
+    qcheck) (for cfg in "JSLP_NODE_QUEUE=0 JSLP_SNAPSHOT_TRANSPOSE=0" "JSLP_NODE_COW=0" "JSLP_NODE_COW=1" "JSLP_NODE_COW=1 JSLP_SNAPSHOT_TRANSPOSE=0" "JSLP_NODE_QUEUE=2" "JSLP_ZERO_COPY=0" "JSLP_GROUP_MAX=100"; do echo "== $cfg"; env $cfg timeout 120 python tools/queue_check.py; done) > $out/queue_check.log 2>&1 < /dev/null; echo "qcheck rc=$?"; cat $out/queue_check.log ;;
     qprof) (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/qprof -o q -- python $GRAFT_REPO_ROOT/tools/wglds_timing.py rate > $GRAFT_REPO_ROOT/$out/qprof.log 2>&1 < /dev/null); echo "qprof rc=$?"; tail -2 $out/qprof.log
           timeout 60 python tools/rocpd_stats.py $(ls $out/qprof/*.db | head -1) 2>/dev/null | head -12 ;;
     batchtests) timeout 900 python -m pytest tests -m gpu -q -x -k "batch or pool or relax" > $out/batchtests.log 2>&1 < /dev/null; echo "batchtests rc=$?"; tail -5 $out/batchtests.log ;;

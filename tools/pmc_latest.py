@@ -41,10 +41,9 @@ def main(run_dir, key, source):
     assert w["units"] == w2["units"] and w["kernel"] == w2["kernel"]
     fetch_kib, nf, gf = counter_sum(run_dir, "pmc_%s_fetch" % key, "FETCH_SIZE", w["kernel"])
     write_kib, nw, gw = counter_sum(run_dir, "pmc_%s_write" % key, "WRITE_SIZE", w["kernel"])
-    if key == "relax":  # one workgroup = one node: count the units from the dispatches themselves (grid size / workgroup size)
-        assert gf == gw, (gf, gw)
-        w["units"] = gf
-    wide = key == "relax"  # k_node_wg streams rows with 16 B per lane; the resident kernel issues 8-byte agent-scope loads
+    if key == "relax":  # one dispatch per call of the workload: the units are the nodes those calls evaluated
+        assert nf == nw == w["dispatches"], (nf, nw, w["dispatches"])
+    wide = key == "relax"  # the node kernels stream rows with 16 B per lane; the resident kernel issues 8-byte agent-scope loads
     fetch = fetch_kib * 1024.0 * (2.0 if wide else 1.0) / w["units"]
     write = write_kib * 1024.0 / w["units"]
     entry = {"kernel": w["kernel"], "workload": w["workload"], "unit": w["unit"], "units_counted": w["units"],

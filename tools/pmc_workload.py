@@ -2,7 +2,7 @@
 """The two workloads of bench.py in a form whose units of work can be matched to kernel dispatches exactly, for the
 rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs: tools/gpu_round.sh pmc).
   tools/pmc_workload.py pivots [n]   -> K solves of config 3a (k_simplex_resident: one dispatch per solve)
-  tools/pmc_workload.py relax        -> the 2416-node Monster_II batch, K one-launch calls (k_node_wg: 3 dispatches per call)
+  tools/pmc_workload.py relax        -> the 2416-node Monster_II batch, K one-launch calls (k_node_queue: one dispatch per call)
 Prints one JSON line: which kernel, how many dispatches of it to expect, how many units (pivots / relaxations) they did."""
 import gzip
 import json
@@ -58,8 +58,8 @@ def relax(calls=12, reps=16):
     sys.path.insert(0, ROOT)
     import bench
     per_node = bench.gated_bytes(c, W, W + 2 * cap + 2, H) / c["relaxations"]
-    groups = (len(nodes) + 1023) // 1024
-    print(json.dumps({"key": "relaxations", "kernel": "k_node_lds" if os.environ.get("JSLP_NO_WGLDS") != "1" else "k_node_wg", "dispatches": groups * (calls + 1), "units": len(nodes) * (calls + 1),
+    # every call after the first is ONE dispatch of k_node_queue (resident workgroups pulling the nodes from a queue)
+    print(json.dumps({"key": "relaxations", "kernel": "k_node_queue", "dispatches": calls + 1, "units": len(nodes) * (calls + 1),
                       "unit": "LP relaxation", "algorithmic_bytes_per_unit": per_node,
                       "workload": "Monster_II %d-node batch, %d one-launch calls" % (len(nodes), calls + 1)}))
 

@@ -45,10 +45,19 @@ else:
         print(t.get_counters(), flush=True)
         t.set_counting(False)
     best = 1e9
+    want_rows = os.environ.get("WANT_ROWS", "1") == "1"
+    watched = os.environ.get("WATCHED", "0") == "1"
+    if watched:
+        t.set_watched_variables([int(v) for v in model.integer_index_array])
     for _ in range(8):
         t0 = time.perf_counter()
-        t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+        if watched:
+            t.applyCutsBatchWatched(None, check_cycles=True, packed=packed)
+        else:
+            t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False, want_rows=want_rows)
         best = min(best, time.perf_counter() - t0)
+    if watched:
+        print("compact read-back: %d watched variables per node" % t.n_watched)
     print("batch %d nodes: %.0f us, %.0f relaxations/s  [threads %s group %s wglds %s]" % (
         len(nodes), best * 1e6, len(nodes) / best, os.environ.get("JSLP_WG_BATCH_THREADS", "512"), os.environ.get("JSLP_GROUP_MAX", "1024"),
         "off" if os.environ.get("JSLP_NO_WGLDS") == "1" else "on"), flush=True)
