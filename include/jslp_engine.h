@@ -150,6 +150,10 @@ int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
  * Zero-copy variant: the outcomes stay in the engine's own pinned read-back buffer.  On return *rhs / *var_index_by_row
  * point at n_nodes x *out_stride arrays (row i = node i, first out[i].height entries valid) that remain valid until
  * the next call on this engine; pass NULL for what is not needed (less PCIe traffic).  Same semantics otherwise.
+ * *out_stride is the engine's choice (>= the row capacity; padded so that every node's slice is 16-byte aligned).
+ * "The engine's own tableau is left holding the last node" reads here: of the nodes the first of its tableau copies
+ * evaluated (a large batch is spread over as many copies as the chip keeps workgroups resident, each pulling the next
+ * node from a queue): restore() before using the live tableau again.
  */
 int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
                                    const int32_t* var_index, const double* value, int check_cycles,

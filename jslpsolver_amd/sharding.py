@@ -91,9 +91,10 @@ def pack_local(results, rhs, rows, n_mine, per, stride):
     if n_mine:
         res = np.frombuffer(results, dtype=np.uint8, count=n_mine * RES_BYTES).reshape(n_mine, RES_BYTES)
         local[:n_mine, :RES_BYTES] = res
-        local[:n_mine, RES_BYTES:RES_BYTES + 8 * stride] = np.ascontiguousarray(rhs[:n_mine]).view(np.uint8).reshape(n_mine, 8 * stride)
+        # (the engine's own read-back buffers may be laid out with a wider, aligned row stride: keep the first `stride` entries)
+        local[:n_mine, RES_BYTES:RES_BYTES + 8 * stride] = np.ascontiguousarray(rhs[:n_mine, :stride]).view(np.uint8).reshape(n_mine, 8 * stride)
         o = RES_BYTES + 8 * stride
-        local[:n_mine, o:o + 4 * stride] = np.ascontiguousarray(rows[:n_mine]).view(np.uint8).reshape(n_mine, 4 * stride)
+        local[:n_mine, o:o + 4 * stride] = np.ascontiguousarray(rows[:n_mine, :stride]).view(np.uint8).reshape(n_mine, 4 * stride)
     return local
 
 
