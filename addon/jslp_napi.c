@@ -51,6 +51,8 @@ static struct {
     int (*host_matrix)(jslp_engine*, double**, int64_t*);
     int (*set_watched)(jslp_engine*, const int32_t*, int32_t);
     int (*relax_watched)(jslp_engine*, int32_t, const int8_t*, const int32_t*, const double*, int, jslp_simplex_result*, int32_t*, double*);
+    int (*relax_batch_watched)(jslp_engine*, int32_t, const int32_t*, const int8_t*, const int32_t*, const double*, int, jslp_simplex_result*,
+                               int32_t*, double*);
     int (*set_counting)(jslp_engine*, int);
     int (*get_counters)(jslp_engine*, jslp_work_counters*);
     int (*pool_create)(jslp_pool**, jslp_engine*, const int32_t*, int32_t);
@@ -63,7 +65,7 @@ static struct {
 
 /* what a JS engine handle points at: the engine plus the dimensions it was created with (argument checks without a
    device round trip) */
-typedef struct { jslp_engine* e; int32_t h0, w, cap; } ebox;
+typedef struct { jslp_engine* e; int32_t h0, w, cap, n_watched; } ebox;
 
 #define THROW(env, msg)                       \
     do {                                      \
@@ -192,7 +194,7 @@ static napi_value fn_load(napi_env env, napi_callback_info info) {
     SYM(checkpoint_create, "jslp_engine_checkpoint_create"); SYM(checkpoint_restore, "jslp_engine_checkpoint_restore");
     SYM(checkpoint_release, "jslp_engine_checkpoint_release"); SYM(relax_from, "jslp_engine_relax_from");
     SYM(host_matrix, "jslp_engine_host_matrix"); SYM(set_watched, "jslp_engine_set_watched_variables");
-    SYM(relax_watched, "jslp_engine_relax_watched"); SYM(set_counting, "jslp_engine_set_counting");
+    SYM(relax_watched, "jslp_engine_relax_watched"); SYM(relax_batch_watched, "jslp_engine_relax_batch_watched"); SYM(set_counting, "jslp_engine_set_counting");
     SYM(get_counters, "jslp_engine_get_counters"); SYM(pool_create, "jslp_pool_create"); SYM(pool_destroy, "jslp_pool_destroy");
     SYM(pool_size, "jslp_pool_size"); SYM(pool_sync_root, "jslp_pool_sync_root"); SYM(pool_relax_batch, "jslp_pool_relax_batch");
     napi_value s;
@@ -515,6 +517,44 @@ static napi_value fn_relax_batch(napi_env env, napi_callback_info info) {
     return arr;
 }
 
+/* relaxBatchWatched(h, Int32Array offsets, type, varIndex, value, checkCycles, Int32Array rowsOut|null, Float64Array valuesOut|null)
+   -> [result]: node i's watched variables at [i * nWatched, (i + 1) * nWatched) (setWatchedVariables first) */
+static napi_value fn_relax_batch_watched(napi_env env, napi_callback_info info) {
+    napi_value argv[8];
+    if (!get_args(env, info, 8, argv)) return NULL;
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    void *o, *t, *v, *x, *wr, *wv;
+    size_t no, nt, nv, nx, nwr, nwv;
+    bool check;
+    if (!typed(env, argv[1], napi_int32_array, &o, &no) || !typed(env, argv[2], napi_int8_array, &t, &nt) ||
+        !typed(env, argv[3], napi_int32_array, &v, &nv) || !typed(env, argv[4], napi_float64_array, &x, &nx))
+        return NULL;
+    NAPI_OK(env, napi_get_value_bool(env, argv[5], &check));
+    if (!typed(env, argv[6], napi_int32_array, &wr, &nwr) || !typed(env, argv[7], napi_float64_array, &wv, &nwv)) return NULL;
+    if (no < 1) THROW(env, "relaxBatchWatched: offsets must hold n_nodes + 1 entries");
+    const int32_t n_nodes = (int32_t)no - 1;
+    if (nt != nv || nv != nx || (size_t)((const int32_t*)o)[n_nodes] != nt) THROW(env, "relaxBatchWatched: offsets[n_nodes] must equal the length of the cut arrays");
+    const size_t n_watched = (size_t)box_of(env, argv[0])->n_watched;
+    if (n_watched == 0) THROW(env, "relaxBatchWatched: setWatchedVariables first");
+    if ((wr && nwr < (size_t)n_nodes * n_watched) || (wv && nwv < (size_t)n_nodes * n_watched))
+        THROW(env, "relaxBatchWatched: output arrays shorter than n_nodes * nWatched");
+    jslp_simplex_result* res = (jslp_simplex_result*)calloc((size_t)(n_nodes > 0 ? n_nodes : 1), sizeof *res);
+    int rc = L.relax_batch_watched(e, n_nodes, (const int32_t*)o, (const int8_t*)t, (const int32_t*)v, (const double*)x,
+                                   check ? 1 : 0, res, (int32_t*)wr, (double*)wv);
+    if (rc != JSLP_OK) free(res);
+    ENGINE_OK(env, rc, "jslp_engine_relax_batch_watched");
+    napi_value arr;
+    if (napi_create_array_with_length(env, (size_t)n_nodes, &arr) != napi_ok) { free(res); THROW(env, "array"); }
+    for (int32_t i = 0; i < n_nodes; i++) {
+        napi_value ro = result_object(env, &res[i]);
+        if (!ro) { free(res); return NULL; }
+        napi_set_element(env, arr, (uint32_t)i, ro);
+    }
+    free(res);
+    return arr;
+}
+
 /* dims(h) -> {height, width, nVarIndexes} */
 static napi_value fn_dims(napi_env env, napi_callback_info info) {
     napi_value argv[1];
@@ -633,6 +673,10 @@ static napi_value fn_set_watched(napi_env env, napi_callback_info info) {
     void* v; size_t n;
     if (!typed(env, argv[1], napi_int32_array, &v, &n)) return NULL;
     ENGINE_OK(env, L.set_watched(e, (const int32_t*)v, (int32_t)n), "jslp_engine_set_watched_variables");
+    {   /* relaxBatchWatched sizes its output checks by this */
+        void* p = NULL;
+        if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) ((ebox*)p)->n_watched = (int32_t)n;
+    }
     return NULL;
 }
 
@@ -797,7 +841,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"releasePooledResources", fn_release_pooled}, {"setIntegerVariables", fn_set_integer_variables}, {"applyMirCuts", fn_apply_mir_cuts},
         {"checkpointCreate", fn_checkpoint_create}, {"checkpointRestore", fn_checkpoint_restore},
         {"checkpointRelease", fn_checkpoint_release}, {"relaxFrom", fn_relax_from},
-        {"hostMatrix", fn_host_matrix}, {"detach", fn_detach}, {"setWatchedVariables", fn_set_watched}, {"relaxWatched", fn_relax_watched},
+        {"hostMatrix", fn_host_matrix}, {"detach", fn_detach}, {"setWatchedVariables", fn_set_watched}, {"relaxWatched", fn_relax_watched}, {"relaxBatchWatched", fn_relax_batch_watched},
         {"setCounting", fn_set_counting}, {"getCounters", fn_get_counters},
         {"poolCreate", fn_pool_create}, {"poolDestroy", fn_pool_destroy}, {"poolSize", fn_pool_size},
         {"poolSyncRoot", fn_pool_sync_root}, {"poolRelaxBatch", fn_pool_relax_batch},

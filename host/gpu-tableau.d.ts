@@ -32,8 +32,17 @@ export interface InstallOptions extends LoadOptions {
     device?: number;
     /** > 1: default B&B policy with n-node speculative batches (in-order commit); needs `solver` */
     speculate?: number;
-    /** tableaus with fewer cells stay on the reference's own TypeScript path (default 0: everything runs on the engine) */
+    /**
+     * tableaus with fewer cells (width x height) stay on the reference's own TypeScript path.  Default (measured,
+     * profiles/r02_mincells_sweep.md): 8192 for LPs, 262144 for models with integer variables, 32768 for those when `speculate` > 1;
+     * 0 sends everything to the engine.
+     */
     minCells?: number;
+    /**
+     * HIP device ordinals of a device pool (jslp_pool_*): speculative batches are split over one engine per ordinal (the
+     * first must be `device`); the same ordinal may appear several times ("virtual devices" on one GPU)
+     */
+    devices?: number[];
 }
 
 /** host part of a device-resident checkpoint (StateCheckpoint, src/tableau/incremental-branch-and-cut.ts:31-44) */
@@ -71,8 +80,16 @@ export function install(Tableau: TableauClass, options?: InstallOptions): () => 
 export function sync<T>(tableau: T): T;
 /** (row, col) of every pivot since the upload, interleaved; null when the tableau is not on the engine */
 export function pivotTrace(tableau: any): Int32Array | null;
-/** destroy the tableau's engine now (its resources go to the library's pool) */
+/**
+ * destroy the tableau's engine now (its resources go to the library's pool).  The tableau keeps its last read-back; a later
+ * simplex() / applyCuts() on it throws instead of silently running on stale data.
+ */
 export function release(tableau: any): void;
+/**
+ * bring the live tableau back into the JS object and detach it from the engine: what the wrappers of the reference's
+ * post-solve editing API (addConstraint, removeVariable, ... src/tableau/dynamic-modification.ts) do before they run
+ */
+export function bringHome(tableau: any): void;
 /** keep options.useIncremental solves entirely on the reference's CPU path (for hosts that install() without `solver`) */
 export function guardIncremental(solver: SolverLike): () => void;
 export function isOnEngine(tableau: any): boolean;
@@ -80,5 +97,11 @@ export function createCheckpoint(tableau: any): Checkpoint;
 export function relaxFromCheckpoint<T>(tableau: T, checkpoint: Checkpoint, cuts: BranchCut[]): T;
 export function releaseCheckpoint(tableau: any, checkpoint: Checkpoint): void;
 export function relaxBatch(tableau: any, cutLists: BranchCut[][]): RelaxationOutcome[];
+/**
+ * relaxBatch with the compact read-back (jslp_engine_relax_batch_watched): per node only rowByVarIndex (-1 = not basic) and the
+ * RHS cell of `varIndexes` (default: the model's integer variables)
+ */
+export function relaxBatchWatched(tableau: any, cutLists: BranchCut[][], varIndexes?: ArrayLike<number>):
+    Array<{ res: RelaxationOutcome["res"]; rows: Int32Array; values: Float64Array }>;
 export function commitOutcome<T>(tableau: T, cuts: BranchCut[], outcome: RelaxationOutcome): T;
 export function backend(): string | null;

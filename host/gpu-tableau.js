@@ -554,6 +554,44 @@ function relaxBatch(t, cutLists) {
     return out;
 }
 
+// relaxBatch with the compact read-back (jslp_engine_relax_batch_watched): per node only rowByVarIndex / the RHS cell of
+// `varIndexes` (default: the model's integer variables) -- what isIntegral / getMostFractionalVar read between relaxations
+// (mip-utils.ts:43-61, 100-126); ~10x fewer bytes over PCIe than the full RHS columns + row maps of relaxBatch
+function relaxBatchWatched(t, cutLists, varIndexes) {
+    const st = t.__gpu;
+    if (!st || !st.active) throw new Error("[gpu-tableau] relaxBatchWatched: tableau is not on the engine");
+    const watched = varIndexes ? Int32Array.from(varIndexes) : Int32Array.from(t.model.integerVariables.map((v) => v.index));
+    const key = Array.prototype.join.call(watched, ",");
+    if (st.watchedKey !== key) {
+        addon.setWatchedVariables(st.h, watched);
+        st.watchedKey = key;
+    }
+    const n = cutLists.length, w = watched.length;
+    const offsets = new Int32Array(n + 1);
+    let total = 0;
+    for (let i = 0; i < n; i++) {
+        total += cutLists[i].length;
+        offsets[i + 1] = total;
+    }
+    const type = new Int8Array(total);
+    const varIndex = new Int32Array(total);
+    const value = new Float64Array(total);
+    for (let i = 0, k = 0; i < n; i++) {
+        const cuts = cutLists[i];
+        for (let j = 0; j < cuts.length; j++, k++) {
+            type[k] = cuts[j].type === "min" ? 0 : 1;
+            varIndex[k] = cuts[j].varIndex;
+            value[k] = cuts[j].value;
+        }
+    }
+    const rows = new Int32Array(n * w), values = new Float64Array(n * w);
+    const check = t.model ? t.model.checkForCycles === true : false;
+    const results = addon.relaxBatchWatched(st.h, offsets, type, varIndex, value, check, rows, values);
+    const out = new Array(n);
+    for (let i = 0; i < n; i++) out[i] = { res: results[i], rows: rows.subarray(i * w, (i + 1) * w), values: values.subarray(i * w, (i + 1) * w) };
+    return out;
+}
+
 // make `t` the tableau of a node evaluated earlier by relaxBatch: the host bookkeeping of restore() + addCutConstraints(cuts)
 // and then the cached outcome in place of simplex()
 function commitOutcome(t, cuts, outcome) {
@@ -643,7 +681,7 @@ function bringHome(t) {
 
 const api = {
     loadEngine, install, sync, pivotTrace, release, guardIncremental, createCheckpoint, relaxFromCheckpoint, releaseCheckpoint,
-    relaxBatch, commitOutcome, isOnEngine, bringHome,
+    relaxBatch, relaxBatchWatched, commitOutcome, isOnEngine, bringHome,
     backend: () => backend,
 };
 module.exports = api;

@@ -272,6 +272,32 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
         if (bad.length) { fail += 1; console.log("FAIL pool", f, bad.join("; ")); } else poolOk += usedPool ? 1 : 0;
     }
 }
+// compact read-back of a batch (relaxBatchWatched) against the full one, node by node
+let watchedOk = 0;
+if (!filter && dir.indexOf("fixtures") >= 0) {
+    uninstall();
+    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16, minCells: 0 });
+    const g = loadGolden(dir, "Monster_II.json.gz");
+    const m = JSON.parse(JSON.stringify(g.model));
+    if (m.options) delete m.options.timeout;
+    const solution = solver.Solve(m, undefined, true);
+    const t = solution._tableau;
+    const ints = t.model.integerVariables.map((v) => v.index);
+    const lists = [[]];
+    for (let i = 0; i < 24; i++) lists.push([{ type: i % 2 ? "min" : "max", varIndex: ints[i], value: i % 3 }, { type: "max", varIndex: ints[(i * 7) % ints.length], value: 1 }]);
+    const full = gpu.relaxBatch(t, lists), compact = gpu.relaxBatchWatched(t, lists);
+    for (let i = 0; i < lists.length; i++) {
+        const rowOf = new Map();
+        for (let r = 1; r < full[i].rows.length; r++) rowOf.set(full[i].rows[r], r);
+        let same = full[i].res.feasible === compact[i].res.feasible && full[i].res.height === compact[i].res.height;
+        for (let k = 0; k < ints.length && same; k++) {
+            const r = rowOf.has(ints[k]) ? rowOf.get(ints[k]) : -1;
+            same = compact[i].rows[k] === r && Object.is(compact[i].values[k], r > 0 ? full[i].rhs[r] : 0);
+        }
+        if (same) watchedOk += 1; else { fail += 1; console.log("FAIL watched batch, node", i); }
+    }
+    gpu.release(t);
+}
 // the DEFAULT size policy (no minCells given): small tableaus stay on the reference's own path -- also under the injected services
 let policyOk = 0;
 if (!filter && dir.indexOf("fixtures") >= 0) {
@@ -295,5 +321,5 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
 }
 console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk,
     incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk,
-    size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, pool_ok: poolOk }));
+    size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, pool_ok: poolOk, watched_ok: watchedOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);
