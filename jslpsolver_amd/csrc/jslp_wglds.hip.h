@@ -43,6 +43,8 @@ struct WgLds {
     // the slot's copy of a row an earlier node wrote and this one did not is stale and never read (dirty flag 2)
     const double* snapA;
     bool cow;
+    bool preloaded;  // rhs / r0 / vibr / vibc are already in LDS (the queue kernel fills them from the saved root)
+    int H_hint, err_hint;  // preloaded only: the height and st->err the simplex starts with (the caller just wrote them)
 };
 __host__ __device__ __forceinline__ size_t wglds_bytes(int ld, int cap_rows) {
     const size_t hc = ((size_t)cap_rows + 1) & ~(size_t)1;
@@ -59,7 +61,7 @@ __device__ __forceinline__ WgLds wglds_carve(double* base, int ld, int cap_rows)
     L.vibr = L.list + hc;
     L.vibc = L.vibr + hc;
     L.cur = reinterpret_cast<uint8_t*>(L.vibc + ld);
-    L.snapT = nullptr; L.ldT = 0; L.Hs = 0; L.snapA = nullptr; L.cow = false;
+    L.snapT = nullptr; L.ldT = 0; L.Hs = 0; L.snapA = nullptr; L.cow = false; L.preloaded = false; L.H_hint = 0; L.err_hint = 0;
     return L;
 }
 
@@ -171,11 +173,15 @@ __device__ __forceinline__ void wglds_copy_row(double2* dst, const double2* src,
 // `first`: the node's first write of this row (copy-on-write): every column is read from root_row (the saved root's row) and
 // written to the slot, not only the live ones
 template <int UN>
-__device__ __forceinline__ void wglds_update_row(const Ctx& c, const WgLds& L, int r, double k, int pc, double quot, int lane, bool first, const double* root_row) {
+// (col_begin: this call covers columns [col_begin, col_begin + 128 * UN): a row is split into such passes so that a pivot with
+//  fewer gated rows than waves still keeps every wave busy; col_begin < 0: the whole row)
+__device__ __forceinline__ void wglds_update_row(const Ctx& c, const WgLds& L, int r, double k, int pc, double quot, int lane, bool first, const double* root_row,
+                                                 int col_begin = -1) {
     const int ld = c.ld;
     double* row = c.A + (long long)r * ld;
     const double* src = first ? root_row : row;
-    for (int base = lane * 2; base < ld; base += 128 * UN) {
+    const int b0 = (col_begin < 0 ? 0 : col_begin) + lane * 2, b1 = col_begin < 0 ? ld : min(ld, col_begin + 128 * UN);
+    for (int base = b0; base < b1; base += 128 * UN) {
         double2 a[UN];
         unsigned live = 0;
 #pragma unroll
@@ -209,6 +215,9 @@ __device__ __forceinline__ void wglds_update_row(const Ctx& c, const WgLds& L, i
     }
 }
 
+#ifndef WGL_UN512
+#define WGL_UN512 4  // column pairs per lane in flight in one row-update work item of the 512-thread kernels (1024 columns per item)
+#endif
 #define WGL_KP 2  // pivot-row values a thread keeps in registers across the cycle check (ld <= WGL_KP * threads)
 
 template <int UN>
@@ -216,12 +225,16 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
     WL_BEGIN(c.cnt);
     DevState* st = c.st;
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6, nw = nt >> 6;
-    if (tid == 0) { begin_simplex(st, iters_cap); sm.n_list = 0; }
+    if (tid == 0) {
+        if (L.preloaded) st->err = L.err_hint;  // (begin_simplex keeps a cut error: it re-reads what is stored here, no load of the old value)
+        begin_simplex(st, iters_cap);
+        sm.n_list = 0;
+    }
     __syncthreads();
-    const int H = st->H, W = c.W, ld = c.ld;  // the height is fixed during a simplex() call
+    const int H = L.preloaded ? L.H_hint : st->H, W = c.W, ld = c.ld;  // the height is fixed during a simplex() call
     const double precision = c.precision;
     double* A = c.A;
-    {   // column 0 and row 0 into LDS (the slot's contiguous RHS mirror when it is valid, else one strided gather)
+    if (!L.preloaded) {  // column 0 and row 0 into LDS (the slot's contiguous RHS mirror when it is valid, else one strided gather)
         const bool mirrored = c.rhs && st->rhs_valid;
         for (int r = tid; r < H; r += nt) L.rhs[r] = mirrored ? c.rhs[r] : A[(long long)r * ld];
         {
@@ -231,8 +244,8 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
         for (int r = tid; r < H; r += nt) L.vibr[r] = c.vibr[r];
         for (int col = tid; col < W; col += nt) L.vibc[col] = c.vibc[col];
     }
-    const int err0 = st->err;
-    long long trace_n = st->trace_n;
+    const int err0 = L.preloaded ? L.err_hint : st->err;
+    long long trace_n = (L.preloaded && c.trace_cap == 0) ? 0 : st->trace_n;
     __syncthreads();
     if (err0 != ERR_NONE) {  // a bad cut list: report, do not solve
         if (tid == 0) finish(c);
@@ -505,9 +518,17 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
         (void)n_gated;
         __syncthreads();  // L.prow complete
         WL_MARK(8);
-        for (int i = w; i < n; i += nw) {
-            const int entry = L.list[i], r = entry & 0x3fffffff;
-            wglds_update_row<UN>(c, L, r, L.pcol[r], pc, quot, lane, (entry & 0x40000000) != 0, rootA + (long long)r * ld);
+        {   // work items = (gated row, pass of UN column pairs per lane = 128 * UN columns).  Every item is one dependent memory
+            // trip for its wave, so what counts under load is trips per wave: measured on the Monster_II batch (8 waves, ~10 gated
+            // rows per pivot, 928 columns) row updates cost 98 k cycles per node with UN = 4 as whole rows (2 trips x 2 rounds),
+            // 93 k with 512-column items (this), 133 k with 256-column items (5 rounds); UN = 8 (one trip per row) does not fit the
+            // 80-VGPR budget of the batch shape (224 bytes of scratch) and that build lost pivots -- not used
+            const int passes = (ld + 128 * UN - 1) / (128 * UN);
+            for (int it = w; it < n * passes; it += nw) {
+                const int i = it / passes, ps = it - i * passes;
+                const int entry = L.list[i], r = entry & 0x3fffffff;
+                wglds_update_row<UN>(c, L, r, L.pcol[r], pc, quot, lane, (entry & 0x40000000) != 0, rootA + (long long)r * ld, ps * 128 * UN);
+            }
         }
         if (tid == 0) sm.n_list = 0;  // for the next pivot (several barriers away from its first use)
         __syncthreads();
@@ -543,7 +564,13 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
 // addCutConstraints (cutting-strategies.ts:16-72) with one WAVE per cut row (add_cuts_slot builds them one after the other:
 // five dependent global trips per node of a Monster_II tree); the slack bookkeeping stays sequential (getNewElementIndex)
 // (rows_src: where the rows of the root are read from -- the slot, or the saved root itself for copy-on-write nodes)
-__device__ __forceinline__ void add_cuts_waves(const Slots& s, const Cuts& cuts, int slot, int node, int cap_rows, const double* rows_src = nullptr) {
+// (maps_rbv / maps_cbv: where rowByVarIndex / colByVarIndex of the cut variables are read from -- the slot's maps or the saved
+//  root's; Lm: LDS mirrors of column 0 and the row map to keep in step, or nullptr)
+// Returns (uniformly) the slot's error code after the cuts when the caller passed H_known and lei_known (ERR_NONE, ERR_CAPACITY,
+// ERR_CUT_ARG: what st->err holds), else -1 (read st->err).
+__device__ __forceinline__ int add_cuts_waves(const Slots& s, const Cuts& cuts, int slot, int node, int cap_rows, const double* rows_src = nullptr,
+                                               const int32_t* maps_rbv = nullptr, const int32_t* maps_cbv = nullptr, const WgLds* Lm = nullptr,
+                                               int H_known = -1, int lei_known = -1) {
     DevState* st = s.st + slot;
     double* A = s.A + (long long)slot * s.A_stride;
     double* rhs = s.rhs + (long long)slot * s.pcol_stride;
@@ -551,27 +578,31 @@ __device__ __forceinline__ void add_cuts_waves(const Slots& s, const Cuts& cuts,
     int32_t* rbv = s.rbv + (long long)slot * s.idx_stride;
     int32_t* cbv = s.cbv + (long long)slot * s.idx_stride;
     const int a = cuts.offs[node], n = cuts.offs[node + 1] - a;
-    const int H = st->H, W = s.W, ld = s.ld;
+    // (H_known / lei_known: the caller set st->H / st->last_element_index a moment ago and says what to; re-reading them is a
+    //  global round trip each, and the slack loop below used to pay one per cut)
+    const int H = H_known >= 0 ? H_known : st->H, W = s.W, ld = s.ld;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if (H + n > cap_rows) {
         if (threadIdx.x == 0) st->err = ERR_CAPACITY;
-        return;
+        return (H_known >= 0 && lei_known >= 0) ? (int)ERR_CAPACITY : -1;
     }
+    int my_bad = 0;
     for (int h = w; h < n; h += nw) {
         const int vi = cuts.var[a + h];
         const double sign = cuts.type[a + h] == 0 ? -1.0 : 1.0;  // "min" -> -1 (:41)
         const double value = cuts.value[a + h];
         double* cut = A + (long long)(H + h) * ld;
-        const int var_row = (vi >= 0 && vi < s.idx_stride) ? rbv[vi] : -2;
-        const int var_col = (vi >= 0 && vi < s.idx_stride) ? cbv[vi] : -1;
+        const int var_row = (vi >= 0 && vi < s.idx_stride) ? (maps_rbv ? maps_rbv : rbv)[vi] : -2;
+        const int var_col = (vi >= 0 && vi < s.idx_stride) ? (maps_cbv ? maps_cbv : cbv)[vi] : -1;
         if (var_row == -2 || (var_row == -1 && var_col < 0)) {
             if (lane == 0) st->err = ERR_CUT_ARG;
+            my_bad = 1;
             continue;
         }
         if (var_row == -1) {  // non-basic variable: unit row (:46-53)
             for (int col = lane; col < ld; col += 64) {
                 double v = 0.0;
-                if (col == 0) { v = sign * value; rhs[H + h] = v; }
+                if (col == 0) { v = sign * value; rhs[H + h] = v; if (Lm) Lm->rhs[H + h] = v; }
                 else if (col == var_col) v = sign;
                 cut[col] = v;
             }
@@ -586,24 +617,30 @@ __device__ __forceinline__ void add_cuts_waves(const Slots& s, const Cuts& cuts,
                     const int col = col0 + 64 * u;
                     if (col >= ld) continue;
                     double v = 0.0;
-                    if (col == 0) { v = sign * (value - x[u]); rhs[H + h] = v; }
+                    if (col == 0) { v = sign * (value - x[u]); rhs[H + h] = v; if (Lm) Lm->rhs[H + h] = v; }
                     else if (col < W) v = -sign * x[u];
                     cut[col] = v;
                 }
             }
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && st->err != ERR_CUT_ARG) {
+    const int bad = __syncthreads_or(my_bad);  // (a bad cut list: every thread knows, nobody re-reads st->err)
+    if (threadIdx.x == 0 && !bad) {
+        int lei = lei_known >= 0 ? lei_known : st->last_element_index;
         for (int h = 0; h < n; h++) {  // getNewElementIndex + map updates (:64-69)
-            const int slack = st->last_element_index++;
+            const int slack = lei++;
             if (slack >= s.idx_stride) { st->err = ERR_CAPACITY; break; }
             vibr[H + h] = slack;
+            if (Lm) Lm->vibr[H + h] = slack;
             rbv[slack] = H + h;
             cbv[slack] = -1;
         }
+        st->last_element_index = lei;
         st->H = H + n;
     }
+    if (H_known < 0 || lei_known < 0) return -1;
+    if (bad) return (int)ERR_CUT_ARG;
+    return lei_known + n > s.idx_stride ? (int)ERR_CAPACITY : (int)ERR_NONE;
 }
 
 // simplex() of slots [first_slot, first_slot + gridDim.x): the LDS twin of k_simplex_wg
@@ -613,7 +650,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_lds(Slots s, int first_slot
     __shared__ SmemL sm;
     const Ctx c = slot_ctx(s, first_slot + blockIdx.x, check_cycles);
     const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
-    simplex_wg_lds<(THREADS >= 1024 ? 8 : 4)>(c, sm, L, iters_cap);
+    simplex_wg_lds<(THREADS >= 1024 ? 8 : WGL_UN512)>(c, sm, L, iters_cap);
 }
 
 // The LDS twin of k_node_wg: ONE branch-and-bound child per workgroup in ONE launch -- restore of the rows the previous node
@@ -692,16 +729,50 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
     double* A = s.A + (long long)slot * s.A_stride;
     uint8_t* dirty = s.dirty + (long long)slot * s.pcol_stride;
     double* rhs = s.rhs + (long long)slot * s.pcol_stride;
-    if (COW) {
-        // restore() without moving a row: what the previous node wrote becomes stale (2: never read, copied back only by whoever
-        // needs the slot whole again -- k_restore, the other node kernels, the end of this launch for slot 0); its column 0 comes back
-        int n_mine = 0;
-        for (int r = tid; r < H; r += blockDim.x)
-            if (dirty[r] == 1) { dirty[r] = 2; rhs[r] = snap.rhs[r]; n_mine += 1; }
-        if (s.cnt) {
-            for (int off = 32; off > 0; off >>= 1) n_mine += __shfl_down(n_mine, off, 64);
-            if (lane == 0 && n_mine) atomicAdd(s.cnt + CNT_RESTORED, (cnt_t)n_mine);
+    int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
+    int32_t* vibc = s.vibc + (long long)slot * s.vibc_stride;
+    int32_t* rbv = s.rbv + (long long)slot * s.idx_stride;
+    int32_t* cbv = s.cbv + (long long)slot * s.idx_stride;
+    int cut_err = (int)ERR_NONE;
+    auto restore_maps = [&]() {  // the index maps: all loads of a pass issued before its stores
+        const int nt4 = blockDim.x * 4;
+        for (int i0 = tid; i0 < snap.n_idx; i0 += nt4) {
+            int32_t x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; x[u] = i < snap.n_idx ? snap.rbv[i] : 0; y[u] = i < snap.n_idx ? snap.cbv[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; if (i < snap.n_idx) { rbv[i] = x[u]; cbv[i] = y[u]; } }
         }
+        for (int i0 = tid; i0 < H || i0 < s.W; i0 += nt4) {
+            int32_t x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; x[u] = i < H ? snap.vibr[i] : 0; y[u] = i < s.W ? snap.vibc[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; if (i < H) vibr[i] = x[u]; if (i < s.W) vibc[i] = y[u]; }
+        }
+    };
+    if (COW) {
+        // restore() without moving a byte of the slot: the node starts from the saved root, so everything it starts from is READ
+        // from there -- column 0, the cost row and the row / column maps go straight into LDS (independent loads, one trip), the
+        // cut variables' rows are looked up in the root's maps.  No dirty-row scan, no row copies, no map copies: a row the
+        // previous nodes wrote stays flagged (dirty: the slot differs from the root there) and is simply not current (L.cur).
+        // Slot 0 is the engine's live tableau: its global maps are kept as before.
+        for (int r = tid; r < H; r += blockDim.x) { L.cur[r] = 0; L.rhs[r] = snap.rhs[r]; L.vibr[r] = snap.vibr[r]; }
+        for (int col = tid; col < s.ld; col += blockDim.x) L.r0[col] = snap.A[col];
+        for (int col = tid; col < s.W; col += blockDim.x) L.vibc[col] = snap.vibc[col];
+        if (slot == 0) restore_maps();
+        const int lei0 = s.st[0].s_last_element_index;
+        if (tid == 0) {
+            st->H = H;
+            st->last_element_index = lei0;
+            st->err = ERR_NONE;
+        }
+        __syncthreads();
+        WL_MARK(0);
+        WL_MARK(1);
+        cut_err = add_cuts_waves(s, cuts, slot, node, cap_rows, snap.A, snap.rbv, snap.cbv, &L, H, lei0);
+        __syncthreads();
+        WL_MARK(2);
     } else {
     // restore(): the dirty rows, found by all threads at once and compacted into the LDS list
     if (tid == 0) sm.n_list = 0;
@@ -719,29 +790,8 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
         if (lane == 0) { dirty[r] = 0; rhs[r] = snap.rhs[r]; }
     }
     __syncthreads();
-    }
     WL_MARK(0);
-    int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
-    int32_t* vibc = s.vibc + (long long)slot * s.vibc_stride;
-    int32_t* rbv = s.rbv + (long long)slot * s.idx_stride;
-    int32_t* cbv = s.cbv + (long long)slot * s.idx_stride;
-    {   // the index maps: all loads of a pass issued before its stores
-        const int nt4 = blockDim.x * 4;
-        for (int i0 = tid; i0 < snap.n_idx; i0 += nt4) {
-            int32_t x[4], y[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; x[u] = i < snap.n_idx ? snap.rbv[i] : 0; y[u] = i < snap.n_idx ? snap.cbv[i] : 0; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; if (i < snap.n_idx) { rbv[i] = x[u]; cbv[i] = y[u]; } }
-        }
-        for (int i0 = tid; i0 < H || i0 < s.W; i0 += nt4) {
-            int32_t x[4], y[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; x[u] = i < H ? snap.vibr[i] : 0; y[u] = i < s.W ? snap.vibc[i] : 0; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + u * (int)blockDim.x; if (i < H) vibr[i] = x[u]; if (i < s.W) vibc[i] = y[u]; }
-        }
-    }
+    restore_maps();
     for (int r = tid; r < H; r += blockDim.x) L.cur[r] = 0;  // every row of the root is as saved
     if (tid == 0) {
         st->H = H;
@@ -750,17 +800,28 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
     }
     __syncthreads();
     WL_MARK(1);
-    add_cuts_waves(s, cuts, slot, node, cap_rows, COW ? snap.A : nullptr);
+    add_cuts_waves(s, cuts, slot, node, cap_rows);
     __syncthreads();
     WL_MARK(2);
+    }
     const Ctx c = slot_ctx(s, slot, check_cycles);
     WgLds Ln = L;
     if (snap.AT) { Ln.snapT = snap.AT; Ln.ldT = snap.ldT; Ln.Hs = H; }
-    if (COW) { Ln.snapA = snap.A; Ln.Hs = H; Ln.cow = true; }
-    simplex_wg_lds<(THREADS >= 1024 ? 8 : 4)>(c, sm, Ln, iters_cap);
+    if (COW) {
+        Ln.snapA = snap.A; Ln.Hs = H; Ln.cow = true; Ln.preloaded = true;
+        Ln.err_hint = cut_err;
+        Ln.H_hint = cut_err == (int)ERR_NONE ? H + (cuts.offs[node + 1] - cuts.offs[node]) : H;
+    }
+    simplex_wg_lds<(THREADS >= 1024 ? 8 : WGL_UN512)>(c, sm, Ln, iters_cap);
 #ifdef JSLP_DEBUG_WGLDS
     wl_prev = __builtin_amdgcn_s_memtime();
 #endif
+    if (COW && s.cnt) {  // rows of the root this node wrote = what a restore() before the next node has to bring back
+        int n_mine = 0;
+        for (int r = tid; r < H; r += blockDim.x) n_mine += L.cur[r] ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) n_mine += __shfl_down(n_mine, off, 64);
+        if (lane == 0 && n_mine) atomicAdd(s.cnt + CNT_RESTORED, (cnt_t)n_mine);
+    }
     if (st->err == ERR_NONE && (out_stride >= 0 || s.watch_pos)) gather_slot_lds(s, Ln, slot, rhs_out, rows_out, state_out, out_stride, o);
     else gather_slot(s, slot, rhs_out, rows_out, state_out, out_stride, o);
     __syncthreads();
@@ -797,27 +858,30 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
     __shared__ SmemL sm;
     __shared__ int q_next;
     const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
+    bool ran = false;
     for (;;) {
         if (threadIdx.x == 0) q_next = atomicAdd(queue, 1);
         __syncthreads();
         const int k = q_next;
         __syncthreads();
         if (k >= n_nodes) break;
+        ran = true;
         const int node = order ? order[k] : k;
         int slot = blockIdx.x;
         asm volatile("" : "+s"(slot));  // opaque per iteration: nothing derived from the slot is hoisted and kept live across nodes
         node_lds_run<THREADS, COW>(s, snap, cuts, sm, L, slot, node, node, check_cycles, iters_cap, cap_rows, rhs_out, rows_out, state_out, out_stride);
         __syncthreads();
     }
-    if (COW && blockIdx.x == 0) {
+    if (COW && blockIdx.x == 0 && ran) {
         // slot 0 is also the engine's live tableau: leave it whole (the last node this workgroup evaluated), as the other
-        // batch shapes do -- its stale rows come back from the saved root.  The other slots keep theirs until someone restores them.
+        // batch shapes do -- the rows earlier nodes wrote and the last one did not come back from the saved root.  The other
+        // slots keep theirs (flagged dirty) until someone restores them.
         const int H = s.st[0].s_H, ld2 = s.ld / 2, lane = threadIdx.x & 63;
         uint8_t* dirty = s.dirty;
         const double2* src = reinterpret_cast<const double2*>(snap.A);
         double2* dst = reinterpret_cast<double2*>(s.A);
         for (int r = threadIdx.x >> 6; r < H; r += blockDim.x >> 6)
-            if (dirty[r] == 2) {
+            if (dirty[r] != 0 && !L.cur[r]) {
                 wglds_copy_row(dst + (long long)r * ld2, src + (long long)r * ld2, ld2, lane);
                 if (lane == 0) dirty[r] = 0;
             }

@@ -29,7 +29,7 @@ for s in $steps; do
     stress) for i in 1 2 3; do timeout 120 python tools/wglds_timing.py rate; done > $out/stress.log 2>&1 < /dev/null; echo "stress rc=$?"; grep -c relaxations $out/stress.log; tail -3 $out/stress.log ;;
     sweep) timeout 600 node tools/mincells_sweep.js > $out/mincells_sweep.md 2> $out/mincells_sweep.err < /dev/null; echo "sweep rc=$?"; cat $out/mincells_sweep.md ;;
     dense) (timeout 300 python tools/dense_lp_times.py; JSLP_HIP_LIBRARY=build/libjslp_hip_nodefer.so timeout 300 python tools/dense_lp_times.py) > $out/dense_lp_times.log 2>&1 < /dev/null; echo "dense rc=$?"; cat $out/dense_lp_times.log ;;
-    zc) (for t in 0 1; do echo "node_cow=$t"; JSLP_NODE_COW=$t timeout 120 python tools/wglds_timing.py rate; done
+    zc) (ROUNDS=3 timeout 200 python tools/batch_modes.py | tail -8
          JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py batch) > $out/zero_copy.log 2>&1 < /dev/null; echo "zc rc=$?"; grep -v micro $out/zero_copy.log ;;
     pmcrelax) for cow in 0 1; do for c in fetch write; do
            C=FETCH_SIZE; [ $c = write ] && C=WRITE_SIZE
