@@ -35,8 +35,14 @@
 #ifndef JSLP_RES_PRICE_DPP
 #define JSLP_RES_PRICE_DPP 0 // 1: pricing with one DPP (batch, key, index) reduction per wave and one barrier -- MEASURED SLOWER (7.5 k against 3.8 k cycles per pivot, r02_w: all 16 waves pay the wave stage and the 16-entry scan; the three LDS-atomic rounds keep 15 of them parked)
 #endif
+#ifndef JSLP_RES_ALLGATHER
+#define JSLP_RES_ALLGATHER 1  // phase 2 without unrestricted variables and with the cycle check off: EVERY workgroup gathers the <= 256 summaries itself (coalesced: thread t polls granules t, t + blockDim, ...; the payloads meet in LDS) and takes the leader's decision redundantly -- the decision broadcast and its poll (one fabric hop) disappear
+#endif
+#ifndef JSLP_RES_DPP_DECIDE_LEADER
+#define JSLP_RES_DPP_DECIDE_LEADER 0  // 1: the same in the leader's four sweep waves of the gather-by-leader protocol -- WRONG for phase 1, whose summaries are negative RHS values: the DPP reduction orders candidates by their BITS, which is the numeric order of positive doubles only (that, not the compiler, was the "release build loses the pivot sequence" of r02_w)
+#endif
 #ifndef JSLP_RES_DPP_DECIDE
-#define JSLP_RES_DPP_DECIDE 0  // 1: the leader's four sweep waves reduce their summaries with DPP exchanges instead of 18 ds_bpermute shuffles (-700 cycles per pivot in the instrumented build, r02_w) -- NOT USABLE: the release build of the same source loses the pivot sequence (cause not found)
+#define JSLP_RES_DPP_DECIDE 3  // all-gather protocol (phase 2: quotients > 0): bit 0 = (quotient, row) minimum, bit 1 = first degenerate row, by DPP exchanges + readlanes instead of ds_bpermute shuffles (120.9 k vs 119.2 k pivots/s, r02_x)
 #endif
 #ifndef JSLP_RES_PRICE_2B
 #define JSLP_RES_PRICE_2B 0  // 1: pricing in two barriers (batch by ballot + LDS atomic, then a DPP (key, column) reduction in the one or two waves holding the winning batch) -- MEASURED NO FASTER (3.9-4.2 k against 3.2-3.6 k cycles, r02_w: the dependent DPP chain of one wave is longer than two LDS-atomic rounds) and NOT validated in the release build
@@ -83,6 +89,7 @@ struct RSmem {
     int32_t ok;
     int32_t okx[2];      // step E's verdict, alternating (one barrier per use)
     double nv[JSLP_R_MAXROWS + 1];  // -k / quot of my rows' pivot-column entries (and of the cost row's), one lane each
+    unsigned gsum[JSLP_F_MAXG * JSLP_R_GRAN];  // all-gather by every workgroup: the payloads of everybody's summary granules
     int32_t pw_b[16], pw_i[16];  // pricing: per wave (first batch, key of the best value in it, first column with it)
     u64_t pw_k[16];
     int32_t pw_n[2];     // two-barrier pricing: waves that hold a candidate of the winning batch, alternating by call
@@ -656,7 +663,9 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         bool swept = true;
         SweptCand sc;
         sc.qbits = ~0ull; sc.kq = 0; sc.kdeg = 0; sc.r = 0; sc.rdeg = 0x7fffffff;
-        const bool sweeper = b == 0 && tid >= sweep0;
+        // all-gather by every workgroup (JSLP_RES_ALLGATHER): no leader, no decision broadcast
+        const bool allg = PHASE == 2 && !UNR && !DEFER && JSLP_RES_ALLGATHER != 0 && !c.check_cycles;
+        const bool sweeper = b == 0 && !allg && tid >= sweep0;
         // ... and the rest of my rows where it costs nobody anything: the leader's other waves while its sweepers gather, every
         // other workgroup after its row flag is up (while it waits for the decision), the sweepers after they have broadcast it
         auto pend_apply_rest = [&]() {
@@ -665,7 +674,33 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                 if (r_begin + i != pubrow) pend_apply_row(i);
         };
         if (DEFER && R.pending && b == 0 && !sweeper) pend_apply_rest();
-        if (sweeper) swept = sweep_summary(f, par, tag, tid - sweep0, sc);
+        if (allg) {
+            // thread t polls granules t, t + blockDim, ... of the [G][8] array (adjacent lanes, adjacent granules: 64-byte requests)
+            // until every tag matches; the payloads go to LDS, where lane w of the last four waves picks workgroup w's seven up
+            const int NG = f.G * JSLP_R_GRAN;
+            u64_t x[4];
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int g = tid + q * (int)blockDim.x;
+                    const bool used = g < NG && (g & (JSLP_R_GRAN - 1)) != JSLP_R_GRAN - 1;
+                    x[q] = used ? AG_LOAD(f.gran[par] + g) : ((u64_t)tag << 32);
+                    ok = ok && (unsigned)(x[q] >> 32) == tag;
+                }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { swept = false; break; }
+                if (spins > f.spin_limit) { if ((tid & 63) == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int g = tid + q * (int)blockDim.x;
+                if (g < JSLP_F_MAXG * JSLP_R_GRAN) sm.gsum[g] = (unsigned)x[q];
+            }
+        } else if (sweeper) swept = sweep_summary(f, par, tag, tid - sweep0, sc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { end_code = 5; break; }
@@ -675,10 +710,89 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         // ---- D: the leader decides (winner, unboundedness, cycle check) and broadcasts three tagged granules -----------
         int pr = 0, stop = 0;
         double quot = 0.0;
-        if (b == 0) {
+        if (allg) {
+            // every workgroup decides for itself, out of the LDS copy of everybody's summary: ONE wave (lane l folds workgroups
+            // l, l + 64, l + 128, l + 192, then six shuffle stages on the keys), one barrier, and the winner's pivot-column
+            // entry is read back from the same LDS copy by everybody
+            if (tid >= (int)blockDim.x - 64) {
+                const int l = tid & 63;
+                u64_t q = ~0ull;
+                int r = 0, rdeg = 0x7fffffff;
+#pragma unroll
+                for (int k4 = 0; k4 < JSLP_F_MAXG / 64; k4++) {
+                    const int wg = l + 64 * k4;
+                    if (wg < f.G) {
+                        const unsigned* gq = sm.gsum + wg * JSLP_R_GRAN;
+                        const unsigned rr = gq[6];
+                        const int r2 = (int)(rr & 0xffffu);
+                        const unsigned rd = rr >> 16;
+                        const int rd2 = rd == 0xffffu ? 0x7fffffff : (int)rd;
+                        const u64_t q2 = r2 != 0 ? ((u64_t)gq[0] | ((u64_t)gq[1] << 32)) : ~0ull;
+                        const double d2 = __longlong_as_double((long long)q2), d1 = __longlong_as_double((long long)q);
+                        const bool take = r2 != 0 && (r == 0 || d2 < d1 || (d2 == d1 && r2 < r));
+                        q = take ? q2 : q;
+                        r = take ? r2 : r;
+                        rdeg = rd2 < rdeg ? rd2 : rdeg;
+                    }
+                }
+                if (JSLP_RES_DPP_DECIDE) {
+                    // DPP exchanges inside the 16-lane rows + readlanes across them instead of 24 ds_bpermute round trips
+                    // (positive doubles order like their bits; ~0 = no candidate)
+                    if (JSLP_RES_DPP_DECIDE & 1) {
+                        KI x;
+                        x.k = q; x.i = r != 0 ? r : 0x7fffffff; x.pad = 0;
+                        x = ki_wave_min(x);
+                        r = x.k == ~0ull ? 0 : x.i;
+                    } else {
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) {
+                            const u64_t q2 = __shfl_xor(q, off, 64);
+                            const int r2 = __shfl_xor(r, off, 64);
+                            const double d2 = __longlong_as_double((long long)q2), d1 = __longlong_as_double((long long)q);
+                            const bool take = r2 != 0 && (r == 0 || d2 < d1 || (d2 == d1 && r2 < r));
+                            q = take ? q2 : q;
+                            r = take ? r2 : r;
+                        }
+                    }
+                    if (JSLP_RES_DPP_DECIDE & 2) {
+                        rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0xB1, 0xf, 0xf, false));
+                        rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x4E, 0xf, 0xf, false));
+                        rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x141, 0xf, 0xf, false));
+                        rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x140, 0xf, 0xf, false));
+                        rdeg = min(min(__builtin_amdgcn_readlane(rdeg, 0), __builtin_amdgcn_readlane(rdeg, 16)),
+                                   min(__builtin_amdgcn_readlane(rdeg, 32), __builtin_amdgcn_readlane(rdeg, 48)));
+                    } else {
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) { const int rd2 = __shfl_xor(rdeg, off, 64); rdeg = rd2 < rdeg ? rd2 : rdeg; }
+                    }
+                } else {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const u64_t q2 = __shfl_xor(q, off, 64);
+                    const int r2 = __shfl_xor(r, off, 64), rd2 = __shfl_xor(rdeg, off, 64);
+                    const double d2 = __longlong_as_double((long long)q2), d1 = __longlong_as_double((long long)q);
+                    const bool take = r2 != 0 && (r == 0 || d2 < d1 || (d2 == d1 && r2 < r));
+                    q = take ? q2 : q;
+                    r = take ? r2 : r;
+                    rdeg = rd2 < rdeg ? rd2 : rdeg;
+                }
+                }
+                if (l == 0) { sm.w_r[0] = r; sm.w_rdeg[0] = rdeg; }
+            }
+            __syncthreads();
+            const int wr = sm.w_r[0], wrdeg = sm.w_rdeg[0];
+            if (wrdeg != 0x7fffffff) pr = wrdeg;
+            else if (wr != 0) pr = wr;
+            else stop = 3;  // unbounded (simplex.ts:298-303)
+            if (!stop) {  // the owner of row pr published both of its entries
+                const unsigned* gq = sm.gsum + (pr / f.rpb) * JSLP_R_GRAN;
+                const u64_t kb = wrdeg != 0x7fffffff ? ((u64_t)gq[4] | ((u64_t)gq[5] << 32)) : ((u64_t)gq[2] | ((u64_t)gq[3] << 32));
+                quot = __longlong_as_double((long long)kb);
+            }
+        } else if (b == 0) {
             // (min rdeg) else (min q, then min r): each sweep wave reduces its 64 summaries with shuffles on the keys
             // only, the four wave results meet in LDS, the lane that holds the winner supplies its pivot-column entry
-            if (sweeper && JSLP_RES_DPP_DECIDE) {
+            if (sweeper && JSLP_RES_DPP_DECIDE_LEADER) {
                 // DPP exchanges inside the 16-lane rows + readlanes across them (no ds_bpermute round trips): smallest quotient
                 // (positive doubles order like their bits), first row on ties; and the first degenerate row
                 KI x;
