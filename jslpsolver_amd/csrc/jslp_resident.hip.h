@@ -36,7 +36,7 @@
 #define JSLP_RES_PRICE_DPP 0 // 1: pricing with one DPP (batch, key, index) reduction per wave and one barrier -- MEASURED SLOWER (7.5 k against 3.8 k cycles per pivot, r02_w: all 16 waves pay the wave stage and the 16-entry scan; the three LDS-atomic rounds keep 15 of them parked)
 #endif
 #ifndef JSLP_RES_ALLGATHER
-#define JSLP_RES_ALLGATHER 1  // phase 2 without unrestricted variables and with the cycle check off: EVERY workgroup gathers the <= 256 summaries itself (coalesced: thread t polls granules t, t + blockDim, ...; the payloads meet in LDS) and takes the leader's decision redundantly -- the decision broadcast and its poll (one fabric hop) disappear
+#define JSLP_RES_ALLGATHER 1  // no unrestricted variables, cycle check off (both phases): EVERY workgroup gathers the <= 256 summaries itself (coalesced: thread t polls granules t, t + blockDim, ...; the payloads meet in LDS) and takes the leader's decision redundantly -- the decision broadcast and its poll (one fabric hop) disappear
 #endif
 #ifndef JSLP_RES_DPP_DECIDE_LEADER
 #define JSLP_RES_DPP_DECIDE_LEADER 0  // 1: the same in the leader's four sweep waves of the gather-by-leader protocol -- WRONG for phase 1, whose summaries are negative RHS values: the DPP reduction orders candidates by their BITS, which is the numeric order of positive doubles only (that, not the compiler, was the "release build loses the pivot sequence" of r02_w)
@@ -664,7 +664,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         SweptCand sc;
         sc.qbits = ~0ull; sc.kq = 0; sc.kdeg = 0; sc.r = 0; sc.rdeg = 0x7fffffff;
         // all-gather by every workgroup (JSLP_RES_ALLGATHER): no leader, no decision broadcast
-        const bool allg = PHASE == 2 && !UNR && !DEFER && JSLP_RES_ALLGATHER != 0 && !c.check_cycles;
+        const bool allg = !UNR && !DEFER && JSLP_RES_ALLGATHER != 0 && !c.check_cycles;
         const bool sweeper = b == 0 && !allg && tid >= sweep0;
         // ... and the rest of my rows where it costs nobody anything: the leader's other waves while its sweepers gather, every
         // other workgroup after its row flag is up (while it waits for the decision), the sweepers after they have broadcast it
@@ -739,10 +739,10 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                     // DPP exchanges inside the 16-lane rows + readlanes across them instead of 24 ds_bpermute round trips
                     // (positive doubles order like their bits; ~0 = no candidate)
                     if (JSLP_RES_DPP_DECIDE & 1) {
-                        KI x;
-                        x.k = q; x.i = r != 0 ? r : 0x7fffffff; x.pad = 0;
+                        KI x;  // (key_asc: the unsigned order of the keys is the numeric order -- phase 1's candidates are negative)
+                        x.k = r != 0 ? key_asc(__longlong_as_double((long long)q)) : KI_NONE_KEY; x.i = r != 0 ? r : 0x7fffffff; x.pad = 0;
                         x = ki_wave_min(x);
-                        r = x.k == ~0ull ? 0 : x.i;
+                        r = x.k == KI_NONE_KEY ? 0 : x.i;
                     } else {
 #pragma unroll
                         for (int off = 32; off > 0; off >>= 1) {
@@ -783,8 +783,8 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             const int wr = sm.w_r[0], wrdeg = sm.w_rdeg[0];
             if (wrdeg != 0x7fffffff) pr = wrdeg;
             else if (wr != 0) pr = wr;
-            else stop = 3;  // unbounded (simplex.ts:298-303)
-            if (!stop) {  // the owner of row pr published both of its entries
+            else stop = phase == 1 ? 4 : 3;  // phase 1: no violated row -> feasible (:51-54); phase 2: unbounded (:298-303)
+            if (!stop) {  // the owner of row pr published both of its entries (phase 1 finds quot later, with the entering column)
                 const unsigned* gq = sm.gsum + (pr / f.rpb) * JSLP_R_GRAN;
                 const u64_t kb = wrdeg != 0x7fffffff ? ((u64_t)gq[4] | ((u64_t)gq[5] << 32)) : ((u64_t)gq[2] | ((u64_t)gq[3] << 32));
                 quot = __longlong_as_double((long long)kb);
