@@ -38,6 +38,9 @@
 #ifndef JSLP_RES_ALLGATHER
 #define JSLP_RES_ALLGATHER 1  // no unrestricted variables, cycle check off (both phases): EVERY workgroup gathers the <= 256 summaries itself (coalesced: thread t polls granules t, t + blockDim, ...; the payloads meet in LDS) and takes the leader's decision redundantly -- the decision broadcast and its poll (one fabric hop) disappear
 #endif
+#ifndef JSLP_RES_EARLY_ROWFLAG
+#define JSLP_RES_EARLY_ROWFLAG 0  // 1: all-gather protocol: raise the row flag as soon as the row stores have drained, before the gather -- MEASURED NO FASTER (r02_x: step E0 is one fabric round trip for the flag + row loads whenever the flag went up)
+#endif
 #ifndef JSLP_RES_DPP_DECIDE_LEADER
 #define JSLP_RES_DPP_DECIDE_LEADER 0  // 1: the same in the leader's four sweep waves of the gather-by-leader protocol -- WRONG for phase 1, whose summaries are negative RHS values: the DPP reduction orders candidates by their BITS, which is the numeric order of positive doubles only (that, not the compiler, was the "release build loses the pivot sequence" of r02_w)
 #endif
@@ -675,6 +678,13 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         };
         if (DEFER && R.pending && b == 0 && !sweeper) pend_apply_rest();
         if (allg) {
+            // the row flag first: it only has to follow this workgroup's row stores, and whoever needs the row reads the flag
+            // right after the decision -- raised behind the gather below it came ~4 k cycles later than it could
+            if (JSLP_RES_EARLY_ROWFLAG) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);
+            }
             // thread t polls granules t, t + blockDim, ... of the [G][8] array (adjacent lanes, adjacent granules: 64-byte requests)
             // until every tag matches; the payloads go to LDS, where lane w of the last four waves picks workgroup w's seven up
             const int NG = f.G * JSLP_R_GRAN;
@@ -704,7 +714,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { end_code = 5; break; }
-        if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: row is visible
+        if (tid == 0 && pubrow != 0 && !(allg && JSLP_RES_EARLY_ROWFLAG)) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: row is visible
         if (DEFER && R.pending && b != 0) pend_apply_rest();
         RT_MARK(2);
         // ---- D: the leader decides (winner, unboundedness, cycle check) and broadcasts three tagged granules -----------
