@@ -918,6 +918,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             rc.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
             rc.G = (H + rc.rpb - 1) / rc.rpb;
             rc.H = H;
+            rc.n_idx = e->n_idx;
             rc.iters_cap = cap;
             rc.spin_limit = e->spin_limit;
             rc.test_abort_epoch = e->test_abort_epoch;

@@ -23,6 +23,8 @@
 #define JSLP_R_MAXROWS 16   // ... of the tall geometry (512 lanes x 4 columns x 16 rows: H <= 16 * 256)
 #define JSLP_R_GRAN 8        // 8-byte granules per workgroup summary (7 used)
 #define JSLP_R_LDMAX 4096    // widest padded row any geometry takes (512 lanes x 8 columns)
+#define JSLP_R_LUNR 8192     // variable indexes whose unrestricted flag fits the LDS copy (more: gather-by-leader protocol)
+#define JSLP_R_LHIST 10240   // cycle-check history entries kept in LDS (80 KB)
 #ifndef JSLP_RES_DEFER
 #define JSLP_RES_DEFER 0     // 1: phase 2 keeps a pivot's row update pending until the next summary is out -- MEASURED SLOWER in both placements (before the drain: 96.0 k, behind the sweep / decision wait: 89.9 k, against 102.5 k pivots/s, r02_r / r02_s): the wait it was meant to fill is not idle enough
 #endif
@@ -65,6 +67,7 @@ struct ResCtx {
     u64_t* verdict[2];    // phase 1 only: leader's cycle-check verdict {tag | stop} (the entering column is known late there)
     u64_t* gor[2];        // [G] rare slow path: tagged per-workgroup flags for a chip-wide OR
     int32_t G, rpb, H;
+    int32_t n_idx;             // variable indexes in use (the LDS copy of the unrestricted flags covers JSLP_R_LUNR of them)
     int32_t iters_cap;
     uint32_t spin_limit;       // bound of every poll loop (polls, not cycles); reaching it raises the device-wide abort flag
     int32_t test_abort_epoch;  // tests only (JSLP_TEST_RESIDENT_ABORT): the last workgroup aborts the hand-off at this pivot; -1 = never
@@ -109,8 +112,16 @@ struct RSmem {
     double colq[2][JSLP_R_MAXROWS];  // deferred row update: pivot-column entries of my rows, by pivot parity
     // pricing by ONE wave (price_row_w0): every lane mirrors its columns of the cost row here after each update
     double p_k0;                  // signed reduced cost of the entering column
-    double r0[JSLP_R_LDMAX];
-    uint8_t unrc[JSLP_R_LDMAX];   // UNR builds: the column's variable is unrestricted
+    double r0[JSLP_RES_PRICE_W0 ? JSLP_R_LDMAX : 2];
+    uint8_t unrc[JSLP_RES_PRICE_W0 ? JSLP_R_LDMAX : 2];   // UNR builds: the column's variable is unrestricted
+    // All-gather protocol: what only workgroup 0 knows in the gather-by-leader protocol lives in EVERY workgroup's LDS -- the
+    // row / column maps (swapped at every pivot like the global ones), the unrestricted flag of every variable index, and the
+    // cycle-check history (the first JSLP_R_LHIST entries; a longer solve continues with the leader protocol, whose check
+    // reads the global history workgroup 0 has been mirroring all along)
+    int32_t lvibr[JSLP_R_MAXROWS * JSLP_F_MAXG];
+    int32_t lvibc[JSLP_R_LDMAX];
+    uint8_t lunr[JSLP_R_LUNR];
+    int2 lhist[JSLP_R_LHIST];
 };
 
 // The leader's last FOUR waves gather every workgroup's summary of this epoch (all-gather with the data as the flag,
@@ -667,7 +678,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         SweptCand sc;
         sc.qbits = ~0ull; sc.kq = 0; sc.kdeg = 0; sc.r = 0; sc.rdeg = 0x7fffffff;
         // all-gather by every workgroup (JSLP_RES_ALLGATHER): no leader, no decision broadcast
-        const bool allg = !UNR && !DEFER && JSLP_RES_ALLGATHER != 0 && !c.check_cycles;
+        const bool allg = !DEFER && JSLP_RES_ALLGATHER != 0 && (!UNR || f.n_idx <= JSLP_R_LUNR) && (!c.check_cycles || (hist_n < JSLP_R_LHIST && hist_n < c.hist_cap));
         const bool sweeper = b == 0 && !allg && tid >= sweep0;
         // ... and the rest of my rows where it costs nobody anything: the leader's other waves while its sweepers gather, every
         // other workgroup after its row flag is up (while it waits for the decision), the sweepers after they have broadcast it
@@ -799,6 +810,18 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                 const u64_t kb = wrdeg != 0x7fffffff ? ((u64_t)gq[4] | ((u64_t)gq[5] << 32)) : ((u64_t)gq[2] | ((u64_t)gq[3] << 32));
                 quot = __longlong_as_double((long long)kb);
             }
+            if (!stop && phase == 2 && c.check_cycles) {  // simplex.ts:305-320 by every workgroup, on its own LDS history
+                if (tid == 0) {
+                    const int2 pair = make_int2(sm.lvibr[pr], sm.lvibc[pc]);
+                    sm.lhist[hist_n] = pair;
+                    if (b == 0) c.hist[hist_n] = pair;  // the host's cycle message, and the leader protocol's history should this one outgrow LDS
+                }
+                __syncthreads();
+                hist_n += 1;
+                if (suffix_is_square(sm.lhist, hist_n, sm.f.red)) stop = 1;
+            }
+            if (UNR && !stop && tid == 0) sm.dec[0] = sm.lunr[sm.lvibr[pr]] ? (1u << 24) : 0u;  // "the leaving variable is unrestricted"
+            if (UNR) __syncthreads();
         } else if (b == 0) {
             // (min rdeg) else (min q, then min r): each sweep wave reduces its 64 summaries with shuffles on the keys
             // only, the four wave results meet in LDS, the lane that holds the winner supplies its pivot-column entry
@@ -993,7 +1016,16 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             __syncthreads();
             quot = sm.xq[0];
             k0 = sm.xq[1];
-            if (c.check_cycles) {  // simplex.ts:78-93: only now is the (leaving, entering) pair known
+            if (c.check_cycles && allg) {  // simplex.ts:78-93 by every workgroup, on its own LDS history
+                if (tid == 0) {
+                    const int2 pair = make_int2(sm.lvibr[pr], sm.lvibc[pc]);
+                    sm.lhist[hist_n] = pair;
+                    if (b == 0) c.hist[hist_n] = pair;
+                }
+                __syncthreads();
+                hist_n += 1;
+                if (suffix_is_square(sm.lhist, hist_n, sm.f.red)) { end_code = 3; break; }
+            } else if (c.check_cycles) {  // simplex.ts:78-93: only now is the (leaving, entering) pair known
                 if (b == 0) {
                     int cstop = 0;
                     if (hist_n >= c.hist_cap) {
@@ -1120,6 +1152,11 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
 #pragma unroll
             for (int i = 0; i < ROWS; i++) sm.rhs[i] = a[i][0];
         }
+        if (tid == 0) {  // every workgroup's LDS maps (simplex.ts:339-349)
+            const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc];
+            sm.lvibr[pr] = entering;
+            sm.lvibc[pc] = leaving;
+        }
         // workgroup 0 commits the basis change (simplex.ts:339-349)
         if (b == 0 && tid == 0) {
             const int leaving = c.vibr[pr], entering = c.vibc[pc];
@@ -1136,7 +1173,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             for (int j = 0; j < CPT; j++)
                 if (pc == c0 + j) {
                     R.unr = (R.unr & ~(1u << j)) | ((leaving_unr ? 1u : 0u) << j);
-                    sm.unrc[pc] = leaving_unr ? 1 : 0;
+                    if (JSLP_RES_PRICE_W0) sm.unrc[pc] = leaving_unr ? 1 : 0;
                 }
         }
         trace_n += 1;
@@ -1164,6 +1201,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
 template <int THREADS, int CPT, int ROWS, bool UNR>
 __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     static_assert(ROWS <= JSLP_R_MAXROWS, "RSmem holds one entry per row of the workgroup");
+    static_assert(sizeof(RSmem) <= 160 * 1024, "one workgroup per CU: all of the CU's LDS, no more");
     __shared__ RSmem sm;
     ResRegs<CPT, ROWS> R;
 #ifdef JSLP_DEBUG_RESIDENT
@@ -1229,6 +1267,11 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
         __syncthreads();
     }
 #endif
+    // every workgroup's own copy of the maps (and of the unrestricted flags): see RSmem
+    for (int r = tid; r < f.H; r += (int)blockDim.x) sm.lvibr[r] = c.vibr[r];
+    for (int col = tid; col < c.W; col += (int)blockDim.x) sm.lvibc[col] = c.vibc[col];
+    if (UNR)
+        for (int v = tid; v < f.n_idx && v < JSLP_R_LUNR; v += (int)blockDim.x) sm.lunr[v] = c.unr[v];
     if (tid == 0) { reset_reductions(sm); sm.pw_n[0] = 0; sm.pw_n[1] = 0; }
     __syncthreads();
     // pricing batch of my columns (simplex.ts:118-127): fixed for the whole solve
