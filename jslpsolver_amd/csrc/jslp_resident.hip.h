@@ -40,6 +40,9 @@
 #ifndef JSLP_RES_ALLGATHER
 #define JSLP_RES_ALLGATHER 1  // no unrestricted variables, cycle check off (both phases): EVERY workgroup gathers the <= 256 summaries itself (coalesced: thread t polls granules t, t + blockDim, ...; the payloads meet in LDS) and takes the leader's decision redundantly -- the decision broadcast and its poll (one fabric hop) disappear
 #endif
+#ifndef JSLP_RES_PIPE_PRICE
+#define JSLP_RES_PIPE_PRICE 0  // 1: phase 2: the pricing rounds of the next pivot interleaved with thirds of the row update -- MEASURED NO FASTER (F + G 7.1 k against 6.4-6.9 k cycles, 120.1 k against 123.4 k pivots/s, r02_x): the rounds are not idle latency the row update could fill
+#endif
 #ifndef JSLP_RES_EARLY_ROWFLAG
 #define JSLP_RES_EARLY_ROWFLAG 0  // 1: all-gather protocol: raise the row flag as soon as the row stores have drained, before the gather -- MEASURED NO FASTER (r02_x: step E0 is one fabric round trip for the flag + row loads whenever the flag went up)
 #endif
@@ -1121,54 +1124,97 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             for (int j = 0; j < CPT; j++) R.pp[j] = p[j];
             R.pquot = quot; R.ppc = pc; R.ppr = pr; R.ppar = par; R.pending = 1;
         }
-#pragma unroll
-        for (int i = 0; i < (DEFER ? 0 : ROWS); i++) {
-            const int r = r_begin + i;
-            if (r >= r_end) continue;
-            if (r == 0) {  // workgroup 0 owns the cost row
-#pragma unroll
-                for (int j = 0; j < CPT; j++) a[i][j] = r0[j];
-                continue;
-            }
-            if (r == pr) {
-#pragma unroll
-                for (int j = 0; j < CPT; j++) a[i][j] = p[j];
-                continue;
-            }
-            const double ki = sm.col[i];  // pivot-column entry of row i (still in LDS from step A)
-            if (nonzero16(ki)) {
+        const int pc_now = pc;  // (the pipelined pricing below names the NEXT entering column while rows are still being updated)
+        const bool has_pc_now = has_pc;
+        // (a macro, not a lambda: through a closure the register arrays a[][] / p[] / nz[] end up in scratch)
+#define JSLP_RES_UPDATE_ROWS(LO, HI)                                                                        \
+        _Pragma("unroll") for (int i = (LO); i < (DEFER ? 0 : (HI)); i++) {                                 \
+            const int r = r_begin + i;                                                                      \
+            if (r >= r_end) continue;                                                                       \
+            if (r == 0) { /* workgroup 0 owns the cost row */                                               \
+                _Pragma("unroll") for (int j = 0; j < CPT; j++) a[i][j] = r0[j];                            \
+                continue;                                                                                   \
+            }                                                                                               \
+            if (r == pr) {                                                                                  \
+                _Pragma("unroll") for (int j = 0; j < CPT; j++) a[i][j] = p[j];                             \
+                continue;                                                                                   \
+            }                                                                                               \
+            const double ki = sm.col[i]; /* pivot-column entry of row i (still in LDS from step A) */       \
+            if (nonzero16(ki)) {                                                                            \
+                _Pragma("unroll") for (int j = 0; j < CPT; j++)                                             \
+                    if (nz[j]) a[i][j] = eliminate(a[i][j], ki, p[j]);                                      \
+                if (has_pc_now) {                                                                           \
+                    const double nv = PARDIV ? sm.nv[i] : -ki / quot;                                       \
+                    _Pragma("unroll") for (int j = 0; j < CPT; j++)                                         \
+                        if (pc_now == c0 + j) a[i][j] = nv;                                                 \
+                }                                                                                           \
+            }                                                                                               \
+        }
+        // Pricing of the NEXT pivot (step G) pipelined into the row update: its three LDS-atomic rounds are latency (an atomic,
+        // a barrier, a read back), the row update is instruction issue of all 16 waves -- a third of the rows goes between two
+        // rounds, so the waves work while the atomics fly.  Only the cost row (updated above) and the flags of the entering
+        // column (updated first, below) are needed to price.
+        constexpr bool PIPE = PHASE == 2 && !DEFER && JSLP_RES_PIPE_PRICE != 0 && !JSLP_RES_PRICE_W0 && !JSLP_RES_PRICE_DPP && !JSLP_RES_PRICE_2B &&
+                              !JSLP_RES_ONE_LANE_SUMMARY;
+        double g_bv = precision;
+        int g_bi = 0, g_bb = 0;
+        if (PIPE) {
+            if (UNR && has_pc_now) {
 #pragma unroll
                 for (int j = 0; j < CPT; j++)
-                    if (nz[j]) a[i][j] = eliminate(a[i][j], ki, p[j]);
-                if (has_pc) {
-                    const double nv = PARDIV ? sm.nv[i] : -ki / quot;
-#pragma unroll
-                    for (int j = 0; j < CPT; j++)
-                        if (pc == c0 + j) a[i][j] = nv;
-                }
+                    if (pc_now == c0 + j) R.unr = (R.unr & ~(1u << j)) | ((leaving_unr ? 1u : 0u) << j);
             }
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {  // my columns in order: earlier batch first, bigger value inside a batch, first index on ties
+                const int col = c0 + j;
+                const double val = (UNR && ((R.unr >> j) & 1u) && r0[j] < 0) ? -r0[j] : r0[j];
+                const bool ok = col >= 1 && col < W && val > precision;
+                const bool take = ok && (g_bi == 0 || pb[j] < g_bb || (pb[j] == g_bb && val > g_bv));
+                g_bv = take ? val : g_bv;
+                g_bi = take ? col : g_bi;
+                g_bb = take ? pb[j] : g_bb;
+            }
+            const unsigned long long m = __ballot(g_bi != 0);
+            if (m != 0ull) {  // batch ids grow with the lane index: the wave's earliest batch is that of its first candidate lane
+                const int first = __ffsll((long long)m) - 1;
+                const int wave_b = __builtin_amdgcn_readlane(g_bb, first);
+                if ((tid & 63) == 0) atomicMin(&sm.p_batch, wave_b);
+            }
+            JSLP_RES_UPDATE_ROWS(0, ROWS / 3)
+            __syncthreads();
+            const int wb = sm.p_batch;
+            const bool mine = wb != 0x7fffffff && g_bi != 0 && g_bb == wb;
+            const u64_t bits = (u64_t)__double_as_longlong(g_bv);
+            if (mine) atomicMax(&sm.p_val, bits);
+            JSLP_RES_UPDATE_ROWS(ROWS / 3, 2 * ROWS / 3)
+            __syncthreads();
+            if (mine && bits == sm.p_val) atomicMin(&sm.p_col, g_bi);
+            JSLP_RES_UPDATE_ROWS(2 * ROWS / 3, ROWS)
+        } else {
+            JSLP_RES_UPDATE_ROWS(0, ROWS)
         }
+#undef JSLP_RES_UPDATE_ROWS
         if (FASTA && tid == 0) {  // column 0 of my (updated) rows, for the lane that will hold the next pivot column
 #pragma unroll
             for (int i = 0; i < ROWS; i++) sm.rhs[i] = a[i][0];
         }
         if (tid == 0) {  // every workgroup's LDS maps (simplex.ts:339-349)
-            const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc];
+            const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc_now];
             sm.lvibr[pr] = entering;
-            sm.lvibc[pc] = leaving;
+            sm.lvibc[pc_now] = leaving;
         }
         // workgroup 0 commits the basis change (simplex.ts:339-349)
         if (b == 0 && tid == 0) {
-            const int leaving = c.vibr[pr], entering = c.vibc[pc];
+            const int leaving = c.vibr[pr], entering = c.vibc[pc_now];
             c.vibr[pr] = entering;
-            c.vibc[pc] = leaving;
+            c.vibc[pc_now] = leaving;
             c.rbv[entering] = pr;
             c.rbv[leaving] = -1;
             c.cbv[entering] = -1;
-            c.cbv[leaving] = pc;
-            if (trace_n < c.trace_cap) c.trace[trace_n] = make_int2(pr, pc);
+            c.cbv[leaving] = pc_now;
+            if (trace_n < c.trace_cap) c.trace[trace_n] = make_int2(pr, pc_now);
         }
-        if (UNR && has_pc) {
+        if (UNR && has_pc && !PIPE) {
 #pragma unroll
             for (int j = 0; j < CPT; j++)
                 if (pc == c0 + j) {
@@ -1181,7 +1227,27 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         epoch += 1;
         RT_MARK(6);
         // ---- G: phase 2: price the new cost row -> entering column of the next pivot -----------------------------------
-        if (phase == 2) {
+        if (PIPE) {  // the third round's result
+            __syncthreads();
+            const int wb = sm.p_batch;
+            int pcol = 0;
+            double v = 0.0;
+            if (wb != 0x7fffffff) {
+                pcol = sm.p_col;
+                v = __longlong_as_double((long long)sm.p_val);
+                if (UNR) {  // the lane holding the winner knows the sign of its reduced cost
+#pragma unroll
+                    for (int j = 0; j < CPT; j++)
+                        if (pcol == c0 + j) sm.p_neg = (((R.unr >> j) & 1u) && r0[j] < 0) ? 1 : 0;
+                    __syncthreads();
+                    R.neg = sm.p_neg;
+                    if (R.neg) v = -v;
+                }
+            }
+            k0 = v;
+            pc = pcol;
+            if (pc == 0) end_code = 1;
+        } else if (phase == 2) {
             pc = JSLP_RES_PRICE_W0 ? price_row_w0<UNR>(c, sm, &k0, &R.neg)
                  : (JSLP_RES_PRICE_DPP ? price_row_dpp<CPT, UNR>(r0, c0, pb, c, sm, &k0, R.unr, &R.neg)
                     : (JSLP_RES_PRICE_2B ? price_row_2b<CPT, UNR>(r0, c0, pb, c, sm, &k0, R.unr, &R.neg, R.pq)
