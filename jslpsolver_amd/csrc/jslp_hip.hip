@@ -117,6 +117,7 @@ struct jslp_engine {
     char* arena32 = nullptr;
     // policy
     int force_path = 0;  // 0 auto, 1 workgroup kernel, 2 select+update kernels only, 3 fused phase 2
+    int force_resident = 0;  // JSLP_FORCE_PATH=resident: also the register-resident geometries the default policy leaves to the streaming kernels
     int32_t n_unr = 0;
     int nt = 0;  // JSLP_NT=1: non-temporal hints in the fused kernel
     // fused phase-2 pipeline (ping-pong buffer + per-workgroup candidates)
@@ -415,7 +416,7 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     if (fp && !strcmp(fp, "wg")) e->force_path = 1;
     if (fp && !strcmp(fp, "sp")) e->force_path = 2;
     if (fp && !strcmp(fp, "fused")) { e->force_path = 3; e->no_resident = 1; }
-    if (fp && !strcmp(fp, "resident")) e->force_path = 3;
+    if (fp && !strcmp(fp, "resident")) { e->force_path = 3; e->force_resident = 1; }
     const char* nr = getenv("JSLP_NO_RESIDENT");
     if (nr && nr[0] == '1') e->no_resident = 1;
     const char* rcpt = getenv("JSLP_RES_CPT");
@@ -733,6 +734,13 @@ static int resident_geometry(const jslp_engine* e, int H) {
     if (e->no_resident || e->force_path == 2 || e->n_opt > 0 || e->precision < 1e-15) return 0;  // (see k_pivot_fused for the precision condition)
     const int rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
     if (e->ld <= 2048 && rpb <= 8) return e->res_cpt == 4 ? 2 : 1;
+    // The taller / wider geometries hold 64-72 MB of tableau in the 128 MB of vector registers and spill ~0.5 KB per lane to
+    // scratch (560+ scratch loads in the pivot loop): measured at the end of round 2 they LOSE to the streaming kernels --
+    // 4001 x 2001: 22.3 k pivots/s against 36.4 k through k_pivot_fused; 2501 x 2001: 26.6 k against 48.8 k; 3001 x 3001: 21.5 k
+    // against 23.7 k through k_select + k_update; 2001 x 4001: 20.1 k against 26.1 k (tools/tall_one.py, r02_z).  They stay
+    // built and tested (JSLP_FORCE_PATH=resident, JSLP_RES_WIDE_TALL=1) but the default policy no longer picks them.
+    static const bool wide_tall = getenv("JSLP_RES_WIDE_TALL") && atoi(getenv("JSLP_RES_WIDE_TALL")) != 0;
+    if (!e->force_resident && !wide_tall) return 0;
     if (e->ld <= 2048 && rpb <= 16) return 3;
     if (e->ld <= 3072 && rpb <= 12) return 4;
     if (e->ld <= 4096 && rpb <= 8) return 5;

@@ -12,7 +12,8 @@ from jslpsolver_amd.engine import Tableau
 lib = _capi.load_hip()
 os.environ["JSLP_FORCE_PATH"] = "resident"
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
+n_rows = int(sys.argv[2]) if len(sys.argv) > 2 else n  # (variables, constraints): 2000 4000 = the tall geometry
+m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n_rows)
 t = Tableau(m, vibr, vibc, lib=lib)
 res = t.simplex(check_cycles=False)
 print("pivots", len(t.pivot_trace()))
