@@ -730,6 +730,9 @@ static bool fused_eligible(const jslp_engine* e) {
 //   1: <1024, 2, 8>   ld <= 2048, H <= 2048 (the headline shape)      2: <512, 4, 8>  (JSLP_RES_CPT=4, measured slower)
 //   3: <512, 4, 16>   ld <= 2048, H <= 4096                            4: <512, 6, 12> ld <= 3072, H <= 3072 (3001 x 3001: 72 MB)
 //   5: <512, 8, 8>    ld <= 4096, H <= 2048
+// (256-lane geometries -- ONE wave per SIMD, 512 registers per lane: <256, 8, 8> compiles without a spill -- were measured and
+//  dropped: 72.5 k against 105.7 k pivots/s on a 2001 x 2001 LP, 17.4 k on 4001 x 2001, r02_z: a lone wave per SIMD does not hide
+//  its own instruction latency)
 static int resident_geometry(const jslp_engine* e, int H) {
     if (e->no_resident || e->force_path == 2 || e->n_opt > 0 || e->precision < 1e-15) return 0;  // (see k_pivot_fused for the precision condition)
     const int rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
