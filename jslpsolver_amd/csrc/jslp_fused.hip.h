@@ -12,7 +12,7 @@
 // the updated rows are still in registers prepares pivot t+1: every workgroup re-derives the updated cost row
 // and prices it (same result everywhere), then its rows' ratio-test candidates and pivot-column entries.
 // Workgroup w owns `rpb` consecutive rows; lane pairs own two adjacent columns (16-byte accesses).
-// Preconditions checked by the host: phase 2, no unrestricted variables, ld <= 2048, H <= 64 * 256,
+// Preconditions checked by the host: phase 2, ld <= 4096 (two column tiles per lane), H <= 64 * 256, no optional objectives,
 // precision >= 1e-15 (then the entering cost is never "tiny" and simplex.ts:381-383 always fires).
 // The cycle check is done by workgroup 0 alone; the other workgroups pivot speculatively into the OTHER
 // buffer, which is simply not adopted when the check (or unboundedness) stops the solve.
@@ -45,16 +45,21 @@ struct FusedCtx {
     int32_t G, rpb;
     int32_t H;   // height is fixed during a simplex() call: known to the host, so no load gates the prefetch
     int32_t nt;  // non-temporal hints on the streamed tableau cells
+    // UNR builds: "the variable of column c / of row r is unrestricted", double-buffered like the candidates (every workgroup
+    // reads [launch & 1], workgroup 0 writes [(launch + 1) & 1]): the maps themselves are swapped by workgroup 0 at the END of a
+    // launch, so another workgroup reading them mid-launch could see either side of the swap
+    uint8_t* ucol[2];
+    uint8_t* urow[2];
 };
 
-__device__ __forceinline__ void fcand_consider(FCand& best, int r, double colv, double rhs, double precision) {
+__device__ __forceinline__ void fcand_consider(FCand& best, int r, double colv, double rhs, double precision, int neg = 0) {
     // one row of the ratio test (simplex.ts:276-296), rows visited in ascending order
     if (-precision < colv && colv < precision) return;
     if (colv > 0 && precision > rhs && rhs > -precision) {
         if (r < best.rdeg) { best.rdeg = r; best.kdeg = colv; }
         return;
     }
-    const double quo = rhs / colv;  // isReducedCostNegative is false without unrestricted variables
+    const double quo = neg ? -rhs / colv : rhs / colv;  // neg = isReducedCostNegative (unrestricted entering variable, simplex.ts:282)
     if (quo > precision && best.q > quo) { best.q = quo; best.r = r; best.kq = colv; }
 }
 
@@ -86,6 +91,7 @@ struct FSmem {
     FCand win;
     double col[JSLP_F_RG];
     double rhs[JSLP_F_RG];
+    int neg;  // pricing with unrestricted variables: isReducedCostNegative of the winner
 };
 
 __device__ __forceinline__ FCand fcand_none() {
@@ -108,34 +114,48 @@ __device__ __forceinline__ FCand fcand_block_reduce(FCand x, FSmem& sm) {
     return sm.win;
 }
 
-// pricing of a cost-row pair held in registers (columns c0, c0+1): simplex.ts:118-219 without unrestricted vars
-__device__ __forceinline__ int price_row(double x0, double x1, int c0, const Ctx& c, Smem& sm, unsigned long long* dbg = nullptr) {
-    // the lane's two columns, written out field by field (no struct select: a `Cand e = cand` inside an unrolled
-    // loop was observed to keep the FIRST column's index with the SECOND column's value on gfx950 / ROCm 7.2)
-    const int col1 = c0 + 1;
-    const bool ok0 = c0 >= 1 && c0 < c.W && x0 > c.precision;
-    const bool ok1 = col1 < c.W && x1 > c.precision;   // col1 >= 1 always
-    const int b0 = c.use_partial ? (c0 - 1) / c.batch : 0;
-    const int b1 = c.use_partial ? (col1 - 1) / c.batch : 0;
+// Pricing (simplex.ts:118-219) of the cost-row pairs a lane holds -- NT tiles of 2 x JSLP_F_THREADS columns, the lane's pair of
+// tile t at columns c0 + t * 2 * JSLP_F_THREADS -- reduced over the workgroup.  UNR: bit (2 t + j) of `um` says the variable of
+// that column is unrestricted: it prices with |reduced cost| and hands isReducedCostNegative (*neg) to the ratio test
+// (simplex.ts:164-177, 282).  Returns the entering column (0 = optimal).
+#define JSLP_F_TW (2 * JSLP_F_THREADS)  // columns per tile
+template <int NT, bool UNR>
+__device__ __forceinline__ int price_row(const double2 (&x)[NT], int c0, unsigned um, const Ctx& c, FSmem& sm, int* neg) {
+    // (candidates written out field by field: a struct select inside an unrolled loop was observed to keep the FIRST
+    //  column's index with the SECOND column's value on gfx950 / ROCm 7.2)
     double bv = c.precision;
     int bi = 0, bb = 0;
-    if (ok0) { bv = x0; bi = c0; bb = b0; }
-    // column c0+1 replaces column c0 only when strictly better in (batch asc, value desc); ties keep c0
-    const bool take1 = ok1 && (bi == 0 || b1 < bb || (b1 == bb && x1 > bv));
-    bv = take1 ? x1 : bv;
-    bi = take1 ? col1 : bi;
-    bb = take1 ? b1 : bb;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {  // my columns ascend: earlier batch first, bigger value inside a batch, first index on ties
+            const int col = c0 + t * JSLP_F_TW + j;
+            const double rc = j ? x[t].y : x[t].x;
+            const double val = (UNR && ((um >> (2 * t + j)) & 1u) && rc < 0) ? -rc : rc;
+            const bool ok = col >= 1 && col < c.W && val > c.precision;
+            const int b = c.use_partial ? (col - 1) / c.batch : 0;
+            const bool take = ok && (bi == 0 || b < bb || (b == bb && val > bv));
+            bv = take ? val : bv;
+            bi = take ? col : bi;
+            bb = take ? b : bb;
+        }
+    }
     Cand e;
     e.v = bv; e.i = bi; e.b = bb;
-    if (dbg) {
-        dbg[threadIdx.x * 4] = (unsigned long long)__double_as_longlong(e.v);
-        dbg[threadIdx.x * 4 + 1] = (unsigned long long)(unsigned)e.i | ((unsigned long long)(unsigned)e.b << 32);
-        dbg[threadIdx.x * 4 + 2] = (unsigned long long)__double_as_longlong(x0);
-        dbg[threadIdx.x * 4 + 3] = (unsigned long long)__double_as_longlong(x1);
+    e = block_reduce(e, PriceFirst(), sm.red);
+    const int cn = e.i;
+    if (UNR) {  // the lane holding the winner knows the sign of its reduced cost
+        if (threadIdx.x == 0) sm.neg = 0;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                if (cn != 0 && cn == c0 + t * JSLP_F_TW + j) sm.neg = (((um >> (2 * t + j)) & 1u) && (j ? x[t].y : x[t].x) < 0) ? 1 : 0;
+        __syncthreads();
+        *neg = sm.neg;
     }
-    e = block_reduce(e, PriceFirst(), sm);
-    if (dbg && threadIdx.x == 0) dbg[4096] = (unsigned long long)(unsigned)e.i;
-    return e.i;
+    return cn;
 }
 
 // streamed tableau cells: every cell is read once and written once per launch, so optionally bypass the
@@ -160,6 +180,9 @@ __device__ __forceinline__ void st_stream(double* p, double2 v, int nt) {
     }
 }
 
+// NT: column tiles per lane (ld <= NT * 2048); UNR: unrestricted variables present (per-column flags read from the maps at the
+// top of every launch; the entering column's isReducedCostNegative travels with f_pc, bit 30)
+template <int NT, bool UNR>
 __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int launch) {
     __shared__ FSmem sm;
     const Ctx& c = f.c;
@@ -178,32 +201,49 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
     const double precision = c.precision;
 
     const int H = f.H;
-    const int c0 = tid * 2;
-    const bool colok = c0 < ld;
+    const int c0 = tid * 2;  // my pair of tile t: columns c0 + t * JSLP_F_TW, +1
     const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
     // Everything whose address does not depend on the selection is requested FIRST, before any barrier: the
     // workgroup's first row group (8 rows x 16 B per lane), its pivot-column entries, the cost row, the
     // candidates and the state.  The selection below then runs while these loads are in flight.
     double2 a[JSLP_F_RG];
     double k[JSLP_F_RG];
-    double2 row0 = make_double2(0, 0);
+    double2 row0[NT];
     double k0 = 0.0;
     FCand mine = fcand_none();
     // (vmcnt retires in order: the selection's own inputs go first so that waiting for them leaves the bulk
     // row loads in flight)
     const int status = sin->status;
-    const int pc_in = sin->f_pc;
+    const int pc_raw = sin->f_pc;
+    const int pc_in = pc_raw & 0x3fffffff;
+    const int neg_in = UNR ? ((pc_raw >> 30) & 1) : 0;
     const int iters_left_in = sin->iters_left;
+    unsigned um = 0;  // UNR: which of my columns carry an unrestricted variable
+    if (UNR) {
+        const uint8_t* ucin = f.ucol[launch & 1];
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = c0 + t * JSLP_F_TW + j;
+                // (launch 0 changes no map: it reads them directly and workgroup 0 builds the first flag arrays from them)
+                if (col >= 1 && col < W && (init ? c.unr[c.vibc[col]] : ucin[col]) != 0) um |= 1u << (2 * t + j);
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) row0[t] = make_double2(0, 0);
     if (!init) {
         if (tid < f.G) mine = cin[tid];
         k0 = pin[0];
-        if (colok) row0 = *reinterpret_cast<const double2*>(Min + c0);
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            if (c0 + t * JSLP_F_TW < ld) row0[t] = *reinterpret_cast<const double2*>(Min + c0 + t * JSLP_F_TW);
 #pragma unroll
         for (int i = 0; i < JSLP_F_RG; i++) {
             const int r = r_begin + i;
             k[i] = r < r_end ? pin[r] : 0.0;
             a[i] = make_double2(0, 0);
-            if (r < r_end && colok) a[i] = ld_stream(Min + (long long)r * ld + c0, f.nt);
+            if (r < r_end && c0 < ld) a[i] = ld_stream(Min + (long long)r * ld + c0, f.nt);
         }
     }
     const bool live = init ? (status == ST_PHASE1_DONE) : (status == ST_RUNNING);
@@ -213,9 +253,14 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
     }
     if (init) {
         // first phase-2 step: price the current cost row, then scan the entering column for candidates
-        double2 r0 = make_double2(0, 0);
-        if (colok) r0 = *reinterpret_cast<const double2*>(Min + c0);
-        const int cn = price_row(r0.x, r0.y, c0, c, sm.red);
+        double2 r0[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            r0[t] = make_double2(0, 0);
+            if (c0 + t * JSLP_F_TW < ld) r0[t] = *reinterpret_cast<const double2*>(Min + c0 + t * JSLP_F_TW);
+        }
+        int neg = 0;
+        const int cn = price_row<NT, UNR>(r0, c0, um, c, sm, &neg);
         if (cn == 0) {  // already optimal (simplex.ts:265-269)
             if (b == 0 && tid == 0) {
                 copy_state(sout, sin); DevState& s = *sout;
@@ -228,21 +273,28 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
             for (int r = r_begin + tid; r < r_end; r += 64) {
                 const double colv = Min[(long long)r * ld + cn];
                 pout[r] = colv;
-                if (r >= 1) fcand_consider(best, r, colv, Min[(long long)r * ld], precision);
+                if (r >= 1) fcand_consider(best, r, colv, Min[(long long)r * ld], precision, neg);
             }
             // lanes hold rows in interleaved order: the reduction's (q, r) / min-rdeg orders are total
             best = fcand_wave_reduce(best);
             if (tid == 0) cout[b] = best;
         }
+        if (UNR && b == 0) {
+            uint8_t* uco = f.ucol[(launch + 1) & 1];
+            uint8_t* uro = f.urow[(launch + 1) & 1];
+            for (int col = tid; col < W; col += JSLP_F_THREADS) uco[col] = col >= 1 ? c.unr[c.vibc[col]] : 0;
+            for (int r = tid; r < H; r += JSLP_F_THREADS) uro[r] = r >= 1 ? c.unr[c.vibr[r]] : 0;
+        }
         if (b == 0 && tid == 0) {
             copy_state(sout, sin); DevState& s = *sout;
-            s.status = ST_RUNNING; s.f_pc = cn; s.f_final_buf = 0; s.do_pivot = 0;
+            s.status = ST_RUNNING; s.f_pc = cn | (neg << 30); s.f_final_buf = 0; s.do_pivot = 0;
         }
         return;
     }
 
     // ---- STEP: pivot t ---------------------------------------------------------------------------
     const int pc = pc_in;
+    (void)neg_in;  // (the candidates of this pivot were built with it by the previous launch)
     if (iters_left_in <= 0) {
         if (b == 0 && tid == 0) {
             copy_state(sout, sin); DevState& s = *sout;
@@ -283,63 +335,108 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
             return;  // the other workgroups write the other buffer, which nobody adopts
         }
     }
-    // normalised pivot row in registers (simplex.ts:352-364; anyrow is true in phase 2, see header)
-    double2 p = make_double2(0, 0);
-    if (colok) {
-        const double2 pv = *reinterpret_cast<const double2*>(Min + (long long)pr * ld + c0);
+    // UNR: the entering column inherits the LEAVING variable (simplex.ts:339-349): its flag for the pricing below; workgroup 0
+    // hands the flag arrays of the new basis to the next launch
+    if (UNR) {
+        const bool leaving_unr = f.urow[launch & 1][pr] != 0;
+        bool entering_unr = false;
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int col = c0 + j;
-            const double val = j ? pv.y : pv.x;
-            double v = 0.0;
-            if (col < W) {
-                const bool innz = nonzero16(val);
-                v = innz ? val / quot : 0.0;
-                if (col == pc) v = 1.0 / quot;
-                if (innz && !nonzero16(v) && v != 0.0) v = 0.0;
-            }
-            if (j) p.y = v; else p.x = v;
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                if (pc == c0 + t * JSLP_F_TW + j) {
+                    entering_unr = ((um >> (2 * t + j)) & 1u) != 0;
+                    um = (um & ~(1u << (2 * t + j))) | ((leaving_unr ? 1u : 0u) << (2 * t + j));
+                    if (b == 0) f.urow[(launch + 1) & 1][pr] = entering_unr ? 1 : 0;
+                }
+        if (b == 0) {
+            uint8_t* uco = f.ucol[(launch + 1) & 1];
+            const uint8_t* uri = f.urow[launch & 1];
+            uint8_t* uro = f.urow[(launch + 1) & 1];
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int col = c0 + t * JSLP_F_TW + j;
+                    if (col < W) uco[col] = (um >> (2 * t + j)) & 1u;
+                }
+            for (int r = tid; r < H; r += JSLP_F_THREADS)
+                if (r != pr) uro[r] = uri[r];
         }
     }
-    const bool v0 = nonzero16(p.x), v1 = nonzero16(p.y);
-    const bool has_pc = colok && ((pc == c0) || (pc == c0 + 1));
-    // updated cost row (every workgroup derives the same values), priced for pivot t+1
-    double2 n0 = row0;
-    if (nonzero16(k0)) {
-        if (v0) n0.x = eliminate(n0.x, k0, p.x);
-        if (v1) n0.y = eliminate(n0.y, k0, p.y);
-        if (has_pc) { const double nv = -k0 / quot; if (pc == c0) n0.x = nv; else n0.y = nv; }
+    // normalised pivot row in registers (simplex.ts:352-364; anyrow is true in phase 2, see header)
+    double2 p[NT];
+    bool v0[NT], v1[NT], has_pc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int ct = c0 + t * JSLP_F_TW;
+        p[t] = make_double2(0, 0);
+        if (ct < ld) {
+            const double2 pv = *reinterpret_cast<const double2*>(Min + (long long)pr * ld + ct);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = ct + j;
+                const double val = j ? pv.y : pv.x;
+                double v = 0.0;
+                if (col < W) {
+                    const bool innz = nonzero16(val);
+                    v = innz ? val / quot : 0.0;
+                    if (col == pc) v = 1.0 / quot;
+                    if (innz && !nonzero16(v) && v != 0.0) v = 0.0;
+                }
+                if (j) p[t].y = v; else p[t].x = v;
+            }
+        }
+        v0[t] = nonzero16(p[t].x); v1[t] = nonzero16(p[t].y);
+        has_pc[t] = ct < ld && ((pc == ct) || (pc == ct + 1));
     }
-    const int cn = price_row(n0.x, n0.y, c0, c, sm.red);  // 0 => optimal after this pivot
+    // updated cost row (every workgroup derives the same values), priced for pivot t+1
+    double2 n0[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        n0[t] = row0[t];
+        if (nonzero16(k0)) {
+            if (v0[t]) n0[t].x = eliminate(n0[t].x, k0, p[t].x);
+            if (v1[t]) n0[t].y = eliminate(n0[t].y, k0, p[t].y);
+            if (has_pc[t]) { const double nv = -k0 / quot; if (pc == c0 + t * JSLP_F_TW) n0[t].x = nv; else n0[t].y = nv; }
+        }
+    }
+    int neg = 0;
+    const int cn = price_row<NT, UNR>(n0, c0, um, c, sm, &neg);  // 0 => optimal after this pivot
 
     // ---- stream my rows ---------------------------------------------------------------------------
     FCand best = fcand_none();  // kept by lanes 0..7 of wave 0: lane i sees rows r_begin+i, +8, ... in order
     for (int g0 = r_begin; g0 < r_end; g0 += JSLP_F_RG) {
-        if (g0 != r_begin) {  // the first group was prefetched at the top
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int ct = c0 + t * JSLP_F_TW;
+            const bool colok = ct < ld;
+            if (g0 != r_begin || t != 0) {  // the first group's first tile was prefetched at the top
+#pragma unroll
+                for (int i = 0; i < JSLP_F_RG; i++) {
+                    const int r = g0 + i;
+                    if (t == 0) k[i] = r < r_end ? pin[r] : 0.0;
+                    a[i] = make_double2(0, 0);
+                    if (r < r_end && colok) a[i] = ld_stream(Min + (long long)r * ld + ct, f.nt);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < JSLP_F_RG; i++) {
                 const int r = g0 + i;
-                k[i] = r < r_end ? pin[r] : 0.0;
-                a[i] = make_double2(0, 0);
-                if (r < r_end && colok) a[i] = ld_stream(Min + (long long)r * ld + c0, f.nt);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < JSLP_F_RG; i++) {
-            const int r = g0 + i;
-            if (r >= r_end) break;
-            double2 x = a[i];
-            if (r == pr) {
-                x = p;
-            } else if (nonzero16(k[i])) {
-                if (v0) x.x = eliminate(x.x, k[i], p.x);
-                if (v1) x.y = eliminate(x.y, k[i], p.y);
-                if (has_pc) { const double nv = -k[i] / quot; if (pc == c0) x.x = nv; else x.y = nv; }
-            }
-            if (colok) st_stream(Mout + (long long)r * ld + c0, x, f.nt);
-            if (cn != 0) {
-                if (cn == c0) sm.col[i] = x.x; else if (cn == c0 + 1) sm.col[i] = x.y;
-                if (tid == 0) sm.rhs[i] = x.x;
+                if (r >= r_end) break;
+                double2 x = a[i];
+                if (r == pr) {
+                    x = p[t];
+                } else if (nonzero16(k[i])) {
+                    if (v0[t]) x.x = eliminate(x.x, k[i], p[t].x);
+                    if (v1[t]) x.y = eliminate(x.y, k[i], p[t].y);
+                    if (has_pc[t]) { const double nv = -k[i] / quot; if (pc == ct) x.x = nv; else x.y = nv; }
+                }
+                if (colok) st_stream(Mout + (long long)r * ld + ct, x, f.nt);
+                if (cn != 0) {
+                    if (cn == ct) sm.col[i] = x.x; else if (cn == ct + 1) sm.col[i] = x.y;
+                    if (t == 0 && tid == 0) sm.rhs[i] = x.x;
+                }
             }
         }
         if (cn != 0) {
@@ -348,7 +445,7 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
                 const int r = g0 + tid;
                 const double colv = sm.col[tid];
                 pout[r] = colv;
-                if (r >= 1) fcand_consider(best, r, colv, sm.rhs[tid], precision);
+                if (r >= 1) fcand_consider(best, r, colv, sm.rhs[tid], precision, neg);
             }
             __syncthreads();
         }
@@ -373,11 +470,11 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
         s.it2 += 1;
         s.iters_left -= 1;
         s.pr = pr; s.pc = pc; s.quot = quot;
-        s.f_pc = cn;
+        s.f_pc = cn | (neg << 30);
         s.f_final_buf = in_buf ^ 1;
         if (cn == 0) {  // optimal after this pivot
             s.status = ST_DONE; s.optimal = 1; s.do_pivot = 0;
-            s.obj_cell = n0.x;  // thread 0 owns column 0 of the updated cost row
+            s.obj_cell = n0[0].x;  // thread 0 owns column 0 of the updated cost row
         }
     }
 }

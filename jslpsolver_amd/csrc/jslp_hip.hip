@@ -122,6 +122,7 @@ struct jslp_engine {
     int nt = 0;  // JSLP_NT=1: non-temporal hints in the fused kernel
     // fused phase-2 pipeline (ping-pong buffer + per-workgroup candidates)
     double* f_buf1 = nullptr; FCand* f_cands[2] = {nullptr, nullptr}; double* f_pcol[2] = {nullptr, nullptr};
+    uint8_t* f_uflags = nullptr;  // fused pipeline with unrestricted variables: 2 x (column flags | row flags)
     DevState* f_st[2] = {nullptr, nullptr};
     // register-resident phase 2 (one cooperative launch): hand-off buffers
     u64_t* r_gran = nullptr;  // [2][G][8] granules then [2][G] row flags (one allocation, zeroed per launch)
@@ -527,6 +528,7 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     hipFree(e->static_arena); hipFree(e->snap_oo);
     drop_checkpoints(e, 1);
     hipFree(e->arena32);
+    hipFree(e->f_uflags);
     hipFree(e->f_buf1); hipFree(e->f_cands[0]); hipFree(e->f_cands[1]); hipFree(e->f_pcol[0]); hipFree(e->f_pcol[1]);
     hipFree(e->f_st[0]); hipFree(e->f_st[1]);
     hipFree(e->d_cuts); if (e->h_cuts) hipHostFree(e->h_cuts);
@@ -722,7 +724,7 @@ static bool use_wg_single(const jslp_engine* e) {
 // the fused one-launch-per-pivot phase 2 (see k_pivot_fused for the preconditions)
 static bool fused_eligible(const jslp_engine* e) {
     if (e->force_path == 2) return false;
-    return e->n_unr == 0 && e->n_opt == 0 && e->ld <= 2 * JSLP_F_THREADS && e->cap_rows <= 64 * JSLP_F_MAXG && e->precision >= 1e-15;
+    return e->n_opt == 0 && e->ld <= 2 * JSLP_F_TW && e->cap_rows <= 64 * JSLP_F_MAXG && e->precision >= 1e-15;
 }
 
 // Geometry of the register-resident kernel for this tableau: lanes x columns per lane must cover a row (ld), rows per
@@ -787,6 +789,8 @@ static int ensure_fused(jslp_engine* e) {
         HIPC(hipMalloc(&e->f_st[i], sizeof(DevState)));
         HIPC(hipMemsetAsync(e->f_st[i], 0, sizeof(DevState), e->stream));
     }
+    HIPC(hipMalloc(&e->f_uflags, 2 * ((size_t)e->ld + (size_t)e->cap_rows)));
+    HIPC(hipMemsetAsync(e->f_uflags, 0, 2 * ((size_t)e->ld + (size_t)e->cap_rows), e->stream));
     return JSLP_OK;
 }
 
@@ -1044,8 +1048,15 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             f.G = (H + f.rpb - 1) / f.rpb;
             f.H = H;
             f.nt = e->nt;
+            for (int i = 0; i < 2; i++) {
+                f.ucol[i] = e->f_uflags + (size_t)i * ((size_t)e->ld + e->cap_rows);
+                f.urow[i] = f.ucol[i] + e->ld;
+            }
+            // column tiles per lane (ld <= 2048: one) x unrestricted variables present
+            void (*kfused)(FusedCtx, int) = e->ld <= JSLP_F_TW ? (e->n_unr > 0 ? k_pivot_fused<1, true> : k_pivot_fused<1, false>)
+                                                              : (e->n_unr > 0 ? k_pivot_fused<2, true> : k_pivot_fused<2, false>);
             int launch = 0;
-            hipLaunchKernelGGL(k_pivot_fused, dim3(f.G), dim3(JSLP_F_THREADS), 0, s, f, launch);
+            hipLaunchKernelGGL(kfused, dim3(f.G), dim3(JSLP_F_THREADS), 0, s, f, launch);
             launch++;
             chunk = 16;
             long long it2_prev = e->h_state->it2;
@@ -1053,7 +1064,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                 if (e->timing) { int r2 = ensure_events(e, 2 * (size_t)chunk); if (r2) return r2; }
                 for (int i = 0; i < chunk; i++) {
                     if (e->timing) HIPC(hipEventRecord(e->ev_pool[2 * i], s));
-                    hipLaunchKernelGGL(k_pivot_fused, dim3(f.G), dim3(JSLP_F_THREADS), 0, s, f, launch);
+                    hipLaunchKernelGGL(kfused, dim3(f.G), dim3(JSLP_F_THREADS), 0, s, f, launch);
                     if (e->timing) HIPC(hipEventRecord(e->ev_pool[2 * i + 1], s));
                     launch++;
                 }
