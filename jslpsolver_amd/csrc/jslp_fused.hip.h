@@ -479,6 +479,282 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
     }
 }
 
+// ===================================================================================================
+// Fused PHASE 1 (simplex.ts:25-98), one launch per pivot, same out-of-place streaming as k_pivot_fused.
+// What launch t-1 leaves behind is only the per-workgroup "most negative RHS" candidate of its rows (FCand: q = the RHS value,
+// r = the row).  Launch t reduces them to the leaving row pr (none: phase 1 is over -> ST_PHASE1_DONE, the phase-2 pipeline
+// takes over), EVERY workgroup then derives the entering column from row pr and the cost row (both read from the input buffer:
+// 2 x 16-32 KB of L2 hits; max -cost/coef over unrestricted or coef < -precision, first index on ties), loads its rows'
+// entries of that column, and streams its rows; while the updated rows are in registers it collects the next candidate.
+// Workgroup 0 runs the cycle check and commits the maps.
+// The one case a workgroup cannot decide alone: simplex.ts:381-383 zeroes the tiny (< 1e-16, non-zero) entries of the stored
+// pivot row iff ANY other row has an entry in the pivot column.  The cost row's entry (every workgroup has it) settles that
+// almost always; when it does not and a tiny entry exists, nothing is pivoted and the state says ST_P1_SLOW: the host runs
+// that ONE pivot through k_select + k_update and restarts this pipeline.
+// ===================================================================================================
+#define JSLP_F_RPB_MAX 64   // rows per workgroup (cap_rows <= 64 * 256)
+template <int NT, bool UNR>
+__global__ void __launch_bounds__(JSLP_F_THREADS) k_fused_p1(FusedCtx f, int launch) {
+    __shared__ FSmem sm;
+    __shared__ double s_kcol[JSLP_F_RPB_MAX];
+    __shared__ double s_xq[2];
+    const Ctx& c = f.c;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const bool init = launch == 0;
+    const DevState* sin = init ? c.st : f.fst[launch & 1];
+    DevState* sout = f.fst[(launch + 1) & 1];
+    // (launch 0 does not pivot: it reads buf[0] and leaves the tableau there; launch t >= 1 reads what launch t-1 wrote)
+    const int in_buf = init ? 0 : ((launch - 1) & 1);
+    const double* Min = f.buf[in_buf];
+    double* Mout = f.buf[in_buf ^ 1];
+    const FCand* cin = f.cands[launch & 1];
+    FCand* cout = f.cands[(launch + 1) & 1];
+    const int ld = c.ld, W = c.W;
+    const double precision = c.precision;
+    const int H = f.H;
+    const int c0 = tid * 2;
+    const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
+    const int status = sin->status;
+    const bool live = status == ST_RUNNING && sin->phase == 1;
+    if (!live) {  // phase 1 already ended (or never ran): carry the state forward
+        if (b == 0 && tid == 0) { copy_state(sout, sin); if (init) sout->f_final_buf = 0; }
+        return;
+    }
+    if (init) {  // candidates of the first pivot; the flag arrays of the unrestricted variables
+        FCand best = fcand_none();
+        if (tid < 64) {
+            for (int r = r_begin + tid; r < r_end; r += 64) {
+                const double v = Min[(long long)r * ld];
+                if (r >= 1 && v < -precision && (best.r == 0 || v < best.q)) { best.q = v; best.r = r; }  // (rows ascend per lane)
+            }
+            best = fcand_wave_reduce(best);
+            if (tid == 0) cout[b] = best;
+        }
+        if (UNR && b == 0) {
+            uint8_t* uco = f.ucol[(launch + 1) & 1];
+            uint8_t* uro = f.urow[(launch + 1) & 1];
+            for (int col = tid; col < W; col += JSLP_F_THREADS) uco[col] = col >= 1 ? c.unr[c.vibc[col]] : 0;
+            for (int r = tid; r < H; r += JSLP_F_THREADS) uro[r] = r >= 1 ? c.unr[c.vibr[r]] : 0;
+        }
+        if (b == 0 && tid == 0) { copy_state(sout, sin); sout->f_final_buf = 0; sout->do_pivot = 0; }
+        return;
+    }
+    // ---- STEP ---------------------------------------------------------------------------------------------------------
+    if (sin->iters_left <= 0) {
+        if (b == 0 && tid == 0) {
+            copy_state(sout, sin); DevState& s = *sout;
+            s.err = ERR_ITER_LIMIT; s.status = ST_DONE; s.do_pivot = 0; s.obj_cell = Min[0]; s.f_final_buf = in_buf;
+        }
+        return;
+    }
+    FCand mine = fcand_none();
+    if (tid < f.G) mine = cin[tid];
+    const FCand win = fcand_block_reduce(mine, sm);
+    if (win.r == 0) {  // simplex.ts:51-54: feasible, phase 2 starts with a fresh history
+        if (b == 0 && tid == 0) {
+            copy_state(sout, sin); DevState& s = *sout;
+            s.feasible = 1; s.phase = 2; s.entered_phase2 = 1; s.hist_n = 0; s.status = ST_PHASE1_DONE; s.do_pivot = 0;
+            s.f_final_buf = in_buf;
+        }
+        return;
+    }
+    const int pr = win.r;
+    // entering column (simplex.ts:56-71) from row pr and the cost row, both as the previous launch left them
+    unsigned um = 0;
+    double2 rowp[NT], row0[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int ct = c0 + t * JSLP_F_TW;
+        rowp[t] = make_double2(0, 0); row0[t] = make_double2(0, 0);
+        if (ct < ld) {
+            rowp[t] = *reinterpret_cast<const double2*>(Min + (long long)pr * ld + ct);
+            row0[t] = *reinterpret_cast<const double2*>(Min + ct);
+        }
+        if (UNR) {
+            const uint8_t* ucin = f.ucol[launch & 1];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                if (ct + j >= 1 && ct + j < W && ucin[ct + j] != 0) um |= 1u << (2 * t + j);
+        }
+    }
+    Cand q; q.v = -INFINITY; q.i = 0; q.b = 0;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int col = c0 + t * JSLP_F_TW + j;
+            const double coef = j ? rowp[t].y : rowp[t].x;
+            const bool un = UNR && ((um >> (2 * t + j)) & 1u);
+            if (col >= 1 && col < W && (un || coef < -precision)) {
+                const double quo = -(j ? row0[t].y : row0[t].x) / coef;
+                const bool take = q.v < quo;  // (my columns ascend: ties keep the earlier one)
+                q.v = take ? quo : q.v;
+                q.i = take ? col : q.i;
+            }
+        }
+    q = block_reduce(q, MaxFirst(), sm.red);
+    if (q.i == 0) {  // simplex.ts:73-76: infeasible
+        if (b == 0 && tid == 0) {
+            copy_state(sout, sin); DevState& s = *sout;
+            s.feasible = 0; s.status = ST_DONE; s.do_pivot = 0; s.obj_cell = Min[0]; s.f_final_buf = in_buf;
+        }
+        return;
+    }
+    const int pc = q.i;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            if (pc == c0 + t * JSLP_F_TW + j) { s_xq[0] = j ? rowp[t].y : rowp[t].x; s_xq[1] = j ? row0[t].y : row0[t].x; }
+    // my rows' entries of the pivot column (one strided trip), while workgroup 0 runs the cycle check
+    if (tid < JSLP_F_RPB_MAX && r_begin + tid < r_end) s_kcol[tid] = Min[(long long)(r_begin + tid) * ld + pc];
+    if (b == 0 && c.check_cycles) {  // simplex.ts:78-93
+        const int n = sin->hist_n;
+        if (n >= c.hist_cap) {
+            if (tid == 0) {
+                copy_state(sout, sin); DevState& s = *sout;
+                s.err = ERR_HIST_FULL; s.status = ST_DONE; s.do_pivot = 0; s.obj_cell = Min[0]; s.f_final_buf = in_buf;
+            }
+            return;
+        }
+        if (tid == 0) c.hist[n] = make_int2(c.vibr[pr], c.vibc[pc]);
+        __syncthreads();
+        if (suffix_is_square(c.hist, n + 1, sm.red)) {
+            if (tid == 0) {
+                copy_state(sout, sin); DevState& s = *sout;
+                s.hist_n = n + 1; s.cycle_phase = 1; s.feasible = 0; s.status = ST_DONE; s.do_pivot = 0;
+                s.obj_cell = Min[0]; s.f_final_buf = in_buf;
+            }
+            return;  // the other workgroups write the other buffer, which nobody adopts
+        }
+    }
+    __syncthreads();
+    const double quot = s_xq[0], k0 = s_xq[1];
+    // normalised pivot row (simplex.ts:352-364) under "some other row has an entry in column pc"
+    double2 p[NT];
+    bool v0[NT], v1[NT], has_pc[NT];
+    int tiny = 0;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int ct = c0 + t * JSLP_F_TW;
+        p[t] = make_double2(0, 0);
+        if (ct < ld) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = ct + j;
+                const double val = j ? rowp[t].y : rowp[t].x;
+                double v = 0.0;
+                if (col < W) {
+                    const bool innz = nonzero16(val);
+                    v = innz ? val / quot : 0.0;
+                    if (col == pc) v = 1.0 / quot;
+                    if (innz && !nonzero16(v) && v != 0.0) { tiny = 1; v = 0.0; }
+                }
+                if (j) p[t].y = v; else p[t].x = v;
+            }
+        }
+        v0[t] = nonzero16(p[t].x); v1[t] = nonzero16(p[t].y);
+        has_pc[t] = ct < ld && ((pc == ct) || (pc == ct + 1));
+    }
+    if (__syncthreads_or(tiny) && !nonzero16(k0)) {
+        // whether the tiny entries are zeroed depends on the other workgroups' rows: not decidable here
+        if (b == 0 && tid == 0) {
+            copy_state(sout, sin); DevState& s = *sout;
+            s.status = ST_P1_SLOW; s.do_pivot = 0; s.f_final_buf = in_buf;
+        }
+        return;
+    }
+    if (UNR) {  // the entering column inherits the leaving variable's flag; workgroup 0 hands the flag arrays on
+        const bool leaving_unr = f.urow[launch & 1][pr] != 0;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                if (pc == c0 + t * JSLP_F_TW + j) {
+                    const bool entering_unr = ((um >> (2 * t + j)) & 1u) != 0;
+                    um = (um & ~(1u << (2 * t + j))) | ((leaving_unr ? 1u : 0u) << (2 * t + j));
+                    if (b == 0) f.urow[(launch + 1) & 1][pr] = entering_unr ? 1 : 0;
+                }
+        if (b == 0) {
+            uint8_t* uco = f.ucol[(launch + 1) & 1];
+            const uint8_t* uri = f.urow[launch & 1];
+            uint8_t* uro = f.urow[(launch + 1) & 1];
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int col = c0 + t * JSLP_F_TW + j;
+                    if (col < W) uco[col] = (um >> (2 * t + j)) & 1u;
+                }
+            for (int r = tid; r < H; r += JSLP_F_THREADS)
+                if (r != pr) uro[r] = uri[r];
+        }
+    }
+    // ---- stream my rows; the next pivot's candidate (most negative RHS below -precision, first row on ties) ---------------
+    FCand best = fcand_none();  // kept by lanes 0..7 of wave 0: lane i sees rows r_begin + i, + 8, ... in order
+    double2 a[JSLP_F_RG];
+    for (int g0 = r_begin; g0 < r_end; g0 += JSLP_F_RG) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int ct = c0 + t * JSLP_F_TW;
+            const bool colok = ct < ld;
+#pragma unroll
+            for (int i = 0; i < JSLP_F_RG; i++) {
+                const int r = g0 + i;
+                a[i] = make_double2(0, 0);
+                if (r < r_end && colok) a[i] = ld_stream(Min + (long long)r * ld + ct, f.nt);
+            }
+#pragma unroll
+            for (int i = 0; i < JSLP_F_RG; i++) {
+                const int r = g0 + i;
+                if (r >= r_end) break;
+                const double ki = s_kcol[r - r_begin];
+                double2 x = a[i];
+                if (r == pr) {
+                    x = p[t];
+                } else if (nonzero16(ki)) {
+                    if (v0[t]) x.x = eliminate(x.x, ki, p[t].x);
+                    if (v1[t]) x.y = eliminate(x.y, ki, p[t].y);
+                    if (has_pc[t]) { const double nv = -ki / quot; if (pc == ct) x.x = nv; else x.y = nv; }
+                }
+                if (colok) st_stream(Mout + (long long)r * ld + ct, x, f.nt);
+                if (t == 0 && tid == 0) sm.rhs[i] = x.x;
+            }
+        }
+        __syncthreads();
+        if (tid < JSLP_F_RG && g0 + tid < r_end) {
+            const int r = g0 + tid;
+            const double v = sm.rhs[tid];
+            if (r >= 1 && v < -precision && (best.r == 0 || v < best.q)) { best.q = v; best.r = r; }
+        }
+        __syncthreads();
+    }
+    if (tid < 64) {
+        best = fcand_wave_reduce(best);
+        if (tid == 0) cout[b] = best;
+    }
+    if (b == 0 && tid == 0) {  // simplex.ts:339-349
+        copy_state(sout, sin); DevState& s = *sout;
+        const int leaving = c.vibr[pr], entering = c.vibc[pc];
+        c.vibr[pr] = entering;
+        c.vibc[pc] = leaving;
+        c.rbv[entering] = pr;
+        c.rbv[leaving] = -1;
+        c.cbv[entering] = -1;
+        c.cbv[leaving] = pc;
+        if (s.trace_n < c.trace_cap) c.trace[s.trace_n] = make_int2(pr, pc);
+        s.trace_n += 1;
+        if (c.check_cycles) s.hist_n += 1;
+        s.it1 += 1;
+        s.iters_left -= 1;
+        s.pr = pr; s.pc = pc; s.quot = quot;
+        s.f_final_buf = in_buf ^ 1;
+    }
+}
+
+// after ST_P1_SLOW was adopted into the canonical state: k_select takes the next pivot
+__global__ void k_p1_resume(DevState* st) { st->status = ST_RUNNING; }
+
 // End of the fused pipeline: adopt the final state and make buf[0] hold the final tableau.
 __global__ void __launch_bounds__(256) k_fused_finish(FusedCtx f, int last_launch) {
     const DevState* fin = f.fst[(last_launch + 1) & 1];

@@ -123,6 +123,7 @@ struct jslp_engine {
     // fused phase-2 pipeline (ping-pong buffer + per-workgroup candidates)
     double* f_buf1 = nullptr; FCand* f_cands[2] = {nullptr, nullptr}; double* f_pcol[2] = {nullptr, nullptr};
     uint8_t* f_uflags = nullptr;  // fused pipeline with unrestricted variables: 2 x (column flags | row flags)
+    long long p1_slow_pivots = 0;  // pivots the fused phase 1 handed to k_select + k_update (tiny pivot-row entries, see k_fused_p1)
     DevState* f_st[2] = {nullptr, nullptr};
     // register-resident phase 2 (one cooperative launch): hand-off buffers
     u64_t* r_gran = nullptr;  // [2][G][8] granules then [2][G] row flags (one allocation, zeroed per launch)
@@ -794,6 +795,30 @@ static int ensure_fused(jslp_engine* e) {
     return JSLP_OK;
 }
 
+static FusedCtx make_fused_ctx(const jslp_engine* e, const Ctx& c, int H) {
+    FusedCtx f;
+    f.c = c;
+    f.buf[0] = e->s.A; f.buf[1] = e->f_buf1;
+    for (int i = 0; i < 2; i++) { f.cands[i] = e->f_cands[i]; f.pcol[i] = e->f_pcol[i]; f.fst[i] = e->f_st[i]; }
+    f.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
+    f.G = (H + f.rpb - 1) / f.rpb;
+    f.H = H;
+    f.nt = e->nt;
+    for (int i = 0; i < 2; i++) {
+        f.ucol[i] = e->f_uflags + (size_t)i * ((size_t)e->ld + e->cap_rows);
+        f.urow[i] = f.ucol[i] + e->ld;
+    }
+    return f;
+}
+static int fused_p1_on() {  // phase 1 of the large LPs through k_fused_p1 (one launch per pivot) instead of k_select + k_update
+    static int v = -1;
+    if (v < 0) {
+        const char* t = getenv("JSLP_FUSED_P1");  // tuning knob
+        v = t ? atoi(t) : 1;
+    }
+    return v;
+}
+
 static dim3 update_grid(const jslp_engine* e, int H) {
     return dim3((e->ld + JSLP_UPD_COLS - 1) / JSLP_UPD_COLS, (H + JSLP_UPD_ROWS - 1) / JSLP_UPD_ROWS, 1);
 }
@@ -1006,10 +1031,47 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             }
         }
         if (!resident_done) {
+        // ---- phase 1 through the fused pipeline (one launch per pivot; k_fused_p1), when the fused pipeline applies -----------
+        bool p1_fused = false;
+        if (fused && fused_p1_on()) {
+            int r = ensure_fused(e);
+            if (r) return r;
+            const FusedCtx f = make_fused_ctx(e, c, H);
+            void (*kp1)(FusedCtx, int) = e->ld <= JSLP_F_TW ? (e->n_unr > 0 ? k_fused_p1<1, true> : k_fused_p1<1, false>)
+                                                           : (e->n_unr > 0 ? k_fused_p1<2, true> : k_fused_p1<2, false>);
+            for (;;) {
+                int launch = 0;
+                hipLaunchKernelGGL(kp1, dim3(f.G), dim3(JSLP_F_THREADS), 0, s, f, launch);
+                launch++;
+                int chunk1 = 2;
+                for (;;) {
+                    for (int i = 0; i < chunk1; i++) { hipLaunchKernelGGL(kp1, dim3(f.G), dim3(JSLP_F_THREADS), 0, s, f, launch); launch++; }
+                    HIPC(hipGetLastError());
+                    HIPC(hipMemcpyAsync(e->h_state, f.fst[launch & 1], sizeof(DevState), hipMemcpyDeviceToHost, s));
+                    HIPC(hipStreamSynchronize(s));
+                    if (e->h_state->status != ST_RUNNING) break;
+                    chunk1 = std::min(chunk1 * 2, 512);
+                }
+                hipLaunchKernelGGL(k_fused_finish, dim3(512), dim3(256), 0, s, f, launch - 1);  // state -> slot 0's, tableau -> buf[0]
+                HIPC(hipGetLastError());
+                if (e->h_state->status != ST_P1_SLOW) break;
+                // the one pivot k_fused_p1 cannot decide alone (see there): k_select + k_update, then the pipeline again
+                hipLaunchKernelGGL(k_p1_resume, dim3(1), dim3(1), 0, s, e->s.st);
+                hipLaunchKernelGGL(k_select, dim3(1), dim3(JSLP_WG_THREADS), 0, s, c);
+                hipLaunchKernelGGL(k_update, grid, dim3(JSLP_UPD_THREADS), 0, s, c);
+                HIPC(hipGetLastError());
+                HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+                HIPC(hipStreamSynchronize(s));
+                e->p1_slow_pivots += 1;
+                if (e->h_state->status != ST_RUNNING) break;
+            }
+            p1_fused = true;
+            e->last_path = "fused";
+        }
         // ---- phase 1 (and phase 2 when the fused pipeline does not apply): k_select + k_update per pivot ----
         int chunk = fused ? 1 : 8;
         long long done_prev = 0;
-        for (;;) {
+        for (; !p1_fused;) {
             if (e->timing && !fused) { int r = ensure_events(e, 2 * (size_t)chunk); if (r) return r; }
             for (int i = 0; i < chunk; i++) {
                 hipLaunchKernelGGL(k_select, dim3(1), dim3(JSLP_WG_THREADS), 0, s, c);
@@ -1040,18 +1102,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             int r = ensure_fused(e);
             if (r) return r;
             e->last_path = "fused";
-            FusedCtx f;
-            f.c = c;
-            f.buf[0] = e->s.A; f.buf[1] = e->f_buf1;
-            for (int i = 0; i < 2; i++) { f.cands[i] = e->f_cands[i]; f.pcol[i] = e->f_pcol[i]; f.fst[i] = e->f_st[i]; }
-            f.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
-            f.G = (H + f.rpb - 1) / f.rpb;
-            f.H = H;
-            f.nt = e->nt;
-            for (int i = 0; i < 2; i++) {
-                f.ucol[i] = e->f_uflags + (size_t)i * ((size_t)e->ld + e->cap_rows);
-                f.urow[i] = f.ucol[i] + e->ld;
-            }
+            const FusedCtx f = make_fused_ctx(e, c, H);
             // column tiles per lane (ld <= 2048: one) x unrestricted variables present
             void (*kfused)(FusedCtx, int) = e->ld <= JSLP_F_TW ? (e->n_unr > 0 ? k_pivot_fused<1, true> : k_pivot_fused<1, false>)
                                                               : (e->n_unr > 0 ? k_pivot_fused<2, true> : k_pivot_fused<2, false>);

@@ -28,7 +28,7 @@
 #define JSLP_UPD_ROWS 8           // rows per workgroup in the streaming row update
 #define JSLP_UPD_COLS (JSLP_UPD_THREADS * 2)
 
-enum { ST_RUNNING = 0, ST_DONE = 1, ST_PHASE1_DONE = 2 };
+enum { ST_RUNNING = 0, ST_DONE = 1, ST_PHASE1_DONE = 2, ST_P1_SLOW = 3 };  // ST_P1_SLOW: the fused phase 1 hands ONE pivot to k_select + k_update (see k_fused_p1)
 enum { ERR_NONE = 0, ERR_HIST_FULL = 1, ERR_ITER_LIMIT = 2, ERR_CUT_ARG = 3, ERR_CAPACITY = 4, ERR_BARRIER = 5, ERR_NOT_SYNCED = 6 };
 
 // Per-tableau device state (one per slot).  Plain ints so the host can read it back with one copy.

@@ -31,7 +31,7 @@ const cases = [
     { name: "unrestricted_RA_1000x950_k50", build: () => unrestrictedRA(1000, 950, 50, 12345), exit: false, meta: { kind: "unrestricted", n: 1000, m: 950, k: 50 } },
     { name: "unrestricted_RA_2000x3950_k50", build: () => unrestrictedRA(2000, 3950, 50, 12345), exit: false, meta: { kind: "unrestricted", n: 2000, m: 3950, k: 50 } },
     { name: "cyclecheck_RA_2000x2000", build: () => gen.generateResourceAllocation({ seed: 12345, numVariables: 2000, numConstraints: 2000, density: 1.0 }), exit: true, meta: { kind: "ra", n: 2000, m: 2000 } },
-    { name: "wide_RandomLP_3000x3000", build: () => gen.generateRandomLP({ seed: 12345, numVariables: 3000, numConstraints: 3000, density: 1.0 }), exit: false, meta: { kind: "lp", n: 3000, m: 3000 } },
+    // (generateRandomLP 3000 x 3000 was tried here: the reference does not finish it in hours, with or without its cycle check)
     { name: "wide_RA_3000x3000", build: () => gen.generateResourceAllocation({ seed: 12345, numVariables: 3000, numConstraints: 3000, density: 1.0 }), exit: false, meta: { kind: "ra", n: 3000, m: 3000 } },
 ];
 const filter = process.argv[2] || "";
