@@ -34,29 +34,22 @@
 #ifndef JSLP_RES_FAST
 #define JSLP_RES_FAST 1      // one barrier around the row flag (step E); the -k/quot entries of the pivot column computed by eight lanes in parallel while the winning row is in flight instead of one after the other by the lane that owns the column (step F)
 #endif
-#ifndef JSLP_RES_PRICE_DPP
-#define JSLP_RES_PRICE_DPP 0 // 1: pricing with one DPP (batch, key, index) reduction per wave and one barrier -- MEASURED SLOWER (7.5 k against 3.8 k cycles per pivot, r02_w: all 16 waves pay the wave stage and the 16-entry scan; the three LDS-atomic rounds keep 15 of them parked)
-#endif
 #ifndef JSLP_RES_ALLGATHER
 #define JSLP_RES_ALLGATHER 1  // no unrestricted variables, cycle check off (both phases): EVERY workgroup gathers the <= 256 summaries itself (coalesced: thread t polls granules t, t + blockDim, ...; the payloads meet in LDS) and takes the leader's decision redundantly -- the decision broadcast and its poll (one fabric hop) disappear
 #endif
-#ifndef JSLP_RES_PIPE_PRICE
-#define JSLP_RES_PIPE_PRICE 0  // 1: phase 2: the pricing rounds of the next pivot interleaved with thirds of the row update -- MEASURED NO FASTER (F + G 7.1 k against 6.4-6.9 k cycles, 120.1 k against 123.4 k pivots/s, r02_x): the rounds are not idle latency the row update could fill
-#endif
-#ifndef JSLP_RES_EARLY_ROWFLAG
-#define JSLP_RES_EARLY_ROWFLAG 0  // 1: all-gather protocol: raise the row flag as soon as the row stores have drained, before the gather -- MEASURED NO FASTER (r02_x: step E0 is one fabric round trip for the flag + row loads whenever the flag went up)
-#endif
-#ifndef JSLP_RES_DPP_DECIDE_LEADER
-#define JSLP_RES_DPP_DECIDE_LEADER 0  // 1: the same in the leader's four sweep waves of the gather-by-leader protocol -- WRONG for phase 1, whose summaries are negative RHS values: the DPP reduction orders candidates by their BITS, which is the numeric order of positive doubles only (that, not the compiler, was the "release build loses the pivot sequence" of r02_w)
-#endif
+// Measured in round 2 and dropped (the code is in the history: commits 57ce867 ... 31f93eb), config 3a, 2001 x 2001:
+//   * pricing with one DPP (batch, key, index) reduction per wave and one barrier: 7.5 k against 3.8 k cycles per pivot (all 16
+//     waves pay the wave stage and the 16-entry scan; the three LDS-atomic rounds keep 15 of them parked);
+//   * pricing in two barriers (batch by ballot + LDS atomic, then a DPP (key, column) reduction in the one or two waves holding
+//     the winning batch): 3.9-4.2 k against 3.2-3.6 k cycles;
+//   * the whole ratio-test summary by the ONE lane that holds the pivot column (one barrier instead of two): no faster, its
+//     eight divisions run one after the other;
+//   * the pricing rounds of the next pivot interleaved with thirds of the row update: 120.1 k against 123.4 k pivots/s;
+//   * the row flag raised before the gather instead of behind it: no faster (step E0 is one fabric round trip either way);
+//   * 256-lane geometries (one wave per SIMD, 512 registers per lane): 72.5 k against 105.7 k pivots/s;
+//   * DPP reductions in the LEADER's decision: wrong for phase 1, whose keys are negative (bits order positive doubles only).
 #ifndef JSLP_RES_DPP_DECIDE
 #define JSLP_RES_DPP_DECIDE 3  // all-gather protocol (phase 2: quotients > 0): bit 0 = (quotient, row) minimum, bit 1 = first degenerate row, by DPP exchanges + readlanes instead of ds_bpermute shuffles (120.9 k vs 119.2 k pivots/s, r02_x)
-#endif
-#ifndef JSLP_RES_PRICE_2B
-#define JSLP_RES_PRICE_2B 0  // 1: pricing in two barriers (batch by ballot + LDS atomic, then a DPP (key, column) reduction in the one or two waves holding the winning batch) -- MEASURED NO FASTER (3.9-4.2 k against 3.2-3.6 k cycles, r02_w: the dependent DPP chain of one wave is longer than two LDS-atomic rounds) and NOT validated in the release build
-#endif
-#ifndef JSLP_RES_ONE_LANE_SUMMARY
-#define JSLP_RES_ONE_LANE_SUMMARY 0  // 1: the lane holding the pivot column computes and publishes the whole ratio-test summary (one barrier instead of two) -- MEASURED NO FASTER (r02_w): its eight divisions run one after the other
 #endif
 typedef unsigned long long u64_t;
 
@@ -99,11 +92,6 @@ struct RSmem {
     int32_t okx[2];      // step E's verdict, alternating (one barrier per use)
     double nv[JSLP_R_MAXROWS + 1];  // -k / quot of my rows' pivot-column entries (and of the cost row's), one lane each
     unsigned gsum[JSLP_F_MAXG * JSLP_R_GRAN];  // all-gather by every workgroup: the payloads of everybody's summary granules
-    int32_t pw_b[16], pw_i[16];  // pricing: per wave (first batch, key of the best value in it, first column with it)
-    u64_t pw_k[16];
-    int32_t pw_n[2];     // two-barrier pricing: waves that hold a candidate of the winning batch, alternating by call
-    u64_t pw2_k[2][16];
-    int32_t pw2_i[2][16];
     int32_t p_neg;    // pricing: isReducedCostNegative of the winning column (unrestricted variables only, simplex.ts:164-177)
     int32_t pubrow;
     unsigned dec[4];
@@ -218,160 +206,6 @@ __device__ __forceinline__ int price_row_lds(const double (&x)[CPT], int c0, con
     return pcol;
 }
 
-// The same pricing with ONE barrier: a candidate is the triple (batch, key of the value: larger value = smaller key, column),
-// the selection its lexicographic minimum -- four DPP exchanges inside the 16-lane rows + readlanes across them per wave, the
-// <= 16 wave results meet in LDS, every thread scans them.
-struct K3 {
-    int32_t b;
-    unsigned long long k;
-    int32_t i;
-};
-__device__ __forceinline__ K3 k3_min(K3 a, K3 x) {
-    const bool t = x.b < a.b || (x.b == a.b && (x.k < a.k || (x.k == a.k && x.i < a.i)));
-    K3 r; r.b = t ? x.b : a.b; r.k = t ? x.k : a.k; r.i = t ? x.i : a.i;
-    return r;
-}
-template <int CTRL>
-__device__ __forceinline__ K3 k3_dpp(K3 x) {
-    const int lo = (int)(unsigned)x.k, hi = (int)(unsigned)(x.k >> 32);
-    K3 y;
-    y.k = ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false) << 32) |
-          (unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    y.i = __builtin_amdgcn_update_dpp(x.i, x.i, CTRL, 0xf, 0xf, false);
-    y.b = __builtin_amdgcn_update_dpp(x.b, x.b, CTRL, 0xf, 0xf, false);
-    return y;
-}
-__device__ __forceinline__ K3 k3_readlane(K3 x, int lane) {
-    K3 y;
-    y.k = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x.k >> 32), lane) << 32) |
-          (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)x.k, lane);
-    y.i = __builtin_amdgcn_readlane(x.i, lane);
-    y.b = __builtin_amdgcn_readlane(x.b, lane);
-    return y;
-}
-__device__ __forceinline__ K3 k3_wave_min(K3 x) {
-    x = k3_min(x, k3_dpp<0xB1>(x));
-    x = k3_min(x, k3_dpp<0x4E>(x));
-    x = k3_min(x, k3_dpp<0x141>(x));
-    x = k3_min(x, k3_dpp<0x140>(x));
-    K3 r = k3_readlane(x, 0);
-    r = k3_min(r, k3_readlane(x, 16));
-    r = k3_min(r, k3_readlane(x, 32));
-    r = k3_min(r, k3_readlane(x, 48));
-    return r;
-}
-template <int CPT, bool UNR>
-__device__ __forceinline__ int price_row_dpp(const double (&x)[CPT], int c0, const int (&pb)[CPT], const Ctx& c, RSmem& sm,
-                                             double* value, unsigned unr, int* neg) {
-    double bv = c.precision;
-    int bi = 0, bb = 0;
-#pragma unroll
-    for (int j = 0; j < CPT; j++) {  // my columns in order: earlier batch first, bigger value inside a batch, first index on ties
-        const int col = c0 + j;
-        const double val = (UNR && ((unr >> j) & 1u) && x[j] < 0) ? -x[j] : x[j];
-        const bool ok = col >= 1 && col < c.W && val > c.precision;
-        const bool take = ok && (bi == 0 || pb[j] < bb || (pb[j] == bb && val > bv));
-        bv = take ? val : bv;
-        bi = take ? col : bi;
-        bb = take ? pb[j] : bb;
-    }
-    K3 m;
-    m.b = bi != 0 ? bb : 0x7fffffff;
-    m.k = bi != 0 ? key_desc(bv) : ~0ull;
-    m.i = bi != 0 ? bi : 0x7fffffff;
-    m = k3_wave_min(m);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (lane == 0) { sm.pw_b[w] = m.b; sm.pw_k[w] = m.k; sm.pw_i[w] = m.i; }
-    __syncthreads();
-    K3 r; r.b = sm.pw_b[0]; r.k = sm.pw_k[0]; r.i = sm.pw_i[0];
-#pragma unroll
-    for (int i = 1; i < 16; i++)
-        if (i < nw) { K3 y; y.b = sm.pw_b[i]; y.k = sm.pw_k[i]; y.i = sm.pw_i[i]; r = k3_min(r, y); }
-    if (r.b == 0x7fffffff) return 0;  // uniform: no candidate anywhere -> optimal
-    const int pcol = r.i;
-    double v = __longlong_as_double((long long)(~r.k & 0x7fffffffffffffffull));  // (candidates are > precision > 0)
-    if (UNR) {  // the lane holding the winner knows the sign of its reduced cost
-#pragma unroll
-        for (int j = 0; j < CPT; j++)
-            if (pcol == c0 + j) sm.p_neg = (((unr >> j) & 1u) && x[j] < 0) ? 1 : 0;
-        __syncthreads();
-        *neg = sm.p_neg;
-        if (*neg) v = -v;
-    }
-    *value = v;
-    return pcol;
-}
-
-// The same pricing in TWO barriers: the first batch holding a candidate as in price_row_lds (a ballot per wave, one LDS atomic);
-// then only the waves that hold candidates of that batch (one or two of the sixteen: a batch is <= 64 adjacent columns) reduce
-// (key of the value, column) with DPP exchanges and leave their result in LDS for everybody -- the other waves go straight
-// to the barrier instead of paying two more atomic rounds' worth of instructions and a third barrier.
-// `sm.p_batch` must have been reset before a preceding barrier (reset_reductions); the slots alternate by call (`q`), each call
-// clears the OTHER counter once nobody can still be reading it (sm.pw_n = {0, 0} at kernel start).
-template <int CPT, bool UNR>
-__device__ __forceinline__ int price_row_2b(const double (&x)[CPT], int c0, const int (&pb)[CPT], const Ctx& c, RSmem& sm,
-                                            double* value, unsigned unr, int* neg, int& q) {
-    double bv = c.precision;
-    int bi = 0, bb = 0;
-#pragma unroll
-    for (int j = 0; j < CPT; j++) {  // my columns in order: earlier batch first, bigger value inside a batch, first index on ties
-        const int col = c0 + j;
-        const double val = (UNR && ((unr >> j) & 1u) && x[j] < 0) ? -x[j] : x[j];
-        const bool ok = col >= 1 && col < c.W && val > c.precision;
-        const bool take = ok && (bi == 0 || pb[j] < bb || (pb[j] == bb && val > bv));
-        bv = take ? val : bv;
-        bi = take ? col : bi;
-        bb = take ? pb[j] : bb;
-    }
-    {   // batch ids grow with the lane index: the wave's earliest batch is that of its first candidate lane
-        const unsigned long long m = __ballot(bi != 0);
-        if (m != 0ull) {
-            const int first = __ffsll((long long)m) - 1;
-            const int wave_b = __builtin_amdgcn_readlane(bb, first);
-            if ((threadIdx.x & 63) == 0) atomicMin(&sm.p_batch, wave_b);
-        }
-    }
-    __syncthreads();
-    const int wb = sm.p_batch;
-    if (wb == 0x7fffffff) return 0;  // uniform: no candidate anywhere -> optimal
-    const bool mine = bi != 0 && bb == wb;
-    const int qq = q;
-    q ^= 1;
-    if (threadIdx.x == 0) sm.pw_n[qq ^ 1] = 0;  // (everybody is past the barrier above: the previous call's readers are done)
-    if (__ballot(mine) != 0ull) {
-        KI k;
-        k.k = mine ? key_desc(bv) : KI_NONE_KEY; k.i = mine ? bi : 0x7fffffff; k.pad = 0;
-        k = ki_wave_min(k);
-        if ((threadIdx.x & 63) == 0) {
-            const int slot = atomicAdd(&sm.pw_n[qq], 1);
-            sm.pw2_k[qq][slot] = k.k; sm.pw2_i[qq][slot] = k.i;
-        }
-    }
-    __syncthreads();
-    const int n = sm.pw_n[qq];
-    unsigned long long rk = sm.pw2_k[qq][0];
-    int ri = sm.pw2_i[qq][0];
-    for (int i = 1; i < n; i++) {
-        const unsigned long long k2 = sm.pw2_k[qq][i];
-        const int i2 = sm.pw2_i[qq][i];
-        const bool t = k2 < rk || (k2 == rk && i2 < ri);
-        rk = t ? k2 : rk;
-        ri = t ? i2 : ri;
-    }
-    const int pcol = ri;
-    double v = __longlong_as_double((long long)(~rk & 0x7fffffffffffffffull));  // (candidates are > precision > 0)
-    if (UNR) {  // the lane holding the winner knows the sign of its reduced cost
-#pragma unroll
-        for (int j = 0; j < CPT; j++)
-            if (pcol == c0 + j) sm.p_neg = (((unr >> j) & 1u) && x[j] < 0) ? 1 : 0;
-        __syncthreads();
-        *neg = sm.p_neg;
-        if (*neg) v = -v;
-    }
-    *value = v;
-    return pcol;
-}
-
 // Pricing (simplex.ts:118-219) by ONE wave over the LDS copy of the cost row.  The three-round version above costs every one of
 // the 16 waves its instructions and three barriers (4-4.5 k cycles per pivot, r01_d); here wave 0 walks the batches in order --
 // one batch (<= 64 columns for ld <= 4096) per step, a ballot says whether it holds a candidate -- and reduces only the first
@@ -461,7 +295,6 @@ struct ResRegs {
     int ppc, ppr, ppar, pending;
     unsigned unr;  // bit j: the variable of my column j is unrestricted (UNR builds)
     int neg;       // isReducedCostNegative of the entering column (phase 2, UNR builds)
-    int pq;        // parity of the next pricing call's LDS slots (price_row_2b)
     int pc, end_code, unbounded_col, hist_n, it1, it2;
     unsigned epoch;
     long long trace_n;
@@ -547,47 +380,6 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         //         below -precision (simplex.ts:39-49) -------------------------------------------------------------------
         bool has_pc = phase == 2 && colok && pc >= c0 && pc < c0 + CPT;
         double* colnow = DEFER ? sm.colq[par] : sm.col;
-        constexpr bool FASTA = PHASE == 2 && !DEFER && JSLP_RES_ONE_LANE_SUMMARY != 0;
-        if (FASTA) {
-            // the ONE lane holding the pivot column classifies my rows (column 0 has been waiting in LDS since the last update),
-            // merges the verdicts in row order, publishes the seven granules and names the row that can win: one barrier
-            if (has_pc) {
-#pragma unroll
-                for (int j = 0; j < CPT; j++)
-                    if (pc == c0 + j) {
-#pragma unroll
-                        for (int i = 0; i < ROWS; i++) sm.col[i] = a[i][j];
-                    }
-                FCand mine = fcand_none();
-#pragma unroll
-                for (int i = 0; i < ROWS; i++) {
-                    const int r = r_begin + i;
-                    const double colv = sm.col[i], rhs = sm.rhs[i];
-                    if (r >= 1 && r < r_end && !(-precision < colv && colv < precision)) {
-                        if (colv > 0 && precision > rhs && rhs > -precision) {
-                            if (r < mine.rdeg) { mine.rdeg = r; mine.kdeg = colv; }
-                        } else {
-                            const double quo = (UNR && R.neg) ? -rhs / colv : rhs / colv;
-                            if (quo > precision && mine.q > quo) { mine.q = quo; mine.r = r; mine.kq = colv; }
-                        }
-                    }
-                }
-                const u64_t qb = (u64_t)__double_as_longlong(mine.q), kqb = (u64_t)__double_as_longlong(mine.kq),
-                            kdb = (u64_t)__double_as_longlong(mine.kdeg);
-                u64_t* g = f.gran[par] + (long long)b * JSLP_R_GRAN;
-                const u64_t t32 = (u64_t)tag << 32;
-                AG_STORE(g + 0, t32 | (unsigned)qb);
-                AG_STORE(g + 1, t32 | (unsigned)(qb >> 32));
-                AG_STORE(g + 2, t32 | (unsigned)kqb);
-                AG_STORE(g + 3, t32 | (unsigned)(kqb >> 32));
-                AG_STORE(g + 4, t32 | (unsigned)kdb);
-                AG_STORE(g + 5, t32 | (unsigned)(kdb >> 32));
-                AG_STORE(g + 6, t32 | ((unsigned)mine.r | ((mine.rdeg == 0x7fffffff ? 0xffffu : (unsigned)mine.rdeg) << 16)));
-                sm.pubrow = mine.rdeg != 0x7fffffff ? mine.rdeg : mine.r;  // the only row of mine that can win
-            }
-            if (tid == 0) reset_reductions(sm);
-            __syncthreads();
-        } else {
         if (has_pc) {  // (conditional stores, not selects among register-array elements: those end up in scratch)
 #pragma unroll
             for (int j = 0; j < CPT; j++)
@@ -649,7 +441,6 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             if (tid == 0) sm.pubrow = mine.rdeg != 0x7fffffff ? mine.rdeg : mine.r;  // the only row of mine that can win
         }
         __syncthreads();
-        }  // !FASTA
         RT_MARK(0);
         // ---- B: publish that row (write-through 8-byte agent stores); its own flag follows the drain ---------------
         const int pubrow = sm.pubrow;
@@ -692,13 +483,6 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         };
         if (DEFER && R.pending && b == 0 && !sweeper) pend_apply_rest();
         if (allg) {
-            // the row flag first: it only has to follow this workgroup's row stores, and whoever needs the row reads the flag
-            // right after the decision -- raised behind the gather below it came ~4 k cycles later than it could
-            if (JSLP_RES_EARLY_ROWFLAG) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);
-            }
             // thread t polls granules t, t + blockDim, ... of the [G][8] array (adjacent lanes, adjacent granules: 64-byte requests)
             // until every tag matches; the payloads go to LDS, where lane w of the last four waves picks workgroup w's seven up
             const int NG = f.G * JSLP_R_GRAN;
@@ -728,7 +512,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { end_code = 5; break; }
-        if (tid == 0 && pubrow != 0 && !(allg && JSLP_RES_EARLY_ROWFLAG)) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: row is visible
+        if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: row is visible
         if (DEFER && R.pending && b != 0) pend_apply_rest();
         RT_MARK(2);
         // ---- D: the leader decides (winner, unboundedness, cycle check) and broadcasts three tagged granules -----------
@@ -828,24 +612,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         } else if (b == 0) {
             // (min rdeg) else (min q, then min r): each sweep wave reduces its 64 summaries with shuffles on the keys
             // only, the four wave results meet in LDS, the lane that holds the winner supplies its pivot-column entry
-            if (sweeper && JSLP_RES_DPP_DECIDE_LEADER) {
-                // DPP exchanges inside the 16-lane rows + readlanes across them (no ds_bpermute round trips): smallest quotient
-                // (positive doubles order like their bits), first row on ties; and the first degenerate row
-                KI x;
-                x.k = sc.qbits; x.i = sc.r != 0 ? sc.r : 0x7fffffff; x.pad = 0;
-                x = ki_wave_min(x);
-                int rdeg = sc.rdeg;
-                rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0xB1, 0xf, 0xf, false));
-                rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x4E, 0xf, 0xf, false));
-                rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x141, 0xf, 0xf, false));
-                rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x140, 0xf, 0xf, false));
-                rdeg = min(min(__builtin_amdgcn_readlane(rdeg, 0), __builtin_amdgcn_readlane(rdeg, 16)),
-                           min(__builtin_amdgcn_readlane(rdeg, 32), __builtin_amdgcn_readlane(rdeg, 48)));
-                if ((tid & 63) == 0) {
-                    const int wv = (tid - sweep0) >> 6;
-                    sm.w_q[wv] = x.k; sm.w_r[wv] = x.k == ~0ull ? 0 : x.i; sm.w_rdeg[wv] = rdeg;
-                }
-            } else if (sweeper) {
+            if (sweeper) {
                 u64_t q = sc.qbits;
                 int r = sc.r, rdeg = sc.rdeg;
 #pragma unroll
@@ -1124,8 +891,6 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             for (int j = 0; j < CPT; j++) R.pp[j] = p[j];
             R.pquot = quot; R.ppc = pc; R.ppr = pr; R.ppar = par; R.pending = 1;
         }
-        const int pc_now = pc;  // (the pipelined pricing below names the NEXT entering column while rows are still being updated)
-        const bool has_pc_now = has_pc;
         // (a macro, not a lambda: through a closure the register arrays a[][] / p[] / nz[] end up in scratch)
 #define JSLP_RES_UPDATE_ROWS(LO, HI)                                                                        \
         _Pragma("unroll") for (int i = (LO); i < (DEFER ? 0 : (HI)); i++) {                                 \
@@ -1143,78 +908,32 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             if (nonzero16(ki)) {                                                                            \
                 _Pragma("unroll") for (int j = 0; j < CPT; j++)                                             \
                     if (nz[j]) a[i][j] = eliminate(a[i][j], ki, p[j]);                                      \
-                if (has_pc_now) {                                                                           \
+                if (has_pc) {                                                                           \
                     const double nv = PARDIV ? sm.nv[i] : -ki / quot;                                       \
                     _Pragma("unroll") for (int j = 0; j < CPT; j++)                                         \
-                        if (pc_now == c0 + j) a[i][j] = nv;                                                 \
+                        if (pc == c0 + j) a[i][j] = nv;                                                 \
                 }                                                                                           \
             }                                                                                               \
         }
-        // Pricing of the NEXT pivot (step G) pipelined into the row update: its three LDS-atomic rounds are latency (an atomic,
-        // a barrier, a read back), the row update is instruction issue of all 16 waves -- a third of the rows goes between two
-        // rounds, so the waves work while the atomics fly.  Only the cost row (updated above) and the flags of the entering
-        // column (updated first, below) are needed to price.
-        constexpr bool PIPE = PHASE == 2 && !DEFER && JSLP_RES_PIPE_PRICE != 0 && !JSLP_RES_PRICE_W0 && !JSLP_RES_PRICE_DPP && !JSLP_RES_PRICE_2B &&
-                              !JSLP_RES_ONE_LANE_SUMMARY;
-        double g_bv = precision;
-        int g_bi = 0, g_bb = 0;
-        if (PIPE) {
-            if (UNR && has_pc_now) {
-#pragma unroll
-                for (int j = 0; j < CPT; j++)
-                    if (pc_now == c0 + j) R.unr = (R.unr & ~(1u << j)) | ((leaving_unr ? 1u : 0u) << j);
-            }
-#pragma unroll
-            for (int j = 0; j < CPT; j++) {  // my columns in order: earlier batch first, bigger value inside a batch, first index on ties
-                const int col = c0 + j;
-                const double val = (UNR && ((R.unr >> j) & 1u) && r0[j] < 0) ? -r0[j] : r0[j];
-                const bool ok = col >= 1 && col < W && val > precision;
-                const bool take = ok && (g_bi == 0 || pb[j] < g_bb || (pb[j] == g_bb && val > g_bv));
-                g_bv = take ? val : g_bv;
-                g_bi = take ? col : g_bi;
-                g_bb = take ? pb[j] : g_bb;
-            }
-            const unsigned long long m = __ballot(g_bi != 0);
-            if (m != 0ull) {  // batch ids grow with the lane index: the wave's earliest batch is that of its first candidate lane
-                const int first = __ffsll((long long)m) - 1;
-                const int wave_b = __builtin_amdgcn_readlane(g_bb, first);
-                if ((tid & 63) == 0) atomicMin(&sm.p_batch, wave_b);
-            }
-            JSLP_RES_UPDATE_ROWS(0, ROWS / 3)
-            __syncthreads();
-            const int wb = sm.p_batch;
-            const bool mine = wb != 0x7fffffff && g_bi != 0 && g_bb == wb;
-            const u64_t bits = (u64_t)__double_as_longlong(g_bv);
-            if (mine) atomicMax(&sm.p_val, bits);
-            JSLP_RES_UPDATE_ROWS(ROWS / 3, 2 * ROWS / 3)
-            __syncthreads();
-            if (mine && bits == sm.p_val) atomicMin(&sm.p_col, g_bi);
-            JSLP_RES_UPDATE_ROWS(2 * ROWS / 3, ROWS)
-        } else {
-            JSLP_RES_UPDATE_ROWS(0, ROWS)
-        }
+        JSLP_RES_UPDATE_ROWS(0, ROWS)
 #undef JSLP_RES_UPDATE_ROWS
-        if (FASTA && tid == 0) {  // column 0 of my (updated) rows, for the lane that will hold the next pivot column
-#pragma unroll
-            for (int i = 0; i < ROWS; i++) sm.rhs[i] = a[i][0];
-        }
         if (tid == 0) {  // every workgroup's LDS maps (simplex.ts:339-349)
-            const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc_now];
+            const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc];
             sm.lvibr[pr] = entering;
-            sm.lvibc[pc_now] = leaving;
+            sm.lvibc[pc] = leaving;
         }
         // workgroup 0 commits the basis change (simplex.ts:339-349)
         if (b == 0 && tid == 0) {
-            const int leaving = c.vibr[pr], entering = c.vibc[pc_now];
+            const int leaving = c.vibr[pr], entering = c.vibc[pc];
             c.vibr[pr] = entering;
-            c.vibc[pc_now] = leaving;
+            c.vibc[pc] = leaving;
             c.rbv[entering] = pr;
             c.rbv[leaving] = -1;
             c.cbv[entering] = -1;
-            c.cbv[leaving] = pc_now;
-            if (trace_n < c.trace_cap) c.trace[trace_n] = make_int2(pr, pc_now);
+            c.cbv[leaving] = pc;
+            if (trace_n < c.trace_cap) c.trace[trace_n] = make_int2(pr, pc);
         }
-        if (UNR && has_pc && !PIPE) {
+        if (UNR && has_pc) {
 #pragma unroll
             for (int j = 0; j < CPT; j++)
                 if (pc == c0 + j) {
@@ -1227,31 +946,8 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         epoch += 1;
         RT_MARK(6);
         // ---- G: phase 2: price the new cost row -> entering column of the next pivot -----------------------------------
-        if (PIPE) {  // the third round's result
-            __syncthreads();
-            const int wb = sm.p_batch;
-            int pcol = 0;
-            double v = 0.0;
-            if (wb != 0x7fffffff) {
-                pcol = sm.p_col;
-                v = __longlong_as_double((long long)sm.p_val);
-                if (UNR) {  // the lane holding the winner knows the sign of its reduced cost
-#pragma unroll
-                    for (int j = 0; j < CPT; j++)
-                        if (pcol == c0 + j) sm.p_neg = (((R.unr >> j) & 1u) && r0[j] < 0) ? 1 : 0;
-                    __syncthreads();
-                    R.neg = sm.p_neg;
-                    if (R.neg) v = -v;
-                }
-            }
-            k0 = v;
-            pc = pcol;
-            if (pc == 0) end_code = 1;
-        } else if (phase == 2) {
-            pc = JSLP_RES_PRICE_W0 ? price_row_w0<UNR>(c, sm, &k0, &R.neg)
-                 : (JSLP_RES_PRICE_DPP ? price_row_dpp<CPT, UNR>(r0, c0, pb, c, sm, &k0, R.unr, &R.neg)
-                    : (JSLP_RES_PRICE_2B ? price_row_2b<CPT, UNR>(r0, c0, pb, c, sm, &k0, R.unr, &R.neg, R.pq)
-                                     : price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &k0, R.unr, &R.neg)));
+        if (phase == 2) {
+            pc = JSLP_RES_PRICE_W0 ? price_row_w0<UNR>(c, sm, &k0, &R.neg) : price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &k0, R.unr, &R.neg);
             if (pc == 0) end_code = 1;
         }
     }
@@ -1338,7 +1034,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     for (int col = tid; col < c.W; col += (int)blockDim.x) sm.lvibc[col] = c.vibc[col];
     if (UNR)
         for (int v = tid; v < f.n_idx && v < JSLP_R_LUNR; v += (int)blockDim.x) sm.lunr[v] = c.unr[v];
-    if (tid == 0) { reset_reductions(sm); sm.pw_n[0] = 0; sm.pw_n[1] = 0; }
+    if (tid == 0) reset_reductions(sm);
     __syncthreads();
     // pricing batch of my columns (simplex.ts:118-127): fixed for the whole solve
     int pb[CPT];
@@ -1347,7 +1043,6 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     R.k0 = 0.0;  // reduced cost of the entering column = cost-row entry of column pc
     R.unr = 0;
     R.neg = 0;
-    R.pq = 0;
     R.pending = 0; R.ppc = 0; R.ppr = 0; R.ppar = 0; R.pquot = 1.0;
 #pragma unroll
     for (int j = 0; j < CPT; j++) R.pp[j] = 0.0;
@@ -1370,14 +1065,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
             for (int j = 0; j < CPT; j++)
                 if (c0 + j < ld) { sm.r0[c0 + j] = r0[j]; if (UNR) sm.unrc[c0 + j] = (R.unr >> j) & 1u; }
         }
-        if (JSLP_RES_ONE_LANE_SUMMARY && tid == 0) {  // column 0 of my rows waits in LDS for the lane that will hold the pivot column (step A)
-#pragma unroll
-            for (int i = 0; i < ROWS; i++) sm.rhs[i] = R.a[i][0];
-        }
-        R.pc = JSLP_RES_PRICE_W0 ? price_row_w0<UNR>(c, sm, &R.k0, &R.neg)
-               : (JSLP_RES_PRICE_DPP ? price_row_dpp<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg)
-                  : (JSLP_RES_PRICE_2B ? price_row_2b<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg, R.pq)
-                                   : price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg)));
+        R.pc = JSLP_RES_PRICE_W0 ? price_row_w0<UNR>(c, sm, &R.k0, &R.neg) : price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg);
         if (R.pc == 0) R.end_code = 1;
         else resident_phase<2, CPT, ROWS, UNR>(f, sm, R, it1_start, it2_start, pb);
     }
