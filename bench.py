@@ -90,8 +90,8 @@ def pmc_traffic(key, kernel, alg_bytes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--lp-size", dest="n", type=int, default=2000, help="variables = constraints of the dense LP (2000 = config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pivots", type=int, default=3000)
@@ -220,7 +220,11 @@ def main():
                         "bytes_per_unit": bytes_per_unit, "unit_of_work": "one pivot (16*H*W algorithmic bytes)",
                         "avg_unit_us": avg_s * 1e6, "units": launches, "timed_in": "the %d timed steps (HIP events on the engine's stream)" % args.steps,
                         "whole_step_frac": (bytes_per_unit * value / max(world, 1)) / HBM_PEAK,
-                        "rocprof_hbm_gb_s": (traffic / avg_s / 1e9) if traffic else None}
+                        "rocprof_hbm_gb_s": (traffic / avg_s / 1e9) if traffic else None,
+                        "note": "achieved = ALGORITHMIC bytes (16*H*W per pivot, SURVEY.md 8d) / measured kernel time per pivot.  The tableau "
+                                "stays in the chip's vector registers for the whole solve (k_simplex_resident), so this fraction is a figure of "
+                                "merit against a streaming implementation, not a bound (it may pass 1.0); what really crosses HBM is `traffic` "
+                                "(PMC) = candidate-row publication, and the kernel is bound by two fabric hand-offs + ~10 workgroup barriers per pivot"}
 
         extras = {}
         if not args.no_extras:
