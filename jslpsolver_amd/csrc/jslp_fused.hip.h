@@ -12,7 +12,7 @@
 // the updated rows are still in registers prepares pivot t+1: every workgroup re-derives the updated cost row
 // and prices it (same result everywhere), then its rows' ratio-test candidates and pivot-column entries.
 // Workgroup w owns `rpb` consecutive rows; lane pairs own two adjacent columns (16-byte accesses).
-// Preconditions checked by the host: phase 2, ld <= 4096 (two column tiles per lane), H <= 64 * 256, no optional objectives,
+// Preconditions checked by the host: phase 2, ld <= 4096 (two column tiles per lane), H <= 64 * 256,
 // precision >= 1e-15 (then the entering cost is never "tiny" and simplex.ts:381-383 always fires).
 // The cycle check is done by workgroup 0 alone; the other workgroups pivot speculatively into the OTHER
 // buffer, which is simply not adopted when the check (or unboundedness) stops the solve.
@@ -50,6 +50,9 @@ struct FusedCtx {
     // launch, so another workgroup reading them mid-launch could see either side of the swap
     uint8_t* ucol[2];
     uint8_t* urow[2];
+    // optional objectives (c.n_opt rows of ld doubles): ping-pong with the tableau buffers (oo[i] belongs to buf[i]); workgroup 0
+    // writes the updated rows, every workgroup reads the input side
+    double* oo[2];
 };
 
 __device__ __forceinline__ void fcand_consider(FCand& best, int r, double colv, double rhs, double precision, int neg = 0) {
@@ -119,6 +122,85 @@ __device__ __forceinline__ FCand fcand_block_reduce(FCand x, FSmem& sm) {
 // that column is unrestricted: it prices with |reduced cost| and hands isReducedCostNegative (*neg) to the ratio test
 // (simplex.ts:164-177, 282).  Returns the entering column (0 = optimal).
 #define JSLP_F_TW (2 * JSLP_F_THREADS)  // columns per tile
+
+// One cell of an optional objective row after the pivot (pr, pc) (simplex.ts:394-412: the same elimination as for the cost row,
+// but with exact `!== 0` tests, on the FINAL normalised pivot row entry pval)
+__device__ __forceinline__ double oo_cell_after(double rc, double coefficient, int col, int pc, double quot, double pval) {
+    if (coefficient != 0.0) {
+        if (col == pc) return -coefficient / quot;
+        if (pval != 0.0) return eliminate(rc, coefficient, pval);
+    }
+    return rc;
+}
+// workgroup 0: every optional objective row, input side -> output side
+template <int NT>
+__device__ __forceinline__ void fused_update_oo(const Ctx& c, const double* oo_in, double* oo_out, int c0, int pc, double quot,
+                                                const double2 (&p)[NT]) {
+    const int ld = c.ld, W = c.W;
+    for (int o = 0; o < c.n_opt; o++) {
+        const double* rin = oo_in + (long long)o * ld;
+        double* rout = oo_out + (long long)o * ld;
+        const double coefficient = rin[pc];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int ct = c0 + t * JSLP_F_TW;
+            if (ct >= ld) continue;
+            double2 rc = *reinterpret_cast<const double2*>(rin + ct);
+            if (ct < W) rc.x = oo_cell_after(rc.x, coefficient, ct, pc, quot, p[t].x);
+            if (ct + 1 < W) rc.y = oo_cell_after(rc.y, coefficient, ct + 1, pc, quot, p[t].y);
+            *reinterpret_cast<double2*>(rout + ct) = rc;
+        }
+    }
+}
+// simplex.ts:221-263: no column prices out on the main row -> the optional objectives break the tie, in priority order, among
+// the columns whose reduced cost is within +-precision on the main row and on every earlier objective.  x[] = the main cost row
+// (already updated); the objective rows are read from oo_in and, when `after` (a pivot (pr, pc) is being applied in this very
+// launch), brought up to date on the fly.  Returns the entering column (0 = none) and which row named it / its sign.
+template <int NT, bool UNR>
+__device__ __forceinline__ int price_optional(const double2 (&x)[NT], int c0, unsigned um, const Ctx& c, FSmem& sm, const double* oo_in,
+                                              bool after, int pc, double quot, const double2 (&p)[NT], int* neg) {
+    const double precision = c.precision;
+    const int ld = c.ld;
+    for (int o = 0; o < c.n_opt; o++) {
+        Cand best; best.v = precision; best.i = 0; best.b = 0;
+        int bneg = 0;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = c0 + t * JSLP_F_TW + j;
+                if (col < 1 || col >= c.W) continue;
+                const double rc0 = j ? x[t].y : x[t].x;
+                const double pval = j ? p[t].y : p[t].x;
+                bool deferred = -precision < rc0 && rc0 < precision;
+                for (int q = 0; deferred && q <= o; q++) {
+                    const double* rq = oo_in + (long long)q * ld;
+                    double v = rq[col];
+                    if (after) v = oo_cell_after(v, rq[pc], col, pc, quot, pval);
+                    if (q < o) { deferred = -precision < v && v < precision; continue; }
+                    if (-precision < v && v < precision) break;  // (q == o) this objective does not price the column out either
+                    const bool un = UNR && ((um >> (2 * t + j)) & 1u);
+                    const double val = (un && v < 0) ? -v : v;
+                    const bool take = val > best.v;  // strict: my columns ascend, ties keep the earlier one
+                    best.v = take ? val : best.v;
+                    best.i = take ? col : best.i;
+                    bneg = take ? ((un && v < 0) ? 1 : 0) : bneg;
+                }
+            }
+        const Cand e = block_reduce(best, PriceFirst(), sm.red);
+        if (e.i != 0) {
+            if (UNR) {
+                if (threadIdx.x == 0) sm.neg = 0;
+                __syncthreads();
+                if (best.i == e.i) sm.neg = bneg;  // (one lane holds that column)
+                __syncthreads();
+                *neg = sm.neg;
+            }
+            return e.i;
+        }
+    }
+    return 0;
+}
 template <int NT, bool UNR>
 __device__ __forceinline__ int price_row(const double2 (&x)[NT], int c0, unsigned um, const Ctx& c, FSmem& sm, int* neg) {
     // (candidates written out field by field: a struct select inside an unrolled loop was observed to keep the FIRST
@@ -182,7 +264,9 @@ __device__ __forceinline__ void st_stream(double* p, double2 v, int nt) {
 
 // NT: column tiles per lane (ld <= NT * 2048); UNR: unrestricted variables present (per-column flags read from the maps at the
 // top of every launch; the entering column's isReducedCostNegative travels with f_pc, bit 30)
-template <int NT, bool UNR>
+// OPT: optional objectives present (workgroup 0 keeps their rows up to date; they break pricing ties; an entering column they
+// name may have a ~0 main cost, and then the tiny-entry rule of simplex.ts:381-383 is not decidable here: ST_P1_SLOW, see k_fused_p1)
+template <int NT, bool UNR, bool OPT>
 __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int launch) {
     __shared__ FSmem sm;
     const Ctx& c = f.c;
@@ -260,7 +344,8 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
             if (c0 + t * JSLP_F_TW < ld) r0[t] = *reinterpret_cast<const double2*>(Min + c0 + t * JSLP_F_TW);
         }
         int neg = 0;
-        const int cn = price_row<NT, UNR>(r0, c0, um, c, sm, &neg);
+        int cn = price_row<NT, UNR>(r0, c0, um, c, sm, &neg);
+        if (OPT && cn == 0) cn = price_optional<NT, UNR>(r0, c0, um, c, sm, f.oo[0], false, 0, 1.0, r0, &neg);
         if (cn == 0) {  // already optimal (simplex.ts:265-269)
             if (b == 0 && tid == 0) {
                 copy_state(sout, sin); DevState& s = *sout;
@@ -367,6 +452,7 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
     // normalised pivot row in registers (simplex.ts:352-364; anyrow is true in phase 2, see header)
     double2 p[NT];
     bool v0[NT], v1[NT], has_pc[NT];
+    int tiny = 0;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const int ct = c0 + t * JSLP_F_TW;
@@ -382,7 +468,7 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
                     const bool innz = nonzero16(val);
                     v = innz ? val / quot : 0.0;
                     if (col == pc) v = 1.0 / quot;
-                    if (innz && !nonzero16(v) && v != 0.0) v = 0.0;
+                    if (innz && !nonzero16(v) && v != 0.0) { tiny = 1; v = 0.0; }
                 }
                 if (j) p[t].y = v; else p[t].x = v;
             }
@@ -390,6 +476,17 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
         v0[t] = nonzero16(p[t].x); v1[t] = nonzero16(p[t].y);
         has_pc[t] = ct < ld && ((pc == ct) || (pc == ct + 1));
     }
+    if (OPT) {  // (without optional objectives the entering cost is > precision: some other row always has an entry)
+        if (__syncthreads_or(tiny) && !nonzero16(k0)) {
+            if (b == 0 && tid == 0) {
+                copy_state(sout, sin); DevState& s = *sout;
+                s.status = ST_P1_SLOW; s.do_pivot = 0; s.f_final_buf = in_buf;
+            }
+            return;
+        }
+        if (b == 0) fused_update_oo<NT>(c, f.oo[in_buf], f.oo[in_buf ^ 1], c0, pc, quot, p);
+    }
+    (void)tiny;
     // updated cost row (every workgroup derives the same values), priced for pivot t+1
     double2 n0[NT];
 #pragma unroll
@@ -402,7 +499,8 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
         }
     }
     int neg = 0;
-    const int cn = price_row<NT, UNR>(n0, c0, um, c, sm, &neg);  // 0 => optimal after this pivot
+    int cn = price_row<NT, UNR>(n0, c0, um, c, sm, &neg);  // 0 => optimal after this pivot
+    if (OPT && cn == 0) cn = price_optional<NT, UNR>(n0, c0, um, c, sm, f.oo[in_buf], true, pc, quot, p, &neg);
 
     // ---- stream my rows ---------------------------------------------------------------------------
     FCand best = fcand_none();  // kept by lanes 0..7 of wave 0: lane i sees rows r_begin+i, +8, ... in order
@@ -664,6 +762,7 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_fused_p1(FusedCtx f, int lau
         }
         return;
     }
+    if (c.n_opt > 0 && b == 0) fused_update_oo<NT>(c, f.oo[in_buf], f.oo[in_buf ^ 1], c0, pc, quot, p);  // simplex.ts:394-412
     if (UNR) {  // the entering column inherits the leaving variable's flag; workgroup 0 hands the flag arrays on
         const bool leaving_unr = f.urow[launch & 1][pr] != 0;
 #pragma unroll
@@ -752,8 +851,9 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_fused_p1(FusedCtx f, int lau
     }
 }
 
-// after ST_P1_SLOW was adopted into the canonical state: k_select takes the next pivot
-__global__ void k_p1_resume(DevState* st) { st->status = ST_RUNNING; }
+// after ST_P1_SLOW was adopted into the canonical state: k_select takes the next pivot (status = ST_RUNNING); then, in phase 2,
+// the pipeline starts over from its first launch (status = ST_PHASE1_DONE)
+__global__ void k_p1_resume(DevState* st, int status) { st->status = status; }
 
 // End of the fused pipeline: adopt the final state and make buf[0] hold the final tableau.
 __global__ void __launch_bounds__(256) k_fused_finish(FusedCtx f, int last_launch) {
@@ -765,6 +865,8 @@ __global__ void __launch_bounds__(256) k_fused_finish(FusedCtx f, int last_launc
         const double2* src = reinterpret_cast<const double2*>(f.buf[1]);
         double2* dst = reinterpret_cast<double2*>(f.buf[0]);
         for (long long i = tid; i < n2; i += nt) dst[i] = src[i];
+        const long long no = (long long)f.c.n_opt * f.c.ld;  // the optional objectives travel with their buffer
+        for (long long i = tid; i < no; i += nt) f.oo[0][i] = f.oo[1][i];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         copy_state(f.c.st, fin);

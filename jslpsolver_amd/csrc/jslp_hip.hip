@@ -123,6 +123,7 @@ struct jslp_engine {
     // fused phase-2 pipeline (ping-pong buffer + per-workgroup candidates)
     double* f_buf1 = nullptr; FCand* f_cands[2] = {nullptr, nullptr}; double* f_pcol[2] = {nullptr, nullptr};
     uint8_t* f_uflags = nullptr;  // fused pipeline with unrestricted variables: 2 x (column flags | row flags)
+    double* f_oo1 = nullptr; int f_oo1_rows = 0;  // fused pipeline: the optional objectives' second (ping-pong) buffer
     long long p1_slow_pivots = 0;  // pivots the fused phase 1 handed to k_select + k_update (tiny pivot-row entries, see k_fused_p1)
     DevState* f_st[2] = {nullptr, nullptr};
     // register-resident phase 2 (one cooperative launch): hand-off buffers
@@ -530,6 +531,7 @@ extern "C" void jslp_engine_destroy(jslp_engine* e) {
     drop_checkpoints(e, 1);
     hipFree(e->arena32);
     hipFree(e->f_uflags);
+    hipFree(e->f_oo1);
     hipFree(e->f_buf1); hipFree(e->f_cands[0]); hipFree(e->f_cands[1]); hipFree(e->f_pcol[0]); hipFree(e->f_pcol[1]);
     hipFree(e->f_st[0]); hipFree(e->f_st[1]);
     hipFree(e->d_cuts); if (e->h_cuts) hipHostFree(e->h_cuts);
@@ -725,7 +727,7 @@ static bool use_wg_single(const jslp_engine* e) {
 // the fused one-launch-per-pivot phase 2 (see k_pivot_fused for the preconditions)
 static bool fused_eligible(const jslp_engine* e) {
     if (e->force_path == 2) return false;
-    return e->n_opt == 0 && e->ld <= 2 * JSLP_F_TW && e->cap_rows <= 64 * JSLP_F_MAXG && e->precision >= 1e-15;
+    return e->ld <= 2 * JSLP_F_TW && e->cap_rows <= 64 * JSLP_F_MAXG && e->precision >= 1e-15;
 }
 
 // Geometry of the register-resident kernel for this tableau: lanes x columns per lane must cover a row (ld), rows per
@@ -795,6 +797,16 @@ static int ensure_fused(jslp_engine* e) {
     return JSLP_OK;
 }
 
+static int ensure_fused_oo(jslp_engine* e) {  // (the number of optional objectives is set per model, after create())
+    if (e->n_opt <= e->f_oo1_rows) return JSLP_OK;
+    HIPC(hipStreamSynchronize(e->stream));
+    hipFree(e->f_oo1);
+    e->f_oo1 = nullptr; e->f_oo1_rows = 0;
+    HIPC(hipMalloc(&e->f_oo1, sizeof(double) * (size_t)e->n_opt * e->ld));
+    HIPC(hipMemsetAsync(e->f_oo1, 0, sizeof(double) * (size_t)e->n_opt * e->ld, e->stream));
+    e->f_oo1_rows = e->n_opt;
+    return JSLP_OK;
+}
 static FusedCtx make_fused_ctx(const jslp_engine* e, const Ctx& c, int H) {
     FusedCtx f;
     f.c = c;
@@ -808,6 +820,7 @@ static FusedCtx make_fused_ctx(const jslp_engine* e, const Ctx& c, int H) {
         f.ucol[i] = e->f_uflags + (size_t)i * ((size_t)e->ld + e->cap_rows);
         f.urow[i] = f.ucol[i] + e->ld;
     }
+    f.oo[0] = e->s.oo; f.oo[1] = e->f_oo1;
     return f;
 }
 static int fused_p1_on() {  // phase 1 of the large LPs through k_fused_p1 (one launch per pivot) instead of k_select + k_update
@@ -1036,6 +1049,8 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
         if (fused && fused_p1_on()) {
             int r = ensure_fused(e);
             if (r) return r;
+            r = ensure_fused_oo(e);
+            if (r) return r;
             const FusedCtx f = make_fused_ctx(e, c, H);
             void (*kp1)(FusedCtx, int) = e->ld <= JSLP_F_TW ? (e->n_unr > 0 ? k_fused_p1<1, true> : k_fused_p1<1, false>)
                                                            : (e->n_unr > 0 ? k_fused_p1<2, true> : k_fused_p1<2, false>);
@@ -1056,7 +1071,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                 HIPC(hipGetLastError());
                 if (e->h_state->status != ST_P1_SLOW) break;
                 // the one pivot k_fused_p1 cannot decide alone (see there): k_select + k_update, then the pipeline again
-                hipLaunchKernelGGL(k_p1_resume, dim3(1), dim3(1), 0, s, e->s.st);
+                hipLaunchKernelGGL(k_p1_resume, dim3(1), dim3(1), 0, s, e->s.st, (int)ST_RUNNING);
                 hipLaunchKernelGGL(k_select, dim3(1), dim3(JSLP_WG_THREADS), 0, s, c);
                 hipLaunchKernelGGL(k_update, grid, dim3(JSLP_UPD_THREADS), 0, s, c);
                 HIPC(hipGetLastError());
@@ -1098,14 +1113,20 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             chunk = std::min(chunk * 2, 256);
         }
         // ---- phase 2: one fused launch per pivot ----------------------------------------------------------
-        if (e->h_state->status == ST_PHASE1_DONE) {
+        while (e->h_state->status == ST_PHASE1_DONE) {
             int r = ensure_fused(e);
+            if (r) return r;
+            r = ensure_fused_oo(e);
             if (r) return r;
             e->last_path = "fused";
             const FusedCtx f = make_fused_ctx(e, c, H);
-            // column tiles per lane (ld <= 2048: one) x unrestricted variables present
-            void (*kfused)(FusedCtx, int) = e->ld <= JSLP_F_TW ? (e->n_unr > 0 ? k_pivot_fused<1, true> : k_pivot_fused<1, false>)
-                                                              : (e->n_unr > 0 ? k_pivot_fused<2, true> : k_pivot_fused<2, false>);
+            // column tiles per lane (ld <= 2048: one) x unrestricted variables present x optional objectives present
+            const bool unr = e->n_unr > 0, opt = e->n_opt > 0;
+            void (*kfused)(FusedCtx, int) =
+                e->ld <= JSLP_F_TW ? (unr ? (opt ? k_pivot_fused<1, true, true> : k_pivot_fused<1, true, false>)
+                                          : (opt ? k_pivot_fused<1, false, true> : k_pivot_fused<1, false, false>))
+                                   : (unr ? (opt ? k_pivot_fused<2, true, true> : k_pivot_fused<2, true, false>)
+                                          : (opt ? k_pivot_fused<2, false, true> : k_pivot_fused<2, false, false>));
             int launch = 0;
             hipLaunchKernelGGL(kfused, dim3(f.G), dim3(JSLP_F_THREADS), 0, s, f, launch);
             launch++;
@@ -1132,16 +1153,33 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                     e->upd_launches += real;
                     it2_prev = st.it2;
                 }
-                if (st.status == ST_DONE) break;
+                if (st.status != ST_RUNNING) break;
                 chunk = std::min(chunk * 2, 512);
             }
             hipLaunchKernelGGL(k_fused_finish, dim3(512), dim3(256), 0, s, f, launch - 1);
             HIPC(hipGetLastError());
+            if (e->h_state->status == ST_P1_SLOW) {
+                // an entering column named by an optional objective with a ~0 main cost and a tiny pivot-row entry: that ONE pivot
+                // through k_select + k_update (see k_pivot_fused), then the pipeline again from its first launch
+                hipLaunchKernelGGL(k_p1_resume, dim3(1), dim3(1), 0, s, e->s.st, (int)ST_RUNNING);
+                hipLaunchKernelGGL(k_select, dim3(1), dim3(JSLP_WG_THREADS), 0, s, c);
+                hipLaunchKernelGGL(k_update, grid, dim3(JSLP_UPD_THREADS), 0, s, c);
+                HIPC(hipGetLastError());
+                HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+                HIPC(hipStreamSynchronize(s));
+                e->p1_slow_pivots += 1;
+                if (e->h_state->status != ST_RUNNING) break;  // that pivot ended the solve
+                hipLaunchKernelGGL(k_p1_resume, dim3(1), dim3(1), 0, s, e->s.st, (int)ST_PHASE1_DONE);
+                e->h_state->status = ST_PHASE1_DONE;
+                continue;
+            }
             HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
             if (e->counting) {  // the fused launches stream every cell (phase 1 went through k_select: counted on the device)
                 e->wc.gated_cells += (long long)e->h_state->it2 * (long long)(H - 1) * e->W;
                 e->wc.gated_rows += (long long)e->h_state->it2 * (long long)(H - 1);
             }
+            HIPC(hipStreamSynchronize(s));
+            break;
         }
         }  // !resident_done
         HIPC(hipEventRecord(e->ev_end, s));
