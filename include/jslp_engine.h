@@ -138,8 +138,10 @@ int jslp_engine_relax(jslp_engine* e, int32_t n_cuts, const int8_t* type, const 
  * The same for a batch of independent branch-and-bound nodes (each a pure function of the saved root and
  * its cut list): node i owns cuts [cut_offsets[i], cut_offsets[i+1]).  Results land in
  * out[i]; rhs / var_index_by_row are n_nodes x out_stride arrays (row i = node i, first out[i].height
- * entries valid).  The engine's own tableau is left holding the LAST node.  This is the unit that shards
- * across GPUs (one engine per rank, disjoint node ranges).
+ * entries valid).  Afterwards the engine's own (live) tableau holds ONE of the batch's nodes -- which one is
+ * unspecified (the nodes are spread over tableau copies, the live one being the first of them): restore() before
+ * using it; the engine's evaluation is the last node's.  This is the unit that shards across GPUs (one engine per
+ * rank, disjoint node ranges).
  */
 int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
                             const int32_t* var_index, const double* value, int check_cycles,
@@ -151,9 +153,6 @@ int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
  * point at n_nodes x *out_stride arrays (row i = node i, first out[i].height entries valid) that remain valid until
  * the next call on this engine; pass NULL for what is not needed (less PCIe traffic).  Same semantics otherwise.
  * *out_stride is the engine's choice (>= the row capacity; padded so that every node's slice is 16-byte aligned).
- * "The engine's own tableau is left holding the last node" reads here: of the nodes the first of its tableau copies
- * evaluated (a large batch is spread over as many copies as the chip keeps workgroups resident, each pulling the next
- * node from a queue): restore() before using the live tableau again.
  */
 int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
                                    const int32_t* var_index, const double* value, int check_cycles,
