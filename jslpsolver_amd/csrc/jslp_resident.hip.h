@@ -25,19 +25,17 @@
 #define JSLP_R_LDMAX 4096    // widest padded row any geometry takes (512 lanes x 8 columns)
 #define JSLP_R_LUNR 8192     // variable indexes whose unrestricted flag fits the LDS copy (more: gather-by-leader protocol)
 #define JSLP_R_LHIST 10240   // cycle-check history entries kept in LDS (80 KB)
-#ifndef JSLP_RES_DEFER
-#define JSLP_RES_DEFER 0     // 1: phase 2 keeps a pivot's row update pending until the next summary is out -- MEASURED SLOWER in both placements (before the drain: 96.0 k, behind the sweep / decision wait: 89.9 k, against 102.5 k pivots/s, r02_r / r02_s): the wait it was meant to fill is not idle enough
-#endif
-#ifndef JSLP_RES_PRICE_W0
-#define JSLP_RES_PRICE_W0 0  // 1: pricing by one wave over an LDS copy of the cost row -- MEASURED SLOWER (93.2 k vs 103.2 k pivots/s on config 3a, r02_q: the wave walks up to 40 batches before it meets a candidate); 0: three LDS-atomic rounds by all waves
-#endif
 #ifndef JSLP_RES_FAST
 #define JSLP_RES_FAST 1      // one barrier around the row flag (step E); the -k/quot entries of the pivot column computed by eight lanes in parallel while the winning row is in flight instead of one after the other by the lane that owns the column (step F)
 #endif
 #ifndef JSLP_RES_ALLGATHER
 #define JSLP_RES_ALLGATHER 1  // no unrestricted variables, cycle check off (both phases): EVERY workgroup gathers the <= 256 summaries itself (coalesced: thread t polls granules t, t + blockDim, ...; the payloads meet in LDS) and takes the leader's decision redundantly -- the decision broadcast and its poll (one fabric hop) disappear
 #endif
-// Measured in round 2 and dropped (the code is in the history: commits 57ce867 ... 31f93eb), config 3a, 2001 x 2001:
+// Measured in round 2 and dropped (the code is in the history: commits 46ab798 ... 31f93eb), config 3a, 2001 x 2001:
+//   * the row update of a pivot kept pending until the next summary is out (two placements): 96.0 k and 89.9 k against 102.5 k
+//     pivots/s (the wait it was meant to fill is not idle enough);
+//   * pricing by ONE wave over an LDS copy of the cost row: 93.2 k against 103.2 k pivots/s (the wave walks up to 40 batches
+//     before it meets a candidate);
 //   * pricing with one DPP (batch, key, index) reduction per wave and one barrier: 7.5 k against 3.8 k cycles per pivot (all 16
 //     waves pay the wave stage and the 16-entry scan; the three LDS-atomic rounds keep 15 of them parked);
 //   * pricing in two barriers (batch by ballot + LDS atomic, then a DPP (key, column) reduction in the one or two waves holding
@@ -100,11 +98,6 @@ struct RSmem {
     int32_t kind[JSLP_R_MAXROWS];
     double col[JSLP_R_MAXROWS];  // my rows' entries in the pivot column / in column 0
     double rhs[JSLP_R_MAXROWS];
-    double colq[2][JSLP_R_MAXROWS];  // deferred row update: pivot-column entries of my rows, by pivot parity
-    // pricing by ONE wave (price_row_w0): every lane mirrors its columns of the cost row here after each update
-    double p_k0;                  // signed reduced cost of the entering column
-    double r0[JSLP_RES_PRICE_W0 ? JSLP_R_LDMAX : 2];
-    uint8_t unrc[JSLP_RES_PRICE_W0 ? JSLP_R_LDMAX : 2];   // UNR builds: the column's variable is unrestricted
     // All-gather protocol: what only workgroup 0 knows in the gather-by-leader protocol lives in EVERY workgroup's LDS -- the
     // row / column maps (swapped at every pivot like the global ones), the unrestricted flag of every variable index, and the
     // cycle-check history (the first JSLP_R_LHIST entries; a longer solve continues with the leader protocol, whose check
@@ -206,49 +199,6 @@ __device__ __forceinline__ int price_row_lds(const double (&x)[CPT], int c0, con
     return pcol;
 }
 
-// Pricing (simplex.ts:118-219) by ONE wave over the LDS copy of the cost row.  The three-round version above costs every one of
-// the 16 waves its instructions and three barriers (4-4.5 k cycles per pivot, r01_d); here wave 0 walks the batches in order --
-// one batch (<= 64 columns for ld <= 4096) per step, a ballot says whether it holds a candidate -- and reduces only the first
-// batch that does: largest value, first index (a DPP (key, index) minimum).  One barrier hands (pc, signed reduced cost,
-// isReducedCostNegative) to everybody.  Returns the column (0 = optimal).
-template <bool UNR>
-__device__ __forceinline__ int price_row_w0(const Ctx& c, RSmem& sm, double* value, int* neg) {
-    __syncthreads();  // every lane's mirror writes of this pivot are in LDS
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x, W = c.W;
-        const int B = c.use_partial ? c.batch : (W - 1 > 0 ? W - 1 : 1);
-        int pcol = 0;
-        for (int base = 1; base < W && pcol == 0; base += B) {
-            const int end = min(base + B, W);
-            KI best = ki_none();
-            for (int s0 = base; s0 < end; s0 += 64) {  // (one step whenever the batch fits the wave)
-                const int col = s0 + lane;
-                if (col < end) {
-                    const double rc = sm.r0[col];
-                    const double val = (UNR && sm.unrc[col] && rc < 0) ? -rc : rc;
-                    if (val > c.precision) {
-                        const unsigned long long k = key_desc(val);
-                        if (k < best.k) { best.k = k; best.i = col; }  // my columns ascend: ties keep the earlier one
-                    }
-                }
-            }
-            if (__ballot(best.k != KI_NONE_KEY) == 0ull) continue;
-            best = ki_wave_min(best);
-            pcol = best.i;
-        }
-        if (lane == 0) {
-            sm.p_col = pcol;
-            const double rc = pcol ? sm.r0[pcol] : 0.0;
-            sm.p_k0 = rc;
-            sm.p_neg = (UNR && pcol && sm.unrc[pcol] && rc < 0) ? 1 : 0;
-        }
-    }
-    __syncthreads();
-    *value = sm.p_k0;
-    if (UNR) *neg = sm.p_neg;
-    return sm.p_col;
-}
-
 #ifdef JSLP_DEBUG_RESIDENT
 #define RT_MARK(i) do { const u64_t _now = __builtin_amdgcn_s_memtime(); rt_acc[i] += _now - rt_prev; rt_prev = _now; } while (0)
 #else
@@ -288,11 +238,6 @@ struct ResRegs {
     double a[ROWS][CPT];  // my rows: CPT adjacent columns per lane
     double r0[CPT];              // my copy of the cost row
     double k0;
-    // deferred row update (phase 2, JSLP_RES_DEFER): the last pivot's normalised row / pivot element / column / row / parity;
-    // the cost row r0 is always current, the rows a[][] lag one pivot behind until the next summary is out
-    double pp[CPT];
-    double pquot;
-    int ppc, ppr, ppar, pending;
     unsigned unr;  // bit j: the variable of my column j is unrestricted (UNR builds)
     int neg;       // isReducedCostNegative of the entering column (phase 2, UNR builds)
     int pc, end_code, unbounded_col, hist_n, it1, it2;
@@ -342,29 +287,6 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
     const int pub_bytes = f.G * ld * 8;
     const auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_bytes, 0x00020000);
     const auto rsrc1 = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[1], 0, pub_bytes, 0x00020000);
-    // Deferred row update (phase 2).  A pivot's chain is: decision -> winner's row -> cost row -> pricing -> MY rows' entries in
-    // the new entering column and in column 0 -> summary -> (fabric) -> leader.  The elimination of my 8 x CPT cells per lane
-    // (~3 k cycles, step F) sat in the middle of that chain although the summary needs only TWO columns of it.  So the update
-    // of a pivot is kept pending: the owners of the two columns evaluate their updated entries on the fly (same operations,
-    // same bits), the summary and the one row that can win (updated first) go out, and the rest of the rows are updated while
-    // the row stores drain and the leader gathers -- time every workgroup used to spend waiting.
-    constexpr bool DEFER = PHASE == 2 && JSLP_RES_DEFER != 0;
-    auto pend_cell = [&](int i, int j, double x) -> double {  // a[i][j] once the pending pivot is applied (x = a[i][j])
-        const int r = r_begin + i;
-        if (r >= r_end) return x;
-        if (r == 0) return r0[j];       // the cost row's copy in workgroup 0
-        if (r == R.ppr) return R.pp[j];
-        const double ki = sm.colq[R.ppar][i];
-        if (nonzero16(ki)) {
-            if (nonzero16(R.pp[j])) x = eliminate(x, ki, R.pp[j]);
-            if (R.ppc == c0 + j) x = -ki / R.pquot;
-        }
-        return x;
-    };
-    auto pend_apply_row = [&](int i) {
-#pragma unroll
-        for (int j = 0; j < CPT; j++) a[i][j] = pend_cell(i, j, a[i][j]);
-    };
     int okslot = 0;
     while (end_code == 0) {
         if ((it1 - it1_start) + (it2 - it2_start) >= f.iters_cap) { end_code = 4; break; }
@@ -379,18 +301,18 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         // ---- A: my rows' summary: phase 2 = ratio test for column pc (simplex.ts:276-296); phase 1 = most negative RHS
         //         below -precision (simplex.ts:39-49) -------------------------------------------------------------------
         bool has_pc = phase == 2 && colok && pc >= c0 && pc < c0 + CPT;
-        double* colnow = DEFER ? sm.colq[par] : sm.col;
+        double* colnow = sm.col;
         if (has_pc) {  // (conditional stores, not selects among register-array elements: those end up in scratch)
 #pragma unroll
             for (int j = 0; j < CPT; j++)
                 if (pc == c0 + j) {
 #pragma unroll
-                    for (int i = 0; i < ROWS; i++) colnow[i] = (DEFER && R.pending) ? pend_cell(i, j, a[i][j]) : a[i][j];
+                    for (int i = 0; i < ROWS; i++) colnow[i] = a[i][j];
                 }
         }
         if (tid == 0) {
 #pragma unroll
-            for (int i = 0; i < ROWS; i++) sm.rhs[i] = (DEFER && R.pending) ? pend_cell(i, 0, a[i][0]) : a[i][0];
+            for (int i = 0; i < ROWS; i++) sm.rhs[i] = a[i][0];
             reset_reductions(sm);
         }
         __syncthreads();
@@ -444,11 +366,6 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         RT_MARK(0);
         // ---- B: publish that row (write-through 8-byte agent stores); its own flag follows the drain ---------------
         const int pubrow = sm.pubrow;
-        if (DEFER && R.pending) {  // the one row that goes out must be current
-#pragma unroll
-            for (int i = 0; i < ROWS; i++)
-                if (r_begin + i == pubrow) pend_apply_row(i);  // uniform
-        }
         if (pubrow != 0 && colok) {
             const int off = (b * ld + c0) * 8;
 #pragma unroll
@@ -472,16 +389,8 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         SweptCand sc;
         sc.qbits = ~0ull; sc.kq = 0; sc.kdeg = 0; sc.r = 0; sc.rdeg = 0x7fffffff;
         // all-gather by every workgroup (JSLP_RES_ALLGATHER): no leader, no decision broadcast
-        const bool allg = !DEFER && JSLP_RES_ALLGATHER != 0 && (!UNR || f.n_idx <= JSLP_R_LUNR) && (!c.check_cycles || (hist_n < JSLP_R_LHIST && hist_n < c.hist_cap));
+        const bool allg = JSLP_RES_ALLGATHER != 0 && (!UNR || f.n_idx <= JSLP_R_LUNR) && (!c.check_cycles || (hist_n < JSLP_R_LHIST && hist_n < c.hist_cap));
         const bool sweeper = b == 0 && !allg && tid >= sweep0;
-        // ... and the rest of my rows where it costs nobody anything: the leader's other waves while its sweepers gather, every
-        // other workgroup after its row flag is up (while it waits for the decision), the sweepers after they have broadcast it
-        auto pend_apply_rest = [&]() {
-#pragma unroll
-            for (int i = 0; i < ROWS; i++)
-                if (r_begin + i != pubrow) pend_apply_row(i);
-        };
-        if (DEFER && R.pending && b == 0 && !sweeper) pend_apply_rest();
         if (allg) {
             // thread t polls granules t, t + blockDim, ... of the [G][8] array (adjacent lanes, adjacent granules: 64-byte requests)
             // until every tag matches; the payloads go to LDS, where lane w of the last four waves picks workgroup w's seven up
@@ -513,7 +422,6 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { end_code = 5; break; }
         if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: row is visible
-        if (DEFER && R.pending && b != 0) pend_apply_rest();
         RT_MARK(2);
         // ---- D: the leader decides (winner, unboundedness, cycle check) and broadcasts three tagged granules -----------
         int pr = 0, stop = 0;
@@ -695,8 +603,6 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             quot = __longlong_as_double((long long)((u64_t)sm.dec[1] | ((u64_t)sm.dec[2] << 32)));
         }
         const bool leaving_unr = UNR && ((sm.dec[0] >> 24) & 1u);
-        if (DEFER && R.pending && sweeper) pend_apply_rest();
-        if (DEFER) R.pending = 0;
         RT_MARK(3);
         if (stop == 3) { end_code = 2; unbounded_col = pc; break; }
         if (stop == 1) { end_code = 3; break; }
@@ -708,7 +614,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         }
         // the entries the pivot column itself receives (-k / quot, simplex.ts:386; row 0: -k0 / quot): one lane each, now, while
         // the winning row is in flight -- the lane that owns the column would run these divisions one after the other in step F
-        constexpr bool PARDIV = PHASE == 2 && !DEFER && JSLP_RES_FAST != 0;
+        constexpr bool PARDIV = PHASE == 2 && JSLP_RES_FAST != 0;
         if (PARDIV && tid <= ROWS) sm.nv[tid] = -(tid < ROWS ? sm.col[tid] : k0) / quot;
         // ---- E: the winning row: loaded speculatively together with its flag; re-loaded in the rare case the flag
         //         (which follows the winner's drain) was not up yet ------------------------------------------------------
@@ -881,19 +787,9 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                     if (pc == c0 + j) r0[j] = nv;
             }
         }
-        if (JSLP_RES_PRICE_W0 && phase == 2 && colok) {  // the LDS copy the next pricing reads
-#pragma unroll
-            for (int j = 0; j < CPT; j += 2)
-                if (c0 + j < ld) *reinterpret_cast<double2*>(&sm.r0[c0 + j]) = make_double2(r0[j], r0[j + 1]);
-        }
-        if (DEFER) {  // keep this pivot pending: the rows are updated after the next summary is out
-#pragma unroll
-            for (int j = 0; j < CPT; j++) R.pp[j] = p[j];
-            R.pquot = quot; R.ppc = pc; R.ppr = pr; R.ppar = par; R.pending = 1;
-        }
         // (a macro, not a lambda: through a closure the register arrays a[][] / p[] / nz[] end up in scratch)
 #define JSLP_RES_UPDATE_ROWS(LO, HI)                                                                        \
-        _Pragma("unroll") for (int i = (LO); i < (DEFER ? 0 : (HI)); i++) {                                 \
+        _Pragma("unroll") for (int i = (LO); i < (HI); i++) {                                               \
             const int r = r_begin + i;                                                                      \
             if (r >= r_end) continue;                                                                       \
             if (r == 0) { /* workgroup 0 owns the cost row */                                               \
@@ -938,7 +834,6 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             for (int j = 0; j < CPT; j++)
                 if (pc == c0 + j) {
                     R.unr = (R.unr & ~(1u << j)) | ((leaving_unr ? 1u : 0u) << j);
-                    if (JSLP_RES_PRICE_W0) sm.unrc[pc] = leaving_unr ? 1 : 0;
                 }
         }
         trace_n += 1;
@@ -947,14 +842,9 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         RT_MARK(6);
         // ---- G: phase 2: price the new cost row -> entering column of the next pivot -----------------------------------
         if (phase == 2) {
-            pc = JSLP_RES_PRICE_W0 ? price_row_w0<UNR>(c, sm, &k0, &R.neg) : price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &k0, R.unr, &R.neg);
+            pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &k0, R.unr, &R.neg);
             if (pc == 0) end_code = 1;
         }
-    }
-    if (DEFER && R.pending) {  // the solve ended with a pivot still pending (optimal after it, iteration cap): bring the rows up to date
-#pragma unroll
-        for (int i = 0; i < ROWS; i++) pend_apply_row(i);
-        R.pending = 0;
     }
 }
 
@@ -1043,9 +933,6 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     R.k0 = 0.0;  // reduced cost of the entering column = cost-row entry of column pc
     R.unr = 0;
     R.neg = 0;
-    R.pending = 0; R.ppc = 0; R.ppr = 0; R.ppar = 0; R.pquot = 1.0;
-#pragma unroll
-    for (int j = 0; j < CPT; j++) R.pp[j] = 0.0;
     if (UNR) {  // which of my columns carry an unrestricted variable (model.unrestrictedVariables, tableau.ts:57)
 #pragma unroll
         for (int j = 0; j < CPT; j++)
@@ -1060,12 +947,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
         if (R.end_code == 0) phase = 2;
     }
     if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
-        if (JSLP_RES_PRICE_W0 && colok) {  // phase 1 may have changed every column: mirror the whole cost row (and the flags)
-#pragma unroll
-            for (int j = 0; j < CPT; j++)
-                if (c0 + j < ld) { sm.r0[c0 + j] = r0[j]; if (UNR) sm.unrc[c0 + j] = (R.unr >> j) & 1u; }
-        }
-        R.pc = JSLP_RES_PRICE_W0 ? price_row_w0<UNR>(c, sm, &R.k0, &R.neg) : price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg);
+        R.pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg);
         if (R.pc == 0) R.end_code = 1;
         else resident_phase<2, CPT, ROWS, UNR>(f, sm, R, it1_start, it2_start, pb);
     }
