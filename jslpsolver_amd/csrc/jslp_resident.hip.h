@@ -45,6 +45,10 @@
 //   * the pricing rounds of the next pivot interleaved with thirds of the row update: 120.1 k against 123.4 k pivots/s;
 //   * the row flag raised before the gather instead of behind it: no faster (step E0 is one fabric round trip either way);
 //   * 256-lane geometries (one wave per SIMD, 512 registers per lane): 72.5 k against 105.7 k pivots/s;
+//   * no speculative candidate rows (leaderless protocol): the owner of the winning row publishes it after the decision as tagged
+//     8-byte granules the others poll -- 0.77 MB instead of 4.19 MB of HBM traffic per pivot (PMC), but 50.4 k against 123 k
+//     pivots/s: the narrow sc1 stores and 256 workgroups polling 2 x 2001 granules cost more than the hop they replace (and the
+//     mere presence of the branch cost the default path 9 %: 112.8 k);
 //   * DPP reductions in the LEADER's decision: wrong for phase 1, whose keys are negative (bits order positive doubles only).
 #ifndef JSLP_RES_DPP_DECIDE
 #define JSLP_RES_DPP_DECIDE 3  // all-gather protocol (phase 2: quotients > 0): bit 0 = (quotient, row) minimum, bit 1 = first degenerate row, by DPP exchanges + readlanes instead of ds_bpermute shuffles (120.9 k vs 119.2 k pivots/s, r02_x)
