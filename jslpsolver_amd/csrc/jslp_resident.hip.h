@@ -256,7 +256,7 @@ struct ResRegs {
 // One phase of the solve.  PHASE is a compile-time constant so that the phase-2 loop -- the hot one -- carries none of
 // the phase-1 branches; returns when the solve ends (R.end_code != 0) or, for PHASE == 1, when phase 1 is over
 // (end_code stays 0 and the caller starts phase 2).
-template <int PHASE, int CPT, int ROWS, bool UNR>
+template <int PHASE, int THREADS, int CPT, int ROWS, bool UNR>
 __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start,
                                                const int (&pb)[CPT]) {
     const Ctx& c = f.c;
@@ -399,12 +399,13 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             // thread t polls granules t, t + blockDim, ... of the [G][8] array (adjacent lanes, adjacent granules: 64-byte requests)
             // until every tag matches; the payloads go to LDS, where lane w of the last four waves picks workgroup w's seven up
             const int NG = f.G * JSLP_R_GRAN;
-            u64_t x[4];
+            constexpr int NQ = (JSLP_F_MAXG * JSLP_R_GRAN + THREADS - 1) / THREADS;  // granules per thread: 2 at 1024 lanes, 4 at 512
+            u64_t x[NQ];
             unsigned spins = 0;
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < NQ; q++) {
                     const int g = tid + q * (int)blockDim.x;
                     const bool used = g < NG && (g & (JSLP_R_GRAN - 1)) != JSLP_R_GRAN - 1;
                     x[q] = used ? AG_LOAD(f.gran[par] + g) : ((u64_t)tag << 32);
@@ -417,7 +418,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                 if (spins > f.spin_limit) { if ((tid & 63) == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NQ; q++) {
                 const int g = tid + q * (int)blockDim.x;
                 if (g < JSLP_F_MAXG * JSLP_R_GRAN) sm.gsum[g] = (unsigned)x[q];
             }
@@ -947,13 +948,13 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     R.unbounded_col = 0;
     R.epoch = 0;
     if (phase == 1) {
-        resident_phase<1, CPT, ROWS, UNR>(f, sm, R, it1_start, it2_start, pb);
+        resident_phase<1, THREADS, CPT, ROWS, UNR>(f, sm, R, it1_start, it2_start, pb);
         if (R.end_code == 0) phase = 2;
     }
     if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
         R.pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg);
         if (R.pc == 0) R.end_code = 1;
-        else resident_phase<2, CPT, ROWS, UNR>(f, sm, R, it1_start, it2_start, pb);
+        else resident_phase<2, THREADS, CPT, ROWS, UNR>(f, sm, R, it1_start, it2_start, pb);
     }
     const int end_code = R.end_code, unbounded_col = R.unbounded_col, hist_n = R.hist_n, it1 = R.it1, it2 = R.it2;
     const unsigned epoch = R.epoch;
