@@ -40,7 +40,7 @@ struct WgLds {
     int ldT, Hs;          // Hs = rows of the saved root
     // Copy-on-write nodes (k_node_queue): nothing is restored between nodes -- a row the node has not written yet is READ from
     // the saved root (row-major copy, shared by the whole batch, cache-resident) and written to the slot on its first update;
-    // the slot's copy of a row an earlier node wrote and this one did not is stale and never read (dirty flag 2)
+    // the slot's copy of a row an earlier node wrote and this one did not is stale and never read (it stays flagged dirty; LDS `cur` says what this node wrote)
     const double* snapA;
     bool cow;
     bool preloaded;  // rhs / r0 / vibr / vibc are already in LDS (the queue kernel fills them from the saved root)
