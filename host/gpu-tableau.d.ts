@@ -30,7 +30,10 @@ export interface InstallOptions extends LoadOptions {
     solver?: SolverLike;
     /** HIP device ordinal (default 0) */
     device?: number;
-    /** > 1: default B&B policy with n-node speculative batches (in-order commit); needs `solver` */
+    /**
+     * > 1: default B&B policy with n-node speculative batches (in-order commit: same results and relaxation counts as the
+     * sequential walk); needs `solver`.  Default 16 when `solver` is given; 0 keeps the reference's one-node-at-a-time services.
+     */
     speculate?: number;
     /**
      * tableaus with fewer cells (width x height) stay on the reference's own TypeScript path.  Default (measured,

@@ -249,8 +249,13 @@ function flush(t) {
     st.stale = false;
 }
 
+// speculative batches are the default whenever the solver instance is handed over (they need its service seam): same results and
+// relaxation counts as the sequential walk by construction, Monster_II 17.0 -> 9.7 ms (profiles/r02_z_config_wall_times.md);
+// install(..., { speculate: 0 }) keeps the reference's one-node-at-a-time services
+const DEFAULT_SPECULATE = 16;
 function install(Tableau, options) {
-    const opts = options || {};
+    const opts = Object.assign({}, options || {});
+    if (opts.solver && opts.speculate === undefined) opts.speculate = DEFAULT_SPECULATE;
     installedOpts = opts;
     if (!addon) loadEngine(opts);
     const P = Tableau.prototype;

@@ -59,7 +59,7 @@ function editScript(file) {
 const editFiles = ["Berlin_Air_Lift_Problem", "Wiki_1", "Monster_Problem", "Shift_Work_Problem"];
 const editBase = {};
 if (!filter && dir.indexOf("fixtures") >= 0) for (const f of editFiles) editBase[f] = editScript(f);
-let uninstall = gpu.install(Tableau, { SlackVariable, solver, minCells: 0 }); // parity runs: EVERY tableau on the engine
+let uninstall = gpu.install(Tableau, { SlackVariable, solver, minCells: 0, speculate: 0 }); // parity runs: EVERY tableau on the engine, the reference's own one-node-at-a-time services
 
 function num(x) {
     if (typeof x !== "number") return x;
@@ -199,7 +199,7 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
 let fuzzOk = 0;
 if (!filter && dir.indexOf("fixtures") >= 0) {
     uninstall();
-    uninstall = gpu.install(Tableau, { SlackVariable, solver, minCells: 0 });
+    uninstall = gpu.install(Tableau, { SlackVariable, solver, minCells: 0, speculate: 0 });
     for (const name of ["fuzz_services.jsonl.gz", "fuzz_soft.jsonl.gz"]) {
         const file = path.join(root, "tests", "golden", name);
         if (!fs.existsSync(file)) continue;
@@ -302,7 +302,7 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
 let policyOk = 0;
 if (!filter && dir.indexOf("fixtures") >= 0) {
     uninstall();
-    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16 });
+    uninstall = gpu.install(Tableau, { SlackVariable, solver });  // nothing but the defaults: size policy + 16-node speculative batches
     for (const [f, expectOnEngine] of [["Knapsack_1", false], ["LargeFarmMIP", false], ["Monster_II", true], ["Monster_Problem", true]]) {
         for (const extra of [{}, { useIncremental: true }]) {
             const g = loadGolden(dir, f + ".json.gz");

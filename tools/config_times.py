@@ -63,7 +63,7 @@ def main(out_path=None):
             times[spec] = (sorted(ts)[2], r["result"])
         ref, shim, shim16 = node_results[name]
         rows.append((label, g["tableau"]["height"], g["tableau"]["width"], g["nPivots"], len(g["simplexCalls"]), times[1], times[16], shim, shim16, ref))
-    lines = ["| config | tableau | pivots | LP relaxations | Python host + HIP (ms) | same, 16-node speculative batches (ms) | reference host + N-API + HIP (ms) | same, install(..., {speculate: 16}) (ms) | reference TS on CPU, node 12 (ms) | result |",
+    lines = ["| config | tableau | pivots | LP relaxations | Python host + HIP (ms) | same, 16-node speculative batches (ms) | reference host + N-API + HIP, install(..., {speculate: 1}) (ms) | same with the default 16-node speculative batches (ms) | reference TS on CPU, node 12 (ms) | result |",
              "|---|---|---|---|---|---|---|---|---|---|"]
     fmt = lambda x: "%.1f" % x["ms"] if x["ms"] else "n/a"
     for label, h, w, p, n, t1, t16, shim, shim16, ref in rows:

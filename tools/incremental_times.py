@@ -20,7 +20,7 @@ const root=process.argv[1], mode=process.argv[2], file=process.argv[3], options=
 const solver=require(path.join(root,'oracle/_ref/src/solver.js')).default;
 if(mode==='gpu'){const T=require(path.join(root,'oracle/_ref/src/tableau/tableau.js')).default;
  const {SlackVariable}=require(path.join(root,'oracle/_ref/src/expressions.js'));
- const gpu=require(path.join(root,'host/gpu-tableau.js'));gpu.loadEngine(process.env.JSLP_HIP_LIBRARY?{library:path.resolve(process.env.JSLP_HIP_LIBRARY)}:{});gpu.install(T,{SlackVariable,solver});}
+ const gpu=require(path.join(root,'host/gpu-tableau.js'));gpu.loadEngine(process.env.JSLP_HIP_LIBRARY?{library:path.resolve(process.env.JSLP_HIP_LIBRARY)}:{});gpu.install(T,{SlackVariable,solver,speculate:0});}
 const g=JSON.parse(zlib.gunzipSync(fs.readFileSync(file)).toString());
 const run=()=>{const m=JSON.parse(JSON.stringify(g.model));m.options=Object.assign({},m.options||{},options);delete m.options.timeout;
  const t0=process.hrtime.bigint();const r=solver.Solve(m,undefined,true);const ms=Number(process.hrtime.bigint()-t0)/1e6;

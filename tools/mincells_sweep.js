@@ -34,7 +34,7 @@ function time(model) {
 }
 for (const c of cases) { const [ms, res, feas] = time(c.model); c.cpu = ms; c.res = res; c.feas = feas; }
 gpu.loadEngine(process.argv[2] ? { library: path.resolve(process.argv[2]) } : {});
-gpu.install(T, { SlackVariable, solver, minCells: 0 });
+gpu.install(T, { SlackVariable, solver, minCells: 0, speculate: 0 });
 console.log("| model | tableau cells | reference on CPU (ms) | reference host + engine (ms) | engine / CPU | same result |");
 console.log("|---|---|---|---|---|---|");
 for (const c of cases) {

@@ -26,7 +26,7 @@ for (const k of Object.keys(addon)) {
         }
     };
 }
-gpu.install(T, { SlackVariable, solver, minCells: 0 }); // profile the engine path whatever the size
+gpu.install(T, { SlackVariable, solver, minCells: 0, speculate: 0 }); // profile the engine path whatever the size, one node at a time
 const g = JSON.parse(zlib.gunzipSync(fs.readFileSync(path.join(root, "tests/golden/fixtures", process.argv[2] + ".json.gz"))).toString());
 const origSolve = M.prototype.solve;
 let tSolve = 0;
