@@ -24,7 +24,7 @@ for s in $steps; do
           timeout 120 python tools/wglds_timing.py rate; JSLP_GROUP_MAX=768 timeout 120 python tools/wglds_timing.py rate; timeout 120 python tools/wglds_timing.py single) > $out/wglds_timing.log 2>&1 < /dev/null; echo "wgt rc=$?"; grep -v "^{" $out/wglds_timing.log ;;
     sq) (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $GRAFT_REPO_ROOT/$out/pmc_sq -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py relax > $GRAFT_REPO_ROOT/$out/pmc_sq.log 2>&1 < /dev/null); echo "sq rc=$?"
         (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT -d $GRAFT_REPO_ROOT/$out/pmc_sq2 -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py relax > $GRAFT_REPO_ROOT/$out/pmc_sq2.log 2>&1 < /dev/null); echo "sq2 rc=$?"
-        timeout 120 python tools/rocpd_pmc.py $out $out/pmc_sq_summary.json < /dev/null | grep -A40 "k_node_lds" | head -120 ;;
+        timeout 120 python tools/rocpd_pmc.py $out $out/pmc_sq_summary.json < /dev/null | grep -A40 "k_node_queue" | head -120 ;;
     wgm) (JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py single; JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py batch) 2>&1 | grep -i "micro\|total\|single\|batch" > $out/wglds_micro.log; cat $out/wglds_micro.log ;;
     stress) for i in 1 2 3; do timeout 120 python tools/wglds_timing.py rate; done > $out/stress.log 2>&1 < /dev/null; echo "stress rc=$?"; grep -c relaxations $out/stress.log; tail -3 $out/stress.log ;;
     sweep) timeout 600 node tools/mincells_sweep.js > $out/mincells_sweep.md 2> $out/mincells_sweep.err < /dev/null; echo "sweep rc=$?"; cat $out/mincells_sweep.md ;;
