@@ -697,7 +697,12 @@ static napi_value fn_relax_watched(napi_env env, napi_callback_info info) {
     if (nt != nv || nv != nx) THROW(env, "relaxWatched: array lengths differ");
     /* the engine writes one entry per watched variable: the host sized both arrays by the list it registered, and the
        engine refuses lists longer than the row capacity */
-    if (!wr || !wv || nwr != nwv) THROW(env, "relaxWatched: watchedRow and watchedValue must have one entry per watched variable");
+    {
+        const int32_t n_watched = box_of(env, argv[0])->n_watched;
+        if (n_watched <= 0) THROW(env, "relaxWatched: setWatchedVariables first");
+        if (!wr || !wv || nwr != nwv || nwr < (size_t)n_watched)
+            THROW(env, "relaxWatched: watchedRow and watchedValue must have one entry per watched variable");
+    }
     jslp_simplex_result r;
     ENGINE_OK(env, L.relax_watched(e, (int32_t)nt, (const int8_t*)t, (const int32_t*)v, (const double*)x, check ? 1 : 0, &r,
                                    (int32_t*)wr, (double*)wv), "jslp_engine_relax_watched");
@@ -731,11 +736,18 @@ static napi_value fn_get_counters(napi_env env, napi_callback_info info) {
 }
 
 /* ---- device pool (jslp_pool_*) ---- */
-typedef struct { jslp_pool* p; int32_t cap; } pbox;
+typedef struct { jslp_pool* p; int32_t cap; napi_ref primary; } pbox;
+/* The pool's members must go before the primary engine does, and finalisers run in no particular order: the box holds a
+   reference to the primary's handle, so the primary outlives the pool whichever way the pool ends -- poolDestroy (what the
+   binding calls before it destroys the primary) or this finaliser (a tableau that was simply dropped: the N - 1 member
+   engines, their streams and their worker threads must not live on for the rest of the process). */
+static void pool_box_close(napi_env env, pbox* box) {
+    if (box->p) { L.pool_destroy(box->p); box->p = NULL; }
+    if (box->primary) { napi_delete_reference(env, box->primary); box->primary = NULL; }
+}
 static void finalize_pool(napi_env env, void* data, void* hint) {
-    (void)env; (void)hint;
-    /* NOT destroyed here: the pool's members must go before the primary engine does, and finalisers run in no particular
-       order -- the binding destroys its pools explicitly (poolDestroy) before it destroys the primary */
+    (void)hint;
+    pool_box_close(env, (pbox*)data);
     free(data);
 }
 static jslp_pool* pool_handle(napi_env env, napi_value v, int32_t* cap) {
@@ -762,7 +774,12 @@ static napi_value fn_pool_create(napi_env env, napi_callback_info info) {
     if (rc != JSLP_OK) free(box);
     ENGINE_OK(env, rc, "jslp_pool_create");
     napi_value ext;
-    NAPI_OK(env, napi_create_external(env, box, finalize_pool, NULL, &ext));
+    if (napi_create_reference(env, argv[0], 1, &box->primary) != napi_ok) box->primary = NULL;
+    if (napi_create_external(env, box, finalize_pool, NULL, &ext) != napi_ok) {
+        pool_box_close(env, box);
+        free(box);
+        THROW(env, "poolCreate: napi_create_external failed");
+    }
     return ext;
 }
 static napi_value fn_pool_destroy(napi_env env, napi_callback_info info) {
@@ -770,8 +787,7 @@ static napi_value fn_pool_destroy(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 1, argv)) return NULL;
     void* p = NULL;
     if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
-        pbox* box = (pbox*)p;
-        if (box->p) { L.pool_destroy(box->p); box->p = NULL; }
+        pool_box_close(env, (pbox*)p);
     }
     return NULL;
 }

@@ -80,6 +80,13 @@ function activate(t, opts) {
     let pre = t.__gpuEngine || null;
     t.__gpuEngine = null;
     if (pre && (pre.height !== t.height || pre.width !== t.width)) {
+        // the tableau grew or shrank between initialize() and its first simplex(): the matrix moves to ordinary memory BEFORE the
+        // engine (and with it the pinned buffer `t.matrix` may still view) goes back to the library's resource pool
+        if (pre.pinnedMatrix) {
+            if (t.matrix === pre.pinnedMatrix) t.matrix = new Float64Array(pre.pinnedMatrix);
+            addon.detach(pre.pinnedMatrix);
+            pre.pinnedMatrix = null;
+        }
         addon.destroy(pre.h);
         pre = null;
     }
@@ -416,7 +423,11 @@ function install(Tableau, options) {
         origSolve = solver.Solve;
         solver.Solve = function (model, precision, full) {
             const result = origSolve.apply(this, arguments);
-            if (!full && this.lastSolvedModel && this.lastSolvedModel.tableau) release(this.lastSolvedModel.tableau);
+            // a Model INSTANCE handed in by the caller stays the caller's (main.ts:127-134: `modelInstance = model`; it may be
+            // edited and solved again): its tableau keeps its engine.  Only the Model that Solve() itself built from a JSON
+            // definition is finished when Solve() returns.
+            const callersInstance = this.lastSolvedModel === model;
+            if (!full && !callersInstance && this.lastSolvedModel && this.lastSolvedModel.tableau) release(this.lastSolvedModel.tableau);
             return result;
         };
         const service = require("./gpu-incremental-service.js");

@@ -56,7 +56,23 @@ function editScript(file) {
     out.push(snap(model.solve()));
     return out;
 }
+// a Model INSTANCE handed to Solve() (main.ts:127-134) stays the caller's: solve, solve again, edit, solve again -- all through
+// solver.Solve(instance) with the simplified result, i.e. the path that hands engines back when it built the Model itself
+function instanceScript(file) {
+    const def = JSON.parse(JSON.stringify(loadGolden(strategyDir, file + ".json.gz").model));
+    const model = new solver.Model(undefined, undefined, solver.selectBranchAndCutService(def)).loadJson(def);
+    const out = [];
+    out.push(JSON.stringify(solver.Solve(model)));
+    out.push(JSON.stringify(solver.Solve(model)));
+    const c0 = model.constraints[0];
+    model.updateRightHandSide(c0, c0.isUpperBound ? 2 : -2);
+    out.push(JSON.stringify(solver.Solve(model)));
+    out.push(JSON.stringify(model.solve().generateSolutionSet()));
+    return out;
+}
 const editFiles = ["Berlin_Air_Lift_Problem", "Wiki_1", "Monster_Problem", "Shift_Work_Problem"];
+const instanceBase = {};
+if (!filter && dir.indexOf("fixtures") >= 0) for (const f of editFiles) instanceBase[f] = instanceScript(f);
 const editBase = {};
 if (!filter && dir.indexOf("fixtures") >= 0) for (const f of editFiles) editBase[f] = editScript(f);
 let uninstall = gpu.install(Tableau, { SlackVariable, solver, minCells: 0, speculate: 0 }); // parity runs: EVERY tableau on the engine, the reference's own one-node-at-a-time services
@@ -235,6 +251,16 @@ for (const f of Object.keys(editBase)) {
     }
     gpu.bringHome(solver.lastSolvedModel.tableau);
 }
+// Solve(modelInstance) twice, edited in between (ADVICE r02: the engine of a caller's instance must not be released)
+let instanceOk = 0;
+for (const f of Object.keys(instanceBase)) {
+    const got = instanceScript(f);
+    for (let i = 0; i < got.length; i++) {
+        if (got[i] === instanceBase[f][i]) instanceOk += 1;
+        else { fail += 1; console.log("FAIL model instance re-solve", f, "step", i); }
+    }
+    gpu.bringHome(solver.lastSolvedModel.tableau);
+}
 // a tableau whose engine went back to the pool when Solve() returned must refuse further solves (never a stale host copy)
 let releasedOk = 0;
 if (!filter && dir.indexOf("fixtures") >= 0) {
@@ -321,5 +347,5 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
 }
 console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk,
     incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk,
-    size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, pool_ok: poolOk, watched_ok: watchedOk }));
+    size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, instance_ok: instanceOk, pool_ok: poolOk, watched_ok: watchedOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);

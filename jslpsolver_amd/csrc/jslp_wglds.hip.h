@@ -670,12 +670,23 @@ __device__ __forceinline__ void gather_slot_lds(const Slots& s, const WgLds& L, 
     const int H = st->H;
     if (out_stride < 0) {
         const int n = -out_stride < s.n_watch ? -out_stride : s.n_watch;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) L.list[i] = -1;
-        __syncthreads();
-        for (int r = 1 + threadIdx.x; r < H; r += blockDim.x) {
-            const int v = L.vibr[r];
-            const int p = (v >= 0 && v < s.idx_stride) ? s.watch_pos[v] : -1;
-            if (p >= 0 && p < n) L.list[p] = r;
+        if (s.watch_pos) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) L.list[i] = -1;
+            __syncthreads();
+            for (int r = 1 + threadIdx.x; r < H; r += blockDim.x) {
+                const int v = L.vibr[r];
+                const int p = (v >= 0 && v < s.idx_stride) ? s.watch_pos[v] : -1;
+                if (p >= 0 && p < n) L.list[p] = r;
+            }
+        } else {
+            // a variable listed twice has no single position: every listed entry looks its row up in the LDS row map (the global
+            // maps of a copy-on-write slot are stale, so gather_slot() is not an option here)
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int v = s.watch[i];
+                int row = -1;
+                for (int r = 1; r < H; r++) row = L.vibr[r] == v ? r : row;
+                L.list[i] = row;
+            }
         }
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -822,7 +833,7 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
         for (int off = 32; off > 0; off >>= 1) n_mine += __shfl_down(n_mine, off, 64);
         if (lane == 0 && n_mine) atomicAdd(s.cnt + CNT_RESTORED, (cnt_t)n_mine);
     }
-    if (st->err == ERR_NONE && (out_stride >= 0 || s.watch_pos)) gather_slot_lds(s, Ln, slot, rhs_out, rows_out, state_out, out_stride, o);
+    if (st->err == ERR_NONE) gather_slot_lds(s, Ln, slot, rhs_out, rows_out, state_out, out_stride, o);
     else gather_slot(s, slot, rhs_out, rows_out, state_out, out_stride, o);
     __syncthreads();
     WL_MARK(12);
