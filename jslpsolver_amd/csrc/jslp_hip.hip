@@ -101,6 +101,7 @@ struct jslp_engine {
     unsigned long long* d_nnz = nullptr; long long nnz = -1;  // non-zero cells of the uploaded tableau (counted on the device)
     unsigned spin_limit = 0; int test_abort_epoch = -1;
     int resident_fallbacks = 0;  // solves that were rolled back and re-run through the streaming kernels
+    int resident_handovers = 0;  // solves the lean resident kernel handed to the general one (cycle-check history beyond its LDS copy)
     // checkpoints (incremental-branch-and-cut.ts:31-44): equally sized device buffers, recycled through a free list
     struct Ckpt {
         char* mem = nullptr;
@@ -762,7 +763,7 @@ static int ensure_resident(jslp_engine* e) {
     // resource pool hands from engine to engine (hipMalloc / hipFree of these cost a small Solve more than its pivots)
     for (int pass = 0; pass < 2; pass++) {
         Carver cv{pass ? e->r_arena : nullptr, 0};
-        e->r_gran = cv.take<u64_t>(2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32);
+        e->r_gran = cv.take<u64_t>(JSLP_R_SYNC_WORDS);
         for (int i = 0; i < 2; i++) e->r_rows[i] = cv.take<u64_t>((size_t)JSLP_F_MAXG * e->ld);
         e->r_sync = cv.take<unsigned>(16);
         e->rb_A = cv.take<double>((size_t)e->cap_rows * e->ld);
@@ -966,8 +967,9 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             rc.verdict[1] = rc.decision[0] + 24;
             rc.gor[0] = rc.decision[0] + 32;
             rc.gor[1] = rc.gor[0] + JSLP_F_MAXG;
+            rc.gran16 = e->r_gran + (size_t)2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32;  // [2][MAXG] 16-byte granules
             rc.abort_flag = e->r_sync + 4;
-            HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32), s));  // tags restart at 1
+            HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * JSLP_R_SYNC_WORDS, s));  // tags restart at 1
             rc.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
             rc.G = (H + rc.rpb - 1) / rc.rpb;
             rc.H = H;
@@ -996,10 +998,18 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             // 512 lanes x 4 columns x 16 rows -- 2 waves per SIMD leave 256 VGPRs per lane for the 64 MB of tableau
             hipError_t le = hipErrorInvalidValue;
             const bool unr = e->n_unr > 0;  // unrestricted variables: the UNR build threads the per-column flags through
-#define JSLP_RES_LAUNCH(T, C, R)                                                                                             \
-    le = unr ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, true>, dim3(rc.G), dim3(T), args, 0, s)    \
-             : hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false>, dim3(rc.G), dim3(T), args, 0, s)
-            switch (resident_geometry(e, H)) {
+            // The LEAN build (all-gather protocol only, software-pipelined phase 2: jslp_resident_pipe.hip.h) takes every solve
+            // without unrestricted variables; should its cycle-check history outgrow LDS it hands the solve over (status
+            // ST_RUNNING / ST_PHASE1_DONE instead of ST_DONE) and the general build continues it in a second launch.
+            static const bool lean_on = !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
+            bool lean = lean_on && !unr;
+            const int geometry = resident_geometry(e, H);
+#define JSLP_RES_LAUNCH(T, C, R)                                                                                                    \
+    le = lean ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false, true>, dim3(rc.G), dim3(T), args, 0, s) \
+       : unr  ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, true>, dim3(rc.G), dim3(T), args, 0, s)        \
+              : hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false>, dim3(rc.G), dim3(T), args, 0, s)
+          resident_relaunch:
+            switch (geometry) {
                 case 1: JSLP_RES_LAUNCH(1024, 2, 8); break;
                 case 2: JSLP_RES_LAUNCH(512, 4, 8); break;
                 case 3: JSLP_RES_LAUNCH(512, 4, 16); break;
@@ -1007,6 +1017,16 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                 case 5: JSLP_RES_LAUNCH(512, 8, 8); break;
             }
 #undef JSLP_RES_LAUNCH
+            if (le == hipSuccess && lean) {  // did the lean kernel finish the solve?
+                HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+                HIPC(hipStreamSynchronize(s));
+                if (e->h_state->err == ERR_NONE && e->h_state->status != ST_DONE) {
+                    lean = false;
+                    e->resident_handovers += 1;
+                    HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * JSLP_R_SYNC_WORDS, s));  // the second launch's tags restart at 1
+                    goto resident_relaunch;
+                }
+            }
             if (le == hipSuccess) {
                 if (e->timing) HIPC(hipEventRecord(k1, s));
                 const int it_before = 0;  // k_begin zeroed the pivot counters

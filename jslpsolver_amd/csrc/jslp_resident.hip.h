@@ -25,6 +25,9 @@
 #define JSLP_R_LDMAX 4096    // widest padded row any geometry takes (512 lanes x 8 columns)
 #define JSLP_R_LUNR 8192     // variable indexes whose unrestricted flag fits the LDS copy (more: gather-by-leader protocol)
 #define JSLP_R_LHIST 10240   // cycle-check history entries kept in LDS (80 KB)
+// hand-off words of one engine (one allocation, zeroed per launch): [2][G][8] granules, [2][G] row flags, [2][G] chip-wide OR flags,
+// 32 words of decision / verdict, then the lean kernel's [2][G] 16-byte summary granules
+#define JSLP_R_SYNC_WORDS (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32 + 2 * JSLP_F_MAXG * 2)
 #ifndef JSLP_RES_FAST
 #define JSLP_RES_FAST 1      // one barrier around the row flag (step E); the -k/quot entries of the pivot column computed by eight lanes in parallel while the winning row is in flight instead of one after the other by the lane that owns the column (step F)
 #endif
@@ -64,6 +67,7 @@ struct ResCtx {
     u64_t* decision[2];   // leader's per-pivot decision: 3 tagged granules {pr | stop << 16}, {quot lo}, {quot hi}
     u64_t* verdict[2];    // phase 1 only: leader's cycle-check verdict {tag | stop} (the entering column is known late there)
     u64_t* gor[2];        // [G] rare slow path: tagged per-workgroup flags for a chip-wide OR
+    u64_t* gran16;        // [2][MAXG] 16-byte summary granules of the lean kernel's pipelined phase 2 (jslp_resident_pipe.hip.h)
     int32_t G, rpb, H;
     int32_t n_idx;             // variable indexes in use (the LDS copy of the unrestricted flags covers JSLP_R_LUNR of them)
     int32_t iters_cap;
@@ -102,6 +106,13 @@ struct RSmem {
     int32_t kind[JSLP_R_MAXROWS];
     double col[JSLP_R_MAXROWS];  // my rows' entries in the pivot column / in column 0
     double rhs[JSLP_R_MAXROWS];
+    // pipelined phase 2 (jslp_resident_pipe.hip.h): pivot-column entries by pivot parity (the pending update still needs the
+    // previous pivot's), column 0 of my rows, the four polling waves' partial decisions, quot broadcast with the row flag
+    double colb[2][JSLP_R_MAXROWS];
+    double rhsb[JSLP_R_MAXROWS];
+    u64_t part_k[JSLP_F_MAXG / 64];
+    int32_t part_r[JSLP_F_MAXG / 64], part_rdeg[JSLP_F_MAXG / 64];
+    double xq2[2];
     // All-gather protocol: what only workgroup 0 knows in the gather-by-leader protocol lives in EVERY workgroup's LDS -- the
     // row / column maps (swapped at every pivot like the global ones), the unrestricted flag of every variable index, and the
     // cycle-check history (the first JSLP_R_LHIST entries; a longer solve continues with the leader protocol, whose check
@@ -256,7 +267,10 @@ struct ResRegs {
 // One phase of the solve.  PHASE is a compile-time constant so that the phase-2 loop -- the hot one -- carries none of
 // the phase-1 branches; returns when the solve ends (R.end_code != 0) or, for PHASE == 1, when phase 1 is over
 // (end_code stays 0 and the caller starts phase 2).
-template <int PHASE, int THREADS, int CPT, int ROWS, bool UNR>
+// LEAN (k_simplex_resident<.., LEAN = true>): the all-gather protocol only -- the gather-by-leader branches, which the general
+// kernel needs for unrestricted variables beyond the LDS copy and for histories that outgrow LDS, are compiled out; a solve
+// that comes to need them leaves with end_code 8 and the host continues it with the general kernel.
+template <int PHASE, int THREADS, int CPT, int ROWS, bool UNR, bool LEAN = false>
 __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start,
                                                const int (&pb)[CPT]) {
     const Ctx& c = f.c;
@@ -294,6 +308,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
     int okslot = 0;
     while (end_code == 0) {
         if ((it1 - it1_start) + (it2 - it2_start) >= f.iters_cap) { end_code = 4; break; }
+        if (LEAN && c.check_cycles && !(hist_n < JSLP_R_LHIST && hist_n < c.hist_cap)) { end_code = 8; break; }  // history outgrows LDS
         const int par = epoch & 1;
         const unsigned tag = epoch + 1;
         if (f.test_abort_epoch >= 0 && (int)epoch == f.test_abort_epoch && b == f.G - 1) {  // tests: a workgroup gives up
@@ -393,7 +408,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         SweptCand sc;
         sc.qbits = ~0ull; sc.kq = 0; sc.kdeg = 0; sc.r = 0; sc.rdeg = 0x7fffffff;
         // all-gather by every workgroup (JSLP_RES_ALLGATHER): no leader, no decision broadcast
-        const bool allg = JSLP_RES_ALLGATHER != 0 && (!UNR || f.n_idx <= JSLP_R_LUNR) && (!c.check_cycles || (hist_n < JSLP_R_LHIST && hist_n < c.hist_cap));
+        const bool allg = LEAN || (JSLP_RES_ALLGATHER != 0 && (!UNR || f.n_idx <= JSLP_R_LUNR) && (!c.check_cycles || (hist_n < JSLP_R_LHIST && hist_n < c.hist_cap)));
         const bool sweeper = b == 0 && !allg && tid >= sweep0;
         if (allg) {
             // thread t polls granules t, t + blockDim, ... of the [G][8] array (adjacent lanes, adjacent granules: 64-byte requests)
@@ -853,10 +868,13 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
     }
 }
 
+#include "jslp_resident_pipe.hip.h"  // the lean kernel's phase 2 (needs everything above, is needed by the kernel below)
+
 // THREADS x CPT >= ld: <1024, 2> = lane pairs of columns, 4 waves per SIMD; <512, 4> = half the waves to synchronise,
 // twice the independent work per lane (and 256 VGPRs per lane).
-template <int THREADS, int CPT, int ROWS, bool UNR>
+template <int THREADS, int CPT, int ROWS, bool UNR, bool LEAN = false>
 __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
+    static_assert(!(LEAN && UNR), "the lean kernel leaves unrestricted variables to the general one");
     static_assert(ROWS <= JSLP_R_MAXROWS, "RSmem holds one entry per row of the workgroup");
     static_assert(sizeof(RSmem) <= 160 * 1024, "one workgroup per CU: all of the CU's LDS, no more");
     __shared__ RSmem sm;
@@ -948,12 +966,13 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     R.unbounded_col = 0;
     R.epoch = 0;
     if (phase == 1) {
-        resident_phase<1, THREADS, CPT, ROWS, UNR>(f, sm, R, it1_start, it2_start, pb);
+        resident_phase<1, THREADS, CPT, ROWS, UNR, LEAN>(f, sm, R, it1_start, it2_start, pb);
         if (R.end_code == 0) phase = 2;
     }
     if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
         R.pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg);
         if (R.pc == 0) R.end_code = 1;
+        else if (LEAN) resident_phase2_pipe<THREADS, CPT, ROWS>(f, sm, R, it1_start, it2_start, pb);
         else resident_phase<2, THREADS, CPT, ROWS, UNR>(f, sm, R, it1_start, it2_start, pb);
     }
     const int end_code = R.end_code, unbounded_col = R.unbounded_col, hist_n = R.hist_n, it1 = R.it1, it2 = R.it2;
@@ -988,7 +1007,8 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
         st->hist_n = hist_n;
         st->iters_left -= (it1 - it1_start) + (it2 - it2_start);
         st->do_pivot = 0;
-        st->status = ST_DONE;
+        // end_code 8 (lean kernel only): the solve goes on in the general kernel, which picks the phase up from the status
+        st->status = end_code == 8 ? (phase == 2 ? ST_PHASE1_DONE : ST_RUNNING) : ST_DONE;
         st->phase = phase;
         if (phase == 2) { st->entered_phase2 = 1; st->feasible = 1; }  // phase 1 found no violated row (simplex.ts:51-54)
         st->obj_cell = r0[0];  // column 0 of the cost row

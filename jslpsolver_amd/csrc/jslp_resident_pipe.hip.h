@@ -1,0 +1,428 @@
+// jslp_resident_pipe.hip.h -- the LEAN register-resident kernel's phase 2: a software-pipelined pivot loop.
+// Included by jslp_resident.hip.h between its building blocks (ResCtx / RSmem / ResRegs / price_row_lds) and its kernel.
+#pragma once
+
+// ===================================================================================================================
+// Why a second loop.  k_simplex_resident's general pivot loop (jslp_resident.hip.h) runs its steps strictly one after the
+// other: summary -> publish -> gather -> decide -> fetch the winning row -> update my rows -> price -> summary ...; the row
+// update (16 waves x 8 rows x 2 columns of two-rounding eliminations, ~3 k cycles) and the fabric hop of the NEXT pivot's
+// summary (~1 us) both sit on the critical path although neither needs the other.  Here the loop is rotated:
+//
+//   winner row of pivot t lands
+//     -> normalise it, update the COST row only, price it                  (entering column of pivot t+1: simplex.ts:118-219)
+//     -> the ONE lane that holds column pc(t+1) evaluates what pivot t makes of that column in my rows, lane 0 of the
+//        workgroup does the same for column 0, the wave that owns pc(t+1) runs the ratio test on the two       (simplex.ts:271-296)
+//     -> the summary of pivot t+1 is published, the row that can win is brought up to date and published
+//     -> ONLY NOW the bulk of pivot t's row update (simplex.ts:367-391), while the summaries cross the fabric
+//     -> gather, decide, fetch the winning row of pivot t+1 ...
+//
+// Same arithmetic on the same operands in the same order for every cell (each cell still receives exactly one
+// `a - k * p` with both roundings per pivot; "early" values are computed from the same inputs as the bulk update computes
+// them later), so the pivot sequence and every bit of the final tableau are unchanged -- the parity tests do not
+// distinguish the two loops.
+//
+// Protocol differences from the general loop (all-gather form):
+//   * the ratio-test summary is ONE 16-byte granule per workgroup: {tag32 | q_lo32}{tag16 | kind | row15 | q_hi32} -- the winner's
+//     pivot-column entry (`quot`) is no longer published: it is column pc of the winning row, which every workgroup fetches
+//     anyway (the lane that holds the column broadcasts it through LDS under the barrier the row flag needs);
+//     a workgroup with a degenerate row publishes only that (its quotient candidates cannot win: simplex.ts:285-289);
+//   * four waves poll (lane w = workgroup w, one 16-byte sc1 load each) and reduce their 64 summaries in registers (DPP);
+//     the four partial results meet in LDS under the barrier that also drains the row stores: no separate decision stage;
+//   * 6 workgroup barriers per pivot instead of 8 (cycle check off).
+// ===================================================================================================================
+#ifndef JSLP_PIPE_EARLYPOLL
+#define JSLP_PIPE_EARLYPOLL 0  // 1: the first poll of the gather is issued before the bulk update and examined after it
+#endif
+
+template <int THREADS, int CPT, int ROWS>
+__device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start,
+                                                     const int (&pb)[CPT]) {
+    const Ctx& c = f.c;
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ld = c.ld, W = c.W;
+    const double precision = c.precision;
+    const int c0 = tid * CPT;
+    const bool colok = c0 < ld;
+    const int r_begin = b * f.rpb, r_end = min(f.H, r_begin + f.rpb);
+    double (&a)[ROWS][CPT] = R.a;
+    double (&r0)[CPT] = R.r0;
+    typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+    const int pub_stride = (int)((const char*)f.rows_pub[1] - (const char*)f.rows_pub[0]);  // (both carved from one arena, [0] first)
+    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + f.G * ld * 8, 0x00020000);
+    const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, 2 * JSLP_F_MAXG * 16, 0x00020000);
+#ifdef JSLP_DEBUG_RESIDENT
+    u64_t (&rt_acc)[8] = R.rt_acc;
+    u64_t& rt_prev = R.rt_prev;
+#endif
+
+    // the pending pivot (its row update has not reached my registers yet)
+    double p[CPT];      // its normalised pivot row, my columns
+    unsigned nzm = 0;   // bit j: p[j] is non-zero by the reference's test (simplex.ts:379)
+    int pr_p = 0, pc_p = 0, par_p = 0;
+    bool pend = false;
+#pragma unroll
+    for (int j = 0; j < CPT; j++) p[j] = 0.0;
+    int okslot = 0;
+
+    // row i of mine <- pivot (pr_p, pc_p): exactly the general loop's step F for one row
+#define JSLP_PIPE_UPDATE_ROW(i)                                                                             \
+    do {                                                                                                    \
+        const int r_ = r_begin + (i);                                                                       \
+        if (r_ >= r_end) break;                                                                             \
+        if (r_ == 0) { /* workgroup 0 mirrors the cost row */                                               \
+            _Pragma("unroll") for (int j = 0; j < CPT; j++) a[i][j] = r0[j];                                \
+            break;                                                                                          \
+        }                                                                                                   \
+        if (r_ == pr_p) {                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < CPT; j++) a[i][j] = p[j];                                 \
+            break;                                                                                          \
+        }                                                                                                   \
+        const double ki_ = sm.colb[par_p][i];                                                               \
+        if (nonzero16(ki_)) {                                                                               \
+            _Pragma("unroll") for (int j = 0; j < CPT; j++)                                                 \
+                if ((nzm >> j) & 1u) a[i][j] = eliminate(a[i][j], ki_, p[j]);                               \
+            if (has_pc_p) {                                                                                 \
+                const double nv_ = sm.nv[i];                                                                \
+                _Pragma("unroll") for (int j = 0; j < CPT; j++)                                             \
+                    if (pc_p == c0 + j) a[i][j] = nv_;                                                      \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < ROWS; i++) sm.rhsb[i] = a[i][0];
+        reset_reductions(sm);
+    }
+    __syncthreads();
+
+    while (R.end_code == 0) {
+        const bool has_pc_p = pend && colok && pc_p >= c0 && pc_p < c0 + CPT;
+        // ---- exits that hand the tableau on: bring it up to date first --------------------------------------------------
+        {
+            int leave = 0;
+            if ((R.it1 - it1_start) + (R.it2 - it2_start) >= f.iters_cap) leave = 4;
+            else if (c.check_cycles && !(R.hist_n < JSLP_R_LHIST && R.hist_n < c.hist_cap)) leave = 8;  // history outgrows LDS: the general kernel continues
+            if (leave) {
+                if (pend) {
+#pragma unroll
+                    for (int i = 0; i < ROWS; i++) JSLP_PIPE_UPDATE_ROW(i);
+                }
+                R.end_code = leave;
+                break;
+            }
+        }
+        const unsigned epoch = R.epoch;
+        const int par = epoch & 1;
+        const unsigned tag = epoch + 1;
+        const int pc = R.pc;
+        if (f.test_abort_epoch >= 0 && (int)epoch == f.test_abort_epoch && b == f.G - 1) {  // tests: a workgroup gives up
+            if (tid == 0) AG_STORE(f.abort_flag, 1u);
+            R.end_code = 5;
+            break;
+        }
+        RT_MARK(7);
+        // ---- S: ratio test for column pc (simplex.ts:271-296) by the wave that holds the column ---------------------------
+        if (wv == ((pc / CPT) >> 6)) {
+            if (colok && pc >= c0 && pc < c0 + CPT) {
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if (pc == c0 + j) {
+#pragma unroll
+                        for (int i = 0; i < ROWS; i++) {
+                            double v = a[i][j];
+                            if (pend) {  // what the pending pivot makes of this cell (the bulk update will compute the same)
+                                const int r = r_begin + i;
+                                const double ki = sm.colb[par_p][i];
+                                if (r == pr_p) v = p[j];
+                                else if (r != 0 && r < r_end && nonzero16(ki)) {
+                                    if (pc_p == pc) v = sm.nv[i];
+                                    else if ((nzm >> j) & 1u) v = eliminate(v, ki, p[j]);
+                                }
+                            }
+                            sm.colb[par][i] = v;
+                        }
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+            if (lane < ROWS) {
+                const int r = r_begin + lane;
+                const double colv = sm.colb[par][lane], rhs = sm.rhsb[lane];
+                int kind = 0;  // 0 skip, 1 degenerate winner, 2 quotient candidate
+                double quo = 0.0;
+                if (r >= 1 && r < r_end && !(-precision < colv && colv < precision)) {
+                    if (colv > 0 && precision > rhs && rhs > -precision) kind = 1;
+                    else { quo = rhs / colv; kind = quo > precision ? 2 : 0; }
+                }
+                sm.quo[lane] = quo;
+                sm.kind[lane] = kind;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            double bq = INFINITY;
+            int br = 0, brdeg = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) {
+                const int kind = sm.kind[i];
+                const double quo = sm.quo[i];
+                const int r = r_begin + i;
+                if (kind == 1) { if (r < brdeg) brdeg = r; }
+                else if (kind == 2 && bq > quo) { bq = quo; br = r; }
+            }
+            if (lane == 0) {
+                const bool deg = brdeg != 0x7fffffff;
+                const int row = deg ? brdeg : br;  // the only row of mine that can win (0: none)
+                const u64_t qb = (deg || br == 0) ? 0ull : (u64_t)__double_as_longlong(bq);
+                v4u_t g;
+                g.x = (unsigned)qb;
+                g.y = tag;
+                g.z = (unsigned)(qb >> 32);
+                g.w = ((tag & 0xffffu) << 16) | (deg ? 0x8000u : 0u) | (unsigned)row;
+                __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_g16, (par * JSLP_F_MAXG + b) * 16, 0, 16);  // aux 16 = sc1
+                sm.pubrow = row;
+            }
+        }
+        __syncthreads();
+        RT_MARK(0);
+        // ---- P: the row that can win: brought up to date, then published (16-byte write-through stores) ----------------------
+        const int pubrow = sm.pubrow;
+        if (pubrow != 0) {
+#pragma unroll
+            for (int i = 0; i < ROWS; i++)
+                if (r_begin + i == pubrow) {  // uniform
+                    if (pend) JSLP_PIPE_UPDATE_ROW(i);
+                    if (colok) {
+                        const int off = par * pub_stride + (b * ld + c0) * 8;
+#pragma unroll
+                        for (int j = 0; j < CPT; j += 2) {
+                            if (c0 + j >= ld) continue;
+                            const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
+                            v4u_t v;
+                            v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, 16);
+                        }
+                    }
+                }
+        }
+        RT_MARK(1);
+        // ---- C: gather: lane w of the first four waves polls workgroup w's granule; U: the bulk of the pending update -----------
+        bool swept = true;
+        const bool poller = tid < JSLP_F_MAXG;
+        const bool used = tid < f.G;
+        v4u_t g;
+        g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;  // lanes beyond the grid: "no candidate"
+        const int goff = (par * JSLP_F_MAXG + tid) * 16;
+        if (JSLP_PIPE_EARLYPOLL && poller && used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
+        if (pend) {
+#pragma unroll
+            for (int i = 0; i < ROWS; i++)
+                if (r_begin + i != pubrow || pubrow == 0) JSLP_PIPE_UPDATE_ROW(i);
+        }
+        pend = false;
+        RT_MARK(2);
+        if (poller) {
+            unsigned spins = 0;
+            bool first = JSLP_PIPE_EARLYPOLL != 0;
+            for (;;) {
+                if (!first && used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
+                first = false;
+                const bool ok = g.y == tag && (g.w >> 16) == (tag & 0xffffu);
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { swept = false; break; }
+                if (spins > f.spin_limit) { if (lane == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
+            }
+            // my workgroup's summary -> the wave's: first degenerate row, else smallest quotient (first row on ties)
+            const int row = (int)(g.w & 0x7fffu);
+            const bool deg = (g.w & 0x8000u) != 0u;
+            int rdeg = (deg && row != 0) ? row : 0x7fffffff;
+            rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0xB1, 0xf, 0xf, false));
+            rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x4E, 0xf, 0xf, false));
+            rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x141, 0xf, 0xf, false));
+            rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x140, 0xf, 0xf, false));
+            rdeg = min(min(__builtin_amdgcn_readlane(rdeg, 0), __builtin_amdgcn_readlane(rdeg, 16)),
+                       min(__builtin_amdgcn_readlane(rdeg, 32), __builtin_amdgcn_readlane(rdeg, 48)));
+            KI x;  // quotients are > precision > 0: positive doubles order like their bit patterns
+            const bool cand = !deg && row != 0;
+            x.k = cand ? ((u64_t)g.x | ((u64_t)g.z << 32)) : KI_NONE_KEY;
+            x.i = cand ? row : 0x7fffffff;
+            x.pad = 0;
+            x = ki_wave_min(x);
+            if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; sm.part_rdeg[wv] = rdeg; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my row stores are written through
+        const int all_swept = __syncthreads_and(swept ? 1 : 0);
+        if (!all_swept) { R.end_code = 5; break; }
+        if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: the row is visible
+        RT_MARK(3);
+        // ---- D: every thread folds the four partial results ------------------------------------------------------------------
+        int pr = 0, stop = 0;
+        {
+            u64_t wk = sm.part_k[0];
+            int wr = sm.part_r[0], wrdeg = sm.part_rdeg[0];
+#pragma unroll
+            for (int i = 1; i < JSLP_F_MAXG / 64; i++) {
+                const u64_t k2 = sm.part_k[i];
+                const int r2 = sm.part_r[i], rd2 = sm.part_rdeg[i];
+                const bool take = r2 != 0 && (wr == 0 || k2 < wk || (k2 == wk && r2 < wr));
+                wk = take ? k2 : wk;
+                wr = take ? r2 : wr;
+                wrdeg = rd2 < wrdeg ? rd2 : wrdeg;
+            }
+            if (wrdeg != 0x7fffffff) pr = wrdeg;
+            else if (wr != 0) pr = wr;
+            else stop = 3;  // unbounded (simplex.ts:298-303)
+        }
+        if (!stop && c.check_cycles) {  // simplex.ts:305-320 by every workgroup, on its own LDS history
+            if (tid == 0) {
+                const int2 pair = make_int2(sm.lvibr[pr], sm.lvibc[pc]);
+                sm.lhist[R.hist_n] = pair;
+                if (b == 0) c.hist[R.hist_n] = pair;  // the host's cycle message; the general kernel's history should this one outgrow LDS
+            }
+            __syncthreads();
+            R.hist_n += 1;
+            if (suffix_is_square(sm.lhist, R.hist_n, sm.f.red)) stop = 1;
+        }
+        if (stop == 3) { R.end_code = 2; R.unbounded_col = pc; break; }
+        if (stop == 1) { R.end_code = 3; break; }
+        // ---- E: the winning row, loaded speculatively together with its flag (re-loaded in the rare case the flag was not up
+        //         yet); the lane that holds column pc broadcasts quot = A[pr, pc] --------------------------------------------------
+        const int bw = pr / f.rpb;
+        const int off_in = par * pub_stride + (bw * ld + c0) * 8;
+        const bool has_pc = colok && pc >= c0 && pc < c0 + CPT;
+        double pv[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; j++) pv[j] = 0.0;
+        double quot = 0.0;
+        for (;;) {
+            u64_t flag = 0;
+            if (tid == 0) flag = AG_LOAD(f.rowflag[par] + bw);
+            if (colok) {
+#pragma unroll
+                for (int j = 0; j < CPT; j += 2) {
+                    if (c0 + j >= ld) continue;
+                    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + j * 8, 0, 16);
+                    pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
+                    pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
+                }
+            }
+            if (has_pc) {
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if (pc == c0 + j) sm.xq2[okslot] = pv[j];
+            }
+            if (tid == 0) {
+                int ok = 1;
+                if ((unsigned)flag != tag) {
+                    unsigned spins = 0;
+                    ok = 2;  // the row must be re-read once the flag is up
+                    while ((unsigned)AG_LOAD(f.rowflag[par] + bw) != tag) {
+                        __builtin_amdgcn_s_sleep(1);
+                        ++spins;
+                        if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
+                        if (spins > f.spin_limit) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+                    }
+                }
+                sm.okx[okslot] = ok;
+                sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff;  // pricing's reductions (reset before a barrier)
+            }
+            __syncthreads();
+            const int okv = sm.okx[okslot];
+            quot = sm.xq2[okslot];
+            okslot ^= 1;  // the next use writes the other words: one barrier per use
+            if (okv == 2) continue;
+            if (okv == 0) R.end_code = 5;
+            break;
+        }
+        if (R.end_code == 5) break;
+        RT_MARK(4);
+        // ---- N: normalised pivot row (simplex.ts:352-364; phase 2: some other row is always eliminated, so the tiny entries
+        //         simplex.ts:381-383 zeroes are zero) -----------------------------------------------------------------------------
+        nzm = 0;
+        if (colok) {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const int col = c0 + j;
+                const double val = pv[j];
+                double v = 0.0;
+                if (col < W) {
+                    const bool innz = nonzero16(val);
+                    v = innz ? val / quot : 0.0;
+                    if (col == pc) v = 1.0 / quot;
+                    if (innz && !nonzero16(v) && v != 0.0) v = 0.0;
+                }
+                p[j] = v;
+                nzm |= nonzero16(v) ? (1u << j) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) p[j] = 0.0;
+        }
+        // the pivot column's own new entries (-k / quot, simplex.ts:386), one lane each; column 0 of my rows after this pivot
+        if (tid < ROWS) sm.nv[tid] = -sm.colb[par][tid] / quot;
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) {
+                const int r = r_begin + i;
+                double v = a[i][0];
+                const double ki = sm.colb[par][i];
+                if (r == pr) v = p[0];
+                else if (r != 0 && r < r_end && nonzero16(ki) && (nzm & 1u)) v = eliminate(v, ki, p[0]);
+                sm.rhsb[i] = v;
+            }
+        }
+        // ---- R0: the cost row (every workgroup its own copy) -----------------------------------------------------------------------
+        {
+            const double k0 = R.k0;
+            if (nonzero16(k0)) {
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if ((nzm >> j) & 1u) r0[j] = eliminate(r0[j], k0, p[j]);
+                if (has_pc) {
+                    const double nv0 = -k0 / quot;
+#pragma unroll
+                    for (int j = 0; j < CPT; j++)
+                        if (pc == c0 + j) r0[j] = nv0;
+                }
+            }
+        }
+        // ---- commit the basis change (simplex.ts:339-349): every workgroup's LDS maps, workgroup 0 the global ones ---------------------
+        if (tid == 0) {
+            const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc];
+            sm.lvibr[pr] = entering;
+            sm.lvibc[pc] = leaving;
+            if (b == 0) {
+                c.vibr[pr] = entering;
+                c.vibc[pc] = leaving;
+                c.rbv[entering] = pr;
+                c.rbv[leaving] = -1;
+                c.cbv[entering] = -1;
+                c.cbv[leaving] = pc;
+                if (R.trace_n < c.trace_cap) c.trace[R.trace_n] = make_int2(pr, pc);
+            }
+        }
+        R.trace_n += 1;
+        R.it2 += 1;
+        R.epoch = epoch + 1;
+        pend = true; pr_p = pr; pc_p = pc; par_p = par;
+        RT_MARK(5);
+        // ---- G: price the new cost row -> entering column of the next pivot ----------------------------------------------------------
+        {
+            int neg_unused = 0;
+            R.pc = price_row_lds<CPT, false>(r0, c0, pb, c, sm, &R.k0, 0u, &neg_unused);
+        }
+        RT_MARK(6);
+        if (R.pc == 0) {  // optimal (simplex.ts:265-269): finish the pending update and leave
+            const bool has_pc_p2 = colok && pc_p >= c0 && pc_p < c0 + CPT;
+            {
+                const bool has_pc_p = has_pc_p2;
+#pragma unroll
+                for (int i = 0; i < ROWS; i++) JSLP_PIPE_UPDATE_ROW(i);
+            }
+            R.end_code = 1;
+        }
+    }
+#undef JSLP_PIPE_UPDATE_ROW
+}
