@@ -34,6 +34,13 @@
 #define JSLP_PIPE_EARLYPOLL 0  // 1: the first poll of the gather is issued before the bulk update and examined after it
 #endif
 
+__device__ __forceinline__ double readlane_f64(double x, int src_lane) {  // src_lane must be wave-uniform
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src_lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), src_lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 template <int THREADS, int CPT, int ROWS>
 __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start,
                                                      const int (&pb)[CPT]) {
@@ -103,14 +110,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             int leave = 0;
             if ((R.it1 - it1_start) + (R.it2 - it2_start) >= f.iters_cap) leave = 4;
             else if (c.check_cycles && !(R.hist_n < JSLP_R_LHIST && R.hist_n < c.hist_cap)) leave = 8;  // history outgrows LDS: the general kernel continues
-            if (leave) {
-                if (pend) {
-#pragma unroll
-                    for (int i = 0; i < ROWS; i++) JSLP_PIPE_UPDATE_ROW(i);
-                }
-                R.end_code = leave;
-                break;
-            }
+            if (leave) { R.end_code = leave; break; }  // (the pending update is applied behind the loop)
         }
         const unsigned epoch = R.epoch;
         const int par = epoch & 1;
@@ -122,58 +122,71 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             break;
         }
         RT_MARK(7);
-        // ---- S: ratio test for column pc (simplex.ts:271-296) by the wave that holds the column ---------------------------
+        // ---- S: ratio test for column pc (simplex.ts:271-296) by the wave that holds the column: the ONE lane that holds it
+        //         evaluates my rows' entries (what the pending pivot makes of them), readlanes hand entry i to lane i, lanes 0..ROWS-1
+        //         classify their row in parallel (one division each), DPP reductions fold the verdicts -- no LDS round trip, no
+        //         workgroup barrier inside -----------------------------------------------------------------------------------------
         if (wv == ((pc / CPT) >> 6)) {
-            if (colok && pc >= c0 && pc < c0 + CPT) {
+            const int ol = __builtin_amdgcn_readfirstlane((pc / CPT) & 63);  // the lane that holds column pc
+            double v[ROWS];
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) v[i] = 0.0;
+            if (lane == ol) {
 #pragma unroll
                 for (int j = 0; j < CPT; j++)
                     if (pc == c0 + j) {
 #pragma unroll
                         for (int i = 0; i < ROWS; i++) {
-                            double v = a[i][j];
+                            double x = a[i][j];
                             if (pend) {  // what the pending pivot makes of this cell (the bulk update will compute the same)
                                 const int r = r_begin + i;
                                 const double ki = sm.colb[par_p][i];
-                                if (r == pr_p) v = p[j];
-                                else if (r != 0 && r < r_end && nonzero16(ki)) {
-                                    if (pc_p == pc) v = sm.nv[i];
-                                    else if ((nzm >> j) & 1u) v = eliminate(v, ki, p[j]);
-                                }
+                                const double nvv = sm.nv[i];
+                                const double e = eliminate(x, ki, p[j]);
+                                if (r == pr_p) x = p[j];
+                                else if (r != 0 && r < r_end && nonzero16(ki)) x = pc_p == pc ? nvv : (((nzm >> j) & 1u) ? e : x);
                             }
-                            sm.colb[par][i] = v;
+                            v[i] = x;
+                            sm.colb[par][i] = x;  // every thread's bulk update of THIS pivot reads it (after the barrier below)
                         }
                     }
             }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+            double colv = 0.0;
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) {
+                const double x = readlane_f64(v[i], ol);
+                colv = lane == i ? x : colv;
+            }
+            int kind = 0;  // 0 skip, 1 degenerate winner, 2 quotient candidate
+            double quo = 0.0;
+            const int r = r_begin + lane;
             if (lane < ROWS) {
-                const int r = r_begin + lane;
-                const double colv = sm.colb[par][lane], rhs = sm.rhsb[lane];
-                int kind = 0;  // 0 skip, 1 degenerate winner, 2 quotient candidate
-                double quo = 0.0;
+                const double rhs = sm.rhsb[lane];
                 if (r >= 1 && r < r_end && !(-precision < colv && colv < precision)) {
                     if (colv > 0 && precision > rhs && rhs > -precision) kind = 1;
                     else { quo = rhs / colv; kind = quo > precision ? 2 : 0; }
                 }
-                sm.quo[lane] = quo;
-                sm.kind[lane] = kind;
             }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            double bq = INFINITY;
-            int br = 0, brdeg = 0x7fffffff;
-#pragma unroll
-            for (int i = 0; i < ROWS; i++) {
-                const int kind = sm.kind[i];
-                const double quo = sm.quo[i];
-                const int r = r_begin + i;
-                if (kind == 1) { if (r < brdeg) brdeg = r; }
-                else if (kind == 2 && bq > quo) { bq = quo; br = r; }
-            }
+            int brdeg = kind == 1 ? r : 0x7fffffff;  // rows ascend with the lane: the smallest row is the first one
+            brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0xB1, 0xf, 0xf, false));
+            brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0x4E, 0xf, 0xf, false));
+            brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0x141, 0xf, 0xf, false));
+            brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0x140, 0xf, 0xf, false));
+            brdeg = __builtin_amdgcn_readlane(brdeg, 0);  // (ROWS <= 16: the candidates sit in the first 16-lane row)
+            KI x;  // quotients are > precision > 0: positive doubles order like their bit patterns; ties -> first row
+            x.k = kind == 2 ? (u64_t)__double_as_longlong(quo) : KI_NONE_KEY;
+            x.i = kind == 2 ? r : 0x7fffffff;
+            x.pad = 0;
+            x = ki_min(x, ki_dpp<0xB1>(x));
+            x = ki_min(x, ki_dpp<0x4E>(x));
+            x = ki_min(x, ki_dpp<0x141>(x));
+            x = ki_min(x, ki_dpp<0x140>(x));
+            x = ki_readlane(x, 0);
             if (lane == 0) {
                 const bool deg = brdeg != 0x7fffffff;
-                const int row = deg ? brdeg : br;  // the only row of mine that can win (0: none)
-                const u64_t qb = (deg || br == 0) ? 0ull : (u64_t)__double_as_longlong(bq);
+                const bool have = x.k != KI_NONE_KEY;
+                const int row = deg ? brdeg : (have ? x.i : 0);  // the only row of mine that can win (0: none)
+                const u64_t qb = (deg || !have) ? 0ull : x.k;
                 v4u_t g;
                 g.x = (unsigned)qb;
                 g.y = tag;
@@ -185,28 +198,10 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         }
         __syncthreads();
         RT_MARK(0);
-        // ---- P: the row that can win: brought up to date, then published (16-byte write-through stores) ----------------------
+        // ---- P + U: the pending pivot's row update (simplex.ts:367-391), ONE pass over my rows; the row that can win is
+        //         published (16-byte write-through stores) as soon as it is up to date.  The summaries are crossing the fabric
+        //         meanwhile ----------------------------------------------------------------------------------------------------------
         const int pubrow = sm.pubrow;
-        if (pubrow != 0) {
-#pragma unroll
-            for (int i = 0; i < ROWS; i++)
-                if (r_begin + i == pubrow) {  // uniform
-                    if (pend) JSLP_PIPE_UPDATE_ROW(i);
-                    if (colok) {
-                        const int off = par * pub_stride + (b * ld + c0) * 8;
-#pragma unroll
-                        for (int j = 0; j < CPT; j += 2) {
-                            if (c0 + j >= ld) continue;
-                            const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
-                            v4u_t v;
-                            v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
-                            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, 16);
-                        }
-                    }
-                }
-        }
-        RT_MARK(1);
-        // ---- C: gather: lane w of the first four waves polls workgroup w's granule; U: the bulk of the pending update -----------
         bool swept = true;
         const bool poller = tid < JSLP_F_MAXG;
         const bool used = tid < f.G;
@@ -214,13 +209,24 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;  // lanes beyond the grid: "no candidate"
         const int goff = (par * JSLP_F_MAXG + tid) * 16;
         if (JSLP_PIPE_EARLYPOLL && poller && used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
-        if (pend) {
 #pragma unroll
-            for (int i = 0; i < ROWS; i++)
-                if (r_begin + i != pubrow || pubrow == 0) JSLP_PIPE_UPDATE_ROW(i);
+        for (int i = 0; i < ROWS; i++) {
+            if (pend) JSLP_PIPE_UPDATE_ROW(i);
+            if (pubrow != 0 && r_begin + i == pubrow && colok) {  // (uniform but for colok)
+                const int off = par * pub_stride + (b * ld + c0) * 8;
+#pragma unroll
+                for (int j = 0; j < CPT; j += 2) {
+                    if (c0 + j >= ld) continue;
+                    const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
+                    v4u_t v;
+                    v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, 16);
+                }
+            }
         }
         pend = false;
         RT_MARK(2);
+        // ---- C: gather: lane w of the first four waves polls workgroup w's granule ------------------------------------------------
         if (poller) {
             unsigned spins = 0;
             bool first = JSLP_PIPE_EARLYPOLL != 0;
@@ -360,17 +366,19 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
             for (int j = 0; j < CPT; j++) p[j] = 0.0;
         }
-        // the pivot column's own new entries (-k / quot, simplex.ts:386), one lane each; column 0 of my rows after this pivot
-        if (tid < ROWS) sm.nv[tid] = -sm.colb[par][tid] / quot;
-        if (tid == 0) {
-#pragma unroll
-            for (int i = 0; i < ROWS; i++) {
-                const int r = r_begin + i;
-                double v = a[i][0];
-                const double ki = sm.colb[par][i];
-                if (r == pr) v = p[0];
-                else if (r != 0 && r < r_end && nonzero16(ki) && (nzm & 1u)) v = eliminate(v, ki, p[0]);
-                sm.rhsb[i] = v;
+        // the pivot column's own new entries (-k / quot, simplex.ts:386) and column 0 of my rows after this pivot (sm.rhsb is
+        // the ratio test's copy of that column: it receives what the bulk update will give a[i][0]): lanes 0..ROWS-1 of wave 0
+        if (wv == 0) {
+            const double p0 = readlane_f64(p[0], 0);
+            const unsigned nz0 = (unsigned)__builtin_amdgcn_readfirstlane((int)nzm) & 1u;
+            if (lane < ROWS) {
+                const int r = r_begin + lane;
+                const double ki = sm.colb[par][lane];
+                double v = sm.rhsb[lane];
+                if (r == pr) v = p0;
+                else if (r != 0 && r < r_end && nonzero16(ki) && nz0) v = eliminate(v, ki, p0);
+                sm.rhsb[lane] = v;
+                sm.nv[lane] = -ki / quot;
             }
         }
         // ---- R0: the cost row (every workgroup its own copy) -----------------------------------------------------------------------
@@ -389,7 +397,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             }
         }
         // ---- commit the basis change (simplex.ts:339-349): every workgroup's LDS maps, workgroup 0 the global ones ---------------------
-        if (tid == 0) {
+        if (tid == THREADS - 64) {  // (not thread 0: its wave carries the column-0 work above)
             const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc];
             sm.lvibr[pr] = entering;
             sm.lvibc[pc] = leaving;
@@ -414,15 +422,12 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             R.pc = price_row_lds<CPT, false>(r0, c0, pb, c, sm, &R.k0, 0u, &neg_unused);
         }
         RT_MARK(6);
-        if (R.pc == 0) {  // optimal (simplex.ts:265-269): finish the pending update and leave
-            const bool has_pc_p2 = colok && pc_p >= c0 && pc_p < c0 + CPT;
-            {
-                const bool has_pc_p = has_pc_p2;
+        if (R.pc == 0) R.end_code = 1;  // optimal (simplex.ts:265-269)
+    }
+    if (pend && R.end_code != 5) {  // whoever leaves with a pivot pending (optimal, iteration cap, hand-over) brings the rows up to date
+        const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;
 #pragma unroll
-                for (int i = 0; i < ROWS; i++) JSLP_PIPE_UPDATE_ROW(i);
-            }
-            R.end_code = 1;
-        }
+        for (int i = 0; i < ROWS; i++) JSLP_PIPE_UPDATE_ROW(i);
     }
 #undef JSLP_PIPE_UPDATE_ROW
 }
