@@ -128,38 +128,36 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         //         workgroup barrier inside -----------------------------------------------------------------------------------------
         if (wv == ((pc / CPT) >> 6)) {
             const int ol = __builtin_amdgcn_readfirstlane((pc / CPT) & 63);  // the lane that holds column pc
-            double v[ROWS];
+            const int jsel = __builtin_amdgcn_readfirstlane(pc % CPT);        // ... as its column jsel
+            // lane i < ROWS receives row i's current entry, the pending pivot's row entry of that column and its non-zero flag,
+            // and applies the pending pivot to it (what the bulk update will compute for that cell)
+            double x = 0.0, pj = 0.0;
+            unsigned nzj = 0;
 #pragma unroll
-            for (int i = 0; i < ROWS; i++) v[i] = 0.0;
-            if (lane == ol) {
+            for (int j = 0; j < CPT; j++)
+                if (jsel == j) {  // uniform
 #pragma unroll
-                for (int j = 0; j < CPT; j++)
-                    if (pc == c0 + j) {
-#pragma unroll
-                        for (int i = 0; i < ROWS; i++) {
-                            double x = a[i][j];
-                            if (pend) {  // what the pending pivot makes of this cell (the bulk update will compute the same)
-                                const int r = r_begin + i;
-                                const double ki = sm.colb[par_p][i];
-                                const double nvv = sm.nv[i];
-                                const double e = eliminate(x, ki, p[j]);
-                                if (r == pr_p) x = p[j];
-                                else if (r != 0 && r < r_end && nonzero16(ki)) x = pc_p == pc ? nvv : (((nzm >> j) & 1u) ? e : x);
-                            }
-                            v[i] = x;
-                            sm.colb[par][i] = x;  // every thread's bulk update of THIS pivot reads it (after the barrier below)
-                        }
+                    for (int i = 0; i < ROWS; i++) {
+                        const double xi = readlane_f64(a[i][j], ol);
+                        x = lane == i ? xi : x;
                     }
-            }
+                    pj = readlane_f64(p[j], ol);
+                    nzj = ((unsigned)__builtin_amdgcn_readlane((int)nzm, ol) >> j) & 1u;
+                }
+            const int r = r_begin + lane;
             double colv = 0.0;
-#pragma unroll
-            for (int i = 0; i < ROWS; i++) {
-                const double x = readlane_f64(v[i], ol);
-                colv = lane == i ? x : colv;
+            if (lane < ROWS) {
+                colv = x;
+                if (pend) {
+                    const double ki = sm.colb[par_p][lane];
+                    const double nvv = sm.nv[lane];
+                    if (r == pr_p) colv = pj;
+                    else if (r != 0 && r < r_end && nonzero16(ki)) colv = pc_p == pc ? nvv : (nzj ? eliminate(x, ki, pj) : x);
+                }
+                sm.colb[par][lane] = colv;  // every thread's bulk update of THIS pivot reads it (after the barrier below)
             }
             int kind = 0;  // 0 skip, 1 degenerate winner, 2 quotient candidate
             double quo = 0.0;
-            const int r = r_begin + lane;
             if (lane < ROWS) {
                 const double rhs = sm.rhsb[lane];
                 if (r >= 1 && r < r_end && !(-precision < colv && colv < precision)) {
@@ -173,20 +171,20 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0x141, 0xf, 0xf, false));
             brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0x140, 0xf, 0xf, false));
             brdeg = __builtin_amdgcn_readlane(brdeg, 0);  // (ROWS <= 16: the candidates sit in the first 16-lane row)
-            KI x;  // quotients are > precision > 0: positive doubles order like their bit patterns; ties -> first row
-            x.k = kind == 2 ? (u64_t)__double_as_longlong(quo) : KI_NONE_KEY;
-            x.i = kind == 2 ? r : 0x7fffffff;
-            x.pad = 0;
-            x = ki_min(x, ki_dpp<0xB1>(x));
-            x = ki_min(x, ki_dpp<0x4E>(x));
-            x = ki_min(x, ki_dpp<0x141>(x));
-            x = ki_min(x, ki_dpp<0x140>(x));
-            x = ki_readlane(x, 0);
+            KI bk;  // quotients are > precision > 0: positive doubles order like their bit patterns; ties -> first row
+            bk.k = kind == 2 ? (u64_t)__double_as_longlong(quo) : KI_NONE_KEY;
+            bk.i = kind == 2 ? r : 0x7fffffff;
+            bk.pad = 0;
+            bk = ki_min(bk, ki_dpp<0xB1>(bk));
+            bk = ki_min(bk, ki_dpp<0x4E>(bk));
+            bk = ki_min(bk, ki_dpp<0x141>(bk));
+            bk = ki_min(bk, ki_dpp<0x140>(bk));
+            bk = ki_readlane(bk, 0);
             if (lane == 0) {
                 const bool deg = brdeg != 0x7fffffff;
-                const bool have = x.k != KI_NONE_KEY;
-                const int row = deg ? brdeg : (have ? x.i : 0);  // the only row of mine that can win (0: none)
-                const u64_t qb = (deg || !have) ? 0ull : x.k;
+                const bool have = bk.k != KI_NONE_KEY;
+                const int row = deg ? brdeg : (have ? bk.i : 0);  // the only row of mine that can win (0: none)
+                const u64_t qb = (deg || !have) ? 0ull : bk.k;
                 v4u_t g;
                 g.x = (unsigned)qb;
                 g.y = tag;

@@ -38,7 +38,7 @@ struct Args {
     u64* gran;     // [2][G]
     u64* grp;      // [2][16] group granules (flavours 5, 6)
     u64* out;      // [G][4]: cycles, timeouts, xcc, n_mem
-    int G, rounds, flavour;
+    int G, rounds, flavour, stride;  // stride: u64 words between consecutive workgroups' granules (1 = packed; 512 = one per 4 KB)
     unsigned spin_limit;
 };
 
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) k_bench(Args a) {
     for (int round = 0; round < a.rounds; round++) {
         const int par = round & 1;
         const u64 tag = (u64)(round + 1);
-        u64* mine = a.gran + (size_t)par * a.G + b;
+        u64* mine = a.gran + ((size_t)par * a.G + b) * a.stride;
         const u64 val = (tag << 32) | (unsigned)(b * 7 + round);
         if (tid == 0) {
             switch (a.flavour) {
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) k_bench(Args a) {
         for (int base = 0; base < nm; base += 256) {
             const int k = base + tid;
             if (k < nm) {
-                u64* p = a.gran + (size_t)par * a.G + mem[k];
+                u64* p = a.gran + ((size_t)par * a.G + mem[k]) * a.stride;
                 unsigned spins = 0;
                 for (;;) {
                     u64 x;
@@ -130,11 +130,11 @@ __global__ void __launch_bounds__(256) k_bench(Args a) {
 }
 
 int main(int argc, char** argv) {
-    const int G = argc > 1 ? atoi(argv[1]) : 256, rounds = argc > 2 ? atoi(argv[2]) : 2000;
+    const int G = argc > 1 ? atoi(argv[1]) : 256, rounds = argc > 2 ? atoi(argv[2]) : 2000, stride = argc > 3 ? atoi(argv[3]) : 1;
     u64 *xcctab, *gran, *out, *grp;
     CHECK(hipMalloc(&grp, sizeof(u64) * 32));
     CHECK(hipMalloc(&xcctab, sizeof(u64) * G));
-    CHECK(hipMalloc(&gran, sizeof(u64) * 2 * G));
+    CHECK(hipMalloc(&gran, sizeof(u64) * 2 * G * stride));
     CHECK(hipMalloc(&out, sizeof(u64) * 4 * G));
     const size_t lds = 148 * 1024;  // one workgroup per CU
     CHECK(hipFuncSetAttribute((const void*)k_bench, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -145,10 +145,10 @@ int main(int argc, char** argv) {
         if (fl == 2 || fl == 3) continue;  // (L2-executed atomics: measured 8.8-12.7 k cycles per round, r03_b)
         for (int rep = 0; rep < 2; rep++) {
             CHECK(hipMemset(xcctab, 0, sizeof(u64) * G));
-            CHECK(hipMemset(gran, 0, sizeof(u64) * 2 * G));
+            CHECK(hipMemset(gran, 0, sizeof(u64) * 2 * G * stride));
             CHECK(hipMemset(out, 0, sizeof(u64) * 4 * G));
             CHECK(hipMemset(grp, 0, sizeof(u64) * 32));
-            Args a{xcctab, gran, grp, out, G, rounds, fl, 1u << 16};
+            Args a{xcctab, gran, grp, out, G, rounds, fl, stride, 1u << 16};
             void* args[] = {&a};
             CHECK(hipLaunchCooperativeKernel((const void*)k_bench, dim3(G), dim3(256), args, lds, 0));
             CHECK(hipDeviceSynchronize());
@@ -163,7 +163,7 @@ int main(int argc, char** argv) {
                 members[h[b * 4 + 2] & 15]++;
             }
             if (rep == 1) {
-                printf("flavour %d (%s): cycles/round min %llu max %llu, timed-out rounds (summed over workgroups) %llu of %d x %d; members per XCC:", fl, names[fl],
+                printf("stride %d words, flavour %d (%s): cycles/round min %llu max %llu, timed-out rounds (summed over workgroups) %llu of %d x %d; members per XCC:", stride, fl, names[fl],
                        cyc_min, cyc_max, to, rounds, G);
                 for (int x = 0; x < 16; x++) if (members[x]) printf(" %d:%d", x, members[x]);
                 printf("\n");
