@@ -26,8 +26,9 @@
 #define JSLP_R_LUNR 8192     // variable indexes whose unrestricted flag fits the LDS copy (more: gather-by-leader protocol)
 #define JSLP_R_LHIST 10240   // cycle-check history entries kept in LDS (80 KB)
 // hand-off words of one engine (one allocation, zeroed per launch): [2][G][8] granules, [2][G] row flags, [2][G] chip-wide OR flags,
-// 32 words of decision / verdict, then the lean kernel's [2][G] 16-byte summary granules
-#define JSLP_R_SYNC_WORDS (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32 + 2 * JSLP_F_MAXG * 2)
+// 32 words of decision / verdict, then the lean kernel's [2][G] 16-byte summary granules (JSLP_G16_STRIDE bytes apart)
+#define JSLP_R_SYNC_WORDS_GENERAL (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32 + 2 * JSLP_F_MAXG * 2)  // (the last 8 KB: the lean kernel's XCD-local summaries)
+#define JSLP_R_SYNC_WORDS (JSLP_R_SYNC_WORDS_GENERAL + 2 * 32 * JSLP_F_MAXG * 8)  // (room for 32 copies of the lean kernel's granules, 64 bytes apart: 1 MB)
 #ifndef JSLP_RES_FAST
 #define JSLP_RES_FAST 1      // one barrier around the row flag (step E); the -k/quot entries of the pivot column computed by eight lanes in parallel while the winning row is in flight instead of one after the other by the lane that owns the column (step F)
 #endif
@@ -67,7 +68,8 @@ struct ResCtx {
     u64_t* decision[2];   // leader's per-pivot decision: 3 tagged granules {pr | stop << 16}, {quot lo}, {quot hi}
     u64_t* verdict[2];    // phase 1 only: leader's cycle-check verdict {tag | stop} (the entering column is known late there)
     u64_t* gor[2];        // [G] rare slow path: tagged per-workgroup flags for a chip-wide OR
-    u64_t* gran16;        // [2][MAXG] 16-byte summary granules of the lean kernel's pipelined phase 2 (jslp_resident_pipe.hip.h)
+    u64_t* gran16;        // [2][REPL][MAXG] 16-byte summary granules of the lean kernel's pipelined phase 2 (jslp_resident_pipe.hip.h)
+    u64_t* g1;            // [2][8][32] the same summaries once more, XCD-local (plain stores: they live in the XCD's L2)
     int32_t G, rpb, H;
     int32_t n_idx;             // variable indexes in use (the LDS copy of the unrestricted flags covers JSLP_R_LUNR of them)
     int32_t iters_cap;
@@ -113,6 +115,8 @@ struct RSmem {
     u64_t part_k[JSLP_F_MAXG / 64];
     int32_t part_r[JSLP_F_MAXG / 64], part_rdeg[JSLP_F_MAXG / 64];
     double xq2[2];
+    unsigned myg[4];   // my own summary granule, for the pruning wave
+    int32_t pubme;     // the pruning wave's verdict: my candidate row is published
     // All-gather protocol: what only workgroup 0 knows in the gather-by-leader protocol lives in EVERY workgroup's LDS -- the
     // row / column maps (swapped at every pivot like the global ones), the unrestricted flag of every variable index, and the
     // cycle-check history (the first JSLP_R_LHIST entries; a longer solve continues with the leader protocol, whose check

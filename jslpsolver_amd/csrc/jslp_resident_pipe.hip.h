@@ -30,6 +30,30 @@
 //     the four partial results meet in LDS under the barrier that also drains the row stores: no separate decision stage;
 //   * 6 workgroup barriers per pivot instead of 8 (cycle check off).
 // ===================================================================================================================
+#ifndef JSLP_G16_STRIDE
+// bytes between two workgroups' 16-byte summary granules: one granule per 64-byte line.  Granules that share a line cost the
+// chip-wide all-gather 7.7 k cycles per round against 4.8 k with a line each (tools/micro/xcd_handoff_bench.hip, r03_d): the
+// write-through stores of different CUs to one line serialise at the memory side
+#define JSLP_G16_STRIDE 64
+#endif
+#ifndef JSLP_G16_REPL
+// copies of every summary granule.  A chip-wide all-gather is bound by its READERS: 256 CUs polling one line are served one
+// after the other by that line's memory channel (micro-benchmark, r03_d: 8 publishers -> 256 pollers 4.5 k cycles per round,
+// 32 -> 32 pollers 2.2 k).  The publishing wave's lanes 0..REPL-1 store one copy each (one instruction), workgroup b polls copy
+// b % REPL: 256 / REPL readers per line.
+#define JSLP_G16_REPL 8
+#endif
+#ifndef JSLP_PIPE_PRUNE
+// Speculative row publication pruned inside the XCD.  Every workgroup used to publish the one row of its own that can win
+// (16 KB write-through each: 4 MB per pivot chip-wide, one row in 256 consumed) and then had to wait for that burst to drain
+// before it could raise its row flag.  Now the workgroups that share an XCD -- b % 8 as observed on gfx950; any grouping is
+// CORRECT, see below -- also exchange their summaries through the XCD's own L2 (plain 16-byte store, sc1 load: 2 k cycles per
+// exchange against 4.8-7.7 k chip-wide, tools/micro/xcd_handoff_bench.hip) while the row update runs, and a workgroup that
+// sees a better candidate than its own among them does not publish.  The chip-wide winner never sees a better candidate, so
+// it always publishes: a summary that is late, stale or never visible (wrong guess about the placement) only means one more
+// row published, never a missing one.  ~8 rows per pivot instead of 256.
+#define JSLP_PIPE_PRUNE 1
+#endif
 #ifndef JSLP_PIPE_EARLYPOLL
 #define JSLP_PIPE_EARLYPOLL 0  // 1: the first poll of the gather is issued before the bulk update and examined after it
 #endif
@@ -56,7 +80,9 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
     const int pub_stride = (int)((const char*)f.rows_pub[1] - (const char*)f.rows_pub[0]);  // (both carved from one arena, [0] first)
     const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + f.G * ld * 8, 0x00020000);
-    const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, 2 * JSLP_F_MAXG * 16, 0x00020000);
+    const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, 2 * JSLP_G16_REPL * JSLP_F_MAXG * JSLP_G16_STRIDE, 0x00020000);
+    const auto rsrc_g1 = __builtin_amdgcn_make_buffer_rsrc(f.g1, 0, 2 * JSLP_F_MAXG * 16, 0x00020000);  // [2][8 groups][32 members] x 16 bytes
+    const int grp = b & 7, mem = b >> 3;  // my group (the XCD block b is observed to run on) and my place in it
 #ifdef JSLP_DEBUG_RESIDENT
     u64_t (&rt_acc)[8] = R.rt_acc;
     u64_t& rt_prev = R.rt_prev;
@@ -84,7 +110,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             _Pragma("unroll") for (int j = 0; j < CPT; j++) a[i][j] = p[j];                                 \
             break;                                                                                          \
         }                                                                                                   \
-        const double ki_ = sm.colb[par_p][i];                                                               \
+        const double ki_ = kis[i];                                                                          \
         if (nonzero16(ki_)) {                                                                               \
             _Pragma("unroll") for (int j = 0; j < CPT; j++)                                                 \
                 if ((nzm >> j) & 1u) a[i][j] = eliminate(a[i][j], ki_, p[j]);                               \
@@ -180,7 +206,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             bk = ki_min(bk, ki_dpp<0x141>(bk));
             bk = ki_min(bk, ki_dpp<0x140>(bk));
             bk = ki_readlane(bk, 0);
-            if (lane == 0) {
+            if (lane < JSLP_G16_REPL) {
                 const bool deg = brdeg != 0x7fffffff;
                 const bool have = bk.k != KI_NONE_KEY;
                 const int row = deg ? brdeg : (have ? bk.i : 0);  // the only row of mine that can win (0: none)
@@ -190,8 +216,14 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 g.y = tag;
                 g.z = (unsigned)(qb >> 32);
                 g.w = ((tag & 0xffffu) << 16) | (deg ? 0x8000u : 0u) | (unsigned)row;
-                __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_g16, (par * JSLP_F_MAXG + b) * 16, 0, 16);  // aux 16 = sc1
-                sm.pubrow = row;
+                __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_g16, ((par * JSLP_G16_REPL + lane) * JSLP_F_MAXG + b) * JSLP_G16_STRIDE, 0, 16);  // aux 16 = sc1
+                if (lane == 0) {
+                    sm.pubrow = row;
+                    if (JSLP_PIPE_PRUNE) {  // the XCD-local copy: a PLAIN store (stays in this XCD's L2), and my own summary for the pruning wave
+                        __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_g1, ((par * 8 + grp) * 32 + mem) * 16, 0, 0);
+                        sm.myg[0] = g.x; sm.myg[1] = g.y; sm.myg[2] = g.z; sm.myg[3] = g.w;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -205,12 +237,63 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         const bool used = tid < f.G;
         v4u_t g;
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;  // lanes beyond the grid: "no candidate"
-        const int goff = (par * JSLP_F_MAXG + tid) * 16;
+        const int goff = ((par * JSLP_G16_REPL + (b % JSLP_G16_REPL)) * JSLP_F_MAXG + tid) * JSLP_G16_STRIDE;
         if (JSLP_PIPE_EARLYPOLL && poller && used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
+        if (JSLP_PIPE_PRUNE && wv == THREADS / 64 - 1) {
+            // the last wave: is my candidate the best one among the workgroups of my XCD?  Lane l looks at member l of my group
+            // (a few bounded polls of the XCD-local copies; what is not visible by then counts as "no candidate")
+            int pubme = 0;
+            if (pubrow != 0) {
+                const int w = grp + 8 * lane;
+                const bool other = lane < 32 && w < f.G && lane != mem;
+                v4u_t h;
+                h.x = sm.myg[0]; h.y = sm.myg[1]; h.z = sm.myg[2]; h.w = sm.myg[3];  // (my own lane and the unused ones: my summary)
+                const int hoff = ((par * 8 + grp) * 32 + lane) * 16;
+                bool ok = !other;
+#pragma unroll 1
+                for (int spin = 0; spin < 4; spin++) {
+                    if (other && !ok) {
+                        const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g1, hoff, 0, 16);
+                        if (t.y == tag && (t.w >> 16) == (tag & 0xffffu)) { h = t; ok = true; }
+                    }
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                const int row = (int)(h.w & 0x7fffu);
+                const bool deg = (h.w & 0x8000u) != 0u;
+                int rdeg = (deg && row != 0) ? row : 0x7fffffff;
+                rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0xB1, 0xf, 0xf, false));
+                rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x4E, 0xf, 0xf, false));
+                rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x141, 0xf, 0xf, false));
+                rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x140, 0xf, 0xf, false));
+                rdeg = min(min(__builtin_amdgcn_readlane(rdeg, 0), __builtin_amdgcn_readlane(rdeg, 16)),
+                           min(__builtin_amdgcn_readlane(rdeg, 32), __builtin_amdgcn_readlane(rdeg, 48)));
+                KI y;
+                const bool cand = !deg && row != 0;
+                y.k = cand ? ((u64_t)h.x | ((u64_t)h.z << 32)) : KI_NONE_KEY;
+                y.i = cand ? row : 0x7fffffff;
+                y.pad = 0;
+                y = ki_wave_min(y);
+                const int best = rdeg != 0x7fffffff ? rdeg : (y.k == KI_NONE_KEY ? 0 : y.i);
+                pubme = best == pubrow ? 1 : 0;
+            }
+            if (lane == 0) sm.pubme = pubme;
+        }
+        double kis[ROWS];  // the pending pivot's column entries of my rows: ROWS broadcast reads in flight together, one wait
+#pragma unroll
+        for (int i = 0; i < ROWS; i++) kis[i] = sm.colb[par_p][i];
+        if (JSLP_PIPE_PRUNE) {
+            if (pend) {
+#pragma unroll
+                for (int i = 0; i < ROWS; i++) JSLP_PIPE_UPDATE_ROW(i);
+            }
+            __syncthreads();  // the pruning wave's verdict (the summaries are still crossing the fabric: this barrier is not on the critical path)
+        }
+        const bool publish = pubrow != 0 && (!JSLP_PIPE_PRUNE || sm.pubme != 0);
 #pragma unroll
         for (int i = 0; i < ROWS; i++) {
-            if (pend) JSLP_PIPE_UPDATE_ROW(i);
-            if (pubrow != 0 && r_begin + i == pubrow && colok) {  // (uniform but for colok)
+            if (!JSLP_PIPE_PRUNE && pend) JSLP_PIPE_UPDATE_ROW(i);
+            if (publish && r_begin + i == pubrow && colok) {  // (uniform but for colok)
                 const int off = par * pub_stride + (b * ld + c0) * 8;
 #pragma unroll
                 for (int j = 0; j < CPT; j += 2) {
@@ -256,10 +339,11 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             x = ki_wave_min(x);
             if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; sm.part_rdeg[wv] = rdeg; }
         }
+        RT_MARK(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my row stores are written through
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
-        if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: the row is visible
+        if (tid == 0 && publish) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: the row is visible
         RT_MARK(3);
         // ---- D: every thread folds the four partial results ------------------------------------------------------------------
         int pr = 0, stop = 0;
@@ -424,6 +508,9 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     }
     if (pend && R.end_code != 5) {  // whoever leaves with a pivot pending (optimal, iteration cap, hand-over) brings the rows up to date
         const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;
+        double kis[ROWS];
+#pragma unroll
+        for (int i = 0; i < ROWS; i++) kis[i] = sm.colb[par_p][i];
 #pragma unroll
         for (int i = 0; i < ROWS; i++) JSLP_PIPE_UPDATE_ROW(i);
     }
