@@ -967,11 +967,9 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             rc.verdict[1] = rc.decision[0] + 24;
             rc.gor[0] = rc.decision[0] + 32;
             rc.gor[1] = rc.gor[0] + JSLP_F_MAXG;
-            rc.g1 = e->r_gran + (size_t)2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32;  // [2][8][32] 16-byte granules
-            rc.gran16 = e->r_gran + JSLP_R_SYNC_WORDS_GENERAL;                       // [2][REPL][MAXG] granules, 64 bytes apart
+            rc.gran16 = e->r_gran + JSLP_R_SYNC_WORDS_GENERAL;  // [2][MAXG] granules, 64 bytes apart
             rc.abort_flag = e->r_sync + 4;
-            // tags restart at 1 (the lean kernel's granule copies: only the ones this build uses)
-            HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * JSLP_R_SYNC_WORDS_GENERAL + (size_t)2 * JSLP_G16_REPL * JSLP_F_MAXG * JSLP_G16_STRIDE, s));
+            HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * JSLP_R_SYNC_WORDS, s));  // tags restart at 1
             rc.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
             rc.G = (H + rc.rpb - 1) / rc.rpb;
             rc.H = H;

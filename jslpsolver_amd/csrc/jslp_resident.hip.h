@@ -27,8 +27,8 @@
 #define JSLP_R_LHIST 10240   // cycle-check history entries kept in LDS (80 KB)
 // hand-off words of one engine (one allocation, zeroed per launch): [2][G][8] granules, [2][G] row flags, [2][G] chip-wide OR flags,
 // 32 words of decision / verdict, then the lean kernel's [2][G] 16-byte summary granules (JSLP_G16_STRIDE bytes apart)
-#define JSLP_R_SYNC_WORDS_GENERAL (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32 + 2 * JSLP_F_MAXG * 2)  // (the last 8 KB: the lean kernel's XCD-local summaries)
-#define JSLP_R_SYNC_WORDS (JSLP_R_SYNC_WORDS_GENERAL + 2 * 32 * JSLP_F_MAXG * 8)  // (room for 32 copies of the lean kernel's granules, 64 bytes apart: 1 MB)
+#define JSLP_R_SYNC_WORDS_GENERAL (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32)
+#define JSLP_R_SYNC_WORDS (JSLP_R_SYNC_WORDS_GENERAL + 2 * JSLP_F_MAXG * 8)  // (+ the lean kernel's granules, 64 bytes apart)
 #ifndef JSLP_RES_FAST
 #define JSLP_RES_FAST 1      // one barrier around the row flag (step E); the -k/quot entries of the pivot column computed by eight lanes in parallel while the winning row is in flight instead of one after the other by the lane that owns the column (step F)
 #endif
@@ -68,8 +68,7 @@ struct ResCtx {
     u64_t* decision[2];   // leader's per-pivot decision: 3 tagged granules {pr | stop << 16}, {quot lo}, {quot hi}
     u64_t* verdict[2];    // phase 1 only: leader's cycle-check verdict {tag | stop} (the entering column is known late there)
     u64_t* gor[2];        // [G] rare slow path: tagged per-workgroup flags for a chip-wide OR
-    u64_t* gran16;        // [2][REPL][MAXG] 16-byte summary granules of the lean kernel's pipelined phase 2 (jslp_resident_pipe.hip.h)
-    u64_t* g1;            // [2][8][32] the same summaries once more, XCD-local (plain stores: they live in the XCD's L2)
+    u64_t* gran16;        // [2][MAXG] 16-byte summary granules of the lean kernel's pipelined phase 2, 64 bytes apart (jslp_resident_pipe.hip.h)
     int32_t G, rpb, H;
     int32_t n_idx;             // variable indexes in use (the LDS copy of the unrestricted flags covers JSLP_R_LUNR of them)
     int32_t iters_cap;
@@ -115,8 +114,6 @@ struct RSmem {
     u64_t part_k[JSLP_F_MAXG / 64];
     int32_t part_r[JSLP_F_MAXG / 64], part_rdeg[JSLP_F_MAXG / 64];
     double xq2[2];
-    unsigned myg[4];   // my own summary granule, for the pruning wave
-    int32_t pubme;     // the pruning wave's verdict: my candidate row is published
     // All-gather protocol: what only workgroup 0 knows in the gather-by-leader protocol lives in EVERY workgroup's LDS -- the
     // row / column maps (swapped at every pivot like the global ones), the unrestricted flag of every variable index, and the
     // cycle-check history (the first JSLP_R_LHIST entries; a longer solve continues with the leader protocol, whose check
@@ -974,10 +971,13 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
         if (R.end_code == 0) phase = 2;
     }
     if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
-        R.pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg);
-        if (R.pc == 0) R.end_code = 1;
-        else if (LEAN) resident_phase2_pipe<THREADS, CPT, ROWS>(f, sm, R, it1_start, it2_start, pb);
-        else resident_phase<2, THREADS, CPT, ROWS, UNR>(f, sm, R, it1_start, it2_start, pb);
+        if (LEAN) {
+            resident_phase2_pipe<THREADS, CPT, ROWS>(f, sm, R, it1_start, it2_start, pb);  // (prices at the top of its loop)
+        } else {
+            R.pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg);
+            if (R.pc == 0) R.end_code = 1;
+            else resident_phase<2, THREADS, CPT, ROWS, UNR>(f, sm, R, it1_start, it2_start, pb);
+        }
     }
     const int end_code = R.end_code, unbounded_col = R.unbounded_col, hist_n = R.hist_n, it1 = R.it1, it2 = R.it2;
     const unsigned epoch = R.epoch;

@@ -1,23 +1,25 @@
 // jslp_resident_pipe.hip.h -- the LEAN register-resident kernel's phase 2: a software-pipelined pivot loop.
-// Included by jslp_resident.hip.h between its building blocks (ResCtx / RSmem / ResRegs / price_row_lds) and its kernel.
+// Included by jslp_resident.hip.h between its building blocks (ResCtx / RSmem / ResRegs) and its kernel.
 #pragma once
 
 // ===================================================================================================================
 // Why a second loop.  k_simplex_resident's general pivot loop (jslp_resident.hip.h) runs its steps strictly one after the
 // other: summary -> publish -> gather -> decide -> fetch the winning row -> update my rows -> price -> summary ...; the row
 // update (16 waves x 8 rows x 2 columns of two-rounding eliminations, ~3 k cycles) and the fabric hop of the NEXT pivot's
-// summary (~1 us) both sit on the critical path although neither needs the other.  Here the loop is rotated:
+// summary (~2 us) both sit on the critical path although neither needs the other.  Here the loop is rotated:
 //
 //   winner row of pivot t lands
-//     -> normalise it, update the COST row only, price it                  (entering column of pivot t+1: simplex.ts:118-219)
-//     -> the ONE lane that holds column pc(t+1) evaluates what pivot t makes of that column in my rows, lane 0 of the
-//        workgroup does the same for column 0, the wave that owns pc(t+1) runs the ratio test on the two       (simplex.ts:271-296)
-//     -> the summary of pivot t+1 is published, the row that can win is brought up to date and published
-//     -> ONLY NOW the bulk of pivot t's row update (simplex.ts:367-391), while the summaries cross the fabric
+//     -> normalise it, update the COST row only                                                    (simplex.ts:352-364, 394-412)
+//     -> price it: entering column of pivot t+1                                                    (simplex.ts:118-219)
+//     -> the wave that holds that column evaluates what pivot t makes of the column in my rows (eight lanes, one row each)
+//        and runs the ratio test on it                                                              (simplex.ts:271-296)
+//     -> the summary of pivot t+1 is published
+//     -> ONLY NOW the row update of pivot t (simplex.ts:367-391), while the summaries cross the fabric; the row that can win
+//        is published from inside that pass
 //     -> gather, decide, fetch the winning row of pivot t+1 ...
 //
 // Same arithmetic on the same operands in the same order for every cell (each cell still receives exactly one
-// `a - k * p` with both roundings per pivot; "early" values are computed from the same inputs as the bulk update computes
+// `a - k * p` with both roundings per pivot; "early" values are computed from the same inputs as the update pass computes
 // them later), so the pivot sequence and every bit of the final tableau are unchanged -- the parity tests do not
 // distinguish the two loops.
 //
@@ -28,35 +30,22 @@
 //     a workgroup with a degenerate row publishes only that (its quotient candidates cannot win: simplex.ts:285-289);
 //   * four waves poll (lane w = workgroup w, one 16-byte sc1 load each) and reduce their 64 summaries in registers (DPP);
 //     the four partial results meet in LDS under the barrier that also drains the row stores: no separate decision stage;
+//   * pricing moved to the top of the loop (the loop is entered with the tableau whole and leaves a pending update to its epilogue);
 //   * 6 workgroup barriers per pivot instead of 8 (cycle check off).
+//
+// Measured on the way and left out (config 3a, pivots/s; r03_e ... r03_h): summary granules 16 / 64 / 128 bytes apart 160.4 k /
+// 161.7 k / 161.4 k (the micro-benchmark's 7.7 k -> 4.8 k cycles per chip-wide all-gather for one line per granule does not show
+// in the kernel); 8 / 16 / 32 copies of every granule, workgroup b polling copy b % n: 160.1 k / 161.4 k / 161.8 k against 162.2 k
+// for one; the first poll issued before the update pass: 128.6 k against 128.8 k at the time; 512 lanes x 4 columns: 145.6 k
+// against 161.7 k; candidate rows published only by the workgroup that holds the best summary of its XCD (summaries exchanged
+// once more through the XCD's own L2 -- plain store + sc1 load, tools/micro/xcd_handoff_bench.hip -- while the update runs:
+// ~8 rows of write-through per pivot instead of 256): 133.2 k against 161.3 k, the verdict arrives behind the update and the
+// 4 MB burst it removes was not what the gather waits for; pricing and ratio test sharing their barriers (round A: one DPP
+// maximum per wave + one LDS atomic into a per-batch slot; every wave holding a column with that value claims it and runs the
+// ratio test for its claim into a per-wave staging area; 4 barriers per pivot): 154.3 k against 161.7 k -- the wave-wide 64-bit
+// maximum in all 16 waves costs more than the two LDS-atomic rounds it replaces.
 // ===================================================================================================================
-#ifndef JSLP_G16_STRIDE
-// bytes between two workgroups' 16-byte summary granules: one granule per 64-byte line.  Granules that share a line cost the
-// chip-wide all-gather 7.7 k cycles per round against 4.8 k with a line each (tools/micro/xcd_handoff_bench.hip, r03_d): the
-// write-through stores of different CUs to one line serialise at the memory side
-#define JSLP_G16_STRIDE 64
-#endif
-#ifndef JSLP_G16_REPL
-// copies of every summary granule.  A chip-wide all-gather is bound by its READERS: 256 CUs polling one line are served one
-// after the other by that line's memory channel (micro-benchmark, r03_d: 8 publishers -> 256 pollers 4.5 k cycles per round,
-// 32 -> 32 pollers 2.2 k).  The publishing wave's lanes 0..REPL-1 store one copy each (one instruction), workgroup b polls copy
-// b % REPL: 256 / REPL readers per line.
-#define JSLP_G16_REPL 8
-#endif
-#ifndef JSLP_PIPE_PRUNE
-// Speculative row publication pruned inside the XCD.  Every workgroup used to publish the one row of its own that can win
-// (16 KB write-through each: 4 MB per pivot chip-wide, one row in 256 consumed) and then had to wait for that burst to drain
-// before it could raise its row flag.  Now the workgroups that share an XCD -- b % 8 as observed on gfx950; any grouping is
-// CORRECT, see below -- also exchange their summaries through the XCD's own L2 (plain 16-byte store, sc1 load: 2 k cycles per
-// exchange against 4.8-7.7 k chip-wide, tools/micro/xcd_handoff_bench.hip) while the row update runs, and a workgroup that
-// sees a better candidate than its own among them does not publish.  The chip-wide winner never sees a better candidate, so
-// it always publishes: a summary that is late, stale or never visible (wrong guess about the placement) only means one more
-// row published, never a missing one.  ~8 rows per pivot instead of 256.
-#define JSLP_PIPE_PRUNE 1
-#endif
-#ifndef JSLP_PIPE_EARLYPOLL
-#define JSLP_PIPE_EARLYPOLL 0  // 1: the first poll of the gather is issued before the bulk update and examined after it
-#endif
+#define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
 
 __device__ __forceinline__ double readlane_f64(double x, int src_lane) {  // src_lane must be wave-uniform
     const long long b = __double_as_longlong(x);
@@ -80,9 +69,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
     const int pub_stride = (int)((const char*)f.rows_pub[1] - (const char*)f.rows_pub[0]);  // (both carved from one arena, [0] first)
     const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + f.G * ld * 8, 0x00020000);
-    const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, 2 * JSLP_G16_REPL * JSLP_F_MAXG * JSLP_G16_STRIDE, 0x00020000);
-    const auto rsrc_g1 = __builtin_amdgcn_make_buffer_rsrc(f.g1, 0, 2 * JSLP_F_MAXG * 16, 0x00020000);  // [2][8 groups][32 members] x 16 bytes
-    const int grp = b & 7, mem = b >> 3;  // my group (the XCD block b is observed to run on) and my place in it
+    const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, 2 * JSLP_F_MAXG * JSLP_G16_STRIDE, 0x00020000);
 #ifdef JSLP_DEBUG_RESIDENT
     u64_t (&rt_acc)[8] = R.rt_acc;
     u64_t& rt_prev = R.rt_prev;
@@ -91,7 +78,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     // the pending pivot (its row update has not reached my registers yet)
     double p[CPT];      // its normalised pivot row, my columns
     unsigned nzm = 0;   // bit j: p[j] is non-zero by the reference's test (simplex.ts:379)
-    int pr_p = 0, pc_p = 0, par_p = 0;
+    int pr_p = 0, pc_p = 0, par_p = 0;  // its row, column and parity
     bool pend = false;
 #pragma unroll
     for (int j = 0; j < CPT; j++) p[j] = 0.0;
@@ -125,38 +112,39 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < ROWS; i++) sm.rhsb[i] = a[i][0];
-        reset_reductions(sm);
+        sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff;
     }
     __syncthreads();
 
     while (R.end_code == 0) {
         const bool has_pc_p = pend && colok && pc_p >= c0 && pc_p < c0 + CPT;
-        // ---- exits that hand the tableau on: bring it up to date first --------------------------------------------------
-        {
-            int leave = 0;
-            if ((R.it1 - it1_start) + (R.it2 - it2_start) >= f.iters_cap) leave = 4;
-            else if (c.check_cycles && !(R.hist_n < JSLP_R_LHIST && R.hist_n < c.hist_cap)) leave = 8;  // history outgrows LDS: the general kernel continues
-            if (leave) { R.end_code = leave; break; }  // (the pending update is applied behind the loop)
-        }
+        // ---- exits that hand the tableau on (the pending update is applied behind the loop) ---------------------------------
+        if ((R.it1 - it1_start) + (R.it2 - it2_start) >= f.iters_cap) { R.end_code = 4; break; }
+        if (c.check_cycles && !(R.hist_n < JSLP_R_LHIST && R.hist_n < c.hist_cap)) { R.end_code = 8; break; }  // history outgrows LDS: the general kernel continues
         const unsigned epoch = R.epoch;
         const int par = epoch & 1;
         const unsigned tag = epoch + 1;
-        const int pc = R.pc;
         if (f.test_abort_epoch >= 0 && (int)epoch == f.test_abort_epoch && b == f.G - 1) {  // tests: a workgroup gives up
             if (tid == 0) AG_STORE(f.abort_flag, 1u);
             R.end_code = 5;
             break;
         }
         RT_MARK(7);
-        // ---- S: ratio test for column pc (simplex.ts:271-296) by the wave that holds the column: the ONE lane that holds it
-        //         evaluates my rows' entries (what the pending pivot makes of them), readlanes hand entry i to lane i, lanes 0..ROWS-1
-        //         classify their row in parallel (one division each), DPP reductions fold the verdicts -- no LDS round trip, no
-        //         workgroup barrier inside -----------------------------------------------------------------------------------------
+        // ---- G: price the cost row -> entering column (simplex.ts:118-219; three LDS-atomic rounds) -------------------------------
+        double k0 = 0.0;  // reduced cost of the entering column
+        int pc;
+        {
+            int neg_unused = 0;
+            pc = price_row_lds<CPT, false>(r0, c0, pb, c, sm, &k0, 0u, &neg_unused);
+        }
+        if (pc == 0) { R.end_code = 1; break; }  // uniform: optimal (simplex.ts:265-269)
+        RT_MARK(6);
+        // ---- S: ratio test for column pc (simplex.ts:271-296) by the wave that holds the column: the ONE lane that holds it hands
+        //      entry i to lane i (readlanes), lanes 0..ROWS-1 apply the pending pivot to their entry and classify their row in
+        //      parallel (one division each), DPP reductions fold the verdicts -- no LDS round trip, no workgroup barrier inside ------
         if (wv == ((pc / CPT) >> 6)) {
             const int ol = __builtin_amdgcn_readfirstlane((pc / CPT) & 63);  // the lane that holds column pc
             const int jsel = __builtin_amdgcn_readfirstlane(pc % CPT);        // ... as its column jsel
-            // lane i < ROWS receives row i's current entry, the pending pivot's row entry of that column and its non-zero flag,
-            // and applies the pending pivot to it (what the bulk update will compute for that cell)
             double x = 0.0, pj = 0.0;
             unsigned nzj = 0;
 #pragma unroll
@@ -172,19 +160,17 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 }
             const int r = r_begin + lane;
             double colv = 0.0;
+            int kind = 0;  // 0 skip, 1 degenerate winner, 2 quotient candidate
+            double quo = 0.0;
             if (lane < ROWS) {
                 colv = x;
-                if (pend) {
+                if (pend) {  // what the pending pivot makes of this cell (the update pass will compute the same)
                     const double ki = sm.colb[par_p][lane];
                     const double nvv = sm.nv[lane];
                     if (r == pr_p) colv = pj;
                     else if (r != 0 && r < r_end && nonzero16(ki)) colv = pc_p == pc ? nvv : (nzj ? eliminate(x, ki, pj) : x);
                 }
-                sm.colb[par][lane] = colv;  // every thread's bulk update of THIS pivot reads it (after the barrier below)
-            }
-            int kind = 0;  // 0 skip, 1 degenerate winner, 2 quotient candidate
-            double quo = 0.0;
-            if (lane < ROWS) {
+                sm.colb[par][lane] = colv;  // every thread's update pass of THIS pivot reads it (after the barrier below)
                 const double rhs = sm.rhsb[lane];
                 if (r >= 1 && r < r_end && !(-precision < colv && colv < precision)) {
                     if (colv > 0 && precision > rhs && rhs > -precision) kind = 1;
@@ -206,7 +192,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             bk = ki_min(bk, ki_dpp<0x141>(bk));
             bk = ki_min(bk, ki_dpp<0x140>(bk));
             bk = ki_readlane(bk, 0);
-            if (lane < JSLP_G16_REPL) {
+            if (lane == 0) {
                 const bool deg = brdeg != 0x7fffffff;
                 const bool have = bk.k != KI_NONE_KEY;
                 const int row = deg ? brdeg : (have ? bk.i : 0);  // the only row of mine that can win (0: none)
@@ -216,92 +202,39 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 g.y = tag;
                 g.z = (unsigned)(qb >> 32);
                 g.w = ((tag & 0xffffu) << 16) | (deg ? 0x8000u : 0u) | (unsigned)row;
-                __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_g16, ((par * JSLP_G16_REPL + lane) * JSLP_F_MAXG + b) * JSLP_G16_STRIDE, 0, 16);  // aux 16 = sc1
-                if (lane == 0) {
-                    sm.pubrow = row;
-                    if (JSLP_PIPE_PRUNE) {  // the XCD-local copy: a PLAIN store (stays in this XCD's L2), and my own summary for the pruning wave
-                        __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_g1, ((par * 8 + grp) * 32 + mem) * 16, 0, 0);
-                        sm.myg[0] = g.x; sm.myg[1] = g.y; sm.myg[2] = g.z; sm.myg[3] = g.w;
-                    }
-                }
+                __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_g16, (par * JSLP_F_MAXG + b) * JSLP_G16_STRIDE, 0, 16);  // aux 16 = sc1
+                sm.pubrow = row;
             }
         }
         __syncthreads();
+        const int pubrow = sm.pubrow;
         RT_MARK(0);
-        // ---- P + U: the pending pivot's row update (simplex.ts:367-391), ONE pass over my rows; the row that can win is
+        // ---- U + P: the pending pivot's row update (simplex.ts:367-391), ONE pass over my rows; the row that can win is
         //         published (16-byte write-through stores) as soon as it is up to date.  The summaries are crossing the fabric
         //         meanwhile ----------------------------------------------------------------------------------------------------------
-        const int pubrow = sm.pubrow;
         bool swept = true;
         const bool poller = tid < JSLP_F_MAXG;
         const bool used = tid < f.G;
         v4u_t g;
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;  // lanes beyond the grid: "no candidate"
-        const int goff = ((par * JSLP_G16_REPL + (b % JSLP_G16_REPL)) * JSLP_F_MAXG + tid) * JSLP_G16_STRIDE;
-        if (JSLP_PIPE_EARLYPOLL && poller && used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
-        if (JSLP_PIPE_PRUNE && wv == THREADS / 64 - 1) {
-            // the last wave: is my candidate the best one among the workgroups of my XCD?  Lane l looks at member l of my group
-            // (a few bounded polls of the XCD-local copies; what is not visible by then counts as "no candidate")
-            int pubme = 0;
-            if (pubrow != 0) {
-                const int w = grp + 8 * lane;
-                const bool other = lane < 32 && w < f.G && lane != mem;
-                v4u_t h;
-                h.x = sm.myg[0]; h.y = sm.myg[1]; h.z = sm.myg[2]; h.w = sm.myg[3];  // (my own lane and the unused ones: my summary)
-                const int hoff = ((par * 8 + grp) * 32 + lane) * 16;
-                bool ok = !other;
-#pragma unroll 1
-                for (int spin = 0; spin < 4; spin++) {
-                    if (other && !ok) {
-                        const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g1, hoff, 0, 16);
-                        if (t.y == tag && (t.w >> 16) == (tag & 0xffffu)) { h = t; ok = true; }
+        const int goff = (par * JSLP_F_MAXG + tid) * JSLP_G16_STRIDE;
+        {
+            double kis[ROWS];  // the pending pivot's column entries of my rows: ROWS broadcast reads in flight together, one wait
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) kis[i] = sm.colb[par_p][i];
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) {
+                if (pend) JSLP_PIPE_UPDATE_ROW(i);
+                if (pubrow != 0 && r_begin + i == pubrow && colok) {  // (uniform but for colok)
+                    const int off = par * pub_stride + (b * ld + c0) * 8;
+#pragma unroll
+                    for (int j = 0; j < CPT; j += 2) {
+                        if (c0 + j >= ld) continue;
+                        const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
+                        v4u_t v;
+                        v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, 16);
                     }
-                    if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                const int row = (int)(h.w & 0x7fffu);
-                const bool deg = (h.w & 0x8000u) != 0u;
-                int rdeg = (deg && row != 0) ? row : 0x7fffffff;
-                rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0xB1, 0xf, 0xf, false));
-                rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x4E, 0xf, 0xf, false));
-                rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x141, 0xf, 0xf, false));
-                rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x140, 0xf, 0xf, false));
-                rdeg = min(min(__builtin_amdgcn_readlane(rdeg, 0), __builtin_amdgcn_readlane(rdeg, 16)),
-                           min(__builtin_amdgcn_readlane(rdeg, 32), __builtin_amdgcn_readlane(rdeg, 48)));
-                KI y;
-                const bool cand = !deg && row != 0;
-                y.k = cand ? ((u64_t)h.x | ((u64_t)h.z << 32)) : KI_NONE_KEY;
-                y.i = cand ? row : 0x7fffffff;
-                y.pad = 0;
-                y = ki_wave_min(y);
-                const int best = rdeg != 0x7fffffff ? rdeg : (y.k == KI_NONE_KEY ? 0 : y.i);
-                pubme = best == pubrow ? 1 : 0;
-            }
-            if (lane == 0) sm.pubme = pubme;
-        }
-        double kis[ROWS];  // the pending pivot's column entries of my rows: ROWS broadcast reads in flight together, one wait
-#pragma unroll
-        for (int i = 0; i < ROWS; i++) kis[i] = sm.colb[par_p][i];
-        if (JSLP_PIPE_PRUNE) {
-            if (pend) {
-#pragma unroll
-                for (int i = 0; i < ROWS; i++) JSLP_PIPE_UPDATE_ROW(i);
-            }
-            __syncthreads();  // the pruning wave's verdict (the summaries are still crossing the fabric: this barrier is not on the critical path)
-        }
-        const bool publish = pubrow != 0 && (!JSLP_PIPE_PRUNE || sm.pubme != 0);
-#pragma unroll
-        for (int i = 0; i < ROWS; i++) {
-            if (!JSLP_PIPE_PRUNE && pend) JSLP_PIPE_UPDATE_ROW(i);
-            if (publish && r_begin + i == pubrow && colok) {  // (uniform but for colok)
-                const int off = par * pub_stride + (b * ld + c0) * 8;
-#pragma unroll
-                for (int j = 0; j < CPT; j += 2) {
-                    if (c0 + j >= ld) continue;
-                    const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
-                    v4u_t v;
-                    v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, 16);
                 }
             }
         }
@@ -310,10 +243,8 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         // ---- C: gather: lane w of the first four waves polls workgroup w's granule ------------------------------------------------
         if (poller) {
             unsigned spins = 0;
-            bool first = JSLP_PIPE_EARLYPOLL != 0;
             for (;;) {
-                if (!first && used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
-                first = false;
+                if (used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
                 const bool ok = g.y == tag && (g.w >> 16) == (tag & 0xffffu);
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
@@ -343,7 +274,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my row stores are written through
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
-        if (tid == 0 && publish) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: the row is visible
+        if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: the row is visible
         RT_MARK(3);
         // ---- D: every thread folds the four partial results ------------------------------------------------------------------
         int pr = 0, stop = 0;
@@ -414,7 +345,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                     }
                 }
                 sm.okx[okslot] = ok;
-                sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff;  // pricing's reductions (reset before a barrier)
+                sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff;  // the next pricing's reductions (reset before a barrier)
             }
             __syncthreads();
             const int okv = sm.okx[okslot];
@@ -449,7 +380,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             for (int j = 0; j < CPT; j++) p[j] = 0.0;
         }
         // the pivot column's own new entries (-k / quot, simplex.ts:386) and column 0 of my rows after this pivot (sm.rhsb is
-        // the ratio test's copy of that column: it receives what the bulk update will give a[i][0]): lanes 0..ROWS-1 of wave 0
+        // the ratio test's copy of that column: it receives what the update pass will give a[i][0]): lanes 0..ROWS-1 of wave 0
         if (wv == 0) {
             const double p0 = readlane_f64(p[0], 0);
             const unsigned nz0 = (unsigned)__builtin_amdgcn_readfirstlane((int)nzm) & 1u;
@@ -464,18 +395,15 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             }
         }
         // ---- R0: the cost row (every workgroup its own copy) -----------------------------------------------------------------------
-        {
-            const double k0 = R.k0;
-            if (nonzero16(k0)) {
+        if (nonzero16(k0)) {
+#pragma unroll
+            for (int j = 0; j < CPT; j++)
+                if ((nzm >> j) & 1u) r0[j] = eliminate(r0[j], k0, p[j]);
+            if (has_pc) {
+                const double nv0 = -k0 / quot;
 #pragma unroll
                 for (int j = 0; j < CPT; j++)
-                    if ((nzm >> j) & 1u) r0[j] = eliminate(r0[j], k0, p[j]);
-                if (has_pc) {
-                    const double nv0 = -k0 / quot;
-#pragma unroll
-                    for (int j = 0; j < CPT; j++)
-                        if (pc == c0 + j) r0[j] = nv0;
-                }
+                    if (pc == c0 + j) r0[j] = nv0;
             }
         }
         // ---- commit the basis change (simplex.ts:339-349): every workgroup's LDS maps, workgroup 0 the global ones ---------------------
@@ -498,13 +426,6 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         R.epoch = epoch + 1;
         pend = true; pr_p = pr; pc_p = pc; par_p = par;
         RT_MARK(5);
-        // ---- G: price the new cost row -> entering column of the next pivot ----------------------------------------------------------
-        {
-            int neg_unused = 0;
-            R.pc = price_row_lds<CPT, false>(r0, c0, pb, c, sm, &R.k0, 0u, &neg_unused);
-        }
-        RT_MARK(6);
-        if (R.pc == 0) R.end_code = 1;  // optimal (simplex.ts:265-269)
     }
     if (pend && R.end_code != 5) {  // whoever leaves with a pivot pending (optimal, iteration cap, hand-over) brings the rows up to date
         const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;

@@ -20,7 +20,7 @@ print("pivots", len(t.pivot_trace()))
 d = np.fromfile("gpurun_out/resident_r0.bin", dtype=np.uint64)[12288:]
 names = ["A cands", "B row stores", "C sweep/drain/sync", "D decide/poll", "E0 rowflag", "E row load+norm", "F update", "G price"]
 if os.environ.get("JSLP_RES_LEAN", "1") != "0":  # the lean kernel's pipelined loop (jslp_resident_pipe.hip.h) marks other sections
-    names = ["S summary", "C1 poll+reduce", "U update+publish", "C2 drain+barrier", "D decide + E row fetch", "N/R0/commit", "G price", "loop top"]
+    names = ["S claim + ratio test", "C1 poll+reduce", "U update+publish", "C2 drain+barrier", "D decide + E row fetch", "N/R0/commit", "G pricing round A", "loop top"]
 for label, off in (("wg0", 0), ("wg100", 16), ("wgLast", 32)):
     acc = d[off:off + 8].astype(np.float64); ep = float(d[off + 8])
     print(label, "epochs", ep, " ".join("%s=%.0f" % (nm, a / max(ep, 1)) for nm, a in zip(names, acc)), "total cyc/pivot %.0f" % (acc.sum() / max(ep, 1)))
