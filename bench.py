@@ -72,6 +72,71 @@ def cpu_baseline(n, sample_pivots):
         return {"value": None, "unit": "pivots/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
 
 
+DROPIN_NODE = r"""
+const fs=require('fs'),path=require('path'),zlib=require('zlib');
+const root=process.argv[1], mode=process.argv[2];
+const solver=require(path.join(root,'oracle/_ref/src/solver.js')).default;
+if(mode!=='cpu'){const T=require(path.join(root,'oracle/_ref/src/tableau/tableau.js')).default;
+ const {SlackVariable}=require(path.join(root,'oracle/_ref/src/expressions.js'));
+ const gpu=require(path.join(root,'host/gpu-tableau.js'));gpu.loadEngine({});gpu.install(T,{SlackVariable,solver});}
+const out={};
+for(const name of process.argv.slice(3)){
+ const g=JSON.parse(zlib.gunzipSync(fs.readFileSync(path.join(root,'tests/golden/fixtures',name+'.json.gz'))).toString());
+ const run=()=>{const m=JSON.parse(JSON.stringify(g.model));const t0=process.hrtime.bigint();const r=solver.Solve(m);return [Number(process.hrtime.bigint()-t0)/1e6,r.result];};
+ for(let i=0;i<12;i++)run();const a=[];for(let i=0;i<15;i++)a.push(run()[0]);a.sort((x,y)=>x-y);
+ out[name]={ms:a[7],min_ms:a[0],result:run()[1],want:g.result.result};}
+console.log(JSON.stringify(out));
+"""
+
+
+def dropin_leg(with_cpu):
+    """THE drop-in, end to end: solver.Solve(model) through the reference's own host (oracle/_ref: JSON parsing, presolve, the
+    branch-and-bound tree) + host/gpu-tableau.js + the N-API addon + the HIP engine, default install() options, JIT-warm median
+    of 15 -- next to the unpatched reference on this box's CPU.  Runs in a child process BEFORE this process touches the GPU."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "src", "solver.js")) or not os.path.exists(os.path.join(ROOT, "addon", "jslp_napi.node")):
+        return None
+    names = ["Monster_Problem", "Monster_II"]
+    res = {}
+    for mode in (("gpu", "cpu") if with_cpu else ("gpu",)):
+        try:
+            out = subprocess.run(["node", "-e", DROPIN_NODE, ROOT, mode] + names, capture_output=True, text=True, timeout=600)
+            res[mode] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as e:
+            res[mode] = {"error": repr(e)}
+    leg = {"what": "solver.Solve(model) through the reference host (type-erased TS under node) + host/gpu-tableau.js + N-API addon + HIP engine, "
+                   "default install(Tableau, {solver}) options (size policy, 16-node speculative batches); JIT-warm median of 15 solves, ms",
+           "configs": {}}
+    for n in names:
+        g, c = res.get("gpu", {}).get(n), res.get("cpu", {}).get(n)
+        if g and g.get("result") != g.get("want"):
+            raise WrongAnswer("drop-in Solve(%s): %r, the reference: %r" % (n, g.get("result"), g.get("want")))
+        leg["configs"][n] = {"dropin_ms": g and g["ms"], "dropin_min_ms": g and g["min_ms"], "reference_cpu_ms": c and c["ms"],
+                             "speedup": (c["ms"] / g["ms"]) if (g and c and g.get("ms") and c.get("ms")) else None, "result": g and g["result"]}
+    return leg
+
+
+# MI355X constants of the latency floor below (MI355X_MICROARCH.md: chip table, "Persistent kernels: price list")
+SHADER_CLOCK_HZ = 2.4e9
+FP64_FLOP_PER_CLK_PER_CU = 128.0   # 78.6 TFLOP/s fp64 vector / 256 CUs / 2.4 GHz
+HANDOFF_US = 0.8                   # row handoff-1to1, idle, 8-byte granule: one producer -> one consumer through the fabric
+ROW_FETCH_US = 1.0                 # row handoff-payload: a freshly published 16 KB tile is read at 12-20 GB/s (latency-bound)
+
+
+def resident_latency_floor(H, W, n_cus=256):
+    """What bounds a register-resident pivot.  No tableau byte has to cross HBM (the tableau lives in the chip's registers), so
+    the HBM roofline does not apply; per pivot there remains a dependency chain no scheduling can shorten:
+      ratio test = a min over ALL rows, which live in 256 CUs    -> one fabric hand-off of the summaries (>= handoff-1to1)
+      the winner's row must reach every CU                        -> a 16 KB read of freshly published data (handoff-payload)
+      every CU eliminates its rows                                 -> (cells per CU) x (mul + add) fp64 on its four SIMDs
+    Pricing and the per-workgroup reductions are priced at zero (they are what the kernel can still shave)."""
+    rows_per_wg = -(-H // n_cus)
+    ld = -(-W // 16) * 16
+    valu_us = rows_per_wg * ld * 2.0 / FP64_FLOP_PER_CLK_PER_CU / SHADER_CLOCK_HZ * 1e6
+    return {"summary_handoff_us": HANDOFF_US, "row_fetch_us": ROW_FETCH_US, "valu_us": valu_us, "floor_us": HANDOFF_US + ROW_FETCH_US + valu_us,
+            "source": "MI355X_MICROARCH.md price list: handoff-1to1 (idle, 8 B) 0.8 us; handoff-payload 16 KB at 12-20 GB/s ~ 1.0 us; "
+                      "fp64 vector 78.6 TFLOP/s = 128 flop/clk/CU at 2.4 GHz"}
+
+
 def pmc_traffic(key, kernel, alg_bytes):
     """HBM bytes per unit of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
     runs, gfx950 FETCH_SIZE x2 correction): counters cannot be read from inside this process, so the committed summary of
@@ -98,6 +163,8 @@ def main():
     ap.add_argument("--no-relaxations", action="store_true")
     ap.add_argument("--only-relaxations", action="store_true", help="profiling runs: skip the dense-LP legs")
     ap.add_argument("--no-extras", action="store_true", help="profiling runs: only the timed headline steps")
+    ap.add_argument("--sustain-s", type=float, default=6.0, help="seconds of back-to-back headline solves after the timed steps (0 = off)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the end-to-end Solve() leg through the reference host (node)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -122,9 +189,17 @@ def main():
     red_device = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         if backend == "nccl":
+            if torch.cuda.device_count() < world:
+                raise SystemExit("bench.py: --gpus %d over RCCL needs %d visible GPUs, found %d" % (world, world, torch.cuda.device_count()))
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus or dist.get_backend() != backend:
+            raise SystemExit("bench.py: process group is %s x %d, wanted %s x %d" % (dist.get_backend(), dist.get_world_size(), backend, args.gpus))
+
+    dropin = None
+    if rank == 0 and world == 1 and not args.no_dropin and not args.only_relaxations:
+        dropin = dropin_leg(with_cpu=not args.no_cpu_baseline)  # (a child process, before this one creates its HIP context)
 
     from jslpsolver_amd import _capi, generators
     from jslpsolver_amd.engine import Tableau, pivot_digest
@@ -144,10 +219,19 @@ def main():
         dist.all_reduce(t, op=op)
         return float(t.item())
 
+    def gather_ranks(x):
+        """every rank's value, in rank order (a one-hot all-reduce: works on both backends)"""
+        if world == 1:
+            return [float(x)]
+        t = torch.zeros(world, dtype=torch.float64, device=red_device)
+        t[rank] = float(x)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
     max_over_ranks = lambda x: reduce_ranks(x, dist.ReduceOp.MAX)
     sum_over_ranks = lambda x: reduce_ranks(x, dist.ReduceOp.SUM)
     ctx = {"lib": lib, "device": device_index, "rank": rank, "world": world, "barrier": barrier, "max": max_over_ranks,
-           "sum": sum_over_ranks, "group": dist.group.WORLD if world > 1 else None}
+           "sum": sum_over_ranks, "gather": gather_ranks, "group": dist.group.WORLD if world > 1 else None}
 
     line = None
     n = args.n
@@ -215,18 +299,43 @@ def main():
             avg_s = (kern_ms / 1e3) / max(launches, 1)
             achieved = bytes_per_unit / avg_s if launches else 0.0
             traffic, traffic_note = pmc_traffic("pivots", kernel_name, bytes_per_unit)
-            roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_note,
-                        "bytes_per_unit": bytes_per_unit, "unit_of_work": "one pivot (16*H*W algorithmic bytes)",
-                        "avg_unit_us": avg_s * 1e6, "units": launches, "timed_in": "the %d timed steps (HIP events on the engine's stream)" % args.steps,
-                        "whole_step_frac": (bytes_per_unit * value / max(world, 1)) / HBM_PEAK,
-                        "rocprof_hbm_gb_s": (traffic / avg_s / 1e9) if traffic else None,
-                        "note": "achieved = ALGORITHMIC bytes (16*H*W per pivot, SURVEY.md 8d) / measured kernel time per pivot.  The tableau "
-                                "stays in the chip's vector registers for the whole solve (k_simplex_resident), so this fraction is a figure of "
-                                "merit against a streaming implementation, not a bound (it may pass 1.0); what really crosses HBM is `traffic` "
-                                "(PMC) = candidate-row publication, and the kernel is bound by two fabric hand-offs + ~10 workgroup barriers per pivot"}
+            rate = 1.0 / avg_s if launches else 0.0
+            if path_used == "resident":
+                # register-resident: the HBM roofline is not the bound (see resident_latency_floor); the fraction on algorithmic
+                # bytes stays as a figure of merit against a streaming implementation, the real HBM use comes from the PMC passes
+                fl = resident_latency_floor(H, W)
+                roofline = {"bound": "on-chip sync latency", "kernel": kernel_name, "achieved": rate, "peak": 1e6 / fl["floor_us"],
+                            "unit": "pivots/s (one kernel, one tableau)", "frac": fl["floor_us"] / (avg_s * 1e6) if launches else None,
+                            "floor_model": fl, "avg_unit_us": avg_s * 1e6}
+            else:
+                roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK, "avg_unit_us": avg_s * 1e6}
+            roofline.update({
+                "traffic": traffic, "traffic_source": traffic_note, "units": launches,
+                "unit_of_work": "one pivot", "timed_in": "the %d timed steps (HIP events on the engine's stream)" % args.steps,
+                "algorithmic": {"bytes_per_unit": bytes_per_unit, "gb_s": achieved / 1e9, "frac_of_hbm_peak": achieved / HBM_PEAK,
+                                "whole_step_frac": (bytes_per_unit * value / max(world, 1)) / HBM_PEAK,
+                                "note": "16*H*W bytes per pivot (SURVEY.md 8d) / measured kernel time per pivot: what a streaming implementation would "
+                                        "have to sustain to match; may exceed 1.0 for the register-resident kernel, which does not stream"},
+                "hbm": {"bytes_per_unit": traffic, "gb_s": (traffic / avg_s / 1e9) if traffic else None,
+                        "frac_of_hbm_peak": (traffic / avg_s / HBM_PEAK) if traffic else None,
+                        "note": "PMC FETCH_SIZE + WRITE_SIZE of the same kernel on the same workload (separate rocprofv3 passes, committed summary)"}})
 
         extras = {}
+        if not args.no_extras and rank == 0 and args.sustain_s > 0:
+            # the timed region above is ~1 s: a few more seconds of the same solves back to back (also what a 5 s sampler of GPU
+            # activity gets to see); same answer checked by the digest above
+            t.restore(); t.simplex(check_cycles=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); n_s = 0; piv_s = 0
+            while time.perf_counter() - t0 < args.sustain_s:
+                t.restore()
+                r_s = t.simplex(check_cycles=False)
+                piv_s += r_s.pivots_phase1 + max(r_s.pivots_phase2, 0)
+                n_s += 1
+            el_s = time.perf_counter() - t0
+            extras["sustained"] = {"solves": n_s, "seconds": el_s, "value": piv_s / el_s, "unit": "pivots/s",
+                                   "note": "the headline workload repeated for ~%.0f s on rank 0, restore + simplex per solve, wall clock" % args.sustain_s}
         if not args.no_extras:
             # ---- the reference's DEFAULT: checkForCycles on (model.ts:73; simplex.ts:415-440 after every selection) ----------
             # (every rank runs it: the timed region is bracketed by the same barriers; rank 0 reports its own replica)
@@ -274,6 +383,8 @@ def main():
                 "roofline": roofline,
             }
             line.update(extras)
+            if dropin is not None:
+                line["dropin_js"] = dropin
 
     # ---- LP relaxations/sec: Monster_II (config 4) ----------------------------------------------------------------------
     relax = None
@@ -379,6 +490,7 @@ def relaxation_legs(ctx, args, reps=16):
     if rank == 0:
         check_outcomes(results, rhs, rows, list(range(rank, len(nodes), world)), "relaxation batch")
     total = sum_over_ranks(float(len(mine)))
+    per_rank_rate = ctx["gather"](len(mine) / (sum(per_call) / len(per_call)))  # every rank's own clock, before the max over ranks
     piv = sum_over_ranks(float(sum(results[i].pivots_phase1 + max(results[i].pivots_phase2, 0) for i in range(len(mine)))))
     # the same batch with the compact read-back (jslp_engine_relax_batch_watched_pinned): per node only rowByVarIndex / the RHS
     # cell of the integer variables, which is what a host walking the tree reads between relaxations (mip-utils.ts:43-61, 100-126)
@@ -407,6 +519,7 @@ def relaxation_legs(ctx, args, reps=16):
                                  "note": "jslp_engine_relax_batch_watched_pinned: rowByVarIndex + RHS cell of the %d integer variables per node; "
                                          "checked node by node against the full read-back" % len(ints)},
            "calls_averaged": 10, "per_call_us": [round(1e6 * x) for x in per_call], "scaling": "weak",
+           "per_rank_relaxations_per_s": per_rank_rate,
            "outcomes_checked": "sha256(RHS column + row map) of every node of the last call == the reference's (rank 0's share)",
            "workload": "config 4: Monster_II (935x925 root, 112 ints), the reference's 151 visited cut lists x%d as one batch of "
                        "independent nodes per rank, sharded round-robin over %d rank(s)" % (reps, world)}
@@ -456,7 +569,16 @@ def relaxation_legs(ctx, args, reps=16):
     def solve_tree():
         return Solve(g["model"], full=True, lib=lib, device=device, speculate=spec, group=group)
 
-    sol, el_tree, per_tree = timed_calls(solve_tree, 3, 5)
+    from jslpsolver_amd.branch_and_cut import EVAL_STATS
+    from jslpsolver_amd.sharding import EXCHANGE_STATS
+    for _ in range(3):
+        solve_tree()
+    for st in (EVAL_STATS, EXCHANGE_STATS):
+        for k in st:
+            st[k] = 0 * st[k]
+    sol, el_tree, per_tree = timed_calls(solve_tree, 0, 5)
+    eval_ms = 1e3 * EVAL_STATS["seconds"] / 5
+    exch_ms = 1e3 * EXCHANGE_STATS["seconds"] / 5
     if sol["iter"] != g["final"]["branchAndCutIterations"] or sol["result"].get("result") != want.get("result"):
         raise WrongAnswer("Monster_II tree: result %r after %d relaxations, the reference: %r after %d"
                           % (sol["result"].get("result"), sol["iter"], want.get("result"), g["final"]["branchAndCutIterations"]))
@@ -464,7 +586,12 @@ def relaxation_legs(ctx, args, reps=16):
                                "outcomes all-gathered (%s)" % (sol["iter"], spec, world, "RCCL" if (world > 1 and os.environ.get("JSLP_BENCH_BACKEND", "nccl") == "nccl") else ("gloo" if world > 1 else "no exchange at N = 1")),
                    "scaling": "strong", "ms_per_solve": 1e3 * el_tree, "solves_per_s": 1.0 / el_tree, "committed_relaxations_per_s": sol["iter"] / el_tree,
                    "result": sol["result"].get("result"), "result_checked": "result and relaxation count == the reference's (%s, %d)" % (want.get("result"), g["final"]["branchAndCutIterations"]),
-                   "per_solve_ms": [round(1e3 * x, 2) for x in per_tree], "includes": "model parsing, upload, root LP, the whole tree and the read-back (host logic in Python)"}
+                   "per_solve_ms": [round(1e3 * x, 2) for x in per_tree],
+                   # what shards and what does not (rank 0's clock): the evaluation share = the speculative batches (engine calls +
+                   # exchange step); the rest = model parsing, upload, root LP, tree bookkeeping on one host thread
+                   "eval_ms": eval_ms, "exchange_ms": exch_ms, "host_ms": 1e3 * el_tree - eval_ms,
+                   "eval_batches_per_solve": EVAL_STATS["batches"] / 5, "eval_nodes_per_solve": EVAL_STATS["nodes"] / 5, "includes": "model parsing, upload, root LP, the whole tree and the read-back (host logic in Python)",
+                   "host": "python mirror of the reference host, no presolve (the drop-in is `dropin_js`: the reference's own host under node)"}
     return out if rank == 0 else None
 
 

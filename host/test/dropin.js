@@ -241,6 +241,27 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
         }
     }
 }
+// DETECTED cycles (tests/golden/cycles: reference runs that end in "Cycle in phase N"): same result object and the same three
+// model.messages ("Cycle in phase N", "Start :s", "Length :l" -- simplex.ts:86-88 / 313-315) through the binding
+let cycleOk = 0;
+if (!filter && dir.indexOf("fixtures") >= 0) {
+    const cdir = path.join(root, "tests", "golden", "cycles");
+    for (const f of (fs.existsSync(cdir) ? fs.readdirSync(cdir) : []).filter((x) => x.endsWith(".json.gz") && !x.startsWith("embedded")).sort()) {
+        const g = loadGolden(cdir, f);
+        const solution = solver.Solve(JSON.parse(JSON.stringify(g.model)), undefined, true);
+        const res = solver.buildSimplifiedResult(solution);
+        const got = {};
+        for (const k of Object.keys(res)) got[k] = num(res[k]);
+        const msgs = solver.lastSolvedModel.messages;
+        const trace = gpu.pivotTrace(solution._tableau);
+        const bad = [];
+        if (JSON.stringify(got) !== JSON.stringify(g.result)) bad.push("result");
+        if (JSON.stringify(msgs) !== JSON.stringify(g.messages)) bad.push("messages " + JSON.stringify(msgs) + " != " + JSON.stringify(g.messages));
+        if (!trace || digest(trace) !== g.pivotDigest) bad.push("pivot digest");
+        gpu.release(solution._tableau);
+        if (bad.length) { fail += 1; console.log("FAIL cycle", f, bad.join("; ")); } else cycleOk += 1;
+    }
+}
 // the editing API under the binding (see editScript above)
 let editOk = 0;
 for (const f of Object.keys(editBase)) {
@@ -347,5 +368,5 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
 }
 console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk,
     incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk,
-    size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, instance_ok: instanceOk, pool_ok: poolOk, watched_ok: watchedOk }));
+    size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, instance_ok: instanceOk, cycle_ok: cycleOk, pool_ok: poolOk, watched_ok: watchedOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);

@@ -168,6 +168,9 @@ class _NodeEval:
         self.res, self.rhs, self.vibr = res, rhs, vibr
 
 
+EVAL_STATS = {"seconds": 0.0, "batches": 0, "nodes": 0}  # speculative batches since the caller last zeroed it (bench.py)
+
+
 def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
     """branch-and-cut.ts:54-199.  Leaves `tableau` holding the incumbent; returns the iteration count and
     whether an integral node was accepted (tableau.__isIntegral).
@@ -203,11 +206,19 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
     speculated = 0
 
     def run_batch(cut_lists):
-        if evaluate_batch is not None:
-            return evaluate_batch(cut_lists)
-        results, rhs, vibr = tableau.applyCutsBatch(cut_lists, check_cycles=check)
-        return [_NodeEval(results[i], rhs[i, :results[i].height].copy(), vibr[i, :results[i].height].copy())
-                for i in range(len(cut_lists))]
+        # (wall time of the evaluation share of the tree -- the engine calls, and for a sharded tree the exchange step --, so that
+        #  a strong-scaling run can be read: bench.py's `tree.eval_ms` / `tree.host_ms`)
+        t0 = time.perf_counter()
+        try:
+            if evaluate_batch is not None:
+                return evaluate_batch(cut_lists)
+            results, rhs, vibr = tableau.applyCutsBatch(cut_lists, check_cycles=check)
+            return [_NodeEval(results[i], rhs[i, :results[i].height].copy(), vibr[i, :results[i].height].copy())
+                    for i in range(len(cut_lists))]
+        finally:
+            EVAL_STATS["seconds"] += time.perf_counter() - t0
+            EVAL_STATS["batches"] += 1
+            EVAL_STATS["nodes"] += len(cut_lists)
 
     branches.push(-math.inf, [])
     while len(branches) > 0 and tolerance_flag and time.time() * 1000.0 < terminal_time:

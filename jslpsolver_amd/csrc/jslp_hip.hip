@@ -748,8 +748,15 @@ static int resident_geometry(const jslp_engine* e, int H) {
     // 4001 x 2001: 22.3 k pivots/s against 36.4 k through k_pivot_fused; 2501 x 2001: 26.6 k against 48.8 k; 3001 x 3001: 21.5 k
     // against 23.7 k through k_select + k_update; 2001 x 4001: 20.1 k against 26.1 k (tools/tall_one.py, r02_z).  They stay
     // built and tested (JSLP_FORCE_PATH=resident, JSLP_RES_WIDE_TALL=1) but the default policy no longer picks them.
-    static const bool wide_tall = getenv("JSLP_RES_WIDE_TALL") && atoi(getenv("JSLP_RES_WIDE_TALL")) != 0;
-    if (!e->force_resident && !wide_tall) return 0;
+    // Round 3: the LEAN build's pipelined phase 2 does fit (jslp_resident_pipe.hip.h; 4 scratch loads per pivot) and beats the
+    // streaming kernels 2-3x on these shapes (r03_j), so tableaus it can take -- no unrestricted variables -- get these geometries
+    // by default for their phase 2 (phase 1 through the fused pipeline: run_simplex).  JSLP_RES_WIDE_TALL=0 switches that off, =1
+    // also sends the general build's (unrestricted variables) there.
+    const char* wt_env = getenv("JSLP_RES_WIDE_TALL");  // (read per call: tests switch it inside one process)
+    const int wide_tall = wt_env ? atoi(wt_env) : -1;
+    const bool lean_env = !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
+    const bool lean = lean_env && e->n_unr == 0;
+    if (!e->force_resident && wide_tall != 1 && !(lean && wide_tall != 0)) return 0;
     if (e->ld <= 2048 && rpb <= 16) return 3;
     if (e->ld <= 3072 && rpb <= 12) return 4;
     if (e->ld <= 4096 && rpb <= 8) return 5;
@@ -949,9 +956,11 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
         const int H = e->h_state->H;
         const dim3 grid = update_grid(e, H);
         hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, e->s, 0, cap);
-        bool resident_done = false;
         // ---- register-resident path: the WHOLE simplex (phase 1 and phase 2) in one cooperative launch -------------
-        if (resident_eligible(e, H)) {
+        bool resident_done = false;
+        const int geometry = resident_geometry(e, H);
+        // `it_before`: pivots the solve had done when the kernel is launched (0, or a phase 1 done by the fused pipeline)
+        auto run_resident = [&](long long it_before) -> int {
             int r = ensure_resident(e);
             if (r) return r;
             ResCtx rc;
@@ -1001,9 +1010,8 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             // The LEAN build (all-gather protocol only, software-pipelined phase 2: jslp_resident_pipe.hip.h) takes every solve
             // without unrestricted variables; should its cycle-check history outgrow LDS it hands the solve over (status
             // ST_RUNNING / ST_PHASE1_DONE instead of ST_DONE) and the general build continues it in a second launch.
-            static const bool lean_on = !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
+            const bool lean_on = !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
             bool lean = lean_on && !unr;
-            const int geometry = resident_geometry(e, H);
 #define JSLP_RES_LAUNCH(T, C, R)                                                                                                    \
     le = lean ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false, true>, dim3(rc.G), dim3(T), args, 0, s) \
        : unr  ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, true>, dim3(rc.G), dim3(T), args, 0, s)        \
@@ -1029,7 +1037,6 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             }
             if (le == hipSuccess) {
                 if (e->timing) HIPC(hipEventRecord(k1, s));
-                const int it_before = 0;  // k_begin zeroed the pivot counters
                 HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
                 HIPC(hipStreamSynchronize(s));
                 if (e->timing) {
@@ -1062,6 +1069,18 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             } else {
                 (void)hipGetLastError();  // not co-resident on this device: use one launch per pivot instead
             }
+            return JSLP_OK;
+        };
+        // The headline geometries run the WHOLE solve register-resident (phase 1 included).  The tall / wide ones (H > 2048 or more
+        // than 2048 columns) take only phase 2 there -- their phase-1 loop does not fit the 256 registers a lane has next to 64-72 MB
+        // of tableau (it spills: 22 k pivots/s against 33.7 k through k_fused_p1 on 4001 x 2001) while the lean kernel's pipelined
+        // phase 2 does (4 scratch loads per pivot): phase 1 goes through the fused pipeline first, which hands over with
+        // ST_PHASE1_DONE.  r03_j: 4001 x 2001 113.4 k pivots/s against 35.7 k fused, 2501 x 2001 128.6 k against 48.5 k,
+        // 2001 x 4001 75.5 k against 34.8 k.
+        const bool resident_phase2_only = geometry >= 3;
+        if (geometry != 0 && !resident_phase2_only) {
+            int r = run_resident(0);
+            if (r) return r;
         }
         if (!resident_done) {
         // ---- phase 1 through the fused pipeline (one launch per pivot; k_fused_p1), when the fused pipeline applies -----------
@@ -1132,8 +1151,13 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             if (st.status != ST_RUNNING) break;
             chunk = std::min(chunk * 2, 256);
         }
+        // ---- phase 2 of the tall / wide geometries: register-resident (see above) ------------------------------
+        if (resident_phase2_only && e->h_state->status == ST_PHASE1_DONE && e->h_state->err == ERR_NONE) {
+            int r = run_resident((long long)e->h_state->it1 + e->h_state->it2);
+            if (r) return r;
+        }
         // ---- phase 2: one fused launch per pivot ----------------------------------------------------------
-        while (e->h_state->status == ST_PHASE1_DONE) {
+        while (!resident_done && e->h_state->status == ST_PHASE1_DONE) {
             int r = ensure_fused(e);
             if (r) return r;
             r = ensure_fused_oo(e);
@@ -2124,13 +2148,29 @@ extern "C" int jslp_pool_create(jslp_pool** out, jslp_engine* primary, const int
         int rc = jslp_engine_create(&m, devices[i], primary->H0, primary->W, primary->cap_rows, primary->precision);
         if (rc) { jslp_pool_destroy(p); return rc; }
         p->members.push_back(m);
-        if (devices[i] != primary->device) {  // direct xGMI copies where the platform allows them (else staged by the runtime)
+        // The root fan-out (pool_adopt_root) is a set of peer copies primary -> member: direct xGMI transfers need peer access.
+        // A platform that refuses it would still run -- the runtime stages peer copies through host memory -- at a fraction of
+        // the bandwidth and silently: the pool fails LOUDLY instead (JSLP_POOL_ALLOW_STAGED=1 accepts the staged copies).
+        // JSLP_TEST_PEER_REFUSED=1 (tests) makes every member look refused, virtual devices included.
+        static const bool test_refused = getenv("JSLP_TEST_PEER_REFUSED") && atoi(getenv("JSLP_TEST_PEER_REFUSED")) != 0;
+        static const bool allow_staged = getenv("JSLP_POOL_ALLOW_STAGED") && atoi(getenv("JSLP_POOL_ALLOW_STAGED")) != 0;
+        if (devices[i] != primary->device || test_refused) {
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devices[i], primary->device) == hipSuccess && can) {
+            bool ok = !test_refused && hipDeviceCanAccessPeer(&can, devices[i], primary->device) == hipSuccess && can;
+            if (ok) {
                 hipSetDevice(devices[i]);
-                if (hipDeviceEnablePeerAccess(primary->device, 0) != hipSuccess) (void)hipGetLastError();
+                const hipError_t pe = hipDeviceEnablePeerAccess(primary->device, 0);
+                ok = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
             }
             (void)hipGetLastError();
+            if (!ok && !allow_staged) {
+                hipSetDevice(primary->device);
+                jslp_pool_destroy(p);  // members created so far, their worker threads; never the primary
+                char msg[160];
+                snprintf(msg, sizeof msg, "pool_create: device %d cannot access device %d's memory (peer access refused); "
+                         "JSLP_POOL_ALLOW_STAGED=1 accepts host-staged copies", (int)devices[i], (int)primary->device);
+                return fail(JSLP_ERR_DEVICE, msg);
+            }
         }
         PoolWorker* w = new PoolWorker();
         w->th = std::thread([w] { w->loop(); });

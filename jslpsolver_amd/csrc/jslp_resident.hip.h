@@ -966,9 +966,17 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     R.end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted hand-off, 6 history full, 7 infeasible
     R.unbounded_col = 0;
     R.epoch = 0;
+    // The lean build of the tall / wide geometries is a phase-2 kernel: the host runs their phase 1 through the fused pipeline
+    // (run_simplex), the phase-1 loop is not even compiled for them (next to 64-72 MB of tableau it does not fit the registers: it
+    // spilled ~0.5 KB per lane, and r03_j saw a 3001 x 3001 solve go wrong after ONE pass through that spilling code).
+    constexpr bool P2ONLY = LEAN && (ROWS > JSLP_R_ROWS || CPT > 4);
     if (phase == 1) {
-        resident_phase<1, THREADS, CPT, ROWS, UNR, LEAN>(f, sm, R, it1_start, it2_start, pb);
-        if (R.end_code == 0) phase = 2;
+        if (P2ONLY) {
+            R.end_code = 5;  // never launched like this; if it were, the host rolls back and streams (like an aborted hand-off)
+        } else {
+            resident_phase<1, THREADS, CPT, ROWS, UNR, LEAN>(f, sm, R, it1_start, it2_start, pb);
+            if (R.end_code == 0) phase = 2;
+        }
     }
     if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
         if (LEAN) {

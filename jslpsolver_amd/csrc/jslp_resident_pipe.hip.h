@@ -46,6 +46,7 @@
 // maximum in all 16 waves costs more than the two LDS-atomic rounds it replaces.
 // ===================================================================================================================
 #define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
+#define JSLP_PIPE_KCHUNK 8    // pivot-column entries the update pass keeps in flight (registers: the tall / wide geometries have few to spare)
 
 __device__ __forceinline__ double readlane_f64(double x, int src_lane) {  // src_lane must be wave-uniform
     const long long b = __double_as_longlong(x);
@@ -218,12 +219,14 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         v4u_t g;
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;  // lanes beyond the grid: "no candidate"
         const int goff = (par * JSLP_F_MAXG + tid) * JSLP_G16_STRIDE;
-        {
-            double kis[ROWS];  // the pending pivot's column entries of my rows: ROWS broadcast reads in flight together, one wait
+        // (the pending pivot's column entries of my rows: broadcast LDS reads, JSLP_PIPE_KCHUNK of them in flight together)
 #pragma unroll
-            for (int i = 0; i < ROWS; i++) kis[i] = sm.colb[par_p][i];
+        for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
+            double kis[ROWS];
 #pragma unroll
-            for (int i = 0; i < ROWS; i++) {
+            for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) kis[i] = sm.colb[par_p][i];
+#pragma unroll
+            for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) {
                 if (pend) JSLP_PIPE_UPDATE_ROW(i);
                 if (pubrow != 0 && r_begin + i == pubrow && colok) {  // (uniform but for colok)
                     const int off = par * pub_stride + (b * ld + c0) * 8;
@@ -429,11 +432,14 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     }
     if (pend && R.end_code != 5) {  // whoever leaves with a pivot pending (optimal, iteration cap, hand-over) brings the rows up to date
         const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;
-        double kis[ROWS];
 #pragma unroll
-        for (int i = 0; i < ROWS; i++) kis[i] = sm.colb[par_p][i];
+        for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
+            double kis[ROWS];
 #pragma unroll
-        for (int i = 0; i < ROWS; i++) JSLP_PIPE_UPDATE_ROW(i);
+            for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) kis[i] = sm.colb[par_p][i];
+#pragma unroll
+            for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) JSLP_PIPE_UPDATE_ROW(i);
+        }
     }
 #undef JSLP_PIPE_UPDATE_ROW
 }

@@ -69,8 +69,22 @@ class ShardedOutcomes:
         return h[idx % self.world, idx // self.world]
 
 
+EXCHANGE_STATS = {"seconds": 0.0, "calls": 0, "bytes": 0}  # the exchange step since the caller last zeroed it (bench.py)
+
+
 def exchange_outcomes(local, n, group):
     """all-gather of the per-rank payloads ([per, node_bytes] uint8, padded to equal size) -> ShardedOutcomes"""
+    import time
+    t0 = time.perf_counter()
+    try:
+        return _exchange_outcomes(local, n, group)
+    finally:
+        EXCHANGE_STATS["seconds"] += time.perf_counter() - t0
+        EXCHANGE_STATS["calls"] += 1
+        EXCHANGE_STATS["bytes"] += int(local.size)
+
+
+def _exchange_outcomes(local, n, group):
     import torch
     import torch.distributed as dist
 

@@ -54,6 +54,31 @@ def main():
         ok = ok and bool(ev.res.feasible) == call["feasible"] and ev.res.height == call["height"]
         ok = ok and G.sha_rhs(ev.rhs, ev.vibr) == call["rhsSha"]
     report["cases"].append({"name": "Monster_II node batch", "ok": bool(ok)})
+    # 3. ragged batches: fewer nodes than ranks, a batch that does not divide by the world size, an empty batch (ranks without a
+    #    node still take part in the exchange step with a padded, empty contribution)
+    for n_take in (0, 1, max(world - 1, 1), world + 1):
+        sub = nodes[:n_take]
+        out = evaluate_nodes_sharded(t, sub, True, dist.group.WORLD)
+        ok = len(out) == len(sub)
+        for i, call in enumerate(calls[1:1 + n_take]):
+            ev = out.node(i)
+            ok = ok and bool(ev.res.feasible) == call["feasible"] and ev.res.height == call["height"] and G.sha_rhs(ev.rhs, ev.vibr) == call["rhsSha"]
+        report["cases"].append({"name": "ragged batch of %d node(s) over %d rank(s)" % (n_take, world), "ok": bool(ok)})
+    t.close()
+    # 4. a MILP whose ROOT relaxation is infeasible (no tree, no batch, hence no exchange step at all: no rank may wait for one),
+    #    and one that is integral at the root; both against the same host without sharding
+    base = {"optimize": "profit", "opType": "max",
+            "constraints": {"cap": {"max": 10}, "need": {"min": 12}},
+            "variables": {"x": {"profit": 3, "cap": 1, "need": 1}, "y": {"profit": 2, "cap": 1, "need": 1}},
+            "ints": {"x": 1, "y": 1}}
+    feasible_root = dict(base, constraints={"cap": {"max": 10}, "need": {"min": 4}})
+    for label, model in (("infeasible root", base), ("integral root", feasible_root)):
+        sharded = Solve(model, full=True, lib=lib, speculate=2 * world, group=dist.group.WORLD)
+        local = Solve(model, full=True, lib=lib)
+        ok = sharded["result"] == local["result"] and sharded["iter"] == local["iter"]
+        if label == "infeasible root":
+            ok = ok and sharded["result"]["feasible"] is False
+        report["cases"].append({"name": label, "ok": bool(ok)})
     gathered = [None] * world
     dist.all_gather_object(gathered, report)
     if rank == 0:

@@ -1,0 +1,124 @@
+"""DETECTED cycles (simplex.ts:78-93, 305-320, 415-440) against the reference itself: tests/golden/cycles/*.json.gz hold runs
+of the reference that end in "Cycle in phase 2" -- small degenerate LPs, small LPs with unrestricted variables, and the same
+LPs embedded in tableaus large enough for the chip-wide kernels (gen_golden_cycles.js explains the embedding).  Pinned: every
+pivot up to the stop, the flags (feasible = false), the phase of the hit and the reference's "Start :" / "Length :" messages
+(cycle_start / cycle_length of the C ABI), the final tableau.
+CPU: the test-only oracle library; -m gpu: the HIP library through every launch shape the instance fits."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as G
+from jslpsolver_amd import Model
+from jslpsolver_amd.engine import Tableau, pivot_digest
+
+CYCLES = os.path.join(G.GOLDEN, "cycles")
+SMALL = sorted(p for p in glob.glob(os.path.join(CYCLES, "*.json.gz")) if "embedded" not in p)
+EMBEDDED = sorted(glob.glob(os.path.join(CYCLES, "embedded_*.json.gz")))
+
+
+def _lcg(seed):
+    s = [seed & 0xffffffff]
+
+    def r():
+        s[0] = (s[0] * 1664525 + 1013904223) & 0xffffffff  # == (Math.imul(s, 1664525) + 1013904223) >>> 0
+        return s[0] / 4294967296.0
+    return r
+
+
+def _embed(model, extra_vars, extra_cons, seed=777):
+    """gen_golden_cycles.js `embed`, draw for draw"""
+    r = _lcg(seed)
+    big = {"optimize": model["optimize"], "opType": model["opType"], "constraints": dict(model["constraints"]),
+           "variables": {k: dict(v) for k, v in model["variables"].items()}}
+    if "unrestricted" in model:
+        big["unrestricted"] = dict(model["unrestricted"])
+    for i in range(extra_cons):
+        big["constraints"]["fc%d" % i] = {"max": 100 + int(r() * 900)}
+    for j in range(extra_vars):
+        big["variables"]["f%d" % j] = {"fc%d" % i: 1 + int(r() * 20) for i in range(extra_cons)}
+    big["options"] = {"presolve": False}
+    return big
+
+
+def _instance(path):
+    g = G.load(path)
+    name = G.ident(path)
+    if g["model"] is not None:
+        m, vibr, vibc = G.dense_tableau(g["tableau"])
+    else:  # embedded_<family>_<seed>_<vars>x<cons>: rebuilt from the small golden's model
+        _, fam, seed, dims = name.split("_")
+        nv, nc = (int(x) for x in dims.split("x"))
+        small = G.load(os.path.join(CYCLES, "%s_%s.json.gz" % (fam, seed)))["model"]
+        m, vibr, vibc = Model(_embed(small, nv, nc)).build_tableau()
+    assert m.shape == (g["tableau"]["height"], g["tableau"]["width"])
+    assert G.sha_matrix(m) == g["tableau"]["matrixSha"], "the rebuilt tableau is not the reference's"
+    return g, m, vibr, vibc
+
+
+def _messages(res):
+    return ["Cycle in phase %d" % res.cycle_phase, "Start :%d" % res.cycle_start, "Length :%d" % res.cycle_length] if res.cycle_phase else []
+
+
+def _check(lib, path, expect_path=None):
+    g, m, vibr, vibc = _instance(path)
+    assert g["messages"] and g["messages"][0].startswith("Cycle in phase"), "golden without a detected cycle"
+    t = Tableau(m, vibr, vibc, g["tableau"]["unrestricted"], precision=g["tableau"]["precision"], lib=lib)
+    res = t.simplex(check_cycles=True)
+    call = g["simplexCalls"][0]
+    assert _messages(res) == g["messages"]                       # the phase, and the reference's [start, length] of the repeated block
+    assert bool(res.feasible) == call["feasible"] is False       # simplex.ts:90 / 317
+    assert (res.pivots_phase1, res.pivots_phase2) == (call["p1"], call["p2"])
+    trace = t.pivot_trace()
+    assert len(trace) == g["nPivots"] and pivot_digest(trace) == g["pivotDigest"]
+    assert G.sha_matrix(t.download()[0]) == g["final"]["matrixSha"]
+    rhs, rows = t.read_rhs()
+    assert G.sha_rhs(rhs, rows) == call["rhsSha"]
+    if expect_path is not None:
+        assert t.last_path() == expect_path
+    t.close()
+
+
+def test_goldens_are_there():
+    assert len(SMALL) == 13 and len(EMBEDDED) == 6
+
+
+@pytest.mark.parametrize("path", SMALL + EMBEDDED, ids=G.ident)
+def test_oracle_stops_where_the_reference_stops(oracle_lib, path):
+    _check(oracle_lib, path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["auto", "wg", "sp", "fused", "resident"])
+@pytest.mark.parametrize("path", SMALL, ids=G.ident)
+def test_hip_small_every_launch_shape(hip_lib, path, mode, monkeypatch):
+    if mode != "auto":
+        monkeypatch.setenv("JSLP_FORCE_PATH", mode)
+    _check(hip_lib, path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", EMBEDDED, ids=G.ident)
+def test_hip_embedded_default_policy_runs_register_resident(hip_lib, path):
+    """the default policy on the large embeddings: the lean register-resident kernel (every workgroup runs the suffix test on its
+    own LDS history), its tall / wide geometries, and -- with unrestricted variables -- the general build"""
+    name = G.ident(path)
+    _check(hip_lib, path, None if ("unr" in name and "3000" in name) else "resident")  # (4001-row unrestricted: fused by default)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", EMBEDDED, ids=G.ident)
+def test_hip_embedded_through_the_streaming_kernels(hip_lib, path, monkeypatch):
+    """workgroup 0's check in k_pivot_fused / k_select"""
+    monkeypatch.setenv("JSLP_FORCE_PATH", "fused")
+    _check(hip_lib, path, "fused")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", [p for p in EMBEDDED if "2040x2030" in p], ids=G.ident)
+def test_hip_embedded_general_resident_build(hip_lib, path, monkeypatch):
+    """JSLP_RES_LEAN=0: the general build's leaderless protocol (per-workgroup LDS history) on the headline geometry"""
+    monkeypatch.setenv("JSLP_RES_LEAN", "0")
+    _check(hip_lib, path, "resident")

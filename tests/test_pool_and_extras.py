@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 
 import golden_util as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from jslpsolver_amd import generators
 from jslpsolver_amd.engine import DevicePool, Tableau, pivot_digest
 
@@ -82,13 +84,15 @@ def _check_watched(lib):
     t.close()
 
 
-def _check_watched_batch(lib, reps):
+def _check_watched_batch(lib, reps, duplicate=False):
     """the compact read-back of a whole batch (jslp_engine_relax_batch_watched) against the full one, node by node; reps > 1 makes
     the batch larger than the resident workgroups of the HIP engine's queue kernel (several nodes per slot, copy-on-write)"""
     g = G.load(MONSTER_II)
     t, calls = _root(lib, g)
     from jslpsolver_amd import Model
     ints = [int(v) for v in Model(g["model"]).integer_index_array]
+    if duplicate:  # a variable listed twice (the API allows it): no variable -> position table on the device, every entry looks its row up
+        ints = ints + ints[:5] + [ints[0]]
     t.set_watched_variables(ints)
     nodes = [c["cuts"] or [] for c in calls[1:]] * reps
     packed = t.pack_cut_lists(nodes)
@@ -119,6 +123,17 @@ def test_watched_batch_equals_full_batch_oracle(oracle_lib):
 @pytest.mark.parametrize("reps", [1, 8])
 def test_watched_batch_equals_full_batch_hip(hip_lib, reps):
     _check_watched_batch(hip_lib, reps)
+
+
+def test_watched_batch_with_a_variable_listed_twice_oracle(oracle_lib):
+    _check_watched_batch(oracle_lib, 1, duplicate=True)
+
+
+@pytest.mark.gpu
+def test_watched_batch_with_a_variable_listed_twice_hip(hip_lib):
+    """1208 nodes > the resident workgroups of the queue kernel: nodes land on copy-on-write slots whose GLOBAL maps are stale,
+    so the compact read-back must come from the LDS row map"""
+    _check_watched_batch(hip_lib, 8, duplicate=True)
 
 
 def test_watched_read_back_equals_full_read_back_oracle(oracle_lib):
@@ -210,6 +225,38 @@ def test_resident_abort_rolls_back_and_resolves(hip_lib, abort_at, monkeypatch):
         assert x.tobytes() == y.tobytes()
     t.close()
     t2.close()
+
+
+@pytest.mark.gpu
+def test_pool_creation_fails_loudly_when_peer_access_is_refused(hip_lib):
+    """jslp_pool_create on a platform that refuses peer access (injected: JSLP_TEST_PEER_REFUSED=1 makes every member look
+    refused): a clean error that names the devices, nothing leaked, and the primary engine is as usable as before"""
+    code = r"""
+import os, sys
+os.environ["JSLP_TEST_PEER_REFUSED"] = "1"
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import golden_util as G
+from jslpsolver_amd import _capi
+from jslpsolver_amd.engine import Tableau, DevicePool
+lib = _capi.load_hip()
+g = G.load(os.path.join(G.GOLDEN, "fixtures", "Monster_II.json.gz"))
+tab = g["tableau"]; m, vibr, vibc = G.dense_tableau(tab)
+t = Tableau(m, vibr, vibc, tab["unrestricted"], precision=tab["precision"], row_capacity=tab["height"] + 40, lib=lib)
+r0 = t.applyCuts([], check_cycles=True); t.save()
+for _ in range(3):
+    try:
+        DevicePool(t, [0, 0, 0])
+        print("NO ERROR"); sys.exit(1)
+    except Exception as e:
+        assert "peer access refused" in str(e), str(e)
+r1 = t.applyCuts(g["simplexCalls"][1]["cuts"] or [], check_cycles=True)
+assert r1.height == g["simplexCalls"][1]["height"] and bool(r1.feasible) == g["simplexCalls"][1]["feasible"]
+os.environ["JSLP_POOL_ALLOW_STAGED"] = "1"  # (read once per process: still refused here)
+t.close(); print("OK")
+""" % (ROOT, ROOT)
+    import subprocess, sys
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-2000:] + out.stderr[-2000:]
 
 
 @pytest.mark.gpu

@@ -54,6 +54,18 @@ def test_two_ranks_shard_nodes_and_agree(oracle_lib):
         assert all(c["ok"] for c in rep["cases"]), rep
 
 
+def test_four_ranks_ragged_batches_and_infeasible_root(oracle_lib):
+    """world_size 4 on CPU (gloo, oracle engines): batches with fewer nodes than ranks / not divisible by the world size / empty,
+    a MILP whose root relaxation is infeasible and one that is integral at the root (no exchange step must be waited for)"""
+    reports = _run("oracle", 4, 29561)
+    assert len(reports) == 4
+    for rep in reports:
+        assert rep["world"] == 4 and rep["backend"] == "oracle-c"
+        names = [c["name"] for c in rep["cases"]]
+        assert "infeasible root" in names and "ragged batch of 0 node(s) over 4 rank(s)" in names and "ragged batch of 5 node(s) over 4 rank(s)" in names
+        assert all(c["ok"] for c in rep["cases"]), rep
+
+
 @pytest.mark.gpu
 def test_bench_multi_rank_code_path_on_one_gpu(hip_lib):
     """bench.py's N > 1 branch (process group, barrier, max / sum over ranks, replica + sharded-relaxation accounting)

@@ -18,6 +18,14 @@ for s in $steps; do
            (cd /tmp && timeout 600 rocprofv3 --pmc $C -d $GRAFT_REPO_ROOT/$out/pmc_${k}_$c -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py $k > $GRAFT_REPO_ROOT/$out/pmc_${k}_$c.log 2>&1 < /dev/null); echo "pmc $k $c rc=$?"
          done; timeout 120 python tools/pmc_latest.py $out $k "gpurun_out/$tag (tools/gpu_round.sh pmc), round 2" < /dev/null | head -40; done
          cp profiles/pmc_latest.json $out/pmc_latest.json ;;
+    profw) for w in ${PROFW:-3a 3a_check 3b tall_4001x2001 wide_2001x4001 big_3001x3001}; do
+             mkdir -p $out/profw/$w
+             (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$out/profw/$w/kt -o k -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py $w > $GRAFT_REPO_ROOT/$out/profw/$w/kt.log 2>&1 < /dev/null)
+             (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/$out/profw/$w/fetch -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py $w > $GRAFT_REPO_ROOT/$out/profw/$w/fetch.log 2>&1 < /dev/null)
+             (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/$out/profw/$w/write -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py $w > $GRAFT_REPO_ROOT/$out/profw/$w/write.log 2>&1 < /dev/null)
+             echo "profw $w rc=$?"
+           done
+           timeout 120 python tools/workload_rows.py $out/profw $out/workload_rows.md $out/workload_rows.json < /dev/null ;;
     shim) for f in Monster_Problem Monster_II LargeFarmMIP Knapsack_1 Vendor_Selection; do echo "== $f" >> $out/shim_profile.log; timeout 300 node tools/shim_profile.js $f >> $out/shim_profile.log 2>&1 < /dev/null; done; echo "shim rc=$?"; cat $out/shim_profile.log | cut -c1-400 ;;
     config) timeout 900 python tools/config_times.py $out/config_times.md > $out/config_times.log 2>&1 < /dev/null; echo "config rc=$?"; cat $out/config_times.md ;;
     wgt) (JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py single; JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py batch

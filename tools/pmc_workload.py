@@ -33,6 +33,45 @@ def pivots(n=2000, solves=2):
                       "workload": "config 3a %dx%d fp64, %d solves" % (H, W, solves)}))
 
 
+def dense(kind, n_vars, n_rows, check, solves=2, key=None):
+    """one dense LP solved `solves` times from the device-side snapshot; the kernel that ran is read back from the engine"""
+    lib = _capi.load_hip()
+    if kind == "ra":
+        m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n_vars, n_rows)
+    else:
+        m, vibr, vibc, _ = generators.dense_random_lp_tableau(12345, n_vars, n_rows)
+    t = Tableau(m, vibr, vibc, lib=lib)
+    t.save()
+    total, p1 = 0, 0
+    for _ in range(solves):
+        t.restore()
+        r = t.simplex(check_cycles=check)
+        total += r.pivots_phase1 + max(r.pivots_phase2, 0)
+        p1 += r.pivots_phase1
+    path = t.last_path()
+    t.close()
+    H, W = m.shape
+    one_launch = path == "resident"
+    kernel = {"resident": "k_simplex_resident", "fused": "k_fused_p1" if p1 == total else "k_pivot_fused", "select+update": "k_update"}.get(path, path)
+    print(json.dumps({"key": key or ("%s_%dx%d_%s" % (kind, H, W, "check" if check else "nocheck")), "kernel": kernel,
+                      # the resident kernel runs a whole solve per dispatch; the streaming kernels one pivot per dispatch (plus a few
+                      # empty over-launches past the end of a solve, which the summary drops by duration)
+                      "dispatches": solves if one_launch else total, "units": total, "unit": "pivot", "one_dispatch_per": "solve" if one_launch else "pivot",
+                      "algorithmic_bytes_per_unit": 16.0 * H * W, "path": path, "phase1_pivots": p1,
+                      "workload": "%s %dx%d fp64, cycle check %s, %d solves" % (
+                          "generateResourceAllocation" if kind == "ra" else "generateRandomLP", H, W, "on" if check else "off", solves)}))
+
+
+WORKLOADS = {
+    "3a": lambda: dense("ra", 2000, 2000, False, key="3a"),
+    "3a_check": lambda: dense("ra", 2000, 2000, True, key="3a_check"),
+    "3b": lambda: dense("lp", 2000, 2000, False, solves=4, key="3b"),
+    "tall_4001x2001": lambda: dense("ra", 2000, 4000, False, solves=1, key="tall_4001x2001"),
+    "wide_2001x4001": lambda: dense("ra", 4000, 2000, False, solves=1, key="wide_2001x4001"),
+    "big_3001x3001": lambda: dense("ra", 3000, 3000, False, solves=1, key="big_3001x3001"),
+}
+
+
 def relax(calls=12, reps=16):
     lib = _capi.load_hip()
     with gzip.open(os.path.join(ROOT, "tests", "golden", "fixtures", "Monster_II.json.gz"), "rt") as fh:
@@ -67,5 +106,7 @@ def relax(calls=12, reps=16):
 if __name__ == "__main__":
     if sys.argv[1] == "pivots":
         pivots(int(sys.argv[2]) if len(sys.argv) > 2 else 2000)
+    elif sys.argv[1] in WORKLOADS:
+        WORKLOADS[sys.argv[1]]()
     else:
         relax()
