@@ -81,7 +81,8 @@ for (const s of degSeeds) record("deg_" + s, Object.assign(degCase(s), { options
 for (const s of unrSeeds) record("unr_" + s, Object.assign(unrCase(s), { options: { presolve: false } }), false);
 // large: the embedding is rebuilt at test time from the small model + (extraVars, extraCons, seed) by tests/test_cycle_goldens.py
 const big = [
-    { from: "deg", seed: 35358, vars: 2040, cons: 2030 },   // ~2045 x 2052: the headline register-resident geometry, partial pricing
+    { from: "deg", seed: 35358, vars: 2000, cons: 2000 },   // 2011 x 2012: the headline register-resident geometry (1024 lanes x 2 columns x 8 rows), partial pricing
+    { from: "deg", seed: 35358, vars: 2040, cons: 2030 },   // 2041 x 2052: just past 2048 columns -> 512 lanes x 6 columns
     { from: "deg", seed: 292715, vars: 2040, cons: 2030 },
     { from: "deg", seed: 137788, vars: 2600, cons: 2500 },  // ~2511 x 2612: 512 lanes x 6 columns x 12 rows (phase 2 resident) / fused
     { from: "deg", seed: 178868, vars: 1500, cons: 3000 },  // ~3009 x 1512: the tall geometry / fused, one column tile

@@ -82,7 +82,7 @@ def _check(lib, path, expect_path=None):
 
 
 def test_goldens_are_there():
-    assert len(SMALL) == 13 and len(EMBEDDED) == 6
+    assert len(SMALL) == 13 and len(EMBEDDED) == 7
 
 
 @pytest.mark.parametrize("path", SMALL + EMBEDDED, ids=G.ident)
@@ -117,8 +117,11 @@ def test_hip_embedded_through_the_streaming_kernels(hip_lib, path, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("path", [p for p in EMBEDDED if "2040x2030" in p], ids=G.ident)
+@pytest.mark.parametrize("path", [p for p in EMBEDDED if "2040x2030" in p or "2000x2000" in p], ids=G.ident)
 def test_hip_embedded_general_resident_build(hip_lib, path, monkeypatch):
-    """JSLP_RES_LEAN=0: the general build's leaderless protocol (per-workgroup LDS history) on the headline geometry"""
+    """JSLP_RES_LEAN=0 (forced resident: the wide geometries are not the general build's default): the leaderless protocol's
+    per-workgroup LDS history on the headline geometry (2011 x 2012) and on 512 lanes x 6 columns, with and without
+    unrestricted variables"""
     monkeypatch.setenv("JSLP_RES_LEAN", "0")
+    monkeypatch.setenv("JSLP_FORCE_PATH", "resident")
     _check(hip_lib, path, "resident")

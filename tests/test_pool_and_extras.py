@@ -242,14 +242,14 @@ lib = _capi.load_hip()
 g = G.load(os.path.join(G.GOLDEN, "fixtures", "Monster_II.json.gz"))
 tab = g["tableau"]; m, vibr, vibc = G.dense_tableau(tab)
 t = Tableau(m, vibr, vibc, tab["unrestricted"], precision=tab["precision"], row_capacity=tab["height"] + 40, lib=lib)
-r0 = t.applyCuts([], check_cycles=True); t.save()
+t.applyCuts([], check_cycles=True); t.save()
 for _ in range(3):
     try:
         DevicePool(t, [0, 0, 0])
         print("NO ERROR"); sys.exit(1)
     except Exception as e:
         assert "peer access refused" in str(e), str(e)
-r1 = t.applyCuts(g["simplexCalls"][1]["cuts"] or [], check_cycles=True)
+r1, _rhs, _rows = t.applyCuts(g["simplexCalls"][1]["cuts"] or [], check_cycles=True)
 assert r1.height == g["simplexCalls"][1]["height"] and bool(r1.feasible) == g["simplexCalls"][1]["feasible"]
 os.environ["JSLP_POOL_ALLOW_STAGED"] = "1"  # (read once per process: still refused here)
 t.close(); print("OK")

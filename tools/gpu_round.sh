@@ -16,7 +16,7 @@ for s in $steps; do
     pmc) for k in pivots relax; do for c in fetch write; do
            C=FETCH_SIZE; [ $c = write ] && C=WRITE_SIZE
            (cd /tmp && timeout 600 rocprofv3 --pmc $C -d $GRAFT_REPO_ROOT/$out/pmc_${k}_$c -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py $k > $GRAFT_REPO_ROOT/$out/pmc_${k}_$c.log 2>&1 < /dev/null); echo "pmc $k $c rc=$?"
-         done; timeout 120 python tools/pmc_latest.py $out $k "gpurun_out/$tag (tools/gpu_round.sh pmc), round 2" < /dev/null | head -40; done
+         done; timeout 120 python tools/pmc_latest.py $out $k "gpurun_out/$tag (tools/gpu_round.sh pmc)" < /dev/null | head -40; done
          cp profiles/pmc_latest.json $out/pmc_latest.json ;;
     profw) for w in ${PROFW:-3a 3a_check 3b tall_4001x2001 wide_2001x4001 big_3001x3001}; do
              mkdir -p $out/profw/$w
@@ -42,7 +42,7 @@ for s in $steps; do
     pmcrelax) for cow in 0 1; do for c in fetch write; do
            C=FETCH_SIZE; [ $c = write ] && C=WRITE_SIZE
            (cd /tmp && JSLP_NODE_COW=$cow timeout 600 rocprofv3 --pmc $C -d $GRAFT_REPO_ROOT/$out/pmc_relax_$c -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py relax > $GRAFT_REPO_ROOT/$out/pmc_relax_$c.log 2>&1 < /dev/null); echo "pmc relax cow=$cow $c rc=$?"
-         done; timeout 120 python tools/pmc_latest.py $out relax "gpurun_out/$tag (tools/gpu_round.sh pmcrelax, JSLP_NODE_COW=$cow), round 2" < /dev/null | grep "bytes_per_unit\|traffic_over"; rm -rf $out/pmc_relax_fetch $out/pmc_relax_write; done ;;
+         done; timeout 120 python tools/pmc_latest.py $out relax "gpurun_out/$tag (tools/gpu_round.sh pmcrelax, JSLP_NODE_COW=$cow)" < /dev/null | grep "bytes_per_unit\|traffic_over"; rm -rf $out/pmc_relax_fetch $out/pmc_relax_write; done ;;
     qcheck) (for cfg in "JSLP_NODE_QUEUE=0 JSLP_SNAPSHOT_TRANSPOSE=0" "JSLP_NODE_COW=0" "JSLP_NODE_COW=1" "JSLP_NODE_COW=1 JSLP_SNAPSHOT_TRANSPOSE=0" "JSLP_NODE_QUEUE=2" "JSLP_ZERO_COPY=0" "JSLP_GROUP_MAX=100"; do echo "== $cfg"; env $cfg timeout 120 python tools/queue_check.py; done) > $out/queue_check.log 2>&1 < /dev/null; echo "qcheck rc=$?"; cat $out/queue_check.log ;;
     qprof) (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/qprof -o q -- python $GRAFT_REPO_ROOT/tools/wglds_timing.py rate > $GRAFT_REPO_ROOT/$out/qprof.log 2>&1 < /dev/null); echo "qprof rc=$?"; tail -2 $out/qprof.log
           timeout 60 python tools/rocpd_stats.py $(ls $out/qprof/*.db | head -1) 2>/dev/null | head -12 ;;
