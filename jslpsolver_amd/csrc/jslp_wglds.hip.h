@@ -137,7 +137,13 @@ __device__ __forceinline__ KI block_min_ki(KI x, SmemL& sm, int& par) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (w < WGL_SEL / 64) {
         x = ki_wave_min(x);
-        if (lane == 0) { sm.red_k[par][w] = x.k; sm.red_i[par][w] = x.i; }
+        // (the lane test is recomputed here, behind an opaque barrier: hoisted out of the pivot loop it becomes a 64-bit SGPR mask
+        //  that the 64-VGPR / 78-SGPR build spills, and ROCm 7.2's hipcc reloads only its HIGH half before `s_and_b64 exec, exec, mask`
+        //  while the low half's register has meanwhile served as a temporary for the winning index -- DESIGN.md section 8, the
+        //  round-2 "64-VGPR fault": with the batch reduction's index 0 in it no lane published, the next reduction read a stale slot)
+        int l0 = lane;
+        asm volatile("" : "+v"(l0));
+        if (l0 == 0) { sm.red_k[par][w] = x.k; sm.red_i[par][w] = x.i; }
     }
     __syncthreads();
     unsigned long long rk = sm.red_k[par][0];

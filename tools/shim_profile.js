@@ -26,12 +26,15 @@ for (const k of Object.keys(addon)) {
         }
     };
 }
-gpu.install(T, { SlackVariable, solver, minCells: 0, speculate: 0 }); // profile the engine path whatever the size, one node at a time
+// SHIM_DEFAULTS=1: the binding's default options (size policy, 16-node speculative batches); else the engine path whatever the
+// size, one node at a time
+if (process.env.SHIM_DEFAULTS === "1") gpu.install(T, { SlackVariable, solver });
+else gpu.install(T, { SlackVariable, solver, minCells: 0, speculate: 0 });
 const g = JSON.parse(zlib.gunzipSync(fs.readFileSync(path.join(root, "tests/golden/fixtures", process.argv[2] + ".json.gz"))).toString());
 const origSolve = M.prototype.solve;
 let tSolve = 0;
 M.prototype.solve = function () { const t0 = process.hrtime.bigint(); try { return origSolve.apply(this, arguments); } finally { tSolve += Number(process.hrtime.bigint() - t0) / 1e6; } };
-for (let i = 0; i < 8; i++) {
+for (let i = 0; i < (Number(process.env.SHIM_RUNS) || 8); i++) {
     inAddon = 0; tSolve = 0; calls = 0; perFn = {};
     const m = JSON.parse(JSON.stringify(g.model));
     const t0 = process.hrtime.bigint();
