@@ -82,6 +82,8 @@ function createGpuSpeculativeService(gpu, options) {
         // workgroup per node, which only pays while a node's tableau is small next to the chip (a single child of a
         // 20 MB tableau is faster through the chip-wide kernels, one node at a time)
         const speculate = nOpt > 0 || t.width * t.height > 1536 * 1024 ? 1 : width;
+        // the device pool (install(..., {devices})) splits full read-backs only; keep_solutions reads every node's whole column
+        const compact = !(options && options.fullReadBack) && !gpu.usesPool() && !(model && model.keep_solutions);
 
         heap.push(-Infinity, []);
         while (heap.items.length > 0 && withinTolerance && Date.now() < deadline) {
@@ -100,12 +102,15 @@ function createGpuSpeculativeService(gpu, options) {
                     const batch = [node];
                     for (let i = 0; i < ahead.length && batch.length < speculate; i++)
                         if (!cache.has(ahead[i].stamp) && ahead[i].key <= bestEvaluation) batch.push(ahead[i]);
-                    const outcomes = gpu.relaxBatch(t, batch.map((b) => b.cuts));
+                    // compact read-back: per node the row / value of the integer variables -- all the tree reads between relaxations
+                    const outcomes = compact ? gpu.relaxBatchWatched(t, batch.map((b) => b.cuts)) : gpu.relaxBatch(t, batch.map((b) => b.cuts));
                     for (let i = 0; i < batch.length; i++) cache.set(batch[i].stamp, outcomes[i]);
                 }
                 const outcome = cache.get(node.stamp);
                 cache.delete(node.stamp);
-                gpu.commitOutcome(t, cuts, outcome); // restore() + addCutConstraints(cuts) bookkeeping + the cached simplex()
+                // restore() + addCutConstraints(cuts) bookkeeping + the cached simplex()
+                if (compact) gpu.commitWatched(t, cuts, outcome);
+                else gpu.commitOutcome(t, cuts, outcome);
             } else {
                 applyCuts(t, cuts);
             }

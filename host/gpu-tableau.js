@@ -241,7 +241,18 @@ function absorb(t, st, res) {
 // complete the host copy (every row's RHS, the whole rowByVarIndex) from the last read-back
 function flush(t) {
     const st = t.__gpu;
-    if (!st || !st.active || !st.stale) return;
+    if (!st || !st.active) return;
+    if (st.watchedCuts) {
+        // the live node was committed from a COMPACT outcome (commitWatched: only the integer variables' rows are known to the
+        // host): evaluate it once more with the full read-back -- a relaxation is a pure function of the saved root and its cuts
+        const c = packCuts(st.watchedCuts);
+        st.watchedCuts = null;
+        const check = t.model ? t.model.checkForCycles === true : false;
+        const res = addon.relax(st.h, c.type, c.varIndex, c.value, check, st.rhs, st.rows);
+        st.lastHeight = res.height;
+        st.stale = true;
+    }
+    if (!st.stale) return;
     const H = st.lastHeight;
     const width = t.width;
     const rhsColumn = t.rhsColumn;
@@ -324,9 +335,16 @@ function install(Tableau, options) {
         t.varIndexByRow[row] = slack;
         t.rowByVarIndex[slack] = row;
         t.colByVarIndex[slack] = -1;
-        t.variablesPerIndex[slack] = opts.SlackVariable
-            ? new opts.SlackVariable("s" + slack, slack)
-            : { id: "s" + slack, cost: 0, index: slack, value: 0, priority: 0, isSlack: true };
+        // (slack indexes repeat from node to node -- restore() rewinds lastElementIndex --: one object per index is enough)
+        const slackObjects = t.__gpu.slackObjects || (t.__gpu.slackObjects = []);  // per tableau: updateVariableValues writes their values
+        let sv = slackObjects[slack];
+        if (sv === undefined) {
+            sv = opts.SlackVariable
+                ? new opts.SlackVariable("s" + slack, slack)
+                : { id: "s" + slack, cost: 0, index: slack, value: 0, priority: 0, isSlack: true };
+            slackObjects[slack] = sv;
+        }
+        t.variablesPerIndex[slack] = sv;
     }
 
     // Tableau.applyMIRCuts (cutting-strategies.ts:199-212): the scan and the <= 10 new rows happen on the device
@@ -363,6 +381,7 @@ function install(Tableau, options) {
         }
         st.pendingRestore = false;
         st.pendingCuts = null;
+        st.watchedCuts = null;  // a full read-back: the host copy is whole again
         absorb(this, st, res);
         return this;
     };
@@ -618,7 +637,51 @@ function commitOutcome(t, cuts, outcome) {
     st.pendingCuts = null;
     st.rhs.set(outcome.rhs);
     st.rows.set(outcome.rows);
+    st.watchedCuts = null;
     absorb(t, st, outcome.res);
+    return t;
+}
+
+// commitOutcome for a node evaluated by relaxBatchWatched: the host learns what the tree reads between relaxations -- flags,
+// evaluation, and for every integer variable its row and value (mip-utils.ts:43-61, 100-126) -- and nothing else; whoever needs
+// the whole column (getSolution, updateVariableValues, copy, the editing API) goes through flush(), which re-evaluates the node
+function commitWatched(t, cuts, outcome) {
+    const st = t.__gpu;
+    t.restore();
+    t.addCutConstraints(cuts);
+    st.pendingRestore = false;
+    st.pendingCuts = null;
+    const res = outcome.res;
+    t.feasible = res.feasible;
+    t.bounded = res.bounded;
+    if (res.optimal) {
+        t.evaluation = res.evaluation;
+        if (t.simplexIters === 0) t.bestPossibleEval = res.evaluation;
+        t.simplexIters += 1;
+    } else if (!res.bounded) {
+        t.evaluation = -Infinity;
+        t.unboundedVarIndex = res.unboundedVarIndex;
+    }
+    if (res.cyclePhase !== 0 && t.model) {
+        t.model.messages.push("Cycle in phase " + res.cyclePhase);
+        t.model.messages.push("Start :" + res.cycleStart);
+        t.model.messages.push("Length :" + res.cycleLength);
+    }
+    const ints = t.model.integerVariables;
+    const rows = outcome.rows, values = outcome.values;
+    const width = t.width, rhsColumn = t.rhsColumn, matrix = t.matrix;
+    const rowByVarIndex = t.rowByVarIndex, varIndexByRow = t.varIndexByRow;
+    for (let k = 0; k < ints.length; k++) {
+        const v = ints[k].index, r = rows[k];
+        rowByVarIndex[v] = r;
+        if (r > 0) {
+            varIndexByRow[r] = v;
+            matrix[r * width + rhsColumn] = values[k];
+        }
+    }
+    st.lastHeight = res.height;
+    st.stale = false;
+    st.watchedCuts = cuts;  // (flush() completes the picture on demand)
     return t;
 }
 
@@ -695,9 +758,13 @@ function bringHome(t) {
     t.__gpu = undefined;
 }
 
+function usesPool() {
+    return !!(installedOpts.devices && installedOpts.devices.length > 1);
+}
+
 const api = {
     loadEngine, install, sync, pivotTrace, release, guardIncremental, createCheckpoint, relaxFromCheckpoint, releaseCheckpoint,
-    relaxBatch, relaxBatchWatched, commitOutcome, isOnEngine, bringHome,
+    relaxBatch, relaxBatchWatched, commitOutcome, commitWatched, usesPool, isOnEngine, bringHome,
     backend: () => backend,
 };
 module.exports = api;

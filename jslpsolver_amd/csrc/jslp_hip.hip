@@ -145,6 +145,9 @@ struct jslp_engine {
 
 static const long long WG_CELLS_SINGLE = 64 * 1024;         // one workgroup beats 2 launches/pivot below this
 static const long long WG_CELLS_BATCH = 4LL * 1024 * 1024;  // batches use one workgroup per node up to this
+#ifndef JSLP_SMALL_BATCH_1024_DEFAULT
+#define JSLP_SMALL_BATCH_1024_DEFAULT 256  // batches of at most this many nodes (one per CU) take the 1024-thread node kernel: 16 nodes 111 -> 102 us, 64 nodes 147 -> 132 us (r03_o); 0 = never
+#endif
 static int wg_batch_threads() {  // workgroup size of the per-node kernel when a call carries several nodes
     static int v = -1;
     if (v < 0) {
@@ -1828,7 +1831,15 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         if (one_launch) {
             Snapshot sn = root_snapshot(e);
             e->last_path = "workgroup";
-            if (const size_t lds = wglds_smem(e))
+            // a batch that leaves most CUs idle anyway (speculative batches of a real tree: <= 16 nodes) is served by latency, not
+            // by occupancy: the 1024-thread shape of the single-node path, one workgroup per CU
+            static const int small_1024 = getenv("JSLP_SMALL_BATCH_1024") ? atoi(getenv("JSLP_SMALL_BATCH_1024")) : JSLP_SMALL_BATCH_1024_DEFAULT;
+            const size_t lds = wglds_smem(e);
+            if (lds && g <= small_1024)
+                hipLaunchKernelGGL((k_node_lds<1024>), dim3(g), dim3(1024), lds, s, e->s, sn, cu, first, check_cycles, cap,
+                                   (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states,
+                                   g_stride, first, (unsigned*)nullptr, 0u);
+            else if (lds)
                 hipLaunchKernelGGL((k_node_lds<512>), dim3(g), dim3(512), lds, s, e->s, sn, cu, first, check_cycles, cap,
                                    (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states,
                                    g_stride, first, (unsigned*)nullptr, 0u);
