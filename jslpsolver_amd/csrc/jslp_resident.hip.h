@@ -974,7 +974,8 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
         if (P2ONLY) {
             R.end_code = 5;  // never launched like this; if it were, the host rolls back and streams (like an aborted hand-off)
         } else {
-            resident_phase<1, THREADS, CPT, ROWS, UNR, LEAN>(f, sm, R, it1_start, it2_start, pb);
+            if (LEAN) resident_phase1_pipe<THREADS, CPT, ROWS>(f, sm, R, it1_start, it2_start);
+            else resident_phase<1, THREADS, CPT, ROWS, UNR, LEAN>(f, sm, R, it1_start, it2_start, pb);
             if (R.end_code == 0) phase = 2;
         }
     }

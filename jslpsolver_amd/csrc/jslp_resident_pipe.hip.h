@@ -55,6 +55,31 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane) {  // src
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// row i of mine <- pivot (pr_p, pc_p): exactly the general loop's step F for one row
+#define JSLP_PIPE_UPDATE_ROW(i)                                                                             \
+    do {                                                                                                    \
+        const int r_ = r_begin + (i);                                                                       \
+        if (r_ >= r_end) break;                                                                             \
+        if (r_ == 0) { /* workgroup 0 mirrors the cost row */                                               \
+            _Pragma("unroll") for (int j = 0; j < CPT; j++) a[i][j] = r0[j];                                \
+            break;                                                                                          \
+        }                                                                                                   \
+        if (r_ == pr_p) {                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < CPT; j++) a[i][j] = p[j];                                 \
+            break;                                                                                          \
+        }                                                                                                   \
+        const double ki_ = kis[i];                                                                          \
+        if (nonzero16(ki_)) {                                                                               \
+            _Pragma("unroll") for (int j = 0; j < CPT; j++)                                                 \
+                if ((nzm >> j) & 1u) a[i][j] = eliminate(a[i][j], ki_, p[j]);                               \
+            if (has_pc_p) {                                                                                 \
+                const double nv_ = sm.nv[i];                                                                \
+                _Pragma("unroll") for (int j = 0; j < CPT; j++)                                             \
+                    if (pc_p == c0 + j) a[i][j] = nv_;                                                      \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+
 template <int THREADS, int CPT, int ROWS>
 __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start,
                                                      const int (&pb)[CPT]) {
@@ -85,30 +110,6 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     for (int j = 0; j < CPT; j++) p[j] = 0.0;
     int okslot = 0;
 
-    // row i of mine <- pivot (pr_p, pc_p): exactly the general loop's step F for one row
-#define JSLP_PIPE_UPDATE_ROW(i)                                                                             \
-    do {                                                                                                    \
-        const int r_ = r_begin + (i);                                                                       \
-        if (r_ >= r_end) break;                                                                             \
-        if (r_ == 0) { /* workgroup 0 mirrors the cost row */                                               \
-            _Pragma("unroll") for (int j = 0; j < CPT; j++) a[i][j] = r0[j];                                \
-            break;                                                                                          \
-        }                                                                                                   \
-        if (r_ == pr_p) {                                                                                   \
-            _Pragma("unroll") for (int j = 0; j < CPT; j++) a[i][j] = p[j];                                 \
-            break;                                                                                          \
-        }                                                                                                   \
-        const double ki_ = kis[i];                                                                          \
-        if (nonzero16(ki_)) {                                                                               \
-            _Pragma("unroll") for (int j = 0; j < CPT; j++)                                                 \
-                if ((nzm >> j) & 1u) a[i][j] = eliminate(a[i][j], ki_, p[j]);                               \
-            if (has_pc_p) {                                                                                 \
-                const double nv_ = sm.nv[i];                                                                \
-                _Pragma("unroll") for (int j = 0; j < CPT; j++)                                             \
-                    if (pc_p == c0 + j) a[i][j] = nv_;                                                      \
-            }                                                                                               \
-        }                                                                                                   \
-    } while (0)
 
     if (tid == 0) {
 #pragma unroll
@@ -441,5 +442,380 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) JSLP_PIPE_UPDATE_ROW(i);
         }
     }
-#undef JSLP_PIPE_UPDATE_ROW
 }
+
+// maximum of a 64-bit key over the wave, result in every lane (four DPP exchanges inside the 16-lane rows + readlanes across them)
+template <int CTRL>
+__device__ __forceinline__ u64_t u64_dpp(u64_t x) {
+    const int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
+    return ((u64_t)(unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false) << 32) |
+           (u64_t)(unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u64_t u64_readlane(u64_t x, int l) {
+    return ((u64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l) << 32) |
+           (u64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l);
+}
+__device__ __forceinline__ u64_t u64_max(u64_t a, u64_t b) { return a > b ? a : b; }
+__device__ __forceinline__ u64_t u64_wave_max(u64_t x) {
+    x = u64_max(x, u64_dpp<0xB1>(x));
+    x = u64_max(x, u64_dpp<0x4E>(x));
+    x = u64_max(x, u64_dpp<0x141>(x));
+    x = u64_max(x, u64_dpp<0x140>(x));
+    return u64_max(u64_max(u64_readlane(x, 0), u64_readlane(x, 16)), u64_max(u64_readlane(x, 32), u64_readlane(x, 48)));
+}
+
+// ===================================================================================================================
+// Phase 1 (simplex.ts:25-98) in the same pipelined form.  Per pivot: leaving row = most negative RHS below -precision (first
+// index on ties), entering column = max -cost / coefficient over the pivot row's entries below -precision (first index on
+// ties), cycle check, pivot.  The summary a workgroup publishes needs only column 0 of its rows, whose master copy lives in
+// LDS: the eight lanes that bring it up to date when a pivot is decided (`rhs - k * p0`) fold the next summary in the same
+// breath, so pivot t+1's all-gather starts before pivot t's row update, which then overlaps it as in phase 2.  The entering
+// column is a workgroup-wide maximum: one DPP maximum per wave + one LDS atomic per wave on an order-preserving key, then an
+// atomicMin on the column among the lanes that hold that value.  Returns with R.end_code == 0 when phase 1 is over (feasible);
+// the tableau is whole again then.
+// ===================================================================================================================
+template <int THREADS, int CPT, int ROWS>
+__device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start) {
+    const Ctx& c = f.c;
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ld = c.ld, W = c.W;
+    const double precision = c.precision;
+    const int c0 = tid * CPT;
+    const bool colok = c0 < ld;
+    const int r_begin = b * f.rpb, r_end = min(f.H, r_begin + f.rpb);
+    double (&a)[ROWS][CPT] = R.a;
+    double (&r0)[CPT] = R.r0;
+    typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+    const int pub_stride = (int)((const char*)f.rows_pub[1] - (const char*)f.rows_pub[0]);
+    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + f.G * ld * 8, 0x00020000);
+    const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, 2 * JSLP_F_MAXG * JSLP_G16_STRIDE, 0x00020000);
+#ifdef JSLP_DEBUG_RESIDENT
+    u64_t (&rt_acc)[8] = R.rt_acc;
+    u64_t& rt_prev = R.rt_prev;
+#endif
+    double p[CPT];
+    unsigned nzm = 0;
+    int pr_p = 0, pc_p = 0, par_p = 0;
+    bool pend = false;
+#pragma unroll
+    for (int j = 0; j < CPT; j++) p[j] = 0.0;
+    int okslot = 0;
+    bool done = false;  // phase 1 is over: no row below -precision
+
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < ROWS; i++) sm.rhsb[i] = a[i][0];
+        sm.p_val = 0; sm.p_col = 0x7fffffff;
+    }
+    __syncthreads();
+
+    while (R.end_code == 0) {
+        const bool has_pc_p = pend && colok && pc_p >= c0 && pc_p < c0 + CPT;
+        if ((R.it1 - it1_start) + (R.it2 - it2_start) >= f.iters_cap) { R.end_code = 4; break; }
+        if (c.check_cycles && !(R.hist_n < JSLP_R_LHIST && R.hist_n < c.hist_cap)) { R.end_code = 8; break; }
+        const unsigned epoch = R.epoch;
+        const int par = epoch & 1;
+        const unsigned tag = epoch + 1;
+        if (f.test_abort_epoch >= 0 && (int)epoch == f.test_abort_epoch && b == f.G - 1) {
+            if (tid == 0) AG_STORE(f.abort_flag, 1u);
+            R.end_code = 5;
+            break;
+        }
+        RT_MARK(7);
+        // ---- S: my most negative RHS below -precision (simplex.ts:39-49): lanes 0..ROWS-1 of wave 0 on the LDS copy of column 0 ----
+        if (wv == 0) {
+            const int r = r_begin + lane;
+            u64_t key = KI_NONE_KEY;
+            if (lane < ROWS) {
+                const double v = sm.rhsb[lane];
+                if (r >= 1 && r < r_end && v < -precision) key = key_asc(v);  // unsigned order of the keys = numeric order: min = most negative
+            }
+            KI bk;
+            bk.k = key; bk.i = key != KI_NONE_KEY ? r : 0x7fffffff; bk.pad = 0;
+            bk = ki_min(bk, ki_dpp<0xB1>(bk));
+            bk = ki_min(bk, ki_dpp<0x4E>(bk));
+            bk = ki_min(bk, ki_dpp<0x141>(bk));
+            bk = ki_min(bk, ki_dpp<0x140>(bk));
+            bk = ki_readlane(bk, 0);
+            if (lane == 0) {
+                const bool have = bk.k != KI_NONE_KEY;
+                const int row = have ? bk.i : 0;
+                const u64_t qb = have ? bk.k : 0ull;
+                v4u_t g;
+                g.x = (unsigned)qb;
+                g.y = tag;
+                g.z = (unsigned)(qb >> 32);
+                g.w = ((tag & 0xffffu) << 16) | (unsigned)row;
+                __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_g16, (par * JSLP_F_MAXG + b) * JSLP_G16_STRIDE, 0, 16);  // aux 16 = sc1
+                sm.pubrow = row;
+            }
+        }
+        __syncthreads();
+        const int pubrow = sm.pubrow;
+        RT_MARK(0);
+        // ---- U + P: the pending pivot's row update, the candidate row published from inside the pass ----------------------------
+        bool swept = true;
+        const bool poller = tid < JSLP_F_MAXG;
+        const bool used = tid < f.G;
+        v4u_t g;
+        g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;
+        const int goff = (par * JSLP_F_MAXG + tid) * JSLP_G16_STRIDE;
+#pragma unroll
+        for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
+            double kis[ROWS];
+#pragma unroll
+            for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) kis[i] = sm.colb[par_p][i];
+#pragma unroll
+            for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) {
+                if (pend) JSLP_PIPE_UPDATE_ROW(i);
+                if (pubrow != 0 && r_begin + i == pubrow && colok) {
+                    const int off = par * pub_stride + (b * ld + c0) * 8;
+#pragma unroll
+                    for (int j = 0; j < CPT; j += 2) {
+                        if (c0 + j >= ld) continue;
+                        const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
+                        v4u_t v;
+                        v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, 16);
+                    }
+                }
+            }
+        }
+        pend = false;
+        RT_MARK(2);
+        // ---- C: gather ----------------------------------------------------------------------------------------------------
+        if (poller) {
+            unsigned spins = 0;
+            for (;;) {
+                if (used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
+                const bool ok = g.y == tag && (g.w >> 16) == (tag & 0xffffu);
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { swept = false; break; }
+                if (spins > f.spin_limit) { if (lane == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
+            }
+            const int row = (int)(g.w & 0x7fffu);
+            KI x;
+            x.k = row != 0 ? ((u64_t)g.x | ((u64_t)g.z << 32)) : KI_NONE_KEY;
+            x.i = row != 0 ? row : 0x7fffffff;
+            x.pad = 0;
+            x = ki_wave_min(x);
+            if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; }
+        }
+        RT_MARK(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int all_swept = __syncthreads_and(swept ? 1 : 0);
+        if (!all_swept) { R.end_code = 5; break; }
+        if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);
+        RT_MARK(3);
+        // ---- D ---------------------------------------------------------------------------------------------------------------
+        int pr = 0;
+        {
+            u64_t wk = sm.part_k[0];
+            int wr = sm.part_r[0];
+#pragma unroll
+            for (int i = 1; i < JSLP_F_MAXG / 64; i++) {
+                const u64_t k2 = sm.part_k[i];
+                const int r2 = sm.part_r[i];
+                const bool take = r2 != 0 && (wr == 0 || k2 < wk || (k2 == wk && r2 < wr));
+                wk = take ? k2 : wk;
+                wr = take ? r2 : wr;
+            }
+            pr = wr;
+        }
+        if (pr == 0) { done = true; break; }  // no violated row: feasible (simplex.ts:51-54); uniform
+        // ---- E: the pivot row (= the winner's candidate row) -------------------------------------------------------------------
+        const int bw = pr / f.rpb;
+        const int off_in = par * pub_stride + (bw * ld + c0) * 8;
+        double pv[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; j++) pv[j] = 0.0;
+        for (;;) {
+            u64_t flag = 0;
+            if (tid == 0) flag = AG_LOAD(f.rowflag[par] + bw);
+            if (colok) {
+#pragma unroll
+                for (int j = 0; j < CPT; j += 2) {
+                    if (c0 + j >= ld) continue;
+                    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + j * 8, 0, 16);
+                    pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
+                    pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
+                }
+            }
+            if (tid == 0) {
+                int ok = 1;
+                if ((unsigned)flag != tag) {
+                    unsigned spins = 0;
+                    ok = 2;
+                    while ((unsigned)AG_LOAD(f.rowflag[par] + bw) != tag) {
+                        __builtin_amdgcn_s_sleep(1);
+                        ++spins;
+                        if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
+                        if (spins > f.spin_limit) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+                    }
+                }
+                sm.okx[okslot] = ok;
+            }
+            __syncthreads();
+            const int okv = sm.okx[okslot];
+            okslot ^= 1;
+            if (okv == 2) continue;
+            if (okv == 0) R.end_code = 5;
+            break;
+        }
+        if (R.end_code == 5) break;
+        RT_MARK(4);
+        // ---- E1: entering column = max -cost / coefficient over coefficient < -precision, first index on ties (simplex.ts:56-71):
+        //      my best, the wave's maximum (DPP), one LDS atomic per wave; then the first column among the lanes holding that value -----
+        double bq = -INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            const int col = c0 + j;
+            const double coef = pv[j];
+            if (col >= 1 && col < W && coef < -precision) {
+                const double quo = -r0[j] / coef;
+                const bool take = bi == 0 || bq < quo;  // (my columns ascend: ties keep the earlier one)
+                bq = take ? quo : bq;
+                bi = take ? col : bi;
+            }
+        }
+        const u64_t qkey = bi != 0 ? key_asc(bq) : 0ull;  // (key_asc > 0 for every double; -0 folded into +0: simplex.ts compares them equal)
+        {
+            const u64_t wmax = u64_wave_max(qkey);
+            if (lane == 0 && wmax != 0ull) atomicMax(&sm.p_val, wmax);
+        }
+        __syncthreads();
+        const u64_t wkey = sm.p_val;
+        if (wkey == 0ull) { R.end_code = 7; break; }  // infeasible (simplex.ts:73-76); uniform
+        if (bi != 0 && qkey == wkey) atomicMin(&sm.p_col, bi);
+        __syncthreads();
+        const int pc = sm.p_col;
+        const bool has_pc = colok && pc >= c0 && pc < c0 + CPT;
+        if (has_pc) {  // the lane that holds the column: quot = A[pr, pc], k0 = cost[pc], and my rows' entries of the column
+#pragma unroll
+            for (int j = 0; j < CPT; j++)
+                if (pc == c0 + j) {
+                    sm.xq[0] = pv[j];
+                    sm.xq[1] = r0[j];
+#pragma unroll
+                    for (int i = 0; i < ROWS; i++) sm.colb[par][i] = a[i][j];
+                }
+        }
+        __syncthreads();
+        const double quot = sm.xq[0], k0 = sm.xq[1];
+        if (tid == 0) { sm.p_val = 0; sm.p_col = 0x7fffffff; }  // (everybody has read them; the next round is barriers away)
+        if (c.check_cycles) {  // simplex.ts:78-93 by every workgroup, on its own LDS history
+            if (tid == 0) {
+                const int2 pair = make_int2(sm.lvibr[pr], sm.lvibc[pc]);
+                sm.lhist[R.hist_n] = pair;
+                if (b == 0) c.hist[R.hist_n] = pair;
+            }
+            __syncthreads();
+            R.hist_n += 1;
+            if (suffix_is_square(sm.lhist, R.hist_n, sm.f.red)) { R.end_code = 3; break; }
+        }
+        // ---- N: normalised pivot row (simplex.ts:352-364); the tiny entries simplex.ts:381-383 zeroes as soon as ANY other row
+        //      is eliminated need a chip-wide answer in the rare pivot that has them -----------------------------------------------
+        nzm = 0;
+        int tiny = 0;
+        if (colok) {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const int col = c0 + j;
+                const double val = pv[j];
+                double v = 0.0;
+                if (col < W) {
+                    const bool innz = nonzero16(val);
+                    v = innz ? val / quot : 0.0;
+                    if (col == pc) v = 1.0 / quot;
+                    if (innz && !nonzero16(v) && v != 0.0) tiny |= 1 << j;
+                }
+                p[j] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) p[j] = 0.0;
+        }
+        if (__syncthreads_or(tiny)) {
+            int local_any = 0;
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) {
+                const int r = r_begin + i;
+                if (r < r_end && r != pr && nonzero16(sm.colb[par][i])) local_any = 1;
+            }
+            if (b == 0 && nonzero16(k0)) local_any = 1;  // (row 0, the cost row, counts: simplex.ts:367 runs r from 0)
+            const int gany = global_or(f, par, tag, local_any, sm);
+            if (gany < 0) { R.end_code = 5; break; }
+            if (gany != 0) {
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if (tiny & (1 << j)) p[j] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; j++) nzm |= nonzero16(p[j]) ? (1u << j) : 0u;
+        // column 0 of my rows after this pivot, and the pivot column's own new entries: lanes 0..ROWS-1 of wave 0 (the same
+        // lanes fold the next summary out of it at the top of the loop: no barrier in between)
+        if (wv == 0) {
+            const double p0 = readlane_f64(p[0], 0);
+            const unsigned nz0 = (unsigned)__builtin_amdgcn_readfirstlane((int)nzm) & 1u;
+            if (lane < ROWS) {
+                const int r = r_begin + lane;
+                const double ki = sm.colb[par][lane];
+                double v = sm.rhsb[lane];
+                if (r == pr) v = p0;
+                else if (r != 0 && r < r_end && nonzero16(ki) && nz0) v = eliminate(v, ki, p0);
+                sm.rhsb[lane] = v;
+                sm.nv[lane] = -ki / quot;
+            }
+        }
+        if (nonzero16(k0)) {
+#pragma unroll
+            for (int j = 0; j < CPT; j++)
+                if ((nzm >> j) & 1u) r0[j] = eliminate(r0[j], k0, p[j]);
+            if (has_pc) {
+                const double nv0 = -k0 / quot;
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if (pc == c0 + j) r0[j] = nv0;
+            }
+        }
+        if (tid == THREADS - 64) {
+            const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc];
+            sm.lvibr[pr] = entering;
+            sm.lvibc[pc] = leaving;
+            if (b == 0) {
+                c.vibr[pr] = entering;
+                c.vibc[pc] = leaving;
+                c.rbv[entering] = pr;
+                c.rbv[leaving] = -1;
+                c.cbv[entering] = -1;
+                c.cbv[leaving] = pc;
+                if (R.trace_n < c.trace_cap) c.trace[R.trace_n] = make_int2(pr, pc);
+            }
+        }
+        R.trace_n += 1;
+        R.it1 += 1;
+        R.epoch = epoch + 1;
+        pend = true; pr_p = pr; pc_p = pc; par_p = par;
+        RT_MARK(5);
+    }
+    if (pend && R.end_code != 5) {
+        const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;
+#pragma unroll
+        for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
+            double kis[ROWS];
+#pragma unroll
+            for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) kis[i] = sm.colb[par_p][i];
+#pragma unroll
+            for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) JSLP_PIPE_UPDATE_ROW(i);
+        }
+    }
+    if (done) {  // simplex.ts:14-23, 102: phase 2 starts with a fresh history
+        R.hist_n = 0;
+        R.epoch += 1;
+    }
+}
+#undef JSLP_PIPE_UPDATE_ROW
