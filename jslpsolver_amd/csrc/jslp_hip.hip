@@ -743,8 +743,14 @@ static bool fused_eligible(const jslp_engine* e) {
 //  dropped: 72.5 k against 105.7 k pivots/s on a 2001 x 2001 LP, 17.4 k on 4001 x 2001, r02_z: a lone wave per SIMD does not hide
 //  its own instruction latency)
 static int resident_geometry(const jslp_engine* e, int H) {
-    if (e->no_resident || e->force_path == 2 || e->n_opt > 0 || e->precision < 1e-15) return 0;  // (see k_pivot_fused for the precision condition)
+    if (e->no_resident || e->force_path == 2 || e->precision < 1e-15) return 0;  // (see k_pivot_fused for the precision condition)
     const int rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
+    if (e->n_opt > 0) {
+        // optional objectives: the lean build of the headline geometry keeps up to three rows of them in registers (round 3);
+        // everything else (unrestricted variables, taller / wider tableaus, more rows) runs them through the fused pipeline
+        const bool lean_ok = !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0) && e->n_unr == 0;
+        return (lean_ok && e->n_opt <= 3 && e->ld <= 2048 && rpb <= 8) ? 1 : 0;
+    }
     if (e->ld <= 2048 && rpb <= 8) return e->res_cpt == 4 ? 2 : 1;
     // The taller / wider geometries hold 64-72 MB of tableau in the 128 MB of vector registers and spill ~0.5 KB per lane to
     // scratch (560+ scratch loads in the pivot loop): measured at the end of round 2 they LOSE to the streaming kernels --
@@ -961,6 +967,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
         hipLaunchKernelGGL(k_begin, dim3(1), dim3(1), 0, s, e->s, 0, cap);
         // ---- register-resident path: the WHOLE simplex (phase 1 and phase 2) in one cooperative launch -------------
         bool resident_done = false;
+        bool handed_to_streaming = false;  // the lean kernel left mid-solve and the general build cannot continue (optional objectives)
         const int geometry = resident_geometry(e, H);
         // `it_before`: pivots the solve had done when the kernel is launched (0, or a phase 1 done by the fused pipeline)
         auto run_resident = [&](long long it_before) -> int {
@@ -1021,7 +1028,14 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
               : hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false>, dim3(rc.G), dim3(T), args, 0, s)
           resident_relaunch:
             switch (geometry) {
-                case 1: JSLP_RES_LAUNCH(1024, 2, 8); break;
+                case 1:
+                    if (e->n_opt > 0) {  // (resident_geometry admits optional objectives only here, and only for the lean build)
+                        if (!lean) break;  // a hand-over the general build cannot take: the fused pipeline continues (below)
+                        le = hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2, 8, false, true, true>, dim3(rc.G), dim3(1024), args, 0, s);
+                        break;
+                    }
+                    JSLP_RES_LAUNCH(1024, 2, 8);
+                    break;
                 case 2: JSLP_RES_LAUNCH(512, 4, 8); break;
                 case 3: JSLP_RES_LAUNCH(512, 4, 16); break;
                 case 4: JSLP_RES_LAUNCH(512, 6, 12); break;
@@ -1032,8 +1046,15 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                 HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
                 HIPC(hipStreamSynchronize(s));
                 if (e->h_state->err == ERR_NONE && e->h_state->status != ST_DONE) {
-                    lean = false;
                     e->resident_handovers += 1;
+                    if (e->n_opt > 0) {
+                        // optional objectives: the general build does not take them -- the streaming kernels continue from the state the
+                        // lean kernel left (tableau, maps and objective rows written back; status ST_RUNNING or ST_PHASE1_DONE)
+                        handed_to_streaming = true;
+                        if (e->timing) { float ms = 0; HIPC(hipEventRecord(k1, s)); HIPC(hipEventSynchronize(k1)); if (hipEventElapsedTime(&ms, k0, k1) == hipSuccess) e->upd_ms += ms; e->upd_launches += e->h_state->it1 + e->h_state->it2 - it_before; }
+                        return JSLP_OK;
+                    }
+                    lean = false;
                     HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * JSLP_R_SYNC_WORDS_GENERAL, s));  // the second launch's tags restart at 1
                     goto resident_relaunch;
                 }
@@ -1088,7 +1109,9 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
         if (!resident_done) {
         // ---- phase 1 through the fused pipeline (one launch per pivot; k_fused_p1), when the fused pipeline applies -----------
         bool p1_fused = false;
-        if (fused && fused_p1_on()) {
+        const bool phase1_over = handed_to_streaming && e->h_state->status == ST_PHASE1_DONE;  // (h_state is current in that case only)
+        if (phase1_over) p1_fused = true;
+        if (!phase1_over && fused && fused_p1_on()) {
             int r = ensure_fused(e);
             if (r) return r;
             r = ensure_fused_oo(e);

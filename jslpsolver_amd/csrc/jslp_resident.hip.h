@@ -114,6 +114,7 @@ struct RSmem {
     u64_t part_k[JSLP_F_MAXG / 64];
     int32_t part_r[JSLP_F_MAXG / 64], part_rdeg[JSLP_F_MAXG / 64];
     double xq2[2];
+    double ook[2][4];  // the optional objectives' entries of the pivot column, broadcast with quot (OPT builds of the lean kernel)
     // All-gather protocol: what only workgroup 0 knows in the gather-by-leader protocol lives in EVERY workgroup's LDS -- the
     // row / column maps (swapped at every pivot like the global ones), the unrestricted flag of every variable index, and the
     // cycle-check history (the first JSLP_R_LHIST entries; a longer solve continues with the leader protocol, whose check
@@ -253,6 +254,7 @@ template <int CPT, int ROWS>
 struct ResRegs {
     double a[ROWS][CPT];  // my rows: CPT adjacent columns per lane
     double r0[CPT];              // my copy of the cost row
+    double oo[3][CPT];           // my copies of the optional objective rows (lean OPT builds; JSLP_R_MAXOPT)
     double k0;
     unsigned unr;  // bit j: the variable of my column j is unrestricted (UNR builds)
     int neg;       // isReducedCostNegative of the entering column (phase 2, UNR builds)
@@ -873,9 +875,10 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
 
 // THREADS x CPT >= ld: <1024, 2> = lane pairs of columns, 4 waves per SIMD; <512, 4> = half the waves to synchronise,
 // twice the independent work per lane (and 256 VGPRs per lane).
-template <int THREADS, int CPT, int ROWS, bool UNR, bool LEAN = false>
+template <int THREADS, int CPT, int ROWS, bool UNR, bool LEAN = false, bool OPT = false>
 __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     static_assert(!(LEAN && UNR), "the lean kernel leaves unrestricted variables to the general one");
+    static_assert(!OPT || LEAN, "optional objectives: lean builds only");
     static_assert(ROWS <= JSLP_R_MAXROWS, "RSmem holds one entry per row of the workgroup");
     static_assert(sizeof(RSmem) <= 160 * 1024, "one workgroup per CU: all of the CU's LDS, no more");
     __shared__ RSmem sm;
@@ -902,6 +905,10 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
         if (c0 + j < ld) t = *reinterpret_cast<const double2*>(c.A + c0 + j);
         r0[j] = t.x; r0[j + 1] = t.y;
     }
+#pragma unroll
+    for (int o = 0; o < 3; o++)
+#pragma unroll
+        for (int j = 0; j < CPT; j++) R.oo[o][j] = (OPT && o < c.n_opt && c0 + j < ld) ? c.oo[(long long)o * ld + c0 + j] : 0.0;
 #pragma unroll
     for (int i = 0; i < ROWS; i++) {
         const int r = r_begin + i;
@@ -974,14 +981,14 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
         if (P2ONLY) {
             R.end_code = 5;  // never launched like this; if it were, the host rolls back and streams (like an aborted hand-off)
         } else {
-            if (LEAN) resident_phase1_pipe<THREADS, CPT, ROWS>(f, sm, R, it1_start, it2_start);
+            if (LEAN) resident_phase1_pipe<THREADS, CPT, ROWS, OPT>(f, sm, R, it1_start, it2_start);
             else resident_phase<1, THREADS, CPT, ROWS, UNR, LEAN>(f, sm, R, it1_start, it2_start, pb);
             if (R.end_code == 0) phase = 2;
         }
     }
     if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
         if (LEAN) {
-            resident_phase2_pipe<THREADS, CPT, ROWS>(f, sm, R, it1_start, it2_start, pb);  // (prices at the top of its loop)
+            resident_phase2_pipe<THREADS, CPT, ROWS, OPT>(f, sm, R, it1_start, it2_start, pb);  // (prices at the top of its loop)
         } else {
             R.pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg);
             if (R.pc == 0) R.end_code = 1;
@@ -1012,6 +1019,15 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
                     if (c0 + j < ld) *reinterpret_cast<double2*>(c.A + (long long)r * ld + c0 + j) = make_double2(a[i][j], a[i][j + 1]);
             }
         }
+    }
+    if (OPT && b == 0 && end_code != 5 && colok) {  // the optional objective rows go back with the tableau (workgroup 0's copies: all are equal)
+#pragma unroll
+        for (int o = 0; o < 3; o++)
+            if (o < c.n_opt) {
+#pragma unroll
+                for (int j = 0; j < CPT; j++)
+                    if (c0 + j < ld) c.oo[(long long)o * ld + c0 + j] = R.oo[o][j];
+            }
     }
     if (b == 0 && tid == 0) {
         st->it1 = it1;

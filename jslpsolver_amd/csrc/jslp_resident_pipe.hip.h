@@ -55,6 +55,39 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane) {  // src
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+
+#define JSLP_R_MAXOPT 3  // optional objective rows the lean kernel keeps in registers (priorities "strong" / "medium" / "weak": model.ts:141-160)
+
+// simplex.ts:221-263 on the lanes' own copies: no column prices out on the main row -> the optional objectives break the tie, in
+// priority order, among the columns whose reduced cost is within +-precision on the main row and on every earlier objective.
+// Returns the entering column (0: none -> optimal).  A rare path (a generic three-barrier block reduction per objective).
+template <int CPT>
+__device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const double (&oo)[JSLP_R_MAXOPT][CPT], int c0, const Ctx& c, RSmem& sm) {
+    const double precision = c.precision;
+    for (int o = 0; o < c.n_opt && o < JSLP_R_MAXOPT; o++) {
+        Cand best; best.v = precision; best.i = 0; best.b = 0;
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            const int col = c0 + j;
+            if (col < 1 || col >= c.W) continue;
+            bool deferred = -precision < x[j] && x[j] < precision;
+#pragma unroll
+            for (int q = 0; q < JSLP_R_MAXOPT; q++) {
+                if (q > o || !deferred) break;
+                const double v = oo[q][j];
+                if (q < o) { deferred = -precision < v && v < precision; continue; }
+                if (-precision < v && v < precision) break;  // this objective does not price the column out either
+                const bool take = v > best.v;  // strict: my columns ascend, ties keep the earlier one (no unrestricted variables here)
+                best.v = take ? v : best.v;
+                best.i = take ? col : best.i;
+            }
+        }
+        const Cand e = block_reduce(best, PriceFirst(), sm.f.red);
+        if (e.i != 0) return e.i;
+    }
+    return 0;
+}
+
 // row i of mine <- pivot (pr_p, pc_p): exactly the general loop's step F for one row
 #define JSLP_PIPE_UPDATE_ROW(i)                                                                             \
     do {                                                                                                    \
@@ -80,7 +113,7 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane) {  // src
         }                                                                                                   \
     } while (0)
 
-template <int THREADS, int CPT, int ROWS>
+template <int THREADS, int CPT, int ROWS, bool OPT>
 __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start,
                                                      const int (&pb)[CPT]) {
     const Ctx& c = f.c;
@@ -138,6 +171,20 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         {
             int neg_unused = 0;
             pc = price_row_lds<CPT, false>(r0, c0, pb, c, sm, &k0, 0u, &neg_unused);
+        }
+        bool opt_enter = false;  // the entering column is named by an optional objective: its main cost is within +-precision
+        if (OPT && pc == 0 && c.n_opt > 0) {
+            pc = price_optional_regs<CPT>(r0, R.oo, c0, c, sm);
+            if (pc != 0) {
+                opt_enter = true;
+                if (colok && pc >= c0 && pc < c0 + CPT) {
+#pragma unroll
+                    for (int j = 0; j < CPT; j++)
+                        if (pc == c0 + j) sm.xq[0] = r0[j];
+                }
+                __syncthreads();
+                k0 = sm.xq[0];
+            }
         }
         if (pc == 0) { R.end_code = 1; break; }  // uniform: optimal (simplex.ts:265-269)
         RT_MARK(6);
@@ -319,6 +366,9 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
         for (int j = 0; j < CPT; j++) pv[j] = 0.0;
         double quot = 0.0;
+        double ook[JSLP_R_MAXOPT];  // the optional objectives' entries of column pc (OPT builds)
+#pragma unroll
+        for (int o = 0; o < JSLP_R_MAXOPT; o++) ook[o] = 0.0;
         for (;;) {
             u64_t flag = 0;
             if (tid == 0) flag = AG_LOAD(f.rowflag[par] + bw);
@@ -334,7 +384,13 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             if (has_pc) {
 #pragma unroll
                 for (int j = 0; j < CPT; j++)
-                    if (pc == c0 + j) sm.xq2[okslot] = pv[j];
+                    if (pc == c0 + j) {
+                        sm.xq2[okslot] = pv[j];
+                        if (OPT) {
+#pragma unroll
+                            for (int o = 0; o < JSLP_R_MAXOPT; o++) sm.ook[okslot][o] = R.oo[o][j];
+                        }
+                    }
             }
             if (tid == 0) {
                 int ok = 1;
@@ -354,6 +410,10 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             __syncthreads();
             const int okv = sm.okx[okslot];
             quot = sm.xq2[okslot];
+            if (OPT) {
+#pragma unroll
+                for (int o = 0; o < JSLP_R_MAXOPT; o++) ook[o] = sm.ook[okslot][o];
+            }
             okslot ^= 1;  // the next use writes the other words: one barrier per use
             if (okv == 2) continue;
             if (okv == 0) R.end_code = 5;
@@ -364,6 +424,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         // ---- N: normalised pivot row (simplex.ts:352-364; phase 2: some other row is always eliminated, so the tiny entries
         //         simplex.ts:381-383 zeroes are zero) -----------------------------------------------------------------------------
         nzm = 0;
+        int tiny = 0;
         if (colok) {
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
@@ -374,14 +435,47 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                     const bool innz = nonzero16(val);
                     v = innz ? val / quot : 0.0;
                     if (col == pc) v = 1.0 / quot;
-                    if (innz && !nonzero16(v) && v != 0.0) v = 0.0;
+                    if (innz && !nonzero16(v) && v != 0.0) {
+                        if (OPT && opt_enter) tiny |= 1 << j;  // (decided below)
+                        else v = 0.0;
+                    }
                 }
                 p[j] = v;
-                nzm |= nonzero16(v) ? (1u << j) : 0u;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < CPT; j++) p[j] = 0.0;
+        }
+        if (OPT && opt_enter) {
+            // an entering column named by an optional objective may have NO other row to eliminate (its main cost is ~0 too): the
+            // tiny entries are zeroed only if some other row has an entry in the column (simplex.ts:381-383) -- a chip-wide answer
+            if (__syncthreads_or(tiny)) {
+                int local_any = 0;
+#pragma unroll
+                for (int i = 0; i < ROWS; i++) {
+                    const int r = r_begin + i;
+                    if (r >= 1 && r < r_end && r != pr && nonzero16(sm.colb[par][i])) local_any = 1;
+                }
+                if (b == 0 && nonzero16(k0)) local_any = 1;  // (row 0, the cost row: simplex.ts:367 runs r from 0)
+                const int gany = global_or(f, par, tag, local_any, sm);
+                if (gany < 0) { R.end_code = 5; break; }
+                if (gany != 0) {
+#pragma unroll
+                    for (int j = 0; j < CPT; j++)
+                        if (tiny & (1 << j)) p[j] = 0.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; j++) nzm |= nonzero16(p[j]) ? (1u << j) : 0u;
+        if (OPT) {  // the optional objective rows (simplex.ts:394-412: exact `!== 0` tests, on the FINAL pivot row), every lane its columns
+#pragma unroll
+            for (int o = 0; o < JSLP_R_MAXOPT; o++)
+                if (o < c.n_opt) {
+#pragma unroll
+                    for (int j = 0; j < CPT; j++)
+                        if (c0 + j < W) R.oo[o][j] = oo_cell_after(R.oo[o][j], ook[o], c0 + j, pc, quot, p[j]);
+                }
         }
         // the pivot column's own new entries (-k / quot, simplex.ts:386) and column 0 of my rows after this pivot (sm.rhsb is
         // the ratio test's copy of that column: it receives what the update pass will give a[i][0]): lanes 0..ROWS-1 of wave 0
@@ -474,7 +568,7 @@ __device__ __forceinline__ u64_t u64_wave_max(u64_t x) {
 // atomicMin on the column among the lanes that hold that value.  Returns with R.end_code == 0 when phase 1 is over (feasible);
 // the tableau is whole again then.
 // ===================================================================================================================
-template <int THREADS, int CPT, int ROWS>
+template <int THREADS, int CPT, int ROWS, bool OPT>
 __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start) {
     const Ctx& c = f.c;
     const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -701,10 +795,17 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                     sm.xq[1] = r0[j];
 #pragma unroll
                     for (int i = 0; i < ROWS; i++) sm.colb[par][i] = a[i][j];
+                    if (OPT) {
+#pragma unroll
+                        for (int o = 0; o < JSLP_R_MAXOPT; o++) sm.ook[0][o] = R.oo[o][j];
+                    }
                 }
         }
         __syncthreads();
         const double quot = sm.xq[0], k0 = sm.xq[1];
+        double ook[JSLP_R_MAXOPT];
+#pragma unroll
+        for (int o = 0; o < JSLP_R_MAXOPT; o++) ook[o] = OPT ? sm.ook[0][o] : 0.0;
         if (tid == 0) { sm.p_val = 0; sm.p_col = 0x7fffffff; }  // (everybody has read them; the next round is barriers away)
         if (c.check_cycles) {  // simplex.ts:78-93 by every workgroup, on its own LDS history
             if (tid == 0) {
@@ -756,6 +857,15 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         }
 #pragma unroll
         for (int j = 0; j < CPT; j++) nzm |= nonzero16(p[j]) ? (1u << j) : 0u;
+        if (OPT) {  // the optional objective rows follow every pivot (simplex.ts:394-412)
+#pragma unroll
+            for (int o = 0; o < JSLP_R_MAXOPT; o++)
+                if (o < c.n_opt) {
+#pragma unroll
+                    for (int j = 0; j < CPT; j++)
+                        if (c0 + j < W) R.oo[o][j] = oo_cell_after(R.oo[o][j], ook[o], c0 + j, pc, quot, p[j]);
+                }
+        }
         // column 0 of my rows after this pivot, and the pivot column's own new entries: lanes 0..ROWS-1 of wave 0 (the same
         // lanes fold the next summary out of it at the top of the loop: no barrier in between)
         if (wv == 0) {

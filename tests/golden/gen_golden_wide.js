@@ -26,11 +26,28 @@ function unrestrictedRA(n, m, k, seed) {
     return model;
 }
 
+// generateResourceAllocation with SOFT constraints: the first k resources are relaxed (`priority` strong / medium / weak in turn,
+// weight 1: src/model.ts:295-331 gives each a relaxation variable whose cost lives in that priority's optional objective row,
+// tableau.ts:278-290) and their limits halved so that the relaxations matter: three optional objective rows that break
+// pricing ties once the main row is optimal (simplex.ts:221-263) and are updated by every pivot (:394-412)
+function softRA(n, m, k, seed) {
+    const model = gen.generateResourceAllocation({ seed, numVariables: n, numConstraints: m, density: 1.0 });
+    const prio = ["strong", "medium", "weak"];
+    for (let i = 0; i < k; i++) {
+        const c = model.constraints["resource" + i];
+        c.max = Math.floor(c.max / 2);
+        c.priority = prio[i % 3];
+        c.weight = 1;
+    }
+    return model;
+}
+
 const cases = [
     { name: "unrestricted_RA_300x250_k20", build: () => unrestrictedRA(300, 250, 20, 12345), exit: false, meta: { kind: "unrestricted", n: 300, m: 250, k: 20 } },
     { name: "unrestricted_RA_1000x950_k50", build: () => unrestrictedRA(1000, 950, 50, 12345), exit: false, meta: { kind: "unrestricted", n: 1000, m: 950, k: 50 } },
     { name: "unrestricted_RA_2000x3950_k50", build: () => unrestrictedRA(2000, 3950, 50, 12345), exit: false, meta: { kind: "unrestricted", n: 2000, m: 3950, k: 50 } },
     { name: "cyclecheck_RA_2000x2000", build: () => gen.generateResourceAllocation({ seed: 12345, numVariables: 2000, numConstraints: 2000, density: 1.0 }), exit: true, meta: { kind: "ra", n: 2000, m: 2000 } },
+    { name: "soft_RA_400x400_k30", build: () => softRA(400, 400, 30, 12345), exit: false, keepModel: true, meta: { kind: "soft", n: 400, m: 400, k: 30 } },
     // (generateRandomLP 3000 x 3000 was tried here: the reference does not finish it in hours, with or without its cycle check)
     { name: "wide_RA_3000x3000", build: () => gen.generateResourceAllocation({ seed: 12345, numVariables: 3000, numConstraints: 3000, density: 1.0 }), exit: false, meta: { kind: "ra", n: 3000, m: 3000 } },
 ];
@@ -39,13 +56,15 @@ for (const c of cases) {
     if (!c.name.includes(filter)) continue;
     const model = c.build();
     if (!c.exit) model.options = { exitOnCycles: false };
-    const out = run(model, true, true);
+    const out = run(model, true, !c.keepModel);
     out.model = null;
     out.meta = c.meta;
     out.exitOnCycles = c.exit;
-    out.tableau.rows = out.tableau.cols = out.tableau.vals = null;
+    if (!c.keepModel) {  // (rebuilt at test time by jslpsolver_amd.generators; the soft instance keeps its tableau dump instead)
+        out.tableau.rows = out.tableau.cols = out.tableau.vals = null;
+        out.final.rhs = null;
+    }
     out.tableau.variableIds = null;
-    out.final.rhs = null;
     write(path.join(__dirname, "wide"), c.name, out);
     console.log(c.name, out.tableau.height + "x" + out.tableau.width, out.nPivots, out.pivotDigest, out.final.feasible, out.final.bounded,
         out.result.result, out.refWallMs.toFixed(0) + "ms");

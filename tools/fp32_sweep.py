@@ -39,8 +39,8 @@ def main(out_path=None):
              ("Monster_II root LP (config 4)",) + fixture_tableau("Monster_II")]
     m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, 500, 500)
     cases.append(("dense resource allocation 500x500 (config 3a generator)", m, vibr, vibc, []))
-    lines = ["| model | tolerance | fp64: outcome / pivots / objective | fp32: outcome / pivots / objective | fp32 objective rel. error vs fp64@1e-8 | same final basis | device ms fp64 / fp32 |",
-             "|---|---|---|---|---|---|---|"]
+    lines = ["| model | tolerance | fp64: outcome / pivots / objective | fp32: outcome / pivots / objective | fp32 objective rel. error vs fp64@1e-8 | same final basis | device ms fp64 / fp32 (both through k_select + k_update) | fp64 through the engine's DEFAULT path: device ms (path) |",
+             "|---|---|---|---|---|---|---|---|"]
     for label, matrix, vibr, vibc, unr in cases:
         ref = Tableau(matrix, vibr, vibc, unr, precision=1e-8, lib=lib)
         r_ref = ref.simplex(check_cycles=False)
@@ -53,11 +53,22 @@ def main(out_path=None):
             _, _, ms64 = t.get_timing()
             rhs64, rows64 = t.read_rhs()
             t.close()
+            # the same solve the way the engine runs it without knobs (register-resident / one LDS workgroup / fused): what an
+            # fp32 variant would have to beat, not the select + update pair
+            forced = os.environ.pop("JSLP_FORCE_PATH", None)
+            td = Tableau(matrix, vibr, vibc, unr, precision=tol, lib=lib)
+            td.set_timing(True)
+            td.simplex(check_cycles=False)
+            _, _, msd = td.get_timing()
+            pathd = td.last_path()
+            td.close()
+            if forced is not None:
+                os.environ["JSLP_FORCE_PATH"] = forced
             err = abs(r32.obj_cell - r_ref.obj_cell) / max(1.0, abs(r_ref.obj_cell))
-            lines.append("| %s | %.0e | %s / %d / %.9g | %s / %d / %.9g | %.2e | %s | %.1f / %.1f |" % (
+            lines.append("| %s | %.0e | %s / %d / %.9g | %s / %d / %.9g | %.2e | %s | %.1f / %.1f | %.2f (%s) |" % (
                 label, tol, flags(r64), r64.pivots_phase1 + max(r64.pivots_phase2, 0), r64.obj_cell,
                 flags(r32), r32.pivots_phase1 + max(r32.pivots_phase2, 0), r32.obj_cell, err,
-                "yes" if np.array_equal(rows32, rows64) else "no", ms64, ms32))
+                "yes" if np.array_equal(rows32, rows64) else "no", ms64, ms32, msd, pathd))
     text = "\n".join(lines) + "\n"
     print(text)
     if out_path:
