@@ -160,6 +160,23 @@ int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, const int32_
                                    int32_t* out_stride);
 
 /*
+ * Outcomes left where they were computed (the one-process-per-GPU path, jslpsolver_amd/sharding.py: the exchange step of a batch
+ * sharded over ranks is an RCCL all-gather, whose input must be device memory -- SURVEY.md 8e; replaces the pinned-host ->
+ * device bounce of that path).  relax_batch_device = jslp_engine_relax_batch whose per-node outcome -- a raw state record of
+ * jslp_engine_state_record_bytes() bytes, the RHS column and the row map (row_stride entries per node, row_stride >= the row
+ * capacity; a multiple of 4 keeps the kernels on their 16-byte stores) -- is written into memory of the ENGINE'S DEVICE that the
+ * caller owns; nothing crosses PCIe.  results_from_states turns records (in host memory; this rank's or, after the exchange,
+ * any rank's) into the result structs of the other entry points; a record carries no pivot history, so cycle_start /
+ * cycle_length come back 0 (flags and cycle_phase are exact).  The oracle library implements the same three entry points over
+ * plain host memory.
+ */
+int32_t jslp_engine_state_record_bytes(void);
+int jslp_engine_relax_batch_device(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                   const int32_t* var_index, const double* value, int check_cycles, void* d_states,
+                                   double* d_rhs, int32_t* d_rows, int32_t row_stride);
+int jslp_engine_results_from_states(jslp_engine* e, const void* states, int32_t n_nodes, jslp_simplex_result* out);
+
+/*
  * MIR cuts (options.useMIRCuts, src/model.ts:354-356).  set_integer_variables hands over model.integerVariables' indexes:
  * the `variable.isInteger` test of addLowerBoundMIRCut (src/tableau/cutting-strategies.ts:82-85, 120-121); call after
  * upload().  apply_mir_cuts = Tableau.applyMIRCuts() (cutting-strategies.ts:199-212): scans rows 1..height-1 in order

@@ -78,6 +78,10 @@ SYMBOLS = {
                                           _P(SimplexResult), _f64p, _i32p, C.c_int32]),
     "jslp_engine_relax_batch_pinned": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p, _i32p, _f64p, C.c_int,
                                                  _P(SimplexResult), _P(_f64p), _P(_i32p), _i32p]),
+    "jslp_engine_state_record_bytes": (C.c_int32, []),
+    "jslp_engine_relax_batch_device": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p, _i32p, _f64p, C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_int32]),
+    "jslp_engine_results_from_states": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _P(SimplexResult)]),
     "jslp_engine_set_integer_variables": (C.c_int, [C.c_void_p, _i32p, C.c_int32]),
     "jslp_engine_apply_mir_cuts": (C.c_int, [C.c_void_p, _i32p]),
     "jslp_engine_mir_round": (C.c_int, [C.c_void_p, C.c_int, _i32p, _P(SimplexResult), _f64p, _i32p]),

@@ -86,6 +86,8 @@ struct jslp_engine {
     int host_matrix_out = 0;  // the host holds a pointer into h_up
     // the one-call-only redirection of the read-back (device pool: every member copies straight into the pool's buffer)
     DevState* ext_states = nullptr; double* ext_rhs = nullptr; int32_t* ext_rows = nullptr;
+    // jslp_engine_relax_batch_device: the caller's DEVICE buffers take the outcomes (no host copy at all)
+    DevState* dev_states = nullptr; double* dev_rhs = nullptr; int32_t* dev_rows = nullptr; int32_t dev_stride = 0;
     // compact read-back (jslp_engine_relax_watched)
     int32_t* d_watch = nullptr; int32_t n_watch = 0;
     // work counters
@@ -1696,13 +1698,14 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
                             const int32_t* var_index, const double* value, int check_cycles, jslp_simplex_result* out,
                             double* rhs, int32_t* var_index_by_row, int32_t out_stride, int pinned, int want_rhs,
                             int want_rows, int checkpoint = -1, int compact = 0) {
-    if (!e || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "relax_batch: null pointer");
+    const bool dev_out = e && e->dev_states != nullptr;  // outcomes stay on the device (jslp_engine_relax_batch_device)
+    if (!e || n_nodes < 0 || !cut_offsets || (!out && !dev_out)) return fail(JSLP_ERR_ARG, "relax_batch: null pointer");
     if (!e->uploaded) return fail(JSLP_ERR_STATE, "relax before upload");
     if (compact && (e->n_watch <= 0 || e->n_watch > e->cap_rows))
         return fail(JSLP_ERR_ARG, "relax_watched: after set_watched_variables (at most row_capacity of them)");
     // gather mode: >= 0 = the whole RHS column / row map with this row stride; < 0 = the watched variables only
-    const int g_stride = compact ? -e->n_watch : (int)out_stride_of(e);
-    const size_t row_stride = compact ? (size_t)e->n_watch : out_stride_of(e);  // entries per node in the read-back buffers
+    const int g_stride = compact ? -e->n_watch : (dev_out ? (int)e->dev_stride : (int)out_stride_of(e));
+    const size_t row_stride = compact ? (size_t)e->n_watch : (dev_out ? (size_t)e->dev_stride : out_stride_of(e));  // entries per node in the read-back buffers
     if (checkpoint >= 0) {
         int rc0 = checkpoint_check(e, checkpoint, "relax_from");
         if (rc0) return rc0;
@@ -1719,7 +1722,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     int rc;
     // ---- ONE child of the saved root, slot 0 already in sync with the snapshot: one launch, one synchronisation ----------
     if (n_nodes == 1 && checkpoint < 0 && e->has_save && e->slot0_synced && !e->timing && e->force_path <= 1 &&
-        e->one_launch_nodes && cells <= wg_cells_child() && !e->ext_states) {
+        e->one_launch_nodes && cells <= wg_cells_child() && !e->ext_states && !dev_out) {
         rc = upload_cuts(e, 1, cut_offsets, type, var_index, value, false);
         if (rc) return rc;
         rc = ensure_out(e, 1);
@@ -1817,6 +1820,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     // the pinned host buffer itself - the stores cross PCIe while the other workgroups compute
     DevState* o_states = e->d_states; double* o_rhs = e->d_rhs; int32_t* o_rows = e->d_rows;
     bool zc = zero_copy() != 0;
+    if (dev_out) { o_states = e->dev_states; o_rhs = e->dev_rhs; o_rows = e->dev_rows; zc = false; }
     if (zc) {
         void *ps = nullptr, *pr = nullptr, *pw = nullptr;
         if (hipHostGetDevicePointer(&ps, e->h_states, 0) == hipSuccess && hipHostGetDevicePointer(&pr, e->h_rhs, 0) == hipSuccess &&
@@ -1839,7 +1843,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
             hipLaunchKernelGGL((k_node_queue<512, false>), dim3(group), dim3(512), lds, s, e->s, sn, cu, (int)n_nodes, order, e->d_queue, check_cycles,
                                cap, (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states, g_stride);
         HIPC(hipGetLastError());
-        if (!zc) {
+        if (!zc && !dev_out) {
             HIPC(hipMemcpyAsync(e->h_states, e->d_states, sizeof(DevState) * (size_t)n_nodes, hipMemcpyDeviceToHost, s));
             if (want_rhs) HIPC(hipMemcpyAsync(e->h_rhs, e->d_rhs, sizeof(double) * (size_t)n_nodes * row_stride, hipMemcpyDeviceToHost, s));
             if (want_rows) HIPC(hipMemcpyAsync(e->h_rows, e->d_rows, sizeof(int32_t) * (size_t)n_nodes * row_stride, hipMemcpyDeviceToHost, s));
@@ -1907,7 +1911,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         }  // !one_launch
         // this group's outcomes cross PCIe on the copy stream while the next group computes (the three regions of the
         // read-back buffer are laid out for all nodes, so a group is one contiguous slice of each)
-        if (zc) continue;
+        if (zc || dev_out) continue;
         HIPC(hipEventRecord(e->ev_group, s));
         HIPC(hipStreamWaitEvent(e->copy_stream, e->ev_group, 0));
         HIPC(hipMemcpyAsync(e->h_states + first, e->d_states + first, sizeof(DevState) * (size_t)g, hipMemcpyDeviceToHost, e->copy_stream));
@@ -1926,6 +1930,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         if (hipEventElapsedTime(&ms, e->ev_begin, e->ev_end) == hipSuccess) e->total_ms += ms;
     }
     if (e->counting) e->wc.cut_rows += cut_offsets[n_nodes];
+    if (dev_out) return JSLP_OK;  // the records are converted (and their error fields checked) by jslp_engine_results_from_states
     for (int i = 0; i < n_nodes; i++) {
         DevState st = e->h_states[i];
         rc = state_error(st);
@@ -1960,6 +1965,38 @@ extern "C" int jslp_engine_relax_batch(jslp_engine* e, int32_t n_nodes, const in
                                        int32_t out_stride) {
     return relax_batch_impl(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, rhs, var_index_by_row,
                             out_stride, 0, rhs != nullptr, var_index_by_row != nullptr);
+}
+
+// ---- outcomes left in DEVICE memory of the caller (the N > 1 process path: they are the input of an RCCL all-gather) -------------
+extern "C" int32_t jslp_engine_state_record_bytes(void) { return (int32_t)sizeof(DevState); }
+
+extern "C" int jslp_engine_relax_batch_device(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                              const int32_t* var_index, const double* value, int check_cycles, void* d_states,
+                                              double* d_rhs, int32_t* d_rows, int32_t row_stride) {
+    if (!e || !d_states || !d_rhs || !d_rows) return fail(JSLP_ERR_ARG, "relax_batch_device: null pointer");
+    if (row_stride < e->cap_rows) return fail(JSLP_ERR_ARG, "relax_batch_device: row_stride < row capacity");
+    e->dev_states = static_cast<DevState*>(d_states); e->dev_rhs = d_rhs; e->dev_rows = d_rows; e->dev_stride = row_stride;
+    const int rc = relax_batch_impl(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, nullptr, nullptr, nullptr, 0, 1, 1, 1);
+    e->dev_states = nullptr; e->dev_rhs = nullptr; e->dev_rows = nullptr; e->dev_stride = 0;
+    return rc;
+}
+
+// `states`: n_nodes raw records in HOST memory (wherever they were evaluated: this rank's own or another rank's, after the
+// exchange) -> the result structs every other entry point returns.  A record carries no pivot history: the [start, length] detail of
+// a detected cycle is reported as 0 (the flags and the phase are exact).
+extern "C" int jslp_engine_results_from_states(jslp_engine* e, const void* states, int32_t n_nodes, jslp_simplex_result* out) {
+    if (!e || !states || !out || n_nodes < 0) return fail(JSLP_ERR_ARG, "results_from_states: bad arguments");
+    const DevState* st = static_cast<const DevState*>(states);
+    for (int32_t i = 0; i < n_nodes; i++) {
+        DevState rec = st[i];
+        int rc = state_error(rec);
+        if (rc) return rc;
+        rec.hist_n = 0;
+        double ev;
+        rc = fill_result(e, rec, 0, e->evaluation, &out[i], &ev);
+        if (rc) return rc;
+    }
+    return JSLP_OK;
 }
 
 extern "C" int jslp_engine_relax_batch_pinned(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets,

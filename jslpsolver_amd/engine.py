@@ -168,6 +168,27 @@ class Tableau:
         vibr = np.ctypeslib.as_array(p_rows, shape=shape) if want_rows else None
         return out, rhs, vibr
 
+    # ---- outcomes left in device memory (the one-process-per-GPU path: sharding.py) ----------------------------------
+    def state_record_bytes(self):
+        return int(self.lib.jslp_engine_state_record_bytes())
+
+    def applyCutsBatchDevice(self, packed, check_cycles, states_ptr, rhs_ptr, rows_ptr, row_stride):
+        """jslp_engine_relax_batch_device: raw addresses of memory on the engine's device (torch tensors' data_ptr(); plain host
+        memory for the oracle library) receive the per-node state records, RHS columns and row maps; nothing is copied back"""
+        n_nodes, offs, t, v, x = packed
+        self.lib.check(self.lib.jslp_engine_relax_batch_device(
+            self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)),
+            _capi.C.c_void_p(states_ptr), _capi.C.c_void_p(rhs_ptr), _capi.C.c_void_p(rows_ptr), int(row_stride)),
+            "jslp_engine_relax_batch_device")
+
+    def results_from_states(self, states_u8, n_nodes):
+        """raw state records (host bytes: this rank's or, after the exchange, another rank's) -> SimplexResult array"""
+        out = (SimplexResult * max(n_nodes, 1))()
+        buf = np.ascontiguousarray(states_u8, dtype=np.uint8)
+        self.lib.check(self.lib.jslp_engine_results_from_states(self._h, _capi.C.c_void_p(buf.ctypes.data), int(n_nodes), out),
+                       "jslp_engine_results_from_states")
+        return out
+
     # ---- compact read-back, work counters, pinned host build --------------------------------------------------
     def set_watched_variables(self, var_indexes):
         """the variable indexes the branch-and-bound tree reads between relaxations (the integer variables)"""

@@ -112,11 +112,91 @@ def pack_local(results, rhs, rows, n_mine, per, stride):
     return local
 
 
+class ShardedOutcomesDevice:
+    """every node's outcome after the all-gather of the DEVICE-resident payloads: rank r's block is one byte vector
+    [per state records | per x stride doubles | per x stride int32], node i sits in rank (i % world)'s block at slot i // world"""
+
+    def __init__(self, blocks, n, world, per, stride, rec, tableau):
+        self.blocks, self.n, self.world, self.per, self.stride, self.rec = blocks, n, world, per, stride, rec  # blocks: [world, block_bytes] uint8
+        self.o_rhs = _align(per * rec)
+        self.o_rows = _align(self.o_rhs + per * stride * 8)
+        # result structs of ALL nodes from the raw records, rank by rank (one library call per rank)
+        self.results = []
+        for r in range(world):
+            k = len(range(r, n, world))
+            self.results.append(tableau.results_from_states(blocks[r, :k * rec], k) if k else None)
+
+    def __len__(self):
+        return self.n
+
+    def result(self, i):
+        return self.results[i % self.world][i // self.world]
+
+    def rhs(self, i, height):
+        o = self.o_rhs + (i // self.world) * self.stride * 8
+        return self.blocks[i % self.world, o:o + 8 * height].view(np.float64)
+
+    def rows(self, i, height):
+        o = self.o_rows + (i // self.world) * self.stride * 4
+        return self.blocks[i % self.world, o:o + 4 * height].view(np.int32)
+
+    def node(self, i):
+        r = self.result(i)
+        return _NodeEval(r, self.rhs(i, r.height).copy(), self.rows(i, r.height).copy())
+
+    def heights(self):
+        return np.array([self.result(i).height for i in range(self.n)], dtype=np.int32)
+
+
+def _align(x, a=64):
+    return (x + a - 1) // a * a
+
+
+def evaluate_nodes_sharded_device(tableau, cut_lists, check_cycles, group, packed_mine=None):
+    """evaluate_nodes_sharded without the host bounce: the engine leaves this rank's outcomes in a device tensor
+    (jslp_engine_relax_batch_device) that IS the all-gather's input; the gathered block crosses PCIe once.  With the gloo backend
+    (CPU tests: the oracle library's "device" memory is host memory) the same code runs on CPU tensors."""
+    import time
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = len(cut_lists)
+    stride = (tableau.row_capacity + 3) // 4 * 4  # 16-byte aligned node slices: the kernels' fast stores
+    rec = tableau.state_record_bytes()
+    per = max((n + world - 1) // world, 1)
+    o_rhs = _align(per * rec)
+    o_rows = _align(o_rhs + per * stride * 8)
+    block = _align(o_rows + per * stride * 4)
+    on_gpu = dist.get_backend(group) == "nccl"
+    local = torch.zeros(block, dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+    n_mine = len(range(rank, n, world))
+    if n_mine:
+        packed = packed_mine if packed_mine is not None else tableau.pack_cut_lists(shard(cut_lists, rank, world))
+        base = local.data_ptr()
+        tableau.applyCutsBatchDevice(packed, check_cycles, base, base + o_rhs, base + o_rows, stride)
+    t0 = time.perf_counter()
+    out = torch.empty((world, block), dtype=torch.uint8, device=local.device)
+    dist.all_gather_into_tensor(out.view(-1), local, group=group)
+    blocks = out.cpu().numpy() if out.is_cuda else out.numpy()
+    EXCHANGE_STATS["seconds"] += time.perf_counter() - t0
+    EXCHANGE_STATS["calls"] += 1
+    EXCHANGE_STATS["bytes"] += int(block)
+    return ShardedOutcomesDevice(blocks, n, world, per, stride, rec, tableau)
+
+
 def evaluate_nodes_sharded(tableau, cut_lists, check_cycles, group, packed_mine=None):
     """Every rank calls this with the same `cut_lists`; returns the outcomes of ALL nodes on every rank
     (ShardedOutcomes).  `packed_mine`: this rank's share already flattened by Tableau.pack_cut_lists."""
+    import os
     import torch.distributed as dist
 
+    # RCCL: outcomes stay on the device until they have been gathered (JSLP_SHARD_DEVICE_PATH=0 / 1 forces the choice: the
+    # CPU tests run both forms over gloo)
+    forced = os.environ.get("JSLP_SHARD_DEVICE_PATH")
+    if forced == "1" or (forced is None and dist.get_backend(group) == "nccl"):
+        return evaluate_nodes_sharded_device(tableau, cut_lists, check_cycles, group, packed_mine)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n = len(cut_lists)

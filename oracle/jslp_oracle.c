@@ -902,6 +902,23 @@ int jslp_engine_host_matrix(jslp_engine* e, double** matrix, int64_t* n_doubles)
     return JSLP_OK;
 }
 
+/* include/jslp_engine.h "outcomes left where they were computed": for this CPU stand-in device memory IS host memory and the raw
+   state record is the result struct itself */
+int32_t jslp_engine_state_record_bytes(void) { return (int32_t)sizeof(jslp_simplex_result); }
+int jslp_engine_relax_batch_device(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                   const int32_t* var_index, const double* value, int check_cycles, void* d_states,
+                                   double* d_rhs, int32_t* d_rows, int32_t row_stride) {
+    if (!e || !d_states || !d_rhs || !d_rows) return fail(JSLP_ERR_ARG, "relax_batch_device: null pointer");
+    return jslp_engine_relax_batch(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, (jslp_simplex_result*)d_states,
+                                   d_rhs, d_rows, row_stride);
+}
+int jslp_engine_results_from_states(jslp_engine* e, const void* states, int32_t n_nodes, jslp_simplex_result* out) {
+    if (!e || !states || !out || n_nodes < 0) return fail(JSLP_ERR_ARG, "results_from_states: bad arguments");
+    memcpy(out, states, sizeof(jslp_simplex_result) * (size_t)n_nodes);
+    for (int32_t i = 0; i < n_nodes; i++) { out[i].cycle_start = 0; out[i].cycle_length = 0; }
+    return JSLP_OK;
+}
+
 int jslp_engine_set_watched_variables(jslp_engine* e, const int32_t* var_indexes, int32_t n) {
     if (!e || !e->uploaded) return fail(JSLP_ERR_STATE, "set_watched_variables before upload");
     if (n < 0 || (n > 0 && !var_indexes)) return fail(JSLP_ERR_ARG, "set_watched_variables: bad arguments");

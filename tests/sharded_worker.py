@@ -48,12 +48,18 @@ def main():
     t.applyCuts([], check_cycles=True)
     t.save()
     nodes = [c["cuts"] or [] for c in calls[1:]]
-    out = evaluate_nodes_sharded(t, nodes, True, dist.group.WORLD)
-    ok = len(out) == len(nodes) and [int(h) for h in out.heights()] == [c["height"] for c in calls[1:]]
-    for ev, call in zip([out.node(i) for i in range(len(out))], calls[1:]):
-        ok = ok and bool(ev.res.feasible) == call["feasible"] and ev.res.height == call["height"]
-        ok = ok and G.sha_rhs(ev.rhs, ev.vibr) == call["rhsSha"]
-    report["cases"].append({"name": "Monster_II node batch", "ok": bool(ok)})
+    # both forms of the exchange step: host payload (gloo's default) and outcomes left in "device" memory until they are gathered
+    # (RCCL's default, jslp_engine_relax_batch_device; over gloo with CPU tensors -- the oracle's device memory is host memory)
+    for form in ("0", "1"):
+        os.environ["JSLP_SHARD_DEVICE_PATH"] = form
+        out = evaluate_nodes_sharded(t, nodes, True, dist.group.WORLD)
+        ok = len(out) == len(nodes) and [int(h) for h in out.heights()] == [c["height"] for c in calls[1:]]
+        ok = ok and type(out).__name__ == ("ShardedOutcomesDevice" if form == "1" else "ShardedOutcomes")
+        for ev, call in zip([out.node(i) for i in range(len(out))], calls[1:]):
+            ok = ok and bool(ev.res.feasible) == call["feasible"] and ev.res.height == call["height"]
+            ok = ok and G.sha_rhs(ev.rhs, ev.vibr) == call["rhsSha"]
+        report["cases"].append({"name": "Monster_II node batch, exchange form %s" % form, "ok": bool(ok)})
+    os.environ.pop("JSLP_SHARD_DEVICE_PATH", None)
     # 3. ragged batches: fewer nodes than ranks, a batch that does not divide by the world size, an empty batch (ranks without a
     #    node still take part in the exchange step with a padded, empty contribution)
     for n_take in (0, 1, max(world - 1, 1), world + 1):
