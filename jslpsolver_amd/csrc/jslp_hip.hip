@@ -710,7 +710,7 @@ static int iters_cap(const jslp_engine* e) {
 
 // dynamic LDS of the LDS-resident one-workgroup kernels (jslp_wglds.hip.h); 0 = use the generic kernels
 static size_t wglds_smem(const jslp_engine* e) {
-    if (!e->use_wglds || e->n_opt > 0) return 0;
+    if (!e->use_wglds) return 0;  // (optional objectives: round 3 -- their rows stay in the slot's global copy, jslp_wglds.hip.h)
     const size_t b = wglds_bytes(e->ld, e->cap_rows);
     return b <= WGLDS_MAX_BYTES ? b : 0;
 }
@@ -948,7 +948,9 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
     HIPC(hipEventRecord(e->ev_begin, s));
     if (use_wg_single(e)) {
         e->last_path = "workgroup";
-        if (const size_t lds = wglds_smem(e))
+        if (const size_t lds = wglds_smem(e); lds && e->s.n_opt > 0)  // optional objectives: a build of their own (jslp_wglds.hip.h)
+            hipLaunchKernelGGL((k_simplex_lds<JSLP_WG_THREADS, true>), dim3(1), dim3(JSLP_WG_THREADS), lds, s, e->s, 0, check_cycles, cap, (int)e->cap_rows);
+        else if (lds)
             hipLaunchKernelGGL((k_simplex_lds<JSLP_WG_THREADS>), dim3(1), dim3(JSLP_WG_THREADS), lds, s, e->s, 0, check_cycles, cap, (int)e->cap_rows);
         else
             hipLaunchKernelGGL((k_simplex_wg<JSLP_WG_THREADS, 4096>), dim3(1), dim3(JSLP_WG_THREADS), 0, s, e->s, 0, check_cycles, cap);
@@ -1741,7 +1743,10 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         HIPC(hipHostGetDevicePointer(&flag_dev, h_flag, 0));
         unsigned* d_flag = static_cast<unsigned*>(flag_dev);
         const unsigned seq = ++e->done_seq ? e->done_seq : ++e->done_seq;  // never 0 (the flag's initial value)
-        if (const size_t lds = wglds_smem(e))
+        if (const size_t lds = wglds_smem(e); lds && e->s.n_opt > 0)
+            hipLaunchKernelGGL((k_node_lds<JSLP_WG_THREADS, true>), dim3(1), dim3(JSLP_WG_THREADS), lds, s, e->s, sn, cu, 0, check_cycles,
+                               cap, (int)e->cap_rows, o_rhs, o_rows, o_state, compact ? g_stride : 0, 0, d_flag, seq);
+        else if (lds)
             hipLaunchKernelGGL((k_node_lds<JSLP_WG_THREADS>), dim3(1), dim3(JSLP_WG_THREADS), lds, s, e->s, sn, cu, 0, check_cycles,
                                cap, (int)e->cap_rows, o_rhs, o_rows, o_state, compact ? g_stride : 0, 0, d_flag, seq);
         else
@@ -1794,7 +1799,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     if (wg) {
         const long long max_slots = std::max<long long>(1, (16LL << 30) / (cells * 8));
         group = (int)std::min<long long>(std::min<long long>(n_nodes, group_max()), max_slots);
-        if (const size_t lds = wglds_smem(e); lds && node_queue() && wg_batch_threads() == 512 && n_nodes > 1) {
+        if (const size_t lds = wglds_smem(e); lds && node_queue() && wg_batch_threads() == 512 && n_nodes > 1 && e->s.n_opt == 0) {
             // the queue kernel wants exactly as many slots as the chip keeps workgroups resident
             if (e->queue_wgs == 0 || e->queue_wgs_lds != lds) {
                 int per_cu = 0, cus = 0;
@@ -1832,7 +1837,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         }
     }
     if (const size_t lds = wglds_smem(e); wg && lds && node_queue() && n_nodes > group && checkpoint < 0 && e->has_save && e->slot0_synced &&
-        group <= e->slots_synced && !e->timing && e->one_launch_nodes && wg_batch_threads() == 512) {
+        group <= e->slots_synced && !e->timing && e->one_launch_nodes && wg_batch_threads() == 512 && e->s.n_opt == 0) {
         Snapshot sn = root_snapshot(e);
         e->last_path = "workgroup";
         const int32_t* order = node_queue() == 2 ? e->d_cut_order : (const int32_t*)nullptr;
@@ -1862,7 +1867,11 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
             // by occupancy: the 1024-thread shape of the single-node path, one workgroup per CU
             static const int small_1024 = getenv("JSLP_SMALL_BATCH_1024") ? atoi(getenv("JSLP_SMALL_BATCH_1024")) : JSLP_SMALL_BATCH_1024_DEFAULT;
             const size_t lds = wglds_smem(e);
-            if (lds && g <= small_1024)
+            if (lds && e->s.n_opt > 0)  // optional objectives: the 1024-thread build only, whatever the batch size
+                hipLaunchKernelGGL((k_node_lds<1024, true>), dim3(g), dim3(1024), lds, s, e->s, sn, cu, first, check_cycles, cap,
+                                   (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states,
+                                   g_stride, first, (unsigned*)nullptr, 0u);
+            else if (lds && g <= small_1024)
                 hipLaunchKernelGGL((k_node_lds<1024>), dim3(g), dim3(1024), lds, s, e->s, sn, cu, first, check_cycles, cap,
                                    (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states,
                                    g_stride, first, (unsigned*)nullptr, 0u);
@@ -1883,9 +1892,12 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         if (wg) {
             e->last_path = "workgroup";
             // one node: the 1024-thread latency shape; a batch: smaller workgroups, more nodes in flight per CU
-            const int shape = g == 1 ? 1024 : wg_batch_threads();
             const size_t lds = wglds_smem(e);
-            if (lds && shape == 1024)
+            const bool opt = lds && e->s.n_opt > 0;
+            const int shape = (g == 1 || opt) ? 1024 : wg_batch_threads();
+            if (opt)
+                hipLaunchKernelGGL((k_simplex_lds<JSLP_WG_THREADS, true>), dim3(g), dim3(JSLP_WG_THREADS), lds, s, e->s, 0, check_cycles, cap, (int)e->cap_rows);
+            else if (lds && shape == 1024)
                 hipLaunchKernelGGL((k_simplex_lds<JSLP_WG_THREADS>), dim3(g), dim3(JSLP_WG_THREADS), lds, s, e->s, 0, check_cycles, cap, (int)e->cap_rows);
             else if (lds && shape == 512)
                 hipLaunchKernelGGL((k_simplex_lds<512>), dim3(g), dim3(512), lds, s, e->s, 0, check_cycles, cap, (int)e->cap_rows);

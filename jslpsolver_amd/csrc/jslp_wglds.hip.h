@@ -226,7 +226,9 @@ __device__ __forceinline__ void wglds_update_row(const Ctx& c, const WgLds& L, i
 #endif
 #define WGL_KP 2  // pivot-row values a thread keeps in registers across the cycle check (ld <= WGL_KP * threads)
 
-template <int UN>
+// OPT: the model has optional objectives (their rows stay in the slot's global copy); a build of its own so that the kernels of
+// every other model keep their register budget (the extra live values cost the 512-thread queue kernel 10 more VGPR spills)
+template <int UN, bool OPT = false>
 __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iters_cap) {
     WL_BEGIN(c.cnt);
     DevState* st = c.st;
@@ -383,10 +385,38 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
             if (ei != 0) { e.k = key_desc(ev); e.i = ei; }
             e = block_min_ki(e, sm, par);
             WL_MARK(5);
+            int opt_row = -1;  // >= 0: the entering column is named by that optional objective (simplex.ts:221-263)
+            for (int o = 0; OPT && e.k == KI_NONE_KEY && o < c.n_opt; o++) {
+                // no column prices out on the main row (nor on the earlier objectives): objective o breaks the tie among the columns
+                // whose reduced cost is within +-precision on all of them.  The objective rows live in the slot's global copy
+                // (n_opt x ld doubles, cache-resident): a rare path
+                double xv = precision;
+                int xi = 0;
+                for (int col = 1 + tid; col < W && tid < WGL_SEL; col += WGL_SEL) {
+                    const double rc0 = L.r0[col];
+                    bool deferred = -precision < rc0 && rc0 < precision;
+                    for (int q = 0; deferred && q < o; q++) {
+                        const double rq = c.oo[(long long)q * ld + col];
+                        deferred = -precision < rq && rq < precision;
+                    }
+                    if (!deferred) continue;
+                    const double rc = c.oo[(long long)o * ld + col];
+                    if (-precision < rc && rc < precision) continue;
+                    const bool un = c.has_unr && c.unr[L.vibc[col]] != 0;
+                    const double val = (un && rc < 0) ? -rc : rc;
+                    const bool take = val > xv;  // strict: my columns ascend, ties keep the earlier one
+                    xv = take ? val : xv;
+                    xi = take ? col : xi;
+                }
+                KI x = ki_none();
+                if (xi != 0) { x.k = key_desc(xv); x.i = xi; }
+                e = block_min_ki(x, sm, par);
+                if (e.k != KI_NONE_KEY) opt_row = o;
+            }
             if (e.k == KI_NONE_KEY) { outcome = 1; break; }  // optimal (simplex.ts:265-269)
             pc = e.i;
             {
-                const double rc = L.r0[pc];
+                const double rc = (!OPT || opt_row < 0) ? L.r0[pc] : c.oo[(long long)opt_row * ld + pc];
                 const bool un = c.has_unr && c.unr[L.vibc[pc]] != 0;
                 neg_flag = (un && rc < 0) ? 1 : 0;
             }
@@ -523,6 +553,20 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
         }
         (void)n_gated;
         __syncthreads();  // L.prow complete
+        // optional objectives (simplex.ts:394-412): the same elimination with exact `!== 0` tests, on the FINAL pivot row; the rows
+        // live in the slot's global copy (the loads below are in flight while the row updates run)
+        for (int o = 0; OPT && o < c.n_opt; o++) {
+            double* rc = c.oo + (long long)o * ld;
+            const double coefficient = rc[pc];  // every thread reads it ...
+            __syncthreads();                    // ... before anyone overwrites rc[pc]
+            if (coefficient != 0.0) {
+                for (int col = tid; col < W; col += nt) {
+                    if (col == pc) { rc[col] = -coefficient / quot; continue; }
+                    const double v0 = L.prow[col];
+                    if (v0 != 0.0) rc[col] = eliminate(rc[col], coefficient, v0);
+                }
+            }
+        }
         WL_MARK(8);
         {   // work items = (gated row, pass of UN column pairs per lane = 128 * UN columns).  Every item is one dependent memory
             // trip for its wave, so what counts under load is trips per wave: measured on the Monster_II batch (8 waves, ~10 gated
@@ -650,13 +694,13 @@ __device__ __forceinline__ int add_cuts_waves(const Slots& s, const Cuts& cuts, 
 }
 
 // simplex() of slots [first_slot, first_slot + gridDim.x): the LDS twin of k_simplex_wg
-template <int THREADS>
+template <int THREADS, bool OPT = false>
 __global__ void __launch_bounds__(THREADS) k_simplex_lds(Slots s, int first_slot, int check_cycles, int iters_cap, int cap_rows) {
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     __shared__ SmemL sm;
     const Ctx c = slot_ctx(s, first_slot + blockIdx.x, check_cycles);
     const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
-    simplex_wg_lds<(THREADS >= 1024 ? 8 : WGL_UN512)>(c, sm, L, iters_cap);
+    simplex_wg_lds<(THREADS >= 1024 ? 8 : WGL_UN512), OPT>(c, sm, L, iters_cap);
 }
 
 // The LDS twin of k_node_wg: ONE branch-and-bound child per workgroup in ONE launch -- restore of the rows the previous node
@@ -731,7 +775,7 @@ __device__ __forceinline__ void gather_slot_lds(const Slots& s, const WgLds& L, 
 }
 
 // one node (= restore + cuts + simplex + read-back) of slot `slot`; false = the slot is not in sync with the snapshot
-template <int THREADS, bool COW = false>
+template <int THREADS, bool COW = false, bool OPT = false>
 __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& snap, const Cuts& cuts, SmemL& sm, const WgLds& L, int slot, int node, int o,
                                              int check_cycles, int iters_cap, int cap_rows, double* rhs_out, int32_t* rows_out,
                                              DevState* state_out, int out_stride) {
@@ -821,6 +865,11 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
     __syncthreads();
     WL_MARK(2);
     }
+    if (OPT && s.n_opt > 0 && snap.oo) {  // restore(): the optional objective rows of the saved root (backup.ts:94-104) into the slot's copy
+        double* oo = s.oo + (long long)slot * s.oo_stride;
+        for (long long i = tid; i < s.oo_stride; i += blockDim.x) oo[i] = snap.oo[i];
+        __syncthreads();
+    }
     const Ctx c = slot_ctx(s, slot, check_cycles);
     WgLds Ln = L;
     if (snap.AT) { Ln.snapT = snap.AT; Ln.ldT = snap.ldT; Ln.Hs = H; }
@@ -829,7 +878,7 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
         Ln.err_hint = cut_err;
         Ln.H_hint = cut_err == (int)ERR_NONE ? H + (cuts.offs[node + 1] - cuts.offs[node]) : H;
     }
-    simplex_wg_lds<(THREADS >= 1024 ? 8 : WGL_UN512)>(c, sm, Ln, iters_cap);
+    simplex_wg_lds<(THREADS >= 1024 ? 8 : WGL_UN512), OPT>(c, sm, Ln, iters_cap);
 #ifdef JSLP_DEBUG_WGLDS
     wl_prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -846,7 +895,7 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
     return true;
 }
 
-template <int THREADS>
+template <int THREADS, bool OPT = false>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES : 4) k_node_lds(Slots s, Snapshot snap, Cuts cuts, int first_node, int check_cycles,
                                                       int iters_cap, int cap_rows, double* rhs_out, int32_t* rows_out,
                                                       DevState* state_out, int out_stride, int first_out,
@@ -854,7 +903,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     __shared__ SmemL sm;
     const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
-    node_lds_run<THREADS>(s, snap, cuts, sm, L, blockIdx.x, first_node + blockIdx.x, first_out + blockIdx.x, check_cycles, iters_cap, cap_rows,
+    node_lds_run<THREADS, false, OPT>(s, snap, cuts, sm, L, blockIdx.x, first_node + blockIdx.x, first_out + blockIdx.x, check_cycles, iters_cap, cap_rows,
                           rhs_out, rows_out, state_out, out_stride);
     if (done_flag) {
         __threadfence_system();

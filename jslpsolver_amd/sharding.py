@@ -169,14 +169,20 @@ def evaluate_nodes_sharded_device(tableau, cut_lists, check_cycles, group, packe
     o_rhs = _align(per * rec)
     o_rows = _align(o_rhs + per * stride * 8)
     block = _align(o_rows + per * stride * 4)
-    on_gpu = dist.get_backend(group) == "nccl"
+    # the engine writes through the pointers: device memory for the HIP engine whatever the process group's backend is (the
+    # test library's "device" memory is host memory)
+    on_gpu = tableau.lib.backend.startswith("hip")
     local = torch.zeros(block, dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+    if on_gpu:
+        torch.cuda.current_stream().synchronize()  # the fill runs on torch's stream, the engine's kernels on the engine's own
     n_mine = len(range(rank, n, world))
     if n_mine:
         packed = packed_mine if packed_mine is not None else tableau.pack_cut_lists(shard(cut_lists, rank, world))
         base = local.data_ptr()
         tableau.applyCutsBatchDevice(packed, check_cycles, base, base + o_rhs, base + o_rows, stride)
     t0 = time.perf_counter()
+    if on_gpu and dist.get_backend(group) != "nccl":  # HIP engines under a CPU process group (N virtual shards on one GPU)
+        local = local.cpu()
     out = torch.empty((world, block), dtype=torch.uint8, device=local.device)
     dist.all_gather_into_tensor(out.view(-1), local, group=group)
     blocks = out.cpu().numpy() if out.is_cuda else out.numpy()

@@ -20,11 +20,11 @@ def instance(k):
     dens = [1.0, 0.6, 0.3][k % 3]
     A[1:, 1:] = np.where(rng.random((m, n)) < dens, rng.integers(1, 13, (m, n)), 0)
     A[0, 1:] = rng.integers(0, 25, n)
-    A[1:, 0] = rng.integers(0 if k % 4 == 1 else 40, 300, m)  # k % 4 == 1: some RHS exactly 0 (degenerate rows)
+    A[1:, 0] = rng.integers(0 if k % 4 == 2 else 40, 300, m)  # k % 4 == 2: some RHS exactly 0 (degenerate rows), no ">=" rows
     n_ge = [0, 5, 0, 9][k % 4]
-    if n_ge:
+    if n_ge:  # ">=" rows x_j >= 1..3 (negated, negative RHS): phase-1 pivots; the "<=" rows (RHS >= 40, coefficients <= 12) stay satisfiable
         ge = rng.choice(np.arange(1, m + 1), min(n_ge, m), replace=False)
-        A[ge, 0] = -rng.integers(2, 15, len(ge))
+        A[ge, 0] = -rng.integers(1, 4, len(ge))
         A[ge, 1:] = 0.0
         A[ge, 1 + rng.choice(n, len(ge), replace=False)] = -1.0
     oo = None
@@ -35,7 +35,7 @@ def instance(k):
             oo[o, 1 + cols] = rng.integers(-6, 20, len(cols))
     vibr = np.array([-1] + list(range(n, n + m)), dtype=np.int32)
     vibc = np.array([-1] + list(range(n)), dtype=np.int32)
-    return A, vibr, vibc, oo, bool(k % 2)
+    return A, vibr, vibc, oo, bool((k // 2) % 2)
 
 
 def run(lib, k, cap=None):
