@@ -262,6 +262,7 @@ struct ResRegs {
     unsigned epoch;
     long long trace_n;
 #ifdef JSLP_DEBUG_RESIDENT
+    u64_t rt_retries;  // row fetches that found the winner's flag not up yet (lean kernel, step E)
     u64_t rt_acc[8];
     u64_t rt_prev;
 #endif
@@ -885,6 +886,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     ResRegs<CPT, ROWS> R;
 #ifdef JSLP_DEBUG_RESIDENT
     for (int i = 0; i < 8; i++) R.rt_acc[i] = 0;
+    R.rt_retries = 0;
     R.rt_prev = __builtin_amdgcn_s_memtime();
 #endif
     const Ctx& c = f.c;
@@ -1006,6 +1008,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
         u64_t* o = f.dbg + (long long)512 * f.G * 2 + 12288 + (b == 0 ? 0 : (b == 100 ? 16 : 32));
         for (int i = 0; i < 8; i++) o[i] = R.rt_acc[i];
         o[8] = epoch;
+        o[9] = R.rt_retries;
     }
 #endif
     // ---- epilogue: registers -> tableau, workgroup 0 -> state -----------------------------------------------------------

@@ -44,6 +44,19 @@
 // maximum per wave + one LDS atomic into a per-batch slot; every wave holding a column with that value claims it and runs the
 // ratio test for its claim into a per-wave staging area; 4 barriers per pivot): 154.3 k against 161.7 k -- the wave-wide 64-bit
 // maximum in all 16 waves costs more than the two LDS-atomic rounds it replaces.
+// r03_u ... r03_w (against 156 k that day): pricing with ONE barrier in the common case -- the earliest batch rarely moves from one
+// pivot to the next, so only the one or two waves holding the previous pivot's batch reduce it (DPP), every wave leaves {batch,
+// value, column} in an LDS slot and its bit in a mask, after the barrier every thread reads the mask and the two slots that
+// matter (a second round when the guessed batch ran dry): the pricing section stays at 2.9 k cycles (what it costs is the
+// per-thread candidate logic x 16 waves and the skew the first barrier absorbs, not the second and third barrier); with every
+// thread scanning all sixteen slots instead: 111 k (40 instructions per slot x 16 waves = 5 k cycles of issue time).  The ratio
+// test (one wave) overlapped with the row update (the other fifteen), the candidate row published after the barrier that
+// follows: 146 k together with the above -- the row leaves later than from inside the pass.  Both in the 512-thread geometries
+// (256 VGPRs, 2-6 spilled): the builds lose pivots on the wide fuzz instances (tools/fuzz_resident.py 8 / 28 / 36) whichever
+// of the two is compiled in, the committed loop does not.
+// In-kernel counter of the debug build (tools/resident_phase_timing.py): 15-65 % of a workgroup's row fetches find the winner's
+// row flag not up yet and are repeated -- the flag leaves only after the winner's own gather and drain; publishing it earlier
+// needs the store acknowledgement (one more fabric trip) ahead of the gather.
 // ===================================================================================================================
 #define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
 #define JSLP_PIPE_KCHUNK 8    // pivot-column entries the update pass keeps in flight (registers: the tall / wide geometries have few to spare)
@@ -415,6 +428,9 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 for (int o = 0; o < JSLP_R_MAXOPT; o++) ook[o] = sm.ook[okslot][o];
             }
             okslot ^= 1;  // the next use writes the other words: one barrier per use
+#ifdef JSLP_DEBUG_RESIDENT
+            if (okv == 2) R.rt_retries += 1;
+#endif
             if (okv == 2) continue;
             if (okv == 0) R.end_code = 5;
             break;

@@ -69,7 +69,10 @@ else:
     z = np.load(PATH)
     bad = 0
     paths = {}
+    only = [int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x]  # FUZZ_ONLY=8,28: those instances only
     for k in range(int(z["n"][0])):
+        if only and k not in only:
+            continue
         meta = json.loads(bytes(z["meta%d" % k]).decode())
         d, tr, fm, path = run(lib, k)
         paths[path] = paths.get(path, 0) + 1

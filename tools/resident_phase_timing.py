@@ -23,6 +23,7 @@ if os.environ.get("JSLP_RES_LEAN", "1") != "0":  # the lean kernel's pipelined l
     names = ["S claim + ratio test", "C1 poll+reduce", "U update+publish", "C2 drain+barrier", "D decide + E row fetch", "N/R0/commit", "G pricing round A", "loop top"]
 for label, off in (("wg0", 0), ("wg100", 16), ("wgLast", 32)):
     acc = d[off:off + 8].astype(np.float64); ep = float(d[off + 8])
+    print(label, "row-fetch retries", int(d[off + 9]), "of", int(ep), "pivots")
     print(label, "epochs", ep, " ".join("%s=%.0f" % (nm, a / max(ep, 1)) for nm, a in zip(names, acc)), "total cyc/pivot %.0f" % (acc.sum() / max(ep, 1)))
 mc = d[64:69]
 print("micro: syncthreads %d ticks, 1024-way LDS atomicMin %d ticks, dependent agent load %d ticks, dependent f64 div+add %d ticks" % (mc[0], mc[1], mc[2], mc[3]))
