@@ -56,7 +56,13 @@
 // of the two is compiled in, the committed loop does not.
 // In-kernel counter of the debug build (tools/resident_phase_timing.py): 15-65 % of a workgroup's row fetches find the winner's
 // row flag not up yet and are repeated -- the flag leaves only after the winner's own gather and drain; publishing it earlier
-// needs the store acknowledgement (one more fabric trip) ahead of the gather.
+// needs the store acknowledgement (one more fabric trip) ahead of the gather.  Tried (r03_w, against 156 k): the row that can win
+// updated and stored FIRST, then drain + barrier + flag BEFORE the gather: the repeats go (44-146 of 9727), the fetch drops from
+// 3.3-5.4 k to 2.7 k cycles, but the acknowledgement of a write-through store takes ~4 k cycles and is not hidden by the 3 k of
+// the update pass: 134 k.  Candidate rows with the epoch tag INSIDE the data ({lo32 | tag}{hi32 | tag} per double, RCCL's LL
+// scheme: no flag, no drain, the fetch re-reads the 16-byte words whose tags are not up): correct, repeats 31-139 of 9727, but
+// twice the row bytes -- 8 MB of stores and an 8 MB fetch burst per pivot -- slow the gather's polls (2.2 k -> 3.8-4.8 k cycles)
+// and the fetch (3.3 k -> 4.0 k): 126 k.  What crosses the fabric per pivot is what the loop waits for.
 // ===================================================================================================================
 #define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
 #define JSLP_PIPE_KCHUNK 8    // pivot-column entries the update pass keeps in flight (registers: the tall / wide geometries have few to spare)
