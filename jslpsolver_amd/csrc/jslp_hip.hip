@@ -753,6 +753,11 @@ static int resident_geometry(const jslp_engine* e, int H) {
         const bool lean_ok = !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0) && e->n_unr == 0;
         return (lean_ok && e->n_opt <= 3 && e->ld <= 2048 && rpb <= 8) ? 1 : 0;
     }
+    if (const char* gx = getenv("JSLP_RES_GEOM")) {  // experiments: force a geometry the tableau fits (lean build, no unrestricted variables)
+        static const int rows_of[6] = {0, 8, 8, 16, 12, 8}, ld_of[6] = {0, 2048, 2048, 2048, 3072, 4096};
+        const int g = atoi(gx);
+        if (g >= 1 && g <= 5 && e->n_unr == 0 && e->ld <= ld_of[g] && rpb <= rows_of[g]) return g;
+    }
     if (e->ld <= 2048 && rpb <= 8) return e->res_cpt == 4 ? 2 : 1;
     // The taller / wider geometries hold 64-72 MB of tableau in the 128 MB of vector registers and spill ~0.5 KB per lane to
     // scratch (560+ scratch loads in the pivot loop): measured at the end of round 2 they LOSE to the streaming kernels --
@@ -994,6 +999,11 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             rc.abort_flag = e->r_sync + 4;
             HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * JSLP_R_SYNC_WORDS, s));  // tags restart at 1
             rc.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
+            if (const char* rx = getenv("JSLP_RES_RPB")) {  // experiments: more rows per workgroup = fewer workgroups (<= the geometry's rows)
+                static const int rows_of[6] = {0, 8, 8, 16, 12, 8};
+                const int want = atoi(rx);
+                if (want > rc.rpb && want <= rows_of[geometry]) rc.rpb = want;
+            }
             rc.G = (H + rc.rpb - 1) / rc.rpb;
             rc.H = H;
             rc.n_idx = e->n_idx;
