@@ -184,6 +184,10 @@ static int snapshot_transpose_on() {  // pivot-column reads of untouched rows fr
     }
     return v;
 }
+static int node_cow_single() {  // single-node call: copy-on-write start (JSLP_NODE_COW_SINGLE=0: restore eagerly, as the batch groups do)
+    static const int v = getenv("JSLP_NODE_COW_SINGLE") ? atoi(getenv("JSLP_NODE_COW_SINGLE")) : 1;
+    return v;
+}
 static int node_cow() {  // queue kernel: copy-on-write slots (no restore between nodes)
     static int v = -1;
     if (v < 0) {
@@ -1755,6 +1759,9 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         const unsigned seq = ++e->done_seq ? e->done_seq : ++e->done_seq;  // never 0 (the flag's initial value)
         if (const size_t lds = wglds_smem(e); lds && e->s.n_opt > 0)
             hipLaunchKernelGGL((k_node_lds<JSLP_WG_THREADS, true>), dim3(1), dim3(JSLP_WG_THREADS), lds, s, e->s, sn, cu, 0, check_cycles,
+                               cap, (int)e->cap_rows, o_rhs, o_rows, o_state, compact ? g_stride : 0, 0, d_flag, seq);
+        else if (lds && node_cow_single())  // copy-on-write start, slot 0 made whole again behind the completion flag (jslp_wglds.hip.h)
+            hipLaunchKernelGGL((k_node_lds<JSLP_WG_THREADS, false, true>), dim3(1), dim3(JSLP_WG_THREADS), lds, s, e->s, sn, cu, 0, check_cycles,
                                cap, (int)e->cap_rows, o_rhs, o_rows, o_state, compact ? g_stride : 0, 0, d_flag, seq);
         else if (lds)
             hipLaunchKernelGGL((k_node_lds<JSLP_WG_THREADS>), dim3(1), dim3(JSLP_WG_THREADS), lds, s, e->s, sn, cu, 0, check_cycles,

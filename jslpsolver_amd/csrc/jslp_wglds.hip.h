@@ -895,7 +895,11 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
     return true;
 }
 
-template <int THREADS, bool OPT = false>
+// COW (the single-node call of the sequential services, one workgroup on slot 0 = the engine's live tableau): the node starts from
+// the saved root without restoring anything first (node_lds_run<.., COW>: what it starts from is READ from the root); the rows
+// earlier nodes wrote and this one did not are brought back from the root AFTER the outcome has left and the completion flag is
+// up -- the host is already walking the tree while the slot is made whole again (the next launch queues behind this one).
+template <int THREADS, bool OPT = false, bool COW = false>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES : 4) k_node_lds(Slots s, Snapshot snap, Cuts cuts, int first_node, int check_cycles,
                                                       int iters_cap, int cap_rows, double* rhs_out, int32_t* rows_out,
                                                       DevState* state_out, int out_stride, int first_out,
@@ -903,12 +907,23 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     __shared__ SmemL sm;
     const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
-    node_lds_run<THREADS, false, OPT>(s, snap, cuts, sm, L, blockIdx.x, first_node + blockIdx.x, first_out + blockIdx.x, check_cycles, iters_cap, cap_rows,
-                          rhs_out, rows_out, state_out, out_stride);
+    const bool ran = node_lds_run<THREADS, COW, OPT>(s, snap, cuts, sm, L, blockIdx.x, first_node + blockIdx.x, first_out + blockIdx.x, check_cycles,
+                                                     iters_cap, cap_rows, rhs_out, rows_out, state_out, out_stride);
     if (done_flag) {
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (COW && ran && blockIdx.x == 0) {  // slot 0 whole again: stale rows (dirty, not written by this node) come back from the saved root
+        const int H = s.st[0].s_H, ld2 = s.ld / 2, lane = threadIdx.x & 63;
+        uint8_t* dirty = s.dirty;
+        const double2* src = reinterpret_cast<const double2*>(snap.A);
+        double2* dst = reinterpret_cast<double2*>(s.A);
+        for (int r = threadIdx.x >> 6; r < H; r += blockDim.x >> 6)
+            if (dirty[r] != 0 && !L.cur[r]) {
+                wglds_copy_row(dst + (long long)r * ld2, src + (long long)r * ld2, ld2, lane);
+                if (lane == 0) dirty[r] = 0;
+            }
     }
 }
 
