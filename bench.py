@@ -79,12 +79,16 @@ const solver=require(path.join(root,'oracle/_ref/src/solver.js')).default;
 if(mode!=='cpu'){const T=require(path.join(root,'oracle/_ref/src/tableau/tableau.js')).default;
  const {SlackVariable}=require(path.join(root,'oracle/_ref/src/expressions.js'));
  const gpu=require(path.join(root,'host/gpu-tableau.js'));gpu.loadEngine({});gpu.install(T,{SlackVariable,solver});}
-const out={};
+// time inside Model.solve (tableau build, simplex / branch-and-cut, read-out) apart from the reference's own JSON parsing and result
+// assembly around it, whose garbage (a scavenge of 1-1.5 ms in most solves) makes the totals of the small configurations noisy
+const M=require(path.join(root,'oracle/_ref/src/model.js')).default;let tSolve=0;const origSolve=M.prototype.solve;
+M.prototype.solve=function(){const t0=process.hrtime.bigint();try{return origSolve.apply(this,arguments);}finally{tSolve+=Number(process.hrtime.bigint()-t0)/1e6;}};
+const out={};const med=(a)=>{const b=a.slice().sort((x,y)=>x-y);return b[b.length>>1];};
 for(const name of process.argv.slice(3)){
  const g=JSON.parse(zlib.gunzipSync(fs.readFileSync(path.join(root,'tests/golden/fixtures',name+'.json.gz'))).toString());
- const run=()=>{const m=JSON.parse(JSON.stringify(g.model));const t0=process.hrtime.bigint();const r=solver.Solve(m);return [Number(process.hrtime.bigint()-t0)/1e6,r.result];};
- for(let i=0;i<12;i++)run();const a=[];for(let i=0;i<15;i++)a.push(run()[0]);a.sort((x,y)=>x-y);
- out[name]={ms:a[7],min_ms:a[0],result:run()[1],want:g.result.result};}
+ const run=()=>{const m=JSON.parse(JSON.stringify(g.model));tSolve=0;const t0=process.hrtime.bigint();const r=solver.Solve(m);return [Number(process.hrtime.bigint()-t0)/1e6,r.result,tSolve];};
+ for(let i=0;i<12;i++)run();const a=[],b=[];for(let i=0;i<31;i++){const r=run();a.push(r[0]);b.push(r[2]);}
+ out[name]={ms:med(a),min_ms:Math.min(...a),model_solve_ms:med(b),runs:a.length,result:run()[1],want:g.result.result};}
 console.log(JSON.stringify(out));
 """
 
@@ -92,7 +96,7 @@ console.log(JSON.stringify(out));
 def dropin_leg(with_cpu):
     """THE drop-in, end to end: solver.Solve(model) through the reference's own host (oracle/_ref: JSON parsing, presolve, the
     branch-and-bound tree) + host/gpu-tableau.js + the N-API addon + the HIP engine, default install() options, JIT-warm median
-    of 15 -- next to the unpatched reference on this box's CPU.  Runs in a child process BEFORE this process touches the GPU."""
+    of 31 (totals, and the time inside Model.solve apart) -- next to the unpatched reference on this box's CPU.  Runs in a child process BEFORE this process touches the GPU."""
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "src", "solver.js")) or not os.path.exists(os.path.join(ROOT, "addon", "jslp_napi.node")):
         return None
     names = ["Monster_Problem", "Monster_II"]
@@ -104,14 +108,20 @@ def dropin_leg(with_cpu):
         except Exception as e:
             res[mode] = {"error": repr(e)}
     leg = {"what": "solver.Solve(model) through the reference host (type-erased TS under node) + host/gpu-tableau.js + N-API addon + HIP engine, "
-                   "default install(Tableau, {solver}) options (size policy, 16-node speculative batches); JIT-warm median of 15 solves, ms",
+                   "default install(Tableau, {solver}) options (size policy, 16-node speculative batches); JIT-warm median of 31 solves, ms",
            "configs": {}}
     for n in names:
         g, c = res.get("gpu", {}).get(n), res.get("cpu", {}).get(n)
         if g and g.get("result") != g.get("want"):
             raise WrongAnswer("drop-in Solve(%s): %r, the reference: %r" % (n, g.get("result"), g.get("want")))
         leg["configs"][n] = {"dropin_ms": g and g["ms"], "dropin_min_ms": g and g["min_ms"], "reference_cpu_ms": c and c["ms"],
-                             "speedup": (c["ms"] / g["ms"]) if (g and c and g.get("ms") and c.get("ms")) else None, "result": g and g["result"]}
+                             "reference_cpu_min_ms": c and c.get("min_ms"),
+                             "speedup": (c["ms"] / g["ms"]) if (g and c and g.get("ms") and c.get("ms")) else None,
+                             # inside Model.solve only (tableau build + simplex / branch-and-cut + read-out: what the binding replaces),
+                             # without the reference's JSON handling around it
+                             "model_solve_ms": g and g.get("model_solve_ms"), "reference_cpu_model_solve_ms": c and c.get("model_solve_ms"),
+                             "model_solve_speedup": (c["model_solve_ms"] / g["model_solve_ms"]) if (g and c and g.get("model_solve_ms") and c.get("model_solve_ms")) else None,
+                             "result": g and g["result"]}
     return leg
 
 
