@@ -63,6 +63,10 @@
 // scheme: no flag, no drain, the fetch re-reads the 16-byte words whose tags are not up): correct, repeats 31-139 of 9727, but
 // twice the row bytes -- 8 MB of stores and an 8 MB fetch burst per pivot -- slow the gather's polls (2.2 k -> 3.8-4.8 k cycles)
 // and the fetch (3.3 k -> 4.0 k): 126 k.  What crosses the fabric per pivot is what the loop waits for.
+// The cycle check (0.7 us per pivot when on) moved out of its three barriers -- the twelve non-polling waves append the pair and
+// share the block lengths while the row loads of step E are in flight, twelve verdict words read under E's barrier: the check-on /
+// check-off ratio moves from 0.893 to 0.905 (r03_w), within the box-to-box spread; one wave for the whole test: 103 k (its ~76
+// dependent LDS reads late in a 9726-pivot solve outlast the row fetch).  Not kept.
 // ===================================================================================================================
 #define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
 #define JSLP_PIPE_KCHUNK 8    // pivot-column entries the update pass keeps in flight (registers: the tall / wide geometries have few to spare)
