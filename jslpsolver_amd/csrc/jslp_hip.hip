@@ -101,7 +101,7 @@ struct jslp_engine {
     DevState* r_backup_st = nullptr;
     double* rb_A = nullptr; int32_t *rb_vibr = nullptr, *rb_vibc = nullptr, *rb_rbv = nullptr, *rb_cbv = nullptr;
     unsigned long long* d_nnz = nullptr; long long nnz = -1;  // non-zero cells of the uploaded tableau (counted on the device)
-    unsigned spin_limit = 0; int test_abort_epoch = -1;
+    unsigned spin_limit = 0; int test_abort_epoch = -1; int test_late_wave0 = 0;
     int resident_fallbacks = 0;  // solves that were rolled back and re-run through the streaming kernels
     int resident_handovers = 0;  // solves the lean resident kernel handed to the general one (cycle-check history beyond its LDS copy)
     // checkpoints (incremental-branch-and-cut.ts:31-44): equally sized device buffers, recycled through a free list
@@ -445,6 +445,8 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     e->spin_limit = sl ? (unsigned)std::max(1LL, atoll(sl)) : JSLP_SPIN_LIMIT_DEFAULT;
     const char* ta = getenv("JSLP_TEST_RESIDENT_ABORT");  // tests only: abort the resident kernel's hand-off at this pivot
     e->test_abort_epoch = ta ? atoi(ta) : -1;
+    const char* tl = getenv("JSLP_TEST_RESIDENT_LATE_WAVE0");  // tests only: wave 0 of every workgroup reaches each row fetch late
+    e->test_late_wave0 = tl ? atoi(tl) : 0;
     int rc = JSLP_OK;
     PooledRes pooled;
     const bool have = pool_take(device, &pooled);
@@ -1000,6 +1002,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             rc.gor[0] = rc.decision[0] + 32;
             rc.gor[1] = rc.gor[0] + JSLP_F_MAXG;
             rc.gran16 = e->r_gran + JSLP_R_SYNC_WORDS_GENERAL;  // [2][MAXG] granules, 64 bytes apart
+            for (int i = 0; i < 2; i++) rc.rowflagc[i] = e->r_gran + JSLP_R_SYNC_WORDS_GENERAL + 2 * JSLP_F_MAXG * 8 + (size_t)i * JSLP_R_FLAGCOPIES * JSLP_F_MAXG;
             rc.abort_flag = e->r_sync + 4;
             HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * JSLP_R_SYNC_WORDS, s));  // tags restart at 1
             rc.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
@@ -1014,6 +1017,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             rc.iters_cap = cap;
             rc.spin_limit = e->spin_limit;
             rc.test_abort_epoch = e->test_abort_epoch;
+            rc.test_late_wave0 = e->test_late_wave0;
             rc.dbg = nullptr;
 #ifdef JSLP_DEBUG_RESIDENT
             static u64_t* dbg_buf = nullptr;
@@ -1073,7 +1077,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                         return JSLP_OK;
                     }
                     lean = false;
-                    HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * JSLP_R_SYNC_WORDS_GENERAL, s));  // the second launch's tags restart at 1
+                    HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * JSLP_R_SYNC_WORDS, s));  // the second launch's tags restart at 1
                     goto resident_relaunch;
                 }
             }

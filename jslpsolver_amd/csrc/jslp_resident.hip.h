@@ -28,7 +28,8 @@
 // hand-off words of one engine (one allocation, zeroed per launch): [2][G][8] granules, [2][G] row flags, [2][G] chip-wide OR flags,
 // 32 words of decision / verdict, then the lean kernel's [2][G] 16-byte summary granules (JSLP_G16_STRIDE bytes apart)
 #define JSLP_R_SYNC_WORDS_GENERAL (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32)
-#define JSLP_R_SYNC_WORDS (JSLP_R_SYNC_WORDS_GENERAL + 2 * JSLP_F_MAXG * 8)  // (+ the lean kernel's granules, 64 bytes apart)
+#define JSLP_R_FLAGCOPIES 16  // copies of every row flag, one per fetching wave (2 KB apart: 4096 waves reading ONE word per pivot is a hot spot)
+#define JSLP_R_SYNC_WORDS (JSLP_R_SYNC_WORDS_GENERAL + 2 * JSLP_F_MAXG * 8 + 2 * JSLP_R_FLAGCOPIES * JSLP_F_MAXG)  // (+ the lean kernel's granules, 64 bytes apart; + the row-flag copies)
 #ifndef JSLP_RES_FAST
 #define JSLP_RES_FAST 1      // one barrier around the row flag (step E); the -k/quot entries of the pivot column computed by eight lanes in parallel while the winning row is in flight instead of one after the other by the lane that owns the column (step F)
 #endif
@@ -64,6 +65,7 @@ struct ResCtx {
     u64_t* gran[2];       // [G][8] data-tagged granules {tag = epoch + 1 : 32 | payload : 32}: q, kq, kdeg halves, rows
     u64_t* rows_pub[2];   // [G][ld] candidate rows (doubles as 8-byte words)
     u64_t* rowflag[2];    // [G] epoch tag: the workgroup's candidate row of that epoch is fully written through
+    u64_t* rowflagc[2];   // [copies][MAXG] the same flag, one copy per fetching wave (every wave looks at the flag itself: step E)
     unsigned* abort_flag; // set when any spin gives up
     u64_t* decision[2];   // leader's per-pivot decision: 3 tagged granules {pr | stop << 16}, {quot lo}, {quot hi}
     u64_t* verdict[2];    // phase 1 only: leader's cycle-check verdict {tag | stop} (the entering column is known late there)
@@ -74,6 +76,7 @@ struct ResCtx {
     int32_t iters_cap;
     uint32_t spin_limit;       // bound of every poll loop (polls, not cycles); reaching it raises the device-wide abort flag
     int32_t test_abort_epoch;  // tests only (JSLP_TEST_RESIDENT_ABORT): the last workgroup aborts the hand-off at this pivot; -1 = never
+    int32_t test_late_wave0;   // tests only (JSLP_TEST_RESIDENT_LATE_WAVE0): the wave holding thread 0 reaches every row fetch ~8 k cycles late
     u64_t* dbg;  // JSLP_DEBUG_RESIDENT builds only
 };
 
@@ -97,6 +100,7 @@ struct RSmem {
     int32_t l_rdeg, l_r;
     int32_t ok;
     int32_t okx[2];      // step E's verdict, alternating (one barrier per use)
+    unsigned okbad;      // step E: number (per workgroup, ever increasing) of the last row fetch in which some wave found the row flag down
     double nv[JSLP_R_MAXROWS + 1];  // -k / quot of my rows' pivot-column entries (and of the cost row's), one lane each
     unsigned gsum[JSLP_F_MAXG * JSLP_R_GRAN];  // all-gather by every workgroup: the payloads of everybody's summary granules
     int32_t p_neg;    // pricing: isReducedCostNegative of the winning column (unrestricted variables only, simplex.ts:164-177)
@@ -260,6 +264,7 @@ struct ResRegs {
     int neg;       // isReducedCostNegative of the entering column (phase 2, UNR builds)
     int pc, end_code, unbounded_col, hist_n, it1, it2;
     unsigned epoch;
+    unsigned efetch;  // row fetches so far (step E: see sm.okbad)
     long long trace_n;
 #ifdef JSLP_DEBUG_RESIDENT
     u64_t rt_retries;  // row fetches that found the winner's flag not up yet (lean kernel, step E)
@@ -310,6 +315,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
     const auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_bytes, 0x00020000);
     const auto rsrc1 = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[1], 0, pub_bytes, 0x00020000);
     int okslot = 0;
+    unsigned& efetch = R.efetch;  // row fetches of this workgroup so far (uniform; one count for both phases: sm.okbad only grows)
     while (end_code == 0) {
         if ((it1 - it1_start) + (it2 - it2_start) >= f.iters_cap) { end_code = 4; break; }
         if (LEAN && c.check_cycles && !(hist_n < JSLP_R_LHIST && hist_n < c.hist_cap)) { end_code = 8; break; }  // history outgrows LDS
@@ -445,7 +451,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { end_code = 5; break; }
-        if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: row is visible
+        if (tid < THREADS / 64 && pubrow != 0) AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);  // every wave has drained: row is visible (one copy of the flag per fetching wave)
         RT_MARK(2);
         // ---- D: the leader decides (winner, unboundedness, cycle check) and broadcasts three tagged granules -----------
         int pr = 0, stop = 0;
@@ -648,8 +654,12 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
 #pragma unroll
         for (int j = 0; j < CPT; j++) pv[j] = 0.0;
         for (;;) {
-            u64_t flag = 0;
-            if (tid == 0) flag = AG_LOAD(f.rowflag[par] + bw);
+            // EVERY wave looks at the flag itself, before its own loads of the row: a row loaded by a wave that ran ahead of the
+            // wave holding thread 0 (a cold instruction cache is enough) used to be accepted on thread 0's later look at the flag
+            efetch += 1;
+            if (f.test_late_wave0 && (tid >> 6) == 0) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch)
+            const u64_t flag = AG_LOAD(f.rowflagc[par] + (tid >> 6) * JSLP_F_MAXG + bw);
+            asm volatile("" ::: "memory");
             if (colok) {
 #pragma unroll
                 for (int j = 0; j < CPT; j += 2) {
@@ -660,12 +670,13 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                     pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
                 }
             }
+            if ((unsigned)flag != tag && (tid & 63) == 0) atomicMax(&sm.okbad, efetch);  // my wave loaded before the flag was up
             if (tid == 0) {
                 int ok = 1;
                 if ((unsigned)flag != tag) {
                     unsigned spins = 0;
                     ok = 2;  // row must be re-read once the flag is up
-                    while ((unsigned)AG_LOAD(f.rowflag[par] + bw) != tag) {
+                    while ((unsigned)AG_LOAD(f.rowflagc[par] + bw) != tag) {
                         __builtin_amdgcn_s_sleep(1);
                         ++spins;
                         if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
@@ -676,10 +687,11 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             }
             __syncthreads();
             const int okv = JSLP_RES_FAST ? sm.okx[okslot] : sm.ok;
+            const bool again = sm.okbad == efetch;  // (the flag is up by now: thread 0 saw it, or waited for it)
             if (JSLP_RES_FAST) okslot ^= 1;  // the next use writes the other word: one barrier per use
             else __syncthreads();
-            if (okv == 2) continue;
-            if (okv == 0) end_code = 5;
+            if (okv == 0) { end_code = 5; break; }
+            if (okv == 2 || again) continue;
             break;
         }
         if (end_code == 5) break;
@@ -957,7 +969,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     for (int col = tid; col < c.W; col += (int)blockDim.x) sm.lvibc[col] = c.vibc[col];
     if (UNR)
         for (int v = tid; v < f.n_idx && v < JSLP_R_LUNR; v += (int)blockDim.x) sm.lunr[v] = c.unr[v];
-    if (tid == 0) reset_reductions(sm);
+    if (tid == 0) { reset_reductions(sm); sm.okbad = 0u; }
     __syncthreads();
     // pricing batch of my columns (simplex.ts:118-127): fixed for the whole solve
     int pb[CPT];
@@ -975,6 +987,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     R.end_code = 0;  // 1 optimal, 2 unbounded, 3 cycle, 4 iteration cap, 5 aborted hand-off, 6 history full, 7 infeasible
     R.unbounded_col = 0;
     R.epoch = 0;
+    R.efetch = 0;
     // The lean build of the tall / wide geometries is a phase-2 kernel: the host runs their phase 1 through the fused pipeline
     // (run_simplex), the phase-1 loop is not even compiled for them (next to 64-72 MB of tableau it does not fit the registers: it
     // spilled ~0.5 KB per lane, and r03_j saw a 3001 x 3001 solve go wrong after ONE pass through that spilling code).

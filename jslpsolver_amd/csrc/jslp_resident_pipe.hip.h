@@ -165,6 +165,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
     for (int j = 0; j < CPT; j++) p[j] = 0.0;
     int okslot = 0;
+    unsigned& efetch = R.efetch;  // row fetches of this workgroup so far (uniform; one count for both phases: sm.okbad only grows)
 
 
     if (tid == 0) {
@@ -348,7 +349,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my row stores are written through
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
-        if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);  // every wave has drained: the row is visible
+        if (tid < THREADS / 64 && pubrow != 0) AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);  // every wave has drained: the row is visible (one copy of the flag per fetching wave)
         RT_MARK(3);
         // ---- D: every thread folds the four partial results ------------------------------------------------------------------
         int pr = 0, stop = 0;
@@ -393,8 +394,11 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
         for (int o = 0; o < JSLP_R_MAXOPT; o++) ook[o] = 0.0;
         for (;;) {
-            u64_t flag = 0;
-            if (tid == 0) flag = AG_LOAD(f.rowflag[par] + bw);
+            // EVERY wave looks at the flag itself, before its own loads of the row (see resident_phase's step E)
+            efetch += 1;
+            if (f.test_late_wave0 && wv == 0) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch)
+            const u64_t flag = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);
+            asm volatile("" ::: "memory");
             if (colok) {
 #pragma unroll
                 for (int j = 0; j < CPT; j += 2) {
@@ -415,12 +419,13 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                         }
                     }
             }
+            if ((unsigned)flag != tag && lane == 0) atomicMax(&sm.okbad, efetch);  // my wave loaded before the flag was up
             if (tid == 0) {
                 int ok = 1;
                 if ((unsigned)flag != tag) {
                     unsigned spins = 0;
                     ok = 2;  // the row must be re-read once the flag is up
-                    while ((unsigned)AG_LOAD(f.rowflag[par] + bw) != tag) {
+                    while ((unsigned)AG_LOAD(f.rowflagc[par] + bw) != tag) {
                         __builtin_amdgcn_s_sleep(1);
                         ++spins;
                         if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
@@ -432,6 +437,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             }
             __syncthreads();
             const int okv = sm.okx[okslot];
+            const bool again = sm.okbad == efetch;  // (the flag is up by now: thread 0 saw it, or waited for it)
             quot = sm.xq2[okslot];
             if (OPT) {
 #pragma unroll
@@ -441,8 +447,8 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #ifdef JSLP_DEBUG_RESIDENT
             if (okv == 2) R.rt_retries += 1;
 #endif
-            if (okv == 2) continue;
-            if (okv == 0) R.end_code = 5;
+            if (okv == 0) { R.end_code = 5; break; }
+            if (okv == 2 || again) continue;
             break;
         }
         if (R.end_code == 5) break;
@@ -620,6 +626,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
     for (int j = 0; j < CPT; j++) p[j] = 0.0;
     int okslot = 0;
+    unsigned& efetch = R.efetch;  // row fetches of this workgroup so far (uniform; one count for both phases: sm.okbad only grows)
     bool done = false;  // phase 1 is over: no row below -precision
 
     if (tid == 0) {
@@ -727,7 +734,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
-        if (tid == 0 && pubrow != 0) AG_STORE(f.rowflag[par] + b, (u64_t)tag);
+        if (tid < THREADS / 64 && pubrow != 0) AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);
         RT_MARK(3);
         // ---- D ---------------------------------------------------------------------------------------------------------------
         int pr = 0;
@@ -752,8 +759,11 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
         for (int j = 0; j < CPT; j++) pv[j] = 0.0;
         for (;;) {
-            u64_t flag = 0;
-            if (tid == 0) flag = AG_LOAD(f.rowflag[par] + bw);
+            // EVERY wave looks at the flag itself, before its own loads of the row (see resident_phase's step E)
+            efetch += 1;
+            if (f.test_late_wave0 && wv == 0) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch)
+            const u64_t flag = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);
+            asm volatile("" ::: "memory");
             if (colok) {
 #pragma unroll
                 for (int j = 0; j < CPT; j += 2) {
@@ -763,12 +773,13 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                     pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
                 }
             }
+            if ((unsigned)flag != tag && lane == 0) atomicMax(&sm.okbad, efetch);
             if (tid == 0) {
                 int ok = 1;
                 if ((unsigned)flag != tag) {
                     unsigned spins = 0;
                     ok = 2;
-                    while ((unsigned)AG_LOAD(f.rowflag[par] + bw) != tag) {
+                    while ((unsigned)AG_LOAD(f.rowflagc[par] + bw) != tag) {
                         __builtin_amdgcn_s_sleep(1);
                         ++spins;
                         if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
@@ -779,9 +790,10 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             }
             __syncthreads();
             const int okv = sm.okx[okslot];
+            const bool again = sm.okbad == efetch;
             okslot ^= 1;
-            if (okv == 2) continue;
-            if (okv == 0) R.end_code = 5;
+            if (okv == 0) { R.end_code = 5; break; }
+            if (okv == 2 || again) continue;
             break;
         }
         if (R.end_code == 5) break;

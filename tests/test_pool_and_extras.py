@@ -228,6 +228,61 @@ def test_resident_abort_rolls_back_and_resolves(hip_lib, abort_at, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,unrestricted", [("ra", 1000, False), ("lp", 500, False), ("ra", 500, True)])
+def test_resident_row_fetch_with_a_late_wave(hip_lib, kind, n, unrestricted, monkeypatch):
+    """The register-resident kernels fetch the winning row speculatively, next to its flag.  Round 3 found the flag looked at by
+    thread 0 only: a wave that ran ahead of thread 0's wave (a cold instruction cache is enough) could load the row before it was
+    visible and have it accepted on thread 0's LATER look -- rare, timing-dependent wrong pivots.  Every wave now looks at the flag
+    itself before its own loads.  JSLP_TEST_RESIDENT_LATE_WAVE0 makes wave 0 of every workgroup reach every fetch ~8 k cycles late:
+    with the old protocol no solve survives that (2942 of 20755 pivots on a 3001 x 3001 LP); the traces must be the reference's.
+    Lean build (phase 2 / phase 1 pipelines) and the general build (unrestricted variables)."""
+    monkeypatch.setenv("JSLP_TEST_RESIDENT_LATE_WAVE0", "1")
+    monkeypatch.setenv("JSLP_FORCE_PATH", "resident")
+    if kind == "ra":
+        m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
+        want = {500: ("1cda2607", 657), 1000: ("77bfa35c", 2833)}[n]
+    else:
+        m, vibr, vibc, _ = generators.dense_random_lp_tableau(12345, n, n)
+        want = None
+    unr = [0, 1, 2] if unrestricted else []  # (variables that never become negative here: same trace, general build)
+    outs = []
+    for late in ("1", "0"):
+        monkeypatch.setenv("JSLP_TEST_RESIDENT_LATE_WAVE0", late)
+        t = Tableau(m, vibr, vibc, unr, lib=hip_lib)
+        res = t.simplex(check_cycles=False)
+        assert t.last_path() == "resident"
+        tr = t.pivot_trace()
+        outs.append((res.pivots_phase1, res.pivots_phase2, bool(res.feasible), pivot_digest(tr), G.sha_matrix(t.download()[0])))
+        t.close()
+    assert outs[0] == outs[1]
+    if want and not unrestricted:
+        assert outs[0][3] == want[0] and outs[0][1] == want[1]
+
+
+@pytest.mark.gpu
+def test_wide_resident_geometry_with_a_late_wave(hip_lib, monkeypatch):
+    """the same for a 512-thread geometry (1201 x 2101: <512,6,12>, phase 2 only): late wave 0 vs. not -- identical traces"""
+    monkeypatch.setenv("JSLP_FORCE_PATH", "resident")
+    rng = np.random.default_rng(99)
+    mm, nn = 1200, 2100
+    A = np.zeros((mm + 1, nn + 1))
+    A[1:, 1:] = rng.integers(1, 21, (mm, nn))
+    A[0, 1:] = rng.integers(1, 51, nn)
+    A[1:, 0] = rng.integers(100, 501, mm)
+    vibr = np.array([-1] + list(range(nn, nn + mm)), dtype=np.int32)
+    vibc = np.array([-1] + list(range(nn)), dtype=np.int32)
+    outs = []
+    for late in ("1", "0"):
+        monkeypatch.setenv("JSLP_TEST_RESIDENT_LATE_WAVE0", late)
+        t = Tableau(A, vibr, vibc, lib=hip_lib)
+        res = t.simplex(check_cycles=False)
+        assert t.last_path() == "resident"
+        outs.append((res.pivots_phase2, pivot_digest(t.pivot_trace()), G.sha_matrix(t.download()[0])))
+        t.close()
+    assert outs[0] == outs[1] and outs[0][0] > 1000
+
+
+@pytest.mark.gpu
 def test_pool_creation_fails_loudly_when_peer_access_is_refused(hip_lib):
     """jslp_pool_create on a platform that refuses peer access (injected: JSLP_TEST_PEER_REFUSED=1 makes every member look
     refused): a clean error that names the devices, nothing leaked, and the primary engine is as usable as before"""
