@@ -52,8 +52,9 @@
 // thread scanning all sixteen slots instead: 111 k (40 instructions per slot x 16 waves = 5 k cycles of issue time).  The ratio
 // test (one wave) overlapped with the row update (the other fifteen), the candidate row published after the barrier that
 // follows: 146 k together with the above -- the row leaves later than from inside the pass.  Both in the 512-thread geometries
-// (256 VGPRs, 2-6 spilled): the builds lose pivots on the wide fuzz instances (tools/fuzz_resident.py 8 / 28 / 36) whichever
-// of the two is compiled in, the committed loop does not.
+// (256 VGPRs, 2-6 spilled): the builds lost pivots on the wide fuzz instances (tools/fuzz_resident.py 8 / 28 / 36) whichever
+// of the two was compiled in -- not the builds' fault, as it turned out: the changed timing opened the race in the row fetch that
+// step E's per-wave look at the flag now closes.
 // In-kernel counter of the debug build (tools/resident_phase_timing.py): 15-65 % of a workgroup's row fetches find the winner's
 // row flag not up yet and are repeated -- the flag leaves only after the winner's own gather and drain; publishing it earlier
 // needs the store acknowledgement (one more fabric trip) ahead of the gather.  Tried (r03_w, against 156 k): the row that can win
