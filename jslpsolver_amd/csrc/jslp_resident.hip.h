@@ -653,46 +653,39 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
         double pv[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; j++) pv[j] = 0.0;
-        for (;;) {
-            // EVERY wave looks at the flag itself, before its own loads of the row: a row loaded by a wave that ran ahead of the
-            // wave holding thread 0 (a cold instruction cache is enough) used to be accepted on thread 0's later look at the flag
+        {
+            // EVERY wave looks at the flag itself, before its own loads of the row, and repeats both on its own until the flag is up: a
+            // row loaded by a wave that ran ahead of the wave holding thread 0 (a cold instruction cache is enough) used to be accepted
+            // on thread 0's later look at the flag.  A flag seen up means the row's stores were acknowledged before the flag store was
+            // issued; my loads of the row are issued after my load of the flag.  A wave that gives up raises sm.okbad to this fetch's
+            // number (the count only grows: no reset, no second word).
             efetch += 1;
-            if (f.test_late_wave0 && (tid >> 6) == 0) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch)
-            const u64_t flag = AG_LOAD(f.rowflagc[par] + (tid >> 6) * JSLP_F_MAXG + bw);
-            asm volatile("" ::: "memory");
-            if (colok) {
+            unsigned spins = 0;
+            for (;;) {
+                if (f.test_late_wave0 && (tid >> 6) == 0) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch)
+                const u64_t flag = AG_LOAD(f.rowflagc[par] + (tid >> 6) * JSLP_F_MAXG + bw);
+                asm volatile("" ::: "memory");
+                if (colok) {
 #pragma unroll
-                for (int j = 0; j < CPT; j += 2) {
-                    if (c0 + j >= ld) continue;
-                    const v4u_t v = par ? __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off_in + j * 8, 0, 16)
-                                        : __builtin_amdgcn_raw_buffer_load_b128(rsrc0, off_in + j * 8, 0, 16);
-                    pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
-                    pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
-                }
-            }
-            if ((unsigned)flag != tag && (tid & 63) == 0) atomicMax(&sm.okbad, efetch);  // my wave loaded before the flag was up
-            if (tid == 0) {
-                int ok = 1;
-                if ((unsigned)flag != tag) {
-                    unsigned spins = 0;
-                    ok = 2;  // row must be re-read once the flag is up
-                    while ((unsigned)AG_LOAD(f.rowflagc[par] + bw) != tag) {
-                        __builtin_amdgcn_s_sleep(1);
-                        ++spins;
-                        if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
-                        if (spins > f.spin_limit) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+                    for (int j = 0; j < CPT; j += 2) {
+                        if (c0 + j >= ld) continue;
+                        const v4u_t v = par ? __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off_in + j * 8, 0, 16)
+                                            : __builtin_amdgcn_raw_buffer_load_b128(rsrc0, off_in + j * 8, 0, 16);
+                        pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
+                        pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
                     }
                 }
-                if (JSLP_RES_FAST) sm.okx[okslot] = ok; else sm.ok = ok;
+                if ((unsigned)flag == tag) break;  // (wave-uniform: one word, one request)
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                bool dead = false;
+                if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead = true;
+                if (spins > f.spin_limit) { if ((tid & 63) == 0) AG_STORE(f.abort_flag, 1u); dead = true; }
+                if (dead) { if ((tid & 63) == 0) atomicMax(&sm.okbad, efetch); break; }
             }
             __syncthreads();
-            const int okv = JSLP_RES_FAST ? sm.okx[okslot] : sm.ok;
-            const bool again = sm.okbad == efetch;  // (the flag is up by now: thread 0 saw it, or waited for it)
-            if (JSLP_RES_FAST) okslot ^= 1;  // the next use writes the other word: one barrier per use
-            else __syncthreads();
-            if (okv == 0) { end_code = 5; break; }
-            if (okv == 2 || again) continue;
-            break;
+            if (sm.okbad == efetch) end_code = 5;
+            if (!JSLP_RES_FAST) __syncthreads();
         }
         if (end_code == 5) break;
         RT_MARK(4);

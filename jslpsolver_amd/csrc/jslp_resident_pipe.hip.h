@@ -394,20 +394,34 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         double ook[JSLP_R_MAXOPT];  // the optional objectives' entries of column pc (OPT builds)
 #pragma unroll
         for (int o = 0; o < JSLP_R_MAXOPT; o++) ook[o] = 0.0;
-        for (;;) {
-            // EVERY wave looks at the flag itself, before its own loads of the row (see resident_phase's step E)
+        {
+            // EVERY wave looks at the flag itself, before its own loads of the row, and repeats both on its own until the flag is up
+            // (see resident_phase's step E); a wave that gives up raises sm.okbad to this fetch's number
             efetch += 1;
-            if (f.test_late_wave0 && wv == 0) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch)
-            const u64_t flag = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);
-            asm volatile("" ::: "memory");
-            if (colok) {
+            unsigned spins = 0;
+            for (;;) {
+                if (f.test_late_wave0 && wv == 0) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch)
+                const u64_t flag = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);
+                asm volatile("" ::: "memory");
+                if (colok) {
 #pragma unroll
-                for (int j = 0; j < CPT; j += 2) {
-                    if (c0 + j >= ld) continue;
-                    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + j * 8, 0, 16);
-                    pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
-                    pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
+                    for (int j = 0; j < CPT; j += 2) {
+                        if (c0 + j >= ld) continue;
+                        const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + j * 8, 0, 16);
+                        pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
+                        pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
+                    }
                 }
+                if ((unsigned)flag == tag) break;  // (wave-uniform: one word, one request)
+#ifdef JSLP_DEBUG_RESIDENT
+                if (tid == 0) R.rt_retries += 1;
+#endif
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                bool dead = false;
+                if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead = true;
+                if (spins > f.spin_limit) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead = true; }
+                if (dead) { if (lane == 0) atomicMax(&sm.okbad, efetch); break; }
             }
             if (has_pc) {
 #pragma unroll
@@ -420,37 +434,15 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                         }
                     }
             }
-            if ((unsigned)flag != tag && lane == 0) atomicMax(&sm.okbad, efetch);  // my wave loaded before the flag was up
-            if (tid == 0) {
-                int ok = 1;
-                if ((unsigned)flag != tag) {
-                    unsigned spins = 0;
-                    ok = 2;  // the row must be re-read once the flag is up
-                    while ((unsigned)AG_LOAD(f.rowflagc[par] + bw) != tag) {
-                        __builtin_amdgcn_s_sleep(1);
-                        ++spins;
-                        if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
-                        if (spins > f.spin_limit) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
-                    }
-                }
-                sm.okx[okslot] = ok;
-                sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff;  // the next pricing's reductions (reset before a barrier)
-            }
+            if (tid == 0) { sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff; }  // the next pricing's reductions (reset before a barrier)
             __syncthreads();
-            const int okv = sm.okx[okslot];
-            const bool again = sm.okbad == efetch;  // (the flag is up by now: thread 0 saw it, or waited for it)
+            if (sm.okbad == efetch) R.end_code = 5;
             quot = sm.xq2[okslot];
             if (OPT) {
 #pragma unroll
                 for (int o = 0; o < JSLP_R_MAXOPT; o++) ook[o] = sm.ook[okslot][o];
             }
             okslot ^= 1;  // the next use writes the other words: one barrier per use
-#ifdef JSLP_DEBUG_RESIDENT
-            if (okv == 2) R.rt_retries += 1;
-#endif
-            if (okv == 0) { R.end_code = 5; break; }
-            if (okv == 2 || again) continue;
-            break;
         }
         if (R.end_code == 5) break;
         RT_MARK(4);
@@ -759,43 +751,33 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         double pv[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; j++) pv[j] = 0.0;
-        for (;;) {
-            // EVERY wave looks at the flag itself, before its own loads of the row (see resident_phase's step E)
+        {
+            // (every wave its own look at the flag and its own repeats: see phase 2)
             efetch += 1;
-            if (f.test_late_wave0 && wv == 0) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch)
-            const u64_t flag = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);
-            asm volatile("" ::: "memory");
-            if (colok) {
+            unsigned spins = 0;
+            for (;;) {
+                if (f.test_late_wave0 && wv == 0) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch)
+                const u64_t flag = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);
+                asm volatile("" ::: "memory");
+                if (colok) {
 #pragma unroll
-                for (int j = 0; j < CPT; j += 2) {
-                    if (c0 + j >= ld) continue;
-                    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + j * 8, 0, 16);
-                    pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
-                    pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
-                }
-            }
-            if ((unsigned)flag != tag && lane == 0) atomicMax(&sm.okbad, efetch);
-            if (tid == 0) {
-                int ok = 1;
-                if ((unsigned)flag != tag) {
-                    unsigned spins = 0;
-                    ok = 2;
-                    while ((unsigned)AG_LOAD(f.rowflagc[par] + bw) != tag) {
-                        __builtin_amdgcn_s_sleep(1);
-                        ++spins;
-                        if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { ok = 0; break; }
-                        if (spins > f.spin_limit) { AG_STORE(f.abort_flag, 1u); ok = 0; break; }
+                    for (int j = 0; j < CPT; j += 2) {
+                        if (c0 + j >= ld) continue;
+                        const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + j * 8, 0, 16);
+                        pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
+                        pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
                     }
                 }
-                sm.okx[okslot] = ok;
+                if ((unsigned)flag == tag) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                bool dead = false;
+                if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead = true;
+                if (spins > f.spin_limit) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead = true; }
+                if (dead) { if (lane == 0) atomicMax(&sm.okbad, efetch); break; }
             }
             __syncthreads();
-            const int okv = sm.okx[okslot];
-            const bool again = sm.okbad == efetch;
-            okslot ^= 1;
-            if (okv == 0) { R.end_code = 5; break; }
-            if (okv == 2 || again) continue;
-            break;
+            if (sm.okbad == efetch) R.end_code = 5;
         }
         if (R.end_code == 5) break;
         RT_MARK(4);
