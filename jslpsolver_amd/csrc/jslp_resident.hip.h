@@ -662,7 +662,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             efetch += 1;
             unsigned spins = 0;
             for (;;) {
-                if (f.test_late_wave0 && (tid >> 6) == 0) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch)
+                if (__builtin_amdgcn_readfirstlane((int)(f.test_late_wave0 != 0 && (tid >> 6) == 0))) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch; a SCALAR branch -- s_sleep ignores EXEC, and predicated by EXEC alone it ran in every wave at every fetch: 157 k -> 102 k pivots/s)
                 const u64_t flag = AG_LOAD(f.rowflagc[par] + (tid >> 6) * JSLP_F_MAXG + bw);
                 asm volatile("" ::: "memory");
                 if (colok) {

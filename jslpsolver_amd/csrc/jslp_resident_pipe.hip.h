@@ -400,7 +400,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             efetch += 1;
             unsigned spins = 0;
             for (;;) {
-                if (f.test_late_wave0 && wv == 0) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch)
+                if (__builtin_amdgcn_readfirstlane((int)(f.test_late_wave0 != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch; a scalar branch: s_sleep ignores EXEC)
                 const u64_t flag = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);
                 asm volatile("" ::: "memory");
                 if (colok) {
@@ -756,7 +756,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             efetch += 1;
             unsigned spins = 0;
             for (;;) {
-                if (f.test_late_wave0 && wv == 0) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch)
+                if (__builtin_amdgcn_readfirstlane((int)(f.test_late_wave0 != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch; a scalar branch: s_sleep ignores EXEC)
                 const u64_t flag = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);
                 asm volatile("" ::: "memory");
                 if (colok) {
