@@ -895,6 +895,28 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
     return true;
 }
 
+// Slot 0 after a copy-on-write node: the rows earlier nodes wrote and the last one did not (dirty, not current) come back from
+// the saved root.  The dirty flags are read by all threads at once and the stale rows compacted into the LDS list (a wave per row
+// reading one flag per trip took ~60 dependent global loads for Monster_II's 945 rows: 70 us behind the completion flag, which
+// the NEXT node of a sequential walk queues behind).
+__device__ __forceinline__ void slot0_whole_again(const Slots& s, const Snapshot& snap, SmemL& sm, const WgLds& L) {
+    const int H = s.st[0].s_H, ld2 = s.ld / 2, lane = threadIdx.x & 63;
+    uint8_t* dirty = s.dirty;
+    if (threadIdx.x == 0) sm.n_list = 0;
+    __syncthreads();
+    for (int r = threadIdx.x; r < H; r += blockDim.x)
+        if (dirty[r] != 0 && !L.cur[r]) L.list[atomicAdd(&sm.n_list, 1)] = r;
+    __syncthreads();
+    const int n = sm.n_list;
+    const double2* src = reinterpret_cast<const double2*>(snap.A);
+    double2* dst = reinterpret_cast<double2*>(s.A);
+    for (int i = threadIdx.x >> 6; i < n; i += blockDim.x >> 6) {
+        const int r = L.list[i];
+        wglds_copy_row(dst + (long long)r * ld2, src + (long long)r * ld2, ld2, lane);
+        if (lane == 0) dirty[r] = 0;
+    }
+}
+
 // COW (the single-node call of the sequential services, one workgroup on slot 0 = the engine's live tableau): the node starts from
 // the saved root without restoring anything first (node_lds_run<.., COW>: what it starts from is READ from the root); the rows
 // earlier nodes wrote and this one did not are brought back from the root AFTER the outcome has left and the completion flag is
@@ -914,17 +936,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (COW && ran && blockIdx.x == 0) {  // slot 0 whole again: stale rows (dirty, not written by this node) come back from the saved root
-        const int H = s.st[0].s_H, ld2 = s.ld / 2, lane = threadIdx.x & 63;
-        uint8_t* dirty = s.dirty;
-        const double2* src = reinterpret_cast<const double2*>(snap.A);
-        double2* dst = reinterpret_cast<double2*>(s.A);
-        for (int r = threadIdx.x >> 6; r < H; r += blockDim.x >> 6)
-            if (dirty[r] != 0 && !L.cur[r]) {
-                wglds_copy_row(dst + (long long)r * ld2, src + (long long)r * ld2, ld2, lane);
-                if (lane == 0) dirty[r] = 0;
-            }
-    }
+    if (COW && ran && blockIdx.x == 0) slot0_whole_again(s, snap, sm, L);
 }
 
 // A whole batch in ONE launch: as many workgroups as the chip keeps resident, each on its own slot, each pulling the next node
@@ -953,18 +965,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
         node_lds_run<THREADS, COW>(s, snap, cuts, sm, L, slot, node, node, check_cycles, iters_cap, cap_rows, rhs_out, rows_out, state_out, out_stride);
         __syncthreads();
     }
-    if (COW && blockIdx.x == 0 && ran) {
-        // slot 0 is also the engine's live tableau: leave it whole (the last node this workgroup evaluated), as the other
-        // batch shapes do -- the rows earlier nodes wrote and the last one did not come back from the saved root.  The other
-        // slots keep theirs (flagged dirty) until someone restores them.
-        const int H = s.st[0].s_H, ld2 = s.ld / 2, lane = threadIdx.x & 63;
-        uint8_t* dirty = s.dirty;
-        const double2* src = reinterpret_cast<const double2*>(snap.A);
-        double2* dst = reinterpret_cast<double2*>(s.A);
-        for (int r = threadIdx.x >> 6; r < H; r += blockDim.x >> 6)
-            if (dirty[r] != 0 && !L.cur[r]) {
-                wglds_copy_row(dst + (long long)r * ld2, src + (long long)r * ld2, ld2, lane);
-                if (lane == 0) dirty[r] = 0;
-            }
-    }
+    // slot 0 is also the engine's live tableau: leave it whole (the last node this workgroup evaluated), as the other batch shapes
+    // do.  The other slots keep their stale rows (flagged dirty) until someone restores them.
+    if (COW && blockIdx.x == 0 && ran) slot0_whole_again(s, snap, sm, L);
 }
