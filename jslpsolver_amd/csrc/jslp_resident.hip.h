@@ -99,8 +99,7 @@ struct RSmem {
     double l_k;       // leader: pivot-column entry of the winning row
     int32_t l_rdeg, l_r;
     int32_t ok;
-    int32_t okx[2];      // step E's verdict, alternating (one barrier per use)
-    unsigned okbad;      // step E: number (per workgroup, ever increasing) of the last row fetch in which some wave found the row flag down
+    unsigned okbad;      // step E: number (per workgroup, ever increasing) of the last row fetch in which some wave gave up waiting for the row flag
     double nv[JSLP_R_MAXROWS + 1];  // -k / quot of my rows' pivot-column entries (and of the cost row's), one lane each
     unsigned gsum[JSLP_F_MAXG * JSLP_R_GRAN];  // all-gather by every workgroup: the payloads of everybody's summary granules
     int32_t p_neg;    // pricing: isReducedCostNegative of the winning column (unrestricted variables only, simplex.ts:164-177)
@@ -314,7 +313,6 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
     const int pub_bytes = f.G * ld * 8;
     const auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_bytes, 0x00020000);
     const auto rsrc1 = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[1], 0, pub_bytes, 0x00020000);
-    int okslot = 0;
     unsigned& efetch = R.efetch;  // row fetches of this workgroup so far (uniform; one count for both phases: sm.okbad only grows)
     while (end_code == 0) {
         if ((it1 - it1_start) + (it2 - it2_start) >= f.iters_cap) { end_code = 4; break; }

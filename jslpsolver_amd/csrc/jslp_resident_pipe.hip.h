@@ -618,7 +618,6 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     bool pend = false;
 #pragma unroll
     for (int j = 0; j < CPT; j++) p[j] = 0.0;
-    int okslot = 0;
     unsigned& efetch = R.efetch;  // row fetches of this workgroup so far (uniform; one count for both phases: sm.okbad only grows)
     bool done = false;  // phase 1 is over: no row below -precision
 
