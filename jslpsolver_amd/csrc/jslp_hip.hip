@@ -131,7 +131,7 @@ struct jslp_engine {
     DevState* f_st[2] = {nullptr, nullptr};
     // register-resident phase 2 (one cooperative launch): hand-off buffers
     u64_t* r_gran = nullptr;  // [2][G][8] granules then [2][G] row flags (one allocation, zeroed per launch)
-    u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr;
+    u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr; int2* r_hist_all = nullptr;
     int no_resident = 0;
     int res_cpt = 2;  // columns per lane of the resident kernel (JSLP_RES_CPT=2|4)
     int one_launch_nodes = 1;  // JSLP_NO_NODE_KERNEL=1: single children go through the five-launch sequence
@@ -794,6 +794,7 @@ static int ensure_resident(jslp_engine* e) {
         Carver cv{pass ? e->r_arena : nullptr, 0};
         e->r_gran = cv.take<u64_t>(JSLP_R_SYNC_WORDS);
         for (int i = 0; i < 2; i++) e->r_rows[i] = cv.take<u64_t>((size_t)JSLP_F_MAXG * e->ld);
+        e->r_hist_all = cv.take<int2>((size_t)JSLP_F_MAXG * JSLP_PIPE_GHIST);  // every workgroup's own copy of the cycle-check history (lean kernel)
         e->r_sync = cv.take<unsigned>(16);
         e->rb_A = cv.take<double>((size_t)e->cap_rows * e->ld);
         e->rb_vibr = cv.take<int32_t>((size_t)e->cap_rows);
@@ -1002,6 +1003,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             rc.gor[0] = rc.decision[0] + 32;
             rc.gor[1] = rc.gor[0] + JSLP_F_MAXG;
             rc.gran16 = e->r_gran + JSLP_R_SYNC_WORDS_GENERAL;  // [2][MAXG] granules, 64 bytes apart
+            rc.hist_all = e->r_hist_all;
             for (int i = 0; i < 2; i++) rc.rowflagc[i] = e->r_gran + JSLP_R_SYNC_WORDS_GENERAL + 2 * JSLP_F_MAXG * 8 + (size_t)i * JSLP_R_FLAGCOPIES * JSLP_F_MAXG;
             rc.abort_flag = e->r_sync + 4;
             HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * JSLP_R_SYNC_WORDS, s));  // tags restart at 1

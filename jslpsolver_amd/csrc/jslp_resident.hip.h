@@ -25,6 +25,14 @@
 #define JSLP_R_LDMAX 4096    // widest padded row any geometry takes (512 lanes x 8 columns)
 #define JSLP_R_LUNR 8192     // variable indexes whose unrestricted flag fits the LDS copy (more: gather-by-leader protocol)
 #define JSLP_R_LHIST 10240   // cycle-check history entries kept in LDS (80 KB)
+// The lean kernel's cycle check (jslp_resident_pipe.hip.h): its LDS holds the first JSLP_PIPE_LHIST pairs of the history and, in the
+// rest of the general build's 80 KB history plus 16 KB more, a 2^19-bit filter of the pairs seen (two hashes per pair); the whole
+// history of every workgroup also goes to its own slice of a global buffer (JSLP_PIPE_GHIST pairs each), which the rare suffix
+// test reads beyond the LDS part -- so a solve longer than the LDS history no longer hands over to the general build
+#define JSLP_PIPE_LHIST 4096
+#define JSLP_PIPE_CYCBITS (1 << 19)
+#define JSLP_PIPE_GHIST (1 << 17)
+#define JSLP_R_CYCEXTRA ((JSLP_PIPE_CYCBITS / 8 - (JSLP_R_LHIST - JSLP_PIPE_LHIST) * 8) / 4)  // words of the filter beyond the general history
 // hand-off words of one engine (one allocation, zeroed per launch): [2][G][8] granules, [2][G] row flags, [2][G] chip-wide OR flags,
 // 32 words of decision / verdict, then the lean kernel's [2][G] 16-byte summary granules (JSLP_G16_STRIDE bytes apart)
 #define JSLP_R_SYNC_WORDS_GENERAL (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32)
@@ -70,6 +78,7 @@ struct ResCtx {
     u64_t* decision[2];   // leader's per-pivot decision: 3 tagged granules {pr | stop << 16}, {quot lo}, {quot hi}
     u64_t* verdict[2];    // phase 1 only: leader's cycle-check verdict {tag | stop} (the entering column is known late there)
     u64_t* gor[2];        // [G] rare slow path: tagged per-workgroup flags for a chip-wide OR
+    int2* hist_all;       // [G][JSLP_PIPE_GHIST] every workgroup's own copy of the cycle-check history (lean kernel; nullptr: LDS part only)
     u64_t* gran16;        // [2][MAXG] 16-byte summary granules of the lean kernel's pipelined phase 2, 64 bytes apart (jslp_resident_pipe.hip.h)
     int32_t G, rpb, H;
     int32_t n_idx;             // variable indexes in use (the LDS copy of the unrestricted flags covers JSLP_R_LUNR of them)
@@ -126,6 +135,11 @@ struct RSmem {
     int32_t lvibc[JSLP_R_LDMAX];
     uint8_t lunr[JSLP_R_LUNR];
     int2 lhist[JSLP_R_LHIST];
+    // lean kernel: bits of the (leaving, entering) pairs seen in this phase, by two hashes -- the filter starts inside lhist (behind
+    // the lean kernel's JSLP_PIPE_LHIST pairs) and ends here.  A repeated block can only end at a pair that occurred before, so a
+    // pair with a clear bit needs no suffix test at all (exact: bits are only ever set; a collision merely runs the test)
+    unsigned cycbits_tail[JSLP_R_CYCEXTRA];
+    int32_t cyc_need;
 };
 
 // The leader's last FOUR waves gather every workgroup's summary of this epoch (all-gather with the data as the flag,

@@ -80,6 +80,42 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane) {  // src
 }
 
 
+// ---- the lean kernel's cycle check (simplex.ts:78-93 / 305-320) ------------------------------------------------------------------
+static_assert(offsetof(RSmem, cycbits_tail) == offsetof(RSmem, lhist) + sizeof(int2) * JSLP_R_LHIST, "the filter runs from inside lhist into cycbits_tail");
+static_assert((JSLP_R_LHIST - JSLP_PIPE_LHIST) * 8 + JSLP_R_CYCEXTRA * 4 == JSLP_PIPE_CYCBITS / 8, "filter size");
+__device__ __forceinline__ unsigned* cyc_bits(RSmem& sm) { return reinterpret_cast<unsigned*>(&sm.lhist[JSLP_PIPE_LHIST]); }
+// first step (thread 0): has this (leaving, entering) pair been seen in this phase?  Sets its two bits.
+__device__ __forceinline__ int cyc_pair_seen(RSmem& sm, int2 pair) {
+    static_assert(JSLP_PIPE_CYCBITS == (1 << 19), "the hashes below yield 19 bits");
+    unsigned* bits = cyc_bits(sm);
+    const unsigned k = (unsigned)pair.x * 0x9E3779B1u ^ (unsigned)pair.y * 0x85EBCA6Bu;
+    const unsigned h1 = k >> (32 - 19), h2 = (k * 0xC2B2AE35u + 0x27D4EB2Fu) >> (32 - 19);
+    const unsigned o1 = bits[h1 >> 5], m1 = 1u << (h1 & 31u);
+    bits[h1 >> 5] = o1 | m1;
+    const unsigned o2 = bits[h2 >> 5], m2 = 1u << (h2 & 31u);  // (read after the first write: h1 and h2 may share a word)
+    bits[h2 >> 5] = o2 | m2;
+    return ((o1 & m1) != 0u && (o2 & m2) != 0u) ? 1 : 0;
+}
+// the suffix test (suffix_is_square of jslp_core.inc.h) over a history whose first JSLP_PIPE_LHIST pairs sit in LDS and the rest
+// in this workgroup's global slice; rare (only behind a filter hit), so the global reads do not matter
+// (`last` = the newest pair, handed over in a register: thread 0 stored it a moment ago)
+__device__ __forceinline__ bool cyc_suffix_is_square(const int2* lds, const int2* glob, int n, int2 last, Smem& red) {
+    auto at = [&](int i) -> int2 { return i < JSLP_PIPE_LHIST ? lds[i] : glob[i]; };
+    int found = 0;
+    for (int L = 1 + threadIdx.x; 2 * L <= n; L += blockDim.x) {
+        const int2 a = at(n - 1 - L);
+        if (a.x != last.x || a.y != last.y) continue;
+        bool eq = true;
+        for (int i = 0; i < L - 1; i++) {
+            const int2 x = at(n - 2 * L + i), y = at(n - L + i);
+            if (x.x != y.x || x.y != y.y) { eq = false; break; }
+        }
+        if (eq) found = 1;
+    }
+    (void)red;
+    return __syncthreads_or(found) != 0;
+}
+
 #define JSLP_R_MAXOPT 3  // optional objective rows the lean kernel keeps in registers (priorities "strong" / "medium" / "weak": model.ts:141-160)
 
 // simplex.ts:221-263 on the lanes' own copies: no column prices out on the main row -> the optional objectives break the tie, in
@@ -169,6 +205,12 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     unsigned& efetch = R.efetch;  // row fetches of this workgroup so far (uniform; one count for both phases: sm.okbad only grows)
 
 
+    // the seen-pair filter of the cycle check covers a history that starts here (a phase entered with pairs already in it -- not
+    // something the hosts do -- keeps testing every pivot)
+    const bool cyc_filter = R.hist_n == 0;
+    int2* const my_hist = f.hist_all ? f.hist_all + (size_t)b * JSLP_PIPE_GHIST : nullptr;  // my own copy of the whole history
+    const int hist_room = my_hist ? JSLP_PIPE_GHIST : JSLP_PIPE_LHIST;
+    for (int i = tid; i < JSLP_PIPE_CYCBITS / 32; i += THREADS) cyc_bits(sm)[i] = 0u;
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < ROWS; i++) sm.rhsb[i] = a[i][0];
@@ -180,7 +222,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         const bool has_pc_p = pend && colok && pc_p >= c0 && pc_p < c0 + CPT;
         // ---- exits that hand the tableau on (the pending update is applied behind the loop) ---------------------------------
         if ((R.it1 - it1_start) + (R.it2 - it2_start) >= f.iters_cap) { R.end_code = 4; break; }
-        if (c.check_cycles && !(R.hist_n < JSLP_R_LHIST && R.hist_n < c.hist_cap)) { R.end_code = 8; break; }  // history outgrows LDS: the general kernel continues
+        if (c.check_cycles && !(R.hist_n < hist_room && R.hist_n < c.hist_cap)) { R.end_code = 8; break; }  // history outgrows its room: the general kernel continues
         const unsigned epoch = R.epoch;
         const int par = epoch & 1;
         const unsigned tag = epoch + 1;
@@ -373,12 +415,16 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         if (!stop && c.check_cycles) {  // simplex.ts:305-320 by every workgroup, on its own LDS history
             if (tid == 0) {
                 const int2 pair = make_int2(sm.lvibr[pr], sm.lvibc[pc]);
-                sm.lhist[R.hist_n] = pair;
-                if (b == 0) c.hist[R.hist_n] = pair;  // the host's cycle message; the general kernel's history should this one outgrow LDS
+                if (R.hist_n < JSLP_PIPE_LHIST) sm.lhist[R.hist_n] = pair;
+                if (my_hist) my_hist[R.hist_n] = pair;
+                if (b == 0) c.hist[R.hist_n] = pair;  // the host's cycle message; the general kernel's history should this one outgrow its room
+                sm.cyc_need = cyc_filter ? cyc_pair_seen(sm, pair) : 1;
             }
             __syncthreads();
             R.hist_n += 1;
-            if (suffix_is_square(sm.lhist, R.hist_n, sm.f.red)) stop = 1;
+            if (sm.cyc_need != 0) {  // (uniform) only a pair that occurred before can end a repeated block
+                if (cyc_suffix_is_square(sm.lhist, my_hist, R.hist_n, make_int2(sm.lvibr[pr], sm.lvibc[pc]), sm.f.red)) stop = 1;
+            }
         }
         if (stop == 3) { R.end_code = 2; R.unbounded_col = pc; break; }
         if (stop == 1) { R.end_code = 3; break; }
@@ -621,6 +667,10 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     unsigned& efetch = R.efetch;  // row fetches of this workgroup so far (uniform; one count for both phases: sm.okbad only grows)
     bool done = false;  // phase 1 is over: no row below -precision
 
+    const bool cyc_filter = R.hist_n == 0;  // (see phase 2)
+    int2* const my_hist = f.hist_all ? f.hist_all + (size_t)b * JSLP_PIPE_GHIST : nullptr;
+    const int hist_room = my_hist ? JSLP_PIPE_GHIST : JSLP_PIPE_LHIST;
+    for (int i = tid; i < JSLP_PIPE_CYCBITS / 32; i += THREADS) cyc_bits(sm)[i] = 0u;
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < ROWS; i++) sm.rhsb[i] = a[i][0];
@@ -631,7 +681,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     while (R.end_code == 0) {
         const bool has_pc_p = pend && colok && pc_p >= c0 && pc_p < c0 + CPT;
         if ((R.it1 - it1_start) + (R.it2 - it2_start) >= f.iters_cap) { R.end_code = 4; break; }
-        if (c.check_cycles && !(R.hist_n < JSLP_R_LHIST && R.hist_n < c.hist_cap)) { R.end_code = 8; break; }
+        if (c.check_cycles && !(R.hist_n < hist_room && R.hist_n < c.hist_cap)) { R.end_code = 8; break; }
         const unsigned epoch = R.epoch;
         const int par = epoch & 1;
         const unsigned tag = epoch + 1;
@@ -830,12 +880,16 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         if (c.check_cycles) {  // simplex.ts:78-93 by every workgroup, on its own LDS history
             if (tid == 0) {
                 const int2 pair = make_int2(sm.lvibr[pr], sm.lvibc[pc]);
-                sm.lhist[R.hist_n] = pair;
+                if (R.hist_n < JSLP_PIPE_LHIST) sm.lhist[R.hist_n] = pair;
+                if (my_hist) my_hist[R.hist_n] = pair;
                 if (b == 0) c.hist[R.hist_n] = pair;
+                sm.cyc_need = cyc_filter ? cyc_pair_seen(sm, pair) : 1;
             }
             __syncthreads();
             R.hist_n += 1;
-            if (suffix_is_square(sm.lhist, R.hist_n, sm.f.red)) { R.end_code = 3; break; }
+            if (sm.cyc_need != 0) {  // (uniform)
+                if (cyc_suffix_is_square(sm.lhist, my_hist, R.hist_n, make_int2(sm.lvibr[pr], sm.lvibc[pc]), sm.f.red)) { R.end_code = 3; break; }
+            }
         }
         // ---- N: normalised pivot row (simplex.ts:352-364); the tiny entries simplex.ts:381-383 zeroes as soon as ANY other row
         //      is eliminated need a chip-wide answer in the rare pivot that has them -----------------------------------------------

@@ -15,7 +15,8 @@ from jslpsolver_amd import Model
 from jslpsolver_amd.engine import Tableau, pivot_digest
 
 CYCLES = os.path.join(G.GOLDEN, "cycles")
-SMALL = sorted(p for p in glob.glob(os.path.join(CYCLES, "*.json.gz")) if "embedded" not in p)
+SMALL = sorted(p for p in glob.glob(os.path.join(CYCLES, "*.json.gz")) if "embedded" not in p and "late_" not in p)
+LATE = os.path.join(CYCLES, "late_deg_35358_after_RA_1500.json.gz")  # gen_golden_late_cycle.js: the hit comes after 6581 pivots
 EMBEDDED = sorted(glob.glob(os.path.join(CYCLES, "embedded_*.json.gz")))
 
 
@@ -43,10 +44,31 @@ def _embed(model, extra_vars, extra_cons, seed=777):
     return big
 
 
+def _late_model(small, n, seed):
+    """gen_golden_late_cycle.js `lateCycle`: generateResourceAllocation(seed, n x n) as a minimisation, then the small cycling LP"""
+    from jslpsolver_amd import generators
+    ra = generators.resource_allocation_model(seed, num_variables=n, num_constraints=n, density=1.0)
+    big = {"optimize": "obj", "opType": "min", "constraints": dict(ra["constraints"]), "variables": {}}
+    for k, v in ra["variables"].items():
+        v = dict(v)
+        v["obj"] = -v.pop(ra["optimize"])
+        big["variables"][k] = v
+    for k, c in small["constraints"].items():
+        big["constraints"]["z_" + k] = c
+    for k, v in small["variables"].items():
+        big["variables"]["z_" + k] = {("obj" if a == small["optimize"] else "z_" + a): x for a, x in v.items()}
+    big["options"] = {"presolve": False}
+    return big
+
+
 def _instance(path):
     g = G.load(path)
     name = G.ident(path)
-    if g["model"] is not None:
+    if name.startswith("late_"):
+        meta = g["meta"]
+        small = G.load(os.path.join(CYCLES, "%s.json.gz" % meta["small"]))["model"]
+        m, vibr, vibc = Model(_late_model(small, meta["n"], meta["seed"])).build_tableau()
+    elif g["model"] is not None:
         m, vibr, vibc = G.dense_tableau(g["tableau"])
     else:  # embedded_<family>_<seed>_<vars>x<cons>: rebuilt from the small golden's model
         _, fam, seed, dims = name.split("_")
@@ -82,7 +104,26 @@ def _check(lib, path, expect_path=None):
 
 
 def test_goldens_are_there():
-    assert len(SMALL) == 13 and len(EMBEDDED) == 7
+    assert len(SMALL) == 13 and len(EMBEDDED) == 7 and os.path.exists(LATE)
+
+
+def test_oracle_finds_the_late_cycle(oracle_lib):
+    """6602 pivots, the repeated block starts at pivot 6581: the reference's own run (3 minutes under node)"""
+    _check(oracle_lib, LATE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["auto", "fused", "resident_general"])
+def test_hip_finds_the_late_cycle(hip_lib, mode, monkeypatch):
+    """default policy: the lean register-resident kernel, whose LDS holds the first 4096 pairs of the history only -- the pair
+    filter says "seen before", the suffix test reads the workgroup's global copy of the history; the streaming kernels; the general
+    resident build (LDS history of 10240 pairs)"""
+    if mode == "fused":
+        monkeypatch.setenv("JSLP_FORCE_PATH", "fused")
+    if mode == "resident_general":
+        monkeypatch.setenv("JSLP_RES_LEAN", "0")
+        monkeypatch.setenv("JSLP_FORCE_PATH", "resident")
+    _check(hip_lib, LATE, "fused" if mode == "fused" else "resident")
 
 
 @pytest.mark.parametrize("path", SMALL + EMBEDDED, ids=G.ident)
