@@ -1047,7 +1047,8 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             const bool lean_on = !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
             bool lean = lean_on && !unr;
 #define JSLP_RES_LAUNCH(T, C, R)                                                                                                    \
-    le = lean ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false, true>, dim3(rc.G), dim3(T), args, 0, s) \
+    le = lean ? (check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false, true, false, true>, dim3(rc.G), dim3(T), args, 0, s)  \
+                              : hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false, true, false, false>, dim3(rc.G), dim3(T), args, 0, s)) \
        : unr  ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, true>, dim3(rc.G), dim3(T), args, 0, s)        \
               : hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false>, dim3(rc.G), dim3(T), args, 0, s)
           resident_relaunch:
@@ -1055,7 +1056,8 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                 case 1:
                     if (e->n_opt > 0) {  // (resident_geometry admits optional objectives only here, and only for the lean build)
                         if (!lean) break;  // a hand-over the general build cannot take: the fused pipeline continues (below)
-                        le = hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2, 8, false, true, true>, dim3(rc.G), dim3(1024), args, 0, s);
+                        le = check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2, 8, false, true, true, true>, dim3(rc.G), dim3(1024), args, 0, s)
+                                          : hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2, 8, false, true, true, false>, dim3(rc.G), dim3(1024), args, 0, s);
                         break;
                     }
                     JSLP_RES_LAUNCH(1024, 2, 8);

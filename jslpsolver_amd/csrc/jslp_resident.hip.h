@@ -139,7 +139,7 @@ struct RSmem {
     // the lean kernel's JSLP_PIPE_LHIST pairs) and ends here.  A repeated block can only end at a pair that occurred before, so a
     // pair with a clear bit needs no suffix test at all (exact: bits are only ever set; a collision merely runs the test)
     unsigned cycbits_tail[JSLP_R_CYCEXTRA];
-    int32_t cyc_need;
+    int32_t cyc_need, cyc_filter_on;
 };
 
 // The leader's last FOUR waves gather every workgroup's summary of this epoch (all-gather with the data as the flag,
@@ -460,10 +460,15 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                 if (g < JSLP_F_MAXG * JSLP_R_GRAN) sm.gsum[g] = (unsigned)x[q];
             }
         } else if (sweeper) swept = sweep_summary(f, par, tag, tid - sweep0, sc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the row have reached the L2
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { end_code = 5; break; }
-        if (tid < THREADS / 64 && pubrow != 0) AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);  // every wave has drained: row is visible (one copy of the flag per fetching wave)
+        if (tid < THREADS / 64 && pubrow != 0) {
+            // ... and memory: the acknowledgement of a write-through store only means the XCD's L2 has it (jslp_resident_pipe.hip.h,
+            // "the winner releases its row"); this build decides later, so every publishing workgroup pays one buffer_wbl2 here
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);  // one copy of the flag per fetching wave
+        }
         RT_MARK(2);
         // ---- D: the leader decides (winner, unboundedness, cycle check) and broadcasts three tagged granules -----------
         int pr = 0, stop = 0;
@@ -893,7 +898,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
 
 // THREADS x CPT >= ld: <1024, 2> = lane pairs of columns, 4 waves per SIMD; <512, 4> = half the waves to synchronise,
 // twice the independent work per lane (and 256 VGPRs per lane).
-template <int THREADS, int CPT, int ROWS, bool UNR, bool LEAN = false, bool OPT = false>
+template <int THREADS, int CPT, int ROWS, bool UNR, bool LEAN = false, bool OPT = false, bool CHK = true>
 __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     static_assert(!(LEAN && UNR), "the lean kernel leaves unrestricted variables to the general one");
     static_assert(!OPT || LEAN, "optional objectives: lean builds only");
@@ -1001,14 +1006,14 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
         if (P2ONLY) {
             R.end_code = 5;  // never launched like this; if it were, the host rolls back and streams (like an aborted hand-off)
         } else {
-            if (LEAN) resident_phase1_pipe<THREADS, CPT, ROWS, OPT>(f, sm, R, it1_start, it2_start);
+            if (LEAN) resident_phase1_pipe<THREADS, CPT, ROWS, OPT, CHK>(f, sm, R, it1_start, it2_start);
             else resident_phase<1, THREADS, CPT, ROWS, UNR, LEAN>(f, sm, R, it1_start, it2_start, pb);
             if (R.end_code == 0) phase = 2;
         }
     }
     if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
         if (LEAN) {
-            resident_phase2_pipe<THREADS, CPT, ROWS, OPT>(f, sm, R, it1_start, it2_start, pb);  // (prices at the top of its loop)
+            resident_phase2_pipe<THREADS, CPT, ROWS, OPT, CHK>(f, sm, R, it1_start, it2_start, pb);  // (prices at the top of its loop)
         } else {
             R.pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg);
             if (R.pc == 0) R.end_code = 1;

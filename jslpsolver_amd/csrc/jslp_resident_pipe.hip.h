@@ -69,6 +69,20 @@
 // check-off ratio moves from 0.893 to 0.905 (r03_w), within the box-to-box spread; one wave for the whole test: 103 k (its ~76
 // dependent LDS reads late in a 9726-pivot solve outlast the row fetch).  Not kept.
 // ===================================================================================================================
+// -DJSLP_CHAOS_BUILD (tests / diagnosis only, never the shipped library): at every phase boundary of the pipelined loops one wave of
+// the workgroup -- a different one per pivot and boundary -- sleeps ~6 k cycles (JSLP_TEST_RESIDENT_LATE_WAVE0=2), and with =3 every
+// fifth workgroup sleeps ~4 k more: whatever in these loops relies on waves or workgroups arriving together shows up as lost pivots
+#ifdef JSLP_CHAOS_BUILD
+#undef RT_MARK
+#define RT_MARK(p)                                                                                                        \
+    do {                                                                                                                  \
+        if (f.test_late_wave0 >= 2) {                                                                                     \
+            const unsigned who_ = (R.epoch * 7u + (unsigned)(p) * 3u) % (unsigned)(THREADS / 64);                         \
+            if (__builtin_amdgcn_readfirstlane((int)((unsigned)(threadIdx.x >> 6) == who_))) __builtin_amdgcn_s_sleep(100); \
+            if (f.test_late_wave0 >= 3 && (R.epoch + (unsigned)(p)) % 5u == (unsigned)blockIdx.x % 5u) __builtin_amdgcn_s_sleep(60); \
+        }                                                                                                                 \
+    } while (0)
+#endif
 #define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
 #define JSLP_PIPE_KCHUNK 8    // pivot-column entries the update pass keeps in flight (registers: the tall / wide geometries have few to spare)
 
@@ -173,7 +187,9 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         }                                                                                                   \
     } while (0)
 
-template <int THREADS, int CPT, int ROWS, bool OPT>
+// CHK = false: a build without any of the cycle check's code (the host launches it when the check is off: with the test's loops
+// inlined in the middle of the pivot loop the check-OFF solve ran 2 % slower)
+template <int THREADS, int CPT, int ROWS, bool OPT, bool CHK>
 __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start,
                                                      const int (&pb)[CPT]) {
     const Ctx& c = f.c;
@@ -207,9 +223,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 
     // the seen-pair filter of the cycle check covers a history that starts here (a phase entered with pairs already in it -- not
     // something the hosts do -- keeps testing every pivot)
-    const bool cyc_filter = R.hist_n == 0;
-    int2* const my_hist = f.hist_all ? f.hist_all + (size_t)b * JSLP_PIPE_GHIST : nullptr;  // my own copy of the whole history
-    const int hist_room = my_hist ? JSLP_PIPE_GHIST : JSLP_PIPE_LHIST;
+    if (tid == 0) sm.cyc_filter_on = R.hist_n == 0 ? 1 : 0;  // (nothing of the cycle check stays in registers across the loop)
     for (int i = tid; i < JSLP_PIPE_CYCBITS / 32; i += THREADS) cyc_bits(sm)[i] = 0u;
     if (tid == 0) {
 #pragma unroll
@@ -222,7 +236,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         const bool has_pc_p = pend && colok && pc_p >= c0 && pc_p < c0 + CPT;
         // ---- exits that hand the tableau on (the pending update is applied behind the loop) ---------------------------------
         if ((R.it1 - it1_start) + (R.it2 - it2_start) >= f.iters_cap) { R.end_code = 4; break; }
-        if (c.check_cycles && !(R.hist_n < hist_room && R.hist_n < c.hist_cap)) { R.end_code = 8; break; }  // history outgrows its room: the general kernel continues
+        if ((CHK && c.check_cycles) && !(R.hist_n < (f.hist_all ? JSLP_PIPE_GHIST : JSLP_PIPE_LHIST) && R.hist_n < c.hist_cap)) { R.end_code = 8; break; }  // history outgrows its room: the general kernel continues
         const unsigned epoch = R.epoch;
         const int par = epoch & 1;
         const unsigned tag = epoch + 1;
@@ -389,10 +403,8 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; sm.part_rdeg[wv] = rdeg; }
         }
         RT_MARK(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my row stores are written through
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
-        if (tid < THREADS / 64 && pubrow != 0) AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);  // every wave has drained: the row is visible (one copy of the flag per fetching wave)
         RT_MARK(3);
         // ---- D: every thread folds the four partial results ------------------------------------------------------------------
         int pr = 0, stop = 0;
@@ -412,25 +424,41 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             else if (wr != 0) pr = wr;
             else stop = 3;  // unbounded (simplex.ts:298-303)
         }
-        if (!stop && c.check_cycles) {  // simplex.ts:305-320 by every workgroup, on its own LDS history
+        if (!stop && (CHK && c.check_cycles)) {  // simplex.ts:305-320 by every workgroup, on its own LDS history
             if (tid == 0) {
                 const int2 pair = make_int2(sm.lvibr[pr], sm.lvibc[pc]);
                 if (R.hist_n < JSLP_PIPE_LHIST) sm.lhist[R.hist_n] = pair;
-                if (my_hist) my_hist[R.hist_n] = pair;
+                if (f.hist_all) f.hist_all[(size_t)b * JSLP_PIPE_GHIST + R.hist_n] = pair;  // my own copy of the whole history
                 if (b == 0) c.hist[R.hist_n] = pair;  // the host's cycle message; the general kernel's history should this one outgrow its room
-                sm.cyc_need = cyc_filter ? cyc_pair_seen(sm, pair) : 1;
+                sm.cyc_need = sm.cyc_filter_on ? cyc_pair_seen(sm, pair) : 1;
             }
             __syncthreads();
             R.hist_n += 1;
             if (sm.cyc_need != 0) {  // (uniform) only a pair that occurred before can end a repeated block
-                if (cyc_suffix_is_square(sm.lhist, my_hist, R.hist_n, make_int2(sm.lvibr[pr], sm.lvibc[pc]), sm.f.red)) stop = 1;
+                if (cyc_suffix_is_square(sm.lhist, f.hist_all ? f.hist_all + (size_t)b * JSLP_PIPE_GHIST : nullptr, R.hist_n, make_int2(sm.lvibr[pr], sm.lvibc[pc]), sm.f.red)) stop = 1;
             }
         }
         if (stop == 3) { R.end_code = 2; R.unbounded_col = pc; break; }
         if (stop == 1) { R.end_code = 3; break; }
-        // ---- E: the winning row, loaded speculatively together with its flag (re-loaded in the rare case the flag was not up
-        //         yet); the lane that holds column pc broadcasts quot = A[pr, pc] --------------------------------------------------
+        // ---- the winner releases its row: ONLY the workgroup that holds row pr raises row flags, behind a real agent-scope release.
+        //      The acknowledgement of a write-through (sc1) store does NOT mean the data has reached memory -- only the XCD's L2:
+        //      with `s_waitcnt vmcnt(0)` alone in front of the flag stores, other XCDs saw the flag before the row about once in 10^5
+        //      pivots on the tall / wide shapes, whose lanes write partial lines (tools/resident_stress.py: 601 x 3001 wrong in 1 of
+        //      40 solves, 4001 x 2001 in 1 of 4, grid time-outs when the replicated cost rows diverged).  `buffer_wbl2 sc1` (what the
+        //      fence emits) closes that.  Issued by every wave of every workgroup it cost 30 us per pivot (the L2 serialises them);
+        //      by one wave of every publishing workgroup at the end of the gather 109 k pivots/s; by one wave of the ONE workgroup
+        //      whose row is going to be read, here, 139 k (155 k with the unsound release) ---------------------------------------------
         const int bw = pr / f.rpb;
+        if (bw == b) {  // (uniform: pr is the row I published -- my candidate was the chip's best)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the row have reached the L2
+            __syncthreads();
+            if (tid < THREADS / 64) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // buffer_wbl2 sc1 + s_waitcnt vmcnt(0): ... and memory
+                AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);  // one copy of the flag per fetching wave
+            }
+        }
+        // ---- E: the winning row: every wave waits for its copy of the flag and loads its columns; the lane that holds column pc
+        //         broadcasts quot = A[pr, pc] --------------------------------------------------------------------------------------
         const int off_in = par * pub_stride + (bw * ld + c0) * 8;
         const bool has_pc = colok && pc >= c0 && pc < c0 + CPT;
         double pv[CPT];
@@ -639,7 +667,7 @@ __device__ __forceinline__ u64_t u64_wave_max(u64_t x) {
 // atomicMin on the column among the lanes that hold that value.  Returns with R.end_code == 0 when phase 1 is over (feasible);
 // the tableau is whole again then.
 // ===================================================================================================================
-template <int THREADS, int CPT, int ROWS, bool OPT>
+template <int THREADS, int CPT, int ROWS, bool OPT, bool CHK>
 __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start) {
     const Ctx& c = f.c;
     const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -667,9 +695,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     unsigned& efetch = R.efetch;  // row fetches of this workgroup so far (uniform; one count for both phases: sm.okbad only grows)
     bool done = false;  // phase 1 is over: no row below -precision
 
-    const bool cyc_filter = R.hist_n == 0;  // (see phase 2)
-    int2* const my_hist = f.hist_all ? f.hist_all + (size_t)b * JSLP_PIPE_GHIST : nullptr;
-    const int hist_room = my_hist ? JSLP_PIPE_GHIST : JSLP_PIPE_LHIST;
+    if (tid == 0) sm.cyc_filter_on = R.hist_n == 0 ? 1 : 0;  // (see phase 2)
     for (int i = tid; i < JSLP_PIPE_CYCBITS / 32; i += THREADS) cyc_bits(sm)[i] = 0u;
     if (tid == 0) {
 #pragma unroll
@@ -681,7 +707,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     while (R.end_code == 0) {
         const bool has_pc_p = pend && colok && pc_p >= c0 && pc_p < c0 + CPT;
         if ((R.it1 - it1_start) + (R.it2 - it2_start) >= f.iters_cap) { R.end_code = 4; break; }
-        if (c.check_cycles && !(R.hist_n < hist_room && R.hist_n < c.hist_cap)) { R.end_code = 8; break; }
+        if ((CHK && c.check_cycles) && !(R.hist_n < (f.hist_all ? JSLP_PIPE_GHIST : JSLP_PIPE_LHIST) && R.hist_n < c.hist_cap)) { R.end_code = 8; break; }
         const unsigned epoch = R.epoch;
         const int par = epoch & 1;
         const unsigned tag = epoch + 1;
@@ -773,10 +799,8 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; }
         }
         RT_MARK(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
-        if (tid < THREADS / 64 && pubrow != 0) AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);
         RT_MARK(3);
         // ---- D ---------------------------------------------------------------------------------------------------------------
         int pr = 0;
@@ -794,8 +818,17 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             pr = wr;
         }
         if (pr == 0) { done = true; break; }  // no violated row: feasible (simplex.ts:51-54); uniform
-        // ---- E: the pivot row (= the winner's candidate row) -------------------------------------------------------------------
+        // ---- the winner releases its row (see phase 2) ---------------------------------------------------------------------------
         const int bw = pr / f.rpb;
+        if (bw == b) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid < THREADS / 64) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);
+            }
+        }
+        // ---- E: the pivot row (= the winner's candidate row) -------------------------------------------------------------------
         const int off_in = par * pub_stride + (bw * ld + c0) * 8;
         double pv[CPT];
 #pragma unroll
@@ -877,18 +910,18 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
         for (int o = 0; o < JSLP_R_MAXOPT; o++) ook[o] = OPT ? sm.ook[0][o] : 0.0;
         if (tid == 0) { sm.p_val = 0; sm.p_col = 0x7fffffff; }  // (everybody has read them; the next round is barriers away)
-        if (c.check_cycles) {  // simplex.ts:78-93 by every workgroup, on its own LDS history
+        if ((CHK && c.check_cycles)) {  // simplex.ts:78-93 by every workgroup, on its own LDS history
             if (tid == 0) {
                 const int2 pair = make_int2(sm.lvibr[pr], sm.lvibc[pc]);
                 if (R.hist_n < JSLP_PIPE_LHIST) sm.lhist[R.hist_n] = pair;
-                if (my_hist) my_hist[R.hist_n] = pair;
+                if (f.hist_all) f.hist_all[(size_t)b * JSLP_PIPE_GHIST + R.hist_n] = pair;  // my own copy of the whole history
                 if (b == 0) c.hist[R.hist_n] = pair;
-                sm.cyc_need = cyc_filter ? cyc_pair_seen(sm, pair) : 1;
+                sm.cyc_need = sm.cyc_filter_on ? cyc_pair_seen(sm, pair) : 1;
             }
             __syncthreads();
             R.hist_n += 1;
             if (sm.cyc_need != 0) {  // (uniform)
-                if (cyc_suffix_is_square(sm.lhist, my_hist, R.hist_n, make_int2(sm.lvibr[pr], sm.lvibc[pc]), sm.f.red)) { R.end_code = 3; break; }
+                if (cyc_suffix_is_square(sm.lhist, f.hist_all ? f.hist_all + (size_t)b * JSLP_PIPE_GHIST : nullptr, R.hist_n, make_int2(sm.lvibr[pr], sm.lvibc[pc]), sm.f.red)) { R.end_code = 3; break; }
             }
         }
         // ---- N: normalised pivot row (simplex.ts:352-364); the tiny entries simplex.ts:381-383 zeroes as soon as ANY other row
