@@ -469,23 +469,13 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
         for (int o = 0; o < JSLP_R_MAXOPT; o++) ook[o] = 0.0;
         {
-            // EVERY wave looks at the flag itself, before its own loads of the row, and repeats both on its own until the flag is up
+            // EVERY wave waits for its own copy of the flag, then loads its columns of the row
             // (see resident_phase's step E); a wave that gives up raises sm.okbad to this fetch's number
             efetch += 1;
             unsigned spins = 0;
             for (;;) {
                 if (__builtin_amdgcn_readfirstlane((int)(f.test_late_wave0 != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch; a scalar branch: s_sleep ignores EXEC)
                 const u64_t flag = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);
-                asm volatile("" ::: "memory");
-                if (colok) {
-#pragma unroll
-                    for (int j = 0; j < CPT; j += 2) {
-                        if (c0 + j >= ld) continue;
-                        const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + j * 8, 0, 16);
-                        pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
-                        pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
-                    }
-                }
                 if ((unsigned)flag == tag) break;  // (wave-uniform: one word, one request)
 #ifdef JSLP_DEBUG_RESIDENT
                 if (tid == 0) R.rt_retries += 1;
@@ -496,6 +486,17 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead = true;
                 if (spins > f.spin_limit) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead = true; }
                 if (dead) { if (lane == 0) atomicMax(&sm.okbad, efetch); break; }
+            }
+            asm volatile("" ::: "memory");
+            if (colok) {  // the row, now that MY look at the flag found it up (the flag comes late by construction -- only the winner raises
+                          // it, after the decision --, so loading the row next to it would only add 4 MB of dead traffic per look)
+#pragma unroll
+                for (int j = 0; j < CPT; j += 2) {
+                    if (c0 + j >= ld) continue;
+                    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + j * 8, 0, 16);
+                    pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
+                    pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
+                }
             }
             if (has_pc) {
 #pragma unroll
@@ -840,16 +841,6 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             for (;;) {
                 if (__builtin_amdgcn_readfirstlane((int)(f.test_late_wave0 != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch; a scalar branch: s_sleep ignores EXEC)
                 const u64_t flag = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);
-                asm volatile("" ::: "memory");
-                if (colok) {
-#pragma unroll
-                    for (int j = 0; j < CPT; j += 2) {
-                        if (c0 + j >= ld) continue;
-                        const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + j * 8, 0, 16);
-                        pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
-                        pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
-                    }
-                }
                 if ((unsigned)flag == tag) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
@@ -857,6 +848,17 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead = true;
                 if (spins > f.spin_limit) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead = true; }
                 if (dead) { if (lane == 0) atomicMax(&sm.okbad, efetch); break; }
+            }
+            asm volatile("" ::: "memory");
+            if (colok) {  // the row, now that MY look at the flag found it up (the flag comes late by construction -- only the winner raises
+                          // it, after the decision --, so loading the row next to it would only add 4 MB of dead traffic per look)
+#pragma unroll
+                for (int j = 0; j < CPT; j += 2) {
+                    if (c0 + j >= ld) continue;
+                    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + j * 8, 0, 16);
+                    pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
+                    pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
+                }
             }
             __syncthreads();
             if (sm.okbad == efetch) R.end_code = 5;
