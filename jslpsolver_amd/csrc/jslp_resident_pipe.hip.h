@@ -83,6 +83,9 @@
         }                                                                                                                 \
     } while (0)
 #endif
+#ifndef JSLP_PIPE_SPECPUB
+#define JSLP_PIPE_SPECPUB 1  // 1: every workgroup stores its candidate row while the summaries cross the fabric; 0: only the winner stores its row, after the decision (measured: config 3a 137 k against 143 k pivots/s, 4001x2001 105 k against 108 k, 2001x4001 91 k against 87 k)
+#endif
 #define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
 #define JSLP_PIPE_KCHUNK 8    // pivot-column entries the update pass keeps in flight (registers: the tall / wide geometries have few to spare)
 
@@ -357,7 +360,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
             for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) {
                 if (pend) JSLP_PIPE_UPDATE_ROW(i);
-                if (pubrow != 0 && r_begin + i == pubrow && colok) {  // (uniform but for colok)
+                if (JSLP_PIPE_SPECPUB && pubrow != 0 && r_begin + i == pubrow && colok) {  // (uniform but for colok)
                     const int off = par * pub_stride + (b * ld + c0) * 8;
 #pragma unroll
                     for (int j = 0; j < CPT; j += 2) {
@@ -450,6 +453,21 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         //      whose row is going to be read, here, 139 k (155 k with the unsound release) ---------------------------------------------
         const int bw = pr / f.rpb;
         if (bw == b) {  // (uniform: pr is the row I published -- my candidate was the chip's best)
+            if (!JSLP_PIPE_SPECPUB && colok) {  // the row leaves only now, and only from here: 16 KB per pivot instead of 4 MB of candidates
+#pragma unroll
+                for (int i = 0; i < ROWS; i++) {
+                    if (r_begin + i != pr) continue;  // (uniform)
+                    const int off = par * pub_stride + (b * ld + c0) * 8;
+#pragma unroll
+                    for (int j = 0; j < CPT; j += 2) {
+                        if (c0 + j >= ld) continue;
+                        const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
+                        v4u_t v;
+                        v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, 16);
+                    }
+                }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the row have reached the L2
             __syncthreads();
             if (tid < THREADS / 64) {
