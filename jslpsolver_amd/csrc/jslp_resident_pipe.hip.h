@@ -68,6 +68,8 @@
 // share the block lengths while the row loads of step E are in flight, twelve verdict words read under E's barrier: the check-on /
 // check-off ratio moves from 0.893 to 0.905 (r03_w), within the box-to-box spread; one wave for the whole test: 103 k (its ~76
 // dependent LDS reads late in a 9726-pivot solve outlast the row fetch).  Not kept.
+// Two looks in flight in the gather's poll and in the wait for the row flag (a look is a fabric round trip, so one at a time notices
+// the last summary half a round trip late on average): 140.0 k against 142.6 k -- the extra looks cost more than the earlier notice.
 // ===================================================================================================================
 // -DJSLP_CHAOS_BUILD (tests / diagnosis only, never the shipped library): at every phase boundary of the pipelined loops one wave of
 // the workgroup -- a different one per pivot and boundary -- sleeps ~6 k cycles (JSLP_TEST_RESIDENT_LATE_WAVE0=2), and with =3 every
