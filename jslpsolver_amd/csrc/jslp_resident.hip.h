@@ -671,7 +671,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
 #pragma unroll
         for (int j = 0; j < CPT; j++) pv[j] = 0.0;
         {
-            // EVERY wave looks at the flag itself, before its own loads of the row, and repeats both on its own until the flag is up: a
+            // EVERY wave waits for its own copy of the flag, then loads its columns of the row: a
             // row loaded by a wave that ran ahead of the wave holding thread 0 (a cold instruction cache is enough) used to be accepted
             // on thread 0's later look at the flag.  A flag seen up means the row's stores were acknowledged before the flag store was
             // issued; my loads of the row are issued after my load of the flag.  A wave that gives up raises sm.okbad to this fetch's
@@ -681,17 +681,6 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
             for (;;) {
                 if (__builtin_amdgcn_readfirstlane((int)(f.test_late_wave0 != 0 && (tid >> 6) == 0))) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch; a SCALAR branch -- s_sleep ignores EXEC, and predicated by EXEC alone it ran in every wave at every fetch: 157 k -> 102 k pivots/s)
                 const u64_t flag = AG_LOAD(f.rowflagc[par] + (tid >> 6) * JSLP_F_MAXG + bw);
-                asm volatile("" ::: "memory");
-                if (colok) {
-#pragma unroll
-                    for (int j = 0; j < CPT; j += 2) {
-                        if (c0 + j >= ld) continue;
-                        const v4u_t v = par ? __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off_in + j * 8, 0, 16)
-                                            : __builtin_amdgcn_raw_buffer_load_b128(rsrc0, off_in + j * 8, 0, 16);
-                        pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
-                        pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
-                    }
-                }
                 if ((unsigned)flag == tag) break;  // (wave-uniform: one word, one request)
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
@@ -699,6 +688,17 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                 if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead = true;
                 if (spins > f.spin_limit) { if ((tid & 63) == 0) AG_STORE(f.abort_flag, 1u); dead = true; }
                 if (dead) { if ((tid & 63) == 0) atomicMax(&sm.okbad, efetch); break; }
+            }
+            asm volatile("" ::: "memory");
+            if (colok) {  // the row, behind MY look at the flag (not next to it: the loads must not be served before the flag is)
+#pragma unroll
+                for (int j = 0; j < CPT; j += 2) {
+                    if (c0 + j >= ld) continue;
+                    const v4u_t v = par ? __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off_in + j * 8, 0, 16)
+                                        : __builtin_amdgcn_raw_buffer_load_b128(rsrc0, off_in + j * 8, 0, 16);
+                    pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
+                    pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
+                }
             }
             __syncthreads();
             if (sm.okbad == efetch) end_code = 5;
