@@ -408,6 +408,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; sm.part_rdeg[wv] = rdeg; }
         }
         RT_MARK(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2 (the winner's release below builds on it)
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
         RT_MARK(3);
@@ -452,7 +453,8 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         //      40 solves, 4001 x 2001 in 1 of 4, grid time-outs when the replicated cost rows diverged).  `buffer_wbl2 sc1` (what the
         //      fence emits) closes that.  Issued by every wave of every workgroup it cost 30 us per pivot (the L2 serialises them);
         //      by one wave of every publishing workgroup at the end of the gather 109 k pivots/s; by one wave of the ONE workgroup
-        //      whose row is going to be read, here, 139 k (155 k with the unsound release) ---------------------------------------------
+        //      whose row is going to be read, here, 139 k -- 149 k with the drain in front of the barrier that closes the gather instead of
+        //      a barrier of its own here (155 k with the unsound release) -------------------------------------------------------------
         const int bw = pr / f.rpb;
         if (bw == b) {  // (uniform: pr is the row I published -- my candidate was the chip's best)
             if (!JSLP_PIPE_SPECPUB && colok) {  // the row leaves only now, and only from here: 16 KB per pivot instead of 4 MB of candidates
@@ -470,9 +472,11 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                     }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the row have reached the L2
-            __syncthreads();
-            if (tid < THREADS / 64) {
+            if (!JSLP_PIPE_SPECPUB) {  // (stored a moment ago: wait for them here)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            if (tid < THREADS / 64) {  // (every wave's stores reached the L2 before the barrier that closed the gather)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // buffer_wbl2 sc1 + s_waitcnt vmcnt(0): ... and memory
                 AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);  // one copy of the flag per fetching wave
             }
@@ -820,6 +824,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; }
         }
         RT_MARK(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
         RT_MARK(3);
@@ -841,13 +846,9 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         if (pr == 0) { done = true; break; }  // no violated row: feasible (simplex.ts:51-54); uniform
         // ---- the winner releases its row (see phase 2) ---------------------------------------------------------------------------
         const int bw = pr / f.rpb;
-        if (bw == b) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid < THREADS / 64) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);
-            }
+        if (bw == b && tid < THREADS / 64) {  // (every wave's stores reached the L2 before the barrier that closed the gather)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);
         }
         // ---- E: the pivot row (= the winner's candidate row) -------------------------------------------------------------------
         const int off_in = par * pub_stride + (bw * ld + c0) * 8;
