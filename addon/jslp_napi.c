@@ -732,6 +732,8 @@ static napi_value fn_get_counters(napi_env env, napi_callback_info info) {
     SET_D("relaxations", (double)c.relaxations); SET_D("simplexCalls", (double)c.simplex_calls); SET_D("pivots", (double)c.pivots);
     SET_D("gatedCells", (double)c.gated_cells); SET_D("gatedRows", (double)c.gated_rows); SET_D("restoredRows", (double)c.restored_rows);
     SET_D("cutRows", (double)c.cut_rows); SET_D("heightSum", (double)c.height_sum);
+    SET_D("residentAborts", (double)c.resident_aborts); SET_D("residentHandovers", (double)c.resident_handovers);
+    SET_D("residentLaunches", (double)c.resident_launches);
     return o;
 }
 

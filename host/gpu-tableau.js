@@ -258,10 +258,14 @@ function flush(t) {
     const rhsColumn = t.rhsColumn;
     const matrix = t.matrix;
     const rowByVarIndex = t.rowByVarIndex;
+    const varIndexByRow = t.varIndexByRow;
     for (let v = 0; v < rowByVarIndex.length; v++) rowByVarIndex[v] = -1;
     for (let r = 0; r < H; r++) {
         matrix[r * width + rhsColumn] = st.rhs[r];
         const v = st.rows[r];
+        // (a compact commit -- commitWatched -- patched only the integer variables' rows of this map: copy(),
+        //  computeFractionalVolume and whoever else reads it after a flush must see the node's whole row map)
+        varIndexByRow[r] = v;
         if (v >= 0) rowByVarIndex[v] = r;
     }
     st.stale = false;

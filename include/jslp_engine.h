@@ -275,6 +275,12 @@ typedef struct jslp_work_counters {
     int64_t restored_rows;  /* rows copied back from the saved root / a checkpoint by restore()                      */
     int64_t cut_rows;       /* rows appended by addCutConstraints                                                    */
     int64_t height_sum;     /* sum over simplex calls of the tableau height (selection traffic = 8 x (W + 2H) per pivot) */
+    /* health of the register-resident kernels (counted whether or not counting is on; set_counting resets them too): a solve whose
+     * cooperative launch ended in a timed-out hand-off is rolled back and re-run through the streaming kernels -- the answer is
+     * still the reference's, but a non-zero count means the fast path failed and nobody would notice from the result alone */
+    int64_t resident_aborts;     /* register-resident launches rolled back (ERR_BARRIER inside the kernel)                  */
+    int64_t resident_handovers;  /* solves the lean resident kernel handed on mid-solve (cycle-check history beyond its room) */
+    int64_t resident_launches;   /* cooperative launches of k_simplex_resident that were accepted                           */
 } jslp_work_counters;
 int jslp_engine_set_counting(jslp_engine* e, int enabled); /* also resets the counters */
 int jslp_engine_get_counters(jslp_engine* e, jslp_work_counters* out);

@@ -46,7 +46,8 @@ class WorkCounters(C.Structure):
     """struct jslp_work_counters (include/jslp_engine.h)"""
 
     _fields_ = [(name, C.c_int64) for name in ("relaxations", "simplex_calls", "pivots", "gated_cells", "gated_rows",
-                                              "restored_rows", "cut_rows", "height_sum")]
+                                              "restored_rows", "cut_rows", "height_sum", "resident_aborts", "resident_handovers",
+                                              "resident_launches")]
 
     def as_dict(self):
         return {name: int(getattr(self, name)) for name, _ in self._fields_}

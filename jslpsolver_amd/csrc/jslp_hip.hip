@@ -104,6 +104,9 @@ struct jslp_engine {
     unsigned spin_limit = 0; int test_abort_epoch = -1; int test_late_wave0 = 0;
     int resident_fallbacks = 0;  // solves that were rolled back and re-run through the streaming kernels
     int resident_handovers = 0;  // solves the lean resident kernel handed to the general one (cycle-check history beyond its LDS copy)
+    int resident_launches = 0;   // cooperative launches of k_simplex_resident the runtime accepted
+    double dev_prev_evaluation = 0.0;  // jslp_engine_relax_batch_device: the evaluation its nodes started from (results_from_states)
+    int dev_prev_valid = 0;
     // checkpoints (incremental-branch-and-cut.ts:31-44): equally sized device buffers, recycled through a free list
     struct Ckpt {
         char* mem = nullptr;
@@ -120,6 +123,7 @@ struct jslp_engine {
     char* arena32 = nullptr;
     // policy
     int force_path = 0;  // 0 auto, 1 workgroup kernel, 2 select+update kernels only, 3 fused phase 2
+    int force_xl = 0, xl_on = 1;  // JSLP_FORCE_PATH=xl / JSLP_XL=0: the XCD-local register-resident geometry (resident_geometry 6)
     int force_resident = 0;  // JSLP_FORCE_PATH=resident: also the register-resident geometries the default policy leaves to the streaming kernels
     int32_t n_unr = 0;
     int nt = 0;  // JSLP_NT=1: non-temporal hints in the fused kernel
@@ -131,7 +135,7 @@ struct jslp_engine {
     DevState* f_st[2] = {nullptr, nullptr};
     // register-resident phase 2 (one cooperative launch): hand-off buffers
     u64_t* r_gran = nullptr;  // [2][G][8] granules then [2][G] row flags (one allocation, zeroed per launch)
-    u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr; int2* r_hist_all = nullptr;
+    u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr; int2* r_hist_all = nullptr; int r_want_hist = 0;
     int no_resident = 0;
     int res_cpt = 2;  // columns per lane of the resident kernel (JSLP_RES_CPT=2|4)
     int one_launch_nodes = 1;  // JSLP_NO_NODE_KERNEL=1: single children go through the five-launch sequence
@@ -430,6 +434,9 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     if (fp && !strcmp(fp, "sp")) e->force_path = 2;
     if (fp && !strcmp(fp, "fused")) { e->force_path = 3; e->no_resident = 1; }
     if (fp && !strcmp(fp, "resident")) { e->force_path = 3; e->force_resident = 1; }
+    if (fp && !strcmp(fp, "xl")) { e->force_path = 3; e->force_resident = 1; e->force_xl = 1; }  // the XCD-local resident geometry whatever the size (<= 1024 x 1024)
+    const char* xl = getenv("JSLP_XL");  // 0: never the XCD-local geometry (what round 3 shipped for these sizes)
+    e->xl_on = !(xl && xl[0] == '0');
     const char* nr = getenv("JSLP_NO_RESIDENT");
     if (nr && nr[0] == '1') e->no_resident = 1;
     const char* rcpt = getenv("JSLP_RES_CPT");
@@ -725,13 +732,18 @@ static size_t wglds_smem(const jslp_engine* e) {
 // LDS-resident one-workgroup kernel touches only the rows and columns the reference's gates let through (Monster LP, 1 %
 // dense: ~5 us per pivot against ~12 for the chip-wide register-resident kernel, whose hand-off latency does not shrink with
 // the work); dense tableaus of that size belong to the chip
+static bool xl_fits(const jslp_engine* e, int H);
 static const long long WG_CELLS_SPARSE = 1024LL * 1024;  // (Vendor Selection, 2.8 M cells, 0.3 % dense: 38.7 ms in one workgroup against 9.0 ms register-resident -- fill-in makes its pivots touch hundreds of rows)
 static const double WG_SPARSE_DENSITY = 0.05;
 static bool use_wg_single(const jslp_engine* e) {
     if (e->force_path == 1) return true;
     if (e->force_path == 2 || e->force_path == 3) return false;
     const long long cells = (long long)e->cap_rows * e->ld;
+    if (e->force_xl) return false;
     if (cells <= WG_CELLS_SINGLE) return true;
+    // (sparse mid-size LPs used to stay in one workgroup -- ~7 us per pivot of dependent global trips; the XCD-local resident
+    //  geometry takes them now whatever their density)
+    if (xl_fits(e, e->cap_rows) && !e->no_resident && e->force_path == 0) return false;
     return wglds_smem(e) != 0 && cells <= WG_CELLS_SPARSE && e->nnz >= 0 &&
            (double)e->nnz <= WG_SPARSE_DENSITY * (double)e->H0 * (double)e->W;
 }
@@ -747,12 +759,20 @@ static bool fused_eligible(const jslp_engine* e) {
 //   1: <1024, 2, 8>   ld <= 2048, H <= 2048 (the headline shape)      2: <512, 4, 8>  (JSLP_RES_CPT=4, measured slower)
 //   3: <512, 4, 16>   ld <= 2048, H <= 4096                            4: <512, 6, 12> ld <= 3072, H <= 3072 (3001 x 3001: 72 MB)
 //   5: <512, 8, 8>    ld <= 4096, H <= 2048
+//   6: <512, 2, 32> XL ld <= 1024, H <= 1024, on the <= 32 workgroups of ONE XCD (round 4): the hand-offs of a pivot go through
+//      that XCD's L2 instead of memory.  Mid-size tableaus: Monster LP 625 x 553, Monster_II's root 945 x 925, 501 x 501 ...
 // (256-lane geometries -- ONE wave per SIMD, 512 registers per lane: <256, 8, 8> compiles without a spill -- were measured and
 //  dropped: 72.5 k against 105.7 k pivots/s on a 2001 x 2001 LP, 17.4 k on 4001 x 2001, r02_z: a lone wave per SIMD does not hide
 //  its own instruction latency)
+static bool xl_fits(const jslp_engine* e, int H) {
+    return e->xl_on && e->n_unr == 0 && e->n_opt == 0 && e->ld <= 1024 && H <= JSLP_XL_MAXG * JSLP_R_MAXROWS && e->precision >= 1e-15 &&
+           !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
+}
 static int resident_geometry(const jslp_engine* e, int H) {
     if (e->no_resident || e->force_path == 2 || e->precision < 1e-15) return 0;  // (see k_pivot_fused for the precision condition)
     const int rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
+    // (JSLP_FORCE_PATH=resident keeps meaning the chip-wide geometries: the tests that force them at small sizes must keep covering them)
+    if (xl_fits(e, H) && !getenv("JSLP_RES_GEOM") && (e->force_xl || !e->force_resident)) return 6;
     if (e->n_opt > 0) {
         // optional objectives: the lean build of the headline geometry keeps up to three rows of them in registers (round 3);
         // everything else (unrestricted variables, taller / wider tableaus, more rows) runs them through the fused pipeline
@@ -786,15 +806,19 @@ static int resident_geometry(const jslp_engine* e, int H) {
 }
 static bool resident_eligible(const jslp_engine* e, int H) { return resident_geometry(e, H) != 0; }
 
-static int ensure_resident(jslp_engine* e) {
-    if (e->r_sync) return JSLP_OK;
+static int ensure_resident(jslp_engine* e, bool want_hist = false) {
+    // (`want_hist`: the lean kernel's per-workgroup copies of the cycle-check history, 256 MiB -- carved only once a solve with the
+    //  cycle check on takes the lean build: pool members, short-lived engines and check-off solves never pay for it)
+    if (want_hist) e->r_want_hist = 1;
+    if (e->r_sync && (!e->r_want_hist || e->r_hist_all)) return JSLP_OK;
+    if (e->r_sync) HIPC(hipStreamSynchronize(e->stream));  // re-carving: nothing in flight may still use the old layout
     // hand-off buffers and the safety-net copy of slot 0 (matrix, maps, state) carved from ONE allocation, which the
     // resource pool hands from engine to engine (hipMalloc / hipFree of these cost a small Solve more than its pivots)
     for (int pass = 0; pass < 2; pass++) {
         Carver cv{pass ? e->r_arena : nullptr, 0};
         e->r_gran = cv.take<u64_t>(JSLP_R_SYNC_WORDS);
         for (int i = 0; i < 2; i++) e->r_rows[i] = cv.take<u64_t>((size_t)JSLP_F_MAXG * e->ld);
-        e->r_hist_all = cv.take<int2>((size_t)JSLP_F_MAXG * JSLP_PIPE_GHIST);  // every workgroup's own copy of the cycle-check history (lean kernel)
+        e->r_hist_all = e->r_want_hist ? cv.take<int2>((size_t)JSLP_F_MAXG * JSLP_PIPE_GHIST) : nullptr;  // every workgroup's own copy of the cycle-check history (lean kernel)
         e->r_sync = cv.take<unsigned>(16);
         e->rb_A = cv.take<double>((size_t)e->cap_rows * e->ld);
         e->rb_vibr = cv.take<int32_t>((size_t)e->cap_rows);
@@ -987,7 +1011,8 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
         const int geometry = resident_geometry(e, H);
         // `it_before`: pivots the solve had done when the kernel is launched (0, or a phase 1 done by the fused pipeline)
         auto run_resident = [&](long long it_before) -> int {
-            int r = ensure_resident(e);
+            const bool lean_on = !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
+            int r = ensure_resident(e, lean_on && e->n_unr == 0 && check_cycles != 0);
             if (r) return r;
             ResCtx rc;
             rc.c = c;
@@ -1007,8 +1032,9 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             for (int i = 0; i < 2; i++) rc.rowflagc[i] = e->r_gran + JSLP_R_SYNC_WORDS_GENERAL + 2 * JSLP_F_MAXG * 8 + (size_t)i * JSLP_R_FLAGCOPIES * JSLP_F_MAXG;
             rc.abort_flag = e->r_sync + 4;
             HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * JSLP_R_SYNC_WORDS, s));  // tags restart at 1
-            rc.rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
-            if (const char* rx = getenv("JSLP_RES_RPB")) {  // experiments: more rows per workgroup = fewer workgroups (<= the geometry's rows)
+            rc.census = e->r_gran + JSLP_R_SYNC_WORDS - JSLP_F_MAXG;
+            rc.rpb = geometry == 6 ? (H + JSLP_XL_MAXG - 1) / JSLP_XL_MAXG : (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
+            if (const char* rx = getenv("JSLP_RES_RPB"); rx && geometry != 6) {  // experiments: more rows per workgroup = fewer workgroups (<= the geometry's rows)
                 static const int rows_of[6] = {0, 8, 8, 16, 12, 8};
                 const int want = atoi(rx);
                 if (want > rc.rpb && want <= rows_of[geometry]) rc.rpb = want;
@@ -1044,7 +1070,6 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             // The LEAN build (all-gather protocol only, software-pipelined phase 2: jslp_resident_pipe.hip.h) takes every solve
             // without unrestricted variables; should its cycle-check history outgrow LDS it hands the solve over (status
             // ST_RUNNING / ST_PHASE1_DONE instead of ST_DONE) and the general build continues it in a second launch.
-            const bool lean_on = !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
             bool lean = lean_on && !unr;
 #define JSLP_RES_LAUNCH(T, C, R)                                                                                                    \
     le = lean ? (check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false, true, false, true>, dim3(rc.G), dim3(T), args, 0, s)  \
@@ -1066,14 +1091,21 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                 case 3: JSLP_RES_LAUNCH(512, 4, 16); break;
                 case 4: JSLP_RES_LAUNCH(512, 6, 12); break;
                 case 5: JSLP_RES_LAUNCH(512, 8, 8); break;
+                case 6:  // XCD-local: every JSLP_XL_SPREAD-th block of the grid works (all of them on one XCD), the others return at once
+                    if (!lean) break;  // (a hand-over the general build cannot take at this geometry: the streaming kernels continue)
+                    le = check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 2, 32, false, true, false, true, true>, dim3(JSLP_XL_SPREAD * rc.G), dim3(512), args, 0, s)
+                                      : hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 2, 32, false, true, false, false, true>, dim3(JSLP_XL_SPREAD * rc.G), dim3(512), args, 0, s);
+                    break;
             }
 #undef JSLP_RES_LAUNCH
+            if (le == hipSuccess) e->resident_launches += 1;
             if (le == hipSuccess && lean) {  // did the lean kernel finish the solve?
                 HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
                 HIPC(hipStreamSynchronize(s));
                 if (e->h_state->err == ERR_NONE && e->h_state->status != ST_DONE) {
                     e->resident_handovers += 1;
-                    if (e->n_opt > 0) {
+                    if (e->n_opt > 0 || geometry == 6) {
+                        // (XCD-local geometry: there is no general build of it)
                         // optional objectives: the general build does not take them -- the streaming kernels continue from the state the
                         // lean kernel left (tableau, maps and objective rows written back; status ST_RUNNING or ST_PHASE1_DONE)
                         handed_to_streaming = true;
@@ -1098,10 +1130,15 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                     // roll slot 0 back to its state before the launch and solve through the streaming kernels instead
                     hipLaunchKernelGGL(k_res_backup, dim3(copy_grid(e, 1).x), dim3(256), 0, s, e->s, bk, e->r_backup_st, H, 0);
                     HIPC(hipGetLastError());
+                    // ... and the host's copy of the state with it: the streaming loops below start from what h_state says (the tall /
+                    // wide geometries come here with ST_PHASE1_DONE: without this the aborted kernel's ST_DONE + ERR_BARRIER ended the
+                    // solve as a device error instead of finishing it through k_pivot_fused)
+                    HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+                    HIPC(hipStreamSynchronize(s));
                     e->resident_fallbacks += 1;
                 } else {
                 resident_done = true;
-                e->last_path = "resident";
+                e->last_path = geometry == 6 ? "resident-xl" : "resident";
                 if (e->counting) {  // a dense streaming update touches every cell: rows x columns per pivot
                     const long long piv = (long long)e->h_state->it1 + e->h_state->it2;
                     e->wc.gated_cells += piv * (long long)(H - 1) * e->W;
@@ -1127,7 +1164,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
         // phase 2 does (4 scratch loads per pivot): phase 1 goes through the fused pipeline first, which hands over with
         // ST_PHASE1_DONE.  r03_j: 4001 x 2001 113.4 k pivots/s against 35.7 k fused, 2501 x 2001 128.6 k against 48.5 k,
         // 2001 x 4001 75.5 k against 34.8 k.
-        const bool resident_phase2_only = geometry >= 3;
+        const bool resident_phase2_only = geometry >= 3 && geometry != 6;  // (6 = XCD-local: the whole solve, like the headline geometry)
         if (geometry != 0 && !resident_phase2_only) {
             int r = run_resident(0);
             if (r) return r;
@@ -1723,6 +1760,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
                             double* rhs, int32_t* var_index_by_row, int32_t out_stride, int pinned, int want_rhs,
                             int want_rows, int checkpoint = -1, int compact = 0) {
     const bool dev_out = e && e->dev_states != nullptr;  // outcomes stay on the device (jslp_engine_relax_batch_device)
+    if (e && !dev_out) e->dev_prev_valid = 0;
     if (!e || n_nodes < 0 || !cut_offsets || (!out && !dev_out)) return fail(JSLP_ERR_ARG, "relax_batch: null pointer");
     if (!e->uploaded) return fail(JSLP_ERR_STATE, "relax before upload");
     if (compact && (e->n_watch <= 0 || e->n_watch > e->cap_rows))
@@ -1967,7 +2005,29 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         if (hipEventElapsedTime(&ms, e->ev_begin, e->ev_end) == hipSuccess) e->total_ms += ms;
     }
     if (e->counting) e->wc.cut_rows += cut_offsets[n_nodes];
-    if (dev_out) return JSLP_OK;  // the records are converted (and their error fields checked) by jslp_engine_results_from_states
+    if (dev_out) {
+        // the outcomes stay on the device (the caller converts the gathered records with jslp_engine_results_from_states), but the
+        // engine's own bookkeeping must not depend on where they went: the 128-byte records of THIS call come back (n x 128 B) so
+        // that a node that ended in an error clears the slot-sync flags (later one-launch / copy-on-write batches must not start
+        // from slots it left dirty), the work counters see the pivots, and the engine's evaluation is the last node's
+        HIPC(hipMemcpy(e->h_states, e->dev_states, sizeof(DevState) * (size_t)n_nodes, hipMemcpyDeviceToHost));
+        e->dev_prev_evaluation = prev_eval;  // what results_from_states hands a node that reaches no optimum (as the host path does)
+        e->dev_prev_valid = 1;
+        for (int i = 0; i < n_nodes; i++) {
+            const DevState& st = e->h_states[i];
+            rc = state_error(st);
+            if (rc) { e->slot0_synced = 0; e->slots_synced = 0; return rc; }
+            account(e, st, 1);
+            if (i == n_nodes - 1) {
+                jslp_simplex_result last;
+                DevState rec = st;
+                rec.hist_n = 0;
+                rc = fill_result(e, rec, 0, prev_eval, &last, &e->evaluation);
+                if (rc) return rc;
+            }
+        }
+        return JSLP_OK;
+    }
     for (int i = 0; i < n_nodes; i++) {
         DevState st = e->h_states[i];
         rc = state_error(st);
@@ -2030,7 +2090,7 @@ extern "C" int jslp_engine_results_from_states(jslp_engine* e, const void* state
         if (rc) return rc;
         rec.hist_n = 0;
         double ev;
-        rc = fill_result(e, rec, 0, e->evaluation, &out[i], &ev);
+        rc = fill_result(e, rec, 0, e->dev_prev_valid ? e->dev_prev_evaluation : e->evaluation, &out[i], &ev);
         if (rc) return rc;
     }
     return JSLP_OK;
@@ -2136,12 +2196,16 @@ extern "C" int jslp_engine_set_counting(jslp_engine* e, int enabled) {
     e->counting = enabled ? 1 : 0;
     e->s.cnt = enabled ? e->d_cnt : nullptr;
     e->wc = jslp_work_counters{};
+    e->resident_fallbacks = e->resident_handovers = e->resident_launches = 0;
     return JSLP_OK;
 }
 
 extern "C" int jslp_engine_get_counters(jslp_engine* e, jslp_work_counters* out) {
     if (!e || !out) return fail(JSLP_ERR_ARG, "get_counters: null pointer");
     *out = e->wc;
+    out->resident_aborts = e->resident_fallbacks;
+    out->resident_handovers = e->resident_handovers;
+    out->resident_launches = e->resident_launches;
     if (e->d_cnt) {
         HIPC(hipSetDevice(e->device));
         HIPC(hipStreamSynchronize(e->stream));
@@ -2467,6 +2531,7 @@ extern "C" int jslp_pool_get_counters(jslp_pool* p, jslp_work_counters* out) {
         sum.relaxations += c.relaxations; sum.simplex_calls += c.simplex_calls; sum.pivots += c.pivots;
         sum.gated_cells += c.gated_cells; sum.gated_rows += c.gated_rows; sum.restored_rows += c.restored_rows;
         sum.cut_rows += c.cut_rows; sum.height_sum += c.height_sum;
+        sum.resident_aborts += c.resident_aborts; sum.resident_handovers += c.resident_handovers; sum.resident_launches += c.resident_launches;
     }
     hipSetDevice(p->members[0]->device);
     *out = sum;

@@ -20,7 +20,10 @@
 // hipLaunchCooperativeKernel (all workgroups co-resident).
 // ===================================================================================================
 #define JSLP_R_ROWS 8       // rows per workgroup of the default geometry (H <= 8 * 256)
-#define JSLP_R_MAXROWS 16   // ... of the tall geometry (512 lanes x 4 columns x 16 rows: H <= 16 * 256)
+#define JSLP_R_MAXROWS 32   // ... of the XCD-local geometry (512 lanes x 2 columns x 32 rows on <= 32 workgroups of ONE XCD: H <= 1024); the tall chip-wide geometry keeps 16 (512 lanes x 4 columns x 16 rows: H <= 16 * 256)
+#define JSLP_R_MAXH (16 * JSLP_F_MAXG)  // tallest tableau any geometry takes (the LDS copy of the row map)
+#define JSLP_XL_MAXG 32      // workgroups of the XCD-local geometry: the CUs of one XCD
+#define JSLP_XL_SPREAD 8     // ... launched as every 8th block of the grid (observed dispatch: block b -> XCD b % 8; the kernel checks it)
 #define JSLP_R_GRAN 8        // 8-byte granules per workgroup summary (7 used)
 #define JSLP_R_LDMAX 4096    // widest padded row any geometry takes (512 lanes x 8 columns)
 #define JSLP_R_LUNR 8192     // variable indexes whose unrestricted flag fits the LDS copy (more: gather-by-leader protocol)
@@ -37,7 +40,7 @@
 // 32 words of decision / verdict, then the lean kernel's [2][G] 16-byte summary granules (JSLP_G16_STRIDE bytes apart)
 #define JSLP_R_SYNC_WORDS_GENERAL (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32)
 #define JSLP_R_FLAGCOPIES 16  // copies of every row flag, one per fetching wave (2 KB apart: 4096 waves reading ONE word per pivot is a hot spot)
-#define JSLP_R_SYNC_WORDS (JSLP_R_SYNC_WORDS_GENERAL + 2 * JSLP_F_MAXG * 8 + 2 * JSLP_R_FLAGCOPIES * JSLP_F_MAXG)  // (+ the lean kernel's granules, 64 bytes apart; + the row-flag copies)
+#define JSLP_R_SYNC_WORDS (JSLP_R_SYNC_WORDS_GENERAL + 2 * JSLP_F_MAXG * 8 + 2 * JSLP_R_FLAGCOPIES * JSLP_F_MAXG + JSLP_F_MAXG)  // (+ the lean kernel's granules, 64 bytes apart; + the row-flag copies; + the XCD-local build's placement census)
 #ifndef JSLP_RES_FAST
 #define JSLP_RES_FAST 1      // one barrier around the row flag (step E); the -k/quot entries of the pivot column computed by eight lanes in parallel while the winning row is in flight instead of one after the other by the lane that owns the column (step F)
 #endif
@@ -80,6 +83,7 @@ struct ResCtx {
     u64_t* gor[2];        // [G] rare slow path: tagged per-workgroup flags for a chip-wide OR
     int2* hist_all;       // [G][JSLP_PIPE_GHIST] every workgroup's own copy of the cycle-check history (lean kernel; nullptr: LDS part only)
     u64_t* gran16;        // [2][MAXG] 16-byte summary granules of the lean kernel's pipelined phase 2, 64 bytes apart (jslp_resident_pipe.hip.h)
+    u64_t* census;        // [MAXG] XCD-local build: {0xA5A5A5A5 | XCC id} of every participating workgroup, written once per launch
     int32_t G, rpb, H;
     int32_t n_idx;             // variable indexes in use (the LDS copy of the unrestricted flags covers JSLP_R_LUNR of them)
     int32_t iters_cap;
@@ -131,7 +135,7 @@ struct RSmem {
     // row / column maps (swapped at every pivot like the global ones), the unrestricted flag of every variable index, and the
     // cycle-check history (the first JSLP_R_LHIST entries; a longer solve continues with the leader protocol, whose check
     // reads the global history workgroup 0 has been mirroring all along)
-    int32_t lvibr[JSLP_R_MAXROWS * JSLP_F_MAXG];
+    int32_t lvibr[JSLP_R_MAXH];
     int32_t lvibc[JSLP_R_LDMAX];
     uint8_t lunr[JSLP_R_LUNR];
     int2 lhist[JSLP_R_LHIST];
@@ -246,8 +250,8 @@ __device__ __forceinline__ void reset_reductions(RSmem& sm) {  // one thread, be
 
 // Chip-wide OR of one flag per workgroup (rare slow path of phase 1, see the lazily-zeroed pivot-row entries):
 // every workgroup publishes a tagged granule and polls everybody else's.  Returns -1 on abort.
-__device__ __forceinline__ int global_or(const ResCtx& f, int par, unsigned tag, int flag, RSmem& sm) {
-    const int tid = threadIdx.x, b = blockIdx.x;
+__device__ __forceinline__ int global_or(const ResCtx& f, int par, unsigned tag, int flag, RSmem& sm, int b) {
+    const int tid = threadIdx.x;
     if (tid == 0) AG_STORE(f.gor[par] + b, ((u64_t)tag << 32) | (unsigned)(flag ? 1 : 0));
     int mine = 0, ok = 1;
     if (tid < f.G) {
@@ -810,7 +814,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
                 const int r = r_begin + i;
                 if (r < r_end && r != pr && nonzero16(sm.col[i])) local_any = 1;
             }
-            const int g = global_or(f, par, tag, local_any, sm);
+            const int g = global_or(f, par, tag, local_any, sm, b);
             if (g < 0) { end_code = 5; break; }
             anyrow = g != 0;
         }
@@ -898,9 +902,16 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
 
 // THREADS x CPT >= ld: <1024, 2> = lane pairs of columns, 4 waves per SIMD; <512, 4> = half the waves to synchronise,
 // twice the independent work per lane (and 256 VGPRs per lane).
-template <int THREADS, int CPT, int ROWS, bool UNR, bool LEAN = false, bool OPT = false, bool CHK = true>
+// XL = the XCD-LOCAL build (round 4): tableaus of up to 1024 x 1024 (8 MB: the 16 MB of vector registers of ONE XCD take them) on
+// <= 32 workgroups that all sit on the same XCD -- the grid is JSLP_XL_SPREAD x G blocks of which every 8th works (observed
+// dispatch: block b runs on XCD b % 8; HIP promises nothing, so the participants compare their XCC ids once per launch and give
+// up -- ERR_BARRIER: the host rolls back and takes another path -- when they differ).  Same loops, same arithmetic; what changes
+// is the transport (jslp_resident_pipe.hip.h, `XL`): the XCD's own L2 instead of memory, no write-back fence.
+template <int THREADS, int CPT, int ROWS, bool UNR, bool LEAN = false, bool OPT = false, bool CHK = true, bool XL = false>
 __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     static_assert(!(LEAN && UNR), "the lean kernel leaves unrestricted variables to the general one");
+    static_assert(!XL || LEAN, "XCD-local transport: lean builds only");
+    if (XL && (blockIdx.x % JSLP_XL_SPREAD) != 0) return;  // (the seven blocks in between only steer the dispatcher)
     static_assert(!OPT || LEAN, "optional objectives: lean builds only");
     static_assert(ROWS <= JSLP_R_MAXROWS, "RSmem holds one entry per row of the workgroup");
     static_assert(sizeof(RSmem) <= 160 * 1024, "one workgroup per CU: all of the CU's LDS, no more");
@@ -912,13 +923,17 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     R.rt_prev = __builtin_amdgcn_s_memtime();
 #endif
     const Ctx& c = f.c;
-    const int tid = threadIdx.x, b = blockIdx.x;
+    const int tid = threadIdx.x, b = XL ? (int)(blockIdx.x / JSLP_XL_SPREAD) : (int)blockIdx.x;
     const int ld = c.ld, H = f.H;
     const int c0 = tid * CPT;
     const bool colok = c0 < ld;
     const int r_begin = b * f.rpb, r_end = min(H, r_begin + f.rpb);
     DevState* st = c.st;
     static_assert(CPT % 2 == 0, "lanes load and store their columns as 16-byte pairs");
+    if (XL && tid == 0) {  // placement census, first half: my XCC id leaves now (write-through: correct wherever the others sit), read below
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xfu;  // HW_REG_XCC_ID[3:0]
+        AG_STORE(f.census + b, (0xA5A5A5A5ull << 32) | xcc);
+    }
 
     // ---- load my rows and the cost row into registers ---------------------------------------------------
     double (&a)[ROWS][CPT] = R.a;
@@ -998,22 +1013,42 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     R.unbounded_col = 0;
     R.epoch = 0;
     R.efetch = 0;
+    if (XL) {  // placement census, second half: every participant sits on MY XCD, or nobody starts (plain stores into one XCD's L2 are
+               // invisible from another: the loops below would read stale summaries)
+        int same = 1;
+        if (tid < f.G) {
+            const unsigned mine = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xfu;
+            unsigned spins = 0;
+            for (;;) {
+                const u64_t x = AG_LOAD(f.census + tid);
+                if ((unsigned)(x >> 32) == 0xA5A5A5A5u) { same = ((unsigned)x & 0xfu) == mine ? 1 : 0; break; }
+                __builtin_amdgcn_s_sleep(JSLP_POLL_SLEEP);
+                ++spins;
+                if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { same = 0; break; }
+                if (spins > f.spin_limit) { AG_STORE(f.abort_flag, 1u); same = 0; break; }
+            }
+        }
+        if (!__syncthreads_and(same)) {
+            if (tid == 0) AG_STORE(f.abort_flag, 1u);
+            R.end_code = 5;
+        }
+    }
     // The lean build of the tall / wide geometries is a phase-2 kernel: the host runs their phase 1 through the fused pipeline
     // (run_simplex), the phase-1 loop is not even compiled for them (next to 64-72 MB of tableau it does not fit the registers: it
     // spilled ~0.5 KB per lane, and r03_j saw a 3001 x 3001 solve go wrong after ONE pass through that spilling code).
-    constexpr bool P2ONLY = LEAN && (ROWS > JSLP_R_ROWS || CPT > 4);
-    if (phase == 1) {
+    constexpr bool P2ONLY = LEAN && !XL && (ROWS > JSLP_R_ROWS || CPT > 4);
+    if (phase == 1 && R.end_code == 0) {
         if (P2ONLY) {
             R.end_code = 5;  // never launched like this; if it were, the host rolls back and streams (like an aborted hand-off)
         } else {
-            if (LEAN) resident_phase1_pipe<THREADS, CPT, ROWS, OPT, CHK>(f, sm, R, it1_start, it2_start);
+            if (LEAN) resident_phase1_pipe<THREADS, CPT, ROWS, OPT, CHK, XL>(f, sm, R, it1_start, it2_start);
             else resident_phase<1, THREADS, CPT, ROWS, UNR, LEAN>(f, sm, R, it1_start, it2_start, pb);
             if (R.end_code == 0) phase = 2;
         }
     }
     if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
         if (LEAN) {
-            resident_phase2_pipe<THREADS, CPT, ROWS, OPT, CHK>(f, sm, R, it1_start, it2_start, pb);  // (prices at the top of its loop)
+            resident_phase2_pipe<THREADS, CPT, ROWS, OPT, CHK, XL>(f, sm, R, it1_start, it2_start, pb);  // (prices at the top of its loop)
         } else {
             R.pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg);
             if (R.pc == 0) R.end_code = 1;

@@ -194,11 +194,17 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
 
 // CHK = false: a build without any of the cycle check's code (the host launches it when the check is off: with the test's loops
 // inlined in the middle of the pivot loop the check-OFF solve ran 2 % slower)
-template <int THREADS, int CPT, int ROWS, bool OPT, bool CHK>
+template <int THREADS, int CPT, int ROWS, bool OPT, bool CHK, bool XL = false>
 __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start,
                                                      const int (&pb)[CPT]) {
     const Ctx& c = f.c;
-    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, b = XL ? (int)(blockIdx.x / JSLP_XL_SPREAD) : (int)blockIdx.x, lane = tid & 63, wv = tid >> 6;
+    // XL (XCD-local build): all <= 32 workgroups sit on ONE XCD (checked at launch: k_simplex_resident's census), whose L2 is their
+    // common point of coherence -- summaries, candidate rows and row flags leave as PLAIN stores (they stay in that L2; `sc1` stores
+    // would drop the line and send the readers to memory) and are read with `sc1` loads (L1-bypassing, L2-served); no write-back
+    // fence anywhere (tools/micro/xcd_handoff_bench.hip flavour 1: 1.9 k cycles per 32 -> 32 exchange against 8.3 k chip-wide)
+    constexpr int ST_AUX = XL ? 0 : 16;           // aux of the hand-off stores: 16 = sc1 (write-through to memory)
+    constexpr int NPOLLW = XL ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
     const int c0 = tid * CPT;
@@ -317,7 +323,9 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0x4E, 0xf, 0xf, false));
             brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0x141, 0xf, 0xf, false));
             brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0x140, 0xf, 0xf, false));
-            brdeg = __builtin_amdgcn_readlane(brdeg, 0);  // (ROWS <= 16: the candidates sit in the first 16-lane row)
+            brdeg = ROWS > 16 ? min(__builtin_amdgcn_readlane(brdeg, 0), __builtin_amdgcn_readlane(brdeg, 16))
+                              : __builtin_amdgcn_readlane(brdeg, 0);  // (ROWS <= 16: the candidates sit in the first 16-lane row; <= 32: in the first two)
+            static_assert(ROWS <= 32, "the summary's DPP folds cover two 16-lane rows");
             KI bk;  // quotients are > precision > 0: positive doubles order like their bit patterns; ties -> first row
             bk.k = kind == 2 ? (u64_t)__double_as_longlong(quo) : KI_NONE_KEY;
             bk.i = kind == 2 ? r : 0x7fffffff;
@@ -326,7 +334,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             bk = ki_min(bk, ki_dpp<0x4E>(bk));
             bk = ki_min(bk, ki_dpp<0x141>(bk));
             bk = ki_min(bk, ki_dpp<0x140>(bk));
-            bk = ki_readlane(bk, 0);
+            bk = ROWS > 16 ? ki_min(ki_readlane(bk, 0), ki_readlane(bk, 16)) : ki_readlane(bk, 0);
             if (lane == 0) {
                 const bool deg = brdeg != 0x7fffffff;
                 const bool have = bk.k != KI_NONE_KEY;
@@ -337,7 +345,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 g.y = tag;
                 g.z = (unsigned)(qb >> 32);
                 g.w = ((tag & 0xffffu) << 16) | (deg ? 0x8000u : 0u) | (unsigned)row;
-                __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_g16, (par * JSLP_F_MAXG + b) * JSLP_G16_STRIDE, 0, 16);  // aux 16 = sc1
+                __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_g16, (par * JSLP_F_MAXG + b) * JSLP_G16_STRIDE, 0, ST_AUX);
                 sm.pubrow = row;
             }
         }
@@ -348,7 +356,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         //         published (16-byte write-through stores) as soon as it is up to date.  The summaries are crossing the fabric
         //         meanwhile ----------------------------------------------------------------------------------------------------------
         bool swept = true;
-        const bool poller = tid < JSLP_F_MAXG;
+        const bool poller = tid < NPOLLW * 64;
         const bool used = tid < f.G;
         v4u_t g;
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;  // lanes beyond the grid: "no candidate"
@@ -370,7 +378,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                         const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
                         v4u_t v;
                         v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, ST_AUX);
                     }
                 }
             }
@@ -418,7 +426,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             u64_t wk = sm.part_k[0];
             int wr = sm.part_r[0], wrdeg = sm.part_rdeg[0];
 #pragma unroll
-            for (int i = 1; i < JSLP_F_MAXG / 64; i++) {
+            for (int i = 1; i < NPOLLW; i++) {
                 const u64_t k2 = sm.part_k[i];
                 const int r2 = sm.part_r[i], rd2 = sm.part_rdeg[i];
                 const bool take = r2 != 0 && (wr == 0 || k2 < wk || (k2 == wk && r2 < wr));
@@ -468,7 +476,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                         const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
                         v4u_t v;
                         v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, ST_AUX);
                     }
                 }
             }
@@ -477,8 +485,12 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 __syncthreads();
             }
             if (tid < THREADS / 64) {  // (every wave's stores reached the L2 before the barrier that closed the gather)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // buffer_wbl2 sc1 + s_waitcnt vmcnt(0): ... and memory
-                AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);  // one copy of the flag per fetching wave
+                if (XL) {  // ... which is where every reader looks: a plain flag store behind the drained row stores is the whole release
+                    *reinterpret_cast<volatile u64_t*>(f.rowflagc[par] + tid * JSLP_F_MAXG + b) = (u64_t)tag;
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // buffer_wbl2 sc1 + s_waitcnt vmcnt(0): ... and memory
+                    AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);  // one copy of the flag per fetching wave
+                }
             }
         }
         // ---- E: the winning row: every wave waits for its copy of the flag and loads its columns; the lane that holds column pc
@@ -581,7 +593,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                     if (r >= 1 && r < r_end && r != pr && nonzero16(sm.colb[par][i])) local_any = 1;
                 }
                 if (b == 0 && nonzero16(k0)) local_any = 1;  // (row 0, the cost row: simplex.ts:367 runs r from 0)
-                const int gany = global_or(f, par, tag, local_any, sm);
+                const int gany = global_or(f, par, tag, local_any, sm, b);
                 if (gany < 0) { R.end_code = 5; break; }
                 if (gany != 0) {
 #pragma unroll
@@ -692,10 +704,16 @@ __device__ __forceinline__ u64_t u64_wave_max(u64_t x) {
 // atomicMin on the column among the lanes that hold that value.  Returns with R.end_code == 0 when phase 1 is over (feasible);
 // the tableau is whole again then.
 // ===================================================================================================================
-template <int THREADS, int CPT, int ROWS, bool OPT, bool CHK>
+template <int THREADS, int CPT, int ROWS, bool OPT, bool CHK, bool XL = false>
 __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start) {
     const Ctx& c = f.c;
-    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, b = XL ? (int)(blockIdx.x / JSLP_XL_SPREAD) : (int)blockIdx.x, lane = tid & 63, wv = tid >> 6;
+    // XL (XCD-local build): all <= 32 workgroups sit on ONE XCD (checked at launch: k_simplex_resident's census), whose L2 is their
+    // common point of coherence -- summaries, candidate rows and row flags leave as PLAIN stores (they stay in that L2; `sc1` stores
+    // would drop the line and send the readers to memory) and are read with `sc1` loads (L1-bypassing, L2-served); no write-back
+    // fence anywhere (tools/micro/xcd_handoff_bench.hip flavour 1: 1.9 k cycles per 32 -> 32 exchange against 8.3 k chip-wide)
+    constexpr int ST_AUX = XL ? 0 : 16;           // aux of the hand-off stores: 16 = sc1 (write-through to memory)
+    constexpr int NPOLLW = XL ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
     const int c0 = tid * CPT;
@@ -756,7 +774,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             bk = ki_min(bk, ki_dpp<0x4E>(bk));
             bk = ki_min(bk, ki_dpp<0x141>(bk));
             bk = ki_min(bk, ki_dpp<0x140>(bk));
-            bk = ki_readlane(bk, 0);
+            bk = ROWS > 16 ? ki_min(ki_readlane(bk, 0), ki_readlane(bk, 16)) : ki_readlane(bk, 0);
             if (lane == 0) {
                 const bool have = bk.k != KI_NONE_KEY;
                 const int row = have ? bk.i : 0;
@@ -766,7 +784,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 g.y = tag;
                 g.z = (unsigned)(qb >> 32);
                 g.w = ((tag & 0xffffu) << 16) | (unsigned)row;
-                __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_g16, (par * JSLP_F_MAXG + b) * JSLP_G16_STRIDE, 0, 16);  // aux 16 = sc1
+                __builtin_amdgcn_raw_buffer_store_b128(g, rsrc_g16, (par * JSLP_F_MAXG + b) * JSLP_G16_STRIDE, 0, ST_AUX);
                 sm.pubrow = row;
             }
         }
@@ -775,7 +793,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         RT_MARK(0);
         // ---- U + P: the pending pivot's row update, the candidate row published from inside the pass ----------------------------
         bool swept = true;
-        const bool poller = tid < JSLP_F_MAXG;
+        const bool poller = tid < NPOLLW * 64;
         const bool used = tid < f.G;
         v4u_t g;
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;
@@ -796,7 +814,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                         const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
                         v4u_t v;
                         v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, ST_AUX);
                     }
                 }
             }
@@ -834,7 +852,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             u64_t wk = sm.part_k[0];
             int wr = sm.part_r[0];
 #pragma unroll
-            for (int i = 1; i < JSLP_F_MAXG / 64; i++) {
+            for (int i = 1; i < NPOLLW; i++) {
                 const u64_t k2 = sm.part_k[i];
                 const int r2 = sm.part_r[i];
                 const bool take = r2 != 0 && (wr == 0 || k2 < wk || (k2 == wk && r2 < wr));
@@ -847,8 +865,12 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         // ---- the winner releases its row (see phase 2) ---------------------------------------------------------------------------
         const int bw = pr / f.rpb;
         if (bw == b && tid < THREADS / 64) {  // (every wave's stores reached the L2 before the barrier that closed the gather)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);
+            if (XL) {
+                *reinterpret_cast<volatile u64_t*>(f.rowflagc[par] + tid * JSLP_F_MAXG + b) = (u64_t)tag;
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                AG_STORE(f.rowflagc[par] + tid * JSLP_F_MAXG + b, (u64_t)tag);
+            }
         }
         // ---- E: the pivot row (= the winner's candidate row) -------------------------------------------------------------------
         const int off_in = par * pub_stride + (bw * ld + c0) * 8;
@@ -977,7 +999,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 if (r < r_end && r != pr && nonzero16(sm.colb[par][i])) local_any = 1;
             }
             if (b == 0 && nonzero16(k0)) local_any = 1;  // (row 0, the cost row, counts: simplex.ts:367 runs r from 0)
-            const int gany = global_or(f, par, tag, local_any, sm);
+            const int gany = global_or(f, par, tag, local_any, sm, b);
             if (gany < 0) { R.end_code = 5; break; }
             if (gany != 0) {
 #pragma unroll

@@ -114,6 +114,27 @@ def unrestricted_resource_allocation_tableau(seed, n, m, k):
     return matrix, vibr, vibc, [m + k + i for i in range(k)]
 
 
+def soft_resource_allocation_tableau(seed, n, m, k):
+    """generateResourceAllocation({seed, numVariables: n, numConstraints: m, density: 1.0}) whose first k resources are SOFT
+    (`priority` strong / medium / weak in turn, weight 1, limit halved) -- tests/golden/gen_golden_wide.js `softRA`.  Every relaxed
+    constraint gets a relaxation variable created right behind it (expressions.ts:73-94), so the k relaxation columns come first
+    (column 1 + i: -1 in row 1 + i, cost 0 on the main row; their costs live in the optional objective rows, tableau.ts:278-290).
+    Tableau (m + 1) x (n + k + 1); returns (matrix, varIndexByRow, varIndexByCol, optional objective rows [3 x W], strong first)."""
+    base, _, _ = dense_resource_allocation_tableau(seed, n, m)
+    W = n + k + 1
+    matrix = np.zeros((m + 1, W), dtype=np.float64)
+    matrix[:, 0] = base[:, 0]
+    matrix[1:k + 1, 0] = np.floor(base[1:k + 1, 0] / 2.0)
+    matrix[:, k + 1:] = base[:, 1:]
+    matrix[1 + np.arange(k), 1 + np.arange(k)] = -1.0
+    # element indexes: constraint i and its relaxation variable alternate for i < k (2i, 2i + 1), then the other constraints, then the activities
+    vibr = np.concatenate(([-1], 2 * np.arange(k), 2 * k + np.arange(m - k))).astype(np.int32)
+    vibc = np.concatenate(([-1], 2 * np.arange(k) + 1, m + k + np.arange(n))).astype(np.int32)
+    oo = np.zeros((3, W), dtype=np.float64)
+    oo[np.arange(k) % 3, 1 + np.arange(k)] = -1.0
+    return matrix, vibr, vibc, oo
+
+
 def dense_random_lp_tableau(seed, n, m):
     """Same for generateRandomLP({seed, numVariables: n, numConstraints: m, density: 1.0}) -- config 3b.
     Returns (matrix, varIndexByRow, varIndexByCol, opType)."""

@@ -1142,6 +1142,7 @@ int jslp_pool_get_counters(jslp_pool* p, jslp_work_counters* out) {
         out->relaxations += c->relaxations; out->simplex_calls += c->simplex_calls; out->pivots += c->pivots;
         out->gated_cells += c->gated_cells; out->gated_rows += c->gated_rows; out->restored_rows += c->restored_rows;
         out->cut_rows += c->cut_rows; out->height_sum += c->height_sum;
+        /* (resident_*: the sequential restatement has no register-resident kernels; always 0) */
     }
     return JSLP_OK;
 }

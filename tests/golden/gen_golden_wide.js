@@ -49,6 +49,12 @@ const cases = [
     { name: "cyclecheck_RA_2000x2000", build: () => gen.generateResourceAllocation({ seed: 12345, numVariables: 2000, numConstraints: 2000, density: 1.0 }), exit: true, meta: { kind: "ra", n: 2000, m: 2000 } },
     { name: "soft_RA_400x400_k30", build: () => softRA(400, 400, 30, 12345), exit: false, keepModel: true, meta: { kind: "soft", n: 400, m: 400, k: 30 } },
     // (generateRandomLP 3000 x 3000 was tried here: the reference does not finish it in hours, with or without its cycle check)
+    // round 4: the shapes whose phase 2 runs in the lean `<512,4,16>` / `<512,8,8>` register-resident geometries BY DEFAULT
+    // (tableau 4001 x 2001 and 2001 x 4001; the tools/pmc_workload.py workloads of the same names), and a soft-constraint instance
+    // beyond the headline geometry (tableau 3001 x 2031 with three optional objective rows)
+    { name: "tall_RA_2000x4000", build: () => gen.generateResourceAllocation({ seed: 12345, numVariables: 2000, numConstraints: 4000, density: 1.0 }), exit: false, meta: { kind: "ra", n: 2000, m: 4000 } },
+    { name: "wide_RA_4000x2000", build: () => gen.generateResourceAllocation({ seed: 12345, numVariables: 4000, numConstraints: 2000, density: 1.0 }), exit: false, meta: { kind: "ra", n: 4000, m: 2000 } },
+    { name: "soft_RA_2000x3000_k30", build: () => softRA(2000, 3000, 30, 12345), exit: false, meta: { kind: "soft", n: 2000, m: 3000, k: 30 } },
     { name: "wide_RA_3000x3000", build: () => gen.generateResourceAllocation({ seed: 12345, numVariables: 3000, numConstraints: 3000, density: 1.0 }), exit: false, meta: { kind: "ra", n: 3000, m: 3000 } },
 ];
 const filter = process.argv[2] || "";

@@ -132,7 +132,7 @@ def test_oracle_stops_where_the_reference_stops(oracle_lib, path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["auto", "wg", "sp", "fused", "resident"])
+@pytest.mark.parametrize("mode", ["auto", "wg", "sp", "fused", "resident", "xl"])
 @pytest.mark.parametrize("path", SMALL, ids=G.ident)
 def test_hip_small_every_launch_shape(hip_lib, path, mode, monkeypatch):
     if mode != "auto":

@@ -93,7 +93,7 @@ def test_argument_and_capacity_errors(oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["auto", "wg", "wggen", "sp", "fused", "resident"])
+@pytest.mark.parametrize("mode", ["auto", "wg", "wggen", "sp", "fused", "resident", "xl"])
 @pytest.mark.parametrize("name,A", _cases(), ids=[c[0] for c in _cases()])
 def test_hip_equals_oracle_on_edge_shapes(hip_lib, oracle_lib, mode, name, A):
     os.environ.pop("JSLP_NO_WGLDS", None)

@@ -18,7 +18,9 @@ pytestmark = pytest.mark.gpu
 
 # resident4: 512 lanes x 4 columns (JSLP_RES_CPT=4); wggen: the generic one-workgroup kernels (selection state in global
 # memory, JSLP_NO_WGLDS=1) -- "wg" and "auto" use their LDS-resident twins wherever the tableau's vectors fit
-PATHS = ["auto", "wg", "wggen", "sp", "fused", "resident", "resident4"]
+# xl: the XCD-local register-resident geometry (round 4; <= 1024 x 1024 without unrestricted variables / optional objectives --
+# what does not fit falls through to the chip-wide resident geometries)
+PATHS = ["auto", "wg", "wggen", "sp", "fused", "resident", "resident4", "xl"]
 
 
 def set_path(mode):
@@ -67,7 +69,7 @@ def test_big_fixture_replay(hip_lib, name):
 @pytest.mark.parametrize("name", ["Monster_Problem", "Monster_II"])
 def test_big_fixture_replay_other_paths(hip_lib, name):
     g = G.load(os.path.join(G.GOLDEN, "fixtures", name + ".json.gz"))
-    for mode in ("wg", "wggen", "sp", "fused", "resident", "resident4"):
+    for mode in ("wg", "wggen", "sp", "fused", "resident", "resident4", "xl"):
         set_path(mode)
         try:
             replay(hip_lib, g)

@@ -282,20 +282,8 @@ def test_wide_resident_geometry_with_a_late_wave(hip_lib, monkeypatch):
     assert outs[0] == outs[1] and outs[0][0] > 1000
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("rows,cols,runs", [(600, 3000, 40), (4000, 2000, 6), (1200, 2100, 20)])
-def test_repeated_solves_of_the_tall_and_wide_shapes_agree(hip_lib, rows, cols, runs):
-    """Round 3: with the row flag raised behind `s_waitcnt vmcnt(0)` only (the acknowledgement of a write-through store means the
-    XCD's L2 has the data, not memory) these shapes went wrong about once in 10^5 pivots -- 601 x 3001 in 1 of 40 solves, 4001 x 2001
-    in 1 of 4 -- until the winner released its row with a real agent-scope fence (buffer_wbl2 sc1).  tools/resident_stress.py: every
-    run's pivot trace and final tableau must equal the first run's."""
-    import subprocess
-    import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "resident_stress.py"), str(rows), str(cols), str(runs)],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
-    last = out.stdout.strip().splitlines()[-1]
-    assert last.endswith(": 0 differ from the first") and "resident" in out.stdout, out.stdout[-1500:]
+# (round 4: the repeated-solve stress of the tall / wide shapes moved to tests/test_resident_pins.py, where every run is compared with the
+#  instance's KNOWN answer -- not with the first run -- and a rolled-back resident launch fails the test)
 
 
 @pytest.mark.gpu

@@ -9,6 +9,9 @@ for s in $steps; do
   case $s in
     quick) JSLP_FORCE_PATH=resident timeout 180 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "dense_synthetic and resident and 200" > $out/quick.log 2>&1 < /dev/null; echo "quick rc=$?"; tail -5 $out/quick.log ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1 < /dev/null; echo "smoke rc=$?" ;;
+    xl) timeout 600 python -m pytest tests/test_xcd_local.py -m gpu -q > $out/xl.log 2>&1 < /dev/null; echo "xl rc=$?"; tail -25 $out/xl.log ;;
+    xlt) timeout 600 python tools/xl_times.py $out/xl_times.md > $out/xl_times.log 2>&1 < /dev/null; echo "xlt rc=$?"; tail -20 $out/xl_times.log ;;
+    pins) timeout 1500 python -m pytest tests/test_resident_pins.py -m gpu -q > $out/pins.log 2>&1 < /dev/null; echo "pins rc=$?"; tail -25 $out/pins.log ;;
     tests) timeout 1200 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1 < /dev/null; echo "tests rc=$?"; tail -4 $out/pytest_gpu.log ;;
     bench) timeout 600 python bench.py --steps 3 --warmup 1 > $out/bench.log 2>&1 < /dev/null; echo "bench rc=$?"; grep '^{' $out/bench.log | cut -c1-1500 ;;
     benchfast) timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench.log 2>&1 < /dev/null; echo "bench rc=$?"; grep '^{' $out/bench.log | cut -c1-1200 ;;

@@ -12,30 +12,56 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from jslpsolver_amd import Model, _capi, generators  # noqa: E402
-from jslpsolver_amd.engine import Tableau  # noqa: E402
+from jslpsolver_amd.engine import Tableau, pivot_digest  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import known_answers as KA  # noqa: E402
+
+
+def _expectation(kind, n_vars, n_rows):
+    """the reference's answer for this instance; without one no row may be written (JSLP_ALLOW_UNVERIFIED=1 overrides)"""
+    want = KA.expected_dense(kind, n_vars, n_rows)
+    if want is None and not KA.unverified_allowed():
+        raise SystemExit("no reference answer for %s %d x %d under tests/golden: refusing to profile an unverified solve "
+                         "(JSLP_ALLOW_UNVERIFIED=1 to override)" % (kind, n_vars, n_rows))
+    return want
+
+
+def _health(t):
+    """the register-resident kernels must not have been rolled back or handed on behind the tool's back"""
+    c = t.get_counters()
+    if c["resident_aborts"]:
+        raise SystemExit("resident kernel aborted %d time(s): the timing would be the streaming fallback's" % c["resident_aborts"])
+    return {"resident_launches": c["resident_launches"], "resident_aborts": c["resident_aborts"], "resident_handovers": c["resident_handovers"]}
 
 
 def pivots(n=2000, solves=2):
     lib = _capi.load_hip()
+    want = _expectation("ra", n, n)
     m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
     t = Tableau(m, vibr, vibc, lib=lib)
     t.save()
     total = 0
-    for _ in range(solves):
+    for i in range(solves):
         t.restore()
         r = t.simplex(check_cycles=False)
         total += r.pivots_phase1 + max(r.pivots_phase2, 0)
+        if want:
+            KA.check(KA.solve_signature(t, r, pivot_digest), want, "config 3a %d x %d, solve %d" % (n, n, i))
     path = t.last_path()
+    health = _health(t)
     t.close()
     H, W = m.shape
     print(json.dumps({"key": "pivots", "kernel": "k_simplex_resident" if path == "resident" else path, "dispatches": solves,
                       "units": total, "unit": "pivot", "algorithmic_bytes_per_unit": 16.0 * H * W,
+                      "verified": ({"pivots": want["pivots"], "digest": want["digest"], "final_sha": want["final_sha"][:16], "source": want["source"]} if want else None),
+                      "health": health,
                       "workload": "config 3a %dx%d fp64, %d solves" % (H, W, solves)}))
 
 
 def dense(kind, n_vars, n_rows, check, solves=2, key=None):
     """one dense LP solved `solves` times from the device-side snapshot; the kernel that ran is read back from the engine"""
     lib = _capi.load_hip()
+    want = _expectation(kind, n_vars, n_rows)  # (the cycle check changes nothing on these instances unless it HITS -- which would change the answer)
     if kind == "ra":
         m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n_vars, n_rows)
     else:
@@ -43,12 +69,15 @@ def dense(kind, n_vars, n_rows, check, solves=2, key=None):
     t = Tableau(m, vibr, vibc, lib=lib)
     t.save()
     total, p1 = 0, 0
-    for _ in range(solves):
+    for i in range(solves):
         t.restore()
         r = t.simplex(check_cycles=check)
         total += r.pivots_phase1 + max(r.pivots_phase2, 0)
         p1 += r.pivots_phase1
+        if want:
+            KA.check(KA.solve_signature(t, r, pivot_digest), want, "%s %d x %d, solve %d" % (kind, n_vars, n_rows, i))
     path = t.last_path()
+    health = _health(t)
     t.close()
     H, W = m.shape
     one_launch = path == "resident"
@@ -58,6 +87,8 @@ def dense(kind, n_vars, n_rows, check, solves=2, key=None):
                       # empty over-launches past the end of a solve, which the summary drops by duration)
                       "dispatches": solves if one_launch else total, "units": total, "unit": "pivot", "one_dispatch_per": "solve" if one_launch else "pivot",
                       "algorithmic_bytes_per_unit": 16.0 * H * W, "path": path, "phase1_pivots": p1,
+                      "verified": ({"pivots": want["pivots"], "digest": want["digest"], "final_sha": want["final_sha"][:16], "source": want["source"]} if want else None),
+                      "health": health,
                       "workload": "%s %dx%d fp64, cycle check %s, %d solves" % (
                           "generateResourceAllocation" if kind == "ra" else "generateRandomLP", H, W, "on" if check else "off", solves)}))
 
@@ -86,8 +117,17 @@ def relax(calls=12, reps=16):
     nodes = [c["cuts"] or [] for c in g["simplexCalls"][1:]] * reps
     packed = t.pack_cut_lists(nodes)
     t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)  # first call: slots allocated + restored in full (other kernels)
+    import hashlib
+    import numpy as np
+    ref_calls = g["simplexCalls"][1:]
     for _ in range(calls):
-        t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+        results, rhs, rows = t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
+        for i in range(len(nodes)):  # every node of every profiled call against the reference's own relaxation outcome
+            call = ref_calls[i % len(ref_calls)]
+            h = results[i].height
+            sha = hashlib.sha256(np.ascontiguousarray(rhs[i, :h]).tobytes() + np.ascontiguousarray(rows[i, :h]).tobytes()).hexdigest()
+            if h != call["height"] or bool(results[i].feasible) != call["feasible"] or sha != call["rhsSha"]:
+                raise SystemExit("WRONG ANSWER: node %d of the Monster_II batch differs from the reference's relaxation outcome" % i)
     # the same batch once more with the work counters on (host-side only here: the counting pass is not profiled separately)
     t.set_counting(True)
     t.applyCutsBatch(None, check_cycles=True, packed=packed, copy=False)
@@ -100,6 +140,7 @@ def relax(calls=12, reps=16):
     # every call after the first is ONE dispatch of k_node_queue (resident workgroups pulling the nodes from a queue)
     print(json.dumps({"key": "relaxations", "kernel": "k_node_queue", "dispatches": calls + 1, "units": len(nodes) * (calls + 1),
                       "unit": "LP relaxation", "algorithmic_bytes_per_unit": per_node,
+                      "verified": {"nodes_per_call": len(nodes), "source": "tests/golden/fixtures/Monster_II.json.gz: rhsSha / height / feasible of every relaxation (the reference's own run)"},
                       "workload": "Monster_II %d-node batch, %d one-launch calls" % (len(nodes), calls + 1)}))
 
 

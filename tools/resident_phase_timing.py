@@ -10,13 +10,13 @@ import numpy as np
 from jslpsolver_amd import _capi, generators
 from jslpsolver_amd.engine import Tableau
 lib = _capi.load_hip()
-os.environ["JSLP_FORCE_PATH"] = "resident"
+os.environ["JSLP_FORCE_PATH"] = os.environ.get("JSLP_FORCE_PATH", "resident")  # ("xl": the XCD-local geometry)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 n_rows = int(sys.argv[2]) if len(sys.argv) > 2 else n  # (variables, constraints): 2000 4000 = the tall geometry
 m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n_rows)
 t = Tableau(m, vibr, vibc, lib=lib)
 res = t.simplex(check_cycles=False)
-print("pivots", len(t.pivot_trace()))
+print("pivots", len(t.pivot_trace()), "path", t.last_path())
 d = np.fromfile("gpurun_out/resident_r0.bin", dtype=np.uint64)[12288:]
 names = ["A cands", "B row stores", "C sweep/drain/sync", "D decide/poll", "E0 rowflag", "E row load+norm", "F update", "G price"]
 if os.environ.get("JSLP_RES_LEAN", "1") != "0":  # the lean kernel's pipelined loop (jslp_resident_pipe.hip.h) marks other sections

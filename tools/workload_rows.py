@@ -48,6 +48,12 @@ def main(root, out_md, out_json=None):
         if not os.path.exists(os.path.join(run, "kt.log")):
             continue
         w = line(os.path.join(run, "kt.log"))
+        # a row is only written for a workload whose solves were checked against the reference's answer (tools/pmc_workload.py
+        # exits non-zero on a wrong one, so a log without a JSON line never gets here) -- in ALL three passes
+        unverified = [p for p in ("kt", "fetch", "write") if os.path.exists(os.path.join(run, p + ".log")) and not line(os.path.join(run, p + ".log")).get("verified")]
+        if unverified:
+            print("SKIPPED %s: unverified solve in pass(es) %s" % (w.get("key"), ", ".join(unverified)))
+            continue
         d = kernel_durations(run, w["kernel"])
         if w.get("one_dispatch_per") == "pivot":
             d = [x for x in d if x > 3000]  # the engine over-launches a little past the end of a solve; those kernels exit at once
@@ -59,7 +65,8 @@ def main(root, out_md, out_json=None):
                "avg_dispatch_us": total_ns / 1e3 / len(d), "units": w["units"], "unit": w["unit"], "us_per_unit": us_per_unit,
                "units_per_s": 1e6 / us_per_unit, "algorithmic_bytes_per_unit": w["algorithmic_bytes_per_unit"],
                "algorithmic_gb_s": w["algorithmic_bytes_per_unit"] / us_per_unit / 1e3,
-               "algorithmic_frac": w["algorithmic_bytes_per_unit"] / (us_per_unit * 1e-6) / HBM_PEAK}
+               "algorithmic_frac": w["algorithmic_bytes_per_unit"] / (us_per_unit * 1e-6) / HBM_PEAK,
+               "verified": w.get("verified"), "health": w.get("health")}
         try:
             wide = w["kernel"] != "k_simplex_resident"  # streaming kernels read 16 B per lane: gfx950 FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)
             f_kib, nf = counter(run, "fetch", "FETCH_SIZE", w["kernel"])
@@ -74,17 +81,21 @@ def main(root, out_md, out_json=None):
         except Exception as e:  # a run without the PMC passes still gives the timing rows
             row["pmc_error"] = repr(e)
         rows.append(row)
-    lines = ["| workload | kernel | dispatches | avg dispatch us | units | us / unit | units / s | algorithmic MB / unit | algorithmic frac of 8 TB/s | PMC HBM MB / unit | hbm frac |",
-             "|---|---|---|---|---|---|---|---|---|---|---|"]
+    lines = ["| workload | kernel | dispatches | avg dispatch us | units | us / unit | units / s | algorithmic MB / unit | algorithmic frac of 8 TB/s | PMC HBM MB / unit | hbm frac | verified against |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
-        lines.append("| %s | `%s` | %d | %.1f | %d %ss | %.3f | %.0f | %.2f | %.3f | %s | %s |" % (
+        v = r.get("verified") or {}
+        lines.append("| %s | `%s` | %d | %.1f | %d %ss | %.3f | %.0f | %.2f | %.3f | %s | %s | %s |" % (
             r["workload"], r["kernel"], r["dispatches"], r["avg_dispatch_us"], r["units"], r["unit"], r["us_per_unit"], r["units_per_s"],
             r["algorithmic_bytes_per_unit"] / 1e6, r["algorithmic_frac"],
             "%.3f" % (r["pmc_traffic_bytes_per_unit"] / 1e6) if "pmc_traffic_bytes_per_unit" in r else "-",
-            "%.4f" % r["hbm_frac"] if "hbm_frac" in r else "-"))
+            "%.4f" % r["hbm_frac"] if "hbm_frac" in r else "-",
+            ("%s pivots, digest %s" % (v["pivots"], v["digest"])) if "digest" in v else ("%s reference node outcomes per call" % v.get("nodes_per_call", "?"))))
     text = "\n".join(lines) + "\n"
     with open(out_md, "w") as fh:
-        fh.write("One row per (kernel, workload).  Durations: rocprofv3 --kernel-trace of `tools/pmc_workload.py <workload>` (sum of the kernel's dispatch\n"
+        fh.write("Every solve behind a row was checked against the reference's answer (pivot count, pivot digest, sha256 of the final tableau; node\n"
+                 "outcomes for the relaxation batch) by tools/pmc_workload.py in each of the three passes; an unverified workload gets no row.\n"
+                 "One row per (kernel, workload).  Durations: rocprofv3 --kernel-trace of `tools/pmc_workload.py <workload>` (sum of the kernel's dispatch\n"
                  "durations / units of work they did); HBM bytes: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the same command\n"
                  "(KiB units; FETCH_SIZE x2 for the 16 B/lane streaming kernels, raw for the resident kernel's narrow agent-scope loads).\n\n" + text)
     if out_json:
