@@ -61,6 +61,9 @@ static struct {
     int (*pool_sync_root)(jslp_pool*);
     int (*pool_relax_batch)(jslp_pool*, int32_t, const int32_t*, const int8_t*, const int32_t*, const double*, int,
                             jslp_simplex_result*, double*, int32_t*, int32_t);
+    int (*pool_set_watched)(jslp_pool*, const int32_t*, int32_t);
+    int (*pool_relax_batch_watched)(jslp_pool*, int32_t, const int32_t*, const int8_t*, const int32_t*, const double*, int,
+                                    jslp_simplex_result*, int32_t*, double*);
 } L;
 
 /* what a JS engine handle points at: the engine plus the dimensions it was created with (argument checks without a
@@ -197,6 +200,7 @@ static napi_value fn_load(napi_env env, napi_callback_info info) {
     SYM(relax_watched, "jslp_engine_relax_watched"); SYM(relax_batch_watched, "jslp_engine_relax_batch_watched"); SYM(set_counting, "jslp_engine_set_counting");
     SYM(get_counters, "jslp_engine_get_counters"); SYM(pool_create, "jslp_pool_create"); SYM(pool_destroy, "jslp_pool_destroy");
     SYM(pool_size, "jslp_pool_size"); SYM(pool_sync_root, "jslp_pool_sync_root"); SYM(pool_relax_batch, "jslp_pool_relax_batch");
+    SYM(pool_set_watched, "jslp_pool_set_watched_variables"); SYM(pool_relax_batch_watched, "jslp_pool_relax_batch_watched");
     napi_value s;
     NAPI_OK(env, napi_create_string_utf8(env, L.backend_name(), NAPI_AUTO_LENGTH, &s));
     return s;
@@ -738,7 +742,7 @@ static napi_value fn_get_counters(napi_env env, napi_callback_info info) {
 }
 
 /* ---- device pool (jslp_pool_*) ---- */
-typedef struct { jslp_pool* p; int32_t cap; napi_ref primary; } pbox;
+typedef struct { jslp_pool* p; int32_t cap; int32_t n_watched; napi_ref primary; } pbox;
 /* The pool's members must go before the primary engine does, and finalisers run in no particular order: the box holds a
    reference to the primary's handle, so the primary outlives the pool whichever way the pool ends -- poolDestroy (what the
    binding calls before it destroys the primary) or this finaliser (a tableau that was simply dropped: the N - 1 member
@@ -849,6 +853,61 @@ static napi_value fn_pool_relax_batch(napi_env env, napi_callback_info info) {
     return arr;
 }
 
+/* poolSetWatchedVariables(pool, Int32Array varIndexes): jslp_pool_set_watched_variables (every member) */
+static napi_value fn_pool_set_watched(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    jslp_pool* p = pool_handle(env, argv[0], NULL);
+    if (!p) return NULL;
+    void* v; size_t n;
+    if (!typed(env, argv[1], napi_int32_array, &v, &n)) return NULL;
+    ENGINE_OK(env, L.pool_set_watched(p, (const int32_t*)v, (int32_t)n), "jslp_pool_set_watched_variables");
+    {
+        void* bp = NULL;
+        if (napi_get_value_external(env, argv[0], &bp) == napi_ok && bp) ((pbox*)bp)->n_watched = (int32_t)n;
+    }
+    return NULL;
+}
+
+/* poolRelaxBatchWatched(pool, Int32Array offsets, type, varIndex, value, checkCycles, Int32Array rowsOut, Float64Array valuesOut)
+   -> [result]: the compact read-back (mip-utils.ts:43-61, 100-126 need only the integer variables' cells) over every member */
+static napi_value fn_pool_relax_batch_watched(napi_env env, napi_callback_info info) {
+    napi_value argv[8];
+    if (!get_args(env, info, 8, argv)) return NULL;
+    jslp_pool* p = pool_handle(env, argv[0], NULL);
+    if (!p) return NULL;
+    void *o, *t, *v, *x, *wr, *wv, *bp = NULL;
+    size_t no, nt, nv, nx, nwr, nwv;
+    bool check;
+    if (!typed(env, argv[1], napi_int32_array, &o, &no) || !typed(env, argv[2], napi_int8_array, &t, &nt) ||
+        !typed(env, argv[3], napi_int32_array, &v, &nv) || !typed(env, argv[4], napi_float64_array, &x, &nx))
+        return NULL;
+    NAPI_OK(env, napi_get_value_bool(env, argv[5], &check));
+    if (!typed(env, argv[6], napi_int32_array, &wr, &nwr) || !typed(env, argv[7], napi_float64_array, &wv, &nwv)) return NULL;
+    if (no < 1) THROW(env, "poolRelaxBatchWatched: offsets must hold n_nodes + 1 entries");
+    const int32_t n_nodes = (int32_t)no - 1;
+    if (nt != nv || nv != nx || (size_t)((const int32_t*)o)[n_nodes] != nt) THROW(env, "poolRelaxBatchWatched: offsets[n_nodes] must equal the length of the cut arrays");
+    NAPI_OK(env, napi_get_value_external(env, argv[0], &bp));
+    const size_t n_watched = (size_t)((pbox*)bp)->n_watched;
+    if (n_watched == 0) THROW(env, "poolRelaxBatchWatched: poolSetWatchedVariables first");
+    if ((wr && nwr < (size_t)n_nodes * n_watched) || (wv && nwv < (size_t)n_nodes * n_watched))
+        THROW(env, "poolRelaxBatchWatched: output arrays shorter than n_nodes * nWatched");
+    jslp_simplex_result* res = (jslp_simplex_result*)calloc((size_t)(n_nodes > 0 ? n_nodes : 1), sizeof *res);
+    int rc = L.pool_relax_batch_watched(p, n_nodes, (const int32_t*)o, (const int8_t*)t, (const int32_t*)v, (const double*)x,
+                                        check ? 1 : 0, res, (int32_t*)wr, (double*)wv);
+    if (rc != JSLP_OK) free(res);
+    ENGINE_OK(env, rc, "jslp_pool_relax_batch_watched");
+    napi_value arr;
+    if (napi_create_array_with_length(env, (size_t)n_nodes, &arr) != napi_ok) { free(res); THROW(env, "array"); }
+    for (int32_t i = 0; i < n_nodes; i++) {
+        napi_value ro = result_object(env, &res[i]);
+        if (!ro) { free(res); return NULL; }
+        napi_set_element(env, arr, (uint32_t)i, ro);
+    }
+    free(res);
+    return arr;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"load", fn_load}, {"deviceCount", fn_device_count}, {"create", fn_create}, {"destroy", fn_destroy},
@@ -863,6 +922,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"setCounting", fn_set_counting}, {"getCounters", fn_get_counters},
         {"poolCreate", fn_pool_create}, {"poolDestroy", fn_pool_destroy}, {"poolSize", fn_pool_size},
         {"poolSyncRoot", fn_pool_sync_root}, {"poolRelaxBatch", fn_pool_relax_batch},
+        {"poolSetWatchedVariables", fn_pool_set_watched}, {"poolRelaxBatchWatched", fn_pool_relax_batch_watched},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

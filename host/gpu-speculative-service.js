@@ -82,8 +82,9 @@ function createGpuSpeculativeService(gpu, options) {
         // workgroup per node, which only pays while a node's tableau is small next to the chip (a single child of a
         // 20 MB tableau is faster through the chip-wide kernels, one node at a time)
         const speculate = nOpt > 0 || t.width * t.height > 1536 * 1024 ? 1 : width;
-        // the device pool (install(..., {devices})) splits full read-backs only; keep_solutions reads every node's whole column
-        const compact = !(options && options.fullReadBack) && !gpu.usesPool() && !(model && model.keep_solutions);
+        // keep_solutions reads every node's whole column (round 4: the device pool -- install(..., {devices}) -- splits the compact
+        // read-back too: jslp_pool_relax_batch_watched)
+        const compact = !(options && options.fullReadBack) && !(model && model.keep_solutions);
 
         heap.push(-Infinity, []);
         while (heap.items.length > 0 && withinTolerance && Date.now() < deadline) {

@@ -467,7 +467,7 @@ function install(Tableau, options) {
             // models that ask for another policy or for MIR cuts keep the reference's own services
             if (opts.speculate > 1 && !(o && (o.nodeSelection || o.branching || o.useMIRCuts))) {
                 return require("./gpu-speculative-service.js").createGpuSpeculativeService(api, { speculate: opts.speculate,
-                    fallback: origSelect.call(this, model) });
+                    fullReadBack: opts.fullReadBack === true, fallback: origSelect.call(this, model) });
             }
             return origSelect.call(this, model);
         };
@@ -599,12 +599,17 @@ function relaxBatch(t, cutLists) {
 function relaxBatchWatched(t, cutLists, varIndexes) {
     const st = t.__gpu;
     if (!st || !st.active) throw new Error("[gpu-tableau] relaxBatchWatched: tableau is not on the engine");
+    // install(..., { devices: [0, 1, ...] }): the compact read-back over the device pool too (jslp_pool_relax_batch_watched: every member's
+    // outcomes in one pinned [nodes x watched] buffer; round 3's pool split full read-backs only -- 11.2 KB per Monster_II node per member)
+    const devices = installedOpts.devices;
+    if (devices && devices.length > 1 && !st.pool) st.pool = addon.poolCreate(st.h, Int32Array.from(devices));
+    const setWatched = (w) => (st.pool ? addon.poolSetWatchedVariables(st.pool, w) : addon.setWatchedVariables(st.h, w));
     let watched;
     if (varIndexes) {
         watched = Int32Array.from(varIndexes);
         const key = Array.prototype.join.call(watched, ",");
         if (st.watchedKey !== key) {
-            addon.setWatchedVariables(st.h, watched);
+            setWatched(watched);
             st.watchedKey = key;
         }
     } else {
@@ -613,7 +618,7 @@ function relaxBatchWatched(t, cutLists, varIndexes) {
         watched = st.watchedDefault;
         if (!watched) watched = st.watchedDefault = Int32Array.from(t.model.integerVariables.map((v) => v.index));
         if (st.watchedKey !== "\u0000model") {  // (no list of indexes joins to this)
-            addon.setWatchedVariables(st.h, watched);
+            setWatched(watched);
             st.watchedKey = "\u0000model";
         }
     }
@@ -637,7 +642,9 @@ function relaxBatchWatched(t, cutLists, varIndexes) {
     }
     const rows = new Int32Array(n * w), values = new Float64Array(n * w);
     const check = t.model ? t.model.checkForCycles === true : false;
-    const results = addon.relaxBatchWatched(st.h, offsets, type, varIndex, value, check, rows, values);
+    const results = st.pool
+        ? addon.poolRelaxBatchWatched(st.pool, offsets, type, varIndex, value, check, rows, values)
+        : addon.relaxBatchWatched(st.h, offsets, type, varIndex, value, check, rows, values);
     const out = new Array(n);
     for (let i = 0; i < n; i++) out[i] = { res: results[i], rows: rows.subarray(i * w, (i + 1) * w), values: values.subarray(i * w, (i + 1) * w) };
     return out;

@@ -296,10 +296,11 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
 }
 // install(..., { speculate: 16, devices: [0, 0, 0, 0] }): the speculative batches split over a device pool (jslp_pool_*;
 // here four engines on device 0 -- "virtual devices" -- each with its own stream and host thread inside the library)
-let poolOk = 0;
-if (!filter && dir.indexOf("fixtures") >= 0) {
+// -- with the compact read-back (round 4: jslp_pool_relax_batch_watched, the default) and with the full one (fullReadBack: true)
+let poolOk = 0, poolFullOk = 0;
+for (const fullReadBack of [false, true]) if (!filter && dir.indexOf("fixtures") >= 0) {
     uninstall();
-    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16, devices: [0, 0, 0, 0], minCells: 0 });
+    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16, devices: [0, 0, 0, 0], minCells: 0, fullReadBack });
     for (const f of fs.readdirSync(dir).filter((x) => x.endsWith(".json.gz")).sort()) {
         const g = loadGolden(dir, f);
         if (!g.model || !g.tableau || g.tableau.integerVarIndexes.length === 0) continue;
@@ -317,14 +318,17 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
         if (solution._tableau.branchAndCutIterations !== g.final.branchAndCutIterations) bad.push("B&B iterations");
         const usedPool = !!(solution._tableau.__gpu && solution._tableau.__gpu.pool);
         gpu.release(solution._tableau);
-        if (bad.length) { fail += 1; console.log("FAIL pool", f, bad.join("; ")); } else poolOk += usedPool ? 1 : 0;
+        if (bad.length) { fail += 1; console.log("FAIL pool", fullReadBack ? "(full read-back)" : "(compact)", f, bad.join("; ")); }
+        else if (fullReadBack) poolFullOk += usedPool ? 1 : 0;
+        else poolOk += usedPool ? 1 : 0;
     }
 }
 // compact read-back of a batch (relaxBatchWatched) against the full one, node by node
-let watchedOk = 0;
-if (!filter && dir.indexOf("fixtures") >= 0) {
+// -- on one engine, and over the device pool (poolRelaxBatchWatched against poolRelaxBatch)
+let watchedOk = 0, poolWatchedOk = 0;
+for (const devices of [null, [0, 0, 0, 0]]) if (!filter && dir.indexOf("fixtures") >= 0) {
     uninstall();
-    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16, minCells: 0 });
+    uninstall = gpu.install(Tableau, devices ? { SlackVariable, solver, speculate: 16, minCells: 0, devices } : { SlackVariable, solver, speculate: 16, minCells: 0 });
     const g = loadGolden(dir, "Monster_II.json.gz");
     const m = JSON.parse(JSON.stringify(g.model));
     if (m.options) delete m.options.timeout;
@@ -342,7 +346,9 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
             const r = rowOf.has(ints[k]) ? rowOf.get(ints[k]) : -1;
             same = compact[i].rows[k] === r && Object.is(compact[i].values[k], r > 0 ? full[i].rhs[r] : 0);
         }
-        if (same) watchedOk += 1; else { fail += 1; console.log("FAIL watched batch, node", i); }
+        if (!same) { fail += 1; console.log("FAIL watched batch, node", i, devices ? "(pool)" : ""); }
+        else if (devices) poolWatchedOk += 1;
+        else watchedOk += 1;
     }
     gpu.release(t);
 }
@@ -369,5 +375,5 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
 }
 console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk,
     incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk,
-    size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, instance_ok: instanceOk, cycle_ok: cycleOk, pool_ok: poolOk, watched_ok: watchedOk }));
+    size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, instance_ok: instanceOk, cycle_ok: cycleOk, pool_ok: poolOk, pool_full_ok: poolFullOk, watched_ok: watchedOk, pool_watched_ok: poolWatchedOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);

@@ -311,6 +311,18 @@ int jslp_pool_relax_batch_pinned(jslp_pool* p, int32_t n_nodes, const int32_t* c
                                  jslp_simplex_result* out, const double** rhs, const int32_t** var_index_by_row,
                                  int32_t* out_stride);
 /* Counters of all members added up (see jslp_work_counters); set_counting applies to every member. */
+/* The compact read-back over the pool (round 4): what a branch-and-bound host reads between relaxations is rowByVarIndex and the RHS
+ * cell of the INTEGER variables (mip-utils.ts:43-61, 100-126), not the whole column -- n_watched x 12 bytes per node instead of
+ * height x 12.  set_watched_variables = jslp_engine_set_watched_variables on every member; relax_batch_watched[_pinned] =
+ * jslp_engine_relax_batch_watched[_pinned] with the nodes split over the members like jslp_pool_relax_batch, every member's
+ * outcomes landing in ONE pinned buffer [n_nodes x n_watched] (the _pinned variant hands it out, valid until the next call). */
+int jslp_pool_set_watched_variables(jslp_pool* p, const int32_t* var_indexes, int32_t n);
+int jslp_pool_relax_batch_watched(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                  const int32_t* var_index, const double* value, int check_cycles, jslp_simplex_result* out,
+                                  int32_t* watched_row, double* watched_value);
+int jslp_pool_relax_batch_watched_pinned(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                         const int32_t* var_index, const double* value, int check_cycles, jslp_simplex_result* out,
+                                         const int32_t** watched_row, const double** watched_value);
 int jslp_pool_set_counting(jslp_pool* p, int enabled);
 int jslp_pool_get_counters(jslp_pool* p, jslp_work_counters* out);
 

@@ -107,6 +107,11 @@ SYMBOLS = {
                                         _P(SimplexResult), _f64p, _i32p, C.c_int32]),
     "jslp_pool_relax_batch_pinned": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p, _i32p, _f64p, C.c_int,
                                                _P(SimplexResult), _P(_f64p), _P(_i32p), _i32p]),
+    "jslp_pool_set_watched_variables": (C.c_int, [C.c_void_p, _i32p, C.c_int32]),
+    "jslp_pool_relax_batch_watched": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p, _i32p, _f64p, C.c_int,
+                                                _P(SimplexResult), _i32p, _f64p]),
+    "jslp_pool_relax_batch_watched_pinned": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p, _i32p, _f64p, C.c_int,
+                                                       _P(SimplexResult), _P(_i32p), _P(_f64p)]),
     "jslp_pool_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
     "jslp_pool_get_counters": (C.c_int, [C.c_void_p, _P(WorkCounters)]),
     "jslp_engine_dims": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p]),

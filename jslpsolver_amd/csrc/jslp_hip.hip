@@ -123,7 +123,7 @@ struct jslp_engine {
     char* arena32 = nullptr;
     // policy
     int force_path = 0;  // 0 auto, 1 workgroup kernel, 2 select+update kernels only, 3 fused phase 2
-    int force_xl = 0, xl_on = 1;  // JSLP_FORCE_PATH=xl / JSLP_XL=0: the XCD-local register-resident geometry (resident_geometry 6)
+    int force_xl = 0, xl_on = 0;  // JSLP_FORCE_PATH=xl / JSLP_XL=0: the XCD-local register-resident geometry (resident_geometry 6)
     int force_resident = 0;  // JSLP_FORCE_PATH=resident: also the register-resident geometries the default policy leaves to the streaming kernels
     int32_t n_unr = 0;
     int nt = 0;  // JSLP_NT=1: non-temporal hints in the fused kernel
@@ -435,8 +435,12 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     if (fp && !strcmp(fp, "fused")) { e->force_path = 3; e->no_resident = 1; }
     if (fp && !strcmp(fp, "resident")) { e->force_path = 3; e->force_resident = 1; }
     if (fp && !strcmp(fp, "xl")) { e->force_path = 3; e->force_resident = 1; e->force_xl = 1; }  // the XCD-local resident geometry whatever the size (<= 1024 x 1024)
-    const char* xl = getenv("JSLP_XL");  // 0: never the XCD-local geometry (what round 3 shipped for these sizes)
-    e->xl_on = !(xl && xl[0] == '0');
+    // JSLP_XL=1: the XCD-local geometry for every tableau it takes.  OFF by default: as measured in round 4 (profiles/r04_xl_*) it is
+    // correct on every golden but not faster than what these sizes had -- 6.4-6.8 us per pivot on dense 501 x 501 / 1001 x 1001 against
+    // 6.0 chip-wide, 8.6 against 6.9 (one LDS workgroup) on the sparse Monster LP: its pivot is bound by the instruction stream of
+    // the 32-row unrolled loops, not by the hand-offs it shortens
+    const char* xl = getenv("JSLP_XL");
+    e->xl_on = (xl && xl[0] == '1') ? 1 : 0;
     const char* nr = getenv("JSLP_NO_RESIDENT");
     if (nr && nr[0] == '1') e->no_resident = 1;
     const char* rcpt = getenv("JSLP_RES_CPT");
@@ -741,8 +745,7 @@ static bool use_wg_single(const jslp_engine* e) {
     const long long cells = (long long)e->cap_rows * e->ld;
     if (e->force_xl) return false;
     if (cells <= WG_CELLS_SINGLE) return true;
-    // (sparse mid-size LPs used to stay in one workgroup -- ~7 us per pivot of dependent global trips; the XCD-local resident
-    //  geometry takes them now whatever their density)
+    // (JSLP_XL=1: the XCD-local resident geometry takes the sparse mid-size LPs too)
     if (xl_fits(e, e->cap_rows) && !e->no_resident && e->force_path == 0) return false;
     return wglds_smem(e) != 0 && cells <= WG_CELLS_SPARSE && e->nnz >= 0 &&
            (double)e->nnz <= WG_SPARSE_DENSITY * (double)e->H0 * (double)e->W;
@@ -765,7 +768,7 @@ static bool fused_eligible(const jslp_engine* e) {
 //  dropped: 72.5 k against 105.7 k pivots/s on a 2001 x 2001 LP, 17.4 k on 4001 x 2001, r02_z: a lone wave per SIMD does not hide
 //  its own instruction latency)
 static bool xl_fits(const jslp_engine* e, int H) {
-    return e->xl_on && e->n_unr == 0 && e->n_opt == 0 && e->ld <= 1024 && H <= JSLP_XL_MAXG * JSLP_R_MAXROWS && e->precision >= 1e-15 &&
+    return (e->xl_on || e->force_xl) && e->n_unr == 0 && e->n_opt == 0 && e->ld <= 1024 && H <= JSLP_XL_MAXG * JSLP_R_MAXROWS && e->precision >= 1e-15 &&
            !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
 }
 static int resident_geometry(const jslp_engine* e, int H) {
@@ -1054,6 +1057,12 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             rc.dbg = dbg_buf;
 #endif
             HIPC(hipMemsetAsync(e->r_sync, 0, sizeof(unsigned) * 16, s));
+            if (geometry == 6) {
+                // the XCD-local build's rows carry their epoch tag INSIDE the data and every launch's tags restart at 1: what an earlier
+                // launch left in the row slots would pass for this launch's rows (found by the Knapsack fixture's fifth relaxation: same
+                // pivots, another RHS) -- the slots start from zero (tag 0 is never used)
+                for (int i = 0; i < 2; i++) HIPC(hipMemsetAsync(e->r_rows[i], 0, (size_t)rc.G * e->ld * 16, s));
+            }
             // Safety net.  The kernel commits every pivot's index-map swap as it goes but writes the matrix back only in
             // its epilogue, and a timed-out hand-off (workgroups not co-resident, a stalled GPU) skips that epilogue: keep a
             // copy of slot 0 (one pass over the matrix, ~15 us at 2001 x 2001 against a ~100 ms solve) to roll back to.
@@ -1077,6 +1086,15 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
        : unr  ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, true>, dim3(rc.G), dim3(T), args, 0, s)        \
               : hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false>, dim3(rc.G), dim3(T), args, 0, s)
           resident_relaunch:
+#if defined(JSLP_DEV_HEADLINE_ONLY)  /* development builds: only the headline lean instances are compiled; never shipped */
+            if (geometry != 1 || !lean || e->n_opt > 0) return fail(JSLP_ERR_UNSUPPORTED, "development build: headline lean geometry only");
+            le = check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2, 8, false, true, false, true>, dim3(rc.G), dim3(1024), args, 0, s)
+                              : hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2, 8, false, true, false, false>, dim3(rc.G), dim3(1024), args, 0, s);
+#elif defined(JSLP_DEV_XL_ONLY)  /* development builds: only the XCD-local instances are compiled (40 s instead of 2.5 min); never shipped */
+            if (geometry != 6) return fail(JSLP_ERR_UNSUPPORTED, "development build: XCD-local geometry only");
+            le = check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 2, 32, false, true, false, true, true>, dim3(JSLP_XL_SPREAD * rc.G), dim3(512), args, 0, s)
+                              : hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 2, 32, false, true, false, false, true>, dim3(JSLP_XL_SPREAD * rc.G), dim3(512), args, 0, s);
+#else
             switch (geometry) {
                 case 1:
                     if (e->n_opt > 0) {  // (resident_geometry admits optional objectives only here, and only for the lean build)
@@ -1097,6 +1115,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                                       : hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 2, 32, false, true, false, false, true>, dim3(JSLP_XL_SPREAD * rc.G), dim3(512), args, 0, s);
                     break;
             }
+#endif
 #undef JSLP_RES_LAUNCH
             if (le == hipSuccess) e->resident_launches += 1;
             if (le == hipSuccess && lean) {  // did the lean kernel finish the solve?
@@ -2429,13 +2448,19 @@ extern "C" int jslp_pool_sync_root(jslp_pool* p) {
     return JSLP_OK;
 }
 
+// compact = 1: the watched variables' rows / RHS cells only (rhs / vibr then hold n_watch entries per node, out_stride is ignored)
 static int pool_relax(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type, const int32_t* var_index,
                       const double* value, int check_cycles, jslp_simplex_result* out, double* rhs, int32_t* vibr,
-                      int32_t out_stride, int want_rhs, int want_rows) {
+                      int32_t out_stride, int want_rhs, int want_rows, int compact = 0) {
     if (!p || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "pool_relax_batch: null pointer");
     jslp_engine* e = p->members[0];
     if (!e->uploaded || !e->has_save) return fail(JSLP_ERR_STATE, "pool_relax_batch: the primary has no saved root (save() first)");
-    if ((rhs || vibr) && out_stride < e->cap_rows) return fail(JSLP_ERR_ARG, "pool_relax_batch: out_stride < row capacity");
+    if (!compact && (rhs || vibr) && out_stride < e->cap_rows) return fail(JSLP_ERR_ARG, "pool_relax_batch: out_stride < row capacity");
+    if (compact) {
+        if (e->n_watch <= 0) return fail(JSLP_ERR_ARG, "pool_relax_batch_watched: after jslp_pool_set_watched_variables");
+        for (jslp_engine* m : p->members)
+            if (m->n_watch != e->n_watch) return fail(JSLP_ERR_STATE, "pool_relax_batch_watched: the members' watched variables differ from the primary's (jslp_pool_set_watched_variables sets them all)");
+    }
     if (n_nodes == 0) return JSLP_OK;
     if (cut_offsets[0] != 0) return fail(JSLP_ERR_ARG, "cuts: cut_offsets[0] must be 0");
     for (int32_t i = 0; i < n_nodes; i++)
@@ -2446,7 +2471,7 @@ static int pool_relax(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets,
         if (rc) return rc;
     }
     // ONE pinned buffer for every member's outcomes, laid out for all nodes: [states | rhs | rows]
-    const size_t cap = (size_t)e->cap_rows;
+    const size_t cap = compact ? (size_t)e->n_watch : (size_t)e->cap_rows;  // entries per node in the shared buffer
     const size_t need = (size_t)n_nodes * (sizeof(DevState) + cap * 12);
     if (need > p->h_out_bytes) {
         if (p->h_out) hipHostFree(p->h_out);
@@ -2472,9 +2497,14 @@ static int pool_relax(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets,
         m->ext_rows = g_rows + (size_t)first * cap;
         const int r = relax_batch_impl(m, cnt, o.data(), type ? type + base : nullptr, var_index ? var_index + base : nullptr,
                                        value ? value + base : nullptr, check_cycles, out + first, nullptr, nullptr, 0, 1,
-                                       want_rhs, want_rows);
+                                       want_rhs, want_rows, -1, compact);
         m->ext_states = nullptr; m->ext_rhs = nullptr; m->ext_rows = nullptr;
         if (r) return r;
+        if (compact) {  // same layout on both sides: one copy per member
+            if (rhs) memcpy(rhs + (size_t)first * cap, g_rhs + (size_t)first * cap, sizeof(double) * (size_t)cnt * cap);
+            if (vibr) memcpy(vibr + (size_t)first * cap, g_rows + (size_t)first * cap, sizeof(int32_t) * (size_t)cnt * cap);
+            return JSLP_OK;
+        }
         for (int i = first; i < last && (rhs || vibr); i++) {  // caller-owned arrays: every member copies its own range
             const size_t H = (size_t)out[i].height;
             if (rhs) memcpy(rhs + (size_t)i * out_stride, g_rhs + (size_t)i * cap, sizeof(double) * H);
@@ -2508,6 +2538,42 @@ extern "C" int jslp_pool_relax_batch_pinned(jslp_pool* p, int32_t n_nodes, const
     if (var_index_by_row)
         *var_index_by_row = n_nodes > 0 ? reinterpret_cast<const int32_t*>(p->h_out + (size_t)n_nodes * (sizeof(DevState) + cap * 8)) : nullptr;
     if (out_stride) *out_stride = (int32_t)cap;
+    return JSLP_OK;
+}
+
+extern "C" int jslp_pool_set_watched_variables(jslp_pool* p, const int32_t* var_indexes, int32_t n) {
+    if (!p) return fail(JSLP_ERR_ARG, "pool_set_watched_variables: null pool");
+    jslp_engine* e = p->members[0];
+    // the members learn their dimensions' worth of state with the root: make sure they have it before they are handed index lists
+    if (e->uploaded && e->has_save && (!p->synced || p->synced_seq != e->root_seq)) {
+        int rc = jslp_pool_sync_root(p);
+        if (rc) return rc;
+    }
+    for (jslp_engine* m : p->members) {
+        int rc = jslp_engine_set_watched_variables(m, var_indexes, n);
+        if (rc) { hipSetDevice(e->device); return rc; }
+    }
+    hipSetDevice(e->device);
+    return JSLP_OK;
+}
+
+extern "C" int jslp_pool_relax_batch_watched(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                             const int32_t* var_index, const double* value, int check_cycles,
+                                             jslp_simplex_result* out, int32_t* watched_row, double* watched_value) {
+    return pool_relax(p, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, watched_value, watched_row, 0,
+                      watched_value != nullptr, watched_row != nullptr, 1);
+}
+
+extern "C" int jslp_pool_relax_batch_watched_pinned(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                                    const int32_t* var_index, const double* value, int check_cycles,
+                                                    jslp_simplex_result* out, const int32_t** watched_row, const double** watched_value) {
+    int rc = pool_relax(p, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, nullptr, nullptr, 0, watched_value != nullptr,
+                        watched_row != nullptr, 1);
+    if (rc) return rc;
+    const size_t nw = p && !p->members.empty() ? (size_t)p->members[0]->n_watch : 0;
+    if (watched_value) *watched_value = n_nodes > 0 ? reinterpret_cast<const double*>(p->h_out + (size_t)n_nodes * sizeof(DevState)) : nullptr;
+    if (watched_row)
+        *watched_row = n_nodes > 0 ? reinterpret_cast<const int32_t*>(p->h_out + (size_t)n_nodes * (sizeof(DevState) + nw * 8)) : nullptr;
     return JSLP_OK;
 }
 

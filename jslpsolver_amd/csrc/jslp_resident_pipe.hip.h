@@ -88,6 +88,9 @@
 #ifndef JSLP_PIPE_SPECPUB
 #define JSLP_PIPE_SPECPUB 1  // 1: every workgroup stores its candidate row while the summaries cross the fabric; 0: only the winner stores its row, after the decision (measured: config 3a 137 k against 143 k pivots/s, 4001x2001 105 k against 108 k, 2001x4001 91 k against 87 k)
 #endif
+#ifndef JSLP_PIPE_WINNER_LL
+#define JSLP_PIPE_WINNER_LL 0  // chip-wide lean builds: 1 = ONLY the winner stores its row, after the decision, with the epoch tag inside the data ({lo32 | tag}{hi32 | tag} per double, write-through); the readers poll the row itself -- no candidate rows (4 MB per pivot), no drain, no write-back fence, no flag
+#endif
 #define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
 #define JSLP_PIPE_KCHUNK 8    // pivot-column entries the update pass keeps in flight (registers: the tall / wide geometries have few to spare)
 
@@ -192,6 +195,114 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         }                                                                                                   \
     } while (0)
 
+// ---- XCD-local build (XL): the pending pivot's row update, restructured for 32 rows x 2 columns per lane.  JSLP_PIPE_UPDATE_ROW
+// spends ~55 instructions per row on special cases (is this the pivot row / the cost row / does my lane hold the pivot column / is this
+// the row to publish) next to the 4 that do the work: 230 cycles per row, 10-13 k cycles per pivot at 32 rows (r04_c).  Here the row
+// loop is the gate `|k| > 1e-16` (simplex.ts:370-375; uniform: k is a broadcast LDS read) and the eliminations -- without the
+// per-column gate when every column of the wave is live (dense pivot row; padding columns hold +0 in every row and in p, and
+// (+0) - k * (+0) = +0) -- and the special cases follow ONCE per pivot: the pivot column's own entries by the one wave that holds
+// it, the pivot row by its owner, the cost-row mirror by workgroup 0.  Same operands, same two roundings per cell.
+// (a chain `if (i == row) a[i][j] = ...` over the unrolled rows is what the optimizer likes to fold into ONE store at a[row][j] -- a
+//  dynamic index, which sends the whole register array to scratch: 456 bytes per lane, 1648 scratch instructions, 28-47 k cycles per
+//  update pass (r04_d).  An empty asm per iteration makes every comparison's operand its own opaque value.)
+#define JSLP_OPAQUE_SGPR(x) ({ int o_ = (x); asm volatile("" : "+s"(o_)); o_; })
+#define JSLP_XL_UPDATE_PASS()                                                                                                     \
+    do {                                                                                                                          \
+        /* lane i < ROWS holds the pivot-column entry of my row i; the gate |k| > 1e-16 (simplex.ts:370-375) of all rows is ONE     \
+           ballot, a row's k reaches the multiplier by two readlanes (scalar operands): per (row, column) a scalar bit test, a     \
+           scalar branch and the two roundings -- no per-row LDS read, no per-cell select; the per-column gate is the EXEC mask of \
+           the column's pass over the rows */                                                                                      \
+        const double kl_ = lane < ROWS ? sm.colb[par_p][lane] : 0.0;                                                              \
+        const unsigned km_ = (unsigned)__ballot(nonzero16(kl_)); /* (rows beyond the workgroup's share hold zeros: bit clear) */   \
+        _Pragma("unroll") for (int j = 0; j < CPT; j++) { /* (measured, r04_e ... r04_g: per-row LDS reads + per-cell selects 5.4-6.9 k cycles per   \
+            pass; this form 3.9-5.9 k; one pass over the rows with the column gate as an EXEC-masked branch per cell 5.1-8.5 k; a second,  \
+            gate-free copy of the loop for dense pivot rows costs the register allocator ~400 spills) */                           \
+            if ((nzm >> j) & 1u) {                                                                                                \
+                _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                  \
+                    if (km_ & (1u << i)) a[i][j] = eliminate(a[i][j], readlane_f64(kl_, i), p[j]);                                \
+            }                                                                                                                     \
+        }                                                                                                                         \
+        if (wv == ((pc_p / CPT) >> 6)) { /* the pivot column itself: -k / quot (simplex.ts:386), one lane of this wave */         \
+            const int ol_ = __builtin_amdgcn_readfirstlane((pc_p / CPT) & 63), js_ = __builtin_amdgcn_readfirstlane(pc_p % CPT);  \
+            const double nvl_ = lane < ROWS ? sm.nv[lane] : 0.0;                                                                  \
+            _Pragma("unroll") for (int j = 0; j < CPT; j++)                                                                       \
+                if (js_ == j) {                                                                                                   \
+                    _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                              \
+                        if (km_ & (1u << i)) { const double nv_ = readlane_f64(nvl_, i); if (lane == ol_) a[i][j] = nv_; }        \
+                }                                                                                                                 \
+        }                                                                                                                         \
+        {   /* the pivot row (simplex.ts:352-364): its owner only */                                                              \
+            const int ip_ = __builtin_amdgcn_readfirstlane(pr_p - r_begin);                                                       \
+            if (ip_ >= 0 && ip_ < ROWS) {                                                                                         \
+                _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                  \
+                    if (i == JSLP_OPAQUE_SGPR(ip_)) { _Pragma("unroll") for (int j = 0; j < CPT; j++) a[i][j] = p[j]; }           \
+            }                                                                                                                     \
+        }                                                                                                                         \
+        if (b == 0) { _Pragma("unroll") for (int j = 0; j < CPT; j++) a[0][j] = r0[j]; } /* workgroup 0 mirrors the cost row */   \
+    } while (0)
+// the row that can win, with the epoch tag INSIDE the data: {lo32 | tag}{hi32 | tag} per double (RCCL's LL scheme) -- the readers
+// poll the row itself, no flag, no drain, no ordering between stores to rely on; twice the bytes, which one XCD's L2 does not notice
+#define JSLP_XL_PUBLISH_ROW(ROW)                                                                                                  \
+    do {                                                                                                                          \
+        const int ipub_ = __builtin_amdgcn_readfirstlane((ROW) - r_begin);                                                        \
+        if (colok) {                                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                      \
+                if (i == JSLP_OPAQUE_SGPR(ipub_)) {                                                                                                 \
+                    const int off_ = par * pub_stride + ((WLL ? 0 : b) * ld + c0) * 16; /* (winner-only: ONE row per pivot, one slot) */ \
+                    _Pragma("unroll") for (int j = 0; j < CPT; j++) {                                                             \
+                        if (c0 + j >= ld) continue;                                                                               \
+                        const u64_t d_ = (u64_t)__double_as_longlong(a[i][j]);                                                    \
+                        v4u_t v_;                                                                                                 \
+                        v_.x = (unsigned)d_; v_.y = tag; v_.z = (unsigned)(d_ >> 32); v_.w = tag;                                 \
+                        __builtin_amdgcn_raw_buffer_store_b128(v_, rsrc_rows, off_ + j * 16, 0, ST_AUX);                          \
+                    }                                                                                                             \
+                }                                                                                                                 \
+        }                                                                                                                         \
+    } while (0)
+// ... and its fetch: every lane polls ITS 16-byte words of the winner's row until both tags of each are this epoch's
+#define JSLP_XL_FETCH_ROW(PCCOL, QUOT)                                                                                            \
+    do {                                                                                                                          \
+        efetch += 1;                                                                                                              \
+        unsigned spins_ = 0;                                                                                                      \
+        const int off_ = par * pub_stride + ((WLL ? 0 : bw) * ld + c0) * 16;                                                      \
+        const int offq_ = par * pub_stride + ((WLL ? 0 : bw) * ld + (PCCOL)) * 16; /* (PCCOL > 0: every lane also reads the row's entry of the \
+            entering column -- quot, simplex.ts:333 -- one address per wave: no LDS broadcast, no barrier behind the fetch) */      \
+        if (WLL) { /* the winner stores only now: look at ONE word per wave until it is up (4096 waves x 16 bytes per look instead \
+                      of 256 workgroups x 32 KB), then fetch -- and verify -- the row */                                           \
+            unsigned probes_ = 0;                                                                                                 \
+            for (;;) {                                                                                                            \
+                const v4u_t q_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, offq_, 0, 16);                                  \
+                if (q_.y == tag && q_.w == tag) break;                                                                            \
+                __builtin_amdgcn_s_sleep(1);                                                                                      \
+                if ((++probes_ & 63u) == 0 && (AG_LOAD(f.abort_flag) != 0u || probes_ > f.spin_limit)) break; /* (the loop below gives up properly) */ \
+            }                                                                                                                     \
+        }                                                                                                                         \
+        for (;;) {                                                                                                                \
+            if (__builtin_amdgcn_readfirstlane((int)(f.test_late_wave0 != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);          \
+            bool ok_ = true;                                                                                                      \
+            if (colok) {                                                                                                          \
+                _Pragma("unroll") for (int j = 0; j < CPT; j++) {                                                                 \
+                    if (c0 + j >= ld) continue;                                                                                   \
+                    const v4u_t v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_ + j * 16, 0, 16);                      \
+                    ok_ = ok_ && v_.y == tag && v_.w == tag;                                                                      \
+                    pv[j] = __longlong_as_double((long long)((u64_t)v_.x | ((u64_t)v_.z << 32)));                                 \
+                }                                                                                                                 \
+            }                                                                                                                     \
+            if ((PCCOL) > 0) {                                                                                                    \
+                const v4u_t q_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, offq_, 0, 16);                                  \
+                ok_ = ok_ && q_.y == tag && q_.w == tag;                                                                          \
+                (QUOT) = __longlong_as_double((long long)((u64_t)q_.x | ((u64_t)q_.z << 32)));                                    \
+            }                                                                                                                     \
+            if (__all(ok_)) break;                                                                                                \
+            __builtin_amdgcn_s_sleep(1);                                                                                          \
+            ++spins_;                                                                                                             \
+            bool dead_ = false;                                                                                                   \
+            if ((spins_ & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead_ = true;                                                 \
+            if (spins_ > f.spin_limit) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead_ = true; }                               \
+            if (dead_) { if (lane == 0) atomicMax(&sm.okbad, efetch); break; }                                                    \
+        }                                                                                                                         \
+    } while (0)
+
 // CHK = false: a build without any of the cycle check's code (the host launches it when the check is off: with the test's loops
 // inlined in the middle of the pivot loop the check-OFF solve ran 2 % slower)
 template <int THREADS, int CPT, int ROWS, bool OPT, bool CHK, bool XL = false>
@@ -204,6 +315,8 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     // would drop the line and send the readers to memory) and are read with `sc1` loads (L1-bypassing, L2-served); no write-back
     // fence anywhere (tools/micro/xcd_handoff_bench.hip flavour 1: 1.9 k cycles per 32 -> 32 exchange against 8.3 k chip-wide)
     constexpr int ST_AUX = XL ? 0 : 16;           // aux of the hand-off stores: 16 = sc1 (write-through to memory)
+    constexpr bool WLL = !XL && JSLP_PIPE_WINNER_LL != 0;  // winner-only tagged row (see JSLP_PIPE_WINNER_LL)
+    constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
     constexpr int NPOLLW = XL ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
@@ -214,7 +327,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     double (&r0)[CPT] = R.r0;
     typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
     const int pub_stride = (int)((const char*)f.rows_pub[1] - (const char*)f.rows_pub[0]);  // (both carved from one arena, [0] first)
-    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + f.G * ld * 8, 0x00020000);
+    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + (WLL ? 1 : f.G) * ld * (TAGGED ? 16 : 8), 0x00020000);
     const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, 2 * JSLP_F_MAXG * JSLP_G16_STRIDE, 0x00020000);
 #ifdef JSLP_DEBUG_RESIDENT
     u64_t (&rt_acc)[8] = R.rt_acc;
@@ -278,6 +391,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 k0 = sm.xq[0];
             }
         }
+        if (TAGGED && !OPT && efetch != 0u && sm.okbad == efetch) { R.end_code = 5; pend = false; break; }  // (a wave gave up in the previous pivot's row fetch: its registers hold a stale row)
         if (pc == 0) { R.end_code = 1; break; }  // uniform: optimal (simplex.ts:265-269)
         RT_MARK(6);
         // ---- S: ratio test for column pc (simplex.ts:271-296) by the wave that holds the column: the ONE lane that holds it hands
@@ -291,14 +405,26 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
             for (int j = 0; j < CPT; j++)
                 if (jsel == j) {  // uniform
+                    if (XL) {  // 32 rows: the holding lane lays its entries out in LDS (32 stores of one lane) instead of 128 readlanes
+                        if (lane == ol) {
 #pragma unroll
-                    for (int i = 0; i < ROWS; i++) {
-                        const double xi = readlane_f64(a[i][j], ol);
-                        x = lane == i ? xi : x;
+                            for (int i = 0; i < ROWS; i++) sm.quo[i] = a[i][j];
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < ROWS; i++) {
+                            const double xi = readlane_f64(a[i][j], ol);
+                            x = lane == i ? xi : x;
+                        }
                     }
                     pj = readlane_f64(p[j], ol);
                     nzj = ((unsigned)__builtin_amdgcn_readlane((int)nzm, ol) >> j) & 1u;
                 }
+            if (XL) {
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS stores
+                x = lane < ROWS ? sm.quo[lane] : 0.0;
+            }
             const int r = r_begin + lane;
             double colv = 0.0;
             int kind = 0;  // 0 skip, 1 degenerate winner, 2 quotient candidate
@@ -362,6 +488,10 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;  // lanes beyond the grid: "no candidate"
         const int goff = (par * JSLP_F_MAXG + tid) * JSLP_G16_STRIDE;
         // (the pending pivot's column entries of my rows: broadcast LDS reads, JSLP_PIPE_KCHUNK of them in flight together)
+        if (XL) {
+            if (pend) JSLP_XL_UPDATE_PASS();
+            if (pubrow != 0) JSLP_XL_PUBLISH_ROW(pubrow);
+        } else
 #pragma unroll
         for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
             double kis[ROWS];
@@ -370,7 +500,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
             for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) {
                 if (pend) JSLP_PIPE_UPDATE_ROW(i);
-                if (JSLP_PIPE_SPECPUB && pubrow != 0 && r_begin + i == pubrow && colok) {  // (uniform but for colok)
+                if (JSLP_PIPE_SPECPUB && !WLL && pubrow != 0 && r_begin + i == pubrow && colok) {  // (uniform but for colok)
                     const int off = par * pub_stride + (b * ld + c0) * 8;
 #pragma unroll
                     for (int j = 0; j < CPT; j += 2) {
@@ -416,7 +546,8 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; sm.part_rdeg[wv] = rdeg; }
         }
         RT_MARK(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2 (the winner's release below builds on it)
+        if (TAGGED && !OPT && tid == THREADS - 1) { sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff; }  // the next pricing's reductions: everybody read this pivot's before the barrier that closed S; the barrier below orders the reset in front of the next pricing
+        if (!TAGGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2 (the winner's release below builds on it; XL / winner-only: the row carries its tags)
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
         RT_MARK(3);
@@ -464,7 +595,8 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         //      whose row is going to be read, here, 139 k -- 149 k with the drain in front of the barrier that closes the gather instead of
         //      a barrier of its own here (155 k with the unsound release) -------------------------------------------------------------
         const int bw = pr / f.rpb;
-        if (bw == b) {  // (uniform: pr is the row I published -- my candidate was the chip's best)
+        if (WLL && bw == b) JSLP_XL_PUBLISH_ROW(pr);  // (only the winner, only now: 32 KB per pivot instead of 4 MB of candidates; the tags are the flag)
+        if (!TAGGED && bw == b) {  // (uniform: pr is the row I published -- my candidate was the chip's best; XL: tags inside the row, no flag)
             if (!JSLP_PIPE_SPECPUB && colok) {  // the row leaves only now, and only from here: 16 KB per pivot instead of 4 MB of candidates
 #pragma unroll
                 for (int i = 0; i < ROWS; i++) {
@@ -507,6 +639,9 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         {
             // EVERY wave waits for its own copy of the flag, then loads its columns of the row
             // (see resident_phase's step E); a wave that gives up raises sm.okbad to this fetch's number
+            if (TAGGED) {
+                JSLP_XL_FETCH_ROW(pc, quot);
+            } else {
             efetch += 1;
             unsigned spins = 0;
             for (;;) {
@@ -534,6 +669,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                     pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
                 }
             }
+            }  // !XL
             if (has_pc) {
 #pragma unroll
                 for (int j = 0; j < CPT; j++)
@@ -545,10 +681,12 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                         }
                     }
             }
+            if (!(TAGGED && !OPT)) {  // (XL / winner-only: quot came with the fetch, the reductions were reset in front of the gather's barrier, and a wave that gave up is noticed behind the next pricing's first barrier)
             if (tid == 0) { sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff; }  // the next pricing's reductions (reset before a barrier)
             __syncthreads();
             if (sm.okbad == efetch) R.end_code = 5;
             quot = sm.xq2[okslot];
+            }
             if (OPT) {
 #pragma unroll
                 for (int o = 0; o < JSLP_R_MAXOPT; o++) ook[o] = sm.ook[okslot][o];
@@ -663,6 +801,10 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     }
     if (pend && R.end_code != 5) {  // whoever leaves with a pivot pending (optimal, iteration cap, hand-over) brings the rows up to date
         const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;
+        if (XL) {
+            (void)has_pc_p;
+            JSLP_XL_UPDATE_PASS();
+        } else
 #pragma unroll
         for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
             double kis[ROWS];
@@ -713,6 +855,8 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     // would drop the line and send the readers to memory) and are read with `sc1` loads (L1-bypassing, L2-served); no write-back
     // fence anywhere (tools/micro/xcd_handoff_bench.hip flavour 1: 1.9 k cycles per 32 -> 32 exchange against 8.3 k chip-wide)
     constexpr int ST_AUX = XL ? 0 : 16;           // aux of the hand-off stores: 16 = sc1 (write-through to memory)
+    constexpr bool WLL = !XL && JSLP_PIPE_WINNER_LL != 0;  // winner-only tagged row (see JSLP_PIPE_WINNER_LL)
+    constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
     constexpr int NPOLLW = XL ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
@@ -723,7 +867,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     double (&r0)[CPT] = R.r0;
     typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
     const int pub_stride = (int)((const char*)f.rows_pub[1] - (const char*)f.rows_pub[0]);
-    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + f.G * ld * 8, 0x00020000);
+    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + (WLL ? 1 : f.G) * ld * (TAGGED ? 16 : 8), 0x00020000);
     const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, 2 * JSLP_F_MAXG * JSLP_G16_STRIDE, 0x00020000);
 #ifdef JSLP_DEBUG_RESIDENT
     u64_t (&rt_acc)[8] = R.rt_acc;
@@ -798,6 +942,10 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         v4u_t g;
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;
         const int goff = (par * JSLP_F_MAXG + tid) * JSLP_G16_STRIDE;
+        if (XL) {
+            if (pend) JSLP_XL_UPDATE_PASS();
+            if (pubrow != 0) JSLP_XL_PUBLISH_ROW(pubrow);
+        } else
 #pragma unroll
         for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
             double kis[ROWS];
@@ -806,7 +954,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
             for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) {
                 if (pend) JSLP_PIPE_UPDATE_ROW(i);
-                if (pubrow != 0 && r_begin + i == pubrow && colok) {
+                if (!WLL && pubrow != 0 && r_begin + i == pubrow && colok) {
                     const int off = par * pub_stride + (b * ld + c0) * 8;
 #pragma unroll
                     for (int j = 0; j < CPT; j += 2) {
@@ -842,7 +990,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; }
         }
         RT_MARK(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2
+        if (!TAGGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
         RT_MARK(3);
@@ -864,7 +1012,8 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         if (pr == 0) { done = true; break; }  // no violated row: feasible (simplex.ts:51-54); uniform
         // ---- the winner releases its row (see phase 2) ---------------------------------------------------------------------------
         const int bw = pr / f.rpb;
-        if (bw == b && tid < THREADS / 64) {  // (every wave's stores reached the L2 before the barrier that closed the gather)
+        if (WLL && bw == b) JSLP_XL_PUBLISH_ROW(pr);
+        if (!TAGGED && bw == b && tid < THREADS / 64) {  // (every wave's stores reached the L2 before the barrier that closed the gather)
             if (XL) {
                 *reinterpret_cast<volatile u64_t*>(f.rowflagc[par] + tid * JSLP_F_MAXG + b) = (u64_t)tag;
             } else {
@@ -879,6 +1028,11 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         for (int j = 0; j < CPT; j++) pv[j] = 0.0;
         {
             // (every wave its own look at the flag and its own repeats: see phase 2)
+            if (TAGGED) {
+                double q_unused = 0.0;
+                JSLP_XL_FETCH_ROW(0, q_unused);
+                (void)q_unused;
+            } else {
             efetch += 1;
             unsigned spins = 0;
             for (;;) {
@@ -903,6 +1057,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                     pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
                 }
             }
+            }  // !XL
             __syncthreads();
             if (sm.okbad == efetch) R.end_code = 5;
         }
@@ -1066,6 +1221,10 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     }
     if (pend && R.end_code != 5) {
         const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;
+        if (XL) {
+            (void)has_pc_p;
+            JSLP_XL_UPDATE_PASS();
+        } else
 #pragma unroll
         for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
             double kis[ROWS];
@@ -1081,3 +1240,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     }
 }
 #undef JSLP_PIPE_UPDATE_ROW
+#undef JSLP_OPAQUE_SGPR
+#undef JSLP_XL_UPDATE_PASS
+#undef JSLP_XL_PUBLISH_ROW
+#undef JSLP_XL_FETCH_ROW

@@ -435,6 +435,34 @@ class DevicePool:
         vibr = np.ctypeslib.as_array(p_rows, shape=shape) if want_rows else None
         return out, rhs, vibr
 
+    def set_watched_variables(self, var_indexes):
+        """the variables whose row / RHS cell the compact read-back returns, on every member (jslp_pool_set_watched_variables)"""
+        idx = _capi.as_i32(list(var_indexes))
+        self.lib.check(self.lib.jslp_pool_set_watched_variables(self._p, _capi.ptr_i32(idx), int(idx.shape[0])),
+                       "jslp_pool_set_watched_variables")
+        self.n_watched = int(idx.shape[0])
+
+    def applyCutsBatchWatched(self, cut_lists, check_cycles=True, packed=None, copy=True):
+        """Tableau.applyCutsBatchWatched over every member of the pool: per node rowByVarIndex / the RHS cell of the watched
+        variables (what mip-utils.ts:43-61, 100-126 read between relaxations); copy=False: views of the pool's pinned buffer"""
+        t = self.t
+        n_nodes, offs, ty, v, x = packed if packed is not None else t.pack_cut_lists(cut_lists)
+        out = (SimplexResult * max(n_nodes, 1))()
+        shape = (max(n_nodes, 1), self.n_watched)
+        if not copy:
+            p_rows = _capi._i32p()
+            p_vals = _capi._f64p()
+            self.lib.check(self.lib.jslp_pool_relax_batch_watched_pinned(
+                self._p, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(ty), _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)), out,
+                _capi.C.byref(p_rows), _capi.C.byref(p_vals)), "jslp_pool_relax_batch_watched_pinned")
+            return out, np.ctypeslib.as_array(p_rows, shape=shape), np.ctypeslib.as_array(p_vals, shape=shape)
+        rows = np.empty(shape, dtype=np.int32)
+        vals = np.empty(shape, dtype=np.float64)
+        self.lib.check(self.lib.jslp_pool_relax_batch_watched(self._p, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(ty), _capi.ptr_i32(v),
+                                                              _capi.ptr_f64(x), int(bool(check_cycles)), out, _capi.ptr_i32(rows),
+                                                              _capi.ptr_f64(vals)), "jslp_pool_relax_batch_watched")
+        return out, rows, vals
+
     def set_counting(self, enabled):
         self.lib.check(self.lib.jslp_pool_set_counting(self._p, int(bool(enabled))), "jslp_pool_set_counting")
 

@@ -1128,6 +1128,66 @@ int jslp_pool_relax_batch_pinned(jslp_pool* p, int32_t n_nodes, const int32_t* c
     return JSLP_OK;
 }
 
+/* the compact read-back over the pool: rowByVarIndex / RHS cell of the watched variables per node (mip-utils.ts:43-61) */
+int jslp_pool_set_watched_variables(jslp_pool* p, const int32_t* var_indexes, int32_t n) {
+    if (!p) return fail(JSLP_ERR_ARG, "pool_set_watched_variables: null");
+    jslp_engine* e = p->members[0];
+    if (e->uploaded && e->has_save && (!p->synced || p->synced_seq != e->root_seq)) {
+        int rc = jslp_pool_sync_root(p);
+        if (rc) return rc;
+    }
+    for (int32_t i = 0; i < p->n; i++) {
+        int rc = jslp_engine_set_watched_variables(p->members[i], var_indexes, n);
+        if (rc) return rc;
+    }
+    return JSLP_OK;
+}
+
+int jslp_pool_relax_batch_watched(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                  const int32_t* var_index, const double* value, int check_cycles, jslp_simplex_result* out,
+                                  int32_t* watched_row, double* watched_value) {
+    if (!p || n_nodes < 0 || !cut_offsets || !out) return fail(JSLP_ERR_ARG, "pool_relax_batch_watched: null");
+    jslp_engine* e = p->members[0];
+    if (!e->uploaded || !e->has_save) return fail(JSLP_ERR_STATE, "pool_relax_batch: the primary has no saved root (save() first)");
+    if (e->n_watch <= 0) return fail(JSLP_ERR_ARG, "pool_relax_batch_watched: after jslp_pool_set_watched_variables");
+    for (int32_t i = 0; i < p->n; i++)
+        if (p->members[i]->n_watch != e->n_watch) return fail(JSLP_ERR_STATE, "pool_relax_batch_watched: the members' watched variables differ from the primary's (jslp_pool_set_watched_variables sets them all)");
+    if (!p->synced || p->synced_seq != e->root_seq) {
+        int rc = jslp_pool_sync_root(p);
+        if (rc) return rc;
+    }
+    const size_t nw = (size_t)e->n_watch;
+    for (int32_t mi = 0; mi < p->n; mi++) {
+        const int32_t first = (int32_t)((int64_t)n_nodes * mi / p->n), last = (int32_t)((int64_t)n_nodes * (mi + 1) / p->n);
+        for (int32_t i = first; i < last; i++) {
+            const int32_t a = cut_offsets[i], n = cut_offsets[i + 1] - a;
+            int rc = jslp_engine_relax_watched(p->members[mi], n, type ? type + a : 0, var_index ? var_index + a : 0, value ? value + a : 0,
+                                               check_cycles, &out[i], watched_row ? watched_row + (size_t)i * nw : 0,
+                                               watched_value ? watched_value + (size_t)i * nw : 0);
+            if (rc) return rc;
+        }
+    }
+    return JSLP_OK;
+}
+
+int jslp_pool_relax_batch_watched_pinned(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                         const int32_t* var_index, const double* value, int check_cycles, jslp_simplex_result* out,
+                                         const int32_t** watched_row, const double** watched_value) {
+    if (!p) return fail(JSLP_ERR_ARG, "pool_relax_batch_watched_pinned: null");
+    const size_t nw = (size_t)(p->members[0]->n_watch > 0 ? p->members[0]->n_watch : 1);
+    const size_t need = (size_t)(n_nodes > 0 ? n_nodes : 1) * nw;
+    if (need > p->b_cap) {
+        p->b_rhs = (double*)realloc(p->b_rhs, need * sizeof(double));
+        p->b_rows = (int32_t*)realloc(p->b_rows, need * sizeof(int32_t));
+        p->b_cap = need;
+    }
+    int rc = jslp_pool_relax_batch_watched(p, n_nodes, cut_offsets, type, var_index, value, check_cycles, out, p->b_rows, p->b_rhs);
+    if (rc) return rc;
+    if (watched_row) *watched_row = p->b_rows;
+    if (watched_value) *watched_value = p->b_rhs;
+    return JSLP_OK;
+}
+
 int jslp_pool_set_counting(jslp_pool* p, int enabled) {
     if (!p) return fail(JSLP_ERR_ARG, "pool_set_counting: null");
     for (int32_t i = 0; i < p->n; i++) jslp_engine_set_counting(p->members[i], enabled);

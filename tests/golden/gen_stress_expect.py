@@ -24,7 +24,8 @@ OUT = os.path.join(ROOT, "tests", "golden", "stress_expect.json")
 CASES = [("int", 1000, 1000, 12345), ("int", 2000, 2000, 12345), ("int", 2100, 300, 12345), ("int", 1200, 2100, 12345),
          ("int", 600, 3000, 12345), ("int", 300, 2100, 12345), ("int", 2000, 4000, 12345), ("int", 4000, 2000, 12345),
          ("int", 3000, 3000, 12345),
-         ("int2p", 1000, 1000, 12345), ("int2p", 2100, 300, 12345), ("int2p", 300, 2100, 12345), ("int2p", 1200, 2100, 12345)]
+         ("int2p", 1000, 1000, 12345), ("int2p", 2100, 300, 12345), ("int2p", 300, 2100, 12345), ("int2p", 1200, 2100, 12345),
+         ("intunr3", 1200, 2100, 12345), ("intunr3", 1000, 1000, 12345)]  # the first 3 variables unrestricted: the general build
 
 
 def main(filt=""):
@@ -39,7 +40,7 @@ def main(filt=""):
             continue
         A, vibr, vibc = int_instance(m, n, seed, kind == "int2p")
         t0 = time.time()
-        t = Tableau(A, vibr, vibc, lib=lib)
+        t = Tableau(A, vibr, vibc, list(range(int(kind[6:]))) if kind.startswith("intunr") else [], lib=lib)
         r = t.simplex(check_cycles=False)
         piv = r.pivots_phase1 + max(r.pivots_phase2, 0)
         tr = np.asarray(t.pivot_trace(), dtype=np.int64).reshape(-1, 2)

@@ -60,6 +60,52 @@ def test_pool_reproduces_monster_ii_nodes_oracle(oracle_lib):
     _check_pool(oracle_lib, 3, 1)
 
 
+def _check_pool_watched(lib, n_members, reps):
+    """round 4: the COMPACT read-back over the pool (jslp_pool_relax_batch_watched[_pinned]): per node the row and the RHS cell of
+    the integer variables -- what mip-utils.ts:43-61, 100-126 read -- against the reference's own node outcomes: each node's full
+    RHS column + row map (checked against the reference's sha256 above) yields the expected compact answer"""
+    from jslpsolver_amd import Model
+    g = G.load(MONSTER_II)
+    t, calls = _root(lib, g)
+    ints = [int(v) for v in Model(g["model"]).integer_index_array]
+    nodes = [c["cuts"] or [] for c in calls[1:]] * reps
+    want = [c for c in calls[1:]] * reps
+    pool = DevicePool(t, [0] * n_members)
+    with pytest.raises(Exception):  # the watched set must be given to the POOL (every member), not just to the primary
+        t.set_watched_variables(ints)
+        pool.n_watched = len(ints)
+        pool.applyCutsBatchWatched(nodes[:4], check_cycles=True)
+    pool.set_watched_variables(ints)
+    full_res, rhs, rows = pool.applyCutsBatch(nodes, check_cycles=True, copy=True)
+    ints_a = np.asarray(ints)
+    for copy in (True, False):
+        out, rows_w, vals_w = pool.applyCutsBatchWatched(nodes, check_cycles=True, copy=copy)
+        for i, call in enumerate(want):
+            h = out[i].height
+            assert bool(out[i].feasible) == call["feasible"] and h == call["height"]
+            a_, b_ = out[i].as_dict(), full_res[i].as_dict()
+            if not call["feasible"]:  # (an infeasible node keeps the evaluation its ENGINE had before the call -- tableau.evaluation is
+                a_.pop("evaluation"), b_.pop("evaluation")  # left alone, simplex.ts:73-76 -- and the members' histories differ between the two calls)
+            assert a_ == b_
+            assert G.sha_rhs(rhs[i, :h], rows[i, :h]) == call["rhsSha"]
+            row_of = np.full(int(max(rows[i, :h].max(), ints_a.max())) + 1, -1, dtype=np.int64)
+            row_of[rows[i, 1:h]] = np.arange(1, h)
+            r = row_of[ints_a]
+            assert np.array_equal(rows_w[i], r.astype(np.int32)), (copy, i)
+            assert np.array_equal(vals_w[i].view(np.int64), np.where(r > 0, rhs[i, np.maximum(r, 0)], 0.0).view(np.int64)), (copy, i)
+    pool.close()
+    t.close()
+
+
+def test_pool_compact_read_back_oracle(oracle_lib):
+    _check_pool_watched(oracle_lib, 3, 1)
+
+
+@pytest.mark.gpu
+def test_pool_compact_read_back_of_four_virtual_devices(hip_lib):
+    _check_pool_watched(hip_lib, 4, 3)  # 453 nodes over 4 engines on the one GPU, outcomes in ONE pinned [453 x 112] buffer
+
+
 @pytest.mark.gpu
 def test_pool_of_four_virtual_devices_reproduces_monster_ii_nodes(hip_lib):
     _check_pool(hip_lib, 4, 3)  # 453 nodes over 4 engines / streams / host threads on the one GPU

@@ -1,7 +1,7 @@
 """Round 4: the XCD-LOCAL register-resident geometry (`k_simplex_resident<512, 2, 32, .., XL>`: tableaus up to 1024 x 1024 on the
-<= 32 workgroups of ONE XCD, hand-offs through that XCD's L2 -- jslp_resident.hip.h / jslp_resident_pipe.hip.h, `XL`) is the DEFAULT
-for mid-size LPs without unrestricted variables / optional objectives (BASELINE configs 2 and 4-root: tableau.ts:250-258,
-simplex.ts:14-23).  Against the reference's own goldens (every pivot, flags, final tableau), the C restatement on two-phase
+<= 32 workgroups of ONE XCD, hand-offs through that XCD's L2 -- jslp_resident.hip.h / jslp_resident_pipe.hip.h, `XL`) takes
+mid-size LPs without unrestricted variables / optional objectives (BASELINE configs 2 and 4-root: tableau.ts:250-258,
+simplex.ts:14-23) when JSLP_XL=1 (opt-in: measured correct but not faster than the chip-wide kernel in round 4).  Against the reference's own goldens (every pivot, flags, final tableau), the C restatement on two-phase
 instances, with the health counters asserted: a launch whose workgroups did not land on one XCD is an ABORT, never a silent slow path."""
 import os
 import sys
@@ -30,9 +30,10 @@ def _solve(lib, m, vibr, vibc, check, precision=1e-8):
 
 @pytest.mark.parametrize("check", [False, True])
 @pytest.mark.parametrize("kind,n", [("ra", 500), ("lp", 500), ("ra", 1000), ("lp", 1000)])
-def test_default_policy_mid_size_dense_is_the_reference(hip_lib, kind, n, check):
-    """501 x 501 and 1001 x 1001 (all phase 2 / all phase 1, infeasible): the default policy picks the XCD-local geometry; every
+def test_xcd_local_mid_size_dense_is_the_reference(hip_lib, kind, n, check, monkeypatch):
+    """501 x 501 and 1001 x 1001 (all phase 2 / all phase 1, infeasible) with JSLP_XL=1: the XCD-local geometry; every
     pivot and every double of the final tableau are the reference's; one launch, no abort"""
+    monkeypatch.setenv("JSLP_XL", "1")
     name = ("generateResourceAllocation" if kind == "ra" else "generateRandomLP") + "_%dx%d_seed12345" % (n, n)
     g = G.load(os.path.join(G.GOLDEN, "synthetic", name + ".json.gz"))
     if kind == "ra":
@@ -49,9 +50,10 @@ def test_default_policy_mid_size_dense_is_the_reference(hip_lib, kind, n, check)
 
 
 @pytest.mark.parametrize("name", ["Monster_Problem", "Monster_II"])
-def test_monster_root_lps_run_xcd_local_by_default(hip_lib, name):
-    """BASELINE config 2 (Monster LP, 625 x 553, 1 % dense) and config 4's root relaxation (Monster_II, 945 x 925): the first
+def test_monster_root_lps_xcd_local(hip_lib, name, monkeypatch):
+    """JSLP_XL=1 on BASELINE config 2 (Monster LP, 625 x 553, 1 % dense) and config 4's root relaxation (Monster_II, 945 x 925): the first
     simplex() of the reference's own run -- pivots, RHS column + row map, evaluation"""
+    monkeypatch.setenv("JSLP_XL", "1")
     g = G.load(os.path.join(G.GOLDEN, "fixtures", name + ".json.gz"))
     model = Model(g["model"])
     m, vibr, vibc = model.build_tableau()
@@ -94,6 +96,7 @@ def test_xcd_local_two_phase_against_the_oracle(hip_lib, oracle_lib, shape, kind
 
 @pytest.mark.parametrize("abort_at", [0, 9])
 def test_xcd_local_abort_rolls_back_and_resolves(hip_lib, abort_at, monkeypatch):
+    monkeypatch.setenv("JSLP_XL", "1")
     monkeypatch.setenv("JSLP_TEST_RESIDENT_ABORT", str(abort_at))
     g = G.load(os.path.join(G.GOLDEN, "synthetic", "generateResourceAllocation_500x500_seed12345.json.gz"))
     m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, 500, 500)
@@ -102,8 +105,8 @@ def test_xcd_local_abort_rolls_back_and_resolves(hip_lib, abort_at, monkeypatch)
     assert pivot_digest(o["trace"]) == g["pivotDigest"] and G.sha_matrix(o["final"]) == g["final"]["matrixSha"]
 
 
-def test_xcd_local_can_be_switched_off(hip_lib, monkeypatch):
-    monkeypatch.setenv("JSLP_XL", "0")
+def test_xcd_local_is_opt_in(hip_lib, monkeypatch):
+    monkeypatch.delenv("JSLP_XL", raising=False)
     m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, 500, 500)
     o = _solve(hip_lib, m, vibr, vibc, False)
     assert o["path"] == "resident" and pivot_digest(o["trace"]) == "1cda2607"

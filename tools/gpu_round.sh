@@ -12,7 +12,7 @@ for s in $steps; do
     xl) timeout 600 python -m pytest tests/test_xcd_local.py -m gpu -q > $out/xl.log 2>&1 < /dev/null; echo "xl rc=$?"; tail -25 $out/xl.log ;;
     xlt) timeout 600 python tools/xl_times.py $out/xl_times.md > $out/xl_times.log 2>&1 < /dev/null; echo "xlt rc=$?"; tail -20 $out/xl_times.log ;;
     pins) timeout 1500 python -m pytest tests/test_resident_pins.py -m gpu -q > $out/pins.log 2>&1 < /dev/null; echo "pins rc=$?"; tail -25 $out/pins.log ;;
-    tests) timeout 1200 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1 < /dev/null; echo "tests rc=$?"; tail -4 $out/pytest_gpu.log ;;
+    tests) timeout 1800 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1 < /dev/null; echo "tests rc=$?"; tail -4 $out/pytest_gpu.log ;;
     bench) timeout 600 python bench.py --steps 3 --warmup 1 > $out/bench.log 2>&1 < /dev/null; echo "bench rc=$?"; grep '^{' $out/bench.log | cut -c1-1500 ;;
     benchfast) timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench.log 2>&1 < /dev/null; echo "bench rc=$?"; grep '^{' $out/bench.log | cut -c1-1200 ;;
     prof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/prof -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/prof.log 2>&1 < /dev/null); echo "prof rc=$?"; timeout 120 python tools/rocpd_stats.py $(ls $out/prof/*.db | head -1) $out/kernel_stats.md < /dev/null | tail -12 ;;

@@ -6,7 +6,7 @@ instance has no known answer (JSLP_ALLOW_UNVERIFIED=1: compare with the first ru
     int    (default) dense integer LP, all "<=" rows (phase 2 only): rows x cols constraints x variables, SEED (env) = 12345
     int2p  the same with rows/8 ">=" rows: a phase 1 first (through the fused pipeline on the tall / wide geometries)
     ra/lp  the reference's generateResourceAllocation / generateRandomLP(seed 12345) with cols variables and rows constraints
-    --unr k   the first k variables declared unrestricted (they never go negative on these instances: same answer, GENERAL build)
+    --unr k   the first k variables declared unrestricted (the GENERAL build; its own known answer: they price differently)
     --check   the reference's default cycle check on
   `fresh` = a new engine per run (upload + first launch each time) instead of restore() on one engine.
 Also fails when the engine reports a rolled-back resident launch (jslp_work_counters.resident_aborts): a diverged replica ends in a
@@ -52,7 +52,8 @@ def main(argv):
     seed = int(os.environ.get("SEED", "12345"))
     if kind in ("int", "int2p"):
         A, vibr, vibc = int_instance(m, n, seed, kind == "int2p")
-        want = KA.expected_stress(kind, m + 1, n + 1, seed)
+        # (unrestricted variables price differently -- simplex.ts:164-177 -- so the instance with k of them has its own known answer)
+        want = KA.expected_stress(kind + ("unr%d" % n_unr if n_unr else ""), m + 1, n + 1, seed)
     elif kind == "ra":
         A, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, m)
         want = KA.expected_dense("ra", n, m)

@@ -70,7 +70,7 @@ def run_mode():
 
 def main(out_md=None):
     res = {}
-    for mode, env in (("xl", {}), ("round3", {"JSLP_XL": "0"})):
+    for mode, env in (("xl", {"JSLP_XL": "1"}), ("round3", {"JSLP_XL": "0"})):
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode"], capture_output=True, text=True, env=e, timeout=900)
@@ -88,7 +88,7 @@ def main(out_md=None):
     print(text)
     if out_md:
         with open(out_md, "w") as fh:
-            fh.write("Mid-size LPs: the XCD-local register-resident geometry (default) against what round 3 shipped for them (JSLP_XL=0).\n"
+            fh.write("Mid-size LPs: the XCD-local register-resident geometry (JSLP_XL=1) against the default policy (chip-wide resident kernel / one LDS workgroup).\n"
                      "`simplex()` wall = best of 7 from a device-side restore(); kernel time = HIP events around the cooperative launch.\n\n" + text)
 
 
