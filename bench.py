@@ -147,6 +147,21 @@ def resident_latency_floor(H, W, n_cus=256):
                       "fp64 vector 78.6 TFLOP/s = 128 flop/clk/CU at 2.4 GHz"}
 
 
+def kernel_sources_sha():
+    """identity of the tree a measurement belongs to, as far as the kernels go: sha256 over jslpsolver_amd/csrc/* and the C ABI header
+    (the GPU boxes have no .git; tools/pmc_latest.py stamps the PMC summary with the same hash)"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "jslpsolver_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    with open(os.path.join(ROOT, "include", "jslp_engine.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(key, kernel, alg_bytes):
     """HBM bytes per unit of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
     runs, gfx950 FETCH_SIZE x2 correction): counters cannot be read from inside this process, so the committed summary of
@@ -157,6 +172,9 @@ def pmc_traffic(key, kernel, alg_bytes):
             d = json.load(fh)[key]
         if d["kernel"] != kernel or abs(d["algorithmic_bytes_per_unit"] - alg_bytes) > 1e-2 * alg_bytes:  # (which node a slot evaluated before decides what it restores: ~0.3 % run to run)
             return None, "profiles/pmc_latest.json[%s] is for another workload / kernel (%s)" % (key, d["kernel"])
+        if d.get("kernel_sources_sha") != kernel_sources_sha():  # a summary taken on other kernel sources is not this build's traffic
+            return None, ("profiles/pmc_latest.json[%s] was taken on other kernel sources (%s, this tree: %s): re-run tools/gpu_round.sh pmc"
+                          % (key, d.get("kernel_sources_sha"), kernel_sources_sha()))
         return d["traffic_bytes_per_unit"], "profiles/pmc_latest.json[%s] (%s; %s)" % (key, d["kernel"], d["source"])
     except Exception:
         return None, "no PMC summary committed for %s" % key
@@ -355,7 +373,14 @@ def main():
             extras["cycle_check_on"] = {"workload": "config 3a with options.exitOnCycles = true (the reference's default, src/model.ts:73)",
                                         "value": sum_over_ranks(float(piv2)) / el2, "unit": "pivots/s", "steps": k2, "ms_per_step": 1e3 * el2 / k2,
                                         "pivot_digest": d2, "kernel": t.last_path(),
-                                        "roofline_frac": (bytes_per_unit / ((km2 / 1e3) / max(ln2, 1))) / HBM_PEAK if ln2 else None}
+                                        # (same two figures as the headline's `roofline` object, for this leg's own event-timed pivots)
+                                        "latency_floor_frac": (resident_latency_floor(H, W)["floor_us"] / ((km2 * 1e3) / max(ln2, 1))) if (ln2 and t.last_path() == "resident") else None,
+                                        "algorithmic_frac_of_hbm_peak": (bytes_per_unit / ((km2 / 1e3) / max(ln2, 1))) / HBM_PEAK if ln2 else None}
+            # the register-resident kernels must not have been rolled back / handed on behind the numbers above
+            hc = t.get_counters()
+            if hc["resident_aborts"] or hc["resident_handovers"]:
+                raise WrongAnswer("resident kernel health: %s (a rolled-back launch times the streaming fallback)" % {k: hc[k] for k in ("resident_aborts", "resident_handovers", "resident_launches")})
+            extras["resident_health"] = {k: hc[k] for k in ("resident_launches", "resident_aborts", "resident_handovers")}
         t.close()
 
         # ---- the other config-3 instance (3b: generateRandomLP, every pivot is a phase-1 pivot; ends infeasible) -------------
@@ -509,6 +534,8 @@ def relaxation_legs(ctx, args, reps=16):
     t.set_watched_variables(ints)
     fnw = lambda: t.applyCutsBatchWatched(None, check_cycles=True, packed=packed, copy=False)
     (res_w, rows_w, vals_w), el_w, per_call_w = timed_calls(fnw, 5, 10)
+    rows_w_keep, vals_w_keep = np.array(rows_w), np.array(vals_w)  # (the pool leg below compares with them)
+    res_w = [res_w[i] for i in range(len(mine))]
     if rank == 0:  # against the full read-back checked above, node by node
         ints_a = np.asarray(ints)
         for i in range(len(mine)):
@@ -569,6 +596,17 @@ def relaxation_legs(ctx, args, reps=16):
                                 "note": "jslp_pool_relax_batch_pinned: the same batch split over 4 engines (own stream + host thread each) on "
                                         "the one visible GPU; on a multi-GPU node the members sit on different devices and the root is "
                                         "fanned out with hipMemcpyPeerAsync", "per_call_us": [round(1e6 * x) for x in per4]}
+        # the same over the pool's compact read-back (round 4: jslp_pool_relax_batch_watched_pinned), checked node by node against the
+        # single engine's compact outcomes above
+        pool.set_watched_variables(ints)
+        fnpw = lambda: pool.applyCutsBatchWatched(None, check_cycles=True, packed=packed, copy=False)
+        (r4w, rows4w, vals4w), el4w, per4w = timed_calls(fnpw, 5, 10)
+        for i in range(len(mine)):
+            if (r4w[i].height != res_w[i].height or r4w[i].feasible != res_w[i].feasible or not np.array_equal(rows4w[i], rows_w_keep[i])
+                    or not np.array_equal(vals4w[i].view(np.int64), vals_w_keep[i].view(np.int64))):
+                raise WrongAnswer("device pool, compact read-back: node %d differs from the single engine's" % i)
+        out["pool_virtual4"]["compact"] = {"value": len(mine) / el4w, "unit": "LP relaxations/s", "per_call_us": [round(1e6 * x) for x in per4w],
+                                           "vs_single_engine_compact": (len(mine) / el4w) / (len(mine) / el_w)}
         pool.close()
     t.close()
     # (iii) strong scaling: one real branch-and-bound tree, speculative batches of 8 x world nodes sharded over the ranks

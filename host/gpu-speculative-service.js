@@ -10,7 +10,44 @@
 // (jslp_engine_relax_batch: one workgroup per node).  The loop itself still pops, prunes and commits in the reference's
 // order (speculation with in-order commit), so the incumbent, the iteration count and the result are those of the
 // sequential run (host/test/dropin.js checks that against the goldens).
+//
+// Round 4 -- LOOKAHEAD (install(..., { lookahead: n }); off by default, see below).  A real tree is narrower than a batch: on Monster_II a batch of up to 16 nodes yields ~5 that the walk
+// ever uses, and every NEW node (the children of the node committed a moment ago) costs one dependent round trip of ~115 us
+// -- 31 of them are 4 of the 5 ms a Solve spends in the addon.  A batch therefore also carries the CHILDREN of nodes whose
+// outcome is cached but which the walk has not reached yet: their compact outcome (row and value of every integer variable)
+// is all isIntegral / getMostFractionalVar read (mip-utils.ts:43-61, 100-126), so the two cut lists the walk WILL build when it
+// pops such a node (branch-and-cut.ts:163-191) can be built now.  Outcomes are cached by cut list (a relaxation is a pure
+// function of the saved root and its cuts), so a wrong guess costs a wasted node, never a wrong answer: the walk itself is
+// unchanged.
 "use strict";
+
+// the cut lists branch-and-cut.ts:163-191 derives from a node's outcome -- from the COMPACT read-back, without touching the tableau;
+// null when the walk would not branch on it (infeasible, integral, or pruned by `bound`)
+function predictChildren(cuts, outcome, precision, bound) {
+    const res = outcome.res;
+    if (res.feasible === false || !res.optimal || res.evaluation > bound) return null;
+    const rows = outcome.rows, values = outcome.values;
+    let biggest = 0, selected = -1, selectedValue = 0, integral = true;
+    for (let k = 0; k < rows.length; k++) {
+        if (rows[k] === -1) continue;
+        const v = values[k];
+        const fraction = Math.abs(v - Math.round(v));
+        if (fraction > precision) integral = false;
+        if (fraction > biggest) {
+            biggest = fraction;
+            selected = k;
+            selectedValue = v;
+        }
+    }
+    if (integral || selected < 0) return null;
+    return { k: selected, value: selectedValue };
+}
+
+function cutsKey(cuts) {
+    let s = "";
+    for (let i = 0; i < cuts.length; i++) s += (cuts[i].type === "min" ? "m" : "M") + cuts[i].varIndex + ":" + cuts[i].value + "|";
+    return s;
+}
 
 function Heap() {
     this.items = [];
@@ -67,7 +104,28 @@ function createGpuSpeculativeService(gpu, options) {
         if (fallback && !gpu.isOnEngine(t)) return fallback.branchAndCut(t); // kept off the engine by the host's size policy
         const model = t.model;
         const heap = new Heap();
-        const cache = new Map(); // heap stamp -> outcome of that node
+        const cache = new Map(); // cut list (cutsKey) -> outcome of that node
+        // extra nodes per batch: children of cached nodes.  OFF by default: measured on the MI355X box (profiles/r04_speculative_lookahead.txt)
+        // Monster_II goes from 31 to 28 batches per Solve and 8.4-8.7 to 7.3-8.6 ms (inside the run-to-run spread), LargeFarmMIP from 135
+        // to 97 batches but 35 -> 38 ms (26 % more nodes evaluated and keyed): best-first with LIFO ties DIVES -- the node the walk
+        // needs next is a child of the node it committed a moment ago, whose outcome nothing could have known a batch earlier
+        const lookahead = options && options.lookahead !== undefined ? options.lookahead : 0;
+        const stats = { batches: 0, evaluated: 0, committedFromCache: 0, lookaheadNodes: 0 };
+        const keyOf = (it) => (it.ck !== undefined ? it.ck : (it.ck = cutsKey(it.cuts)));
+        const childLists = (cuts, varIndex, value) => {  // branch-and-cut.ts:163-191
+            const high = [], low = [];
+            for (let k = 0; k < cuts.length; k++) {
+                const cut = cuts[k];
+                if (cut.varIndex !== varIndex) {
+                    high.push(cut);
+                    low.push(cut);
+                } else if (cut.type === "min") low.push(cut);
+                else high.push(cut);
+            }
+            high.push({ type: "min", varIndex, value: Math.ceil(value) });
+            low.push({ type: "max", varIndex, value: Math.floor(value) });
+            return [high, low];
+        };
         let iterations = 0;
         const tolerance = model && model.tolerance ? model.tolerance : 0;
         let withinTolerance = true;
@@ -97,18 +155,41 @@ function createGpuSpeculativeService(gpu, options) {
             if (node.key > bestEvaluation) continue;
             const cuts = node.cuts;
             if (speculate > 1 && saved) {
-                if (!cache.has(node.stamp)) {
+                if (!cache.has(keyOf(node))) {
                     // this node + what the heap would hand out next (best first, LIFO ties) that is not pruned already
                     const ahead = heap.items.slice().sort((a, b) => (a.key !== b.key ? a.key - b.key : b.stamp - a.stamp));
-                    const batch = [node];
-                    for (let i = 0; i < ahead.length && batch.length < speculate; i++)
-                        if (!cache.has(ahead[i].stamp) && ahead[i].key <= bestEvaluation) batch.push(ahead[i]);
+                    const batch = [node.cuts];
+                    const keys = [keyOf(node)];
+                    const inBatch = new Set(keys);
+                    for (let i = 0; i < ahead.length && batch.length < speculate; i++) {
+                        const k = keyOf(ahead[i]);
+                        if (!cache.has(k) && !inBatch.has(k) && ahead[i].key <= bestEvaluation) { batch.push(ahead[i].cuts); keys.push(k); inBatch.add(k); }
+                    }
+                    // lookahead: the children of nodes the walk has not reached yet but whose outcome is known
+                    if (compact && lookahead > 0) {
+                        const ints = model.integerVariables;
+                        const limit = batch.length + lookahead;
+                        for (let i = 0; i < ahead.length && batch.length < limit; i++) {
+                            if (ahead[i].key > bestEvaluation) break;
+                            const oc = cache.get(keyOf(ahead[i]));
+                            if (oc === undefined) continue;
+                            const pick = predictChildren(ahead[i].cuts, oc, t.precision, bestEvaluation);
+                            if (pick === null) continue;
+                            const lists = childLists(ahead[i].cuts, ints[pick.k].index, pick.value);
+                            for (let c = 0; c < 2 && batch.length < limit; c++) {
+                                const k = cutsKey(lists[c]);
+                                if (!cache.has(k) && !inBatch.has(k)) { batch.push(lists[c]); keys.push(k); inBatch.add(k); stats.lookaheadNodes += 1; }
+                            }
+                        }
+                    }
                     // compact read-back: per node the row / value of the integer variables -- all the tree reads between relaxations
-                    const outcomes = compact ? gpu.relaxBatchWatched(t, batch.map((b) => b.cuts)) : gpu.relaxBatch(t, batch.map((b) => b.cuts));
-                    for (let i = 0; i < batch.length; i++) cache.set(batch[i].stamp, outcomes[i]);
-                }
-                const outcome = cache.get(node.stamp);
-                cache.delete(node.stamp);
+                    const outcomes = compact ? gpu.relaxBatchWatched(t, batch) : gpu.relaxBatch(t, batch);
+                    for (let i = 0; i < batch.length; i++) cache.set(keys[i], outcomes[i]);
+                    stats.batches += 1;
+                    stats.evaluated += batch.length;
+                } else stats.committedFromCache += 1;
+                const outcome = cache.get(keyOf(node));
+                cache.delete(keyOf(node));
                 // restore() + addCutConstraints(cuts) bookkeeping + the cached simplex()
                 if (compact) gpu.commitWatched(t, cuts, outcome);
                 else gpu.commitOutcome(t, cuts, outcome);
@@ -154,29 +235,18 @@ function createGpuSpeculativeService(gpu, options) {
                     saved = true;
                 }
                 const variable = t.getMostFractionalVar();
-                const varIndex = variable.index;
-                const high = [];
-                const low = [];
-                for (let k = 0; k < cuts.length; k++) {
-                    const cut = cuts[k];
-                    if (cut.varIndex !== varIndex) {
-                        high.push(cut);
-                        low.push(cut);
-                    } else if (cut.type === "min") low.push(cut);
-                    else high.push(cut);
-                }
-                high.push({ type: "min", varIndex, value: Math.ceil(variable.value) });
-                low.push({ type: "max", varIndex, value: Math.floor(variable.value) });
-                heap.push(evaluation, high);
-                heap.push(evaluation, low);
+                const lists = childLists(cuts, variable.index, variable.value);
+                heap.push(evaluation, lists[0]);
+                heap.push(evaluation, lists[1]);
             }
         }
         if (bestCuts !== null) applyCuts(t, bestCuts); // :194-196
         else if (speculate > 1 && saved && lastCuts !== null) applyCuts(t, lastCuts); // no incumbent: end where the sequential run ends
         t.branchAndCutIterations = iterations;
+        t.__gpuSpeculativeStats = stats; // (diagnostics: host/test/dropin.js, bench.py's dropin_js leg)
     }
 
-    return { applyCuts, branchAndCut, __gpuSpeculative: true };
+    return { applyCuts, branchAndCut, predictChildren, __gpuSpeculative: true };
 }
 
 module.exports = { createGpuSpeculativeService };

@@ -467,7 +467,7 @@ function install(Tableau, options) {
             // models that ask for another policy or for MIR cuts keep the reference's own services
             if (opts.speculate > 1 && !(o && (o.nodeSelection || o.branching || o.useMIRCuts))) {
                 return require("./gpu-speculative-service.js").createGpuSpeculativeService(api, { speculate: opts.speculate,
-                    fullReadBack: opts.fullReadBack === true, fallback: origSelect.call(this, model) });
+                    fullReadBack: opts.fullReadBack === true, lookahead: opts.lookahead, fallback: origSelect.call(this, model) });
             }
             return origSelect.call(this, model);
         };

@@ -274,58 +274,62 @@ def test_resident_abort_rolls_back_and_resolves(hip_lib, abort_at, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,n,unrestricted", [("ra", 1000, False), ("lp", 500, False), ("ra", 500, True)])
+@pytest.mark.parametrize("kind,n,unrestricted", [("ra", 1000, False), ("lp", 500, False), ("lp", 1000, False), ("int", 1000, True)])
 def test_resident_row_fetch_with_a_late_wave(hip_lib, kind, n, unrestricted, monkeypatch):
     """The register-resident kernels fetch the winning row speculatively, next to its flag.  Round 3 found the flag looked at by
     thread 0 only: a wave that ran ahead of thread 0's wave (a cold instruction cache is enough) could load the row before it was
     visible and have it accepted on thread 0's LATER look -- rare, timing-dependent wrong pivots.  Every wave now looks at the flag
     itself before its own loads.  JSLP_TEST_RESIDENT_LATE_WAVE0 makes wave 0 of every workgroup reach every fetch ~8 k cycles late:
-    with the old protocol no solve survives that (2942 of 20755 pivots on a 3001 x 3001 LP); the traces must be the reference's.
-    Lean build (phase 2 / phase 1 pipelines) and the general build (unrestricted variables)."""
-    monkeypatch.setenv("JSLP_TEST_RESIDENT_LATE_WAVE0", "1")
+    with the old protocol no solve survives that (2942 of 20755 pivots on a 3001 x 3001 LP).  Round 4: every run against the KNOWN
+    answer of its instance -- the reference's own goldens; for the general build (3 unrestricted variables) the C restatement's
+    (tests/golden/stress_expect.json) -- not against another HIP run.  Lean build (phase 2 / phase 1 pipelines) and the general build."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import known_answers as KA
+    from resident_stress import int_instance
     monkeypatch.setenv("JSLP_FORCE_PATH", "resident")
     if kind == "ra":
         m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
-        want = {500: ("1cda2607", 657), 1000: ("77bfa35c", 2833)}[n]
-    else:
+        want = KA.expected_dense("ra", n, n)
+    elif kind == "lp":
         m, vibr, vibc, _ = generators.dense_random_lp_tableau(12345, n, n)
-        want = None
-    unr = [0, 1, 2] if unrestricted else []  # (variables that never become negative here: same trace, general build)
-    outs = []
+        want = KA.expected_dense("lp", n, n)
+    else:
+        m, vibr, vibc = int_instance(n, n, 12345)
+        want = KA.expected_stress("intunr3", n + 1, n + 1, 12345)
+    assert want is not None
+    unr = [0, 1, 2] if unrestricted else []
     for late in ("1", "0"):
         monkeypatch.setenv("JSLP_TEST_RESIDENT_LATE_WAVE0", late)
         t = Tableau(m, vibr, vibc, unr, lib=hip_lib)
         res = t.simplex(check_cycles=False)
-        assert t.last_path() == "resident"
+        assert t.last_path() == "resident" and t.get_counters()["resident_aborts"] == 0
         tr = t.pivot_trace()
-        outs.append((res.pivots_phase1, res.pivots_phase2, bool(res.feasible), pivot_digest(tr), G.sha_matrix(t.download()[0])))
+        got = (len(tr), pivot_digest(tr), G.sha_matrix(t.download()[0]), bool(res.feasible))
         t.close()
-    assert outs[0] == outs[1]
-    if want and not unrestricted:
-        assert outs[0][3] == want[0] and outs[0][1] == want[1]
+        assert got == (want["pivots"], want["digest"], want["final_sha"], want["feasible"]), (late, got)
 
 
 @pytest.mark.gpu
 def test_wide_resident_geometry_with_a_late_wave(hip_lib, monkeypatch):
-    """the same for a 512-thread geometry (1201 x 2101: <512,6,12>, phase 2 only): late wave 0 vs. not -- identical traces"""
+    """the same for a 512-thread geometry (1201 x 2101: <512,6,12>, phase 2 only), late wave 0 and not: the known answer of
+    tests/golden/stress_expect.json both times"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import known_answers as KA
+    from resident_stress import int_instance
     monkeypatch.setenv("JSLP_FORCE_PATH", "resident")
-    rng = np.random.default_rng(99)
-    mm, nn = 1200, 2100
-    A = np.zeros((mm + 1, nn + 1))
-    A[1:, 1:] = rng.integers(1, 21, (mm, nn))
-    A[0, 1:] = rng.integers(1, 51, nn)
-    A[1:, 0] = rng.integers(100, 501, mm)
-    vibr = np.array([-1] + list(range(nn, nn + mm)), dtype=np.int32)
-    vibc = np.array([-1] + list(range(nn)), dtype=np.int32)
-    outs = []
+    A, vibr, vibc = int_instance(1200, 2100, 12345)
+    want = KA.expected_stress("int", 1201, 2101, 12345)
     for late in ("1", "0"):
         monkeypatch.setenv("JSLP_TEST_RESIDENT_LATE_WAVE0", late)
         t = Tableau(A, vibr, vibc, lib=hip_lib)
         res = t.simplex(check_cycles=False)
-        assert t.last_path() == "resident"
-        outs.append((res.pivots_phase2, pivot_digest(t.pivot_trace()), G.sha_matrix(t.download()[0])))
+        assert t.last_path() == "resident" and t.get_counters()["resident_aborts"] == 0
+        tr = t.pivot_trace()
+        got = (res.pivots_phase2, pivot_digest(tr), G.sha_matrix(t.download()[0]))
         t.close()
-    assert outs[0] == outs[1] and outs[0][0] > 1000
+        assert got == (want["pivots"], want["digest"], want["final_sha"]), (late, got)
 
 
 # (round 4: the repeated-solve stress of the tall / wide shapes moved to tests/test_resident_pins.py, where every run is compared with the

@@ -12,6 +12,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def counter_sum(run_dir, sub, counter, kernel):
@@ -55,7 +56,12 @@ def main(run_dir, key, source):
                        "kernel's dispatches divided by the units of work they did; FETCH_SIZE %s" % (
                            key, "x2 (gfx950 correction for 16 B/lane streaming reads)" if wide else
                            "RAW (the x2 correction is calibrated for wide streaming reads; this kernel issues 8-byte agent-scope loads: at most 2x the raw value)"),
-             "source": source}
+             "source": source,
+             # which kernel sources the passes ran on: bench.py reports `traffic` only when this equals its own tree's hash
+             "kernel_sources_sha": __import__("bench").kernel_sources_sha(),
+             "verified": w.get("verified")}
+    if not w.get("verified") or not w2.get("verified"):
+        raise SystemExit("refusing to fold an unverified workload into profiles/pmc_latest.json (tools/pmc_workload.py checks every solve)")
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as fh:
