@@ -105,6 +105,7 @@ struct jslp_engine {
     int resident_fallbacks = 0;  // solves that were rolled back and re-run through the streaming kernels
     int resident_handovers = 0;  // solves the lean resident kernel handed to the general one (cycle-check history beyond its LDS copy)
     int resident_launches = 0;   // cooperative launches of k_simplex_resident the runtime accepted
+    int resident_refusals = 0;   // ... it refused (or that no build exists for): the solve went through the streaming kernels
     double dev_prev_evaluation = 0.0;  // jslp_engine_relax_batch_device: the evaluation its nodes started from (results_from_states)
     int dev_prev_valid = 0;
     // checkpoints (incremental-branch-and-cut.ts:31-44): equally sized device buffers, recycled through a free list
@@ -771,6 +772,9 @@ static bool xl_fits(const jslp_engine* e, int H) {
     return (e->xl_on || e->force_xl) && e->n_unr == 0 && e->n_opt == 0 && e->ld <= 1024 && H <= JSLP_XL_MAXG * JSLP_R_MAXROWS && e->precision >= 1e-15 &&
            !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
 }
+// variable indexes that can be live in a tableau of height H: constraints and variables are numbered first, cut slacks continue from
+// lastElementIndex = width + height - 2 (tableau.ts:312-316) -- e->n_idx is the CAPACITY (every cut row the engine has room for)
+static int live_index_bound(const jslp_engine* e, int H) { return std::min<int>(e->n_idx, e->W + H + 2); }
 static int resident_geometry(const jslp_engine* e, int H) {
     if (e->no_resident || e->force_path == 2 || e->precision < 1e-15) return 0;  // (see k_pivot_fused for the precision condition)
     const int rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
@@ -800,8 +804,12 @@ static int resident_geometry(const jslp_engine* e, int H) {
     const char* wt_env = getenv("JSLP_RES_WIDE_TALL");  // (read per call: tests switch it inside one process)
     const int wide_tall = wt_env ? atoi(wt_env) : -1;
     const bool lean_env = !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
-    const bool lean = lean_env && e->n_unr == 0;
-    if (!e->force_resident && wide_tall != 1 && !(lean && wide_tall != 0)) return 0;
+    // (round 4: the lean build takes unrestricted variables too -- per-lane column masks, the flags of all variable indexes in LDS:
+    //  n_idx <= JSLP_R_LUNR; the tall / wide geometries have NO general build any more -- it spilled ~0.5 KB per lane and lost to the
+    //  streaming kernels -- so what the lean build cannot take goes to the fused pipeline)
+    const bool lean = lean_env && (e->n_unr == 0 || live_index_bound(e, H) <= JSLP_R_LUNR);
+    if (!lean) return 0;
+    if (!e->force_resident && wide_tall == 0) return 0;
     if (e->ld <= 2048 && rpb <= 16) return 3;
     if (e->ld <= 3072 && rpb <= 12) return 4;
     if (e->ld <= 4096 && rpb <= 8) return 5;
@@ -1015,7 +1023,8 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
         // `it_before`: pivots the solve had done when the kernel is launched (0, or a phase 1 done by the fused pipeline)
         auto run_resident = [&](long long it_before) -> int {
             const bool lean_on = !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
-            int r = ensure_resident(e, lean_on && e->n_unr == 0 && check_cycles != 0);
+            const bool lean_unr_ok = e->n_unr == 0 || (live_index_bound(e, H) <= JSLP_R_LUNR && e->n_opt == 0);  // (the lean build's LDS copy of the "unrestricted" flags)
+            int r = ensure_resident(e, lean_on && lean_unr_ok && check_cycles != 0);
             if (r) return r;
             ResCtx rc;
             rc.c = c;
@@ -1044,7 +1053,7 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             }
             rc.G = (H + rc.rpb - 1) / rc.rpb;
             rc.H = H;
-            rc.n_idx = e->n_idx;
+            rc.n_idx = live_index_bound(e, H);
             rc.iters_cap = cap;
             rc.spin_limit = e->spin_limit;
             rc.test_abort_epoch = e->test_abort_epoch;
@@ -1079,12 +1088,20 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             // The LEAN build (all-gather protocol only, software-pipelined phase 2: jslp_resident_pipe.hip.h) takes every solve
             // without unrestricted variables; should its cycle-check history outgrow LDS it hands the solve over (status
             // ST_RUNNING / ST_PHASE1_DONE instead of ST_DONE) and the general build continues it in a second launch.
-            bool lean = lean_on && !unr;
+            bool lean = lean_on && lean_unr_ok;
+#define JSLP_RES_LAUNCH_LEAN(T, C, R)                                                                                               \
+    (unr ? (check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, true, true, false, true>, dim3(rc.G), dim3(T), args, 0, s)   \
+                         : hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, true, true, false, false>, dim3(rc.G), dim3(T), args, 0, s)) \
+         : (check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false, true, false, true>, dim3(rc.G), dim3(T), args, 0, s)  \
+                         : hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false, true, false, false>, dim3(rc.G), dim3(T), args, 0, s)))
+// (headline geometries: lean, else the general build)
 #define JSLP_RES_LAUNCH(T, C, R)                                                                                                    \
-    le = lean ? (check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false, true, false, true>, dim3(rc.G), dim3(T), args, 0, s)  \
-                              : hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false, true, false, false>, dim3(rc.G), dim3(T), args, 0, s)) \
+    le = lean ? JSLP_RES_LAUNCH_LEAN(T, C, R)                                                                                       \
        : unr  ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, true>, dim3(rc.G), dim3(T), args, 0, s)        \
               : hipLaunchCooperativeKernel((const void*)k_simplex_resident<T, C, R, false>, dim3(rc.G), dim3(T), args, 0, s)
+// (tall / wide geometries: lean only -- a hand-over the lean build cannot continue goes to the streaming kernels)
+#define JSLP_RES_LAUNCH_LEAN_ONLY(T, C, R)                                                                                          \
+    do { if (lean) le = JSLP_RES_LAUNCH_LEAN(T, C, R); } while (0)
           resident_relaunch:
 #if defined(JSLP_DEV_HEADLINE_ONLY)  /* development builds: only the headline lean instances are compiled; never shipped */
             if (geometry != 1 || !lean || e->n_opt > 0) return fail(JSLP_ERR_UNSUPPORTED, "development build: headline lean geometry only");
@@ -1106,9 +1123,9 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                     JSLP_RES_LAUNCH(1024, 2, 8);
                     break;
                 case 2: JSLP_RES_LAUNCH(512, 4, 8); break;
-                case 3: JSLP_RES_LAUNCH(512, 4, 16); break;
-                case 4: JSLP_RES_LAUNCH(512, 6, 12); break;
-                case 5: JSLP_RES_LAUNCH(512, 8, 8); break;
+                case 3: JSLP_RES_LAUNCH_LEAN_ONLY(512, 4, 16); break;
+                case 4: JSLP_RES_LAUNCH_LEAN_ONLY(512, 6, 12); break;
+                case 5: JSLP_RES_LAUNCH_LEAN_ONLY(512, 8, 8); break;
                 case 6:  // XCD-local: every JSLP_XL_SPREAD-th block of the grid works (all of them on one XCD), the others return at once
                     if (!lean) break;  // (a hand-over the general build cannot take at this geometry: the streaming kernels continue)
                     le = check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 2, 32, false, true, false, true, true>, dim3(JSLP_XL_SPREAD * rc.G), dim3(512), args, 0, s)
@@ -1117,14 +1134,16 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             }
 #endif
 #undef JSLP_RES_LAUNCH
+#undef JSLP_RES_LAUNCH_LEAN
+#undef JSLP_RES_LAUNCH_LEAN_ONLY
             if (le == hipSuccess) e->resident_launches += 1;
             if (le == hipSuccess && lean) {  // did the lean kernel finish the solve?
                 HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
                 HIPC(hipStreamSynchronize(s));
                 if (e->h_state->err == ERR_NONE && e->h_state->status != ST_DONE) {
                     e->resident_handovers += 1;
-                    if (e->n_opt > 0 || geometry == 6) {
-                        // (XCD-local geometry: there is no general build of it)
+                    if (e->n_opt > 0 || geometry >= 3) {
+                        // (XCD-local and tall / wide geometries: there is no general build of them)
                         // optional objectives: the general build does not take them -- the streaming kernels continue from the state the
                         // lean kernel left (tableau, maps and objective rows written back; status ST_RUNNING or ST_PHASE1_DONE)
                         handed_to_streaming = true;
@@ -1174,6 +1193,10 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                 }  // !ERR_BARRIER
             } else {
                 (void)hipGetLastError();  // not co-resident on this device: use one launch per pivot instead
+                e->resident_refusals += 1;
+                if (getenv("JSLP_DEBUG_LAUNCH"))
+                    fprintf(stderr, "[jslp] cooperative launch of k_simplex_resident refused (geometry %d, lean %d, unr %d, G %d): %s\n", geometry, (int)lean,
+                            (int)(e->n_unr > 0), rc.G, hipGetErrorString(le));
             }
             return JSLP_OK;
         };

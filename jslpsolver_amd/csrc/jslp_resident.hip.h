@@ -909,7 +909,7 @@ __device__ __forceinline__ void resident_phase(const ResCtx& f, RSmem& sm, ResRe
 // is the transport (jslp_resident_pipe.hip.h, `XL`): the XCD's own L2 instead of memory, no write-back fence.
 template <int THREADS, int CPT, int ROWS, bool UNR, bool LEAN = false, bool OPT = false, bool CHK = true, bool XL = false>
 __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
-    static_assert(!(LEAN && UNR), "the lean kernel leaves unrestricted variables to the general one");
+    static_assert(!(OPT && UNR), "optional objectives with unrestricted variables: the fused pipeline");
     static_assert(!XL || LEAN, "XCD-local transport: lean builds only");
     if (XL && (blockIdx.x % JSLP_XL_SPREAD) != 0) return;  // (the seven blocks in between only steer the dispatcher)
     static_assert(!OPT || LEAN, "optional objectives: lean builds only");
@@ -1041,14 +1041,14 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
         if (P2ONLY) {
             R.end_code = 5;  // never launched like this; if it were, the host rolls back and streams (like an aborted hand-off)
         } else {
-            if (LEAN) resident_phase1_pipe<THREADS, CPT, ROWS, OPT, CHK, XL>(f, sm, R, it1_start, it2_start);
+            if (LEAN) resident_phase1_pipe<THREADS, CPT, ROWS, OPT, CHK, XL, UNR>(f, sm, R, it1_start, it2_start);
             else resident_phase<1, THREADS, CPT, ROWS, UNR, LEAN>(f, sm, R, it1_start, it2_start, pb);
             if (R.end_code == 0) phase = 2;
         }
     }
     if (R.end_code == 0) {  // phase 2 (simplex.ts:100-325): first entering column, then the hot loop
         if (LEAN) {
-            resident_phase2_pipe<THREADS, CPT, ROWS, OPT, CHK, XL>(f, sm, R, it1_start, it2_start, pb);  // (prices at the top of its loop)
+            resident_phase2_pipe<THREADS, CPT, ROWS, OPT, CHK, XL, UNR>(f, sm, R, it1_start, it2_start, pb);  // (prices at the top of its loop)
         } else {
             R.pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &R.k0, R.unr, &R.neg);
             if (R.pc == 0) R.end_code = 1;

@@ -305,7 +305,12 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
 
 // CHK = false: a build without any of the cycle check's code (the host launches it when the check is off: with the test's loops
 // inlined in the middle of the pivot loop the check-OFF solve ran 2 % slower)
-template <int THREADS, int CPT, int ROWS, bool OPT, bool CHK, bool XL = false>
+// UNR (round 4): unrestricted variables in the lean loops -- a per-lane bit mask of the columns whose variable is unrestricted (R.unr,
+// like the general build's); pricing takes |reduced cost| on them and hands isReducedCostNegative to the ratio test (simplex.ts:164-177,
+// 282); phase 1 admits them whatever the sign of their coefficient (:56-71); the entering column inherits the LEAVING variable and
+// with it that variable's flag (:339-349), read from the workgroup's LDS copy of the flags (sm.lunr: n_idx <= JSLP_R_LUNR -- the host
+// sends larger models to the general build)
+template <int THREADS, int CPT, int ROWS, bool OPT, bool CHK, bool XL = false, bool UNR = false>
 __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start,
                                                      const int (&pb)[CPT]) {
     const Ctx& c = f.c;
@@ -374,8 +379,9 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         double k0 = 0.0;  // reduced cost of the entering column
         int pc;
         {
-            int neg_unused = 0;
-            pc = price_row_lds<CPT, false>(r0, c0, pb, c, sm, &k0, 0u, &neg_unused);
+            int neg_now = 0;
+            pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &k0, R.unr, &neg_now);
+            if (UNR) R.neg = neg_now;  // isReducedCostNegative of the entering column (simplex.ts:164-177): the ratio test's sign
         }
         bool opt_enter = false;  // the entering column is named by an optional objective: its main cost is within +-precision
         if (OPT && pc == 0 && c.n_opt > 0) {
@@ -441,7 +447,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 const double rhs = sm.rhsb[lane];
                 if (r >= 1 && r < r_end && !(-precision < colv && colv < precision)) {
                     if (colv > 0 && precision > rhs && rhs > -precision) kind = 1;
-                    else { quo = rhs / colv; kind = quo > precision ? 2 : 0; }
+                    else { quo = (UNR && R.neg) ? -rhs / colv : rhs / colv; kind = quo > precision ? 2 : 0; }  // simplex.ts:282
                 }
             }
             int brdeg = kind == 1 ? r : 0x7fffffff;  // rows ascend with the lane: the smallest row is the first one
@@ -585,6 +591,9 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         }
         if (stop == 3) { R.end_code = 2; R.unbounded_col = pc; break; }
         if (stop == 1) { R.end_code = 3; break; }
+        // the entering column inherits the LEAVING variable (simplex.ts:339-349) and with it its "unrestricted" flag; the maps still
+        // hold this pivot's leaving variable (the commit at the end of the iteration is a barrier away)
+        const bool leaving_unr = UNR && sm.lunr[sm.lvibr[pr]] != 0;
         // ---- the winner releases its row: ONLY the workgroup that holds row pr raises row flags, behind a real agent-scope release.
         //      The acknowledgement of a write-through (sc1) store does NOT mean the data has reached memory -- only the XCD's L2:
         //      with `s_waitcnt vmcnt(0)` alone in front of the flag stores, other XCDs saw the flag before the row about once in 10^5
@@ -793,6 +802,11 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 if (R.trace_n < c.trace_cap) c.trace[R.trace_n] = make_int2(pr, pc);
             }
         }
+        if (UNR && has_pc) {
+#pragma unroll
+            for (int j = 0; j < CPT; j++)
+                if (pc == c0 + j) R.unr = (R.unr & ~(1u << j)) | ((leaving_unr ? 1u : 0u) << j);
+        }
         R.trace_n += 1;
         R.it2 += 1;
         R.epoch = epoch + 1;
@@ -846,7 +860,7 @@ __device__ __forceinline__ u64_t u64_wave_max(u64_t x) {
 // atomicMin on the column among the lanes that hold that value.  Returns with R.end_code == 0 when phase 1 is over (feasible);
 // the tableau is whole again then.
 // ===================================================================================================================
-template <int THREADS, int CPT, int ROWS, bool OPT, bool CHK, bool XL = false>
+template <int THREADS, int CPT, int ROWS, bool OPT, bool CHK, bool XL = false, bool UNR = false>
 __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm, ResRegs<CPT, ROWS>& R, int it1_start, int it2_start) {
     const Ctx& c = f.c;
     const int tid = threadIdx.x, b = XL ? (int)(blockIdx.x / JSLP_XL_SPREAD) : (int)blockIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1010,6 +1024,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             pr = wr;
         }
         if (pr == 0) { done = true; break; }  // no violated row: feasible (simplex.ts:51-54); uniform
+        const bool leaving_unr = UNR && sm.lunr[sm.lvibr[pr]] != 0;  // (see phase 2)
         // ---- the winner releases its row (see phase 2) ---------------------------------------------------------------------------
         const int bw = pr / f.rpb;
         if (WLL && bw == b) JSLP_XL_PUBLISH_ROW(pr);
@@ -1071,9 +1086,11 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         for (int j = 0; j < CPT; j++) {
             const int col = c0 + j;
             const double coef = pv[j];
-            if (col >= 1 && col < W && coef < -precision) {
+            if (col >= 1 && col < W && ((UNR && ((R.unr >> j) & 1u)) || coef < -precision)) {
                 const double quo = -r0[j] / coef;
-                const bool take = bi == 0 || bq < quo;  // (my columns ascend: ties keep the earlier one)
+                // (my columns ascend: ties keep the earlier one.  UNR: an unrestricted column may have a zero coefficient -- the
+                //  reference's `maxQuotient < quotient` from -Infinity lets +Infinity win, never NaN or -Infinity)
+                const bool take = UNR ? (bq < quo) : (bi == 0 || bq < quo);
                 bq = take ? quo : bq;
                 bi = take ? col : bi;
             }
@@ -1212,6 +1229,11 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 c.cbv[leaving] = pc;
                 if (R.trace_n < c.trace_cap) c.trace[R.trace_n] = make_int2(pr, pc);
             }
+        }
+        if (UNR && has_pc) {
+#pragma unroll
+            for (int j = 0; j < CPT; j++)
+                if (pc == c0 + j) R.unr = (R.unr & ~(1u << j)) | ((leaving_unr ? 1u : 0u) << j);
         }
         R.trace_n += 1;
         R.it1 += 1;

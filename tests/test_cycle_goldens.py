@@ -160,9 +160,10 @@ def test_hip_embedded_through_the_streaming_kernels(hip_lib, path, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", [p for p in EMBEDDED if "2040x2030" in p or "2000x2000" in p], ids=G.ident)
 def test_hip_embedded_general_resident_build(hip_lib, path, monkeypatch):
-    """JSLP_RES_LEAN=0 (forced resident: the wide geometries are not the general build's default): the leaderless protocol's
-    per-workgroup LDS history on the headline geometry (2011 x 2012) and on 512 lanes x 6 columns, with and without
-    unrestricted variables"""
+    """JSLP_RES_LEAN=0, forced resident: the GENERAL build's leaderless protocol with its per-workgroup LDS history on the headline
+    geometry (2011 x 2012), with and without unrestricted variables.  Round 4: the tall / wide geometries have no general build any
+    more (the lean one takes unrestricted variables; the general one spilled and lost to the streaming kernels): the 2041-row
+    embeddings then run the fused pipeline -- same answer"""
     monkeypatch.setenv("JSLP_RES_LEAN", "0")
     monkeypatch.setenv("JSLP_FORCE_PATH", "resident")
-    _check(hip_lib, path, "resident")
+    _check(hip_lib, path, "fused" if "2040x2030" in path else "resident")
