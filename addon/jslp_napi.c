@@ -737,7 +737,8 @@ static napi_value fn_get_counters(napi_env env, napi_callback_info info) {
     SET_D("gatedCells", (double)c.gated_cells); SET_D("gatedRows", (double)c.gated_rows); SET_D("restoredRows", (double)c.restored_rows);
     SET_D("cutRows", (double)c.cut_rows); SET_D("heightSum", (double)c.height_sum);
     SET_D("residentAborts", (double)c.resident_aborts); SET_D("residentHandovers", (double)c.resident_handovers);
-    SET_D("residentLaunches", (double)c.resident_launches);
+    SET_D("residentLaunches", (double)c.resident_launches); SET_D("residentRefusals", (double)c.resident_refusals);
+    SET_D("nodeQueueLaunches", (double)c.node_queue_launches);
     return o;
 }
 

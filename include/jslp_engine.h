@@ -281,6 +281,8 @@ typedef struct jslp_work_counters {
     int64_t resident_aborts;     /* register-resident launches rolled back (ERR_BARRIER inside the kernel)                  */
     int64_t resident_handovers;  /* solves the lean resident kernel handed on mid-solve (cycle-check history beyond its room) */
     int64_t resident_launches;   /* cooperative launches of k_simplex_resident that were accepted                           */
+    int64_t resident_refusals;   /* ... that the runtime refused (not co-resident): the solve took the streaming kernels     */
+    int64_t node_queue_launches; /* node batches evaluated by ONE launch of resident workgroups pulling nodes from a queue   */
 } jslp_work_counters;
 int jslp_engine_set_counting(jslp_engine* e, int enabled); /* also resets the counters */
 int jslp_engine_get_counters(jslp_engine* e, jslp_work_counters* out);

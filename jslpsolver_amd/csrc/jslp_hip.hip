@@ -69,6 +69,7 @@ struct jslp_engine {
     int32_t* d_cut_offs = nullptr; int8_t* d_cut_type = nullptr; int32_t* d_cut_var = nullptr; double* d_cut_val = nullptr;
     int32_t* d_cut_order = nullptr; int* d_queue = nullptr;  // batch hand-out order (most cuts first) + queue counter, uploaded with the cuts
     std::vector<int32_t> order_scratch;
+    bool queue_wgs_opt = false; int node_queue_launches = 0;  // (which build the count below is for; batches that went through k_node_queue)
     int queue_wgs = 0; size_t queue_wgs_lds = 0;             // resident workgroups of k_node_queue<512> for this LDS size
     // read-back staging (device + pinned host)
     // read-back staging: ONE device buffer -> ONE pinned buffer per group: [states | rhs | rows]
@@ -784,7 +785,13 @@ static int resident_geometry(const jslp_engine* e, int H) {
         // optional objectives: the lean build of the headline geometry keeps up to three rows of them in registers (round 3);
         // everything else (unrestricted variables, taller / wider tableaus, more rows) runs them through the fused pipeline
         const bool lean_ok = !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0) && e->n_unr == 0;
-        return (lean_ok && e->n_opt <= 3 && e->ld <= 2048 && rpb <= 8) ? 1 : 0;
+        if (!lean_ok || e->n_opt > 3) return 0;
+        if (e->ld <= 2048 && rpb <= 8) return 1;
+        // round 4: the tall geometry too (its lean phase 2 has the registers for three more rows per lane: 512 lanes x 4 columns);
+        // the 6- and 8-column geometries do not (the objective rows would spill): the fused pipeline keeps those shapes
+        const char* wt = getenv("JSLP_RES_WIDE_TALL");
+        if (wt && atoi(wt) == 0 && !e->force_resident) return 0;
+        return (e->ld <= 2048 && rpb <= 16) ? 3 : 0;
     }
     if (const char* gx = getenv("JSLP_RES_GEOM")) {  // experiments: force a geometry the tableau fits (lean build, no unrestricted variables)
         static const int rows_of[6] = {0, 8, 8, 16, 12, 8}, ld_of[6] = {0, 2048, 2048, 2048, 3072, 4096};
@@ -1123,7 +1130,14 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                     JSLP_RES_LAUNCH(1024, 2, 8);
                     break;
                 case 2: JSLP_RES_LAUNCH(512, 4, 8); break;
-                case 3: JSLP_RES_LAUNCH_LEAN_ONLY(512, 4, 16); break;
+                case 3:
+                    if (e->n_opt > 0) {  // (lean build with the optional objective rows in registers; phase 1 came through the fused pipeline)
+                        if (lean) le = check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 4, 16, false, true, true, true>, dim3(rc.G), dim3(512), args, 0, s)
+                                                    : hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 4, 16, false, true, true, false>, dim3(rc.G), dim3(512), args, 0, s);
+                        break;
+                    }
+                    JSLP_RES_LAUNCH_LEAN_ONLY(512, 4, 16);
+                    break;
                 case 4: JSLP_RES_LAUNCH_LEAN_ONLY(512, 6, 12); break;
                 case 5: JSLP_RES_LAUNCH_LEAN_ONLY(512, 8, 8); break;
                 case 6:  // XCD-local: every JSLP_XL_SPREAD-th block of the grid works (all of them on one XCD), the others return at once
@@ -1904,11 +1918,13 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     if (wg) {
         const long long max_slots = std::max<long long>(1, (16LL << 30) / (cells * 8));
         group = (int)std::min<long long>(std::min<long long>(n_nodes, group_max()), max_slots);
-        if (const size_t lds = wglds_smem(e); lds && node_queue() && wg_batch_threads() == 512 && n_nodes > 1 && e->s.n_opt == 0) {
+        if (const size_t lds = wglds_smem(e); lds && node_queue() && wg_batch_threads() == 512 && n_nodes > 1) {
             // the queue kernel wants exactly as many slots as the chip keeps workgroups resident
-            if (e->queue_wgs == 0 || e->queue_wgs_lds != lds) {
+            if (e->queue_wgs == 0 || e->queue_wgs_lds != lds || e->queue_wgs_opt != (e->s.n_opt > 0)) {
                 int per_cu = 0, cus = 0;
-                HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_node_queue<512, true>, 512, lds));
+                if (e->s.n_opt > 0) HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_node_queue<512, false, true>, 512, lds));
+                else HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_node_queue<512, true>, 512, lds));
+                e->queue_wgs_opt = e->s.n_opt > 0;
                 HIPC(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
                 e->queue_wgs = std::max(1, per_cu * cus);
                 e->queue_wgs_lds = lds;
@@ -1942,11 +1958,15 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         }
     }
     if (const size_t lds = wglds_smem(e); wg && lds && node_queue() && n_nodes > group && checkpoint < 0 && e->has_save && e->slot0_synced &&
-        group <= e->slots_synced && !e->timing && e->one_launch_nodes && wg_batch_threads() == 512 && e->s.n_opt == 0) {
+        group <= e->slots_synced && !e->timing && e->one_launch_nodes && wg_batch_threads() == 512) {
         Snapshot sn = root_snapshot(e);
         e->last_path = "workgroup";
+        e->node_queue_launches += 1;
         const int32_t* order = node_queue() == 2 ? e->d_cut_order : (const int32_t*)nullptr;
-        if (node_cow())
+        if (e->s.n_opt > 0)  // optional objectives: the OPT build (eager restores)
+            hipLaunchKernelGGL((k_node_queue<512, false, true>), dim3(group), dim3(512), lds, s, e->s, sn, cu, (int)n_nodes, order, e->d_queue, check_cycles,
+                               cap, (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states, g_stride);
+        else if (node_cow())
             hipLaunchKernelGGL((k_node_queue<512, true>), dim3(group), dim3(512), lds, s, e->s, sn, cu, (int)n_nodes, order, e->d_queue, check_cycles,
                                cap, (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states, g_stride);
         else
@@ -2238,7 +2258,7 @@ extern "C" int jslp_engine_set_counting(jslp_engine* e, int enabled) {
     e->counting = enabled ? 1 : 0;
     e->s.cnt = enabled ? e->d_cnt : nullptr;
     e->wc = jslp_work_counters{};
-    e->resident_fallbacks = e->resident_handovers = e->resident_launches = 0;
+    e->resident_fallbacks = e->resident_handovers = e->resident_launches = e->resident_refusals = e->node_queue_launches = 0;
     return JSLP_OK;
 }
 
@@ -2248,6 +2268,8 @@ extern "C" int jslp_engine_get_counters(jslp_engine* e, jslp_work_counters* out)
     out->resident_aborts = e->resident_fallbacks;
     out->resident_handovers = e->resident_handovers;
     out->resident_launches = e->resident_launches;
+    out->resident_refusals = e->resident_refusals;
+    out->node_queue_launches = e->node_queue_launches;
     if (e->d_cnt) {
         HIPC(hipSetDevice(e->device));
         HIPC(hipStreamSynchronize(e->stream));
@@ -2621,6 +2643,7 @@ extern "C" int jslp_pool_get_counters(jslp_pool* p, jslp_work_counters* out) {
         sum.gated_cells += c.gated_cells; sum.gated_rows += c.gated_rows; sum.restored_rows += c.restored_rows;
         sum.cut_rows += c.cut_rows; sum.height_sum += c.height_sum;
         sum.resident_aborts += c.resident_aborts; sum.resident_handovers += c.resident_handovers; sum.resident_launches += c.resident_launches;
+        sum.resident_refusals += c.resident_refusals; sum.node_queue_launches += c.node_queue_launches;
     }
     hipSetDevice(p->members[0]->device);
     *out = sum;

@@ -943,7 +943,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
 // from a queue (an atomic counter) until the batch is empty -- no group boundaries, hence no idle tail per group; `order`
 // hands the nodes out most-cuts-first (the cut count predicts the repair pivots: longest-processing-time-first keeps the
 // last workgroups to finish on the cheap nodes).  Node k's outcome goes to index k whatever workgroup / slot evaluated it.
-template <int THREADS, bool COW>
+// OPT (round 4): models with optional objectives -- soft-constraint MILPs -- through the queue too (eager restores: every node takes the
+// saved root's objective rows into its slot's copy, backup.ts:94-104; a build of its own like the other OPT kernels)
+template <int THREADS, bool COW, bool OPT = false>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES : 4) k_node_queue(Slots s, Snapshot snap, Cuts cuts, int n_nodes, const int32_t* order,
                                                       int* queue, int check_cycles, int iters_cap, int cap_rows, double* rhs_out,
                                                       int32_t* rows_out, DevState* state_out, int out_stride) {
@@ -962,7 +964,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES :
         const int node = order ? order[k] : k;
         int slot = blockIdx.x;
         asm volatile("" : "+s"(slot));  // opaque per iteration: nothing derived from the slot is hoisted and kept live across nodes
-        node_lds_run<THREADS, COW>(s, snap, cuts, sm, L, slot, node, node, check_cycles, iters_cap, cap_rows, rhs_out, rows_out, state_out, out_stride);
+        node_lds_run<THREADS, COW, OPT>(s, snap, cuts, sm, L, slot, node, node, check_cycles, iters_cap, cap_rows, rhs_out, rows_out, state_out, out_stride);
         __syncthreads();
     }
     // slot 0 is also the engine's live tableau: leave it whole (the last node this workgroup evaluated), as the other batch shapes

@@ -185,14 +185,16 @@ def test_soft_tall_instance_is_the_reference_tableau():
 def test_soft_constraint_lp_beyond_the_headline_geometry_is_the_reference(hip_lib):
     """generateResourceAllocation 2000 x 3000 with 30 soft resources (tableau 3001 x 2031, three optional objective rows: they are
     updated by every pivot, simplex.ts:394-412, and break pricing ties, :221-263): the reference's own 11 997 pivots and final
-    tableau through whatever the default policy picks at this shape"""
+    tableau through the DEFAULT policy -- since round 4 the lean register-resident kernel's tall geometry with the three objective
+    rows in registers (`k_simplex_resident<512, 4, 16, .., OPT>`; round 3: the fused pipeline, ~3x slower)"""
     g = load("soft_RA_2000x3000_k30")
     m, vibr, vibc, oo = generators.soft_resource_allocation_tableau(12345, g["meta"]["n"], g["meta"]["m"], g["meta"]["k"])
     t = Tableau(m, vibr, vibc, [], precision=g["tableau"]["precision"], lib=hip_lib, optional_objectives=oo)
     res = t.simplex(check_cycles=False)
     call = g["simplexCalls"][0]
-    trace, final, cnt = t.pivot_trace(), t.download()[0], t.get_counters()
+    trace, final, cnt, path = t.pivot_trace(), t.download()[0], t.get_counters(), t.last_path()
     t.close()
+    assert path == "resident" and cnt["resident_launches"] == 1, (path, cnt)
     assert (res.pivots_phase1, res.pivots_phase2) == (call["p1"], call["p2"]) and res.evaluation == call["evaluation"]
     assert len(trace) == g["nPivots"] and pivot_digest(trace) == g["pivotDigest"]
     assert G.sha_matrix(final) == g["final"]["matrixSha"]
