@@ -91,6 +91,9 @@
 #ifndef JSLP_PIPE_WINNER_LL
 #define JSLP_PIPE_WINNER_LL 0  // chip-wide lean builds: 1 = ONLY the winner stores its row, after the decision, with the epoch tag inside the data ({lo32 | tag}{hi32 | tag} per double, write-through); the readers poll the row itself -- no candidate rows (4 MB per pivot), no drain, no write-back fence, no flag
 #endif
+#ifndef JSLP_PIPE_QUOT_DIRECT
+#define JSLP_PIPE_QUOT_DIRECT 0  // chip-wide lean builds without optional objectives: 1 = every wave reads quot (the winning row's entry of the entering column) itself next to its columns of the row -- one address per wave -- instead of the LDS broadcast + barrier behind the fetch
+#endif
 #define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
 #define JSLP_PIPE_KCHUNK 8    // pivot-column entries the update pass keeps in flight (registers: the tall / wide geometries have few to spare)
 
@@ -322,6 +325,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     constexpr int ST_AUX = XL ? 0 : 16;           // aux of the hand-off stores: 16 = sc1 (write-through to memory)
     constexpr bool WLL = !XL && JSLP_PIPE_WINNER_LL != 0;  // winner-only tagged row (see JSLP_PIPE_WINNER_LL)
     constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
+    constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT);  // quot comes with the fetch: no barrier behind it
     constexpr int NPOLLW = XL ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
@@ -397,7 +401,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 k0 = sm.xq[0];
             }
         }
-        if (TAGGED && !OPT && efetch != 0u && sm.okbad == efetch) { R.end_code = 5; pend = false; break; }  // (a wave gave up in the previous pivot's row fetch: its registers hold a stale row)
+        if (QDIRECT && !OPT && efetch != 0u && sm.okbad == efetch) { R.end_code = 5; pend = false; break; }  // (a wave gave up in the previous pivot's row fetch: its registers hold a stale row)
         if (pc == 0) { R.end_code = 1; break; }  // uniform: optimal (simplex.ts:265-269)
         RT_MARK(6);
         // ---- S: ratio test for column pc (simplex.ts:271-296) by the wave that holds the column: the ONE lane that holds it hands
@@ -552,7 +556,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; sm.part_rdeg[wv] = rdeg; }
         }
         RT_MARK(1);
-        if (TAGGED && !OPT && tid == THREADS - 1) { sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff; }  // the next pricing's reductions: everybody read this pivot's before the barrier that closed S; the barrier below orders the reset in front of the next pricing
+        if (QDIRECT && !OPT && tid == THREADS - 1) { sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff; }  // the next pricing's reductions: everybody read this pivot's before the barrier that closed S; the barrier below orders the reset in front of the next pricing
         if (!TAGGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2 (the winner's release below builds on it; XL / winner-only: the row carries its tags)
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
@@ -678,6 +682,10 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                     pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
                 }
             }
+            if (QDIRECT) {  // the pair of the row that holds column pc: the same 16 bytes in every lane (behind the same look at the flag)
+                const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, par * pub_stride + (bw * ld + (pc & ~1)) * 8, 0, 16);
+                quot = (pc & 1) ? __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32))) : __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
+            }
             }  // !XL
             if (has_pc) {
 #pragma unroll
@@ -690,7 +698,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                         }
                     }
             }
-            if (!(TAGGED && !OPT)) {  // (XL / winner-only: quot came with the fetch, the reductions were reset in front of the gather's barrier, and a wave that gave up is noticed behind the next pricing's first barrier)
+            if (!(QDIRECT && !OPT)) {  // (XL / winner-only / JSLP_PIPE_QUOT_DIRECT: quot came with the fetch, the reductions were reset in front of the gather's barrier, and a wave that gave up is noticed behind the next pricing's first barrier)
             if (tid == 0) { sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff; }  // the next pricing's reductions (reset before a barrier)
             __syncthreads();
             if (sm.okbad == efetch) R.end_code = 5;
@@ -871,6 +879,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     constexpr int ST_AUX = XL ? 0 : 16;           // aux of the hand-off stores: 16 = sc1 (write-through to memory)
     constexpr bool WLL = !XL && JSLP_PIPE_WINNER_LL != 0;  // winner-only tagged row (see JSLP_PIPE_WINNER_LL)
     constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
+    constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT);  // quot comes with the fetch: no barrier behind it
     constexpr int NPOLLW = XL ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
