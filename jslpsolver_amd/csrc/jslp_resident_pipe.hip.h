@@ -70,6 +70,26 @@
 // dependent LDS reads late in a 9726-pivot solve outlast the row fetch).  Not kept.
 // Two looks in flight in the gather's poll and in the wait for the row flag (a look is a fabric round trip, so one at a time notices
 // the last summary half a round trip late on average): 140.0 k against 142.6 k -- the extra looks cost more than the earlier notice.
+// Round 4 (r04_a ... r04_o; profiles/r04_*): (1) the XCD-LOCAL build (`XL`: <= 32 workgroups of ONE XCD, 512 lanes x 2 columns x 32 rows,
+// hand-offs through that XCD's L2 with plain stores + sc1 loads, rows with the epoch tag inside the data -- no flag, no drain, no fence;
+// 0 repeated row fetches in every run).  As first instantiated from these loops it was SLOWER than the chip-wide kernel (8.6-10 us per
+// pivot against 6.0 on 501 x 501 / 1001 x 1001): JSLP_PIPE_UPDATE_ROW costs ~55 instructions per row, 10-13 k cycles per pass at 32
+// rows.  With the update pass restructured (one ballot for the row gate, readlane multipliers: 3.9-5.9 k cycles), the tagged rows and
+// quot read with the fetch it is at PARITY -- 5.97 / 6.36 us against 5.98 / 6.05, Monster LP 428 against 411 us in one LDS workgroup,
+// Monster_II's root 440 against 448 us (profiles/r04_xl_times.md) -- on an eighth of the chip: a pivot of these loops is bound by the
+// instruction stream of ~2500 instructions per wave (sections of 1-2 k cycles each whatever the transport: profiles/r04_xl_phase_timing.txt),
+// not by the hand-offs the XCD-local transport shortens.  Opt-in (JSLP_XL=1).  Tried on the way: 256 lanes x 4 columns (one wave per
+// SIMD): 22.6 k cycles per pivot against 14.9 k; a second, gate-free copy of the update loop for dense pivot rows: 365-560 VGPR
+// spills (the register allocator keeps both arms' copies of the 128 tableau registers); the column gate as an EXEC-masked branch per
+// cell: 5.1-8.5 k cycles per pass against 3.9-5.9 k.  (2) WINNER-ONLY tagged row for the chip-wide loops (JSLP_PIPE_WINNER_LL=1: no
+// candidate rows, no drain, no fence, no flag; 32 KB instead of 4 MB per pivot; a one-word probe per wave before the row is read):
+// correct, 117.4 k against 147.6 k pivots/s on config 3a, 103 k against 143 k on 3b -- a store issued AFTER the decision takes a
+// write-through to memory plus a poll to arrive, which the speculative rows have behind them by then (profiles/
+// r04_headline_winner_only_tagged_row.txt).  (3) quot read by every wave next to its columns of the row instead of the LDS broadcast +
+// barrier behind the fetch (JSLP_PIPE_QUOT_DIRECT=1): 148.5 k against 147.6 k with the cycle check off, 130.9 k against 133.8 k with it
+// on (profiles/r04_headline_quot_direct.txt): off.  (4) UNRESTRICTED VARIABLES in these loops (`UNR`) and optional objectives in the
+// tall geometry: the 4001 x 2001 golden with 50 unrestricted variables 105.7 k pivots/s (fused pipeline: 32-35 k), the 3001 x 2031
+// golden with three objective rows 104 k (40.6 k) -- both the reference's own digests.
 // ===================================================================================================================
 // -DJSLP_CHAOS_BUILD (tests / diagnosis only, never the shipped library): at every phase boundary of the pipelined loops one wave of
 // the workgroup -- a different one per pivot and boundary -- sleeps ~6 k cycles (JSLP_TEST_RESIDENT_LATE_WAVE0=2), and with =3 every

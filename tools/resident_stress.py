@@ -65,9 +65,11 @@ def main(argv):
         return 2
     lib = _capi.load_hip()
     unr = list(range(n_unr))
-    first, bad, t, pivots_done, aborts = None, 0, None, 0, 0
+    first, bad, t, pivots_done, aborts, since_upload = None, 0, None, 0, 0, 0
     for i in range(runs):
-        if fresh or t is None:
+        # (an engine's pivot trace holds 2^20 pivots since its upload: a fresh engine before it would overflow)
+        if fresh or t is None or (first is not None and since_upload + first["pivots"] > 1000000):
+            since_upload = 0
             if t is not None:
                 aborts += t.get_counters()["resident_aborts"]
                 t.close()
@@ -79,6 +81,7 @@ def main(argv):
         sig = KA.solve_signature(t, r, pivot_digest)
         sig["path"] = t.last_path()
         pivots_done += sig["pivots"]
+        since_upload += sig["pivots"]
         if first is None:
             first = sig
             print("run 0:", sig["pivots"], sig["digest"], sig["final_sha"][:16], sig["path"], flush=True)
