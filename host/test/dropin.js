@@ -185,10 +185,12 @@ if (!filter && dir.indexOf("fixtures") >= 0 && fs.existsSync(mirFile)) {
 }
 // install(..., { speculate: 16 }): the default policy with 16-node speculative batches (host/gpu-speculative-service.js)
 // must return the sequential run's result object and relaxation count on every integer fixture
-let speculativeOk = 0;
-if (!filter && dir.indexOf("fixtures") >= 0) {
+// -- and with the round-4 lookahead (children of cached nodes evaluated ahead of the walk): same results, same iteration counts,
+//    and the lookahead really ran (some node of some tree was evaluated before the walk built it)
+let speculativeOk = 0, lookaheadOk = 0, lookaheadNodes = 0;
+for (const lookahead of [0, 16]) if (!filter && dir.indexOf("fixtures") >= 0) {
     uninstall();
-    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16, minCells: 0 });
+    uninstall = gpu.install(Tableau, { SlackVariable, solver, speculate: 16, minCells: 0, lookahead });
     for (const f of fs.readdirSync(dir).filter((x) => x.endsWith(".json.gz")).sort()) {
         const g = loadGolden(dir, f);
         if (!g.model || !g.tableau || g.tableau.integerVarIndexes.length === 0) continue;
@@ -205,8 +207,12 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
         if (JSON.stringify(Object.keys(res)) !== JSON.stringify(g.resultKeys)) bad.push("keys");
         if (JSON.stringify(got) !== JSON.stringify(g.result)) bad.push("values");
         if (solution._tableau.branchAndCutIterations !== g.final.branchAndCutIterations) bad.push("B&B iterations " + solution._tableau.branchAndCutIterations + " != " + g.final.branchAndCutIterations);
+        const sp = solution._tableau.__gpuSpeculativeStats;
+        if (lookahead && sp) lookaheadNodes += sp.lookaheadNodes;
         gpu.release(solution._tableau);
-        if (bad.length) { fail += 1; console.log("FAIL speculative", f, bad.join("; ")); } else speculativeOk += 1;
+        if (bad.length) { fail += 1; console.log("FAIL speculative", lookahead ? "(lookahead)" : "", f, bad.join("; ")); }
+        else if (lookahead) lookaheadOk += 1;
+        else speculativeOk += 1;
     }
 }
 // random models (tests/golden/fuzz_*.jsonl.gz: the reference's generators under seven service policies; soft constraints,
@@ -374,6 +380,6 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
     }
 }
 console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk,
-    incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk,
+    incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk, lookahead_ok: lookaheadOk, lookahead_ran: lookaheadNodes > 0,
     size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, instance_ok: instanceOk, cycle_ok: cycleOk, pool_ok: poolOk, pool_full_ok: poolFullOk, watched_ok: watchedOk, pool_watched_ok: poolWatchedOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);
