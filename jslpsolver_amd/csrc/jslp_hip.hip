@@ -835,7 +835,9 @@ static int ensure_resident(jslp_engine* e, bool want_hist = false) {
     for (int pass = 0; pass < 2; pass++) {
         Carver cv{pass ? e->r_arena : nullptr, 0};
         e->r_gran = cv.take<u64_t>(JSLP_R_SYNC_WORDS);
-        for (int i = 0; i < 2; i++) e->r_rows[i] = cv.take<u64_t>((size_t)JSLP_F_MAXG * e->ld);
+        // (slots ld doubles apart; the 6- and 8-column geometries' permuted layout -- jslp_resident_pipe.hip.h, SLOT -- takes lanes x columns per lane
+        //  = 3072 / 4096 doubles plus a skew per slot)
+        for (int i = 0; i < 2; i++) e->r_rows[i] = cv.take<u64_t>((size_t)JSLP_F_MAXG * (e->ld <= 2048 ? (size_t)e->ld : ((size_t)e->ld + 1023) / 1024 * 1024 + JSLP_PUB_SKEW / 8));
         e->r_hist_all = e->r_want_hist ? cv.take<int2>((size_t)JSLP_F_MAXG * JSLP_PIPE_GHIST) : nullptr;  // every workgroup's own copy of the cycle-check history (lean kernel)
         e->r_sync = cv.take<unsigned>(16);
         e->rb_A = cv.take<double>((size_t)e->cap_rows * e->ld);

@@ -114,6 +114,7 @@
 #ifndef JSLP_PIPE_QUOT_DIRECT
 #define JSLP_PIPE_QUOT_DIRECT 0  // chip-wide lean builds without optional objectives: 1 = every wave reads quot (the winning row's entry of the entering column) itself next to its columns of the row -- one address per wave -- instead of the LDS broadcast + barrier behind the fetch
 #endif
+#define JSLP_PUB_SKEW 256     // bytes added to a workgroup's slot of the candidate-row buffer (see SLOT)
 #define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
 #define JSLP_PIPE_KCHUNK 8    // pivot-column entries the update pass keeps in flight (registers: the tall / wide geometries have few to spare)
 
@@ -346,6 +347,19 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     constexpr bool WLL = !XL && JSLP_PIPE_WINNER_LL != 0;  // winner-only tagged row (see JSLP_PIPE_WINNER_LL)
     constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
     constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT);  // quot comes with the fetch: no barrier behind it
+    // candidate rows in the publication buffer (chip-wide builds): pair j of lane t at ((j / 2) * THREADS + t) * 16 inside the
+    // workgroup's slot -- a wave's store of one pair is 1 KB of whole lines (with lane t's CPT columns adjacent, as they sit in the
+    // tableau, the 512-thread geometries wrote 16 bytes into each of 64 lines per instruction: the partial-line writers of round 3);
+    // only lane t of the other workgroups ever reads what lane t wrote, so the permutation is invisible outside these two loops.
+    // Measured (r04_q, pivots/s, adjacent -> permuted): 2001 x 4001 `<512,8,8>` 88.5 k -> 113.2 k, 3001 x 3001 `<512,6,12>` 102.0 k ->
+    // 106.4 k, but 4001 x 2001 `<512,4,16>` 114.4 k -> 111.6 k (two adjacent pairs per lane are half a line already; apart they are
+    // two requests): permuted from 6 columns per lane up
+    constexpr bool PERM = CPT >= 6;
+    // (the 2- and 4-column geometries keep round 3's addressing to the letter -- slots ld doubles apart: with the constant stride the
+    //  tall `<512,4,16>` instance, at its register limit, came out 2 % slower, skewed or not)
+    const int SLOT = PERM ? THREADS * CPT * 8 + JSLP_PUB_SKEW : f.c.ld * 8;
+    constexpr int PAIR_STEP = PERM ? THREADS * 16 : 16;           // bytes from a lane's pair j to its pair j + 2
+    const int lane_off = PERM ? tid * 16 : tid * CPT * 8;          // ... and where its first pair sits in the slot
     constexpr int NPOLLW = XL ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
@@ -356,7 +370,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     double (&r0)[CPT] = R.r0;
     typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
     const int pub_stride = (int)((const char*)f.rows_pub[1] - (const char*)f.rows_pub[0]);  // (both carved from one arena, [0] first)
-    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + (WLL ? 1 : f.G) * ld * (TAGGED ? 16 : 8), 0x00020000);
+    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + (TAGGED ? (WLL ? 1 : f.G) * ld * 16 : f.G * (CPT >= 6 ? THREADS * CPT * 8 + JSLP_PUB_SKEW : ld * 8)), 0x00020000);
     const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, 2 * JSLP_F_MAXG * JSLP_G16_STRIDE, 0x00020000);
 #ifdef JSLP_DEBUG_RESIDENT
     u64_t (&rt_acc)[8] = R.rt_acc;
@@ -531,14 +545,14 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) {
                 if (pend) JSLP_PIPE_UPDATE_ROW(i);
                 if (JSLP_PIPE_SPECPUB && !WLL && pubrow != 0 && r_begin + i == pubrow && colok) {  // (uniform but for colok)
-                    const int off = par * pub_stride + (b * ld + c0) * 8;
+                    const int off = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;
 #pragma unroll
                     for (int j = 0; j < CPT; j += 2) {
                         if (c0 + j >= ld) continue;
                         const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
                         v4u_t v;
                         v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, ST_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + (j >> 1) * PAIR_STEP, 0, ST_AUX);
                     }
                 }
             }
@@ -634,14 +648,14 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
                 for (int i = 0; i < ROWS; i++) {
                     if (r_begin + i != pr) continue;  // (uniform)
-                    const int off = par * pub_stride + (b * ld + c0) * 8;
+                    const int off = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;
 #pragma unroll
                     for (int j = 0; j < CPT; j += 2) {
                         if (c0 + j >= ld) continue;
                         const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
                         v4u_t v;
                         v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, ST_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + (j >> 1) * PAIR_STEP, 0, ST_AUX);
                     }
                 }
             }
@@ -660,7 +674,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         }
         // ---- E: the winning row: every wave waits for its copy of the flag and loads its columns; the lane that holds column pc
         //         broadcasts quot = A[pr, pc] --------------------------------------------------------------------------------------
-        const int off_in = par * pub_stride + (bw * ld + c0) * 8;
+        const int off_in = PERM ? par * pub_stride + bw * SLOT + lane_off : par * pub_stride + (bw * ld + c0) * 8;
         const bool has_pc = colok && pc >= c0 && pc < c0 + CPT;
         double pv[CPT];
 #pragma unroll
@@ -697,13 +711,13 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
                 for (int j = 0; j < CPT; j += 2) {
                     if (c0 + j >= ld) continue;
-                    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + j * 8, 0, 16);
+                    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + (j >> 1) * PAIR_STEP, 0, 16);
                     pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
                     pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
                 }
             }
             if (QDIRECT) {  // the pair of the row that holds column pc: the same 16 bytes in every lane (behind the same look at the flag)
-                const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, par * pub_stride + (bw * ld + (pc & ~1)) * 8, 0, 16);
+                const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, par * pub_stride + bw * SLOT + (PERM ? ((((pc % CPT) >> 1) * THREADS) + pc / CPT) * 16 : (pc & ~1) * 8), 0, 16);
                 quot = (pc & 1) ? __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32))) : __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
             }
             }  // !XL
@@ -900,6 +914,19 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     constexpr bool WLL = !XL && JSLP_PIPE_WINNER_LL != 0;  // winner-only tagged row (see JSLP_PIPE_WINNER_LL)
     constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
     constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT);  // quot comes with the fetch: no barrier behind it
+    // candidate rows in the publication buffer (chip-wide builds): pair j of lane t at ((j / 2) * THREADS + t) * 16 inside the
+    // workgroup's slot -- a wave's store of one pair is 1 KB of whole lines (with lane t's CPT columns adjacent, as they sit in the
+    // tableau, the 512-thread geometries wrote 16 bytes into each of 64 lines per instruction: the partial-line writers of round 3);
+    // only lane t of the other workgroups ever reads what lane t wrote, so the permutation is invisible outside these two loops.
+    // Measured (r04_q, pivots/s, adjacent -> permuted): 2001 x 4001 `<512,8,8>` 88.5 k -> 113.2 k, 3001 x 3001 `<512,6,12>` 102.0 k ->
+    // 106.4 k, but 4001 x 2001 `<512,4,16>` 114.4 k -> 111.6 k (two adjacent pairs per lane are half a line already; apart they are
+    // two requests): permuted from 6 columns per lane up
+    constexpr bool PERM = CPT >= 6;
+    // (the 2- and 4-column geometries keep round 3's addressing to the letter -- slots ld doubles apart: with the constant stride the
+    //  tall `<512,4,16>` instance, at its register limit, came out 2 % slower, skewed or not)
+    const int SLOT = PERM ? THREADS * CPT * 8 + JSLP_PUB_SKEW : f.c.ld * 8;
+    constexpr int PAIR_STEP = PERM ? THREADS * 16 : 16;           // bytes from a lane's pair j to its pair j + 2
+    const int lane_off = PERM ? tid * 16 : tid * CPT * 8;          // ... and where its first pair sits in the slot
     constexpr int NPOLLW = XL ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
@@ -910,7 +937,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     double (&r0)[CPT] = R.r0;
     typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
     const int pub_stride = (int)((const char*)f.rows_pub[1] - (const char*)f.rows_pub[0]);
-    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + (WLL ? 1 : f.G) * ld * (TAGGED ? 16 : 8), 0x00020000);
+    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + (TAGGED ? (WLL ? 1 : f.G) * ld * 16 : f.G * (CPT >= 6 ? THREADS * CPT * 8 + JSLP_PUB_SKEW : ld * 8)), 0x00020000);
     const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, 2 * JSLP_F_MAXG * JSLP_G16_STRIDE, 0x00020000);
 #ifdef JSLP_DEBUG_RESIDENT
     u64_t (&rt_acc)[8] = R.rt_acc;
@@ -998,14 +1025,14 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) {
                 if (pend) JSLP_PIPE_UPDATE_ROW(i);
                 if (!WLL && pubrow != 0 && r_begin + i == pubrow && colok) {
-                    const int off = par * pub_stride + (b * ld + c0) * 8;
+                    const int off = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;
 #pragma unroll
                     for (int j = 0; j < CPT; j += 2) {
                         if (c0 + j >= ld) continue;
                         const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
                         v4u_t v;
                         v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + j * 8, 0, ST_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + (j >> 1) * PAIR_STEP, 0, ST_AUX);
                     }
                 }
             }
@@ -1066,7 +1093,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             }
         }
         // ---- E: the pivot row (= the winner's candidate row) -------------------------------------------------------------------
-        const int off_in = par * pub_stride + (bw * ld + c0) * 8;
+        const int off_in = PERM ? par * pub_stride + bw * SLOT + lane_off : par * pub_stride + (bw * ld + c0) * 8;
         double pv[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; j++) pv[j] = 0.0;
@@ -1096,7 +1123,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
                 for (int j = 0; j < CPT; j += 2) {
                     if (c0 + j >= ld) continue;
-                    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + j * 8, 0, 16);
+                    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + (j >> 1) * PAIR_STEP, 0, 16);
                     pv[j] = __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
                     pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
                 }
