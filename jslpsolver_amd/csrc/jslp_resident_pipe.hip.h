@@ -98,10 +98,10 @@
 #undef RT_MARK
 #define RT_MARK(p)                                                                                                        \
     do {                                                                                                                  \
-        if (f.test_late_wave0 >= 2) {                                                                                     \
+        if (F_TEST_LATE >= 2) {                                                                                     \
             const unsigned who_ = (R.epoch * 7u + (unsigned)(p) * 3u) % (unsigned)(THREADS / 64);                         \
             if (__builtin_amdgcn_readfirstlane((int)((unsigned)(threadIdx.x >> 6) == who_))) __builtin_amdgcn_s_sleep(100); \
-            if (f.test_late_wave0 >= 3 && (R.epoch + (unsigned)(p)) % 5u == (unsigned)blockIdx.x % 5u) __builtin_amdgcn_s_sleep(60); \
+            if (F_TEST_LATE >= 3 && (R.epoch + (unsigned)(p)) % 5u == (unsigned)blockIdx.x % 5u) __builtin_amdgcn_s_sleep(60); \
         }                                                                                                                 \
     } while (0)
 #endif
@@ -298,11 +298,11 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
                 const v4u_t q_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, offq_, 0, 16);                                  \
                 if (q_.y == tag && q_.w == tag) break;                                                                            \
                 __builtin_amdgcn_s_sleep(1);                                                                                      \
-                if ((++probes_ & 63u) == 0 && (AG_LOAD(f.abort_flag) != 0u || probes_ > f.spin_limit)) break; /* (the loop below gives up properly) */ \
+                if ((++probes_ & 63u) == 0 && (AG_LOAD(f.abort_flag) != 0u || probes_ > F_SPIN)) break; /* (the loop below gives up properly) */ \
             }                                                                                                                     \
         }                                                                                                                         \
         for (;;) {                                                                                                                \
-            if (__builtin_amdgcn_readfirstlane((int)(f.test_late_wave0 != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);          \
+            if (__builtin_amdgcn_readfirstlane((int)(F_TEST_LATE != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);          \
             bool ok_ = true;                                                                                                      \
             if (colok) {                                                                                                          \
                 _Pragma("unroll") for (int j = 0; j < CPT; j++) {                                                                 \
@@ -322,7 +322,7 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
             ++spins_;                                                                                                             \
             bool dead_ = false;                                                                                                   \
             if ((spins_ & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead_ = true;                                                 \
-            if (spins_ > f.spin_limit) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead_ = true; }                               \
+            if (spins_ > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead_ = true; }                               \
             if (dead_) { if (lane == 0) atomicMax(&sm.okbad, efetch); break; }                                                    \
         }                                                                                                                         \
     } while (0)
@@ -402,12 +402,12 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     while (R.end_code == 0) {
         const bool has_pc_p = pend && colok && pc_p >= c0 && pc_p < c0 + CPT;
         // ---- exits that hand the tableau on (the pending update is applied behind the loop) ---------------------------------
-        if ((R.it1 - it1_start) + (R.it2 - it2_start) >= f.iters_cap) { R.end_code = 4; break; }
+        if ((R.it1 - it1_start) + (R.it2 - it2_start) >= F_ITERS) { R.end_code = 4; break; }
         if ((CHK && c.check_cycles) && !(R.hist_n < (f.hist_all ? JSLP_PIPE_GHIST : JSLP_PIPE_LHIST) && R.hist_n < c.hist_cap)) { R.end_code = 8; break; }  // history outgrows its room: the general kernel continues
         const unsigned epoch = R.epoch;
         const int par = epoch & 1;
         const unsigned tag = epoch + 1;
-        if (f.test_abort_epoch >= 0 && (int)epoch == f.test_abort_epoch && b == f.G - 1) {  // tests: a workgroup gives up
+        if (F_TEST_ABORT >= 0 && (int)epoch == F_TEST_ABORT && b == f.G - 1) {  // tests: a workgroup gives up
             if (tid == 0) AG_STORE(f.abort_flag, 1u);
             R.end_code = 5;
             break;
@@ -569,7 +569,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
                 if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { swept = false; break; }
-                if (spins > f.spin_limit) { if (lane == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
+                if (spins > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
             }
             // my workgroup's summary -> the wave's: first degenerate row, else smallest quotient (first row on ties)
             const int row = (int)(g.w & 0x7fffu);
@@ -692,7 +692,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             efetch += 1;
             unsigned spins = 0;
             for (;;) {
-                if (__builtin_amdgcn_readfirstlane((int)(f.test_late_wave0 != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch; a scalar branch: s_sleep ignores EXEC)
+                if (__builtin_amdgcn_readfirstlane((int)(F_TEST_LATE != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch; a scalar branch: s_sleep ignores EXEC)
                 const u64_t flag = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);
                 if ((unsigned)flag == tag) break;  // (wave-uniform: one word, one request)
 #ifdef JSLP_DEBUG_RESIDENT
@@ -702,7 +702,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 ++spins;
                 bool dead = false;
                 if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead = true;
-                if (spins > f.spin_limit) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead = true; }
+                if (spins > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead = true; }
                 if (dead) { if (lane == 0) atomicMax(&sm.okbad, efetch); break; }
             }
             asm volatile("" ::: "memory");
@@ -963,12 +963,12 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 
     while (R.end_code == 0) {
         const bool has_pc_p = pend && colok && pc_p >= c0 && pc_p < c0 + CPT;
-        if ((R.it1 - it1_start) + (R.it2 - it2_start) >= f.iters_cap) { R.end_code = 4; break; }
+        if ((R.it1 - it1_start) + (R.it2 - it2_start) >= F_ITERS) { R.end_code = 4; break; }
         if ((CHK && c.check_cycles) && !(R.hist_n < (f.hist_all ? JSLP_PIPE_GHIST : JSLP_PIPE_LHIST) && R.hist_n < c.hist_cap)) { R.end_code = 8; break; }
         const unsigned epoch = R.epoch;
         const int par = epoch & 1;
         const unsigned tag = epoch + 1;
-        if (f.test_abort_epoch >= 0 && (int)epoch == f.test_abort_epoch && b == f.G - 1) {
+        if (F_TEST_ABORT >= 0 && (int)epoch == F_TEST_ABORT && b == f.G - 1) {
             if (tid == 0) AG_STORE(f.abort_flag, 1u);
             R.end_code = 5;
             break;
@@ -1049,7 +1049,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
                 if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { swept = false; break; }
-                if (spins > f.spin_limit) { if (lane == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
+                if (spins > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
             }
             const int row = (int)(g.w & 0x7fffu);
             KI x;
@@ -1107,14 +1107,14 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             efetch += 1;
             unsigned spins = 0;
             for (;;) {
-                if (__builtin_amdgcn_readfirstlane((int)(f.test_late_wave0 != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch; a scalar branch: s_sleep ignores EXEC)
+                if (__builtin_amdgcn_readfirstlane((int)(F_TEST_LATE != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);  // (tests: the skew that used to break the fetch; a scalar branch: s_sleep ignores EXEC)
                 const u64_t flag = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);
                 if ((unsigned)flag == tag) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
                 bool dead = false;
                 if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead = true;
-                if (spins > f.spin_limit) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead = true; }
+                if (spins > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead = true; }
                 if (dead) { if (lane == 0) atomicMax(&sm.okbad, efetch); break; }
             }
             asm volatile("" ::: "memory");

@@ -26,6 +26,17 @@ def oracle_lib():
 
 
 @pytest.fixture(scope="session")
+def hip_hooks_lib():
+    """The TEST build of the product library (libjslp_hip_chaos.so: -DJSLP_CHAOS_BUILD, built by __graft_entry__.build()): the same
+    sources with the test hooks of the register-resident kernels compiled in -- JSLP_TEST_RESIDENT_ABORT, JSLP_TEST_RESIDENT_LATE_WAVE0 --
+    which the shipped library does not carry (they cost the headline kernel 4 % of its pivot rate).  Fails when missing."""
+    from jslpsolver_amd import _capi
+    path = os.path.join(ROOT, "jslpsolver_amd", "csrc", "libjslp_hip_chaos.so")
+    assert os.path.exists(path), "build it: python -c 'import __graft_entry__ as g; g.build()'"
+    return _capi.Library(path)
+
+
+@pytest.fixture(scope="session")
 def hip_lib():
     """The product library; GPU tests fail (not skip) when it is missing."""
     from jslpsolver_amd import _capi

@@ -250,20 +250,20 @@ def test_host_matrix_hip(hip_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("abort_at", [0, 7, 150])
-def test_resident_abort_rolls_back_and_resolves(hip_lib, abort_at, monkeypatch):
+def test_resident_abort_rolls_back_and_resolves(hip_hooks_lib, abort_at, monkeypatch):
     """a timed-out hand-off inside the register-resident kernel (forced: the last workgroup gives up at pivot `abort_at`)
     must not leave the engine with advanced index maps over the old matrix: the solve is rolled back and re-run through
     the streaming kernels, pivot for pivot the reference's"""
     monkeypatch.setenv("JSLP_TEST_RESIDENT_ABORT", str(abort_at))
     monkeypatch.setenv("JSLP_FORCE_PATH", "resident")
     m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, 200, 200)
-    t = Tableau(m, vibr, vibc, lib=hip_lib)
+    t = Tableau(m, vibr, vibc, lib=hip_hooks_lib)
     res = t.simplex(check_cycles=True)
     assert t.last_path() in ("fused", "select+update")
     assert res.feasible and res.optimal and res.pivots_phase2 == 242
     assert pivot_digest(t.pivot_trace()) == "27aaaa0b"
     monkeypatch.delenv("JSLP_TEST_RESIDENT_ABORT")
-    t2 = Tableau(m, vibr, vibc, lib=hip_lib)
+    t2 = Tableau(m, vibr, vibc, lib=hip_hooks_lib)
     t2.simplex(check_cycles=True)
     assert t2.last_path() == "resident"
     a, b = t.download(), t2.download()
@@ -275,7 +275,7 @@ def test_resident_abort_rolls_back_and_resolves(hip_lib, abort_at, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,n,unrestricted", [("ra", 1000, False), ("lp", 500, False), ("lp", 1000, False), ("int", 1000, True)])
-def test_resident_row_fetch_with_a_late_wave(hip_lib, kind, n, unrestricted, monkeypatch):
+def test_resident_row_fetch_with_a_late_wave(hip_hooks_lib, kind, n, unrestricted, monkeypatch):
     """The register-resident kernels fetch the winning row speculatively, next to its flag.  Round 3 found the flag looked at by
     thread 0 only: a wave that ran ahead of thread 0's wave (a cold instruction cache is enough) could load the row before it was
     visible and have it accepted on thread 0's LATER look -- rare, timing-dependent wrong pivots.  Every wave now looks at the flag
@@ -301,7 +301,7 @@ def test_resident_row_fetch_with_a_late_wave(hip_lib, kind, n, unrestricted, mon
     unr = [0, 1, 2] if unrestricted else []
     for late in ("1", "0"):
         monkeypatch.setenv("JSLP_TEST_RESIDENT_LATE_WAVE0", late)
-        t = Tableau(m, vibr, vibc, unr, lib=hip_lib)
+        t = Tableau(m, vibr, vibc, unr, lib=hip_hooks_lib)
         res = t.simplex(check_cycles=False)
         assert t.last_path() == "resident" and t.get_counters()["resident_aborts"] == 0
         tr = t.pivot_trace()
@@ -311,7 +311,7 @@ def test_resident_row_fetch_with_a_late_wave(hip_lib, kind, n, unrestricted, mon
 
 
 @pytest.mark.gpu
-def test_wide_resident_geometry_with_a_late_wave(hip_lib, monkeypatch):
+def test_wide_resident_geometry_with_a_late_wave(hip_hooks_lib, monkeypatch):
     """the same for a 512-thread geometry (1201 x 2101: <512,6,12>, phase 2 only), late wave 0 and not: the known answer of
     tests/golden/stress_expect.json both times"""
     import sys
@@ -323,7 +323,7 @@ def test_wide_resident_geometry_with_a_late_wave(hip_lib, monkeypatch):
     want = KA.expected_stress("int", 1201, 2101, 12345)
     for late in ("1", "0"):
         monkeypatch.setenv("JSLP_TEST_RESIDENT_LATE_WAVE0", late)
-        t = Tableau(A, vibr, vibc, lib=hip_lib)
+        t = Tableau(A, vibr, vibc, lib=hip_hooks_lib)
         res = t.simplex(check_cycles=False)
         assert t.last_path() == "resident" and t.get_counters()["resident_aborts"] == 0
         tr = t.pivot_trace()

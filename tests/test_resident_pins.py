@@ -143,14 +143,14 @@ def test_chaos_build_passes_the_resident_goldens(hip_lib):
     env = dict(os.environ, JSLP_HIP_LIBRARY=lib, JSLP_TEST_RESIDENT_LATE_WAVE0="3")
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                           os.path.join(ROOT, "tests", "test_wide_goldens.py"), os.path.join(ROOT, "tests", "test_cycle_goldens.py"),
-                          os.path.join(ROOT, "tests", "test_resident_pins.py"), "-k", "not chaos and not stress and not 3b"],
+                          os.path.join(ROOT, "tests", "test_resident_pins.py"), "-k", "not chaos and not stress and not 3b and not shipped"],
                          capture_output=True, text=True, timeout=2400, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,abort_at", [((1200, 2100), 5), ((2100, 300), 0), ((600, 3000), 40)])
-def test_resident_abort_on_the_tall_and_wide_geometries_finishes_through_the_fused_pipeline(hip_lib, oracle_lib, shape, abort_at, monkeypatch):
+def test_resident_abort_on_the_tall_and_wide_geometries_finishes_through_the_fused_pipeline(hip_hooks_lib, oracle_lib, shape, abort_at, monkeypatch):
     """geometries 3-5 run only phase 2 register-resident; an aborted hand-off there used to leave the host's copy of the
     state at ST_DONE + ERR_BARRIER after the device-side roll-back, and simplex() returned a device error instead of finishing
     through k_pivot_fused.  Now: rolled back, re-run, the oracle's trace and tableau, and the abort is COUNTED"""
@@ -159,6 +159,7 @@ def test_resident_abort_on_the_tall_and_wide_geometries_finishes_through_the_fus
     A, vibr, vibc = int_instance(m, n, 12345, two_phase=(shape == (2100, 300)))
     monkeypatch.setenv("JSLP_TEST_RESIDENT_ABORT", str(abort_at))
     out = []
+    hip_lib = hip_hooks_lib  # (the abort hook lives in the test build of the library: tests/conftest.py)
     for lib in (oracle_lib, hip_lib):
         t = Tableau(A, vibr, vibc, lib=lib)
         res = t.simplex(check_cycles=False)
@@ -199,3 +200,17 @@ def test_soft_constraint_lp_beyond_the_headline_geometry_is_the_reference(hip_li
     assert len(trace) == g["nPivots"] and pivot_digest(trace) == g["pivotDigest"]
     assert G.sha_matrix(final) == g["final"]["matrixSha"]
     assert cnt["resident_aborts"] == 0
+
+
+@pytest.mark.gpu
+def test_shipped_library_carries_no_test_hooks(hip_lib, monkeypatch):
+    """JSLP_TEST_RESIDENT_ABORT / JSLP_TEST_RESIDENT_LATE_WAVE0 are hooks of the TEST build only (tests/conftest.py `hip_hooks_lib`): in the
+    shipped library they are compile-time constants -- the abort that the test build performs at pivot 0 does not happen here"""
+    monkeypatch.setenv("JSLP_TEST_RESIDENT_ABORT", "0")
+    monkeypatch.setenv("JSLP_TEST_RESIDENT_LATE_WAVE0", "3")
+    m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, 500, 500)
+    t = Tableau(m, vibr, vibc, lib=hip_lib)
+    t.simplex(check_cycles=False)
+    path, cnt, dig = t.last_path(), t.get_counters(), pivot_digest(t.pivot_trace())
+    t.close()
+    assert path == "resident" and cnt["resident_aborts"] == 0 and dig == "1cda2607"

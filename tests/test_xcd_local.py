@@ -95,7 +95,8 @@ def test_xcd_local_two_phase_against_the_oracle(hip_lib, oracle_lib, shape, kind
 
 
 @pytest.mark.parametrize("abort_at", [0, 9])
-def test_xcd_local_abort_rolls_back_and_resolves(hip_lib, abort_at, monkeypatch):
+def test_xcd_local_abort_rolls_back_and_resolves(hip_hooks_lib, abort_at, monkeypatch):
+    hip_lib = hip_hooks_lib  # (the abort hook lives in the test build of the library: tests/conftest.py)
     monkeypatch.setenv("JSLP_XL", "1")
     monkeypatch.setenv("JSLP_TEST_RESIDENT_ABORT", str(abort_at))
     g = G.load(os.path.join(G.GOLDEN, "synthetic", "generateResourceAllocation_500x500_seed12345.json.gz"))
