@@ -137,7 +137,7 @@ struct jslp_engine {
     DevState* f_st[2] = {nullptr, nullptr};
     // register-resident phase 2 (one cooperative launch): hand-off buffers
     u64_t* r_gran = nullptr;  // [2][G][8] granules then [2][G] row flags (one allocation, zeroed per launch)
-    u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr; int2* r_hist_all = nullptr; int r_want_hist = 0;
+    u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr; int2* r_hist_all = nullptr; int r_want_hist = 0; Ctx* r_ctx_dev = nullptr;
     int no_resident = 0;
     int res_cpt = 2;  // columns per lane of the resident kernel (JSLP_RES_CPT=2|4)
     int one_launch_nodes = 1;  // JSLP_NO_NODE_KERNEL=1: single children go through the five-launch sequence
@@ -846,6 +846,7 @@ static int ensure_resident(jslp_engine* e, bool want_hist = false) {
         e->rb_rbv = cv.take<int32_t>((size_t)e->n_idx);
         e->rb_cbv = cv.take<int32_t>((size_t)e->n_idx);
         e->r_backup_st = cv.take<DevState>(1);
+        e->r_ctx_dev = cv.take<Ctx>(1);
         if (!pass && e->r_arena_bytes < cv.off + 256) {
             hipFree(e->r_arena);
             e->r_arena = nullptr; e->r_arena_bytes = 0; e->r_sync = nullptr;
@@ -1054,6 +1055,8 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             rc.abort_flag = e->r_sync + 4;
             HIPC(hipMemsetAsync(e->r_gran, 0, sizeof(u64_t) * JSLP_R_SYNC_WORDS, s));  // tags restart at 1
             rc.census = e->r_gran + JSLP_R_SYNC_WORDS - JSLP_F_MAXG;
+            rc.cdev = e->r_ctx_dev;
+            HIPC(hipMemcpyAsync(e->r_ctx_dev, &rc.c, sizeof(Ctx), hipMemcpyHostToDevice, s));  // (200 bytes; the kernel's one committing thread reads the map / trace pointers from it)
             rc.rpb = geometry == 6 ? (H + JSLP_XL_MAXG - 1) / JSLP_XL_MAXG : (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
             if (const char* rx = getenv("JSLP_RES_RPB"); rx && geometry != 6) {  // experiments: more rows per workgroup = fewer workgroups (<= the geometry's rows)
                 static const int rows_of[6] = {0, 8, 8, 16, 12, 8};

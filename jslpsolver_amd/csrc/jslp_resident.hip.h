@@ -83,6 +83,7 @@ struct ResCtx {
     u64_t* gor[2];        // [G] rare slow path: tagged per-workgroup flags for a chip-wide OR
     int2* hist_all;       // [G][JSLP_PIPE_GHIST] every workgroup's own copy of the cycle-check history (lean kernel; nullptr: LDS part only)
     u64_t* gran16;        // [2][MAXG] 16-byte summary granules of the lean kernel's pipelined phase 2, 64 bytes apart (jslp_resident_pipe.hip.h)
+    const Ctx* cdev;      // the same Ctx in device memory: what ONE thread needs once per pivot (global maps, trace, history) is read from there
     u64_t* census;        // [MAXG] XCD-local build: {0xA5A5A5A5 | XCC id} of every participating workgroup, written once per launch
     int32_t G, rpb, H;
     int32_t n_idx;             // variable indexes in use (the LDS copy of the unrestricted flags covers JSLP_R_LUNR of them)

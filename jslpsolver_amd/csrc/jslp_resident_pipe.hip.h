@@ -114,6 +114,12 @@
 #ifndef JSLP_PIPE_QUOT_DIRECT
 #define JSLP_PIPE_QUOT_DIRECT 0  // chip-wide lean builds without optional objectives: 1 = every wave reads quot (the winning row's entry of the entering column) itself next to its columns of the row -- one address per wave -- instead of the LDS broadcast + barrier behind the fetch
 #endif
+#ifndef JSLP_PIPE_NEW_UPDATE
+#define JSLP_PIPE_NEW_UPDATE 1
+#endif
+#ifndef JSLP_PIPE_S_VIA_LDS
+#define JSLP_PIPE_S_VIA_LDS 1
+#endif
 #define JSLP_PUB_SKEW 256     // bytes added to a workgroup's slot of the candidate-row buffer (see SLOT)
 #define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
 #define JSLP_PIPE_KCHUNK 8    // pivot-column entries the update pass keeps in flight (registers: the tall / wide geometries have few to spare)
@@ -283,6 +289,24 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
                 }                                                                                                                 \
         }                                                                                                                         \
     } while (0)
+// the chip-wide builds' candidate row (untagged: the winner's flag follows its release): the same compare chain, the slot layout of SLOT / PERM
+#define JSLP_PUBLISH_ROW_PLAIN(ROW)                                                                                               \
+    do {                                                                                                                          \
+        const int ipub_ = __builtin_amdgcn_readfirstlane((ROW) - r_begin);                                                        \
+        if (colok) {                                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                      \
+                if (i == JSLP_OPAQUE_SGPR(ipub_)) {                                                                               \
+                    const int off_ = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;        \
+                    _Pragma("unroll") for (int j = 0; j < CPT; j += 2) {                                                          \
+                        if (c0 + j >= ld) continue;                                                                               \
+                        const u64_t lo_ = (u64_t)__double_as_longlong(a[i][j]), hi_ = (u64_t)__double_as_longlong(a[i][j + 1]);  \
+                        v4u_t v_;                                                                                                 \
+                        v_.x = (unsigned)lo_; v_.y = (unsigned)(lo_ >> 32); v_.z = (unsigned)hi_; v_.w = (unsigned)(hi_ >> 32);   \
+                        __builtin_amdgcn_raw_buffer_store_b128(v_, rsrc_rows, off_ + (j >> 1) * PAIR_STEP, 0, ST_AUX);            \
+                    }                                                                                                             \
+                }                                                                                                                 \
+        }                                                                                                                         \
+    } while (0)
 // ... and its fetch: every lane polls ITS 16-byte words of the winner's row until both tags of each are this epoch's
 #define JSLP_XL_FETCH_ROW(PCCOL, QUOT)                                                                                            \
     do {                                                                                                                          \
@@ -347,6 +371,13 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     constexpr bool WLL = !XL && JSLP_PIPE_WINNER_LL != 0;  // winner-only tagged row (see JSLP_PIPE_WINNER_LL)
     constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
     constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT);  // quot comes with the fetch: no barrier behind it
+    // the ratio test's transposition (entry i of the entering column from the ONE lane that holds it to lane i) through LDS: as `x = lane
+    // == i ? readlane(a[i][j]) : x` the compiler precomputes the 64-bit lane masks, spills them and pays two reloads, two moves and two
+    // selects per row on top of the readlanes -- in the one wave the summary waits for
+    constexpr bool S_LDS = XL || JSLP_PIPE_S_VIA_LDS != 0;
+    // the pending pivot's row update in the XCD-local build's form (JSLP_XL_UPDATE_PASS: one ballot for the row gate, readlane multipliers,
+    // the special rows fixed up once per pivot) instead of JSLP_PIPE_UPDATE_ROW's ~55 instructions per row
+    constexpr bool UPD_NEW = XL || (JSLP_PIPE_NEW_UPDATE != 0 && CPT <= 4 && !(OPT && ROWS > 8));  // (the 6- / 8-column geometries and the tall OPT build would spill 14-94 VGPRs with it)
     // candidate rows in the publication buffer (chip-wide builds): pair j of lane t at ((j / 2) * THREADS + t) * 16 inside the
     // workgroup's slot -- a wave's store of one pair is 1 KB of whole lines (with lane t's CPT columns adjacent, as they sit in the
     // tableau, the 512-thread geometries wrote 16 bytes into each of 64 lines per instruction: the partial-line writers of round 3);
@@ -449,7 +480,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
             for (int j = 0; j < CPT; j++)
                 if (jsel == j) {  // uniform
-                    if (XL) {  // 32 rows: the holding lane lays its entries out in LDS (32 stores of one lane) instead of 128 readlanes
+                    if (S_LDS) {  // the holding lane lays its entries out in LDS (one 8-byte store per row, one lane) instead of readlanes
                         if (lane == ol) {
 #pragma unroll
                             for (int i = 0; i < ROWS; i++) sm.quo[i] = a[i][j];
@@ -464,7 +495,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                     pj = readlane_f64(p[j], ol);
                     nzj = ((unsigned)__builtin_amdgcn_readlane((int)nzm, ol) >> j) & 1u;
                 }
-            if (XL) {
+            if (S_LDS) {
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own LDS stores
                 x = lane < ROWS ? sm.quo[lane] : 0.0;
@@ -532,9 +563,12 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;  // lanes beyond the grid: "no candidate"
         const int goff = (par * JSLP_F_MAXG + tid) * JSLP_G16_STRIDE;
         // (the pending pivot's column entries of my rows: broadcast LDS reads, JSLP_PIPE_KCHUNK of them in flight together)
-        if (XL) {
+        if (UPD_NEW) {
             if (pend) JSLP_XL_UPDATE_PASS();
-            if (pubrow != 0) JSLP_XL_PUBLISH_ROW(pubrow);
+            if (pubrow != 0) {
+                if (TAGGED) { if (XL) JSLP_XL_PUBLISH_ROW(pubrow); }  // (winner-only builds publish after the decision)
+                else if (JSLP_PIPE_SPECPUB) JSLP_PUBLISH_ROW_PLAIN(pubrow);
+            }
         } else
 #pragma unroll
         for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
@@ -618,7 +652,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 const int2 pair = make_int2(sm.lvibr[pr], sm.lvibc[pc]);
                 if (R.hist_n < JSLP_PIPE_LHIST) sm.lhist[R.hist_n] = pair;
                 if (f.hist_all) f.hist_all[(size_t)b * JSLP_PIPE_GHIST + R.hist_n] = pair;  // my own copy of the whole history
-                if (b == 0) c.hist[R.hist_n] = pair;  // the host's cycle message; the general kernel's history should this one outgrow its room
+                if (b == 0) f.cdev->hist[R.hist_n] = pair;  // the host's cycle message; the general kernel's history should this one outgrow its room
                 sm.cyc_need = sm.cyc_filter_on ? cyc_pair_seen(sm, pair) : 1;
             }
             __syncthreads();
@@ -759,7 +793,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 if (col < W) {
                     const bool innz = nonzero16(val);
                     v = innz ? val / quot : 0.0;
-                    if (col == pc) v = 1.0 / quot;
+                    if (col == pc) v = 1.0 / quot;  // (as a real branch -- one lane of the workgroup needs this division -- measured no faster: r04_u)
                     if (innz && !nonzero16(v) && v != 0.0) {
                         if (OPT && opt_enter) tiny |= 1 << j;  // (decided below)
                         else v = 0.0;
@@ -835,13 +869,17 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             sm.lvibr[pr] = entering;
             sm.lvibc[pc] = leaving;
             if (b == 0) {
-                c.vibr[pr] = entering;
-                c.vibc[pc] = leaving;
-                c.rbv[entering] = pr;
-                c.rbv[leaving] = -1;
-                c.cbv[entering] = -1;
-                c.cbv[leaving] = pc;
-                if (R.trace_n < c.trace_cap) c.trace[R.trace_n] = make_int2(pr, pc);
+                // (the global maps and the trace are touched by this ONE thread of the chip: their eight pointers come from the device
+                //  copy of the context when needed instead of living in scalar registers through the whole pivot loop -- SGPR pressure,
+                //  jslp_resident.hip.h `ResCtx::cdev`)
+                const Ctx& g = *f.cdev;
+                g.vibr[pr] = entering;
+                g.vibc[pc] = leaving;
+                g.rbv[entering] = pr;
+                g.rbv[leaving] = -1;
+                g.cbv[entering] = -1;
+                g.cbv[leaving] = pc;
+                if (R.trace_n < g.trace_cap) g.trace[R.trace_n] = make_int2(pr, pc);
             }
         }
         if (UNR && has_pc) {
@@ -857,7 +895,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     }
     if (pend && R.end_code != 5) {  // whoever leaves with a pivot pending (optimal, iteration cap, hand-over) brings the rows up to date
         const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;
-        if (XL) {
+        if (UPD_NEW) {
             (void)has_pc_p;
             JSLP_XL_UPDATE_PASS();
         } else
@@ -914,6 +952,13 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     constexpr bool WLL = !XL && JSLP_PIPE_WINNER_LL != 0;  // winner-only tagged row (see JSLP_PIPE_WINNER_LL)
     constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
     constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT);  // quot comes with the fetch: no barrier behind it
+    // the ratio test's transposition (entry i of the entering column from the ONE lane that holds it to lane i) through LDS: as `x = lane
+    // == i ? readlane(a[i][j]) : x` the compiler precomputes the 64-bit lane masks, spills them and pays two reloads, two moves and two
+    // selects per row on top of the readlanes -- in the one wave the summary waits for
+    constexpr bool S_LDS = XL || JSLP_PIPE_S_VIA_LDS != 0;
+    // the pending pivot's row update in the XCD-local build's form (JSLP_XL_UPDATE_PASS: one ballot for the row gate, readlane multipliers,
+    // the special rows fixed up once per pivot) instead of JSLP_PIPE_UPDATE_ROW's ~55 instructions per row
+    constexpr bool UPD_NEW = XL || (JSLP_PIPE_NEW_UPDATE != 0 && CPT <= 4 && !(OPT && ROWS > 8));  // (the 6- / 8-column geometries and the tall OPT build would spill 14-94 VGPRs with it)
     // candidate rows in the publication buffer (chip-wide builds): pair j of lane t at ((j / 2) * THREADS + t) * 16 inside the
     // workgroup's slot -- a wave's store of one pair is 1 KB of whole lines (with lane t's CPT columns adjacent, as they sit in the
     // tableau, the 512-thread geometries wrote 16 bytes into each of 64 lines per instruction: the partial-line writers of round 3);
@@ -1012,9 +1057,12 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         v4u_t g;
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;
         const int goff = (par * JSLP_F_MAXG + tid) * JSLP_G16_STRIDE;
-        if (XL) {
+        if (UPD_NEW) {
             if (pend) JSLP_XL_UPDATE_PASS();
-            if (pubrow != 0) JSLP_XL_PUBLISH_ROW(pubrow);
+            if (pubrow != 0) {
+                if (TAGGED) { if (XL) JSLP_XL_PUBLISH_ROW(pubrow); }  // (winner-only builds publish after the decision)
+                else if (JSLP_PIPE_SPECPUB) JSLP_PUBLISH_ROW_PLAIN(pubrow);
+            }
         } else
 #pragma unroll
         for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
@@ -1188,7 +1236,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 const int2 pair = make_int2(sm.lvibr[pr], sm.lvibc[pc]);
                 if (R.hist_n < JSLP_PIPE_LHIST) sm.lhist[R.hist_n] = pair;
                 if (f.hist_all) f.hist_all[(size_t)b * JSLP_PIPE_GHIST + R.hist_n] = pair;  // my own copy of the whole history
-                if (b == 0) c.hist[R.hist_n] = pair;
+                if (b == 0) f.cdev->hist[R.hist_n] = pair;
                 sm.cyc_need = sm.cyc_filter_on ? cyc_pair_seen(sm, pair) : 1;
             }
             __syncthreads();
@@ -1210,7 +1258,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 if (col < W) {
                     const bool innz = nonzero16(val);
                     v = innz ? val / quot : 0.0;
-                    if (col == pc) v = 1.0 / quot;
+                    if (col == pc) v = 1.0 / quot;  // (as a real branch -- one lane of the workgroup needs this division -- measured no faster: r04_u)
                     if (innz && !nonzero16(v) && v != 0.0) tiny |= 1 << j;
                 }
                 p[j] = v;
@@ -1277,13 +1325,17 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             sm.lvibr[pr] = entering;
             sm.lvibc[pc] = leaving;
             if (b == 0) {
-                c.vibr[pr] = entering;
-                c.vibc[pc] = leaving;
-                c.rbv[entering] = pr;
-                c.rbv[leaving] = -1;
-                c.cbv[entering] = -1;
-                c.cbv[leaving] = pc;
-                if (R.trace_n < c.trace_cap) c.trace[R.trace_n] = make_int2(pr, pc);
+                // (the global maps and the trace are touched by this ONE thread of the chip: their eight pointers come from the device
+                //  copy of the context when needed instead of living in scalar registers through the whole pivot loop -- SGPR pressure,
+                //  jslp_resident.hip.h `ResCtx::cdev`)
+                const Ctx& g = *f.cdev;
+                g.vibr[pr] = entering;
+                g.vibc[pc] = leaving;
+                g.rbv[entering] = pr;
+                g.rbv[leaving] = -1;
+                g.cbv[entering] = -1;
+                g.cbv[leaving] = pc;
+                if (R.trace_n < g.trace_cap) g.trace[R.trace_n] = make_int2(pr, pc);
             }
         }
         if (UNR && has_pc) {
@@ -1299,7 +1351,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     }
     if (pend && R.end_code != 5) {
         const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;
-        if (XL) {
+        if (UPD_NEW) {
             (void)has_pc_p;
             JSLP_XL_UPDATE_PASS();
         } else
@@ -1321,4 +1373,5 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #undef JSLP_OPAQUE_SGPR
 #undef JSLP_XL_UPDATE_PASS
 #undef JSLP_XL_PUBLISH_ROW
+#undef JSLP_PUBLISH_ROW_PLAIN
 #undef JSLP_XL_FETCH_ROW
