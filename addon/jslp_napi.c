@@ -739,6 +739,7 @@ static napi_value fn_get_counters(napi_env env, napi_callback_info info) {
     SET_D("residentAborts", (double)c.resident_aborts); SET_D("residentHandovers", (double)c.resident_handovers);
     SET_D("residentLaunches", (double)c.resident_launches); SET_D("residentRefusals", (double)c.resident_refusals);
     SET_D("nodeQueueLaunches", (double)c.node_queue_launches);
+    SET_D("residentFetchRetries", (double)c.resident_fetch_retries);
     return o;
 }
 

@@ -283,6 +283,8 @@ typedef struct jslp_work_counters {
     int64_t resident_launches;   /* cooperative launches of k_simplex_resident that were accepted                           */
     int64_t resident_refusals;   /* ... that the runtime refused (not co-resident): the solve took the streaming kernels     */
     int64_t node_queue_launches; /* node batches evaluated by ONE launch of resident workgroups pulling nodes from a queue   */
+    int64_t resident_fetch_retries; /* lean resident kernels: looks at a pivot row that had to be repeated because the row's checksum
+                                     * did not match its flag word yet (the end-to-end check of the cross-XCD hand-over: DESIGN.md 4) */
 } jslp_work_counters;
 int jslp_engine_set_counting(jslp_engine* e, int enabled); /* also resets the counters */
 int jslp_engine_get_counters(jslp_engine* e, jslp_work_counters* out);

@@ -47,7 +47,7 @@ class WorkCounters(C.Structure):
 
     _fields_ = [(name, C.c_int64) for name in ("relaxations", "simplex_calls", "pivots", "gated_cells", "gated_rows",
                                               "restored_rows", "cut_rows", "height_sum", "resident_aborts", "resident_handovers",
-                                              "resident_launches", "resident_refusals", "node_queue_launches")]
+                                              "resident_launches", "resident_refusals", "node_queue_launches", "resident_fetch_retries")]
 
     def as_dict(self):
         return {name: int(getattr(self, name)) for name, _ in self._fields_}

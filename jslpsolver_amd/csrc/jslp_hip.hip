@@ -69,7 +69,7 @@ struct jslp_engine {
     int32_t* d_cut_offs = nullptr; int8_t* d_cut_type = nullptr; int32_t* d_cut_var = nullptr; double* d_cut_val = nullptr;
     int32_t* d_cut_order = nullptr; int* d_queue = nullptr;  // batch hand-out order (most cuts first) + queue counter, uploaded with the cuts
     std::vector<int32_t> order_scratch;
-    bool queue_wgs_opt = false; int node_queue_launches = 0;  // (which build the count below is for; batches that went through k_node_queue)
+    bool queue_wgs_opt = false; int node_queue_launches = 0; long long resident_fetch_retries = 0;  // (which build the count below is for; batches that went through k_node_queue)
     int queue_wgs = 0; size_t queue_wgs_lds = 0;             // resident workgroups of k_node_queue<512> for this LDS size
     // read-back staging (device + pinned host)
     // read-back staging: ONE device buffer -> ONE pinned buffer per group: [states | rhs | rows]
@@ -1157,8 +1157,11 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
 #undef JSLP_RES_LAUNCH_LEAN_ONLY
             if (le == hipSuccess) e->resident_launches += 1;
             if (le == hipSuccess && lean) {  // did the lean kernel finish the solve?
+                unsigned* const h_retries = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e->h_state) + sizeof(DevState) + 8);
                 HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
+                HIPC(hipMemcpyAsync(h_retries, e->r_sync + 5, sizeof(unsigned), hipMemcpyDeviceToHost, s));  // repeated looks of the checksummed row hand-over
                 HIPC(hipStreamSynchronize(s));
+                e->resident_fetch_retries += *h_retries;
                 if (e->h_state->err == ERR_NONE && e->h_state->status != ST_DONE) {
                     e->resident_handovers += 1;
                     if (e->n_opt > 0 || geometry >= 3) {
@@ -2264,6 +2267,7 @@ extern "C" int jslp_engine_set_counting(jslp_engine* e, int enabled) {
     e->s.cnt = enabled ? e->d_cnt : nullptr;
     e->wc = jslp_work_counters{};
     e->resident_fallbacks = e->resident_handovers = e->resident_launches = e->resident_refusals = e->node_queue_launches = 0;
+    e->resident_fetch_retries = 0;
     return JSLP_OK;
 }
 
@@ -2275,6 +2279,7 @@ extern "C" int jslp_engine_get_counters(jslp_engine* e, jslp_work_counters* out)
     out->resident_launches = e->resident_launches;
     out->resident_refusals = e->resident_refusals;
     out->node_queue_launches = e->node_queue_launches;
+    out->resident_fetch_retries = e->resident_fetch_retries;
     if (e->d_cnt) {
         HIPC(hipSetDevice(e->device));
         HIPC(hipStreamSynchronize(e->stream));
@@ -2648,7 +2653,7 @@ extern "C" int jslp_pool_get_counters(jslp_pool* p, jslp_work_counters* out) {
         sum.gated_cells += c.gated_cells; sum.gated_rows += c.gated_rows; sum.restored_rows += c.restored_rows;
         sum.cut_rows += c.cut_rows; sum.height_sum += c.height_sum;
         sum.resident_aborts += c.resident_aborts; sum.resident_handovers += c.resident_handovers; sum.resident_launches += c.resident_launches;
-        sum.resident_refusals += c.resident_refusals; sum.node_queue_launches += c.node_queue_launches;
+        sum.resident_refusals += c.resident_refusals; sum.node_queue_launches += c.node_queue_launches; sum.resident_fetch_retries += c.resident_fetch_retries;
     }
     hipSetDevice(p->members[0]->device);
     *out = sum;

@@ -117,6 +117,32 @@
 #ifndef JSLP_PIPE_NEW_UPDATE
 #define JSLP_PIPE_NEW_UPDATE 1
 #endif
+#ifndef JSLP_PIPE_ROW_CHECKSUM
+// 1: the candidate row is handed over END TO END: each wave of the publishing workgroup stores, right behind its 16-byte stores of the
+// row, ONE 8-byte word = (64-bit checksum of what it stored) ^ (epoch tag x odd constant) into its copy of the row flag; the wave of a
+// reader that fetches those columns loads flag and row TOGETHER, recomputes the checksum and repeats the look until the two agree.
+// Nothing is assumed about the order in which the fabric delivers write-through stores -- the reader verifies what it received -- so
+// the winner's release (buffer_wbl2 + flag store AFTER the decision), the readers' wait for that flag and the drain in front of the
+// gather's barrier all leave the critical path.  0: round 3's hand-over (winner drains, fences, raises the flag; readers wait, load).
+#define JSLP_PIPE_ROW_CHECKSUM 1
+#endif
+#ifndef JSLP_PIPE_ROW_CHECKSUM_MAXCPT
+#define JSLP_PIPE_ROW_CHECKSUM_MAXCPT 4  // the 6- / 8-column geometries keep round 3's hand-over: checksummed they ran 3001 x 3001 113.7 k -> 97.1 k and 2001 x 4001 116.0 k -> 100.8 k pivots/s (r04_y: three / four pairs to hash per lane in front of the pivot row's normalisation, in kernels at their register limit)
+#endif
+// the checksum: every 32-bit word a lane stores, times its own odd 32-bit constant, summed in 64 bits (v_mad_u64_u32: one instruction
+// per word); the lane's sum times (2 x thread + 1) -- lanes with the SAME old and the SAME new content (a stale line covers four lanes'
+// pairs) must not cancel; the two 32-bit halves of that, each summed over the wave (DPP adds, no carries between the halves).  A stale
+// or torn row goes unnoticed only if both half-sums survive: ~2^-64 per such event, themselves rare (tools/resident_stress.py counts them)
+#define JSLP_CK_K32(k) ((0x9E3779B1u * (unsigned)(2 * (k) + 1)) | 0x80000001u)
+#define JSLP_CK_PAIR(CK, LO, HI, j)                                                                                               \
+    do {                                                                                                                          \
+        (CK) += (u64_t)(unsigned)(LO) * JSLP_CK_K32(2 * (j)) + (u64_t)(unsigned)((LO) >> 32) * JSLP_CK_K32(2 * (j) + 1);           \
+        (CK) += (u64_t)(unsigned)(HI) * JSLP_CK_K32(2 * (j) + 2) + (u64_t)(unsigned)((HI) >> 32) * JSLP_CK_K32(2 * (j) + 3);       \
+    } while (0)
+#define JSLP_CK_TAGMIX(tag) ((u64_t)(tag) * 0xD6E8FEB86659FD93ull)    // what separates this epoch's flag word from the one two epochs back in the same slot
+#ifndef JSLP_PIPE_EARLY_LOOKS
+#define JSLP_PIPE_EARLY_LOOKS 0  // looks at the summaries issued DURING the row update (1: behind it, 2: also in front of it): measured 169.5-171.4 k pivots/s -> 167 k -> 163.6 k on config 3a (r04_x) -- the summaries are not there yet, and the extra loads sit in front of the row's stores in the wave's memory queue
+#endif
 #ifndef JSLP_PIPE_S_VIA_LDS
 #define JSLP_PIPE_S_VIA_LDS 1
 #endif
@@ -167,6 +193,43 @@ __device__ __forceinline__ bool cyc_suffix_is_square(const int2* lds, const int2
     (void)red;
     return __syncthreads_or(found) != 0;
 }
+
+// maximum of a 64-bit key over the wave, result in every lane (four DPP exchanges inside the 16-lane rows + readlanes across them)
+template <int CTRL>
+__device__ __forceinline__ u64_t u64_dpp(u64_t x) {
+    const int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
+    return ((u64_t)(unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false) << 32) |
+           (u64_t)(unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u64_t u64_readlane(u64_t x, int l) {
+    return ((u64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l) << 32) |
+           (u64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l);
+}
+__device__ __forceinline__ u64_t u64_max(u64_t a, u64_t b) { return a > b ? a : b; }
+__device__ __forceinline__ u64_t u64_wave_max(u64_t x) {
+    x = u64_max(x, u64_dpp<0xB1>(x));
+    x = u64_max(x, u64_dpp<0x4E>(x));
+    x = u64_max(x, u64_dpp<0x141>(x));
+    x = u64_max(x, u64_dpp<0x140>(x));
+    return u64_max(u64_max(u64_readlane(x, 0), u64_readlane(x, 16)), u64_max(u64_readlane(x, 32), u64_readlane(x, 48)));
+}
+// the two 32-bit halves of a 64-bit word, each summed over the wave modulo 2^32 (every exchange pairs disjoint groups: lanes, pairs,
+// quads, the halves of a 16-lane row; then the four rows) -- the checksummed row hand-over's reduction
+__device__ __forceinline__ u64_t u64_wave_add_halves(u64_t x) {
+    unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+#define JSLP_ADD_DPP(CTRL)                                                                          \
+    lo += (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);           \
+    hi += (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+    JSLP_ADD_DPP(0xB1) JSLP_ADD_DPP(0x4E) JSLP_ADD_DPP(0x141) JSLP_ADD_DPP(0x140)
+#undef JSLP_ADD_DPP
+    const unsigned slo = ((unsigned)__builtin_amdgcn_readlane((int)lo, 0) + (unsigned)__builtin_amdgcn_readlane((int)lo, 16)) +
+                         ((unsigned)__builtin_amdgcn_readlane((int)lo, 32) + (unsigned)__builtin_amdgcn_readlane((int)lo, 48));
+    const unsigned shi = ((unsigned)__builtin_amdgcn_readlane((int)hi, 0) + (unsigned)__builtin_amdgcn_readlane((int)hi, 16)) +
+                         ((unsigned)__builtin_amdgcn_readlane((int)hi, 32) + (unsigned)__builtin_amdgcn_readlane((int)hi, 48));
+    return (u64_t)slo | ((u64_t)shi << 32);
+}
+// a lane's checksum -> the wave's word
+#define JSLP_CK_WAVE(CK) u64_wave_add_halves((CK) * (u64_t)(unsigned)(2 * tid + 1))
 
 #define JSLP_R_MAXOPT 3  // optional objective rows the lean kernel keeps in registers (priorities "strong" / "medium" / "weak": model.ts:141-160)
 
@@ -293,6 +356,10 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
 #define JSLP_PUBLISH_ROW_PLAIN(ROW)                                                                                               \
     do {                                                                                                                          \
         const int ipub_ = __builtin_amdgcn_readfirstlane((ROW) - r_begin);                                                        \
+        /* (tests, JSLP_TEST_RESIDENT_LATE_WAVE0=2: wave 0 raises its flag word ~8 k cycles BEFORE it stores its part of the row -- \
+           the order the fabric is allowed to produce; the readers' checksum must send them round again) */                       \
+        const bool flag_first_ = CKS && __builtin_amdgcn_readfirstlane((int)(F_TEST_LATE == 2 && wv == 0)) != 0;                  \
+        u64_t ck_ = 0;                                                                                                            \
         if (colok) {                                                                                                              \
             _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                      \
                 if (i == JSLP_OPAQUE_SGPR(ipub_)) {                                                                               \
@@ -302,11 +369,72 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
                         const u64_t lo_ = (u64_t)__double_as_longlong(a[i][j]), hi_ = (u64_t)__double_as_longlong(a[i][j + 1]);  \
                         v4u_t v_;                                                                                                 \
                         v_.x = (unsigned)lo_; v_.y = (unsigned)(lo_ >> 32); v_.z = (unsigned)hi_; v_.w = (unsigned)(hi_ >> 32);   \
-                        __builtin_amdgcn_raw_buffer_store_b128(v_, rsrc_rows, off_ + (j >> 1) * PAIR_STEP, 0, ST_AUX);            \
+                        if (!flag_first_) __builtin_amdgcn_raw_buffer_store_b128(v_, rsrc_rows, off_ + (j >> 1) * PAIR_STEP, 0, ST_AUX); \
+                        if (CKS) JSLP_CK_PAIR(ck_, lo_, hi_, j);                                              \
                     }                                                                                                             \
                 }                                                                                                                 \
         }                                                                                                                         \
+        if (CKS) JSLP_CKS_RAISE_FLAG(ck_);                                                                                        \
+        if (flag_first_) {                                                                                                        \
+            __builtin_amdgcn_s_sleep(127);                                                                                        \
+            if (colok) {                                                                                                          \
+                _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                  \
+                    if (i == JSLP_OPAQUE_SGPR(ipub_)) {                                                                           \
+                        const int off_ = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;    \
+                        _Pragma("unroll") for (int j = 0; j < CPT; j += 2) {                                                      \
+                            if (c0 + j >= ld) continue;                                                                           \
+                            const u64_t lo_ = (u64_t)__double_as_longlong(a[i][j]), hi_ = (u64_t)__double_as_longlong(a[i][j + 1]); \
+                            v4u_t v_;                                                                                             \
+                            v_.x = (unsigned)lo_; v_.y = (unsigned)(lo_ >> 32); v_.z = (unsigned)hi_; v_.w = (unsigned)(hi_ >> 32); \
+                            __builtin_amdgcn_raw_buffer_store_b128(v_, rsrc_rows, off_ + (j >> 1) * PAIR_STEP, 0, ST_AUX);        \
+                        }                                                                                                         \
+                    }                                                                                                             \
+            }                                                                                                                     \
+        }                                                                                                                         \
     } while (0)
+// (checksummed hand-over) this wave's word behind its stores of the row: no wait for their acknowledgement, no fence -- the reader checks
+#define JSLP_CKS_RAISE_FLAG(CK)                                                                                                   \
+    do {                                                                                                                          \
+        const u64_t x_ = JSLP_CK_WAVE(CK) ^ JSLP_CK_TAGMIX(tag);                                                                  \
+        if (lane == 0) AG_STORE(f.rowflagc[par] + wv * JSLP_F_MAXG + b, x_);                                                      \
+    } while (0)
+// ... and the fetch: flag word and row in ONE look, repeated until the checksum of what arrived matches the word
+#define JSLP_CKS_FETCH_ROW()                                                                                                      \
+    do {                                                                                                                          \
+        efetch += 1;                                                                                                              \
+        unsigned spins_ = 0;                                                                                                      \
+        const u64_t tmix_ = JSLP_CK_TAGMIX(tag);                                                                                  \
+        for (;;) {                                                                                                                \
+            if (__builtin_amdgcn_readfirstlane((int)((F_TEST_LATE & 1) != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);          \
+            const u64_t flag_ = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);                                                 \
+            u64_t ck_ = 0;                                                                                                        \
+            if (colok) {                                                                                                          \
+                _Pragma("unroll") for (int j = 0; j < CPT; j += 2) {                                                              \
+                    if (c0 + j >= ld) continue;                                                                                   \
+                    const v4u_t v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + (j >> 1) * PAIR_STEP, 0, 16);      \
+                    const u64_t lo_ = (u64_t)v_.x | ((u64_t)v_.y << 32), hi_ = (u64_t)v_.z | ((u64_t)v_.w << 32);                 \
+                    pv[j] = __longlong_as_double((long long)lo_);                                                                 \
+                    pv[j + 1] = __longlong_as_double((long long)hi_);                                                             \
+                    JSLP_CK_PAIR(ck_, lo_, hi_, j);                                                           \
+                }                                                                                                                 \
+            }                                                                                                                     \
+            const u64_t x_ = JSLP_CK_WAVE(ck_) ^ tmix_;                                                                           \
+            if (__builtin_amdgcn_readfirstlane((int)(x_ == flag_))) break;                                                        \
+            JSLP_RT_RETRY();                                                                                                      \
+            if (lane == 0) atomicAdd(f.abort_flag + 1, 1u); /* (health counter: looks that found flag word and row disagreeing) */ \
+            __builtin_amdgcn_s_sleep(1);                                                                                          \
+            ++spins_;                                                                                                             \
+            bool dead_ = false;                                                                                                   \
+            if ((spins_ & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead_ = true;                                                 \
+            if (spins_ > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead_ = true; }                                     \
+            if (dead_) { if (lane == 0) atomicMax(&sm.okbad, efetch); break; }                                                    \
+        }                                                                                                                         \
+    } while (0)
+#ifdef JSLP_DEBUG_RESIDENT
+#define JSLP_RT_RETRY() do { if (tid == 0) R.rt_retries += 1; } while (0)
+#else
+#define JSLP_RT_RETRY() do { } while (0)
+#endif
 // ... and its fetch: every lane polls ITS 16-byte words of the winner's row until both tags of each are this epoch's
 #define JSLP_XL_FETCH_ROW(PCCOL, QUOT)                                                                                            \
     do {                                                                                                                          \
@@ -370,7 +498,10 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     constexpr int ST_AUX = XL ? 0 : 16;           // aux of the hand-off stores: 16 = sc1 (write-through to memory)
     constexpr bool WLL = !XL && JSLP_PIPE_WINNER_LL != 0;  // winner-only tagged row (see JSLP_PIPE_WINNER_LL)
     constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
-    constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT);  // quot comes with the fetch: no barrier behind it
+    constexpr bool CKS = !TAGGED && JSLP_PIPE_SPECPUB != 0 && JSLP_PIPE_ROW_CHECKSUM != 0 && CPT <= JSLP_PIPE_ROW_CHECKSUM_MAXCPT;  // checksummed hand-over of the candidate rows (see JSLP_PIPE_ROW_CHECKSUM)
+    constexpr bool UPD_NEW_ = XL || (JSLP_PIPE_NEW_UPDATE != 0 && CPT <= 4 && !(OPT && ROWS > 8));
+    constexpr int EARLY = (!XL && UPD_NEW_) ? JSLP_PIPE_EARLY_LOOKS : 0;  // looks at the summaries that leave during the row update
+    constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT && !CKS);  // quot comes with the fetch: no barrier behind it
     // the ratio test's transposition (entry i of the entering column from the ONE lane that holds it to lane i) through LDS: as `x = lane
     // == i ? readlane(a[i][j]) : x` the compiler precomputes the 64-bit lane masks, spills them and pays two reloads, two moves and two
     // selects per row on top of the readlanes -- in the one wave the summary waits for
@@ -562,14 +693,21 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         v4u_t g;
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;  // lanes beyond the grid: "no candidate"
         const int goff = (par * JSLP_F_MAXG + tid) * JSLP_G16_STRIDE;
+        // early looks at the summaries (JSLP_PIPE_EARLY_LOOKS): a look costs one trip to memory and back, during which this wave has the
+        // row update to do -- the first look leaves in front of the update, the second between update and publication, and the gather
+        // examines them in order before it starts looking again
+        v4u_t ge0 = g, ge1 = g;
+        if (EARLY >= 2 && poller && used) ge0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
         // (the pending pivot's column entries of my rows: broadcast LDS reads, JSLP_PIPE_KCHUNK of them in flight together)
         if (UPD_NEW) {
             if (pend) JSLP_XL_UPDATE_PASS();
+            if (EARLY >= 1 && poller && used) ge1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
             if (pubrow != 0) {
                 if (TAGGED) { if (XL) JSLP_XL_PUBLISH_ROW(pubrow); }  // (winner-only builds publish after the decision)
                 else if (JSLP_PIPE_SPECPUB) JSLP_PUBLISH_ROW_PLAIN(pubrow);
             }
-        } else
+        } else {
+        u64_t ck = 0;
 #pragma unroll
         for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
             double kis[ROWS];
@@ -587,15 +725,27 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                         v4u_t v;
                         v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
                         __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + (j >> 1) * PAIR_STEP, 0, ST_AUX);
+                        if (CKS) JSLP_CK_PAIR(ck, lo, hi, j);
                     }
                 }
             }
+        }
+        if (CKS && pubrow != 0) JSLP_CKS_RAISE_FLAG(ck);
         }
         pend = false;
         RT_MARK(2);
         // ---- C: gather: lane w of the first four waves polls workgroup w's granule ------------------------------------------------
         if (poller) {
             unsigned spins = 0;
+            bool have = false;
+            if (EARLY >= 1) {
+                v4u_t gl = g;
+                if (used) gl = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);  // (leaves before the early looks are examined)
+                if (EARLY >= 2 && __all(ge0.y == tag && (ge0.w >> 16) == (tag & 0xffffu))) { g = ge0; have = true; }
+                else if (__all(ge1.y == tag && (ge1.w >> 16) == (tag & 0xffffu))) { g = ge1; have = true; }
+                else if (__all(gl.y == tag && (gl.w >> 16) == (tag & 0xffffu))) { g = gl; have = true; }
+            }
+            if (!have)
             for (;;) {
                 if (used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
                 const bool ok = g.y == tag && (g.w >> 16) == (tag & 0xffffu);
@@ -625,7 +775,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         }
         RT_MARK(1);
         if (QDIRECT && !OPT && tid == THREADS - 1) { sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff; }  // the next pricing's reductions: everybody read this pivot's before the barrier that closed S; the barrier below orders the reset in front of the next pricing
-        if (!TAGGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2 (the winner's release below builds on it; XL / winner-only: the row carries its tags)
+        if (!TAGGED && !CKS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2 (the winner's release below builds on it; XL / winner-only: the row carries its tags)
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
         RT_MARK(3);
@@ -677,7 +827,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         //      a barrier of its own here (155 k with the unsound release) -------------------------------------------------------------
         const int bw = pr / f.rpb;
         if (WLL && bw == b) JSLP_XL_PUBLISH_ROW(pr);  // (only the winner, only now: 32 KB per pivot instead of 4 MB of candidates; the tags are the flag)
-        if (!TAGGED && bw == b) {  // (uniform: pr is the row I published -- my candidate was the chip's best; XL: tags inside the row, no flag)
+        if (!TAGGED && !CKS && bw == b) {  // (uniform: pr is the row I published -- my candidate was the chip's best; XL: tags inside the row, no flag)
             if (!JSLP_PIPE_SPECPUB && colok) {  // the row leaves only now, and only from here: 16 KB per pivot instead of 4 MB of candidates
 #pragma unroll
                 for (int i = 0; i < ROWS; i++) {
@@ -722,6 +872,8 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             // (see resident_phase's step E); a wave that gives up raises sm.okbad to this fetch's number
             if (TAGGED) {
                 JSLP_XL_FETCH_ROW(pc, quot);
+            } else if (CKS) {
+                JSLP_CKS_FETCH_ROW();
             } else {
             efetch += 1;
             unsigned spins = 0;
@@ -910,25 +1062,6 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     }
 }
 
-// maximum of a 64-bit key over the wave, result in every lane (four DPP exchanges inside the 16-lane rows + readlanes across them)
-template <int CTRL>
-__device__ __forceinline__ u64_t u64_dpp(u64_t x) {
-    const int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
-    return ((u64_t)(unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false) << 32) |
-           (u64_t)(unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-}
-__device__ __forceinline__ u64_t u64_readlane(u64_t x, int l) {
-    return ((u64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l) << 32) |
-           (u64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l);
-}
-__device__ __forceinline__ u64_t u64_max(u64_t a, u64_t b) { return a > b ? a : b; }
-__device__ __forceinline__ u64_t u64_wave_max(u64_t x) {
-    x = u64_max(x, u64_dpp<0xB1>(x));
-    x = u64_max(x, u64_dpp<0x4E>(x));
-    x = u64_max(x, u64_dpp<0x141>(x));
-    x = u64_max(x, u64_dpp<0x140>(x));
-    return u64_max(u64_max(u64_readlane(x, 0), u64_readlane(x, 16)), u64_max(u64_readlane(x, 32), u64_readlane(x, 48)));
-}
 
 // ===================================================================================================================
 // Phase 1 (simplex.ts:25-98) in the same pipelined form.  Per pivot: leaving row = most negative RHS below -precision (first
@@ -951,7 +1084,8 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     constexpr int ST_AUX = XL ? 0 : 16;           // aux of the hand-off stores: 16 = sc1 (write-through to memory)
     constexpr bool WLL = !XL && JSLP_PIPE_WINNER_LL != 0;  // winner-only tagged row (see JSLP_PIPE_WINNER_LL)
     constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
-    constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT);  // quot comes with the fetch: no barrier behind it
+    constexpr bool CKS = !TAGGED && JSLP_PIPE_SPECPUB != 0 && JSLP_PIPE_ROW_CHECKSUM != 0 && CPT <= JSLP_PIPE_ROW_CHECKSUM_MAXCPT;  // checksummed hand-over of the candidate rows (see JSLP_PIPE_ROW_CHECKSUM)
+    constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT && !CKS);  // quot comes with the fetch: no barrier behind it
     // the ratio test's transposition (entry i of the entering column from the ONE lane that holds it to lane i) through LDS: as `x = lane
     // == i ? readlane(a[i][j]) : x` the compiler precomputes the 64-bit lane masks, spills them and pays two reloads, two moves and two
     // selects per row on top of the readlanes -- in the one wave the summary waits for
@@ -1063,7 +1197,8 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 if (TAGGED) { if (XL) JSLP_XL_PUBLISH_ROW(pubrow); }  // (winner-only builds publish after the decision)
                 else if (JSLP_PIPE_SPECPUB) JSLP_PUBLISH_ROW_PLAIN(pubrow);
             }
-        } else
+        } else {
+        u64_t ck = 0;
 #pragma unroll
         for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
             double kis[ROWS];
@@ -1081,9 +1216,12 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                         v4u_t v;
                         v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
                         __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + (j >> 1) * PAIR_STEP, 0, ST_AUX);
+                        if (CKS) JSLP_CK_PAIR(ck, lo, hi, j);
                     }
                 }
             }
+        }
+        if (CKS && pubrow != 0) JSLP_CKS_RAISE_FLAG(ck);
         }
         pend = false;
         RT_MARK(2);
@@ -1108,7 +1246,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; }
         }
         RT_MARK(1);
-        if (!TAGGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2
+        if (!TAGGED && !CKS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
         RT_MARK(3);
@@ -1132,7 +1270,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         // ---- the winner releases its row (see phase 2) ---------------------------------------------------------------------------
         const int bw = pr / f.rpb;
         if (WLL && bw == b) JSLP_XL_PUBLISH_ROW(pr);
-        if (!TAGGED && bw == b && tid < THREADS / 64) {  // (every wave's stores reached the L2 before the barrier that closed the gather)
+        if (!TAGGED && !CKS && bw == b && tid < THREADS / 64) {  // (every wave's stores reached the L2 before the barrier that closed the gather)
             if (XL) {
                 *reinterpret_cast<volatile u64_t*>(f.rowflagc[par] + tid * JSLP_F_MAXG + b) = (u64_t)tag;
             } else {
@@ -1151,6 +1289,8 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 double q_unused = 0.0;
                 JSLP_XL_FETCH_ROW(0, q_unused);
                 (void)q_unused;
+            } else if (CKS) {
+                JSLP_CKS_FETCH_ROW();
             } else {
             efetch += 1;
             unsigned spins = 0;
@@ -1375,3 +1515,6 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #undef JSLP_XL_PUBLISH_ROW
 #undef JSLP_PUBLISH_ROW_PLAIN
 #undef JSLP_XL_FETCH_ROW
+#undef JSLP_CKS_FETCH_ROW
+#undef JSLP_CKS_RAISE_FLAG
+#undef JSLP_RT_RETRY

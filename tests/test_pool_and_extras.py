@@ -332,6 +332,37 @@ def test_wide_resident_geometry_with_a_late_wave(hip_hooks_lib, monkeypatch):
         assert got == (want["pivots"], want["digest"], want["final_sha"]), (late, got)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n", [("ra", 1000), ("lp", 1000), ("ra", 2000)])
+def test_checksummed_row_hand_over_survives_a_flag_that_overtakes_its_row(hip_hooks_lib, kind, n, monkeypatch):
+    """Litmus for the lean kernels' row hand-over (jslp_resident_pipe.hip.h, JSLP_PIPE_ROW_CHECKSUM): nothing orders a wave's flag word
+    behind its 16-byte stores of the candidate row on their way through the fabric -- the reader loads both, recomputes the row's
+    checksum and looks again until it matches the word.  JSLP_TEST_RESIDENT_LATE_WAVE0=2 produces the bad order on purpose: wave 0 of
+    every publishing workgroup raises its flag word ~8 k cycles BEFORE it stores its columns of the row, at every pivot.  A reader that
+    trusted the flag would take the row of two pivots ago; the solve must still be the reference's to the bit (phase 2 and phase 1
+    pipelines), and the repeated looks must show up in jslp_work_counters.resident_fetch_retries (the test is not vacuous)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import known_answers as KA
+    monkeypatch.setenv("JSLP_FORCE_PATH", "resident")
+    if kind == "ra":
+        m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
+    else:
+        m, vibr, vibc, _ = generators.dense_random_lp_tableau(12345, n, n)
+    want = KA.expected_dense(kind, n, n)
+    assert want is not None
+    monkeypatch.setenv("JSLP_TEST_RESIDENT_LATE_WAVE0", "2")
+    t = Tableau(m, vibr, vibc, lib=hip_hooks_lib)
+    res = t.simplex(check_cycles=False)
+    c = t.get_counters()
+    assert t.last_path() == "resident" and c["resident_aborts"] == 0
+    tr = t.pivot_trace()
+    got = (len(tr), pivot_digest(tr), G.sha_matrix(t.download()[0]), bool(res.feasible))
+    t.close()
+    assert got == (want["pivots"], want["digest"], want["final_sha"], want["feasible"]), got
+    assert c["resident_fetch_retries"] >= len(tr) // 2, c  # (every pivot's winner held its row back: its readers looked more than once)
+
+
 # (round 4: the repeated-solve stress of the tall / wide shapes moved to tests/test_resident_pins.py, where every run is compared with the
 #  instance's KNOWN answer -- not with the first run -- and a rolled-back resident launch fails the test)
 

@@ -103,7 +103,7 @@ def _stress(args, env=None, timeout=900):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "resident_stress.py")] + [str(a) for a in args],
                          capture_output=True, text=True, timeout=timeout, env=e)
     last = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else ""
-    assert out.returncode == 0 and ": 0 differ from the known answer" in last and last.endswith("resident aborts 0"), (out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0 and ": 0 differ from the known answer" in last and "; resident aborts 0;" in last, (out.stdout[-2000:], out.stderr[-2000:])
     assert "path resident" in last, last
     return last
 

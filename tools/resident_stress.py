@@ -65,13 +65,14 @@ def main(argv):
         return 2
     lib = _capi.load_hip()
     unr = list(range(n_unr))
-    first, bad, t, pivots_done, aborts, since_upload = None, 0, None, 0, 0, 0
+    first, bad, t, pivots_done, aborts, since_upload, retries = None, 0, None, 0, 0, 0, 0
     for i in range(runs):
         # (an engine's pivot trace holds 2^20 pivots since its upload: a fresh engine before it would overflow)
         if fresh or t is None or (first is not None and since_upload + first["pivots"] > 1000000):
             since_upload = 0
             if t is not None:
                 aborts += t.get_counters()["resident_aborts"]
+                retries += t.get_counters()["resident_fetch_retries"]
                 t.close()
             t = Tableau(A, vibr, vibc, unr, lib=lib)
             t.save()
@@ -92,10 +93,11 @@ def main(argv):
             print("run %d DIFFERS from %s: got %s want %s (path %s)" % (
                 i, "the known answer" if want is not None else "run 0", {k: sig[k] for k in wrong}, {k: ref[k] for k in wrong}, sig["path"]), flush=True)
     aborts += t.get_counters()["resident_aborts"]
+    retries += t.get_counters()["resident_fetch_retries"]
     t.close()
-    print("%d x %d %s%s%s, %d runs (%s), %d pivots, path %s: %d differ from %s; resident aborts %d" % (
+    print("%d x %d %s%s%s, %d runs (%s), %d pivots, path %s: %d differ from %s; resident aborts %d; repeated row looks %d" % (
         m + 1, n + 1, kind, " unr=%d" % n_unr if n_unr else "", " check" if check else "", runs, "fresh engines" if fresh else "one engine",
-        pivots_done, first["path"], bad, ("the known answer [%s]" % want["source"]) if want is not None else "the first (UNVERIFIED)", aborts))
+        pivots_done, first["path"], bad, ("the known answer [%s]" % want["source"]) if want is not None else "the first (UNVERIFIED)", aborts, retries))
     return 1 if (bad or aborts) else 0
 
 
