@@ -204,6 +204,31 @@ __device__ __forceinline__ bool sweep_summary(const ResCtx& f, int par, unsigned
     return true;
 }
 
+// maximum of a 64-bit key over the wave, result in every lane (four DPP exchanges inside the 16-lane rows + readlanes across them)
+template <int CTRL>
+__device__ __forceinline__ u64_t u64_dpp(u64_t x) {
+    const int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
+    return ((u64_t)(unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false) << 32) |
+           (u64_t)(unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u64_t u64_readlane(u64_t x, int l) {
+    return ((u64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l) << 32) |
+           (u64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l);
+}
+__device__ __forceinline__ u64_t u64_max(u64_t a, u64_t b) { return a > b ? a : b; }
+__device__ __forceinline__ u64_t u64_wave_max(u64_t x) {
+    x = u64_max(x, u64_dpp<0xB1>(x));
+    x = u64_max(x, u64_dpp<0x4E>(x));
+    x = u64_max(x, u64_dpp<0x141>(x));
+    x = u64_max(x, u64_dpp<0x140>(x));
+    return u64_max(u64_max(u64_readlane(x, 0), u64_readlane(x, 16)), u64_max(u64_readlane(x, 32), u64_readlane(x, 48)));
+}
+// (Round 4 tried two register-level forms of this reduction on config 3a, both bit-identical, both slower than the three rounds of LDS
+//  atomics below -- 168.7 k pivots/s: (a) every wave folds batch, value and column with a DPP maximum and ballots, 16 bytes per wave, ONE
+//  barrier, every thread scans the 16 results: 139.7 k -- with 16 waves on 4 SIMDs, work replicated in every wave costs four times its
+//  instruction count; (b) round 1 as below, then only the one to five waves holding lanes of the winning batch fold value and column in
+//  registers, second barrier, every thread reads those results: 158.8 k, phase 1 -- which does not price -- slower with it (14 more
+//  spilled SGPRs in the loop).  The atomics' participants are few: a batch is 50-500 columns.)
 // Pricing (simplex.ts:118-219, no unrestricted variables) of the cost-row pair (columns c0, c0+1) each lane
 // holds, reduced with three LDS atomics: first batch holding a candidate, best value in it, first column with
 // that value.  Positive doubles order like their bit patterns.  Returns the column (0 = none) and its value.

@@ -90,10 +90,22 @@
 // on (profiles/r04_headline_quot_direct.txt): off.  (4) UNRESTRICTED VARIABLES in these loops (`UNR`) and optional objectives in the
 // tall geometry: the 4001 x 2001 golden with 50 unrestricted variables 105.7 k pivots/s (fused pipeline: 32-35 k), the 3001 x 2031
 // golden with three objective rows 104 k (40.6 k) -- both the reference's own digests.
+// Round 4, later (r04_u ... r04_z; config 3a 154.0 k at the start): the ratio test's transposition through LDS (+2.7 %), the XCD-local
+// build's update pass for the 2- / 4-column geometries (+4.6 %), the global maps and the trace through a device-side copy of the context
+// instead of eight live pointers (166.5 k).  Then the hand-over itself: (5) the CHECKSUMMED row (JSLP_PIPE_ROW_CHECKSUM, below) -- what
+// round 3's release fence made sound by ordering, the reader now verifies end to end; with flag word and row loaded in ONE look (0
+// repeated looks on config 3a, 0.3 % of the looks on 4001 x 2001) the winner's fence (measured at 0.15 us by leaving it out: 165.8 k ->
+// 170.2 k, unsound), the flag's own trip and the drain are gone: 168.5-171.4 k with the cycle check off, 143.5 k -> 155 k with it on,
+// 4001 x 2001 120 k -> 124 k.  The section that remains (decide + fetch: 3.3-3.6 k cycles, every look answered first time) is one trip
+// to memory and back under 4096 waves asking for the same 16 KB.  (6) looks at the summaries issued during the row update
+// (JSLP_PIPE_EARLY_LOOKS): slower, see there.  (7) pricing folded in registers instead of LDS atomics, two forms: slower, see
+// price_row_lds (jslp_resident.hip.h).
 // ===================================================================================================================
 // -DJSLP_CHAOS_BUILD (tests / diagnosis only, never the shipped library): at every phase boundary of the pipelined loops one wave of
 // the workgroup -- a different one per pivot and boundary -- sleeps ~6 k cycles (JSLP_TEST_RESIDENT_LATE_WAVE0=2), and with =3 every
-// fifth workgroup sleeps ~4 k more: whatever in these loops relies on waves or workgroups arriving together shows up as lost pivots
+// fifth workgroup sleeps ~4 k more: whatever in these loops relies on waves or workgroups arriving together shows up as lost pivots.
+// (=2 exactly also makes wave 0 of every publishing workgroup raise its flag word ~8 k cycles BEFORE it stores its columns of the
+//  candidate row -- the litmus of the checksummed hand-over, JSLP_PUBLISH_ROW_PLAIN; odd values make wave 0 late at every row fetch)
 #ifdef JSLP_CHAOS_BUILD
 #undef RT_MARK
 #define RT_MARK(p)                                                                                                        \
@@ -194,25 +206,6 @@ __device__ __forceinline__ bool cyc_suffix_is_square(const int2* lds, const int2
     return __syncthreads_or(found) != 0;
 }
 
-// maximum of a 64-bit key over the wave, result in every lane (four DPP exchanges inside the 16-lane rows + readlanes across them)
-template <int CTRL>
-__device__ __forceinline__ u64_t u64_dpp(u64_t x) {
-    const int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
-    return ((u64_t)(unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false) << 32) |
-           (u64_t)(unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-}
-__device__ __forceinline__ u64_t u64_readlane(u64_t x, int l) {
-    return ((u64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l) << 32) |
-           (u64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l);
-}
-__device__ __forceinline__ u64_t u64_max(u64_t a, u64_t b) { return a > b ? a : b; }
-__device__ __forceinline__ u64_t u64_wave_max(u64_t x) {
-    x = u64_max(x, u64_dpp<0xB1>(x));
-    x = u64_max(x, u64_dpp<0x4E>(x));
-    x = u64_max(x, u64_dpp<0x141>(x));
-    x = u64_max(x, u64_dpp<0x140>(x));
-    return u64_max(u64_max(u64_readlane(x, 0), u64_readlane(x, 16)), u64_max(u64_readlane(x, 32), u64_readlane(x, 48)));
-}
 // the two 32-bit halves of a 64-bit word, each summed over the wave modulo 2^32 (every exchange pairs disjoint groups: lanes, pairs,
 // quads, the halves of a 16-lane row; then the four rows) -- the checksummed row hand-over's reduction
 __device__ __forceinline__ u64_t u64_wave_add_halves(u64_t x) {
