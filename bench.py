@@ -380,7 +380,7 @@ def main():
             hc = t.get_counters()
             if hc["resident_aborts"] or hc["resident_handovers"]:
                 raise WrongAnswer("resident kernel health: %s (a rolled-back launch times the streaming fallback)" % {k: hc[k] for k in ("resident_aborts", "resident_handovers", "resident_launches")})
-            extras["resident_health"] = {k: hc[k] for k in ("resident_launches", "resident_aborts", "resident_handovers")}
+            extras["resident_health"] = {k: hc[k] for k in ("resident_launches", "resident_aborts", "resident_handovers", "resident_fetch_retries")}
         t.close()
 
         # ---- the other config-3 instance (3b: generateRandomLP, every pivot is a phase-1 pivot; ends infeasible) -------------
