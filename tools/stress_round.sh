@@ -1,8 +1,9 @@
 #!/bin/bash
 # >= 5 M pivots of tools/resident_stress.py over the five register-resident geometries, both pipelines, the cycle check, unrestricted
 # variables: every run against its KNOWN answer (exit status != 0 on any difference or resident abort).  usage: tools/stress_round.sh <out file>
-out=${1:-gpurun_out/resident_stress.txt}; : > $out; rc=0
-run() { timeout 900 python tools/resident_stress.py "$@" >> $out 2>&1 || rc=1; tail -1 $out; }
+# STRESS_DIV=n divides every run count by n (the chaos build sleeps thousands of cycles per pivot)
+out=${1:-gpurun_out/resident_stress.txt}; mkdir -p $(dirname $out); : > $out; rc=0; div=${STRESS_DIV:-1}
+run() { local m=$1 n=$2 r=$(( ($3 + div - 1) / div )); shift 3; timeout 900 python tools/resident_stress.py $m $n $r "$@" >> $out 2>&1 || rc=1; tail -1 $out; }
 run 2000 2000 110                      # <1024,2,8> lean phase 2: 1.4 M pivots
 run 2000 2000 30 --check               # ... with the cycle check
 run 4000 2000 40                       # <512,4,16>
