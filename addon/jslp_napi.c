@@ -9,12 +9,14 @@
  * (jslpsolver_amd/csrc/libjslp_hip.so) and -- in tests only -- the CPU oracle; there is no fallback: every call
  * before a successful load() throws.  TypedArrays are passed zero-copy (napi_get_typedarray_info).
  */
+#define _POSIX_C_SOURCE 200809L  /* clock_gettime under -std=c11 */
 #include <dlfcn.h>
 #include <node_api.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../include/jslp_engine.h"
 
@@ -64,6 +66,10 @@ static struct {
     int (*pool_set_watched)(jslp_pool*, const int32_t*, int32_t);
     int (*pool_relax_batch_watched)(jslp_pool*, int32_t, const int32_t*, const int8_t*, const int32_t*, const double*, int,
                                     jslp_simplex_result*, int32_t*, double*);
+    int32_t (*watched_count)(const jslp_engine*);
+    int32_t (*pool_watched_count)(const jslp_pool*);
+    int (*set_timing)(jslp_engine*, int);
+    int (*get_timing)(jslp_engine*, double*, int64_t*, double*);
 } L;
 
 /* what a JS engine handle points at: the engine plus the dimensions it was created with (argument checks without a
@@ -201,6 +207,8 @@ static napi_value fn_load(napi_env env, napi_callback_info info) {
     SYM(get_counters, "jslp_engine_get_counters"); SYM(pool_create, "jslp_pool_create"); SYM(pool_destroy, "jslp_pool_destroy");
     SYM(pool_size, "jslp_pool_size"); SYM(pool_sync_root, "jslp_pool_sync_root"); SYM(pool_relax_batch, "jslp_pool_relax_batch");
     SYM(pool_set_watched, "jslp_pool_set_watched_variables"); SYM(pool_relax_batch_watched, "jslp_pool_relax_batch_watched");
+    SYM(watched_count, "jslp_engine_watched_count"); SYM(pool_watched_count, "jslp_pool_watched_count");
+    SYM(set_timing, "jslp_engine_set_timing"); SYM(get_timing, "jslp_engine_get_timing");
     napi_value s;
     NAPI_OK(env, napi_create_string_utf8(env, L.backend_name(), NAPI_AUTO_LENGTH, &s));
     return s;
@@ -539,8 +547,11 @@ static napi_value fn_relax_batch_watched(napi_env env, napi_callback_info info) 
     if (no < 1) THROW(env, "relaxBatchWatched: offsets must hold n_nodes + 1 entries");
     const int32_t n_nodes = (int32_t)no - 1;
     if (nt != nv || nv != nx || (size_t)((const int32_t*)o)[n_nodes] != nt) THROW(env, "relaxBatchWatched: offsets[n_nodes] must equal the length of the cut arrays");
-    const size_t n_watched = (size_t)box_of(env, argv[0])->n_watched;
-    if (n_watched == 0) THROW(env, "relaxBatchWatched: setWatchedVariables first");
+    /* (sized by what the LIBRARY will write -- jslp_engine_watched_count -- not by this binding's shadow of the last list it
+       registered itself: another user of the same engine may have changed it) */
+    const int32_t nw_ = L.watched_count(e);
+    if (nw_ <= 0) THROW(env, "relaxBatchWatched: setWatchedVariables first");
+    const size_t n_watched = (size_t)nw_;
     if ((wr && nwr < (size_t)n_nodes * n_watched) || (wv && nwv < (size_t)n_nodes * n_watched))
         THROW(env, "relaxBatchWatched: output arrays shorter than n_nodes * nWatched");
     jslp_simplex_result* res = (jslp_simplex_result*)calloc((size_t)(n_nodes > 0 ? n_nodes : 1), sizeof *res);
@@ -702,7 +713,7 @@ static napi_value fn_relax_watched(napi_env env, napi_callback_info info) {
     /* the engine writes one entry per watched variable: the host sized both arrays by the list it registered, and the
        engine refuses lists longer than the row capacity */
     {
-        const int32_t n_watched = box_of(env, argv[0])->n_watched;
+        const int32_t n_watched = L.watched_count(e);  /* (the library's own count: see relaxBatchWatched) */
         if (n_watched <= 0) THROW(env, "relaxWatched: setWatchedVariables first");
         if (!wr || !wv || nwr != nwv || nwr < (size_t)n_watched)
             THROW(env, "relaxWatched: watchedRow and watchedValue must have one entry per watched variable");
@@ -890,8 +901,11 @@ static napi_value fn_pool_relax_batch_watched(napi_env env, napi_callback_info i
     const int32_t n_nodes = (int32_t)no - 1;
     if (nt != nv || nv != nx || (size_t)((const int32_t*)o)[n_nodes] != nt) THROW(env, "poolRelaxBatchWatched: offsets[n_nodes] must equal the length of the cut arrays");
     NAPI_OK(env, napi_get_value_external(env, argv[0], &bp));
-    const size_t n_watched = (size_t)((pbox*)bp)->n_watched;
-    if (n_watched == 0) THROW(env, "poolRelaxBatchWatched: poolSetWatchedVariables first");
+    (void)bp;
+    const int32_t nwp_ = L.pool_watched_count(p);  /* every member's count, -1 when they differ (not the JS-side shadow) */
+    if (nwp_ == 0) THROW(env, "poolRelaxBatchWatched: poolSetWatchedVariables first");
+    if (nwp_ < 0) THROW(env, "poolRelaxBatchWatched: the members' watched variables differ (poolSetWatchedVariables sets them all)");
+    const size_t n_watched = (size_t)nwp_;
     if ((wr && nwr < (size_t)n_nodes * n_watched) || (wv && nwv < (size_t)n_nodes * n_watched))
         THROW(env, "poolRelaxBatchWatched: output arrays shorter than n_nodes * nWatched");
     jslp_simplex_result* res = (jslp_simplex_result*)calloc((size_t)(n_nodes > 0 ? n_nodes : 1), sizeof *res);
@@ -910,8 +924,29 @@ static napi_value fn_pool_relax_batch_watched(napi_env env, napi_callback_info i
     return arr;
 }
 
-static napi_value init(napi_env env, napi_value exports) {
-    static const struct { const char* name; napi_callback fn; } fns[] = {
+/* ---- where a Solve() spends its time inside the binding ------------------------------------------------------------------------
+   Every exported function runs behind one trampoline that adds its wall time (CLOCK_MONOTONIC) and a call to its entry of `fns`;
+   `timings(reset)` returns { name: [milliseconds, calls], ... } for the entries that were called.  Two clock reads per call (~40 ns):
+   always on.  bench.py's `dropin_js` leg and tools/shim_profile.js build their per-phase tables (create + pin / upload / simplex /
+   read-back / release) from it; the device time inside simplex() is jslp_engine_get_timing's (HIP events), exported as `deviceMs`. */
+typedef struct { const char* name; napi_callback fn; double ns; long long calls; } fn_entry;
+static napi_value fn_timings(napi_env env, napi_callback_info info);
+static napi_value fn_device_ms(napi_env env, napi_callback_info info);
+static napi_value timed_cb(napi_env env, napi_callback_info info) {
+    size_t argc = 0;
+    void* data = NULL;
+    if (napi_get_cb_info(env, info, &argc, NULL, NULL, &data) != napi_ok || !data) THROW(env, "internal: function entry missing");
+    fn_entry* fe = (fn_entry*)data;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    napi_value r = fe->fn(env, info);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    fe->ns += (double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec);
+    fe->calls += 1;
+    return r;
+}
+
+static fn_entry fns[] = {
         {"load", fn_load}, {"deviceCount", fn_device_count}, {"create", fn_create}, {"destroy", fn_destroy},
         {"upload", fn_upload}, {"setOptionalObjectives", fn_set_optional}, {"getOptionalObjectives", fn_get_optional},
         {"simplex", fn_simplex}, {"pivot", fn_pivot}, {"save", fn_save}, {"restore", fn_restore},
@@ -925,12 +960,63 @@ static napi_value init(napi_env env, napi_value exports) {
         {"poolCreate", fn_pool_create}, {"poolDestroy", fn_pool_destroy}, {"poolSize", fn_pool_size},
         {"poolSyncRoot", fn_pool_sync_root}, {"poolRelaxBatch", fn_pool_relax_batch},
         {"poolSetWatchedVariables", fn_pool_set_watched}, {"poolRelaxBatchWatched", fn_pool_relax_batch_watched},
-    };
-    for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+        {"deviceMs", fn_device_ms},
+};
+#define N_FNS (sizeof fns / sizeof fns[0])
+
+/* timings(reset = false) -> { name: [ms, calls] } of every binding function called since the last reset */
+static napi_value fn_timings(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    bool reset = false;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) == napi_ok && argc >= 1) napi_get_value_bool(env, argv[0], &reset);
+    napi_value o;
+    NAPI_OK(env, napi_create_object(env, &o));
+    for (size_t i = 0; i < N_FNS; i++) {
+        if (fns[i].calls == 0) continue;
+        napi_value pair, ms, calls;
+        NAPI_OK(env, napi_create_array_with_length(env, 2, &pair));
+        NAPI_OK(env, napi_create_double(env, fns[i].ns / 1e6, &ms));
+        NAPI_OK(env, napi_create_double(env, (double)fns[i].calls, &calls));
+        napi_set_element(env, pair, 0, ms);
+        napi_set_element(env, pair, 1, calls);
+        NAPI_OK(env, napi_set_named_property(env, o, fns[i].name, pair));
+        if (reset) { fns[i].ns = 0; fns[i].calls = 0; }
+    }
+    return o;
+}
+
+/* deviceMs(engine, enable?) -> milliseconds the engine's stream spent inside simplex() / relax() since timing was switched on
+   (HIP events around the kernels: jslp_engine_get_timing); deviceMs(engine, true) switches it on and zeroes the sum */
+static napi_value fn_device_ms(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < 1) THROW(env, "deviceMs(engine[, enable])");
+    jslp_engine* e = handle(env, argv[0]);
+    if (!e) return NULL;
+    if (!L.set_timing || !L.get_timing) THROW(env, "deviceMs: the loaded library has no timing entry points");
+    if (argc >= 2) {
+        bool on = false;
+        napi_get_value_bool(env, argv[1], &on);
+        ENGINE_OK(env, L.set_timing(e, on ? 1 : 0), "set_timing");
+    }
+    double upd = 0, total = 0;
+    int64_t launches = 0;
+    ENGINE_OK(env, L.get_timing(e, &upd, &launches, &total), "get_timing");
+    napi_value v;
+    NAPI_OK(env, napi_create_double(env, total, &v));
+    return v;
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+    for (size_t i = 0; i < N_FNS; i++) {
         napi_value f;
-        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, timed_cb, &fns[i], &f) != napi_ok) return NULL;
         if (napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) return NULL;
     }
+    napi_value f;  /* (not timed itself) */
+    if (napi_create_function(env, "timings", NAPI_AUTO_LENGTH, fn_timings, NULL, &f) != napi_ok) return NULL;
+    if (napi_set_named_property(env, exports, "timings", f) != napi_ok) return NULL;
     return exports;
 }
 

@@ -76,52 +76,81 @@ DROPIN_NODE = r"""
 const fs=require('fs'),path=require('path'),zlib=require('zlib');
 const root=process.argv[1], mode=process.argv[2];
 const solver=require(path.join(root,'oracle/_ref/src/solver.js')).default;
+let addon=null,gpu=null;
 if(mode!=='cpu'){const T=require(path.join(root,'oracle/_ref/src/tableau/tableau.js')).default;
  const {SlackVariable}=require(path.join(root,'oracle/_ref/src/expressions.js'));
- const gpu=require(path.join(root,'host/gpu-tableau.js'));gpu.loadEngine({});gpu.install(T,{SlackVariable,solver});}
+ gpu=require(path.join(root,'host/gpu-tableau.js'));gpu.loadEngine({});gpu.install(T,{SlackVariable,solver});
+ addon=require(path.join(root,'addon/jslp_napi.node'));}
 // time inside Model.solve (tableau build, simplex / branch-and-cut, read-out) apart from the reference's own JSON parsing and result
 // assembly around it, whose garbage (a scavenge of 1-1.5 ms in most solves) makes the totals of the small configurations noisy
 const M=require(path.join(root,'oracle/_ref/src/model.js')).default;let tSolve=0;const origSolve=M.prototype.solve;
 M.prototype.solve=function(){const t0=process.hrtime.bigint();try{return origSolve.apply(this,arguments);}finally{tSolve+=Number(process.hrtime.bigint()-t0)/1e6;}};
-const out={};const med=(a)=>{const b=a.slice().sort((x,y)=>x-y);return b[b.length>>1];};
-for(const name of process.argv.slice(3)){
- const g=JSON.parse(zlib.gunzipSync(fs.readFileSync(path.join(root,'tests/golden/fixtures',name+'.json.gz'))).toString());
- const run=()=>{const m=JSON.parse(JSON.stringify(g.model));tSolve=0;const t0=process.hrtime.bigint();const r=solver.Solve(m);return [Number(process.hrtime.bigint()-t0)/1e6,r.result,tSolve];};
- for(let i=0;i<12;i++)run();const a=[],b=[];for(let i=0;i<31;i++){const r=run();a.push(r[0]);b.push(r[2]);}
- out[name]={ms:med(a),min_ms:Math.min(...a),model_solve_ms:med(b),runs:a.length,result:run()[1],want:g.result.result};}
+const out={};const q=(a,f)=>{const b=a.slice().sort((x,y)=>x-y);return b[Math.min(b.length-1,Math.floor(f*b.length))];};
+// the binding's calls, grouped into the phases of a Solve() (addon.timings(): wall clock inside each N-API function)
+const PH={create_pin:['create','hostMatrix'],upload:['upload','setOptionalObjectives','setIntegerVariables','setWatchedVariables','save'],
+ simplex:['simplex','relax','relaxWatched','relaxBatch','relaxBatchWatched','relaxFrom','addCuts','applyMirCuts','checkpointCreate','checkpointRestore','checkpointRelease'],
+ read_back:['readRhs','getOptionalObjectives','download','dims','pivotTrace'],release:['detach','destroy','poolDestroy']};
+for(const spec of process.argv.slice(3)){
+ const [name,warm,runs]=spec.split(':');
+ let g;
+ if(name[0]==='@'){const gen=require(path.join(root,'oracle/_ref/src/test-utils/problem-generator.js'));const [n,m,d]=name.slice(1).split('x').map(Number);
+  g={model:gen.generateResourceAllocation({seed:7,numVariables:n,numConstraints:m,density:d}),result:{result:null}};}
+ else g=JSON.parse(zlib.gunzipSync(fs.readFileSync(path.join(root,'tests/golden/fixtures',name+'.json.gz'))).toString());
+ const run=()=>{const m=JSON.parse(JSON.stringify(g.model));tSolve=0;if(addon)addon.timings(true);const t0=process.hrtime.bigint();const r=solver.Solve(m);
+  const ms=Number(process.hrtime.bigint()-t0)/1e6;const ph={};let calls=0;
+  if(addon){const t=addon.timings(true);for(const k of Object.keys(PH)){ph[k]=0;for(const f of PH[k])if(t[f]){ph[k]+=t[f][0];calls+=t[f][1];delete t[f];}}
+   ph.other_calls=0;for(const f of Object.keys(t)){ph.other_calls+=t[f][0];calls+=t[f][1];}}
+  return {ms,res:r.result,solve:tSolve,ph,calls};};
+ for(let i=0;i<Number(warm||12);i++)run();const a=[],b=[],phs=[];let calls=0;
+ for(let i=0;i<Number(runs||31);i++){const r=run();a.push(r.ms);b.push(r.solve);phs.push(r.ph);calls=r.calls;}
+ const e={ms:q(a,0.5),min_ms:Math.min(...a),p90_ms:q(a,0.9),model_solve_ms:q(b,0.5),model_solve_min_ms:Math.min(...b),model_solve_p90_ms:q(b,0.9),runs:a.length,result:run().res,want:g.result.result};
+ if(addon){e.on_engine=calls>0;e.binding_calls=calls;e.phases_ms={};for(const k of Object.keys(phs[0]))e.phases_ms[k]=q(phs.map((p)=>p[k]),0.5);
+  // what is left of Model.solve once the binding's calls are taken out: the reference's own host code (tableau build in the pinned buffer, B&B tree, read-out)
+  const inSolve=['create_pin','upload','simplex','read_back','other_calls'].reduce((s,k)=>s+e.phases_ms[k],0);e.phases_ms.host_in_model_solve=Math.max(0,e.model_solve_ms-inSolve);
+  e.phases_ms.json_and_result=Math.max(0,e.ms-e.model_solve_ms-e.phases_ms.release);}
+ out[name]=e;}
 console.log(JSON.stringify(out));
 """
 
 
 def dropin_leg(with_cpu):
     """THE drop-in, end to end: solver.Solve(model) through the reference's own host (oracle/_ref: JSON parsing, presolve, the
-    branch-and-bound tree) + host/gpu-tableau.js + the N-API addon + the HIP engine, default install() options, JIT-warm median
-    of 31 (totals, and the time inside Model.solve apart) -- next to the unpatched reference on this box's CPU.  Runs in a child process BEFORE this process touches the GPU."""
+    branch-and-bound tree) + host/gpu-tableau.js + the N-API addon + the HIP engine, default install() options, JIT-warm min / median /
+    p90 of 31 (totals, and the time inside Model.solve apart), with the binding's own per-phase wall times (addon.timings()) -- next to
+    the unpatched reference on this box's CPU.  Runs in a child process BEFORE this process touches the GPU."""
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "src", "solver.js")) or not os.path.exists(os.path.join(ROOT, "addon", "jslp_napi.node")):
         return None
-    names = ["Monster_Problem", "Monster_II"]
+    # name[:warm-up solves:timed solves]; "@n x m x density" = the reference's generateResourceAllocation(seed 7) -- a dense mid-size LP the
+    # default policy DOES send to the engine (Monster LP, 1 % dense, it does not: host/gpu-tableau.js `structuralNnz`)
+    specs = ["Monster_Problem", "Monster_II", "Vendor_Selection:4:7", "@300x225x0.8:4:9"]
+    names = [s.split(":")[0] for s in specs]
     res = {}
     for mode in (("gpu", "cpu") if with_cpu else ("gpu",)):
         try:
-            out = subprocess.run(["node", "-e", DROPIN_NODE, ROOT, mode] + names, capture_output=True, text=True, timeout=600)
+            out = subprocess.run(["node", "-e", DROPIN_NODE, ROOT, mode] + specs, capture_output=True, text=True, timeout=900)
             res[mode] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         except Exception as e:
             res[mode] = {"error": repr(e)}
     leg = {"what": "solver.Solve(model) through the reference host (type-erased TS under node) + host/gpu-tableau.js + N-API addon + HIP engine, "
-                   "default install(Tableau, {solver}) options (size policy, 16-node speculative batches); JIT-warm median of 31 solves, ms",
+                   "default install(Tableau, {solver}) options (work-aware size policy: LPs by structural non-zeros, MILPs by cells; 16-node speculative "
+                   "batches); JIT-warm min / median / p90, ms; phases_ms = median wall time inside the binding's calls of one Solve (addon.timings())",
            "configs": {}}
     for n in names:
         g, c = res.get("gpu", {}).get(n), res.get("cpu", {}).get(n)
-        if g and g.get("result") != g.get("want"):
-            raise WrongAnswer("drop-in Solve(%s): %r, the reference: %r" % (n, g.get("result"), g.get("want")))
-        leg["configs"][n] = {"dropin_ms": g and g["ms"], "dropin_min_ms": g and g["min_ms"], "reference_cpu_ms": c and c["ms"],
-                             "reference_cpu_min_ms": c and c.get("min_ms"),
+        want = (g or {}).get("want")
+        if want is None and c:
+            want = c.get("result")  # generated models: the unpatched reference's own answer of this run
+        if g and want is not None and g.get("result") != want:
+            raise WrongAnswer("drop-in Solve(%s): %r, the reference: %r" % (n, g.get("result"), want))
+        leg["configs"][n] = {"dropin_ms": g and g["ms"], "dropin_min_ms": g and g["min_ms"], "dropin_p90_ms": g and g.get("p90_ms"),
+                             "reference_cpu_ms": c and c["ms"], "reference_cpu_min_ms": c and c.get("min_ms"), "reference_cpu_p90_ms": c and c.get("p90_ms"),
                              "speedup": (c["ms"] / g["ms"]) if (g and c and g.get("ms") and c.get("ms")) else None,
                              # inside Model.solve only (tableau build + simplex / branch-and-cut + read-out: what the binding replaces),
                              # without the reference's JSON handling around it
                              "model_solve_ms": g and g.get("model_solve_ms"), "reference_cpu_model_solve_ms": c and c.get("model_solve_ms"),
                              "model_solve_speedup": (c["model_solve_ms"] / g["model_solve_ms"]) if (g and c and g.get("model_solve_ms") and c.get("model_solve_ms")) else None,
-                             "result": g and g["result"]}
+                             "on_engine": g and g.get("on_engine"), "binding_calls": g and g.get("binding_calls"), "phases_ms": g and g.get("phases_ms"),
+                             "runs": g and g.get("runs"), "result": g and g["result"]}
     return leg
 
 
@@ -560,6 +589,30 @@ def relaxation_legs(ctx, args, reps=16):
            "outcomes_checked": "sha256(RHS column + row map) of every node of the last call == the reference's (rank 0's share)",
            "workload": "config 4: Monster_II (935x925 root, 112 ints), the reference's 151 visited cut lists x%d as one batch of "
                        "independent nodes per rank, sharded round-robin over %d rank(s)" % (reps, world)}
+    # (i-b) round 5: the LATENCY of a small batch -- what every dependent batch of a real tree waits for (a speculative batch is <= 16
+    #       nodes: one 1024-thread workgroup per node, each on its own CU): wall time of one call with the compact read-back for the first
+    #       1 / 8 / 16 visited nodes of the reference's tree, median of 30 calls
+    if rank == 0:
+        lat = {}
+        for n_small in (1, 8, 16):
+            sub = nodes[3:3 + n_small]  # (a dive of the reference's tree: nodes 3.. carry 2-5 cuts each)
+            packed_s = t.pack_cut_lists(sub)
+            fns = lambda: t.applyCutsBatchWatched(None, check_cycles=True, packed=packed_s, copy=False)
+            for _ in range(5):
+                fns()
+            ts = []
+            for _ in range(30):
+                t1 = time.perf_counter()
+                r_s, rows_s, vals_s = fns()
+                ts.append(time.perf_counter() - t1)
+            for i in range(n_small):  # against the big batch's (already verified) compact outcome of the same node
+                if r_s[i].height != res_w[3 + i].height or not np.array_equal(np.array(rows_s[i]), rows_w_keep[3 + i]) or not np.array_equal(np.array(vals_s[i]).view(np.int64), vals_w_keep[3 + i].view(np.int64)):
+                    raise WrongAnswer("small batch of %d: node %d differs from the verified outcome" % (n_small, i))
+            ts.sort()
+            piv_s = sum(r_s[i].pivots_phase1 + max(r_s[i].pivots_phase2, 0) for i in range(n_small))
+            lat[str(n_small)] = {"us_per_call_median": 1e6 * ts[len(ts) // 2], "us_per_call_min": 1e6 * ts[0], "us_per_node": 1e6 * ts[len(ts) // 2] / n_small, "pivots": int(piv_s)}
+        out["small_batch_latency"] = dict(lat, note="one jslp_engine_relax_batch_watched_pinned call (upload of the cut lists, one launch of k_node_lds<1024>, "
+                                                    "compact read-back, one synchronisation), host clock; what one dependent batch of a speculative tree costs")
     # (ii) gated algorithmic bytes from the kernels' own counters (a separate, untimed pass over the same batch)
     if rank == 0:
         t.set_counting(True)
@@ -638,6 +691,11 @@ def relaxation_legs(ctx, args, reps=16):
                    # what shards and what does not (rank 0's clock): the evaluation share = the speculative batches (engine calls +
                    # exchange step); the rest = model parsing, upload, root LP, tree bookkeeping on one host thread
                    "eval_ms": eval_ms, "exchange_ms": exch_ms, "host_ms": 1e3 * el_tree - eval_ms,
+                   # round 5: the exchange payload is COMPACT -- per node the 128-byte state record + row / RHS cell of the 112 integer
+                   # variables (jslp_engine_relax_batch_watched_device) instead of the whole RHS column + row map (11.4 KB per node)
+                   "exchange_bytes_per_batch_per_rank": (EXCHANGE_STATS["bytes"] / EXCHANGE_STATS["calls"]) if EXCHANGE_STATS["calls"] else 0,
+                   "exchange_bytes_per_node": (128 + 12 * len(g["tableau"]["integerVarIndexes"])) if world > 1 else 0,
+                   "node_outcome": "compact (integer variables' rows + values; the committed leaf re-evaluated with the full read-back)",
                    "eval_batches_per_solve": EVAL_STATS["batches"] / 5, "eval_nodes_per_solve": EVAL_STATS["nodes"] / 5, "includes": "model parsing, upload, root LP, the whole tree and the read-back (host logic in Python)",
                    "host": "python mirror of the reference host, no presolve (the drop-in is `dropin_js`: the reference's own host under node)"}
     return out if rank == 0 else None

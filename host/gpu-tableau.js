@@ -38,12 +38,18 @@ function loadEngine(options) {
 }
 
 // Size policy: which tableaus go to the engine.  Measured on the MI355X box (tools/mincells_sweep.js, tools/shim_profile.js;
-// profiles/r02_mincells_sweep.md): an LP pays from ~10 k cells (one launch + synchronisation per simplex(), ~0.1 ms, against
-// the reference's whole pivot loop); a branch-and-bound tree walked node by node costs ~50-80 us per relaxation on the engine
-// whatever the size, which the reference's CPU path undercuts until a relaxation touches a few hundred thousand cells
-// (LargeFarmMIP, 36 x 101: 0.017 ms per relaxation on the CPU); batched speculative evaluation (install(..., {speculate}))
-// amortises that latency over the batch.  opts.minCells overrides all three defaults (0 = everything runs on the engine).
+// profiles/r02_mincells_sweep.md, profiles/r05_policy_sweep.md): what the engine charges per simplex() is FIXED -- create + pinned build
+// buffer + upload + one launch + read-back, ~0.3-0.5 ms -- plus ~6-7 us per pivot whatever the pivot touches; what the reference's CPU
+// loop charges is proportional to the cells its zero gates let through (simplex.ts:370-383), i.e. to the NON-ZEROS of the tableau, not
+// to its cells.  An LP therefore goes to the engine by its structural non-zero count (the model's term count, known before the matrix
+// is built): a dense 120 x 90 LP (8.8 k non-zeros) pays, BASELINE's config 2 -- 'Monster LP', 625 x 553 = 345 k cells but 3.4 k non-zeros,
+// 60 pivots, 0.66 ms inside Model.solve on the CPU -- does not and stays on the reference's own path (three rounds it lost 2x on the
+// engine).  A branch-and-bound tree walked node by node costs ~50-80 us per relaxation on the engine whatever the size, which the
+// reference's CPU path undercuts until a relaxation touches a few hundred thousand cells (LargeFarmMIP, 36 x 101: 0.017 ms per
+// relaxation on the CPU); batched speculative evaluation (install(..., {speculate})) amortises that latency over the batch.
+// opts.minCells overrides every default (0 = everything runs on the engine: what the parity runs use); opts.minNnz overrides the LP rule.
 const DEFAULT_MIN_CELLS_LP = 8192;
+const DEFAULT_MIN_NNZ_LP = 8192;
 const DEFAULT_MIN_CELLS_INTEGER = 262144;
 const DEFAULT_MIN_CELLS_INTEGER_BATCHED = 32768;
 function minCellsFor(t, opts) {
@@ -52,10 +58,32 @@ function minCellsFor(t, opts) {
     if (nInts === 0) return DEFAULT_MIN_CELLS_LP;
     return opts.speculate > 1 ? DEFAULT_MIN_CELLS_INTEGER_BATCHED : DEFAULT_MIN_CELLS_INTEGER;
 }
+// structural non-zeros of the tableau _resetMatrix is about to build (tableau.ts:319-380): one cell per term, one per non-zero
+// right-hand side and cost; -1 when the tableau has no model to count on.  O(constraints + variables), no pass over the matrix.
+function structuralNnz(t) {
+    const m = t.model;
+    if (!m || !m.constraints || !m.variables) return -1;
+    let n = 0;
+    const cs = m.constraints;
+    for (let i = 0; i < cs.length; i++) n += cs[i].terms.length + (cs[i].rhs !== 0 ? 1 : 0);
+    const vs = m.variables;
+    for (let i = 0; i < vs.length; i++) if (vs[i].cost !== 0) n += 1;
+    return n;
+}
 function eligible(t, opts) {
     if (bypass !== 0) return false;
     const min = minCellsFor(t, opts);
-    return !(min > 0 && t.width * t.height < min);
+    if (min > 0 && t.width * t.height < min) return false;
+    // LPs: by work, not by area (MILPs keep the cell rule: their trees re-solve the same tableau hundreds of times)
+    if (opts.minCells === undefined || opts.minNnz !== undefined) {
+        const minNnz = opts.minNnz !== undefined ? opts.minNnz : DEFAULT_MIN_NNZ_LP;
+        const nInts = t.model ? t.model.getNumberOfIntegerVariables() : 0;
+        if (minNnz > 0 && nInts === 0) {
+            const nnz = structuralNnz(t);
+            if (nnz >= 0 && nnz < minNnz) return false;
+        }
+    }
+    return true;
 }
 
 // the engine of a tableau whose dimensions are known (Tableau.initialize ran); the upload follows in activate()
@@ -787,7 +815,7 @@ function usesPool() {
 
 const api = {
     loadEngine, install, sync, pivotTrace, release, guardIncremental, createCheckpoint, relaxFromCheckpoint, releaseCheckpoint,
-    relaxBatch, relaxBatchWatched, commitOutcome, commitWatched, usesPool, isOnEngine, bringHome,
+    relaxBatch, relaxBatchWatched, commitOutcome, commitWatched, usesPool, isOnEngine, bringHome, structuralNnz,
     backend: () => backend,
 };
 module.exports = api;

@@ -32,6 +32,13 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
         strategyBase[f + JSON.stringify(v)] = JSON.stringify(solver.Solve(m));
     }
 }
+// a dense LP of the reference's own generator for the size-policy check below, solved by the unpatched reference
+const denseLpGolden = (() => {
+    const gen = require(path.join(refSrc, "test-utils", "problem-generator.js"));
+    const model = gen.generateResourceAllocation({ seed: 7, numVariables: 160, numConstraints: 120, density: 0.8 });
+    const solution = solver.Solve(JSON.parse(JSON.stringify(model)), undefined, true);
+    return { model, final: { feasible: solution.feasible }, result: { result: solver.buildSimplifiedResult(solution).result } };
+})();
 // the post-solve editing API (dynamic-modification.ts through Model.updateRightHandSide / updateCost /
 // updateConstraintCoefficient / smallerThan / removeConstraint, then model.solve() again): same sequence on the unpatched
 // reference first, then under the binding, where every edit brings the tableau home and the next solve uploads it again
@@ -363,9 +370,11 @@ let policyOk = 0;
 if (!filter && dir.indexOf("fixtures") >= 0) {
     uninstall();
     uninstall = gpu.install(Tableau, { SlackVariable, solver });  // nothing but the defaults: size policy + 16-node speculative batches
-    for (const [f, expectOnEngine] of [["Knapsack_1", false], ["LargeFarmMIP", false], ["Monster_II", true], ["Monster_Problem", true]]) {
+    // (round 5: LPs go by their structural non-zeros -- Monster LP, 345 k cells but 3.4 k non-zeros, stays on the reference's own path;
+    //  a dense generated LP of 19 k cells / ~15 k non-zeros goes to the engine)
+    for (const [f, expectOnEngine] of [["Knapsack_1", false], ["LargeFarmMIP", false], ["Monster_II", true], ["Monster_Problem", false], ["@denseLP", true]]) {
         for (const extra of [{}, { useIncremental: true }]) {
-            const g = loadGolden(dir, f + ".json.gz");
+            const g = f === "@denseLP" ? denseLpGolden : loadGolden(dir, f + ".json.gz");
             const m = JSON.parse(JSON.stringify(g.model));
             m.options = Object.assign({}, m.options || {}, extra);
             delete m.options.timeout;

@@ -259,6 +259,16 @@ int jslp_engine_relax_batch_watched(jslp_engine* e, int32_t n_nodes, const int32
 int jslp_engine_relax_batch_watched_pinned(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
                                            const int32_t* var_index, const double* value, int check_cycles,
                                            jslp_simplex_result* out, const int32_t** watched_row, const double** watched_value);
+/* the compact read-back left in DEVICE memory of the caller (round 5): per node the raw state record (jslp_engine_state_record_bytes()
+ * bytes, see jslp_engine_relax_batch_device), watched_row and watched_value -- n_watched x 12 + 128 bytes per node instead of
+ * row_stride x 12 + 128.  This IS the payload of the multi-process exchange (jslpsolver_amd/sharding.py all-gathers it over RCCL: ~1.5 KB
+ * per Monster_II node instead of 11.4 KB): what every rank's copy of the tree reads between relaxations (mip-utils.ts:43-61,100-126);
+ * the full column of the one leaf the tree commits to is re-evaluated on demand (jslp_engine_relax), as the JS host's flush() does. */
+int jslp_engine_relax_batch_watched_device(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                           const int32_t* var_index, const double* value, int check_cycles, void* d_states,
+                                           int32_t* d_watched_row, double* d_watched_value);
+/* how many variables jslp_engine_set_watched_variables registered last (0: none) -- what a binding sizes the compact outputs with */
+int32_t jslp_engine_watched_count(const jslp_engine* e);
 
 /*
  * Work counters (bench.py's roofline of the relaxation path): what the calls since the last reset really had
@@ -327,6 +337,8 @@ int jslp_pool_relax_batch_watched(jslp_pool* p, int32_t n_nodes, const int32_t* 
 int jslp_pool_relax_batch_watched_pinned(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
                                          const int32_t* var_index, const double* value, int check_cycles, jslp_simplex_result* out,
                                          const int32_t** watched_row, const double** watched_value);
+/* the watched-variable count of the pool (= every member's, or -1 when they differ: set them with jslp_pool_set_watched_variables) */
+int32_t jslp_pool_watched_count(const jslp_pool* p);
 int jslp_pool_set_counting(jslp_pool* p, int enabled);
 int jslp_pool_get_counters(jslp_pool* p, jslp_work_counters* out);
 

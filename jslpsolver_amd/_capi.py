@@ -97,6 +97,8 @@ SYMBOLS = {
     "jslp_engine_relax_watched": (C.c_int, [C.c_void_p, C.c_int32, _i8p, _i32p, _f64p, C.c_int, _P(SimplexResult), _i32p, _f64p]),
     "jslp_engine_relax_batch_watched": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p, _i32p, _f64p, C.c_int, _P(SimplexResult), _i32p, _f64p]),
     "jslp_engine_relax_batch_watched_pinned": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p, _i32p, _f64p, C.c_int, _P(SimplexResult), _P(_i32p), _P(_f64p)]),
+    "jslp_engine_relax_batch_watched_device": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p, _i32p, _f64p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jslp_engine_watched_count": (C.c_int32, [C.c_void_p]),
     "jslp_engine_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
     "jslp_engine_get_counters": (C.c_int, [C.c_void_p, _P(WorkCounters)]),
     "jslp_pool_create": (C.c_int, [_P(C.c_void_p), C.c_void_p, _i32p, C.c_int32]),
@@ -112,6 +114,7 @@ SYMBOLS = {
                                                 _P(SimplexResult), _i32p, _f64p]),
     "jslp_pool_relax_batch_watched_pinned": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i8p, _i32p, _f64p, C.c_int,
                                                        _P(SimplexResult), _P(_i32p), _P(_f64p)]),
+    "jslp_pool_watched_count": (C.c_int32, [C.c_void_p]),
     "jslp_pool_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
     "jslp_pool_get_counters": (C.c_int, [C.c_void_p, _P(WorkCounters)]),
     "jslp_engine_dims": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p]),

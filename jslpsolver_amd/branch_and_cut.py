@@ -6,6 +6,7 @@ with LIFO ties (src/tableau/min-heap.ts:43-49), most-fractional branching (src/t
 (restore + addCutConstraints + simplex, branch-and-cut.ts:33-37) are ONE engine call (Tableau.applyCuts).
 """
 import math
+import os
 import time
 
 import numpy as np
@@ -102,9 +103,21 @@ def _js_round_vec(x):
     return np.where(x - f >= 0.5, f + 1.0, f)
 
 
+class _WatchedRows:
+    """the compact outcome of a node (jslp_engine_relax_batch_watched*): rowByVarIndex and the RHS cell of the model's integer
+    variables, in model.integerVariables order -- everything isIntegral / getMostFractionalVar read (mip-utils.ts:43-61, 100-126)"""
+    __slots__ = ("wrows", "wvals")
+
+    def __init__(self, wrows, wvals):
+        self.wrows, self.wvals = wrows, wvals
+
+
 def _integer_values(model, rhs, rows):
     """(variable indexes, values) of the integer variables that are basic, in model.integerVariables order"""
     idx = model.integer_index_array
+    if isinstance(rows, _WatchedRows):
+        basic = rows.wrows != -1
+        return idx[basic], np.asarray(rows.wvals, dtype=np.float64)[basic]
     r = rows.rows(idx)
     basic = r != -1
     return idx[basic], np.asarray(rhs, dtype=np.float64)[r[basic]]
@@ -168,6 +181,15 @@ class _NodeEval:
         self.res, self.rhs, self.vibr = res, rhs, vibr
 
 
+class _NodeEvalWatched:
+    """the same from a COMPACT outcome: the integer variables' rows and values only (the full column of the one leaf the tree commits
+    to is re-evaluated at the end, as host/gpu-tableau.js's flush() does)"""
+    __slots__ = ("res", "wrows", "wvals")
+
+    def __init__(self, res, wrows, wvals):
+        self.res, self.wrows, self.wvals = res, wrows, wvals
+
+
 EVAL_STATS = {"seconds": 0.0, "batches": 0, "nodes": 0}  # speculative batches since the caller last zeroed it (bench.py)
 
 
@@ -201,6 +223,9 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
     if evaluate_batch is None and tableau.width * tableau.height0 > 1536 * 1024:
         speculate = 1  # one workgroup per node only pays for small tableaus; big ones go node by node through the chip-wide kernels
     cache = {}          # heap sequence number -> _NodeEval
+    # (JSLP_TREE_COMPACT=0: whole columns per speculated node, as before round 5)
+    compact_ok = evaluate_batch is None and os.environ.get("JSLP_TREE_COMPACT", "1") != "0" and len(model.integer_index_array) > 0 and hasattr(tableau, "applyCutsBatchWatched")
+    watched_set = []
     saved = False
     last_cuts = None    # cuts of the node the sequential run evaluated last
     speculated = 0
@@ -212,6 +237,15 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
         try:
             if evaluate_batch is not None:
                 return evaluate_batch(cut_lists)
+            if compact_ok:
+                # the compact read-back (jslp_engine_relax_batch_watched): per node the integer variables' rows and values -- what the loop
+                # below reads (mip-utils.ts:43-61, 100-126) -- instead of whole RHS columns + row maps; the leaf the tree commits to is
+                # evaluated once more with the full read-back at the end (tableau.applyCuts(best_cuts))
+                if not watched_set:
+                    tableau.set_watched_variables(model.integer_index_array)
+                    watched_set.append(True)
+                results, wrows, wvals = tableau.applyCutsBatchWatched(cut_lists, check_cycles=check)
+                return [_NodeEvalWatched(results[i], wrows[i].copy(), wvals[i].copy()) for i in range(len(cut_lists))]
             results, rhs, vibr = tableau.applyCutsBatch(cut_lists, check_cycles=check)
             return [_NodeEval(results[i], rhs[i, :results[i].height].copy(), vibr[i, :results[i].height].copy())
                     for i in range(len(cut_lists))]
@@ -242,7 +276,10 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
                 speculated += len(batch)
             ev = cache.pop(seq)
             tableau._absorb(ev.res)
-            rhs, vibr = ev.rhs, ev.vibr
+            if isinstance(ev, _NodeEvalWatched):
+                rhs, vibr = None, _WatchedRows(ev.wrows, ev.wvals)
+            else:
+                rhs, vibr = ev.rhs, ev.vibr
         else:
             _res, rhs, vibr = tableau.applyCuts(cuts, check_cycles=check)
             rhs, vibr = mir_loop(tableau, model, rhs, vibr, check)  # :38-52
@@ -266,7 +303,7 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
                         break
             if worse:
                 continue
-        rows = _rows_by_var(vibr)
+        rows = vibr if isinstance(vibr, _WatchedRows) else _rows_by_var(vibr)
         if is_integral(model, rhs, rows, precision):
             found_integral = True
             if iterations == 1:

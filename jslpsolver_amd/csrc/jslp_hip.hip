@@ -8,6 +8,10 @@
 //     GPU never waits for the host inside a chunk.  Kernels launched after the solve ended exit at once.
 //   * small tableau / batch of branch-and-bound nodes -> k_simplex_wg: one workgroup runs the whole
 //     simplex() of one tableau copy ("slot"); a batch is one launch with grid = #nodes.
+// (see xl_fits below: the XCD-local kernels live in the test library; defined up here because jslp_engine_create reads it first)
+#if (defined(JSLP_CHAOS_BUILD) || defined(JSLP_DEV_XL_ONLY)) && !defined(JSLP_WITH_XL)
+#define JSLP_WITH_XL 1
+#endif
 #include "../../include/jslp_engine.h"
 #include "jslp_kernels.hip.h"
 
@@ -137,6 +141,10 @@ struct jslp_engine {
     DevState* f_st[2] = {nullptr, nullptr};
     // register-resident phase 2 (one cooperative launch): hand-off buffers
     u64_t* r_gran = nullptr;  // [2][G][8] granules then [2][G] row flags (one allocation, zeroed per launch)
+    int32_t max_uploaded_idx = -1;  // largest variable index in the row / column maps of the last upload()
+    int abort_injected = 0;  // JSLP_INJECT_RESIDENT_ABORT_US fired in this simplex() already
+    unsigned* h_abort_ptr = nullptr;  // pinned word the lean resident kernels look at every 1024 pivots (host-requested abort)
+    size_t r_slot_doubles = 0;  // doubles per candidate-row slot the arena was carved for
     u64_t* r_rows[2] = {nullptr, nullptr}; unsigned* r_sync = nullptr; int2* r_hist_all = nullptr; int r_want_hist = 0; Ctx* r_ctx_dev = nullptr;
     int no_resident = 0;
     int res_cpt = 2;  // columns per lane of the resident kernel (JSLP_RES_CPT=2|4)
@@ -436,7 +444,11 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
     if (fp && !strcmp(fp, "sp")) e->force_path = 2;
     if (fp && !strcmp(fp, "fused")) { e->force_path = 3; e->no_resident = 1; }
     if (fp && !strcmp(fp, "resident")) { e->force_path = 3; e->force_resident = 1; }
+#ifdef JSLP_WITH_XL
     if (fp && !strcmp(fp, "xl")) { e->force_path = 3; e->force_resident = 1; e->force_xl = 1; }  // the XCD-local resident geometry whatever the size (<= 1024 x 1024)
+#else
+    if (fp && !strcmp(fp, "xl")) { delete e; return fail(JSLP_ERR_UNSUPPORTED, "JSLP_FORCE_PATH=xl: the XCD-local kernels are compiled into the test library only (libjslp_hip_chaos.so, or build with -DJSLP_WITH_XL)"); }
+#endif
     // JSLP_XL=1: the XCD-local geometry for every tableau it takes.  OFF by default: as measured in round 4 (profiles/r04_xl_*) it is
     // correct on every golden but not faster than what these sizes had -- 6.4-6.8 us per pivot on dense 501 x 501 / 1001 x 1001 against
     // 6.0 chip-wide, 8.6 against 6.9 (one LDS workgroup) on the sparse Monster LP: its pivot is bound by the instruction stream of
@@ -513,7 +525,8 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
             HIPC(hipEventCreate(&e->ev_begin));
             HIPC(hipEventCreate(&e->ev_end));
         }
-        HIPC(hipStreamSynchronize(e->stream));
+        // (no synchronisation here: the two memsets above are ordered in front of everything this engine will ever enqueue -- one
+        //  stream --, and a Solve() of a mid-size LP creates an engine per call)
         // the completion flag lives behind the pinned state and travels with it through the resource pool: continue the
         // previous owner's sequence (a fresh counter would meet the old owner's numbers again)
         e->done_seq = *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e->h_state) + sizeof(DevState));
@@ -620,16 +633,20 @@ extern "C" int jslp_engine_upload(jslp_engine* e, const double* matrix, const in
     int32_t* b_vibc = b_vibr + H;
     int32_t* b_unr = b_vibc + W;
     b_vibr[0] = -1; b_vibc[0] = -1;
+    int32_t max_idx = -1;
     for (int32_t r = 1; r < H; r++) {
         const int32_t v = var_index_by_row[r];
         if (v < 0 || v >= e->n_idx) return fail(JSLP_ERR_ARG, "upload: row variable index out of range");
         b_vibr[r] = v;
+        max_idx = std::max(max_idx, v);
     }
     for (int32_t c = 1; c < W; c++) {
         const int32_t v = var_index_by_col[c];
         if (v < 0 || v >= e->n_idx) return fail(JSLP_ERR_ARG, "upload: column variable index out of range");
         b_vibc[c] = v;
+        max_idx = std::max(max_idx, v);
     }
+    e->max_uploaded_idx = max_idx;
     for (int32_t i = 0; i < n_unrestricted; i++) {
         const int32_t v = unrestricted_var_indexes[i];
         if (v < 0 || v >= e->n_idx) return fail(JSLP_ERR_ARG, "upload: unrestricted variable index out of range");
@@ -769,13 +786,24 @@ static bool fused_eligible(const jslp_engine* e) {
 // (256-lane geometries -- ONE wave per SIMD, 512 registers per lane: <256, 8, 8> compiles without a spill -- were measured and
 //  dropped: 72.5 k against 105.7 k pivots/s on a 2001 x 2001 LP, 17.4 k on 4001 x 2001, r02_z: a lone wave per SIMD does not hide
 //  its own instruction latency)
+// Round 5: the XCD-local instances are compiled into the TEST library only (-DJSLP_CHAOS_BUILD implies -DJSLP_WITH_XL; a hipcc run with
+// -DJSLP_WITH_XL builds a product-like library with them): the default policy never picked the geometry (parity with the chip-wide kernel on
+// an eighth of the chip, profiles/r04_xl_times.md), and its two instances cost the shipped library 40 s of compile time and 320 spilled
+// SGPRs of dead weight.  The shipped library ignores JSLP_XL and refuses JSLP_FORCE_PATH=xl loudly (jslp_engine_create).
 static bool xl_fits(const jslp_engine* e, int H) {
+#ifndef JSLP_WITH_XL
+    (void)e; (void)H;
+    return false;
+#else
     return (e->xl_on || e->force_xl) && e->n_unr == 0 && e->n_opt == 0 && e->ld <= 1024 && H <= JSLP_XL_MAXG * JSLP_R_MAXROWS && e->precision >= 1e-15 &&
            !(getenv("JSLP_RES_LEAN") && atoi(getenv("JSLP_RES_LEAN")) == 0);
+#endif
 }
 // variable indexes that can be live in a tableau of height H: constraints and variables are numbered first, cut slacks continue from
 // lastElementIndex = width + height - 2 (tableau.ts:312-316) -- e->n_idx is the CAPACITY (every cut row the engine has room for)
-static int live_index_bound(const jslp_engine* e, int H) { return std::min<int>(e->n_idx, e->W + H + 2); }
+// (an uploaded tableau need not follow the reference's contiguous numbering -- Model index reuse / removal, a direct C-API caller --
+//  so the largest index upload() saw in the two maps counts too: the lean kernels' LDS copy of the "unrestricted" flags is indexed with it)
+static int live_index_bound(const jslp_engine* e, int H) { return std::min<int>(e->n_idx, std::max<int>(e->W + H + 2, e->max_uploaded_idx + 1)); }
 static int resident_geometry(const jslp_engine* e, int H) {
     if (e->no_resident || e->force_path == 2 || e->precision < 1e-15) return 0;  // (see k_pivot_fused for the precision condition)
     const int rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
@@ -828,7 +856,12 @@ static int ensure_resident(jslp_engine* e, bool want_hist = false) {
     // (`want_hist`: the lean kernel's per-workgroup copies of the cycle-check history, 256 MiB -- carved only once a solve with the
     //  cycle check on takes the lean build: pool members, short-lived engines and check-off solves never pay for it)
     if (want_hist) e->r_want_hist = 1;
-    if (e->r_sync && (!e->r_want_hist || e->r_hist_all)) return JSLP_OK;
+    //  (JSLP_RES_GEOM can force a geometry WIDER than the tableau needs -- 6 or 8 columns per lane on ld <= 2048 / <= 3072 --, whose slots are
+    //   lanes x columns per lane doubles whatever ld is: with the knob set every slot is sized for the widest geometry, 4096 doubles + skew;
+    //   the knob is read per call, so an engine carved without it is carved again)
+    const size_t slot_doubles = getenv("JSLP_RES_GEOM") ? (size_t)4096 + JSLP_PUB_SKEW / 8
+                                : (e->ld <= 2048 ? (size_t)e->ld : ((size_t)e->ld + 1023) / 1024 * 1024 + JSLP_PUB_SKEW / 8);
+    if (e->r_sync && (!e->r_want_hist || e->r_hist_all) && e->r_slot_doubles >= slot_doubles) return JSLP_OK;
     if (e->r_sync) HIPC(hipStreamSynchronize(e->stream));  // re-carving: nothing in flight may still use the old layout
     // hand-off buffers and the safety-net copy of slot 0 (matrix, maps, state) carved from ONE allocation, which the
     // resource pool hands from engine to engine (hipMalloc / hipFree of these cost a small Solve more than its pivots)
@@ -837,7 +870,7 @@ static int ensure_resident(jslp_engine* e, bool want_hist = false) {
         e->r_gran = cv.take<u64_t>(JSLP_R_SYNC_WORDS);
         // (slots ld doubles apart; the 6- and 8-column geometries' permuted layout -- jslp_resident_pipe.hip.h, SLOT -- takes lanes x columns per lane
         //  = 3072 / 4096 doubles plus a skew per slot)
-        for (int i = 0; i < 2; i++) e->r_rows[i] = cv.take<u64_t>((size_t)JSLP_F_MAXG * (e->ld <= 2048 ? (size_t)e->ld : ((size_t)e->ld + 1023) / 1024 * 1024 + JSLP_PUB_SKEW / 8));
+        for (int i = 0; i < 2; i++) e->r_rows[i] = cv.take<u64_t>((size_t)JSLP_F_MAXG * slot_doubles);
         e->r_hist_all = e->r_want_hist ? cv.take<int2>((size_t)JSLP_F_MAXG * JSLP_PIPE_GHIST) : nullptr;  // every workgroup's own copy of the cycle-check history (lean kernel)
         e->r_sync = cv.take<unsigned>(16);
         e->rb_A = cv.take<double>((size_t)e->cap_rows * e->ld);
@@ -846,7 +879,8 @@ static int ensure_resident(jslp_engine* e, bool want_hist = false) {
         e->rb_rbv = cv.take<int32_t>((size_t)e->n_idx);
         e->rb_cbv = cv.take<int32_t>((size_t)e->n_idx);
         e->r_backup_st = cv.take<DevState>(1);
-        e->r_ctx_dev = cv.take<Ctx>(1);
+        e->r_ctx_dev = reinterpret_cast<Ctx*>(cv.take<char>(sizeof(Ctx) + 16));  // (+ the address of the host-abort word: JSLP_HOST_ABORT_CHECK)
+        e->r_slot_doubles = slot_doubles;
         if (!pass && e->r_arena_bytes < cv.off + 256) {
             hipFree(e->r_arena);
             e->r_arena = nullptr; e->r_arena_bytes = 0; e->r_sync = nullptr;
@@ -1001,6 +1035,7 @@ static void account(jslp_engine* e, const DevState& st, int is_relaxation) {
 static int run_simplex(jslp_engine* e, int check_cycles) {
     hipStream_t s = e->stream;
     e->slot0_synced = 0;  // the chip-wide kernels do not maintain the dirty-row flags (k_begin zeroes st.gen)
+    e->abort_injected = 0;
     const int cap = iters_cap(e);
     HIPC(hipEventRecord(e->ev_begin, s));
     if (use_wg_single(e)) {
@@ -1057,6 +1092,12 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             rc.census = e->r_gran + JSLP_R_SYNC_WORDS - JSLP_F_MAXG;
             rc.cdev = e->r_ctx_dev;
             HIPC(hipMemcpyAsync(e->r_ctx_dev, &rc.c, sizeof(Ctx), hipMemcpyHostToDevice, s));  // (200 bytes; the kernel's one committing thread reads the map / trace pointers from it)
+            {   // the host-abort word (pinned, behind the state and the retry counter) and its address behind the device copy of the context
+                unsigned* const h_abort = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e->h_state) + sizeof(DevState) + 16);
+                *h_abort = 0u;
+                e->h_abort_ptr = h_abort;
+                HIPC(hipMemcpyAsync(reinterpret_cast<char*>(e->r_ctx_dev) + sizeof(Ctx), &e->h_abort_ptr, sizeof(unsigned*), hipMemcpyHostToDevice, s));
+            }
             rc.rpb = geometry == 6 ? (H + JSLP_XL_MAXG - 1) / JSLP_XL_MAXG : (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
             if (const char* rx = getenv("JSLP_RES_RPB"); rx && geometry != 6) {  // experiments: more rows per workgroup = fewer workgroups (<= the geometry's rows)
                 static const int rows_of[6] = {0, 8, 8, 16, 12, 8};
@@ -1145,17 +1186,30 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                     break;
                 case 4: JSLP_RES_LAUNCH_LEAN_ONLY(512, 6, 12); break;
                 case 5: JSLP_RES_LAUNCH_LEAN_ONLY(512, 8, 8); break;
+#ifdef JSLP_WITH_XL
                 case 6:  // XCD-local: every JSLP_XL_SPREAD-th block of the grid works (all of them on one XCD), the others return at once
                     if (!lean) break;  // (a hand-over the general build cannot take at this geometry: the streaming kernels continue)
                     le = check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 2, 32, false, true, false, true, true>, dim3(JSLP_XL_SPREAD * rc.G), dim3(512), args, 0, s)
                                       : hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 2, 32, false, true, false, false, true>, dim3(JSLP_XL_SPREAD * rc.G), dim3(512), args, 0, s);
                     break;
+#endif
             }
 #endif
 #undef JSLP_RES_LAUNCH
 #undef JSLP_RES_LAUNCH_LEAN
 #undef JSLP_RES_LAUNCH_LEAN_ONLY
             if (le == hipSuccess) e->resident_launches += 1;
+            if (le == hipSuccess && lean) {
+                // JSLP_INJECT_RESIDENT_ABORT_US=<n>: raise the host-abort word n microseconds into the launch -- the rollback path (kernel gives
+                // up mid-solve, slot 0 restored from the safety-net copy, the solve re-run through the streaming kernels) exercised on the
+                // library users load, whose kernels have no test hooks.  Read per launch (tests set it inside one process); once per solve.
+                const char* inj = getenv("JSLP_INJECT_RESIDENT_ABORT_US");
+                if (inj && atoi(inj) >= 0 && !e->abort_injected) {
+                    e->abort_injected = 1;
+                    std::this_thread::sleep_for(std::chrono::microseconds(atoi(inj)));
+                    __atomic_store_n(e->h_abort_ptr, 1u, __ATOMIC_RELEASE);
+                }
+            }
             if (le == hipSuccess && lean) {  // did the lean kernel finish the solve?
                 unsigned* const h_retries = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e->h_state) + sizeof(DevState) + 8);
                 HIPC(hipMemcpyAsync(e->h_state, e->s.st, sizeof(DevState), hipMemcpyDeviceToHost, s));
@@ -2257,6 +2311,19 @@ extern "C" int jslp_engine_relax_batch_watched_pinned(jslp_engine* e, int32_t n_
 }
 
 // ---- work counters ---------------------------------------------------------------------------------------------------
+// the compact read-back left in the caller's DEVICE memory: the exchange payload of the multi-process path (sharding.py)
+extern "C" int jslp_engine_relax_batch_watched_device(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                                      const int32_t* var_index, const double* value, int check_cycles, void* d_states,
+                                                      int32_t* d_watched_row, double* d_watched_value) {
+    if (!e || !d_states || !d_watched_row || !d_watched_value) return fail(JSLP_ERR_ARG, "relax_batch_watched_device: null pointer");
+    e->dev_states = static_cast<DevState*>(d_states); e->dev_rhs = d_watched_value; e->dev_rows = d_watched_row; e->dev_stride = e->n_watch;
+    const int rc = relax_batch_impl(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, nullptr, nullptr, nullptr, 0, 1, 1, 1, -1, 1);
+    e->dev_states = nullptr; e->dev_rhs = nullptr; e->dev_rows = nullptr; e->dev_stride = 0;
+    return rc;
+}
+
+extern "C" int32_t jslp_engine_watched_count(const jslp_engine* e) { return e ? e->n_watch : 0; }
+
 extern "C" int jslp_engine_set_counting(jslp_engine* e, int enabled) {
     if (!e) return fail(JSLP_ERR_ARG, "set_counting: null engine");
     HIPC(hipSetDevice(e->device));
@@ -2464,6 +2531,7 @@ static int pool_adopt_root(jslp_engine* m, const jslp_engine* src, int s_H, int 
     m->s.has_unr = src->n_unr > 0 ? 1 : 0;
     m->evaluation = src->evaluation;
     m->nnz = src->nnz;
+    m->max_uploaded_idx = src->max_uploaded_idx;
     m->slot0_synced = 0;
     m->slots_synced = 0;
     drop_checkpoints(m, 0);
@@ -2630,6 +2698,14 @@ extern "C" int jslp_pool_relax_batch_watched_pinned(jslp_pool* p, int32_t n_node
     if (watched_row)
         *watched_row = n_nodes > 0 ? reinterpret_cast<const int32_t*>(p->h_out + (size_t)n_nodes * (sizeof(DevState) + nw * 8)) : nullptr;
     return JSLP_OK;
+}
+
+extern "C" int32_t jslp_pool_watched_count(const jslp_pool* p) {
+    if (!p || p->members.empty()) return 0;
+    const int32_t n = p->members[0]->n_watch;
+    for (const jslp_engine* m : p->members)
+        if (m->n_watch != n) return -1;
+    return n;
 }
 
 extern "C" int jslp_pool_set_counting(jslp_pool* p, int enabled) {

@@ -105,7 +105,9 @@
 // the workgroup -- a different one per pivot and boundary -- sleeps ~6 k cycles (JSLP_TEST_RESIDENT_LATE_WAVE0=2), and with =3 every
 // fifth workgroup sleeps ~4 k more: whatever in these loops relies on waves or workgroups arriving together shows up as lost pivots.
 // (=2 exactly also makes wave 0 of every publishing workgroup raise its flag word ~8 k cycles BEFORE it stores its columns of the
-//  candidate row -- the litmus of the checksummed hand-over, JSLP_PUBLISH_ROW_PLAIN; odd values make wave 0 late at every row fetch)
+//  candidate row -- the litmus of the checksummed hand-over, JSLP_PUBLISH_ROW_PLAIN; odd values make wave 0 late at every row fetch;
+//  =4 / =6: the TORN row -- wave 0's even / odd lanes store their pairs, the flag word goes up, the other lanes store ~8 k cycles later:
+//  a reader's first looks find a row that is half this epoch's and half the one two epochs back, which only the checksum can tell)
 #ifdef JSLP_CHAOS_BUILD
 #undef RT_MARK
 #define RT_MARK(p)                                                                                                        \
@@ -161,6 +163,31 @@
 #define JSLP_PUB_SKEW 256     // bytes added to a workgroup's slot of the candidate-row buffer (see SLOT)
 #define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
 #define JSLP_PIPE_KCHUNK 8    // pivot-column entries the update pass keeps in flight (registers: the tall / wide geometries have few to spare)
+
+// A HOST-requested abort, in the SHIPPED build (the test hooks above exist in the test library only).  Every JSLP_HOST_ABORT_PERIOD-th pivot,
+// the first polling wave of the LAST workgroup -- in the RETRY path of its look at the summaries, which a healthy pivot passes through
+// anyway (the summaries take 2-4 k cycles to arrive, the first look leaves right behind the row update) -- looks at one word of pinned host
+// memory (its address sits behind the device copy of the context: no kernel argument).  When the host has raised it, the wave raises the
+// device-wide abort flag and reports the gather as failed: its workgroup leaves through the exit every timed-out gather takes, everybody
+// else meets its silence in the next gather, sees the flag after 64 polls and leaves too -- the epilogue is skipped, the host rolls slot 0
+// back and solves through the streaming kernels (run_simplex).  Raised by the engine itself JSLP_INJECT_RESIDENT_ABORT_US microseconds
+// after the launch (tests/test_pool_and_extras.py: the rollback path of the library users load).
+// (First form, measured r05_a: a check at the top of the pivot loop with a workgroup barrier around the word -- one scalar branch per pivot,
+//  taken once in 1024 -- cost config 3a 169.5 k -> 153.1 k pivots/s and phase 1 157 k -> 134 k: the extra exit changed the loop's register
+//  allocation, 90 -> 107 VGPRs.  In the retry path the fast path's code is the round-4 code.)
+#define JSLP_HOST_ABORT_PERIOD 1024u
+#ifndef JSLP_HOST_ABORT
+#define JSLP_HOST_ABORT 1
+#endif
+#define JSLP_HOST_ABORT_IN_SPIN(SPINS, SWEPT)                                                                                     \
+    if (JSLP_HOST_ABORT && (SPINS) == 1u && (epoch & (JSLP_HOST_ABORT_PERIOD - 1u)) == JSLP_HOST_ABORT_PERIOD - 1u && b == f.G - 1 && wv == 0) { \
+        const unsigned* ha_ = *reinterpret_cast<const unsigned* const*>(reinterpret_cast<const char*>(f.cdev) + sizeof(Ctx));     \
+        if (ha_ != nullptr && __hip_atomic_load(ha_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { /* (one address: uniform) */ \
+            if (lane == 0) AG_STORE(f.abort_flag, 1u);                                                                            \
+            (SWEPT) = false;                                                                                                      \
+            break;                                                                                                                \
+        }                                                                                                                         \
+    }
 
 __device__ __forceinline__ double readlane_f64(double x, int src_lane) {  // src_lane must be wave-uniform
     const long long b = __double_as_longlong(x);
@@ -350,8 +377,12 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
     do {                                                                                                                          \
         const int ipub_ = __builtin_amdgcn_readfirstlane((ROW) - r_begin);                                                        \
         /* (tests, JSLP_TEST_RESIDENT_LATE_WAVE0=2: wave 0 raises its flag word ~8 k cycles BEFORE it stores its part of the row -- \
-           the order the fabric is allowed to produce; the readers' checksum must send them round again) */                       \
+           the order the fabric is allowed to produce; the readers' checksum must send them round again.  =4 / =6: a TORN row --    \
+           the even (=4) / odd (=6) lanes of wave 0 store their pairs, the word goes up, and only ~8 k cycles later the other      \
+           lanes store theirs: every reader's first looks find half of the wave's 1 KB new and half two epochs old) */             \
         const bool flag_first_ = CKS && __builtin_amdgcn_readfirstlane((int)(F_TEST_LATE == 2 && wv == 0)) != 0;                  \
+        const bool torn_ = CKS && __builtin_amdgcn_readfirstlane((int)((F_TEST_LATE == 4 || F_TEST_LATE == 6) && wv == 0)) != 0;  \
+        const bool early_lane_ = !torn_ || ((lane & 1) == (F_TEST_LATE == 6 ? 1 : 0));                                            \
         u64_t ck_ = 0;                                                                                                            \
         if (colok) {                                                                                                              \
             _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                      \
@@ -362,15 +393,15 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
                         const u64_t lo_ = (u64_t)__double_as_longlong(a[i][j]), hi_ = (u64_t)__double_as_longlong(a[i][j + 1]);  \
                         v4u_t v_;                                                                                                 \
                         v_.x = (unsigned)lo_; v_.y = (unsigned)(lo_ >> 32); v_.z = (unsigned)hi_; v_.w = (unsigned)(hi_ >> 32);   \
-                        if (!flag_first_) __builtin_amdgcn_raw_buffer_store_b128(v_, rsrc_rows, off_ + (j >> 1) * PAIR_STEP, 0, ST_AUX); \
+                        if (!flag_first_ && early_lane_) __builtin_amdgcn_raw_buffer_store_b128(v_, rsrc_rows, off_ + (j >> 1) * PAIR_STEP, 0, ST_AUX); \
                         if (CKS) JSLP_CK_PAIR(ck_, lo_, hi_, j);                                              \
                     }                                                                                                             \
                 }                                                                                                                 \
         }                                                                                                                         \
         if (CKS) JSLP_CKS_RAISE_FLAG(ck_);                                                                                        \
-        if (flag_first_) {                                                                                                        \
+        if (flag_first_ || torn_) {                                                                                               \
             __builtin_amdgcn_s_sleep(127);                                                                                        \
-            if (colok) {                                                                                                          \
+            if (colok && (flag_first_ || !early_lane_)) {                                                                         \
                 _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                  \
                     if (i == JSLP_OPAQUE_SGPR(ipub_)) {                                                                           \
                         const int off_ = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;    \
@@ -701,6 +732,10 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             }
         } else {
         u64_t ck = 0;
+        // (tests: the same hooks as JSLP_PUBLISH_ROW_PLAIN -- flag word first (=2), torn row (=4 / =6) -- for the builds that publish from inside this pass)
+        const bool flag_first_o = CKS && __builtin_amdgcn_readfirstlane((int)(F_TEST_LATE == 2 && wv == 0)) != 0;
+        const bool torn_o = CKS && __builtin_amdgcn_readfirstlane((int)((F_TEST_LATE == 4 || F_TEST_LATE == 6) && wv == 0)) != 0;
+        const bool early_lane_o = !torn_o || ((lane & 1) == (F_TEST_LATE == 6 ? 1 : 0));
 #pragma unroll
         for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
             double kis[ROWS];
@@ -717,13 +752,32 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                         const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
                         v4u_t v;
                         v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + (j >> 1) * PAIR_STEP, 0, ST_AUX);
+                        if (!flag_first_o && early_lane_o) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + (j >> 1) * PAIR_STEP, 0, ST_AUX);
                         if (CKS) JSLP_CK_PAIR(ck, lo, hi, j);
                     }
                 }
             }
         }
         if (CKS && pubrow != 0) JSLP_CKS_RAISE_FLAG(ck);
+        if (CKS && pubrow != 0 && (flag_first_o || torn_o)) {  // (tests only) what the hook held back leaves now, behind the flag word
+            __builtin_amdgcn_s_sleep(127);
+            const int ipub_o = __builtin_amdgcn_readfirstlane(pubrow - r_begin);
+            if (colok && (flag_first_o || !early_lane_o)) {
+#pragma unroll
+                for (int i = 0; i < ROWS; i++)
+                    if (i == JSLP_OPAQUE_SGPR(ipub_o)) {
+                        const int off = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;
+#pragma unroll
+                        for (int j = 0; j < CPT; j += 2) {
+                            if (c0 + j >= ld) continue;
+                            const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
+                            v4u_t v;
+                            v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + (j >> 1) * PAIR_STEP, 0, ST_AUX);
+                        }
+                    }
+            }
+        }
         }
         pend = false;
         RT_MARK(2);
@@ -745,6 +799,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
+                JSLP_HOST_ABORT_IN_SPIN(spins, swept);
                 if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { swept = false; break; }
                 if (spins > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
             }
@@ -1192,6 +1247,10 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             }
         } else {
         u64_t ck = 0;
+        // (tests: the same hooks as JSLP_PUBLISH_ROW_PLAIN -- flag word first (=2), torn row (=4 / =6) -- for the builds that publish from inside this pass)
+        const bool flag_first_o = CKS && __builtin_amdgcn_readfirstlane((int)(F_TEST_LATE == 2 && wv == 0)) != 0;
+        const bool torn_o = CKS && __builtin_amdgcn_readfirstlane((int)((F_TEST_LATE == 4 || F_TEST_LATE == 6) && wv == 0)) != 0;
+        const bool early_lane_o = !torn_o || ((lane & 1) == (F_TEST_LATE == 6 ? 1 : 0));
 #pragma unroll
         for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
             double kis[ROWS];
@@ -1208,13 +1267,32 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                         const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
                         v4u_t v;
                         v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + (j >> 1) * PAIR_STEP, 0, ST_AUX);
+                        if (!flag_first_o && early_lane_o) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + (j >> 1) * PAIR_STEP, 0, ST_AUX);
                         if (CKS) JSLP_CK_PAIR(ck, lo, hi, j);
                     }
                 }
             }
         }
         if (CKS && pubrow != 0) JSLP_CKS_RAISE_FLAG(ck);
+        if (CKS && pubrow != 0 && (flag_first_o || torn_o)) {  // (tests only) what the hook held back leaves now, behind the flag word
+            __builtin_amdgcn_s_sleep(127);
+            const int ipub_o = __builtin_amdgcn_readfirstlane(pubrow - r_begin);
+            if (colok && (flag_first_o || !early_lane_o)) {
+#pragma unroll
+                for (int i = 0; i < ROWS; i++)
+                    if (i == JSLP_OPAQUE_SGPR(ipub_o)) {
+                        const int off = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;
+#pragma unroll
+                        for (int j = 0; j < CPT; j += 2) {
+                            if (c0 + j >= ld) continue;
+                            const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
+                            v4u_t v;
+                            v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + (j >> 1) * PAIR_STEP, 0, ST_AUX);
+                        }
+                    }
+            }
+        }
         }
         pend = false;
         RT_MARK(2);
@@ -1227,6 +1305,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
+                JSLP_HOST_ABORT_IN_SPIN(spins, swept);
                 if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { swept = false; break; }
                 if (spins > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
             }

@@ -221,6 +221,41 @@ __device__ __forceinline__ void wglds_update_row(const Ctx& c, const WgLds& L, i
     }
 }
 
+// The same for a work item whose column pairs were loaded BEFORE the pivot row was known (round 5, the 1024-thread latency shapes:
+// the loads of a pivot's first gated rows leave together with the pivot row's own loads, so a pivot is two dependent global trips --
+// pivot column, then pivot row + gated rows -- instead of three).  `a` holds every pair of the pass (the live test needs the
+// normalised pivot row, which did not exist when the loads left); what the reference's gate excludes is simply not written back.
+template <int UN>
+__device__ __forceinline__ void wglds_update_row_preloaded(const Ctx& c, const WgLds& L, int r, double k, int pc, double quot, int lane, bool first,
+                                                           int col_begin, const double2 (&a)[UN]) {
+    const int ld = c.ld;
+    double* row = c.A + (long long)r * ld;
+    const int base = col_begin + lane * 2;
+#pragma unroll
+    for (int j = 0; j < UN; j++) {
+        const int c0 = base + 128 * j;
+        if (c0 >= ld) continue;
+        const double2 p = *reinterpret_cast<const double2*>(L.prow + c0);
+        if (!(first || nonzero16(p.x) || nonzero16(p.y) || pc == c0 || pc == c0 + 1)) continue;
+        double2 x = a[j];
+        if (nonzero16(p.x)) x.x = eliminate(x.x, k, p.x);
+        if (nonzero16(p.y)) x.y = eliminate(x.y, k, p.y);
+        if (pc == c0 || pc == c0 + 1) {
+            const double nv = -k / quot;
+            if (pc == c0) x.x = nv; else x.y = nv;
+        }
+        *reinterpret_cast<double2*>(row + c0) = x;
+        if (c0 == 0) L.rhs[r] = x.x;
+        if (r == 0) *reinterpret_cast<double2*>(L.r0 + c0) = x;
+    }
+}
+
+#ifndef WGL_PREFETCH
+#define WGL_PREFETCH 1  // 1024-thread builds: every wave's FIRST row-update work item is loaded next to the pivot row (see wglds_update_row_preloaded)
+#endif
+#ifndef WGL_UN1024
+#define WGL_UN1024 (WGL_PREFETCH ? 4 : 8)  // ... of the 1024-thread kernels: 8 = a whole Monster_II row per item (one trip per row); with the prefetch, 4: sixteen waves hold the first 8 rows x 2 passes in 16 registers each
+#endif
 #ifndef WGL_UN512
 #define WGL_UN512 4  // column pairs per lane in flight in one row-update work item of the 512-thread kernels (1024 columns per item)
 #endif
@@ -228,7 +263,8 @@ __device__ __forceinline__ void wglds_update_row(const Ctx& c, const WgLds& L, i
 
 // OPT: the model has optional objectives (their rows stay in the slot's global copy); a build of its own so that the kernels of
 // every other model keep their register budget (the extra live values cost the 512-thread queue kernel 10 more VGPR spills)
-template <int UN, bool OPT = false>
+// PF (round 5, the 1024-thread latency shapes): every wave's first row-update work item is loaded next to the pivot row
+template <int UN, bool OPT = false, bool PF = false>
 __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iters_cap) {
     WL_BEGIN(c.cnt);
     DevState* st = c.st;
@@ -485,6 +521,27 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
         WL_MARK(7);
         const int n = sm.n_list;
         const bool anyrow = n > 0;
+        // ---- round 5: my wave's first row-update work item leaves NOW, next to the pivot row's loads (issued above): by the time the
+        //      normalised pivot row is in LDS the gated rows are in registers too.  Every column pair of the pass is loaded (which ones are
+        //      live is only known with the pivot row); the rows are not written by anybody before the update pass below reads them.
+        constexpr bool PREFETCH = WGL_PREFETCH != 0 && PF;
+        const int passes_pf = (ld + 128 * UN - 1) / (128 * UN);
+        double2 pf[UN];
+        int pf_r = -1, pf_col0 = 0;
+        bool pf_first = false;
+        if (PREFETCH && w < n * passes_pf) {
+            const int i = w / passes_pf, ps = w - i * passes_pf;
+            const int entry = L.list[i];
+            pf_r = entry & 0x3fffffff;
+            pf_first = (entry & 0x40000000) != 0;
+            pf_col0 = ps * 128 * UN;
+            const double* src = (pf_first ? rootA : A) + (long long)pf_r * ld;
+#pragma unroll
+            for (int j = 0; j < UN; j++) {
+                const int c0 = pf_col0 + lane * 2 + 128 * j;
+                pf[j] = c0 < ld ? *reinterpret_cast<const double2*>(src + c0) : make_double2(0.0, 0.0);
+            }
+        }
         // ---- pivot row (simplex.ts:352-364) from the registers (or from memory when the row is wider than they hold) -----------
         const double quot = L.pcol[pr];  // = A[pr, pc] (:335)
         double* prow_A = A + (long long)pr * ld;
@@ -574,7 +631,12 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
             // 93 k with 512-column items (this), 133 k with 256-column items (5 rounds); UN = 8 (one trip per row) does not fit the
             // 80-VGPR budget of the batch shape (224 bytes of scratch) and that build lost pivots -- not used
             const int passes = (ld + 128 * UN - 1) / (128 * UN);
-            for (int it = w; it < n * passes; it += nw) {
+            int it = w;
+            if (PREFETCH && pf_r >= 0) {  // the item loaded ahead (same item `w`: same row, same pass)
+                wglds_update_row_preloaded<UN>(c, L, pf_r, L.pcol[pf_r], pc, quot, lane, pf_first, pf_col0, pf);
+                it += nw;
+            }
+            for (; it < n * passes; it += nw) {
                 const int i = it / passes, ps = it - i * passes;
                 const int entry = L.list[i], r = entry & 0x3fffffff;
                 wglds_update_row<UN>(c, L, r, L.pcol[r], pc, quot, lane, (entry & 0x40000000) != 0, rootA + (long long)r * ld, ps * 128 * UN);
@@ -700,7 +762,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_lds(Slots s, int first_slot
     __shared__ SmemL sm;
     const Ctx c = slot_ctx(s, first_slot + blockIdx.x, check_cycles);
     const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
-    simplex_wg_lds<(THREADS >= 1024 ? 8 : WGL_UN512), OPT>(c, sm, L, iters_cap);
+    simplex_wg_lds<(THREADS >= 1024 ? WGL_UN1024 : WGL_UN512), OPT, (THREADS >= 1024)>(c, sm, L, iters_cap);
 }
 
 // The LDS twin of k_node_wg: ONE branch-and-bound child per workgroup in ONE launch -- restore of the rows the previous node
@@ -878,7 +940,7 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
         Ln.err_hint = cut_err;
         Ln.H_hint = cut_err == (int)ERR_NONE ? H + (cuts.offs[node + 1] - cuts.offs[node]) : H;
     }
-    simplex_wg_lds<(THREADS >= 1024 ? 8 : WGL_UN512), OPT>(c, sm, Ln, iters_cap);
+    simplex_wg_lds<(THREADS >= 1024 ? WGL_UN1024 : WGL_UN512), OPT, (THREADS >= 1024)>(c, sm, Ln, iters_cap);
 #ifdef JSLP_DEBUG_WGLDS
     wl_prev = __builtin_amdgcn_s_memtime();
 #endif

@@ -181,6 +181,19 @@ class Tableau:
             _capi.C.c_void_p(states_ptr), _capi.C.c_void_p(rhs_ptr), _capi.C.c_void_p(rows_ptr), int(row_stride)),
             "jslp_engine_relax_batch_device")
 
+    def applyCutsBatchWatchedDevice(self, packed, check_cycles, states_ptr, rows_ptr, values_ptr):
+        """jslp_engine_relax_batch_watched_device: the COMPACT outcome (state record + row / RHS cell of the watched variables per node)
+        left in memory of the engine's device -- the exchange payload of the multi-process path (sharding.py)"""
+        n_nodes, offs, t, v, x = packed
+        self.lib.check(self.lib.jslp_engine_relax_batch_watched_device(
+            self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)),
+            _capi.C.c_void_p(states_ptr), _capi.C.c_void_p(rows_ptr), _capi.C.c_void_p(values_ptr)),
+            "jslp_engine_relax_batch_watched_device")
+
+    def watched_count(self):
+        """how many variables set_watched_variables registered on the engine (jslp_engine_watched_count)"""
+        return int(self.lib.jslp_engine_watched_count(self._h))
+
     def results_from_states(self, states_u8, n_nodes):
         """raw state records (host bytes: this rank's or, after the exchange, another rank's) -> SimplexResult array"""
         out = (SimplexResult * max(n_nodes, 1))()
@@ -391,6 +404,7 @@ class DevicePool:
         self._p = _capi.C.c_void_p()
         self.lib.check(self.lib.jslp_pool_create(_capi.C.byref(self._p), tableau._h, _capi.ptr_i32(d), int(d.shape[0])),
                        "jslp_pool_create")
+        self.n_watched = 0  # (informational: the outputs are sized with jslp_pool_watched_count)
 
     def close(self):
         if getattr(self, "_p", None) is not None and self._p.value:
@@ -448,7 +462,13 @@ class DevicePool:
         t = self.t
         n_nodes, offs, ty, v, x = packed if packed is not None else t.pack_cut_lists(cut_lists)
         out = (SimplexResult * max(n_nodes, 1))()
-        shape = (max(n_nodes, 1), self.n_watched)
+        # (the outputs are sized by what the LIBRARY will write -- jslp_pool_watched_count -- not by a Python-side shadow
+        #  that a direct set_watched_variables on the primary engine would leave behind)
+        n_watched = int(self.lib.jslp_pool_watched_count(self._p))
+        if n_watched <= 0:
+            raise _capi.EngineError("DevicePool.applyCutsBatchWatched: %s" % ("call set_watched_variables first" if n_watched == 0 else
+                                    "the members' watched variables differ (set them through DevicePool.set_watched_variables)"))
+        shape = (max(n_nodes, 1), n_watched)
         if not copy:
             p_rows = _capi._i32p()
             p_vals = _capi._f64p()

@@ -4,9 +4,12 @@ One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the M
 A node's relaxation is a pure function of (saved root tableau, cut list) (branch-and-cut.ts:33-37 always restores the
 root), so the unit of sharding is the node: every rank owns an engine holding the SAME saved root and evaluates nodes
 rank, rank + world, ... of a batch with one engine call.  The one exchange step is the all-gather of the outcomes --
-per node the result struct (flags, evaluation = the bound the tree prunes with, pivot counts), the RHS column and the
-row map, ~12 bytes per row -- after which every rank holds every outcome and replays the same deterministic tree
-(speculation with in-order commit), so the incumbent is agreed on without a further broadcast.
+per node the state record (flags, evaluation = the bound the tree prunes with, pivot counts) and, round 5, only what the
+tree reads between relaxations: the row and the RHS cell of every integer variable (mip-utils.ts:43-61, 100-126; 12 bytes
+per integer variable -- `evaluate_nodes_sharded_watched`; the whole RHS column + row map, ~12 bytes per ROW, remain
+available: `evaluate_nodes_sharded`) -- after which every rank holds every outcome and replays the same deterministic
+tree (speculation with in-order commit), so the incumbent is agreed on without a further broadcast; the full column of the
+leaf the tree commits to is re-evaluated locally at the end.
 
 (Inside ONE process the same split over several GPUs is the engine's own device pool, jslp_pool_* in
 include/jslp_engine.h: host threads and peer copies instead of ranks and collectives.)
@@ -192,6 +195,88 @@ def evaluate_nodes_sharded_device(tableau, cut_lists, check_cycles, group, packe
     return ShardedOutcomesDevice(blocks, n, world, per, stride, rec, tableau)
 
 
+class ShardedOutcomesWatched:
+    """every node's COMPACT outcome after the all-gather of the device-resident payloads: rank r's block is one byte vector
+    [per state records | per x w int32 rows | per x w doubles], node i sits in rank (i % world)'s block at slot i // world; w = the watched
+    (integer) variables.  What the tree reads between relaxations and nothing else: 128 + 12 w bytes per node (Monster_II: 1.5 KB instead
+    of the 11.4 KB of the full RHS column + row map)."""
+
+    def __init__(self, blocks, n, world, per, w, rec, tableau):
+        self.blocks, self.n, self.world, self.per, self.w, self.rec = blocks, n, world, per, w, rec  # blocks: [world, block_bytes] uint8
+        self.o_rows = _align(per * rec)
+        self.o_vals = _align(self.o_rows + per * w * 4)
+        self.results = []
+        for r in range(world):
+            k = len(range(r, n, world))
+            self.results.append(tableau.results_from_states(blocks[r, :k * rec], k) if k else None)
+
+    def __len__(self):
+        return self.n
+
+    def result(self, i):
+        return self.results[i % self.world][i // self.world]
+
+    def watched_rows(self, i):
+        o = self.o_rows + (i // self.world) * self.w * 4
+        return self.blocks[i % self.world, o:o + 4 * self.w].view(np.int32)
+
+    def watched_values(self, i):
+        o = self.o_vals + (i // self.world) * self.w * 8
+        return self.blocks[i % self.world, o:o + 8 * self.w].view(np.float64)
+
+    def node(self, i):
+        from .branch_and_cut import _NodeEvalWatched
+        return _NodeEvalWatched(self.result(i), self.watched_rows(i).copy(), self.watched_values(i).copy())
+
+    def heights(self):
+        return np.array([self.result(i).height for i in range(self.n)], dtype=np.int32)
+
+
+def watched_block_bytes(per, w, rec):
+    """bytes one rank contributes to the compact exchange for `per` nodes and `w` watched variables"""
+    return _align(_align(_align(per * rec) + per * w * 4) + per * w * 8)
+
+
+def evaluate_nodes_sharded_watched(tableau, cut_lists, check_cycles, group, packed_mine=None):
+    """The compact exchange: the engine leaves, per node, the state record and the row / RHS cell of the watched
+    variables in a device tensor (jslp_engine_relax_batch_watched_device) that IS the all-gather's input.  The tableau's watched
+    variables must have been set (Tableau.set_watched_variables(model.integer_index_array)) -- identically on every rank."""
+    import time
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = len(cut_lists)
+    w = tableau.watched_count()
+    if w <= 0:
+        raise ValueError("evaluate_nodes_sharded_watched: Tableau.set_watched_variables first")
+    rec = tableau.state_record_bytes()
+    per = max((n + world - 1) // world, 1)
+    o_rows = _align(per * rec)
+    o_vals = _align(o_rows + per * w * 4)
+    block = _align(o_vals + per * w * 8)
+    on_gpu = tableau.lib.backend.startswith("hip")
+    local = torch.zeros(block, dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+    if on_gpu:
+        torch.cuda.current_stream().synchronize()  # the fill runs on torch's stream, the engine's kernels on the engine's own
+    n_mine = len(range(rank, n, world))
+    if n_mine:
+        packed = packed_mine if packed_mine is not None else tableau.pack_cut_lists(shard(cut_lists, rank, world))
+        base = local.data_ptr()
+        tableau.applyCutsBatchWatchedDevice(packed, check_cycles, base, base + o_rows, base + o_vals)
+    t0 = time.perf_counter()
+    if on_gpu and dist.get_backend(group) != "nccl":  # HIP engines under a CPU process group (N virtual shards on one GPU)
+        local = local.cpu()
+    out = torch.empty((world, block), dtype=torch.uint8, device=local.device)
+    dist.all_gather_into_tensor(out.view(-1), local, group=group)
+    blocks = out.cpu().numpy() if out.is_cuda else out.numpy()
+    EXCHANGE_STATS["seconds"] += time.perf_counter() - t0
+    EXCHANGE_STATS["calls"] += 1
+    EXCHANGE_STATS["bytes"] += int(block)
+    return ShardedOutcomesWatched(blocks, n, world, per, w, rec, tableau)
+
+
 def evaluate_nodes_sharded(tableau, cut_lists, check_cycles, group, packed_mine=None):
     """Every rank calls this with the same `cut_lists`; returns the outcomes of ALL nodes on every rank
     (ShardedOutcomes).  `packed_mine`: this rank's share already flattened by Tableau.pack_cut_lists."""
@@ -218,7 +303,19 @@ def evaluate_nodes_sharded(tableau, cut_lists, check_cycles, group, packed_mine=
     return ShardedOutcomes(blocks, n, world, stride)
 
 
-def make_sharded_evaluator(tableau, check_cycles, group):
+def make_sharded_evaluator(tableau, check_cycles, group, watched=None):
+    """evaluate(cut_lists) for branch_and_cut(evaluate_batch=...).  `watched` = the variable indexes the tree reads between
+    relaxations (the model's integer variables): the COMPACT exchange -- registered on the engine here, once (every rank passes the
+    same list); None = whole RHS columns + row maps (JSLP_SHARD_COMPACT=0 forces that form)."""
+    import os
+    if watched is not None and os.environ.get("JSLP_SHARD_COMPACT", "1") != "0" and len(watched) > 0:
+        tableau.set_watched_variables(watched)
+
+        def evaluate_compact(cut_lists):
+            out = evaluate_nodes_sharded_watched(tableau, cut_lists, check_cycles, group)
+            return [out.node(i) for i in range(len(out))]
+        return evaluate_compact
+
     def evaluate(cut_lists):
         out = evaluate_nodes_sharded(tableau, cut_lists, check_cycles, group)
         return [out.node(i) for i in range(len(out))]  # a speculative batch: a handful of nodes

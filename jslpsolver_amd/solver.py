@@ -80,7 +80,7 @@ def _solve_on(t, m, n_int, incremental, speculate, group, full):
         evaluate = None
         if group is not None:
             from .sharding import make_sharded_evaluator
-            evaluate = make_sharded_evaluator(t, m.checkForCycles, group)
+            evaluate = make_sharded_evaluator(t, m.checkForCycles, group, watched=m.integer_index_array)
         if incremental:  # selectBranchAndCutService (main.ts:62-72)
             from .incremental_branch_and_cut import incremental_branch_and_cut
             iterations, integral = incremental_branch_and_cut(

@@ -990,6 +990,16 @@ int jslp_engine_relax_batch_watched_pinned(jslp_engine* e, int32_t n_nodes, cons
     return JSLP_OK;
 }
 
+/* the compact read-back in "device" memory (host memory here; the raw state record is the result struct, see relax_batch_device) */
+int jslp_engine_relax_batch_watched_device(jslp_engine* e, int32_t n_nodes, const int32_t* cut_offsets, const int8_t* type,
+                                           const int32_t* var_index, const double* value, int check_cycles, void* d_states,
+                                           int32_t* d_watched_row, double* d_watched_value) {
+    if (!e || !d_states || !d_watched_row || !d_watched_value) return fail(JSLP_ERR_ARG, "relax_batch_watched_device: null pointer");
+    return jslp_engine_relax_batch_watched(e, n_nodes, cut_offsets, type, var_index, value, check_cycles, (jslp_simplex_result*)d_states,
+                                           d_watched_row, d_watched_value);
+}
+int32_t jslp_engine_watched_count(const jslp_engine* e) { return e ? e->n_watch : 0; }
+
 int jslp_engine_set_counting(jslp_engine* e, int enabled) {
     if (!e) return fail(JSLP_ERR_ARG, "set_counting: null");
     e->counting = enabled ? 1 : 0;
@@ -1129,6 +1139,13 @@ int jslp_pool_relax_batch_pinned(jslp_pool* p, int32_t n_nodes, const int32_t* c
 }
 
 /* the compact read-back over the pool: rowByVarIndex / RHS cell of the watched variables per node (mip-utils.ts:43-61) */
+int32_t jslp_pool_watched_count(const jslp_pool* p) {
+    if (!p || p->n <= 0) return 0;
+    for (int32_t i = 1; i < p->n; i++)
+        if (p->members[i]->n_watch != p->members[0]->n_watch) return -1;
+    return p->members[0]->n_watch;
+}
+
 int jslp_pool_set_watched_variables(jslp_pool* p, const int32_t* var_indexes, int32_t n) {
     if (!p) return fail(JSLP_ERR_ARG, "pool_set_watched_variables: null");
     jslp_engine* e = p->members[0];

@@ -17,7 +17,7 @@ from jslpsolver_amd import _capi  # noqa: E402
 from jslpsolver_amd.engine import Tableau, pivot_digest  # noqa: E402
 from resident_stress import int_instance  # noqa: E402  (the instance builder is shared with the tool: one definition)
 
-OUT = os.path.join(ROOT, "tests", "golden", "stress_expect.json")
+OUT = os.environ.get("JSLP_STRESS_EXPECT_OUT") or os.path.join(ROOT, "tests", "golden", "stress_expect.json")  # (the override: several keys generated side by side, merged by hand)
 # (kind, constraints m, variables n, seed): every register-resident geometry and both pipelines
 #   <1024,2,8> headline: 1000 x 1000, 2000 x 2000;  <512,4,16> tall: 2100 x 300, 4000 x 2000;  <512,6,12>: 1200 x 2100, 3000 x 3000;
 #   <512,8,8> wide: 600 x 3000, 2000 x 4000;  int2p = with a phase 1
@@ -25,7 +25,10 @@ CASES = [("int", 1000, 1000, 12345), ("int", 2000, 2000, 12345), ("int", 2100, 3
          ("int", 600, 3000, 12345), ("int", 300, 2100, 12345), ("int", 2000, 4000, 12345), ("int", 4000, 2000, 12345),
          ("int", 3000, 3000, 12345),
          ("int2p", 1000, 1000, 12345), ("int2p", 2100, 300, 12345), ("int2p", 300, 2100, 12345), ("int2p", 1200, 2100, 12345),
-         ("intunr3", 1200, 2100, 12345), ("intunr3", 1000, 1000, 12345)]  # the first 3 variables unrestricted: the general build
+         ("intunr3", 1200, 2100, 12345), ("intunr3", 1000, 1000, 12345),  # the first 3 variables unrestricted: the general build
+         # round 5 -- beyond the register file, the shapes the DEFAULT policy streams: 5001 x 3001 (k_pivot_fused<2>; int2p: k_fused_p1<2> first),
+         # 5001 x 2001 (k_pivot_fused<1>), 3001 x 5001 (ld > 4096: k_select + k_update for both phases)
+         ("int", 5000, 3000, 12345), ("int2p", 5000, 3000, 12345), ("int", 5000, 2000, 12345), ("int", 3000, 5000, 12345), ("int2p", 3000, 5000, 12345)]
 
 
 def main(filt=""):

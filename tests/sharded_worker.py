@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import golden_util as G  # noqa: E402
 from jslpsolver_amd import Solve, _capi  # noqa: E402
 from jslpsolver_amd.engine import Tableau  # noqa: E402
-from jslpsolver_amd.sharding import evaluate_nodes_sharded  # noqa: E402
+from jslpsolver_amd.sharding import evaluate_nodes_sharded, evaluate_nodes_sharded_watched, watched_block_bytes  # noqa: E402
 
 
 def main():
@@ -34,10 +34,14 @@ def main():
     # 1. whole solves: sharded speculative B&B == the reference's result
     for name in ("Monster_II", "Knapsack_1", "Integer_Wood_Shop_Problem", "Sudoku4x4"):
         g = G.load(os.path.join(G.GOLDEN, "fixtures", name + ".json.gz"))
-        out = Solve(g["model"], full=True, lib=lib, speculate=4 * world, group=dist.group.WORLD)
         ref = {k: (G.num(v) if not isinstance(v, bool) else v) for k, v in g["result"].items()}
-        ok = out["result"] == ref and out["iter"] == g["final"]["branchAndCutIterations"]
-        report["cases"].append({"name": name, "ok": bool(ok)})
+        # (round 5: the tree's exchange is COMPACT by default -- the integer variables' rows and values; JSLP_SHARD_COMPACT=0: whole columns)
+        for compact in ("1", "0"):
+            os.environ["JSLP_SHARD_COMPACT"] = compact
+            out = Solve(g["model"], full=True, lib=lib, speculate=4 * world, group=dist.group.WORLD)
+            ok = out["result"] == ref and out["iter"] == g["final"]["branchAndCutIterations"]
+            report["cases"].append({"name": name + (" (compact exchange)" if compact == "1" else " (full exchange)"), "ok": bool(ok)})
+        os.environ.pop("JSLP_SHARD_COMPACT", None)
     # 2. the throughput unit: a batch of independent nodes sharded round-robin, outcomes all-gathered
     g = G.load(os.path.join(G.GOLDEN, "fixtures", "Monster_II.json.gz"))
     tab = g["tableau"]
@@ -60,6 +64,35 @@ def main():
             ok = ok and G.sha_rhs(ev.rhs, ev.vibr) == call["rhsSha"]
         report["cases"].append({"name": "Monster_II node batch, exchange form %s" % form, "ok": bool(ok)})
     os.environ.pop("JSLP_SHARD_DEVICE_PATH", None)
+    # 2b. the COMPACT exchange (jslp_engine_relax_batch_watched_device): per node the state record + row / RHS cell of the watched (integer)
+    #     variables; every node against the reference's golden through the full outcome it must agree with
+    import numpy as np
+    watched = np.array(tab["integerVarIndexes"], dtype=np.int32)
+    t.set_watched_variables(watched)
+    full = evaluate_nodes_sharded(t, nodes, True, dist.group.WORLD)
+    comp = evaluate_nodes_sharded_watched(t, nodes, True, dist.group.WORLD)
+    ok = len(comp) == len(nodes) and type(comp).__name__ == "ShardedOutcomesWatched"
+    for i, call in enumerate(calls[1:]):
+        fe, ce = full.node(i), comp.node(i)
+        ok = ok and G.sha_rhs(fe.rhs, fe.vibr) == call["rhsSha"]  # (the full outcome IS the reference's)
+        # (a node without an optimum keeps whatever evaluation its engine held before: compare the bound only where there is one)
+        ok = ok and bool(ce.res.feasible) == call["feasible"] and ce.res.height == call["height"] and (not ce.res.optimal or ce.res.evaluation == fe.res.evaluation)
+        ok = ok and bool(ce.res.optimal) == bool(fe.res.optimal)
+        row_of = {int(v): r for r, v in enumerate(fe.vibr) if r > 0}
+        want_rows = np.array([row_of.get(int(v), -1) for v in watched], dtype=np.int32)
+        want_vals = np.array([fe.rhs[r] if r > 0 else 0.0 for r in want_rows])
+        ok = ok and np.array_equal(ce.wrows, want_rows) and ce.wvals.tobytes() == want_vals.tobytes()
+    per = max((len(nodes) + world - 1) // world, 1)
+    payload = watched_block_bytes(per, len(watched), t.state_record_bytes())
+    report["cases"].append({"name": "Monster_II node batch, compact exchange (%d B per rank, %d B per node)" % (payload, payload // per), "ok": bool(ok)})
+    for n_take in (0, 1, world + 1):  # ragged batches through the compact form
+        sub = nodes[:n_take]
+        comp = evaluate_nodes_sharded_watched(t, sub, True, dist.group.WORLD)
+        ok = len(comp) == len(sub)
+        for i, call in enumerate(calls[1:1 + n_take]):
+            ce = comp.node(i)
+            ok = ok and bool(ce.res.feasible) == call["feasible"] and ce.res.height == call["height"] and len(ce.wrows) == len(watched)
+        report["cases"].append({"name": "ragged compact batch of %d node(s) over %d rank(s)" % (n_take, world), "ok": bool(ok)})
     # 3. ragged batches: fewer nodes than ranks, a batch that does not divide by the world size, an empty batch (ranks without a
     #    node still take part in the exchange step with a padded, empty contribution)
     for n_take in (0, 1, max(world - 1, 1), world + 1):

@@ -134,10 +134,10 @@ def test_oracle_stops_where_the_reference_stops(oracle_lib, path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["auto", "wg", "sp", "fused", "resident", "xl"])
 @pytest.mark.parametrize("path", SMALL, ids=G.ident)
-def test_hip_small_every_launch_shape(hip_lib, path, mode, monkeypatch):
+def test_hip_small_every_launch_shape(hip_lib, hip_hooks_lib, path, mode, monkeypatch):
     if mode != "auto":
         monkeypatch.setenv("JSLP_FORCE_PATH", mode)
-    _check(hip_lib, path)
+    _check(hip_hooks_lib if mode == "xl" else hip_lib, path)  # (round 5: the XCD-local kernels live in the test library only)
 
 
 @pytest.mark.gpu
@@ -162,9 +162,13 @@ def test_hip_embedded_through_the_streaming_kernels(hip_lib, path, monkeypatch):
 def test_hip_embedded_general_resident_build(hip_lib, path, monkeypatch):
     """JSLP_RES_LEAN=0, forced resident: the GENERAL build's leaderless protocol with its per-workgroup LDS history on the headline
     geometry (2011 x 2012), with and without unrestricted variables.  Round 4: the tall / wide geometries have no general build any
-    more (the lean one takes unrestricted variables; the general one spilled and lost to the streaming kernels): the 2041-row
-    embeddings then run the fused pipeline -- same answer"""
+    more (the lean one takes unrestricted variables; the general one spilled and lost to the streaming kernels): the embeddings wider
+    than 2048 columns then run the fused pipeline -- same answer"""
     monkeypatch.setenv("JSLP_RES_LEAN", "0")
     monkeypatch.setenv("JSLP_FORCE_PATH", "resident")
-    # (2040 x 2030 embeddings: 2041 rows fit the headline geometry -> general build; the ones whose padding makes them taller -> fused)
-    _check(hip_lib, path, None if "2040x2030" in path else "resident")
+    # (ADVICE r04: assert the kernel each family runs.  The general build exists for the headline geometry only: <= 2048 rows AND <= 2048
+    #  columns -- 2011 x 2012 and the unrestricted 2040 x 2048 embedding; the other two "2040x2030" embeddings are 2036 x 2049 and
+    #  2041 x 2052 tableaus, wider than the headline geometry, whose geometries have a lean build only -> the fused pipeline)
+    g = G.load(path)
+    fits_headline = g["tableau"]["height"] <= 2048 and g["tableau"]["width"] <= 2048
+    _check(hip_lib, path, "resident" if fits_headline else "fused")

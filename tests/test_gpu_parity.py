@@ -54,11 +54,11 @@ SMALL = [p for p in G.fixture_paths() if "LargeFarm" not in p and "Vendor" not i
 
 
 @pytest.mark.parametrize("path", SMALL, ids=G.ident)
-def test_fixture_replay(hip_lib, path_mode, path):
+def test_fixture_replay(hip_lib, hip_hooks_lib, path_mode, path):
     g = G.load(path)
     if not usable(g):
         pytest.skip("outside the hot-path scope")
-    replay(hip_lib, g)
+    replay(hip_hooks_lib if path_mode == "xl" else hip_lib, g)  # (round 5: the XCD-local kernels live in the test library only)
 
 
 @pytest.mark.parametrize("name", ["Monster_Problem", "Monster_II", "Vendor_Selection", "StockCuttingProblem", "LargeFarmMIP"])
@@ -67,18 +67,20 @@ def test_big_fixture_replay(hip_lib, name):
 
 
 @pytest.mark.parametrize("name", ["Monster_Problem", "Monster_II"])
-def test_big_fixture_replay_other_paths(hip_lib, name):
+def test_big_fixture_replay_other_paths(hip_lib, hip_hooks_lib, name):
     g = G.load(os.path.join(G.GOLDEN, "fixtures", name + ".json.gz"))
     for mode in ("wg", "wggen", "sp", "fused", "resident", "resident4", "xl"):
         set_path(mode)
         try:
-            replay(hip_lib, g)
+            replay(hip_hooks_lib if mode == "xl" else hip_lib, g)
         finally:
             set_path("auto")
 
 
 @pytest.mark.parametrize("path", [p for p in G.synthetic_paths() if "_1000x" not in p and "_2000x" not in p], ids=G.ident)
-def test_synthetic_replay(hip_lib, path_mode, path):
+def test_synthetic_replay(hip_lib, hip_hooks_lib, path_mode, path):
+    if path_mode == "xl":
+        hip_lib = hip_hooks_lib  # (round 5: the XCD-local kernels live in the test library only)
     g = G.load(path)
     if g["tableau"]["rows"] is None or not usable(g):
         pytest.skip("dense instance: see test_dense_synthetic")
@@ -106,7 +108,9 @@ def _dense_case(lib, kind, n, check_cycles):
 
 
 @pytest.mark.parametrize("kind,n", [("ra", 200), ("lp", 200), ("ra", 500), ("lp", 500), ("ra", 1000), ("lp", 1000)])
-def test_dense_synthetic_against_reference_golden(hip_lib, path_mode, kind, n):
+def test_dense_synthetic_against_reference_golden(hip_lib, hip_hooks_lib, path_mode, kind, n):
+    if path_mode == "xl":
+        hip_lib = hip_hooks_lib  # (round 5: the XCD-local kernels live in the test library only)
     if path_mode in ("wg", "wggen") and n > 500:
         pytest.skip("one workgroup on a 1000x1000 dense tableau: correct but slow")
     name = ("generateResourceAllocation" if kind == "ra" else "generateRandomLP") + "_%dx%d_seed12345" % (n, n)
@@ -134,7 +138,9 @@ def test_config3_full_size_against_reference_golden(hip_lib):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_random_lp_hip_equals_oracle(hip_lib, oracle_lib, path_mode, seed):
+def test_random_lp_hip_equals_oracle(hip_lib, hip_hooks_lib, oracle_lib, path_mode, seed):
+    if path_mode == "xl":
+        hip_lib = hip_hooks_lib  # (round 5: the XCD-local kernels live in the test library only)
     """seeded random LPs with ragged shapes, unrestricted variables, negative RHS (phase 1) and degenerate
     rows: flags, pivot sequence and every double of the final tableau must match the oracle"""
     rng = np.random.default_rng(1000 + seed)

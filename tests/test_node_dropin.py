@@ -39,15 +39,15 @@ def test_addon_exports_the_abi():
                          capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip() == ("addCuts,applyMirCuts,checkpointCreate,checkpointRelease,checkpointRestore,create,destroy,detach,"
-                                  "deviceCount,dims,download,getCounters,getOptionalObjectives,hostMatrix,load,pivot,pivotTrace,"
+                                  "deviceCount,deviceMs,dims,download,getCounters,getOptionalObjectives,hostMatrix,load,pivot,pivotTrace,"
                                   "poolCreate,poolDestroy,poolRelaxBatch,poolRelaxBatchWatched,poolSetWatchedVariables,poolSize,poolSyncRoot,readRhs,relax,relaxBatch,relaxBatchWatched,relaxFrom,"
                                   "relaxWatched,releasePooledResources,restore,save,setCounting,setIntegerVariables,"
-                                  "setOptionalObjectives,setWatchedVariables,simplex,upload")
+                                  "setOptionalObjectives,setWatchedVariables,simplex,timings,upload")
 
 
 # exact counts (not lower bounds): a regression that turns cases into skips must fail
 FIXTURE_COUNTS = {"fail": 0, "pass": 47, "solved_on_engine": 43, "strategy_variants_ok": 30, "incremental_ok": 114,
-                  "device_checkpoints": 577, "mir_ok": 67, "speculative_ok": 15, "lookahead_ok": 15, "lookahead_ran": True, "size_policy_ok": 8, "fuzz_ok": 1063,
+                  "device_checkpoints": 577, "mir_ok": 67, "speculative_ok": 15, "lookahead_ok": 15, "lookahead_ran": True, "size_policy_ok": 10, "fuzz_ok": 1063,
                   "edit_ok": 20, "released_ok": 1, "instance_ok": 16, "cycle_ok": 13, "pool_ok": 13, "pool_full_ok": 13, "watched_ok": 25, "pool_watched_ok": 25}
 
 

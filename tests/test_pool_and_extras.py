@@ -363,6 +363,115 @@ def test_checksummed_row_hand_over_survives_a_flag_that_overtakes_its_row(hip_ho
     assert c["resident_fetch_retries"] >= len(tr) // 2, c  # (every pivot's winner held its row back: its readers looked more than once)
 
 
+def _litmus_instance(which):
+    """(matrix, vibr, vibc, unrestricted, optional objectives, check_cycles, known answer) of one build that hands rows over checksummed"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import known_answers as KA
+    wide = os.path.join(G.GOLDEN, "wide")
+    if which == "tall":        # <512,4,16>: two pairs per lane, the geometry that naturally repeats looks
+        m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, 2000, 4000)
+        return m, vibr, vibc, [], None, False, KA.expected_dense("ra", 2000, 4000)
+    if which == "check":       # CHK build of the headline geometry (the reference's default cycle check on)
+        m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, 1000, 1000)
+        return m, vibr, vibc, [], None, True, KA.expected_dense("ra", 1000, 1000)
+    if which == "soft":        # <512,4,16,OPT>: three optional objective rows in registers; publishes from inside the update pass
+        g = G.load(os.path.join(wide, "soft_RA_2000x3000_k30.json.gz"))
+        m, vibr, vibc, oo = generators.soft_resource_allocation_tableau(12345, g["meta"]["n"], g["meta"]["m"], g["meta"]["k"])
+        return m, vibr, vibc, [], oo, False, {"pivots": g["nPivots"], "digest": g["pivotDigest"], "final_sha": g["final"]["matrixSha"], "feasible": g["final"]["feasible"]}
+    if which == "unrestricted":  # <512,4,16,UNR>: per-lane masks of the unrestricted columns
+        g = G.load(os.path.join(wide, "unrestricted_RA_2000x3950_k50.json.gz"))
+        m, vibr, vibc, unr = generators.unrestricted_resource_allocation_tableau(12345, g["meta"]["n"], g["meta"]["m"], g["meta"]["k"])
+        return m, vibr, vibc, unr, None, bool(g["tableau"]["checkForCycles"]), {"pivots": g["nPivots"], "digest": g["pivotDigest"], "final_sha": g["final"]["matrixSha"], "feasible": g["final"]["feasible"]}
+    raise KeyError(which)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hook", ["2", "4", "6"])
+@pytest.mark.parametrize("which", ["tall", "check", "soft", "unrestricted"])
+def test_checksummed_hand_over_litmus_on_every_build_that_uses_it(hip_hooks_lib, which, hook, monkeypatch):
+    """the litmus above ran the 2-column headline build only.  The checksummed hand-over is also live in the tall geometry
+    (`<512,4,16>`: two pairs per lane), its OPT build (publishes from inside the old update pass), its UNR build and the CHK builds.
+    Hooks (test library only): 2 = wave 0's flag word overtakes its whole part of the row; 4 / 6 = a TORN row -- the even / odd lanes of
+    wave 0 store, the word goes up, the other half follows ~8 k cycles later, so a reader's first looks see half of the wave's columns
+    from this epoch and half from two epochs back, which nothing but the checksum can tell.  Every instance against the reference's own
+    golden (simplex.ts:271-296, 394-412), repeats counted."""
+    m, vibr, vibc, unr, oo, check, want = _litmus_instance(which)
+    assert want is not None
+    monkeypatch.setenv("JSLP_TEST_RESIDENT_LATE_WAVE0", hook)
+    kw = {"optional_objectives": oo} if oo is not None else {}
+    t = Tableau(m, vibr, vibc, unr, lib=hip_hooks_lib, **kw)
+    res = t.simplex(check_cycles=check)
+    c = t.get_counters()
+    path = t.last_path()
+    tr = t.pivot_trace()
+    got = (len(tr), pivot_digest(tr), G.sha_matrix(t.download()[0]), bool(res.feasible))
+    t.close()
+    assert path == "resident" and c["resident_aborts"] == 0 and c["resident_handovers"] == 0, (path, c)
+    assert got == (want["pivots"], want["digest"], want["final_sha"], want["feasible"]), got
+    assert c["resident_fetch_retries"] > 0, c  # (the hook did hold rows back: the test is not vacuous)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hook", ["4", "6"])
+@pytest.mark.parametrize("kind,n", [("ra", 1000), ("lp", 1000), ("ra", 2000)])
+def test_checksummed_hand_over_survives_a_torn_row(hip_hooks_lib, kind, n, hook, monkeypatch):
+    """the TORN-row hook on the headline geometry (one pair per lane: half of wave 0's LANES are held back), phase 2 and phase 1 pipelines"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import known_answers as KA
+    monkeypatch.setenv("JSLP_FORCE_PATH", "resident")
+    if kind == "ra":
+        m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
+    else:
+        m, vibr, vibc, _ = generators.dense_random_lp_tableau(12345, n, n)
+    want = KA.expected_dense(kind, n, n)
+    assert want is not None
+    monkeypatch.setenv("JSLP_TEST_RESIDENT_LATE_WAVE0", hook)
+    t = Tableau(m, vibr, vibc, lib=hip_hooks_lib)
+    res = t.simplex(check_cycles=False)
+    c = t.get_counters()
+    assert t.last_path() == "resident" and c["resident_aborts"] == 0
+    tr = t.pivot_trace()
+    got = (len(tr), pivot_digest(tr), G.sha_matrix(t.download()[0]), bool(res.feasible))
+    t.close()
+    assert got == (want["pivots"], want["digest"], want["final_sha"], want["feasible"]), got
+    assert c["resident_fetch_retries"] > 0, c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,after_us,check", [(2000, 9000, False), (2000, 20000, True), (1000, 2500, False)])
+def test_host_requested_abort_rolls_back_on_the_shipped_library(hip_lib, n, after_us, check, monkeypatch):
+    """the library users load has no test hooks, so its abort / rollback path never ran.  JSLP_INJECT_RESIDENT_ABORT_US makes the
+    ENGINE (host side) raise the pinned host-abort word that many microseconds into the cooperative launch; the last workgroup of the lean
+    kernel looks at the word every 1024 pivots, raises the device-wide abort flag and leaves, everybody else meets its silence in the next
+    gather and leaves too (registers abandoned, no epilogue); the host restores slot 0 from the safety-net copy and solves through the
+    streaming kernels: the reference's pivots and final tableau, and the abort COUNTED.  (A kernel that finished before the word went up
+    simply reports no abort: the sizes below leave a wide margin -- 9726 pivots take ~57 ms, 2833 take ~17 ms.)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import known_answers as KA
+    m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
+    want = KA.expected_dense("ra", n, n)
+    monkeypatch.setenv("JSLP_INJECT_RESIDENT_ABORT_US", str(after_us))
+    t = Tableau(m, vibr, vibc, lib=hip_lib)
+    res = t.simplex(check_cycles=check)
+    c = t.get_counters()
+    path = t.last_path()
+    tr = t.pivot_trace()
+    got = (len(tr), pivot_digest(tr), G.sha_matrix(t.download()[0]), bool(res.feasible))
+    assert got == (want["pivots"], want["digest"], want["final_sha"], want["feasible"]), got
+    assert c["resident_launches"] == 1 and c["resident_aborts"] == 1 and path in ("fused", "select+update"), (path, c)
+    # ... and the same engine, knob off, takes the register-resident path again and gives the same answer
+    monkeypatch.delenv("JSLP_INJECT_RESIDENT_ABORT_US")
+    t2 = Tableau(m, vibr, vibc, lib=hip_lib)
+    t2.simplex(check_cycles=check)
+    assert t2.last_path() == "resident" and t2.get_counters()["resident_aborts"] == 0
+    assert G.sha_matrix(t2.download()[0]) == want["final_sha"]
+    t.close()
+    t2.close()
+
+
 # (round 4: the repeated-solve stress of the tall / wide shapes moved to tests/test_resident_pins.py, where every run is compared with the
 #  instance's KNOWN answer -- not with the first run -- and a rolled-back resident launch fails the test)
 

@@ -119,6 +119,10 @@ def _stress(args, env=None, timeout=900):
     (2100, 300, 10, "--kind", "int2p"),   # tall: phase 1 fused, phase 2 resident
     (1000, 1000, 6, "--check"),           # CHK build
     (1200, 2100, 4, "--unr", "3"),        # GENERAL build at a wide shape (forced below)
+    (3000, 2000, 4, "--kind", "soft", "--k", "30"),   # round 5: <512,4,16,OPT> -- three optional objective rows in registers (the reference's golden)
+    (400, 400, 10, "--kind", "soft", "--k", "30"),    # ... and the headline geometry's OPT build
+    (3950, 2000, 2, "--kind", "unr", "--k", "50"),    # <512,4,16,UNR>: 30 434 pivots per run (the reference's golden)
+    (950, 1000, 6, "--kind", "unr", "--k", "50"),     # headline UNR build (14 106 pivots per run)
 ], ids=lambda a: "_".join(str(x).strip("-") for x in a))
 def test_resident_stress_against_known_answers(hip_lib, args):
     """tools/resident_stress.py exits non-zero when ANY run's pivot count, digest or final tableau differs from the known answer, or when
@@ -171,6 +175,40 @@ def test_resident_abort_on_the_tall_and_wide_geometries_finishes_through_the_fus
             assert cnt["resident_aborts"] == 1 and cnt["resident_launches"] == 1, cnt
         t.close()
     assert out[0] == out[1]
+
+
+STREAMING = [("int", 5000, 3000, "fused"), ("int", 5000, 2000, "fused"), ("int", 3000, 5000, "select+update")]
+
+
+def test_streaming_path_expectations_exist():
+    """round 5: known answers for the shapes the DEFAULT policy streams -- beyond 4096 x 2048 / 3072 x 3072 / 2048 x 4096 the
+    tableau does not fit the chip's vector registers (resident_geometry == 0)"""
+    for kind, m, n, _path in STREAMING:
+        want = KA.expected_stress(kind, m + 1, n + 1, 12345)
+        assert want is not None and want["pivots"] > 10000 and len(want["final_sha"]) == 64, (kind, m, n)
+        assert (want["pivots_phase1"] > 0) == (kind == "int2p")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,m,n,path", STREAMING, ids=lambda v: str(v))
+def test_default_policy_beyond_the_register_file_is_the_known_answer(hip_lib, kind, m, n, path):
+    """5001 x 3001 (`k_pivot_fused<2>`; with a phase 1: `k_fused_p1<2>` first), 5001 x 2001 (`k_pivot_fused<1>`), 3001 x 5001 (ld > 4096:
+    `k_select` + `k_update` for both phases) through the DEFAULT policy: pivot count, pivot digest and the sha256 of every double of the final
+    tableau equal the known answer (tests/golden/stress_expect.json: the C restatement, itself pinned against the reference's goldens -- the
+    reference under node would take hours at these sizes), the path is the streaming one and no register-resident launch happened
+    (simplex.ts:330-413 at H x W > 9 M cells)"""
+    from resident_stress import int_instance
+    want = KA.expected_stress(kind, m + 1, n + 1, 12345)
+    assert want is not None
+    A, vibr, vibc = int_instance(m, n, 12345, kind == "int2p")
+    t = Tableau(A, vibr, vibc, lib=hip_lib)
+    res = t.simplex(check_cycles=False)
+    sig = KA.solve_signature(t, res, pivot_digest)
+    cnt, last = t.get_counters(), t.last_path()
+    t.close()
+    assert last == path and cnt["resident_launches"] == 0 and cnt["resident_aborts"] == 0, (last, cnt)
+    assert res.pivots_phase1 == want["pivots_phase1"] and bool(res.optimal) == want["optimal"] and bool(res.feasible) == want["feasible"]
+    assert (sig["pivots"], sig["digest"], sig["final_sha"]) == (want["pivots"], want["digest"], want["final_sha"])
 
 
 def test_soft_tall_instance_is_the_reference_tableau():

@@ -20,6 +20,13 @@ from resident_stress import int_instance  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def xl_lib(hip_hooks_lib):
+    """Round 5: the XCD-local instances live in the TEST library only (libjslp_hip_chaos.so: -DJSLP_CHAOS_BUILD implies -DJSLP_WITH_XL) --
+    the default policy never picked the geometry, so the shipped library no longer carries it"""
+    return hip_hooks_lib
+
+
 def _solve(lib, m, vibr, vibc, check, precision=1e-8):
     t = Tableau(m, vibr, vibc, [], precision=precision, lib=lib)
     res = t.simplex(check_cycles=check)
@@ -30,7 +37,7 @@ def _solve(lib, m, vibr, vibc, check, precision=1e-8):
 
 @pytest.mark.parametrize("check", [False, True])
 @pytest.mark.parametrize("kind,n", [("ra", 500), ("lp", 500), ("ra", 1000), ("lp", 1000)])
-def test_xcd_local_mid_size_dense_is_the_reference(hip_lib, kind, n, check, monkeypatch):
+def test_xcd_local_mid_size_dense_is_the_reference(xl_lib, kind, n, check, monkeypatch):
     """501 x 501 and 1001 x 1001 (all phase 2 / all phase 1, infeasible) with JSLP_XL=1: the XCD-local geometry; every
     pivot and every double of the final tableau are the reference's; one launch, no abort"""
     monkeypatch.setenv("JSLP_XL", "1")
@@ -40,7 +47,7 @@ def test_xcd_local_mid_size_dense_is_the_reference(hip_lib, kind, n, check, monk
         m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n)
     else:
         m, vibr, vibc, _ = generators.dense_random_lp_tableau(12345, n, n)
-    o = _solve(hip_lib, m, vibr, vibc, check)
+    o = _solve(xl_lib, m, vibr, vibc, check)
     assert o["path"] == "resident-xl", o["path"]
     assert (o["cnt"]["resident_launches"], o["cnt"]["resident_aborts"], o["cnt"]["resident_handovers"]) == (1, 0, 0), o["cnt"]
     assert len(o["trace"]) == g["nPivots"] and pivot_digest(o["trace"]) == g["pivotDigest"]
@@ -50,7 +57,7 @@ def test_xcd_local_mid_size_dense_is_the_reference(hip_lib, kind, n, check, monk
 
 
 @pytest.mark.parametrize("name", ["Monster_Problem", "Monster_II"])
-def test_monster_root_lps_xcd_local(hip_lib, name, monkeypatch):
+def test_monster_root_lps_xcd_local(xl_lib, name, monkeypatch):
     """JSLP_XL=1 on BASELINE config 2 (Monster LP, 625 x 553, 1 % dense) and config 4's root relaxation (Monster_II, 945 x 925): the first
     simplex() of the reference's own run -- pivots, RHS column + row map, evaluation"""
     monkeypatch.setenv("JSLP_XL", "1")
@@ -59,7 +66,7 @@ def test_monster_root_lps_xcd_local(hip_lib, name, monkeypatch):
     m, vibr, vibc = model.build_tableau()
     assert G.sha_matrix(m) == g["tableau"]["matrixSha"]
     cap = m.shape[0] + 2 * len(model.integerVariables)
-    t = Tableau(m, vibr, vibc, model.unrestricted, precision=model.precision, row_capacity=cap, lib=hip_lib)
+    t = Tableau(m, vibr, vibc, model.unrestricted, precision=model.precision, row_capacity=cap, lib=xl_lib)
     res = t.simplex(check_cycles=g["tableau"]["checkForCycles"])
     call = g["simplexCalls"][0]
     rhs, rows = t.read_rhs()
@@ -74,19 +81,19 @@ def test_monster_root_lps_xcd_local(hip_lib, name, monkeypatch):
 
 
 @pytest.mark.parametrize("shape,kind", [((1000, 1000), "int2p"), ((1000, 1000), "int"), ((1020, 300), "int2p"), ((300, 1020), "int2p"), ((90, 70), "int2p")])
-def test_xcd_local_two_phase_against_the_oracle(hip_lib, oracle_lib, shape, kind, monkeypatch):
+def test_xcd_local_two_phase_against_the_oracle(xl_lib, oracle_lib, shape, kind, monkeypatch):
     """phase 1 then phase 2 inside the one launch (resident_phase1_pipe hands over to resident_phase2_pipe), ragged shapes: rows
     that do not fill the last workgroup, 32 / 10 / 3 rows per workgroup, fewer than 32 workgroups"""
     monkeypatch.setenv("JSLP_FORCE_PATH", "xl")
     m, n = shape
     A, vibr, vibc = int_instance(m, n, 777, kind == "int2p")
     out = []
-    for lib in (oracle_lib, hip_lib):
+    for lib in (oracle_lib, xl_lib):
         t = Tableau(A, vibr, vibc, lib=lib)
         res = t.simplex(check_cycles=True)
         out.append((res.pivots_phase1, res.pivots_phase2, bool(res.feasible), bool(res.optimal), pivot_digest(t.pivot_trace()),
                     G.sha_matrix(t.download()[0])))
-        if lib is hip_lib:
+        if lib is xl_lib:
             assert t.last_path() == "resident-xl" and t.get_counters()["resident_aborts"] == 0
         t.close()
     assert out[0] == out[1]
@@ -106,8 +113,19 @@ def test_xcd_local_abort_rolls_back_and_resolves(hip_hooks_lib, abort_at, monkey
     assert pivot_digest(o["trace"]) == g["pivotDigest"] and G.sha_matrix(o["final"]) == g["final"]["matrixSha"]
 
 
-def test_xcd_local_is_opt_in(hip_lib, monkeypatch):
+def test_xcd_local_is_opt_in(xl_lib, monkeypatch):
     monkeypatch.delenv("JSLP_XL", raising=False)
+    m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, 500, 500)
+    o = _solve(xl_lib, m, vibr, vibc, False)
+    assert o["path"] == "resident" and pivot_digest(o["trace"]) == "1cda2607"
+
+
+def test_shipped_library_has_no_xcd_local_kernels(hip_lib, monkeypatch):
+    """the shipped library ignores JSLP_XL (the chip-wide geometry answers, same trace) and refuses JSLP_FORCE_PATH=xl loudly"""
+    monkeypatch.setenv("JSLP_XL", "1")
     m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, 500, 500)
     o = _solve(hip_lib, m, vibr, vibc, False)
     assert o["path"] == "resident" and pivot_digest(o["trace"]) == "1cda2607"
+    monkeypatch.setenv("JSLP_FORCE_PATH", "xl")
+    with pytest.raises(Exception, match="test library only"):
+        Tableau(m, vibr, vibc, [], lib=hip_lib)

@@ -38,6 +38,14 @@ for s in $steps; do
         timeout 120 python tools/rocpd_pmc.py $out $out/pmc_sq_summary.json < /dev/null | grep -A40 "k_node_queue" | head -120 ;;
     wgm) (JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py single; JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py batch) 2>&1 | grep -i "micro\|total\|single\|batch" > $out/wglds_micro.log; cat $out/wglds_micro.log ;;
     stress) for i in 1 2 3; do timeout 120 python tools/wglds_timing.py rate; done > $out/stress.log 2>&1 < /dev/null; echo "stress rc=$?"; grep -c relaxations $out/stress.log; tail -3 $out/stress.log ;;
+    sweep5) JSLP_SWEEP_SIZES="${SWEEP_SIZES:-[[60,45],[100,75],[140,105],[200,150],[300,225],[450,340]]}" timeout 420 node tools/policy_sweep.js > $out/policy_sweep.md 2> $out/policy_sweep.err < /dev/null; echo "sweep5 rc=$?"; cat $out/policy_sweep.md ;;
+    litmus) timeout 900 python -m pytest tests/test_pool_and_extras.py -m gpu -q -k "litmus or torn or host_requested or hand_over" > $out/litmus.log 2>&1 < /dev/null; echo "litmus rc=$?"; tail -15 $out/litmus.log ;;
+    stream) timeout 900 python -m pytest tests/test_resident_pins.py -m gpu -q -k "beyond_the_register_file" > $out/stream.log 2>&1 < /dev/null; echo "stream rc=$?"; tail -15 $out/stream.log ;;
+    bench20) timeout 900 python bench.py --steps 20 --warmup 5 > $out/bench20.log 2>&1 < /dev/null; echo "bench20 rc=$?"; grep '^{' $out/bench20.log | cut -c1-2500 ;;
+    ab) (for l in base noabort; do echo "== dense LPs, build/libjslp_dev_$l.so"; JSLP_HIP_LIBRARY=build/libjslp_dev_$l.so timeout 200 python tools/dense_lp_times.py; done
+         for l in base nopf; do echo "== node latency, build/libjslp_dev_$l.so"; JSLP_HIP_LIBRARY=build/libjslp_dev_$l.so timeout 200 python tools/node_latency.py; done
+         echo "== shipped library"; timeout 200 python tools/dense_lp_times.py; timeout 200 python tools/node_latency.py $out/node_latency.md) > $out/ab.log 2>&1 < /dev/null; echo "ab rc=$?"; cat $out/ab.log ;;
+    retest) timeout 1200 python -m pytest tests -m gpu -q -k "xl or xcd or virtual_shards or chaos or beyond_the_register or host_requested or rccl" > $out/retest.log 2>&1 < /dev/null; echo "retest rc=$?"; tail -12 $out/retest.log ;;
     sweep) timeout 600 node tools/mincells_sweep.js > $out/mincells_sweep.md 2> $out/mincells_sweep.err < /dev/null; echo "sweep rc=$?"; cat $out/mincells_sweep.md ;;
     dense) (timeout 300 python tools/dense_lp_times.py; JSLP_HIP_LIBRARY=build/libjslp_hip_nodefer.so timeout 300 python tools/dense_lp_times.py) > $out/dense_lp_times.log 2>&1 < /dev/null; echo "dense rc=$?"; cat $out/dense_lp_times.log ;;
     zc) (ROUNDS=3 timeout 200 python tools/batch_modes.py | tail -8

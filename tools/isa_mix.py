@@ -71,15 +71,28 @@ def main():
     print("kernel %s: %d lines, %d segments (each ends at an s_barrier)" % (lines[0].strip().rstrip(":"), len(lines), len(segs)))
     print("| seg | " + " | ".join(n for n, _ in CLASSES) + " | landmarks |")
     print("|---|" + "---|" * (len(CLASSES) + 1))
+    # round 5: which v_readlane are RELOADS OF SPILLED SGPRs?  The register allocator parks spilled scalars in the lanes of a few reserved
+    # VGPRs (the destinations of v_writelane); a v_readlane whose source is one of those is a reload, every other one is data movement the
+    # source asked for (DPP tails, broadcast multipliers of the update pass).  Printed as readlane = total (reloads).
+    spill_vgprs = {m.group(1) for l in lines for m in [re.match(r"^\s*v_writelane_b32 (v\d+),", l)] if m}
+    reload_rx = re.compile(r"^\s*v_readlane_b32 s\d+, (v\d+),")
     tot = [0] * len(CLASSES)
+    tot_reload = 0
     for i, sg in enumerate(segs):
         if not (a.lo <= i <= a.hi):
             continue
         c = [sum(1 for l in sg if rx.match(l)) for _, rx in CLASSES]
+        n_reload = sum(1 for l in sg for m in [reload_rx.match(l)] if m and m.group(1) in spill_vgprs)
+        tot_reload += n_reload
         marks = sorted({m for l in sg for m in re.findall(r"^\s*(ds_(?:min|max)\w*|buffer_wbl2|s_sleep|buffer_store_dwordx4|buffer_load_dwordx4|s_endpgm)", l)})
         tot = [x + y for x, y in zip(tot, c)]
-        print("| %d | " % i + " | ".join(str(x) for x in c) + " | " + " ".join(marks) + " |")
-    print("| total | " + " | ".join(str(x) for x in tot) + " | |")
+        cs = [str(x) for x in c]
+        cs[2] = "%d (%d)" % (c[2], n_reload)
+        print("| %d | " % i + " | ".join(cs) + " | " + " ".join(marks) + " |")
+    ts = [str(x) for x in tot]
+    ts[2] = "%d (%d)" % (tot[2], tot_reload)
+    print("| total | " + " | ".join(ts) + " | |")
+    print("(readlane column: all v_readlane / v_readfirstlane, in brackets those that reload a spilled SGPR from %s)" % (", ".join(sorted(spill_vgprs)) or "no spill VGPR"))
 
 
 if __name__ == "__main__":

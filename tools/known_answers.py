@@ -38,6 +38,13 @@ def expected_dense(kind, n_vars, n_rows):
     return None
 
 
+def expected_wide(prefix, n_vars, n_rows, k):
+    """the reference's own runs of tests/golden/gen_golden_wide.js: prefix "soft" (k soft resources: optional objectives, simplex.ts:221-263,
+    394-412) or "unrestricted" (k unrestricted variables), generateResourceAllocation(12345) with n_vars variables and n_rows constraints"""
+    p = os.path.join(GOLDEN, "wide", "%s_RA_%dx%d_k%d.json.gz" % (prefix, n_vars, n_rows, k))
+    return _load(p) if os.path.exists(p) else None
+
+
 def expected_stress(kind, rows, cols, seed=12345):
     """kind: "int" / "int2p" (tools/resident_stress.py's instances); rows x cols = the TABLEAU's shape"""
     p = os.path.join(GOLDEN, "stress_expect.json")

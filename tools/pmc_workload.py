@@ -93,7 +93,46 @@ def dense(kind, n_vars, n_rows, check, solves=2, key=None):
                           "generateResourceAllocation" if kind == "ra" else "generateRandomLP", H, W, "on" if check else "off", solves)}))
 
 
+def stream(kind, m, n, key):
+    """Round 5: a dense LP BEYOND the register file (tools/resident_stress.py's integer instances: m constraints x n variables, seed 12345)
+    through the DEFAULT policy -- k_pivot_fused<1|2> (+ k_fused_p1 when the instance has a phase 1) or, past ld = 4096, k_select +
+    k_update -- against the known answer of tests/golden/stress_expect.json.  This is the kernel north_star's ">= 40 % of the HBM roofline
+    in rocprof" literally describes: 16 x H x W algorithmic bytes per pivot, one dispatch per pivot."""
+    import time
+    from resident_stress import int_instance
+    lib = _capi.load_hip()
+    want = KA.expected_stress(kind, m + 1, n + 1, 12345)
+    if want is None and not KA.unverified_allowed():
+        raise SystemExit("no known answer for %s %d x %d (tests/golden/gen_stress_expect.py): refusing to profile an unverified solve" % (kind, m + 1, n + 1))
+    A, vibr, vibc = int_instance(m, n, 12345, kind == "int2p")
+    t = Tableau(A, vibr, vibc, lib=lib)
+    t.save()
+    t0 = time.perf_counter()
+    r = t.simplex(check_cycles=False)
+    wall = time.perf_counter() - t0
+    total, p1 = r.pivots_phase1 + max(r.pivots_phase2, 0), r.pivots_phase1
+    if want:
+        KA.check(KA.solve_signature(t, r, pivot_digest), want, "%s %d x %d" % (kind, m + 1, n + 1))
+    path = t.last_path()
+    c = t.get_counters()
+    t.close()
+    H, W = A.shape
+    if c["resident_launches"]:
+        raise SystemExit("%d x %d took a register-resident launch: not a streaming-path workload" % (H, W))
+    kernel = {"fused": "k_pivot_fused", "select+update": "k_update"}.get(path, path)
+    print(json.dumps({"key": key, "kernel": kernel, "dispatches": total - (p1 if path == "fused" else 0), "units": total - (p1 if path == "fused" else 0), "unit": "pivot",
+                      "one_dispatch_per": "pivot", "algorithmic_bytes_per_unit": 16.0 * H * W, "path": path, "phase1_pivots": p1,
+                      "whole_solve_units_per_s": total / wall, "whole_solve_seconds": wall,
+                      "verified": ({"pivots": want["pivots"], "digest": want["digest"], "final_sha": want["final_sha"][:16], "source": want["source"]} if want else None),
+                      "health": {"resident_launches": c["resident_launches"], "resident_aborts": c["resident_aborts"], "resident_handovers": c["resident_handovers"]},
+                      "workload": "dense integer LP %dx%d fp64 (tools/resident_stress.py %s, seed 12345), default policy, cycle check off, 1 solve" % (H, W, kind)}))
+
+
 WORKLOADS = {
+    "stream_5001x3001": lambda: stream("int", 5000, 3000, "stream_5001x3001"),      # k_pivot_fused<2>
+    "stream_5001x2001": lambda: stream("int", 5000, 2000, "stream_5001x2001"),      # k_pivot_fused<1>
+    "stream_3001x5001": lambda: stream("int", 3000, 5000, "stream_3001x5001"),      # ld > 4096: k_select + k_update
+    "stream2p_5001x3001": lambda: stream("int2p", 5000, 3000, "stream2p_5001x3001"),  # k_fused_p1<2> first
     "3a": lambda: dense("ra", 2000, 2000, False, key="3a"),
     "3a_check": lambda: dense("ra", 2000, 2000, True, key="3a_check"),
     "3b": lambda: dense("lp", 2000, 2000, False, solves=4, key="3b"),

@@ -6,6 +6,9 @@ instance has no known answer (JSLP_ALLOW_UNVERIFIED=1: compare with the first ru
     int    (default) dense integer LP, all "<=" rows (phase 2 only): rows x cols constraints x variables, SEED (env) = 12345
     int2p  the same with rows/8 ">=" rows: a phase 1 first (through the fused pipeline on the tall / wide geometries)
     ra/lp  the reference's generateResourceAllocation / generateRandomLP(seed 12345) with cols variables and rows constraints
+    soft   generateResourceAllocation(12345) with --k soft resources (three optional objective rows: the OPT builds; the known answer is the
+           reference's own run, tests/golden/wide/soft_RA_<cols>x<rows>_k<k>: 2000 x 3000 k 30 and 400 x 400 k 30 exist)
+    unr    the same with --k unrestricted variables (the UNR builds; tests/golden/wide/unrestricted_RA_*: 2000 x 3950 k 50, 1000 x 950 k 50, 300 x 250 k 20)
     --unr k   the first k variables declared unrestricted (the GENERAL build; its own known answer: they price differently)
     --check   the reference's default cycle check on
   `fresh` = a new engine per run (upload + first launch each time) instead of restore() on one engine.
@@ -43,12 +46,15 @@ def int_instance(m, n, seed, two_phase=False):
 
 
 def main(argv):
-    pos = [a for a in argv if not a.startswith("--")]
+    skip = {i + 1 for i, a in enumerate(argv) if a in ("--kind", "--unr", "--k")}
+    pos = [a for i, a in enumerate(argv) if not a.startswith("--") and i not in skip]
     m, n, runs = int(pos[0]), int(pos[1]), int(pos[2])
     fresh = len(pos) > 3 and pos[3] == "fresh"
     kind = argv[argv.index("--kind") + 1] if "--kind" in argv else "int"
     n_unr = int(argv[argv.index("--unr") + 1]) if "--unr" in argv else 0
     check = "--check" in argv or os.environ.get("CHECK_CYCLES", "0") == "1"
+    k_extra = int(argv[argv.index("--k") + 1]) if "--k" in argv else 30
+    oo, unr_list = None, None
     seed = int(os.environ.get("SEED", "12345"))
     if kind in ("int", "int2p"):
         A, vibr, vibc = int_instance(m, n, seed, kind == "int2p")
@@ -57,14 +63,21 @@ def main(argv):
     elif kind == "ra":
         A, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, m)
         want = KA.expected_dense("ra", n, m)
+    elif kind == "soft":
+        A, vibr, vibc, oo = generators.soft_resource_allocation_tableau(12345, n, m, k_extra)
+        want = KA.expected_wide("soft", n, m, k_extra)
+    elif kind == "unr":
+        A, vibr, vibc, unr_list = generators.unrestricted_resource_allocation_tableau(12345, n, m, k_extra)
+        want = KA.expected_wide("unrestricted", n, m, k_extra)
     else:
         A, vibr, vibc, _ = generators.dense_random_lp_tableau(12345, n, m)
         want = KA.expected_dense("lp", n, m)
     if want is None and not KA.unverified_allowed():
-        print("no known answer for %s %d x %d (seed %d): add it to tests/golden/gen_stress_expect.py; refusing to stress an unverified instance" % (kind, m + 1, n + 1, seed))
+        print("no known answer for %s %d x %d (seed %d): add it to tests/golden/gen_stress_expect.py; refusing to stress an unverified instance" % (kind, A.shape[0], A.shape[1], seed))
         return 2
     lib = _capi.load_hip()
-    unr = list(range(n_unr))
+    unr = unr_list if unr_list is not None else list(range(n_unr))
+    kw = {"optional_objectives": oo} if oo is not None else {}
     first, bad, t, pivots_done, aborts, since_upload, retries = None, 0, None, 0, 0, 0, 0
     for i in range(runs):
         # (an engine's pivot trace holds 2^20 pivots since its upload: a fresh engine before it would overflow)
@@ -74,7 +87,7 @@ def main(argv):
                 aborts += t.get_counters()["resident_aborts"]
                 retries += t.get_counters()["resident_fetch_retries"]
                 t.close()
-            t = Tableau(A, vibr, vibc, unr, lib=lib)
+            t = Tableau(A, vibr, vibc, unr, lib=lib, **kw)
             t.save()
         else:
             t.restore()
@@ -96,7 +109,7 @@ def main(argv):
     retries += t.get_counters()["resident_fetch_retries"]
     t.close()
     print("%d x %d %s%s%s, %d runs (%s), %d pivots, path %s: %d differ from %s; resident aborts %d; repeated row looks %d" % (
-        m + 1, n + 1, kind, " unr=%d" % n_unr if n_unr else "", " check" if check else "", runs, "fresh engines" if fresh else "one engine",
+        A.shape[0], A.shape[1], kind, " unr=%d" % n_unr if n_unr else "", " check" if check else "", runs, "fresh engines" if fresh else "one engine",
         pivots_done, first["path"], bad, ("the known answer [%s]" % want["source"]) if want is not None else "the first (UNVERIFIED)", aborts, retries))
     return 1 if (bad or aborts) else 0
 

@@ -66,7 +66,9 @@ def main(root, out_md, out_json=None):
                "units_per_s": 1e6 / us_per_unit, "algorithmic_bytes_per_unit": w["algorithmic_bytes_per_unit"],
                "algorithmic_gb_s": w["algorithmic_bytes_per_unit"] / us_per_unit / 1e3,
                "algorithmic_frac": w["algorithmic_bytes_per_unit"] / (us_per_unit * 1e-6) / HBM_PEAK,
-               "verified": w.get("verified"), "health": w.get("health")}
+               "verified": w.get("verified"), "health": w.get("health"),
+               # (the streaming-path workloads also clock the whole solve on the host: selection kernels, launch gaps and read-backs included)
+               "whole_solve_units_per_s": w.get("whole_solve_units_per_s"), "path": w.get("path"), "phase1_pivots": w.get("phase1_pivots")}
         try:
             wide = w["kernel"] != "k_simplex_resident"  # streaming kernels read 16 B per lane: gfx950 FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)
             f_kib, nf = counter(run, "fetch", "FETCH_SIZE", w["kernel"])
@@ -81,15 +83,16 @@ def main(root, out_md, out_json=None):
         except Exception as e:  # a run without the PMC passes still gives the timing rows
             row["pmc_error"] = repr(e)
         rows.append(row)
-    lines = ["| workload | kernel | dispatches | avg dispatch us | units | us / unit | units / s | algorithmic MB / unit | algorithmic frac of 8 TB/s | PMC HBM MB / unit | hbm frac | verified against |",
-             "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    lines = ["| workload | kernel | dispatches | avg dispatch us | units | us / unit | units / s | algorithmic MB / unit | algorithmic frac of 8 TB/s | PMC HBM MB / unit | hbm frac | whole solve, units / s (host clock) | verified against |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
         v = r.get("verified") or {}
-        lines.append("| %s | `%s` | %d | %.1f | %d %ss | %.3f | %.0f | %.2f | %.3f | %s | %s | %s |" % (
+        lines.append("| %s | `%s` | %d | %.1f | %d %ss | %.3f | %.0f | %.2f | %.3f | %s | %s | %s | %s |" % (
             r["workload"], r["kernel"], r["dispatches"], r["avg_dispatch_us"], r["units"], r["unit"], r["us_per_unit"], r["units_per_s"],
             r["algorithmic_bytes_per_unit"] / 1e6, r["algorithmic_frac"],
             "%.3f" % (r["pmc_traffic_bytes_per_unit"] / 1e6) if "pmc_traffic_bytes_per_unit" in r else "-",
             "%.4f" % r["hbm_frac"] if "hbm_frac" in r else "-",
+            "%.0f" % r["whole_solve_units_per_s"] if r.get("whole_solve_units_per_s") else "-",
             ("%s pivots, digest %s" % (v["pivots"], v["digest"])) if "digest" in v else ("%s reference node outcomes per call" % v.get("nodes_per_call", "?"))))
     text = "\n".join(lines) + "\n"
     with open(out_md, "w") as fh:
