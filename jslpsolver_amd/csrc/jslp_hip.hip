@@ -105,6 +105,7 @@ struct jslp_engine {
     char* r_arena = nullptr; size_t r_arena_bytes = 0;  // hand-off buffers + this backup in ONE allocation (parked in the resource pool)
     DevState* r_backup_st = nullptr;
     double* rb_A = nullptr; int32_t *rb_vibr = nullptr, *rb_vibc = nullptr, *rb_rbv = nullptr, *rb_cbv = nullptr;
+    int* d_done_count = nullptr;  // workgroups of a small batch that have delivered their outcome (k_node_lds: the last one raises the completion flag)
     unsigned long long* d_nnz = nullptr; long long nnz = -1;  // non-zero cells of the uploaded tableau (counted on the device)
     unsigned spin_limit = 0; int test_abort_epoch = -1; int test_late_wave0 = 0;
     int resident_fallbacks = 0;  // solves that were rolled back and re-run through the streaming kernels
@@ -196,6 +197,11 @@ static int snapshot_transpose_on() {  // pivot-column reads of untouched rows fr
         const char* t = getenv("JSLP_SNAPSHOT_TRANSPOSE");  // tuning knob
         v = t ? atoi(t) : 1;
     }
+    return v;
+}
+static int batch_poll_on() {  // a one-group batch of the 1024-thread node kernel ends by polling its completion flag (JSLP_BATCH_POLL=0: stream synchronisation)
+    static int v = -1;
+    if (v < 0) { const char* t = getenv("JSLP_BATCH_POLL"); v = (t && t[0] == '0') ? 0 : 1; }
     return v;
 }
 static int node_cow_single() {  // single-node call: copy-on-write start (JSLP_NODE_COW_SINGLE=0: restore eagerly, as the batch groups do)
@@ -503,6 +509,7 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
                 e->snap_cbv = cv.take<int32_t>((size_t)e->n_idx);
                 e->s.trace = cv.take<int2>((size_t)TRACE_CAP);
                 e->d_nnz = cv.take<unsigned long long>(1);
+                e->d_done_count = cv.take<int>(1);
                 if (!pass) {
                     e->static_bytes = cv.off + 256;
                     if (have && pooled.static_bytes >= e->static_bytes) {
@@ -517,6 +524,7 @@ extern "C" int jslp_engine_create(jslp_engine** out, int device, int32_t height,
             e->s.trace_cap = TRACE_CAP;
         }
         HIPC(hipMemsetAsync(e->d_unr, 0, e->n_idx, e->stream));
+        HIPC(hipMemsetAsync(e->d_done_count, 0, sizeof(int), e->stream));
         int r = ensure_slots(e, 1);
         if (r) return r;
         if (!have) {
@@ -770,10 +778,20 @@ static bool use_wg_single(const jslp_engine* e) {
            (double)e->nnz <= WG_SPARSE_DENSITY * (double)e->H0 * (double)e->W;
 }
 
+#define JSLP_F_MAXNT 4
+static int fused_wide_on() {  // JSLP_FUSED_WIDE=0: tableaus wider than 4096 columns through k_select + k_update, as before round 5
+    static int v = -1;
+    if (v < 0) { const char* t = getenv("JSLP_FUSED_WIDE"); v = (t && t[0] == '0') ? 0 : 1; }
+    return v;
+}
 // the fused one-launch-per-pivot phase 2 (see k_pivot_fused for the preconditions)
 static bool fused_eligible(const jslp_engine* e) {
     if (e->force_path == 2) return false;
-    return e->ld <= 2 * JSLP_F_TW && e->cap_rows <= 64 * JSLP_F_MAXG && e->precision >= 1e-15;
+    // (round 5: three and four column tiles per lane -- 4096 < ld <= 8192 -- for tableaus without unrestricted variables / optional objectives:
+    //  3001 x 5001 ran k_update at 0.83 of the HBM peak but, with the one-workgroup k_select in front of every pivot, 17.3 k pivots/s = 0.52
+    //  end to end, profiles/r05_streaming_workload_rows.md)
+    const int max_tiles = (e->n_unr == 0 && e->n_opt == 0 && fused_wide_on()) ? JSLP_F_MAXNT : 2;
+    return e->ld <= max_tiles * JSLP_F_TW && e->cap_rows <= 64 * JSLP_F_MAXG && e->precision >= 1e-15;
 }
 
 // Geometry of the register-resident kernel for this tableau: lanes x columns per lane must cover a row (ld), rows per
@@ -1299,7 +1317,8 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             if (r) return r;
             const FusedCtx f = make_fused_ctx(e, c, H);
             void (*kp1)(FusedCtx, int) = e->ld <= JSLP_F_TW ? (e->n_unr > 0 ? k_fused_p1<1, true> : k_fused_p1<1, false>)
-                                                           : (e->n_unr > 0 ? k_fused_p1<2, true> : k_fused_p1<2, false>);
+                                         : e->ld <= 2 * JSLP_F_TW ? (e->n_unr > 0 ? k_fused_p1<2, true> : k_fused_p1<2, false>)
+                                         : e->ld <= 3 * JSLP_F_TW ? k_fused_p1<3, false> : k_fused_p1<4, false>;  // (fused_eligible: no unrestricted variables beyond two tiles)
             for (;;) {
                 int launch = 0;
                 hipLaunchKernelGGL(kp1, dim3(f.G), dim3(JSLP_F_THREADS), 0, s, f, launch);
@@ -1376,8 +1395,9 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             void (*kfused)(FusedCtx, int) =
                 e->ld <= JSLP_F_TW ? (unr ? (opt ? k_pivot_fused<1, true, true> : k_pivot_fused<1, true, false>)
                                           : (opt ? k_pivot_fused<1, false, true> : k_pivot_fused<1, false, false>))
-                                   : (unr ? (opt ? k_pivot_fused<2, true, true> : k_pivot_fused<2, true, false>)
-                                          : (opt ? k_pivot_fused<2, false, true> : k_pivot_fused<2, false, false>));
+                : e->ld <= 2 * JSLP_F_TW ? (unr ? (opt ? k_pivot_fused<2, true, true> : k_pivot_fused<2, true, false>)
+                                                : (opt ? k_pivot_fused<2, false, true> : k_pivot_fused<2, false, false>))
+                : e->ld <= 3 * JSLP_F_TW ? k_pivot_fused<3, false, false> : k_pivot_fused<4, false, false>;  // (fused_eligible: plain tableaus only beyond two tiles)
             int launch = 0;
             hipLaunchKernelGGL(kfused, dim3(f.G), dim3(JSLP_F_THREADS), 0, s, f, launch);
             launch++;
@@ -2008,6 +2028,8 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     // the pinned host buffer itself - the stores cross PCIe while the other workgroups compute
     DevState* o_states = e->d_states; double* o_rhs = e->d_rhs; int32_t* o_rows = e->d_rows;
     bool zc = zero_copy() != 0;
+    unsigned* polled_flag = nullptr;  // set when the call ends by polling a completion flag instead of synchronising the streams
+    unsigned polled_seq = 0;
     if (dev_out) { o_states = e->dev_states; o_rhs = e->dev_rhs; o_rows = e->dev_rows; zc = false; }
     if (zc) {
         void *ps = nullptr, *pr = nullptr, *pw = nullptr;
@@ -2058,10 +2080,26 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
                 hipLaunchKernelGGL((k_node_lds<1024, true>), dim3(g), dim3(1024), lds, s, e->s, sn, cu, first, check_cycles, cap,
                                    (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states,
                                    g_stride, first, (unsigned*)nullptr, 0u);
-            else if (lds && g <= small_1024)
+            else if (lds && g <= small_1024) {
+                // a batch that is ONE group, its outcomes written straight into pinned memory: the last workgroup raises the completion
+                // flag the host polls (below) instead of the two stream synchronisations that end the other shapes of this call
+                unsigned* d_flag = nullptr;
+                unsigned seq = 0;
+                if (g == n_nodes && zc && !dev_out && !e->ext_states && batch_poll_on()) {
+                    unsigned* h_flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e->h_state) + sizeof(DevState));
+                    void* flag_dev = nullptr;
+                    if (hipHostGetDevicePointer(&flag_dev, h_flag, 0) == hipSuccess) {
+                        d_flag = static_cast<unsigned*>(flag_dev);
+                        seq = ++e->done_seq ? e->done_seq : ++e->done_seq;  // never 0 (the flag's initial value)
+                        polled_flag = h_flag; polled_seq = seq;
+                    } else {
+                        (void)hipGetLastError();
+                    }
+                }
                 hipLaunchKernelGGL((k_node_lds<1024>), dim3(g), dim3(1024), lds, s, e->s, sn, cu, first, check_cycles, cap,
                                    (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states,
-                                   g_stride, first, (unsigned*)nullptr, 0u);
+                                   g_stride, first, d_flag, seq, d_flag ? e->d_done_count : (int*)nullptr);
+            }
             else if (lds)
                 hipLaunchKernelGGL((k_node_lds<512>), dim3(g), dim3(512), lds, s, e->s, sn, cu, first, check_cycles, cap,
                                    (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states,
@@ -2122,8 +2160,22 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
                                 sizeof(int32_t) * (size_t)g * row_stride, hipMemcpyDeviceToHost, e->copy_stream));
     }
     if (e->timing && wg) HIPC(hipEventRecord(e->ev_end, s));
-    HIPC(hipStreamSynchronize(e->copy_stream));
-    HIPC(hipStreamSynchronize(s));
+    bool arrived = false;
+    if (polled_flag) {  // the small batch's last workgroup ends with a system-scope release store of `polled_seq` into pinned memory
+        unsigned spins = 0;
+        const auto t_begin = std::chrono::steady_clock::now();
+        while (!(arrived = (__atomic_load_n(polled_flag, __ATOMIC_ACQUIRE) == polled_seq))) {
+            if ((++spins & 0x3fffu) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 5.0) break;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    if (!arrived) {  // every other shape -- and a polled batch that did not show up in 5 s: let the runtime report the fault
+        HIPC(hipStreamSynchronize(e->copy_stream));
+        HIPC(hipStreamSynchronize(s));
+    }
     if (wg && e->timing) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e->ev_begin, e->ev_end) == hipSuccess) e->total_ms += ms;

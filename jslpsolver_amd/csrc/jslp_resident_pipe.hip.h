@@ -33,73 +33,8 @@
 //   * pricing moved to the top of the loop (the loop is entered with the tableau whole and leaves a pending update to its epilogue);
 //   * 6 workgroup barriers per pivot instead of 8 (cycle check off).
 //
-// Measured on the way and left out (config 3a, pivots/s; r03_e ... r03_h): summary granules 16 / 64 / 128 bytes apart 160.4 k /
-// 161.7 k / 161.4 k (the micro-benchmark's 7.7 k -> 4.8 k cycles per chip-wide all-gather for one line per granule does not show
-// in the kernel); 8 / 16 / 32 copies of every granule, workgroup b polling copy b % n: 160.1 k / 161.4 k / 161.8 k against 162.2 k
-// for one; the first poll issued before the update pass: 128.6 k against 128.8 k at the time; 512 lanes x 4 columns: 145.6 k
-// against 161.7 k; candidate rows published only by the workgroup that holds the best summary of its XCD (summaries exchanged
-// once more through the XCD's own L2 -- plain store + sc1 load, tools/micro/xcd_handoff_bench.hip -- while the update runs:
-// ~8 rows of write-through per pivot instead of 256): 133.2 k against 161.3 k, the verdict arrives behind the update and the
-// 4 MB burst it removes was not what the gather waits for; pricing and ratio test sharing their barriers (round A: one DPP
-// maximum per wave + one LDS atomic into a per-batch slot; every wave holding a column with that value claims it and runs the
-// ratio test for its claim into a per-wave staging area; 4 barriers per pivot): 154.3 k against 161.7 k -- the wave-wide 64-bit
-// maximum in all 16 waves costs more than the two LDS-atomic rounds it replaces.
-// r03_u ... r03_w (against 156 k that day): pricing with ONE barrier in the common case -- the earliest batch rarely moves from one
-// pivot to the next, so only the one or two waves holding the previous pivot's batch reduce it (DPP), every wave leaves {batch,
-// value, column} in an LDS slot and its bit in a mask, after the barrier every thread reads the mask and the two slots that
-// matter (a second round when the guessed batch ran dry): the pricing section stays at 2.9 k cycles (what it costs is the
-// per-thread candidate logic x 16 waves and the skew the first barrier absorbs, not the second and third barrier); with every
-// thread scanning all sixteen slots instead: 111 k (40 instructions per slot x 16 waves = 5 k cycles of issue time).  The ratio
-// test (one wave) overlapped with the row update (the other fifteen), the candidate row published after the barrier that
-// follows: 146 k together with the above -- the row leaves later than from inside the pass.  Both in the 512-thread geometries
-// (256 VGPRs, 2-6 spilled): the builds lost pivots on the wide fuzz instances (tools/fuzz_resident.py 8 / 28 / 36) whichever
-// of the two was compiled in -- not the builds' fault, as it turned out: the changed timing opened the race in the row fetch that
-// step E's per-wave look at the flag now closes.
-// In-kernel counter of the debug build (tools/resident_phase_timing.py): 15-65 % of a workgroup's row fetches find the winner's
-// row flag not up yet and are repeated -- the flag leaves only after the winner's own gather and drain; publishing it earlier
-// needs the store acknowledgement (one more fabric trip) ahead of the gather.  Tried (r03_w, against 156 k): the row that can win
-// updated and stored FIRST, then drain + barrier + flag BEFORE the gather: the repeats go (44-146 of 9727), the fetch drops from
-// 3.3-5.4 k to 2.7 k cycles, but the acknowledgement of a write-through store takes ~4 k cycles and is not hidden by the 3 k of
-// the update pass: 134 k.  Candidate rows with the epoch tag INSIDE the data ({lo32 | tag}{hi32 | tag} per double, RCCL's LL
-// scheme: no flag, no drain, the fetch re-reads the 16-byte words whose tags are not up): correct, repeats 31-139 of 9727, but
-// twice the row bytes -- 8 MB of stores and an 8 MB fetch burst per pivot -- slow the gather's polls (2.2 k -> 3.8-4.8 k cycles)
-// and the fetch (3.3 k -> 4.0 k): 126 k.  What crosses the fabric per pivot is what the loop waits for.
-// The cycle check (0.7 us per pivot when on) moved out of its three barriers -- the twelve non-polling waves append the pair and
-// share the block lengths while the row loads of step E are in flight, twelve verdict words read under E's barrier: the check-on /
-// check-off ratio moves from 0.893 to 0.905 (r03_w), within the box-to-box spread; one wave for the whole test: 103 k (its ~76
-// dependent LDS reads late in a 9726-pivot solve outlast the row fetch).  Not kept.
-// Two looks in flight in the gather's poll and in the wait for the row flag (a look is a fabric round trip, so one at a time notices
-// the last summary half a round trip late on average): 140.0 k against 142.6 k -- the extra looks cost more than the earlier notice.
-// Round 4 (r04_a ... r04_o; profiles/r04_*): (1) the XCD-LOCAL build (`XL`: <= 32 workgroups of ONE XCD, 512 lanes x 2 columns x 32 rows,
-// hand-offs through that XCD's L2 with plain stores + sc1 loads, rows with the epoch tag inside the data -- no flag, no drain, no fence;
-// 0 repeated row fetches in every run).  As first instantiated from these loops it was SLOWER than the chip-wide kernel (8.6-10 us per
-// pivot against 6.0 on 501 x 501 / 1001 x 1001): JSLP_PIPE_UPDATE_ROW costs ~55 instructions per row, 10-13 k cycles per pass at 32
-// rows.  With the update pass restructured (one ballot for the row gate, readlane multipliers: 3.9-5.9 k cycles), the tagged rows and
-// quot read with the fetch it is at PARITY -- 5.97 / 6.36 us against 5.98 / 6.05, Monster LP 428 against 411 us in one LDS workgroup,
-// Monster_II's root 440 against 448 us (profiles/r04_xl_times.md) -- on an eighth of the chip: a pivot of these loops is bound by the
-// instruction stream of ~2500 instructions per wave (sections of 1-2 k cycles each whatever the transport: profiles/r04_xl_phase_timing.txt),
-// not by the hand-offs the XCD-local transport shortens.  Opt-in (JSLP_XL=1).  Tried on the way: 256 lanes x 4 columns (one wave per
-// SIMD): 22.6 k cycles per pivot against 14.9 k; a second, gate-free copy of the update loop for dense pivot rows: 365-560 VGPR
-// spills (the register allocator keeps both arms' copies of the 128 tableau registers); the column gate as an EXEC-masked branch per
-// cell: 5.1-8.5 k cycles per pass against 3.9-5.9 k.  (2) WINNER-ONLY tagged row for the chip-wide loops (JSLP_PIPE_WINNER_LL=1: no
-// candidate rows, no drain, no fence, no flag; 32 KB instead of 4 MB per pivot; a one-word probe per wave before the row is read):
-// correct, 117.4 k against 147.6 k pivots/s on config 3a, 103 k against 143 k on 3b -- a store issued AFTER the decision takes a
-// write-through to memory plus a poll to arrive, which the speculative rows have behind them by then (profiles/
-// r04_headline_winner_only_tagged_row.txt).  (3) quot read by every wave next to its columns of the row instead of the LDS broadcast +
-// barrier behind the fetch (JSLP_PIPE_QUOT_DIRECT=1): 148.5 k against 147.6 k with the cycle check off, 130.9 k against 133.8 k with it
-// on (profiles/r04_headline_quot_direct.txt): off.  (4) UNRESTRICTED VARIABLES in these loops (`UNR`) and optional objectives in the
-// tall geometry: the 4001 x 2001 golden with 50 unrestricted variables 105.7 k pivots/s (fused pipeline: 32-35 k), the 3001 x 2031
-// golden with three objective rows 104 k (40.6 k) -- both the reference's own digests.
-// Round 4, later (r04_u ... r04_z; config 3a 154.0 k at the start): the ratio test's transposition through LDS (+2.7 %), the XCD-local
-// build's update pass for the 2- / 4-column geometries (+4.6 %), the global maps and the trace through a device-side copy of the context
-// instead of eight live pointers (166.5 k).  Then the hand-over itself: (5) the CHECKSUMMED row (JSLP_PIPE_ROW_CHECKSUM, below) -- what
-// round 3's release fence made sound by ordering, the reader now verifies end to end; with flag word and row loaded in ONE look (0
-// repeated looks on config 3a, 0.3 % of the looks on 4001 x 2001) the winner's fence (measured at 0.15 us by leaving it out: 165.8 k ->
-// 170.2 k, unsound), the flag's own trip and the drain are gone: 168.5-171.4 k with the cycle check off, 143.5 k -> 155 k with it on,
-// 4001 x 2001 120 k -> 124 k.  The section that remains (decide + fetch: 3.3-3.6 k cycles, every look answered first time) is one trip
-// to memory and back under 4096 waves asking for the same 16 KB.  (6) looks at the summaries issued during the row update
-// (JSLP_PIPE_EARLY_LOOKS): slower, see there.  (7) pricing folded in registers instead of LDS atomics, two forms: slower, see
-// price_row_lds (jslp_resident.hip.h).
+// (The lab notebook of these loops -- every variant measured and left out in rounds 3 and 4, with its numbers -- lives in DESIGN.md,
+//  "Appendix: experiments on the lean pipelined loops"; the switches it refers to are the JSLP_PIPE_* macros below.)
 // ===================================================================================================================
 // -DJSLP_CHAOS_BUILD (tests / diagnosis only, never the shipped library): at every phase boundary of the pipelined loops one wave of
 // the workgroup -- a different one per pivot and boundary -- sleeps ~6 k cycles (JSLP_TEST_RESIDENT_LATE_WAVE0=2), and with =3 every

@@ -987,16 +987,26 @@ template <int THREADS, bool OPT = false, bool COW = false>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? JSLP_NODE512_WAVES : 4) k_node_lds(Slots s, Snapshot snap, Cuts cuts, int first_node, int check_cycles,
                                                       int iters_cap, int cap_rows, double* rhs_out, int32_t* rows_out,
                                                       DevState* state_out, int out_stride, int first_out,
-                                                      unsigned* done_flag, unsigned done_seq) {
+                                                      unsigned* done_flag, unsigned done_seq, int* done_count = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     __shared__ SmemL sm;
     const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
     const bool ran = node_lds_run<THREADS, COW, OPT>(s, snap, cuts, sm, L, blockIdx.x, first_node + blockIdx.x, first_out + blockIdx.x, check_cycles,
                                                      iters_cap, cap_rows, rhs_out, rows_out, state_out, out_stride);
     if (done_flag) {
+        // (round 5: a small BATCH announces itself the same way -- every workgroup makes its outcome visible system-wide and counts itself
+        //  in; the one that completes the count raises the flag the host polls: no stream synchronisation, whose wake-up costs a
+        //  speculative tree tens of microseconds per dependent batch)
         __threadfence_system();
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) {
+            bool last = true;
+            if (done_count) {
+                last = atomicAdd(done_count, 1) == (int)gridDim.x - 1;
+                if (last) { *done_count = 0; __threadfence_system(); }  // (the next launch is ordered behind this one on the stream)
+            }
+            if (last) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (COW && ran && blockIdx.x == 0) slot0_whole_again(s, snap, sm, L);
 }

@@ -118,10 +118,11 @@ def test_hip_equals_oracle_on_edge_shapes(hip_lib, hip_hooks_lib, oracle_lib, mo
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["auto", "fused", "sp", "resident"])
 @pytest.mark.parametrize("phase1", [False, True], ids=["phase2", "phase1"])
-@pytest.mark.parametrize("shape", [(3000, 40), (30, 2500), (2300, 300), (4000, 200), (4500, 60)])
+@pytest.mark.parametrize("shape", [(3000, 40), (30, 2500), (2300, 300), (4000, 200), (4500, 60), (40, 5000), (40, 7000), (500, 4300)])
 def test_hip_equals_oracle_beyond_the_register_resident_sizes(hip_lib, oracle_lib, mode, shape, phase1):
     """taller than 8 x 256 rows (the tall register-resident geometry, 16 rows per workgroup, up to 4096 rows; several row
-    groups per workgroup in the fused kernel beyond that) and wider than 2048 columns (falls back to select + update)"""
+    groups per workgroup in the fused kernel beyond that) and wider than 2048 columns (two column tiles per lane; round 5: three and
+    four tiles -- 4096 < ld <= 8192, `k_pivot_fused<3|4>` / `k_fused_p1<3|4>` -- where round 4 fell back to select + update)"""
     m, n = shape
     if phase1 and shape == (2300, 300):
         pytest.skip("25771 phase-1 pivots: 40 s on the CPU oracle; the other shapes cover the path")

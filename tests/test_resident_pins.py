@@ -177,7 +177,7 @@ def test_resident_abort_on_the_tall_and_wide_geometries_finishes_through_the_fus
     assert out[0] == out[1]
 
 
-STREAMING = [("int", 5000, 3000, "fused"), ("int", 5000, 2000, "fused"), ("int", 3000, 5000, "select+update")]
+STREAMING = [("int", 5000, 3000, "fused"), ("int2p", 5000, 3000, "fused"), ("int", 5000, 2000, "fused"), ("int", 3000, 5000, "fused")]
 
 
 def test_streaming_path_expectations_exist():
@@ -193,7 +193,7 @@ def test_streaming_path_expectations_exist():
 @pytest.mark.parametrize("kind,m,n,path", STREAMING, ids=lambda v: str(v))
 def test_default_policy_beyond_the_register_file_is_the_known_answer(hip_lib, kind, m, n, path):
     """5001 x 3001 (`k_pivot_fused<2>`; with a phase 1: `k_fused_p1<2>` first), 5001 x 2001 (`k_pivot_fused<1>`), 3001 x 5001 (ld > 4096:
-    `k_select` + `k_update` for both phases) through the DEFAULT policy: pivot count, pivot digest and the sha256 of every double of the final
+    three column tiles per lane, `k_pivot_fused<3>` -- `k_select` + `k_update` until round 5) through the DEFAULT policy: pivot count, pivot digest and the sha256 of every double of the final
     tableau equal the known answer (tests/golden/stress_expect.json: the C restatement, itself pinned against the reference's goldens -- the
     reference under node would take hours at these sizes), the path is the streaming one and no register-resident launch happened
     (simplex.ts:330-413 at H x W > 9 M cells)"""

@@ -131,7 +131,7 @@ def stream(kind, m, n, key):
 WORKLOADS = {
     "stream_5001x3001": lambda: stream("int", 5000, 3000, "stream_5001x3001"),      # k_pivot_fused<2>
     "stream_5001x2001": lambda: stream("int", 5000, 2000, "stream_5001x2001"),      # k_pivot_fused<1>
-    "stream_3001x5001": lambda: stream("int", 3000, 5000, "stream_3001x5001"),      # ld > 4096: k_select + k_update
+    "stream_3001x5001": lambda: stream("int", 3000, 5000, "stream_3001x5001"),      # ld > 4096: k_pivot_fused<3> (JSLP_FUSED_WIDE=0: k_select + k_update)
     "stream2p_5001x3001": lambda: stream("int2p", 5000, 3000, "stream2p_5001x3001"),  # k_fused_p1<2> first
     "3a": lambda: dense("ra", 2000, 2000, False, key="3a"),
     "3a_check": lambda: dense("ra", 2000, 2000, True, key="3a_check"),

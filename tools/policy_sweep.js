@@ -24,6 +24,7 @@ function nnzOf(model) {  // what structuralNnz() counts from the Model: one per 
 }
 for (const [n, m] of sizes) for (const d of densities) {
     if (n * m * d < 150) continue;  // (nearly empty models: the generator leaves variables without a single coefficient)
+    if (d < 0.5 && n * m > (Number(process.env.JSLP_SWEEP_MAX_SPARSE_CELLS) || 70000)) continue;  // (the CPU leg of the sparser big ones takes minutes per solve)
     const model = gen.generateResourceAllocation({ seed: 7, numVariables: n, numConstraints: m, density: d });
     cases.push({ label: "LP " + n + " x " + m + " @ " + d, cells: (n + 1) * (m + 1), nnz: nnzOf(model), model });
 }
@@ -33,10 +34,15 @@ for (const f of ["Monster_Problem"]) {  // BASELINE config 2
 }
 const med = (a) => a.slice().sort((x, y) => x - y)[a.length >> 1];
 function time(model, reps) {
-    // (bounded: the big dense ones take a second per solve on the CPU -- three warm-up solves, then at most `reps` timed ones or ~2 s of them)
-    for (let i = 0; i < 3; i++) solver.Solve(JSON.parse(JSON.stringify(model)));
+    // bounded: a sparse-ish 300 x 225 LP takes the reference 20-40 s PER SOLVE on the CPU (thousands of pivots on a tableau that fills in).
+    // A first solve that takes more than half a second is the sample; otherwise two more warm-ups, then the median of <= reps (<= ~2 s).
+    const t00 = process.hrtime.bigint();
+    let r = solver.Solve(JSON.parse(JSON.stringify(model)));
+    const first = Number(process.hrtime.bigint() - t00) / 1e6;
+    if (first > 500) return [first, r.result, r.feasible];
+    for (let i = 0; i < 2; i++) solver.Solve(JSON.parse(JSON.stringify(model)));
     const a = [];
-    let r, spent = 0;
+    let spent = 0;
     for (let i = 0; i < reps; i++) {
         const mm = JSON.parse(JSON.stringify(model));
         const t0 = process.hrtime.bigint();
