@@ -433,6 +433,46 @@ def main():
                                          "pivot_digest": d1, "kernel": t1.last_path()}
             t1.close()
 
+        # ---- the STREAMING path at a size that takes it by default (round 5): 5001 x 3001 does not fit the chip's vector registers, so the
+        #      default policy runs one k_pivot_fused<2> launch per pivot -- 16 x H x W algorithmic bytes each: the kernel north_star's
+        #      ">= 40 % of the HBM roofline" literally describes.  One solve (30 844 pivots), checked against the instance's known answer
+        #      (tests/golden/stress_expect.json: data, written by tests/golden/gen_stress_expect.py), kernel time from HIP events per launch.
+        if rank == 0 and not args.no_extras and n >= 2000:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import known_answers as KA
+            from resident_stress import int_instance
+            ms_, ns_ = 5000, 3000
+            want_s = KA.expected_stress("int", ms_ + 1, ns_ + 1, 12345)
+            As, vr_s, vc_s = int_instance(ms_, ns_, 12345)
+            ts_ = Tableau(As, vr_s, vc_s, device=device_index, lib=lib)
+            ts_.set_timing(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rs_ = ts_.simplex(check_cycles=False)
+            wall_s = time.perf_counter() - t0
+            k_ms, k_launches, _tot = ts_.get_timing()
+            ts_.set_timing(False)
+            sig = KA.solve_signature(ts_, rs_, pivot_digest)
+            cs_ = ts_.get_counters()
+            path_s = ts_.last_path()
+            ts_.close()
+            if want_s is None or (sig["pivots"], sig["digest"], sig["final_sha"]) != (want_s["pivots"], want_s["digest"], want_s["final_sha"]):
+                raise WrongAnswer("streaming instance 5001x3001: %s, known answer %s" % ({k: sig[k] for k in ("pivots", "digest")}, want_s and {k: want_s[k] for k in ("pivots", "digest")}))
+            bytes_unit = 16.0 * As.shape[0] * As.shape[1]
+            extras["streaming_instance"] = {
+                "workload": "dense integer LP 5001x3001 fp64 (tools/resident_stress.py int, seed 12345): beyond the register file, DEFAULT policy, cycle check off, one solve, timing events on",
+                "kernel": "k_pivot_fused<2>" if path_s == "fused" else path_s, "path": path_s, "pivots": sig["pivots"], "pivot_digest": sig["digest"],
+                "checked_against": "tests/golden/stress_expect.json (pivot count, digest, sha256 of the final tableau)",
+                "resident_launches": cs_["resident_launches"],
+                "roofline": {"bound": "hbm", "achieved": bytes_unit * k_launches / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None, "peak": (HBM_PEAK / 1e9), "unit": "GB/s",
+                             "frac": (bytes_unit * k_launches / (k_ms * 1e-3) / 1e9 / (HBM_PEAK / 1e9)) if k_ms > 0 else None,
+                             "bytes_per_unit": bytes_unit, "unit_of_work": "one pivot = one launch", "launches_timed": int(k_launches),
+                             "avg_launch_us": (1e3 * k_ms / k_launches) if k_launches else None,
+                             "traffic": "profiles/r05_streaming_workload_rows.md: PMC FETCH_SIZE x2 + WRITE_SIZE = 1.008 x algorithmic on this workload"},
+                "whole_solve": {"pivots_per_s": sig["pivots"] / wall_s, "seconds": wall_s,
+                                "frac_of_hbm_roofline": bytes_unit * sig["pivots"] / wall_s / 1e9 / (HBM_PEAK / 1e9),
+                                "note": "host clock around simplex(): launch gaps, state polls and the per-launch timing events included"}}
+
         if rank == 0:
             line = {
                 "metric": "simplex pivots/sec", "value": value, "unit": "pivots/s", "n_gpus": world, "steps": args.steps,
@@ -595,7 +635,7 @@ def relaxation_legs(ctx, args, reps=16):
     if rank == 0:
         lat = {}
         for n_small in (1, 8, 16):
-            sub = nodes[3:3 + n_small]  # (a dive of the reference's tree: nodes 3.. carry 2-5 cuts each)
+            sub = mine[3:3 + n_small]  # (this rank's share -- what res_w / rows_w_keep hold; at N = 1 a dive of the reference's tree: nodes 3.. carry 2-5 cuts each)
             packed_s = t.pack_cut_lists(sub)
             fns = lambda: t.applyCutsBatchWatched(None, check_cycles=True, packed=packed_s, copy=False)
             for _ in range(5):

@@ -70,20 +70,41 @@ function structuralNnz(t) {
     for (let i = 0; i < vs.length; i++) if (vs[i].cost !== 0) n += 1;
     return n;
 }
+// An LP below the non-zero threshold is not necessarily cheap: a sparse RANDOM 300 x 225 LP with 3.9 k non-zeros fills in and takes the
+// reference 11.9 s (thousands of pivots) where the engine takes 24 ms, while the structured Monster LP with 3.4 k non-zeros is done in 60
+// pivots (profiles/r05_policy_sweep.md).  The count cannot tell them apart, so such an LP STARTS on the reference's own path with a time
+// budget (ski rental: cpuBudgetMs, default 3 ms = several times the engine's fixed cost per Solve, and 4x what Monster LP needs); when the budget runs out the solve
+// is abandoned, the tableau is built again -- this time in the engine's pinned buffer -- and solved on the engine FROM THE START, so the
+// answer and the pivot sequence are the reference's whichever side finishes.  (Continuing the half-done tableau on the engine would
+// re-enter phase 1, which the reference never does in mid-phase 2.)  LPs with optional objectives are not deferred (an aborted run
+// leaves their reducedCosts rows modified, and setModel does not rebuild the slack columns' entries).
+const DEFAULT_CPU_BUDGET_MS = 3;
+const BAIL = { bail: true };  // thrown by the pivot() wrapper when a deferred LP's budget is spent
+function lpBelowNnz(t, opts) {
+    if (!(opts.minCells === undefined || opts.minNnz !== undefined)) return false;
+    const minNnz = opts.minNnz !== undefined ? opts.minNnz : DEFAULT_MIN_NNZ_LP;
+    const nInts = t.model ? t.model.getNumberOfIntegerVariables() : 0;
+    if (!(minNnz > 0 && nInts === 0)) return false;
+    const nnz = structuralNnz(t);
+    return nnz >= 0 && nnz < minNnz;
+}
 function eligible(t, opts) {
     if (bypass !== 0) return false;
     const min = minCellsFor(t, opts);
     if (min > 0 && t.width * t.height < min) return false;
+    if (t.__gpuForce === true) return true;  // (a deferred LP whose CPU budget ran out: to the engine, whatever it counts)
     // LPs: by work, not by area (MILPs keep the cell rule: their trees re-solve the same tableau hundreds of times)
-    if (opts.minCells === undefined || opts.minNnz !== undefined) {
-        const minNnz = opts.minNnz !== undefined ? opts.minNnz : DEFAULT_MIN_NNZ_LP;
-        const nInts = t.model ? t.model.getNumberOfIntegerVariables() : 0;
-        if (minNnz > 0 && nInts === 0) {
-            const nnz = structuralNnz(t);
-            if (nnz >= 0 && nnz < minNnz) return false;
-        }
-    }
+    if (lpBelowNnz(t, opts)) return false;
     return true;
+}
+// may this tableau, kept off the engine by the non-zero rule, still move there when its CPU solve runs long?
+function deferrable(t, opts) {
+    if (bypass !== 0 || t.__gpuForce === true) return false;
+    const budget = opts.cpuBudgetMs !== undefined ? opts.cpuBudgetMs : DEFAULT_CPU_BUDGET_MS;
+    if (!(budget > 0) || !t.model) return false;
+    const min = minCellsFor(t, opts);
+    if (min > 0 && t.width * t.height < min) return false;
+    return lpBelowNnz(t, opts) && t.optionalObjectives.length === 0;
 }
 
 // the engine of a tableau whose dimensions are known (Tableau.initialize ran); the upload follows in activate()
@@ -101,7 +122,7 @@ function activate(t, opts) {
     if (t.__gpuReleased) throw new Error("[gpu-tableau] this tableau's engine was released when Solve() returned; " +
         "use Solve(model, precision, true) (or model.solve()) to keep working with the tableau");
     if (!eligible(t, opts)) {
-        t.__gpu = { active: false };
+        t.__gpu = { active: false, deferred: deferrable(t, opts) };
         return t.__gpu;
     }
     // built in the engine's pinned buffer by the initialize() override?  (same dimensions, nothing appended since)
@@ -183,6 +204,7 @@ function dropEngine(t, st, keepMatrix) {
     st.active = false;
 }
 
+const stats = { deferredToEngine: 0 };  // deferred LPs whose CPU budget ran out (tests / tools read it)
 let installedOpts = {};
 function state(t, opts) {
     return t.__gpu || activate(t, opts || installedOpts);
@@ -344,6 +366,18 @@ function install(Tableau, options) {
             return origEditing[name].apply(this, arguments);
         };
     }
+    // pivot() is also what the reference's own phase loops call (simplex.ts:95, 322): a deferred LP's time budget is checked behind
+    // every eighth pivot, i.e. in a consistent state between two iterations
+    if (origEditing.pivot) {
+        const pivotThenHome = P.pivot;
+        P.pivot = function (r, c) {
+            const b = this.__gpuBudget;
+            if (b === null || b === undefined) return pivotThenHome.call(this, r, c);
+            origEditing.pivot.call(this, r, c);
+            b.pivots += 1;
+            if ((b.pivots & 7) === 0 && process.hrtime.bigint() - b.t0 > b.ns) throw BAIL;
+        };
+    }
     const origCopy = P.copy;
     P.copy = function () {
         const st = this.__gpu;
@@ -396,6 +430,24 @@ function install(Tableau, options) {
 
     P.simplex = function () {
         const st = state(this, opts);
+        if (!st.active && st.deferred === true && this.simplexIters === 0) {
+            // a small-count LP: the reference's own loop with a time budget (see `deferrable`); the pivot() wrapper below throws BAIL
+            const budgetMs = opts.cpuBudgetMs !== undefined ? opts.cpuBudgetMs : DEFAULT_CPU_BUDGET_MS;
+            this.__gpuBudget = { t0: process.hrtime.bigint(), ns: BigInt(Math.round(budgetMs * 1e6)), pivots: 0 };
+            try {
+                return orig.simplex.call(this);
+            } catch (e) {
+                if (e !== BAIL) throw e;
+            } finally {
+                this.__gpuBudget = null;
+            }
+            // budget spent: the same model once more, built in the engine's pinned buffer, solved there from the first pivot
+            stats.deferredToEngine += 1;
+            this.__gpuForce = true;
+            this.__gpu = undefined;
+            this.setModel(this.model);  // (initialize override: engine + pinned matrix; _resetMatrix: the reference's own builder)
+            return this.simplex();
+        }
         if (!st.active) return orig.simplex.call(this);
         const check = this.model ? this.model.checkForCycles === true : false;
         let res;
@@ -815,7 +867,7 @@ function usesPool() {
 
 const api = {
     loadEngine, install, sync, pivotTrace, release, guardIncremental, createCheckpoint, relaxFromCheckpoint, releaseCheckpoint,
-    relaxBatch, relaxBatchWatched, commitOutcome, commitWatched, usesPool, isOnEngine, bringHome, structuralNnz,
+    relaxBatch, relaxBatchWatched, commitOutcome, commitWatched, usesPool, isOnEngine, bringHome, structuralNnz, stats,
     backend: () => backend,
 };
 module.exports = api;

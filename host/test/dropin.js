@@ -369,7 +369,9 @@ for (const devices of [null, [0, 0, 0, 0]]) if (!filter && dir.indexOf("fixtures
 let policyOk = 0;
 if (!filter && dir.indexOf("fixtures") >= 0) {
     uninstall();
-    uninstall = gpu.install(Tableau, { SlackVariable, solver });  // nothing but the defaults: size policy + 16-node speculative batches
+    // (nothing but the defaults: size policy + 16-node speculative batches -- except the CPU time budget of deferred LPs, which is made
+    //  generous here so that the ROUTING is what is checked, whatever the speed of the box; the budget itself is exercised below)
+    uninstall = gpu.install(Tableau, { SlackVariable, solver, cpuBudgetMs: 60000 });
     // (round 5: LPs go by their structural non-zeros -- Monster LP, 345 k cells but 3.4 k non-zeros, stays on the reference's own path;
     //  a dense generated LP of 19 k cells / ~15 k non-zeros goes to the engine)
     for (const [f, expectOnEngine] of [["Knapsack_1", false], ["LargeFarmMIP", false], ["Monster_II", true], ["Monster_Problem", false], ["@denseLP", true]]) {
@@ -388,7 +390,32 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
         }
     }
 }
-console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, strategy_variants_ok: strategyOk,
+// a deferred LP whose CPU budget runs out (made to: 0.001 ms): abandoned on the reference's path, rebuilt in the engine's pinned buffer and
+// solved there from the first pivot -- the reference's result object and the reference's pivot digest; with a generous budget the same LP
+// finishes on the CPU and no engine is created
+let deferOk = 0;
+if (!filter && dir.indexOf("fixtures") >= 0) {
+    for (const [budget, expectOnEngine] of [[0.001, true], [60000, false]]) {
+        uninstall();
+        uninstall = gpu.install(Tableau, { SlackVariable, solver, cpuBudgetMs: budget });
+        const g = loadGolden(dir, "Monster_Problem.json.gz");
+        const before = gpu.stats.deferredToEngine;
+        const solution = solver.Solve(JSON.parse(JSON.stringify(g.model)), undefined, true);
+        const trace = gpu.pivotTrace(solution._tableau);
+        const onEngine = trace !== null;
+        let digestOk = true;
+        if (onEngine) {
+            let h = 2166136261;
+            for (let i = 0; i < trace.length; i++) h = Math.imul(h ^ trace[i], 16777619);
+            digestOk = (h >>> 0).toString(16) === g.pivotDigest && trace.length === 2 * g.nPivots;
+        }
+        gpu.release(solution._tableau);
+        const sameResult = JSON.stringify(solver.buildSimplifiedResult(solution).result) === JSON.stringify(g.result.result);
+        if (onEngine === expectOnEngine && sameResult && digestOk && (gpu.stats.deferredToEngine - before === (expectOnEngine ? 1 : 0))) deferOk += 1;
+        else { fail += 1; console.log("FAIL deferred LP, budget", budget, "on engine:", onEngine, "same result:", sameResult, "digest:", digestOk); }
+    }
+}
+console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, defer_ok: deferOk, strategy_variants_ok: strategyOk,
     incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk, lookahead_ok: lookaheadOk, lookahead_ran: lookaheadNodes > 0,
     size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, instance_ok: instanceOk, cycle_ok: cycleOk, pool_ok: poolOk, pool_full_ok: poolFullOk, watched_ok: watchedOk, pool_watched_ok: poolWatchedOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);

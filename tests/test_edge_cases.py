@@ -118,7 +118,7 @@ def test_hip_equals_oracle_on_edge_shapes(hip_lib, hip_hooks_lib, oracle_lib, mo
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["auto", "fused", "sp", "resident"])
 @pytest.mark.parametrize("phase1", [False, True], ids=["phase2", "phase1"])
-@pytest.mark.parametrize("shape", [(3000, 40), (30, 2500), (2300, 300), (4000, 200), (4500, 60), (40, 5000), (40, 7000), (500, 4300)])
+@pytest.mark.parametrize("shape", [(3000, 40), (30, 2500), (2300, 300), (4000, 200), (4500, 60), (40, 5000), (40, 7000), (200, 4300)])
 def test_hip_equals_oracle_beyond_the_register_resident_sizes(hip_lib, oracle_lib, mode, shape, phase1):
     """taller than 8 x 256 rows (the tall register-resident geometry, 16 rows per workgroup, up to 4096 rows; several row
     groups per workgroup in the fused kernel beyond that) and wider than 2048 columns (two column tiles per lane; round 5: three and
@@ -126,6 +126,8 @@ def test_hip_equals_oracle_beyond_the_register_resident_sizes(hip_lib, oracle_li
     m, n = shape
     if phase1 and shape == (2300, 300):
         pytest.skip("25771 phase-1 pivots: 40 s on the CPU oracle; the other shapes cover the path")
+    if phase1 and shape == (200, 4300):
+        pytest.skip("minutes on the CPU oracle; k_fused_p1<3> is pinned at full size by tests/test_resident_pins.py (int2p 3001 x 5001: 100 phase-1 pivots)")
     rng = np.random.default_rng(m * 7 + n)
     A = np.zeros((m + 1, n + 1))
     A[1:, 1:] = rng.integers(1, 9, (m, n)) * (rng.random((m, n)) < 0.6)

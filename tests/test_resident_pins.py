@@ -177,7 +177,7 @@ def test_resident_abort_on_the_tall_and_wide_geometries_finishes_through_the_fus
     assert out[0] == out[1]
 
 
-STREAMING = [("int", 5000, 3000, "fused"), ("int2p", 5000, 3000, "fused"), ("int", 5000, 2000, "fused"), ("int", 3000, 5000, "fused")]
+STREAMING = [("int", 5000, 3000, "fused"), ("int2p", 5000, 3000, "fused"), ("int", 5000, 2000, "fused"), ("int", 3000, 5000, "fused"), ("int2p", 3000, 5000, "fused")]
 
 
 def test_streaming_path_expectations_exist():

@@ -57,8 +57,6 @@ for (const c of cases) { const [ms, res, feas] = time(c.model, 9); c.cpu = ms; c
 gpu.loadEngine(process.argv[2] ? { library: path.resolve(process.argv[2]) } : {});
 const addon = require(path.join(root, "addon/jslp_napi.node"));
 let uninstall = gpu.install(T, { SlackVariable, solver, minCells: 0, speculate: 0 });
-console.log("| model | cells | structural nnz | reference on CPU (ms) | reference host + engine (ms) | engine / CPU | inside the binding (ms: create+pin / upload / simplex / read-back / release) | default policy sends it to | same result |");
-console.log("|---|---|---|---|---|---|---|---|---|");
 for (const c of cases) {
     time(c.model, 3);
     addon.timings(true);
@@ -71,16 +69,26 @@ for (const c of cases) {
     c.same = res === c.res && feas === c.feas;
     c.phases = phases;
 }
-// what the DEFAULT policy does with each (install() without minCells)
+// what the DEFAULT policy does with each (install() without minCells): where it ends up, whether it got there through the CPU time budget of
+// a deferred LP (host/gpu-tableau.js `deferrable`), and what the Solve() costs that way
 uninstall();
 uninstall = gpu.install(T, { SlackVariable, solver });
 for (const c of cases) {
+    const before = gpu.stats.deferredToEngine;
     const solution = solver.Solve(JSON.parse(JSON.stringify(c.model)), undefined, true);
     c.onEngine = gpu.pivotTrace(solution._tableau) !== null;
+    c.viaBudget = gpu.stats.deferredToEngine > before;
     c.nnz = gpu.structuralNnz(solution._tableau);  // (exactly what the policy counted)
     gpu.release(solution._tableau);
+    const [ms, res, feas] = time(c.model, 9);
+    c.defMs = ms;
+    c.same = c.same && res === c.res && feas === c.feas;
 }
+console.log("| model | cells | structural nnz | reference on CPU (ms) | everything on the engine, minCells 0 (ms) | engine / CPU | inside the binding, engine run (ms: create+pin / upload / simplex / read-back / release) | DEFAULT policy: where | DEFAULT policy (ms) | default / best of the two | same result |");
+console.log("|---|---|---|---|---|---|---|---|---|---|---|");
 for (const c of cases) {
+    const best = Math.min(c.cpu, c.engine);
     console.log("| " + c.label + " | " + c.cells + " | " + c.nnz + " | " + c.cpu.toFixed(2) + " | " + c.engine.toFixed(2) + " | " + (c.engine / c.cpu).toFixed(2) + " | " +
-        c.phases.map((x) => x.toFixed(3)).join(" / ") + " | " + (c.onEngine ? "engine" : "CPU") + (c.onEngine === (c.engine < c.cpu) ? "" : " (!)") + " | " + c.same + " |");
+        c.phases.map((x) => x.toFixed(3)).join(" / ") + " | " + (c.onEngine ? (c.viaBudget ? "CPU for the budget, then engine" : "engine") : "CPU") + " | " + c.defMs.toFixed(2) + " | " +
+        (c.defMs / best).toFixed(2) + " | " + c.same + " |");
 }
