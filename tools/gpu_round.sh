@@ -45,6 +45,7 @@ for s in $steps; do
     ab) (for l in base noabort; do echo "== dense LPs, build/libjslp_dev_$l.so"; JSLP_HIP_LIBRARY=build/libjslp_dev_$l.so timeout 200 python tools/dense_lp_times.py; done
          for l in base nopf; do echo "== node latency, build/libjslp_dev_$l.so"; JSLP_HIP_LIBRARY=build/libjslp_dev_$l.so timeout 200 python tools/node_latency.py; done
          echo "== shipped library"; timeout 200 python tools/dense_lp_times.py; timeout 200 python tools/node_latency.py $out/node_latency.md) > $out/ab.log 2>&1 < /dev/null; echo "ab rc=$?"; cat $out/ab.log ;;
+    cpufull) timeout 400 node --max-old-space-size=8192 oracle/ref_pivot_rate.js 2000 1000000 > $out/cpu_full_run.json 2> $out/cpu_full_run.err < /dev/null; echo "cpufull rc=$?"; cat $out/cpu_full_run.json ;;
     nodelat) timeout 200 python tools/node_latency.py $out/node_latency.md > $out/node_latency.log 2>&1 < /dev/null; echo "nodelat rc=$?"; cat $out/node_latency.md ;;
     retest) timeout 1200 python -m pytest tests -m gpu -q -k "xl or xcd or virtual_shards or chaos or beyond_the_register or host_requested or rccl" > $out/retest.log 2>&1 < /dev/null; echo "retest rc=$?"; tail -12 $out/retest.log ;;
     sweep) timeout 600 node tools/mincells_sweep.js > $out/mincells_sweep.md 2> $out/mincells_sweep.err < /dev/null; echo "sweep rc=$?"; cat $out/mincells_sweep.md ;;
