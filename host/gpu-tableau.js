@@ -63,11 +63,15 @@ function minCellsFor(t, opts) {
 function structuralNnz(t) {
     const m = t.model;
     if (!m || !m.constraints || !m.variables) return -1;
+    // (counted once per built tableau: initialize() and the first simplex() both ask)
+    const c = t.__gpuNnz;
+    if (c !== undefined && c.model === m && c.nc === m.constraints.length && c.nv === m.variables.length) return c.n;
     let n = 0;
     const cs = m.constraints;
     for (let i = 0; i < cs.length; i++) n += cs[i].terms.length + (cs[i].rhs !== 0 ? 1 : 0);
     const vs = m.variables;
     for (let i = 0; i < vs.length; i++) if (vs[i].cost !== 0) n += 1;
+    t.__gpuNnz = { model: m, nc: cs.length, nv: vs.length, n };
     return n;
 }
 // An LP below the non-zero threshold is not necessarily cheap: a sparse RANDOM 300 x 225 LP with 3.9 k non-zeros fills in and takes the

@@ -128,6 +128,7 @@ struct SmemL {
     int32_t red_i[2][16];
     int2 hist[WGL_HIST];    // first entries of the cycle-check history (simplex.ts:415-440): the suffix test runs on them
     int32_t n_list;         // length of the gated-row list
+    int32_t cyc_hit;        // verdict of the cycle check while the history fits `hist` (wave 0 decides it alone)
 };
 // Only the first WGL_SEL threads (four waves, one per SIMD) take part in a selection: a wave-level reduction costs every
 // wave its ~60 instructions whether it holds candidates or not, and at 16 waves per workgroup that issue time -- not memory --
@@ -507,14 +508,42 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
         // cycle check (simplex.ts:78-93 / 305-320): append first, test, stop WITHOUT pivoting on a hit
         if (c.check_cycles) {
             if (hist_n >= c.hist_cap) { outcome = 6; break; }
-            if (tid == 0) {
-                const int2 pair = make_int2(leaving, entering);
-                c.hist[hist_n] = pair;  // the host rebuilds the reference's [start, length] message from the global copy
-                if (hist_n < WGL_HIST) sm.hist[hist_n] = pair;
+            // Round 5: while the history fits its LDS copy (the first WGL_HIST pairs: every node of a tree, every small LP) the suffix test
+            // is WAVE 0's alone -- lane L tests block length L (and L + 64) on the LDS copy, one ballot, the verdict rides the barrier
+            // that completes the gated-row list anyway.  The block-wide form (suffix_is_square: every thread through the test's loop
+            // bounds, then a __syncthreads_or) cost 2.7 k cycles per pivot of a single node and 9 k per pivot in the batch kernel
+            // (profiles/r02_wglds_sections.md: 9 % of a node either way) for histories of five or six pairs.
+            const bool short_hist = hist_n < WGL_HIST;
+            if (w == 0) {
+                if (tid == 0) {
+                    const int2 pair = make_int2(leaving, entering);
+                    c.hist[hist_n] = pair;  // the host rebuilds the reference's [start, length] message from the global copy
+                    if (short_hist) sm.hist[hist_n] = pair;
+                }
+                if (short_hist) {
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): thread 0's LDS store is this wave's own
+                    const int n1 = hist_n + 1;
+                    const int2 last = sm.hist[n1 - 1];
+                    int found = 0;
+                    for (int L = 1 + lane; 2 * L <= n1; L += 64) {
+                        const int2 a = sm.hist[n1 - 1 - L];
+                        if (a.x != last.x || a.y != last.y) continue;
+                        bool eq = true;
+                        for (int i = 0; i < L - 1; i++) {
+                            const int2 x = sm.hist[n1 - 2 * L + i], y = sm.hist[n1 - L + i];
+                            if (x.x != y.x || x.y != y.y) { eq = false; break; }
+                        }
+                        if (eq) found = 1;
+                    }
+                    const unsigned long long hit = __ballot(found != 0);
+                    if (lane == 0) sm.cyc_hit = hit != 0ull ? 1 : 0;
+                }
             }
             __syncthreads();
             hist_n += 1;
-            if (suffix_is_square(hist_n <= WGL_HIST ? sm.hist : c.hist, hist_n, sm.g)) { outcome = 3; break; }
+            const bool cycle = short_hist ? sm.cyc_hit != 0 : suffix_is_square(c.hist, hist_n, sm.g);
+            if (cycle) { outcome = 3; break; }
         } else {
             __syncthreads();  // the list is complete
         }
