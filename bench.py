@@ -209,6 +209,27 @@ def pmc_traffic(key, kernel, alg_bytes):
         return None, "no PMC summary committed for %s" % key
 
 
+def pmc_sq(key, kernel):
+    """what the waves of the dominant kernel did per unit of work (tools/pmc_sq.py: rocprofv3 --pmc SQ_* passes over the same workload,
+    folded into profiles/pmc_latest.json[<key>_sq]); reported only when it was taken on this tree's kernel sources"""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)[key + "_sq"]
+        if d["kernel"] != kernel:
+            return {"note": "profiles/pmc_latest.json[%s_sq] is for another kernel (%s)" % (key, d["kernel"])}
+        if d.get("kernel_sources_sha") != kernel_sources_sha():
+            return {"note": "profiles/pmc_latest.json[%s_sq] was taken on other kernel sources (%s, this tree: %s): re-run tools/gpu_round.sh sq sqp"
+                            % (key, d.get("kernel_sources_sha"), kernel_sources_sha())}
+        keep = ("valu_per_wave_per_pivot", "salu_per_wave_per_pivot", "useful_valu_per_wave_per_pivot", "useful_valu_frac", "waves_per_dispatch",
+                "wait_any_share_of_wave_cycles", "issuing_share_of_wave_cycles", "note")
+        out = {k: d[k] for k in keep if k in d}
+        out["source"] = "profiles/pmc_latest.json[%s_sq] (%s; %s)" % (key, d["kernel"], d["source"])
+        return out
+    except Exception:
+        return {"note": "no SQ-counter summary committed for %s" % key}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -376,7 +397,9 @@ def main():
                                         "have to sustain to match; may exceed 1.0 for the register-resident kernel, which does not stream"},
                 "hbm": {"bytes_per_unit": traffic, "gb_s": (traffic / avg_s / 1e9) if traffic else None,
                         "frac_of_hbm_peak": (traffic / avg_s / HBM_PEAK) if traffic else None,
-                        "note": "PMC FETCH_SIZE + WRITE_SIZE of the same kernel on the same workload (separate rocprofv3 passes, committed summary)"}})
+                        "note": "PMC FETCH_SIZE + WRITE_SIZE of the same kernel on the same workload (separate rocprofv3 passes, committed summary)"},
+                # the issue budget: vector instructions one wave issues per pivot against the 32 that are the update itself
+                "issue": pmc_sq("pivots", kernel_name)})
 
         extras = {}
         if not args.no_extras and rank == 0 and args.sustain_s > 0:
@@ -674,6 +697,7 @@ def relaxation_legs(ctx, args, reps=16):
                            "frac": per_node * rate_rank0 / HBM_PEAK, "bytes_per_unit": per_node, "unit_of_work": "one LP relaxation",
                            "traffic": traffic, "traffic_source": note,
                            "traffic_over_algorithmic": (traffic / per_node) if traffic else None,
+                           "issue": pmc_sq("relaxations", node_kernel),
                            "counters": c, "dense_bytes_per_unit_survey_8d": dense / max(c["relaxations"], 1),
                            "note": "algorithmic bytes = what restore + addCutConstraints + simplex + read-back must move for the cells the "
                                    "reference's own loops touch (gated rows x live pivot-row columns, counted by the kernels: "

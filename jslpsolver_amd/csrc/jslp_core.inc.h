@@ -605,18 +605,20 @@ __global__ void k_end_pivot(Ctx c) {
 }
 
 // simplex() entry: `this.bounded = true; phase1(); if (feasible) phase2()` (simplex.ts:14-23)
-__device__ __forceinline__ void begin_simplex(DevState* st, int iters_cap) {
+// (zero: the batch kernels of jslp_wglds.hip.h pass an opaque 0 -- the compiler otherwise builds ONE 16-byte vector of zeros for these
+//  stores in the kernel's prologue and keeps it in scratch for the whole batch)
+__device__ __forceinline__ void begin_simplex(DevState* st, int iters_cap, int zero = 0) {
     st->status = ST_RUNNING;
     st->phase = 1;
     st->bounded = 1;
-    st->optimal = 0;
+    st->optimal = zero;
     st->unbounded_var = -1;
-    st->it1 = 0;
-    st->it2 = 0;
-    st->entered_phase2 = 0;
-    st->cycle_phase = 0;
-    st->hist_n = 0;
-    st->do_pivot = 0;
+    st->it1 = zero;
+    st->it2 = zero;
+    st->entered_phase2 = zero;
+    st->cycle_phase = zero;
+    st->hist_n = zero;
+    st->do_pivot = zero;
     st->err = st->err == ERR_CUT_ARG || st->err == ERR_CAPACITY ? st->err : ERR_NONE;
     st->iters_left = iters_cap;
 }

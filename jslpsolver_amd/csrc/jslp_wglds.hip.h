@@ -130,6 +130,42 @@ struct SmemL {
     int32_t n_list;         // length of the gated-row list
     int32_t cyc_hit;        // verdict of the cycle check while the history fits `hist` (wave 0 decides it alone)
 };
+// Round 5, register diet of the 512-thread batch shapes (80 VGPRs at three workgroups per CU): what these kernels spilled was not
+// data but loop-invariant trivia -- zero-extended `tid * 8` offsets, per-thread row / column addresses, threadIdx.y / .z for the
+// runtime's __syncthreads_or -- that LLVM hoists out of the node loop and then parks in scratch (13 stores in the prologue, 24
+// reloads; tools/kernel_resources.py: 108-156 bytes per lane).  wgl_tid() hands out the thread index behind an opaque barrier:
+// whatever is derived from it is recomputed where it is used (two or three VALU instructions) instead of being kept live across a
+// whole node, and wgl_block_or() is a workgroup OR that needs nothing but threadIdx.x.
+__device__ __forceinline__ int wgl_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+__device__ __forceinline__ int wgl_block_or(int pred) {
+    __shared__ int wgl_or_flag;
+    __syncthreads();  // every thread is past its read of the previous call's verdict
+    if (threadIdx.x == 0) wgl_or_flag = 0;
+    __syncthreads();
+    if (pred) wgl_or_flag = 1;
+    __syncthreads();
+    return wgl_or_flag;
+}
+// suffix_is_square (jslp_core.inc.h; checkForCycles, simplex.ts:415-440) on the global history, with the helpers above
+__device__ __forceinline__ bool wgl_suffix_is_square(const int2* h, int n) {
+    int found = 0;
+    const int2 last = h[n - 1];
+    for (int L = 1 + wgl_tid(); 2 * L <= n; L += blockDim.x) {
+        const int2 a = h[n - 1 - L];
+        if (a.x != last.x || a.y != last.y) continue;
+        bool eq = true;
+        for (int i = 0; i < L - 1; i++) {
+            const int2 x = h[n - 2 * L + i], y = h[n - L + i];
+            if (x.x != y.x || x.y != y.y) { eq = false; break; }
+        }
+        if (eq) found = 1;
+    }
+    return wgl_block_or(found) != 0;
+}
 // Only the first WGL_SEL threads (four waves, one per SIMD) take part in a selection: a wave-level reduction costs every
 // wave its ~60 instructions whether it holds candidates or not, and at 16 waves per workgroup that issue time -- not memory --
 // was the pivot's largest cost (block reductions: 6.0 k cycles each at 1024 threads, profiles/r02_wglds_sections.md).
@@ -260,22 +296,32 @@ __device__ __forceinline__ void wglds_update_row_preloaded(const Ctx& c, const W
 #ifndef WGL_UN512
 #define WGL_UN512 4  // column pairs per lane in flight in one row-update work item of the 512-thread kernels (1024 columns per item)
 #endif
+#ifndef WGL_PF512
+#define WGL_PF512 0  // 1 = the same prefetch in the 512-thread batch shapes: its 16 registers per lane do not fit the 80-VGPR budget of three
+                     // workgroups per CU (tools/kernel_resources.py: 20 spilled VGPRs, 36 bytes of scratch in k_node_queue<512, true>);
+                     // build/libjslp_dev_pf512.so is the A/B build
+#endif
 #define WGL_KP 2  // pivot-row values a thread keeps in registers across the cycle check (ld <= WGL_KP * threads)
 
 // OPT: the model has optional objectives (their rows stay in the slot's global copy); a build of its own so that the kernels of
 // every other model keep their register budget (the extra live values cost the 512-thread queue kernel 10 more VGPR spills)
 // PF (round 5, the 1024-thread latency shapes): every wave's first row-update work item is loaded next to the pivot row
+#define WGL_OPAQUE_TID(t) do { if (!PF || WGL_PF512) asm volatile("" : "+v"(t)); } while (0)
 template <int UN, bool OPT = false, bool PF = false>
 __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iters_cap) {
     WL_BEGIN(c.cnt);
     DevState* st = c.st;
-    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6, nw = nt >> 6;
+    int tid = threadIdx.x;
+    const int nt = blockDim.x, lane = tid & 63, w = tid >> 6, nw = nt >> 6;
     if (tid == 0) {
         if (L.preloaded) st->err = L.err_hint;  // (begin_simplex keeps a cut error: it re-reads what is stored here, no load of the old value)
-        begin_simplex(st, iters_cap);
+        int zero = 0;
+        if (!PF || WGL_PF512) asm volatile("" : "+v"(zero));
+        begin_simplex(st, iters_cap, zero);
         sm.n_list = 0;
     }
     __syncthreads();
+    WGL_OPAQUE_TID(tid);
     const int H = L.preloaded ? L.H_hint : st->H, W = c.W, ld = c.ld;  // the height is fixed during a simplex() call
     const double precision = c.precision;
     double* A = c.A;
@@ -340,6 +386,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
     int outcome = 0, unbounded_col = 0;
     while (outcome == 0) {
         if (iters_left <= 0) { outcome = 5; break; }
+        WGL_OPAQUE_TID(tid);
         int pr = 0, pc = 0, neg_flag = 0;
         double pv0 = 0.0, pv1 = 0.0;  // my two columns of the pivot row (raw), loaded as early as the row is known
         bool have_pv = false;
@@ -526,7 +573,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
                     const int n1 = hist_n + 1;
                     const int2 last = sm.hist[n1 - 1];
                     int found = 0;
-                    for (int L = 1 + lane; 2 * L <= n1; L += 64) {
+                    for (int L = 1 + (wgl_tid() & 63); 2 * L <= n1; L += 64) {
                         const int2 a = sm.hist[n1 - 1 - L];
                         if (a.x != last.x || a.y != last.y) continue;
                         bool eq = true;
@@ -542,7 +589,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
             }
             __syncthreads();
             hist_n += 1;
-            const bool cycle = short_hist ? sm.cyc_hit != 0 : suffix_is_square(c.hist, hist_n, sm.g);
+            const bool cycle = short_hist ? sm.cyc_hit != 0 : wgl_suffix_is_square(c.hist, hist_n);
             if (cycle) { outcome = 3; break; }
         } else {
             __syncthreads();  // the list is complete
@@ -722,7 +769,7 @@ __device__ __forceinline__ int add_cuts_waves(const Slots& s, const Cuts& cuts, 
     // (H_known / lei_known: the caller set st->H / st->last_element_index a moment ago and says what to; re-reading them is a
     //  global round trip each, and the slack loop below used to pay one per cut)
     const int H = H_known >= 0 ? H_known : st->H, W = s.W, ld = s.ld;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int tid_c = wgl_tid(), lane = tid_c & 63, w = tid_c >> 6, nw = blockDim.x >> 6;
     if (H + n > cap_rows) {
         if (threadIdx.x == 0) st->err = ERR_CAPACITY;
         return (H_known >= 0 && lei_known >= 0) ? (int)ERR_CAPACITY : -1;
@@ -765,7 +812,7 @@ __device__ __forceinline__ int add_cuts_waves(const Slots& s, const Cuts& cuts, 
             }
         }
     }
-    const int bad = __syncthreads_or(my_bad);  // (a bad cut list: every thread knows, nobody re-reads st->err)
+    const int bad = wgl_block_or(my_bad);  // (a bad cut list: every thread knows, nobody re-reads st->err)
     if (threadIdx.x == 0 && !bad) {
         int lei = lei_known >= 0 ? lei_known : st->last_element_index;
         for (int h = 0; h < n; h++) {  // getNewElementIndex + map updates (:64-69)
@@ -791,15 +838,17 @@ __global__ void __launch_bounds__(THREADS) k_simplex_lds(Slots s, int first_slot
     __shared__ SmemL sm;
     const Ctx c = slot_ctx(s, first_slot + blockIdx.x, check_cycles);
     const WgLds L = wglds_carve(lds_dyn, s.ld, cap_rows);
-    simplex_wg_lds<(THREADS >= 1024 ? WGL_UN1024 : WGL_UN512), OPT, (THREADS >= 1024)>(c, sm, L, iters_cap);
+    simplex_wg_lds<(THREADS >= 1024 ? WGL_UN1024 : WGL_UN512), OPT, (THREADS >= 1024 || WGL_PF512)>(c, sm, L, iters_cap);
 }
 
 // The LDS twin of k_node_wg: ONE branch-and-bound child per workgroup in ONE launch -- restore of the rows the previous node
 // dirtied, the index maps, addCutConstraints, simplex() and the read-back (see k_node_wg for the contract).
 #ifndef JSLP_NODE512_WAVES
-// waves per SIMD the 512-thread batch shape is compiled for.  6 = three workgroups per CU, 80 VGPRs, no spills: measured
+// waves per SIMD the 512-thread batch shape is compiled for.  6 = three workgroups per CU, 80 VGPRs: measured (round 2)
 // 1.87 M relaxations/s on the Monster_II batch against 1.79 M for 8 (64 VGPRs, 36 bytes of scratch per lane); with the LDS
-// this kernel declares (40 KB per workgroup) a fourth workgroup does not fit a CU anyway
+// this kernel declares (Monster_II: 47.5 KB dynamic + 1.7 KB static per workgroup) a fourth workgroup does not fit a CU anyway.
+// Round 5: none of the three k_node_queue<512> builds touches scratch any more (0 spilled VGPRs at 75-80; they were 26-38 with
+// 108-156 bytes per lane -- see wgl_tid); at 8 waves per SIMD the copy-on-write build would still spill 6.
 #define JSLP_NODE512_WAVES 6
 #endif
 // Read-back of a node the LDS kernel just solved: column 0 and the row map are still in LDS (no load of what this workgroup
@@ -808,13 +857,13 @@ __global__ void __launch_bounds__(THREADS) k_simplex_lds(Slots s, int first_slot
 __device__ __forceinline__ void gather_slot_lds(const Slots& s, const WgLds& L, int slot, double* rhs, int32_t* rows, DevState* states,
                                                 int out_stride, int o) {
     const DevState* st = s.st + slot;
-    const int H = st->H;
+    const int H = st->H, tid = wgl_tid();
     if (out_stride < 0) {
         const int n = -out_stride < s.n_watch ? -out_stride : s.n_watch;
         if (s.watch_pos) {
-            for (int i = threadIdx.x; i < n; i += blockDim.x) L.list[i] = -1;
+            for (int i = tid; i < n; i += blockDim.x) L.list[i] = -1;
             __syncthreads();
-            for (int r = 1 + threadIdx.x; r < H; r += blockDim.x) {
+            for (int r = 1 + tid; r < H; r += blockDim.x) {
                 const int v = L.vibr[r];
                 const int p = (v >= 0 && v < s.idx_stride) ? s.watch_pos[v] : -1;
                 if (p >= 0 && p < n) L.list[p] = r;
@@ -822,7 +871,7 @@ __device__ __forceinline__ void gather_slot_lds(const Slots& s, const WgLds& L, 
         } else {
             // a variable listed twice has no single position: every listed entry looks its row up in the LDS row map (the global
             // maps of a copy-on-write slot are stale, so gather_slot() is not an option here)
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            for (int i = tid; i < n; i += blockDim.x) {
                 const int v = s.watch[i];
                 int row = -1;
                 for (int r = 1; r < H; r++) row = L.vibr[r] == v ? r : row;
@@ -830,7 +879,7 @@ __device__ __forceinline__ void gather_slot_lds(const Slots& s, const WgLds& L, 
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        for (int i = tid; i < n; i += blockDim.x) {
             const int r = L.list[i];
             if (rows) rows[(long long)o * (-out_stride) + i] = r;
             if (rhs) rhs[(long long)o * (-out_stride) + i] = r > 0 ? L.rhs[r] : 0.0;
@@ -841,7 +890,7 @@ __device__ __forceinline__ void gather_slot_lds(const Slots& s, const WgLds& L, 
         if (rhs) {
             double2* dst = reinterpret_cast<double2*>(rhs + (long long)o * out_stride);
             const double2* src = reinterpret_cast<const double2*>(L.rhs);
-            for (int k = threadIdx.x; 2 * k < H; k += blockDim.x) {
+            for (int k = tid; 2 * k < H; k += blockDim.x) {
                 double2 v = src[k];
                 if (2 * k + 1 >= H) v.y = 0.0;
                 dst[k] = v;
@@ -850,19 +899,19 @@ __device__ __forceinline__ void gather_slot_lds(const Slots& s, const WgLds& L, 
         if (rows) {
             int2* dst = reinterpret_cast<int2*>(rows + (long long)o * out_stride);
             const int2* src = reinterpret_cast<const int2*>(L.vibr);
-            for (int k = threadIdx.x; 2 * k < H; k += blockDim.x) {
+            for (int k = tid; 2 * k < H; k += blockDim.x) {
                 int2 v = src[k];
                 if (2 * k + 1 >= H) v.y = -1;
                 dst[k] = v;
             }
         }
     } else {
-        for (int r = threadIdx.x; r < H; r += blockDim.x) {
+        for (int r = tid; r < H; r += blockDim.x) {
             if (rhs) rhs[(long long)o * out_stride + r] = L.rhs[r];
             if (rows) rows[(long long)o * out_stride + r] = L.vibr[r];
         }
     }
-    if (threadIdx.x == 0) states[o] = *st;
+    if (tid == 0) states[o] = *st;
 }
 
 // one node (= restore + cuts + simplex + read-back) of slot `slot`; false = the slot is not in sync with the snapshot
@@ -872,7 +921,7 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
                                              DevState* state_out, int out_stride) {
     WL_BEGIN(s.cnt);
     DevState* st = s.st + slot;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int tid = THREADS == 512 ? wgl_tid() : (int)threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const int gen = s.st[0].s_gen, H = s.st[0].s_H, ld2 = s.ld / 2;  // every slot shares slot 0's snapshot scalars
     if (gen == 0 || st->gen != gen) {  // must not happen (host bookkeeping): refuse rather than restore wrongly
         if (tid == 0) { st->err = ERR_NOT_SYNCED; st->status = ST_DONE; state_out[o] = *st; }
@@ -958,7 +1007,7 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
     }
     if (OPT && s.n_opt > 0 && snap.oo) {  // restore(): the optional objective rows of the saved root (backup.ts:94-104) into the slot's copy
         double* oo = s.oo + (long long)slot * s.oo_stride;
-        for (long long i = tid; i < s.oo_stride; i += blockDim.x) oo[i] = snap.oo[i];
+        for (long long i = THREADS == 512 ? wgl_tid() : tid; i < s.oo_stride; i += blockDim.x) oo[i] = snap.oo[i];
         __syncthreads();
     }
     const Ctx c = slot_ctx(s, slot, check_cycles);
@@ -969,7 +1018,7 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
         Ln.err_hint = cut_err;
         Ln.H_hint = cut_err == (int)ERR_NONE ? H + (cuts.offs[node + 1] - cuts.offs[node]) : H;
     }
-    simplex_wg_lds<(THREADS >= 1024 ? WGL_UN1024 : WGL_UN512), OPT, (THREADS >= 1024)>(c, sm, Ln, iters_cap);
+    simplex_wg_lds<(THREADS >= 1024 ? WGL_UN1024 : WGL_UN512), OPT, (THREADS >= 1024 || WGL_PF512)>(c, sm, Ln, iters_cap);
 #ifdef JSLP_DEBUG_WGLDS
     wl_prev = __builtin_amdgcn_s_memtime();
 #endif

@@ -12,7 +12,7 @@ for s in $steps; do
     xl) timeout 600 python -m pytest tests/test_xcd_local.py -m gpu -q > $out/xl.log 2>&1 < /dev/null; echo "xl rc=$?"; tail -25 $out/xl.log ;;
     xlt) timeout 600 python tools/xl_times.py $out/xl_times.md > $out/xl_times.log 2>&1 < /dev/null; echo "xlt rc=$?"; tail -20 $out/xl_times.log ;;
     pins) timeout 1500 python -m pytest tests/test_resident_pins.py -m gpu -q > $out/pins.log 2>&1 < /dev/null; echo "pins rc=$?"; tail -25 $out/pins.log ;;
-    tests) timeout 1800 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1 < /dev/null; echo "tests rc=$?"; tail -4 $out/pytest_gpu.log ;;
+    tests) timeout ${TESTS_TIMEOUT:-1800} python -m pytest tests -m gpu -q --timeout 400 --timeout-method thread ${TESTS_ARGS:-} > $out/pytest_gpu.log 2>&1 < /dev/null; echo "tests rc=$?"; tail -4 $out/pytest_gpu.log; grep -a "^FAILED\|^ERROR" $out/pytest_gpu.log | head -20 ;;
     bench) timeout 600 python bench.py --steps 3 --warmup 1 > $out/bench.log 2>&1 < /dev/null; echo "bench rc=$?"; grep '^{' $out/bench.log | cut -c1-1500 ;;
     benchfast) timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench.log 2>&1 < /dev/null; echo "bench rc=$?"; grep '^{' $out/bench.log | cut -c1-1200 ;;
     prof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/prof -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/prof.log 2>&1 < /dev/null); echo "prof rc=$?"; timeout 120 python tools/rocpd_stats.py $(ls $out/prof/*.db | head -1) $out/kernel_stats.md < /dev/null | tail -12 ;;
@@ -33,6 +33,22 @@ for s in $steps; do
     config) timeout 900 python tools/config_times.py $out/config_times.md > $out/config_times.log 2>&1 < /dev/null; echo "config rc=$?"; cat $out/config_times.md ;;
     wgt) (JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py single; JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py batch
           timeout 120 python tools/wglds_timing.py rate; JSLP_GROUP_MAX=768 timeout 120 python tools/wglds_timing.py rate; timeout 120 python tools/wglds_timing.py single) > $out/wglds_timing.log 2>&1 < /dev/null; echo "wgt rc=$?"; grep -v "^{" $out/wglds_timing.log ;;
+    ab5) # round 5: the 512-thread batch kernels after their register diet (shipped) against the sources before it (base) and with the prefetch (pf512)
+         (for l in build/libjslp_dev_base.so shipped build/libjslp_dev_pf512.so; do
+            echo "== library: $l"; L="JSLP_HIP_LIBRARY=$l"; [ $l = shipped ] && L="JSLP_AB_NONE=1"
+            [ $l != build/libjslp_dev_base.so ] && env $L timeout 120 python tools/queue_check.py | head -3
+            for rep in 1 2; do env $L WATCHED=1 timeout 120 python tools/wglds_timing.py rate | tail -1; done
+            [ $l != build/libjslp_dev_pf512.so ] && env $L timeout 120 python tools/wglds_timing.py rate | tail -1
+            [ $l = shipped ] && env $L JSLP_NODE_COW=0 WATCHED=1 timeout 120 python tools/wglds_timing.py rate | tail -1
+            [ $l != build/libjslp_dev_pf512.so ] && env $L timeout 200 python tools/node_latency.py
+          done) > $out/ab5.log 2>&1 < /dev/null; echo "ab5 rc=$?"; cat $out/ab5.log ;;
+    sqp) (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $GRAFT_REPO_ROOT/$out/pmc_sq_pivots -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py pivots > $GRAFT_REPO_ROOT/$out/pmc_sq_pivots.log 2>&1 < /dev/null); echo "sqp rc=$?"
+         timeout 120 python tools/pmc_sq.py $out pivots "gpurun_out/$tag (tools/gpu_round.sh sqp)" $out/headline_sq_counters.md < /dev/null
+         cp profiles/pmc_latest.json $out/pmc_latest.json ;;
+    sqr) (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $GRAFT_REPO_ROOT/$out/pmc_sq_relax -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py relax > $GRAFT_REPO_ROOT/$out/pmc_sq_relax.log 2>&1 < /dev/null); echo "sqr rc=$?"
+         (cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT -d $GRAFT_REPO_ROOT/$out/pmc_sq_relax2 -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py relax > $GRAFT_REPO_ROOT/$out/pmc_sq_relax2.log 2>&1 < /dev/null); echo "sqr2 rc=$?"
+         timeout 120 python tools/pmc_sq.py $out relax "gpurun_out/$tag (tools/gpu_round.sh sqr)" $out/node_kernel_sq_counters.md < /dev/null
+         cp profiles/pmc_latest.json $out/pmc_latest.json ;;
     sq) (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $GRAFT_REPO_ROOT/$out/pmc_sq -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py relax > $GRAFT_REPO_ROOT/$out/pmc_sq.log 2>&1 < /dev/null); echo "sq rc=$?"
         (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT -d $GRAFT_REPO_ROOT/$out/pmc_sq2 -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py relax > $GRAFT_REPO_ROOT/$out/pmc_sq2.log 2>&1 < /dev/null); echo "sq2 rc=$?"
         timeout 120 python tools/rocpd_pmc.py $out $out/pmc_sq_summary.json < /dev/null | grep -A40 "k_node_queue" | head -120 ;;
