@@ -135,7 +135,8 @@ struct SmemL {
 // runtime's __syncthreads_or -- that LLVM hoists out of the node loop and then parks in scratch (13 stores in the prologue, 24
 // reloads; tools/kernel_resources.py: 108-156 bytes per lane).  wgl_tid() hands out the thread index behind an opaque barrier:
 // whatever is derived from it is recomputed where it is used (two or three VALU instructions) instead of being kept live across a
-// whole node, and wgl_block_or() is a workgroup OR that needs nothing but threadIdx.x.
+// whole node, and wgl_block_or() is a workgroup OR that needs nothing but threadIdx.x.  Measured on the Monster_II batch (compact
+// read-back): 3.82-3.90 M -> 4.10-4.14 M relaxations/s in tools/wglds_timing.py, 4.52 M -> 5.05 M in bench.py.
 __device__ __forceinline__ int wgl_tid() {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
@@ -298,8 +299,9 @@ __device__ __forceinline__ void wglds_update_row_preloaded(const Ctx& c, const W
 #endif
 #ifndef WGL_PF512
 #define WGL_PF512 0  // 1 = the same prefetch in the 512-thread batch shapes: its 16 registers per lane do not fit the 80-VGPR budget of three
-                     // workgroups per CU (tools/kernel_resources.py: 20 spilled VGPRs, 36 bytes of scratch in k_node_queue<512, true>);
-                     // build/libjslp_dev_pf512.so is the A/B build
+                     // workgroups per CU (tools/kernel_resources.py: 20 spilled VGPRs, 36 bytes of scratch in k_node_queue<512, true>)
+                     // and measured slower than without it: 3.85-3.94 M against 4.10-4.14 M relaxations/s on the Monster_II batch
+                     // (profiles/r05_batch_kernel_register_diet_ab.md)
 #endif
 #define WGL_KP 2  // pivot-row values a thread keeps in registers across the cycle check (ld <= WGL_KP * threads)
 
@@ -308,7 +310,7 @@ __device__ __forceinline__ void wglds_update_row_preloaded(const Ctx& c, const W
 // PF (round 5, the 1024-thread latency shapes): every wave's first row-update work item is loaded next to the pivot row
 #define WGL_OPAQUE_TID(t) do { if (!PF || WGL_PF512) asm volatile("" : "+v"(t)); } while (0)
 template <int UN, bool OPT = false, bool PF = false>
-__device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iters_cap) {
+__device__ int simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iters_cap) {  // returns what st->err holds at the end (uniform)
     WL_BEGIN(c.cnt);
     DevState* st = c.st;
     int tid = threadIdx.x;
@@ -340,7 +342,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
     __syncthreads();
     if (err0 != ERR_NONE) {  // a bad cut list: report, do not solve
         if (tid == 0) finish(c);
-        return;
+        return err0;
     }
     WL_MARK(3);
 #ifdef JSLP_DEBUG_WGLDS
@@ -374,11 +376,24 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
         return (from_root ? rootA : A) + (long long)r * ld;
     };
     auto gather_column = [&](int col) {  // the pivot column into LDS
-        if (L.snapT) {
-            const double* colT = L.snapT + (long long)col * L.ldT;
-            for (int r = tid; r < H; r += nt) L.pcol[r] = (r < L.Hs && !L.cur[r]) ? colT[r] : A[(long long)r * ld + col];
-        } else {
-            for (int r = tid; r < H; r += nt) L.pcol[r] = rowsrc(r)[col];
+        // Two rows per thread and turn: both addresses first, then BOTH loads, then the LDS stores.  (Written as `L.pcol[r] = ...[r]` in
+        // a plain loop the compiler waits for each load before the next turn's: a tableau taller than the workgroup -- Monster_II's 945
+        // rows in the 512-thread batch shapes -- paid two dependent trips per gather, 11 k cycles per pivot under load.)
+        const double* colT = L.snapT ? L.snapT + (long long)col * L.ldT : nullptr;
+        const int Hs1 = L.Hs > 0 ? L.Hs - 1 : 0;
+        auto src = [&](int r) -> const double* {  // (branch-free: the flag is read at a clamped index, the pointer is a select)
+            const bool untouched = r < L.Hs && L.cur[r < Hs1 ? r : Hs1] == 0;
+            const double* mine = A + (long long)r * ld + col;
+            if (colT) return untouched ? colT + r : mine;
+            return (L.cow && untouched) ? rootA + (long long)r * ld + col : mine;
+        };
+        for (int r0 = tid; r0 < H; r0 += 2 * nt) {
+            const int r1 = r0 + nt, r1c = r1 < H ? r1 : H - 1;  // (a clamped second row: no branch between the two loads)
+            const double* p0 = src(r0);
+            const double* p1 = src(r1c);
+            const double v0 = *p0, v1 = *p1;
+            L.pcol[r0] = v0;
+            L.pcol[r1c] = v1;  // (unconditional: behind `if (r1 < H)` the compiler sinks the second LOAD into the branch, after the first one's wait; the clamped row's value is that row's own)
         }
     };
     int phase = 1, it1 = 0, it2 = 0, hist_n = 0, iters_left = iters_cap, entered2 = 0, par = 0;
@@ -747,6 +762,7 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
     }
     __syncthreads();
     WL_MARK(11);
+    return outcome == 5 ? (int)ERR_ITER_LIMIT : outcome == 6 ? (int)ERR_HIST_FULL : (int)ERR_NONE;
 }
 
 // addCutConstraints (cutting-strategies.ts:16-72) with one WAVE per cut row (add_cuts_slot builds them one after the other:
@@ -758,14 +774,15 @@ __device__ void simplex_wg_lds(const Ctx& c, SmemL& sm, const WgLds& L, int iter
 // ERR_CUT_ARG: what st->err holds), else -1 (read st->err).
 __device__ __forceinline__ int add_cuts_waves(const Slots& s, const Cuts& cuts, int slot, int node, int cap_rows, const double* rows_src = nullptr,
                                                const int32_t* maps_rbv = nullptr, const int32_t* maps_cbv = nullptr, const WgLds* Lm = nullptr,
-                                               int H_known = -1, int lei_known = -1) {
+                                               int H_known = -1, int lei_known = -1, int a_known = -1, int n_known = -1) {
     DevState* st = s.st + slot;
     double* A = s.A + (long long)slot * s.A_stride;
     double* rhs = s.rhs + (long long)slot * s.pcol_stride;
     int32_t* vibr = s.vibr + (long long)slot * s.vibr_stride;
     int32_t* rbv = s.rbv + (long long)slot * s.idx_stride;
     int32_t* cbv = s.cbv + (long long)slot * s.idx_stride;
-    const int a = cuts.offs[node], n = cuts.offs[node + 1] - a;
+    // (a_known / n_known: the node's slice of the cut lists, read by the caller next to its first loads -- one trip less in this chain)
+    const int a = a_known >= 0 ? a_known : cuts.offs[node], n = a_known >= 0 ? n_known : cuts.offs[node + 1] - a;
     // (H_known / lei_known: the caller set st->H / st->last_element_index a moment ago and says what to; re-reading them is a
     //  global round trip each, and the slack loop below used to pay one per cut)
     const int H = H_known >= 0 ? H_known : st->H, W = s.W, ld = s.ld;
@@ -795,19 +812,25 @@ __device__ __forceinline__ int add_cuts_waves(const Slots& s, const Cuts& cuts, 
                 cut[col] = v;
             }
         } else {  // basic variable: negated copy of its row (:54-62)
-            const double* src = (rows_src ? rows_src : A) + (long long)var_row * ld;
-            for (int col0 = lane; col0 < ld; col0 += 256) {  // four loads in flight per lane
-                double x[4];
+            // (column pairs, four 16-byte loads in flight per lane: 512 columns per trip -- as four doubles per lane and turn a Monster_II
+            //  row was four dependent trips of the seven this function's chain had, now two; eight pairs in flight would be one, but their
+            //  32 registers put the batch kernels back into scratch; ld is even, columns >= W read as 0)
+            const double2* src2 = reinterpret_cast<const double2*>((rows_src ? rows_src : A) + (long long)var_row * ld);
+            double2* cut2 = reinterpret_cast<double2*>(cut);
+            const int ld2 = ld >> 1;
+            for (int q0 = lane; q0 < ld2; q0 += 256) {
+                double2 x[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { const int col = col0 + 64 * u; x[u] = col < W ? src[col] : 0.0; }
+                for (int u = 0; u < 4; u++) { const int q = q0 + 64 * u; x[u] = src2[q < ld2 ? q : ld2 - 1]; }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int col = col0 + 64 * u;
-                    if (col >= ld) continue;
-                    double v = 0.0;
-                    if (col == 0) { v = sign * (value - x[u]); rhs[H + h] = v; if (Lm) Lm->rhs[H + h] = v; }
-                    else if (col < W) v = -sign * x[u];
-                    cut[col] = v;
+                    const int q = q0 + 64 * u, col = 2 * q;
+                    if (q >= ld2) continue;
+                    double2 v;
+                    v.x = col < W ? -sign * x[u].x : 0.0;
+                    v.y = col + 1 < W ? -sign * x[u].y : 0.0;
+                    if (q == 0) { v.x = sign * (value - x[u].x); rhs[H + h] = v.x; if (Lm) Lm->rhs[H + h] = v.x; }
+                    cut2[q] = v;
                 }
             }
         }
@@ -855,18 +878,22 @@ __global__ void __launch_bounds__(THREADS) k_simplex_lds(Slots s, int first_slot
 // stored a moment ago).  Compact form (out_stride < 0): the row of each watched variable is found by scattering the rows
 // through watch_pos (variable index -> position in the watched list, -1 elsewhere) into the LDS list.
 __device__ __forceinline__ void gather_slot_lds(const Slots& s, const WgLds& L, int slot, double* rhs, int32_t* rows, DevState* states,
-                                                int out_stride, int o) {
+                                                int out_stride, int o, int H_known = -1) {
     const DevState* st = s.st + slot;
-    const int H = st->H, tid = wgl_tid();
+    const int H = H_known >= 0 ? H_known : st->H, tid = wgl_tid();
     if (out_stride < 0) {
         const int n = -out_stride < s.n_watch ? -out_stride : s.n_watch;
         if (s.watch_pos) {
             for (int i = tid; i < n; i += blockDim.x) L.list[i] = -1;
             __syncthreads();
-            for (int r = 1 + tid; r < H; r += blockDim.x) {
-                const int v = L.vibr[r];
-                const int p = (v >= 0 && v < s.idx_stride) ? s.watch_pos[v] : -1;
-                if (p >= 0 && p < n) L.list[p] = r;
+            for (int r0 = 1 + tid; r0 < H; r0 += 2 * (int)blockDim.x) {  // (both look-ups of a turn in flight together: clamped, unconditional)
+                const int r1 = r0 + (int)blockDim.x, r1c = min(r1, H - 1);
+                const int v0 = L.vibr[r0], v1 = L.vibr[r1c];
+                const bool ok0 = v0 >= 0 && v0 < s.idx_stride, ok1 = v1 >= 0 && v1 < s.idx_stride;
+                const int q0 = s.watch_pos[ok0 ? v0 : 0], q1 = s.watch_pos[ok1 ? v1 : 0];
+                const int p0 = ok0 ? q0 : -1, p1 = ok1 ? q1 : -1;
+                if (p0 >= 0 && p0 < n) L.list[p0] = r0;
+                if (p1 >= 0 && p1 < n) L.list[p1] = r1c;
             }
         } else {
             // a variable listed twice has no single position: every listed entry looks its row up in the LDS row map (the global
@@ -923,6 +950,8 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
     DevState* st = s.st + slot;
     const int tid = THREADS == 512 ? wgl_tid() : (int)threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const int gen = s.st[0].s_gen, H = s.st[0].s_H, ld2 = s.ld / 2;  // every slot shares slot 0's snapshot scalars
+    const int cut_a = cuts.offs[node], cut_n = cuts.offs[node + 1] - cut_a;  // (in flight with the loads above: add_cuts_waves starts with them)
+    const int lei0 = s.st[0].s_last_element_index;
     if (gen == 0 || st->gen != gen) {  // must not happen (host bookkeeping): refuse rather than restore wrongly
         if (tid == 0) { st->err = ERR_NOT_SYNCED; st->status = ST_DONE; state_out[o] = *st; }
         return false;
@@ -958,11 +987,24 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
         // cut variables' rows are looked up in the root's maps.  No dirty-row scan, no row copies, no map copies: a row the
         // previous nodes wrote stays flagged (dirty: the slot differs from the root there) and is simply not current (L.cur).
         // Slot 0 is the engine's live tableau: its global maps are kept as before.
-        for (int r = tid; r < H; r += blockDim.x) { L.cur[r] = 0; L.rhs[r] = snap.rhs[r]; L.vibr[r] = snap.vibr[r]; }
-        for (int col = tid; col < s.ld; col += blockDim.x) L.r0[col] = snap.A[col];
-        for (int col = tid; col < s.W; col += blockDim.x) L.vibc[col] = snap.vibc[col];
+        // (every load of a turn leaves before the first LDS store: two rows and two columns per thread and turn -- as three plain loops
+        //  this was up to six dependent trips for a tableau taller / wider than the workgroup)
+        for (int i0 = tid; i0 < H || i0 < s.ld; i0 += 2 * (int)blockDim.x) {
+            // clamped indexes, unconditional loads and stores (a clamped element gets its own value once more): no branch between the loads
+            const int i1 = i0 + (int)blockDim.x;
+            const int h0 = min(i0, H - 1), h1 = min(i1, H - 1), c0 = min(i0, s.ld - 1), c1 = min(i1, s.ld - 1), w0 = min(i0, s.W - 1), w1 = min(i1, s.W - 1);
+            const double rh0 = snap.rhs[h0], rh1 = snap.rhs[h1];
+            const int32_t vr0 = snap.vibr[h0], vr1 = snap.vibr[h1];
+            const double a0 = snap.A[c0], a1 = snap.A[c1];
+            const int32_t vc0 = snap.vibc[w0], vc1 = snap.vibc[w1];
+            L.cur[h0] = 0; L.rhs[h0] = rh0; L.vibr[h0] = vr0;
+            L.cur[h1] = 0; L.rhs[h1] = rh1; L.vibr[h1] = vr1;
+            L.r0[c0] = a0;
+            L.r0[c1] = a1;
+            L.vibc[w0] = vc0;
+            L.vibc[w1] = vc1;
+        }
         if (slot == 0) restore_maps();
-        const int lei0 = s.st[0].s_last_element_index;
         if (tid == 0) {
             st->H = H;
             st->last_element_index = lei0;
@@ -971,7 +1013,7 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
         __syncthreads();
         WL_MARK(0);
         WL_MARK(1);
-        cut_err = add_cuts_waves(s, cuts, slot, node, cap_rows, snap.A, snap.rbv, snap.cbv, &L, H, lei0);
+        cut_err = add_cuts_waves(s, cuts, slot, node, cap_rows, snap.A, snap.rbv, snap.cbv, &L, H, lei0, cut_a, cut_n);
         __syncthreads();
         WL_MARK(2);
     } else {
@@ -996,12 +1038,12 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
     for (int r = tid; r < H; r += blockDim.x) L.cur[r] = 0;  // every row of the root is as saved
     if (tid == 0) {
         st->H = H;
-        st->last_element_index = s.st[0].s_last_element_index;
+        st->last_element_index = lei0;
         st->err = ERR_NONE;
     }
     __syncthreads();
     WL_MARK(1);
-    add_cuts_waves(s, cuts, slot, node, cap_rows);
+    add_cuts_waves(s, cuts, slot, node, cap_rows, nullptr, nullptr, nullptr, nullptr, -1, -1, cut_a, cut_n);
     __syncthreads();
     WL_MARK(2);
     }
@@ -1016,9 +1058,10 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
     if (COW) {
         Ln.snapA = snap.A; Ln.Hs = H; Ln.cow = true; Ln.preloaded = true;
         Ln.err_hint = cut_err;
-        Ln.H_hint = cut_err == (int)ERR_NONE ? H + (cuts.offs[node + 1] - cuts.offs[node]) : H;
+        Ln.H_hint = cut_err == (int)ERR_NONE ? H + cut_n : H;
     }
-    simplex_wg_lds<(THREADS >= 1024 ? WGL_UN1024 : WGL_UN512), OPT, (THREADS >= 1024 || WGL_PF512)>(c, sm, Ln, iters_cap);
+    // (copy-on-write nodes: the error word and the height the solve ends with are known here -- no global re-reads in front of the read-back)
+    const int err_fin = simplex_wg_lds<(THREADS >= 1024 ? WGL_UN1024 : WGL_UN512), OPT, (THREADS >= 1024 || WGL_PF512)>(c, sm, Ln, iters_cap);
 #ifdef JSLP_DEBUG_WGLDS
     wl_prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -1028,7 +1071,7 @@ __device__ __forceinline__ bool node_lds_run(const Slots& s, const Snapshot& sna
         for (int off = 32; off > 0; off >>= 1) n_mine += __shfl_down(n_mine, off, 64);
         if (lane == 0 && n_mine) atomicAdd(s.cnt + CNT_RESTORED, (cnt_t)n_mine);
     }
-    if (st->err == ERR_NONE) gather_slot_lds(s, Ln, slot, rhs_out, rows_out, state_out, out_stride, o);
+    if ((COW ? err_fin : (int)st->err) == ERR_NONE) gather_slot_lds(s, Ln, slot, rhs_out, rows_out, state_out, out_stride, o, COW ? Ln.H_hint : -1);
     else gather_slot(s, slot, rhs_out, rows_out, state_out, out_stride, o);
     __syncthreads();
     WL_MARK(12);
