@@ -2,7 +2,7 @@
 """Fold the SQ-counter passes of one workload (tools/gpu_round.sh sq / sqp) into profiles/pmc_latest.json[<key>_sq]: what the waves of the
 dominant kernel DID per unit of work -- instructions issued by class, the share of wave-cycles spent waiting, and (pivots) the vector
 instructions one wave issues per pivot next to the 32 that are the Gauss-Jordan update itself (16 cells per lane x v_mul_f64 + v_add_f64).
-  tools/pmc_sq.py <run dir> <key: pivots|relax> <source label> [out.md]
+  tools/pmc_sq.py <run dir> <key: pivots|relax> <source label> [out.md [summary.json, default profiles/pmc_latest.json]]
 <run dir>/pmc_sq_<key>*/ hold the rocpd databases (one --pmc pass each, <= 8 counters), <run dir>/pmc_sq_<key>.log the workload's JSON
 line (tools/pmc_workload.py: kernel, dispatches, units, every solve checked against the reference's answer).  The entry is stamped with
 the kernel sources' hash like the HBM entries: bench.py reports it only for the tree it was taken on."""
@@ -33,7 +33,7 @@ def counters(run_dir, key, kernel):
     return out
 
 
-def main(run_dir, key, source, out_md=None):
+def main(run_dir, key, source, out_md=None, latest_path=None):
     with open(os.path.join(run_dir, "pmc_sq_%s.log" % key)) as fh:
         w = json.loads([l for l in fh.read().splitlines() if l.startswith("{")][-1])
     if not w.get("verified"):
@@ -67,7 +67,7 @@ def main(run_dir, key, source, out_md=None):
                 entry["salu_per_wave_per_pivot"] = g("SQ_INSTS_SALU") / (waves_per_dispatch * units)
             entry["note"] = ("DYNAMIC counts: the polls of the hand-over loops are in them (a wave that waits for the candidate row issues "
                              "instructions while it waits); the static mix of the same loop is tools/isa_mix.py's")
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    path = latest_path or os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as fh:
             doc = json.load(fh)
@@ -94,4 +94,4 @@ def main(run_dir, key, source, out_md=None):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
