@@ -171,6 +171,58 @@ static napi_value result_object(napi_env env, const jslp_simplex_result* r) {
     return o;
 }
 
+/* Batch results, PACKED (round 5): building one JS object per node through N-API costs 12 napi_set_named_property calls each -- tens of
+   microseconds for a 16-node batch, comparable to the batch's kernel --, so the batch entry points take two optional trailing typed
+   arrays and fill them instead: Int32Array[n * 10] = feasible, bounded, optimal, unboundedVarIndex, pivotsPhase1, pivotsPhase2,
+   cyclePhase, cycleStart, cycleLength, height and Float64Array[n * 2] = objCell, evaluation per node -- result_object's fields in
+   result_object's order (host/gpu-tableau.js `unpackResults` makes the same objects from them in JavaScript).  Without the two arrays:
+   the array of objects, as before. */
+#define JSLP_RES_I32 10
+#define JSLP_RES_F64 2
+static napi_value batch_results(napi_env env, jslp_simplex_result* res, int32_t n_nodes, napi_value packed_i, napi_value packed_f, const char* who) {
+    void *pi = NULL, *pf = NULL;
+    size_t ni = 0, nf = 0;
+    if (!typed(env, packed_i, napi_int32_array, &pi, &ni) || !typed(env, packed_f, napi_float64_array, &pf, &nf)) { free(res); return NULL; }
+    if (pi || pf) {
+        if (!pi || !pf || ni < (size_t)n_nodes * JSLP_RES_I32 || nf < (size_t)n_nodes * JSLP_RES_F64) {
+            free(res);
+            napi_throw_error(env, "JSLP", who);
+            return NULL;
+        }
+        int32_t* I = (int32_t*)pi;
+        double* F = (double*)pf;
+        for (int32_t i = 0; i < n_nodes; i++, I += JSLP_RES_I32, F += JSLP_RES_F64) {
+            const jslp_simplex_result* r = &res[i];
+            I[0] = r->feasible != 0; I[1] = r->bounded != 0; I[2] = r->optimal != 0; I[3] = r->unbounded_var_index;
+            I[4] = r->pivots_phase1; I[5] = r->pivots_phase2; I[6] = r->cycle_phase; I[7] = r->cycle_start; I[8] = r->cycle_length;
+            I[9] = r->height;
+            F[0] = r->obj_cell; F[1] = r->evaluation;
+        }
+        free(res);
+        napi_value u;
+        NAPI_OK(env, napi_get_undefined(env, &u));
+        return u;
+    }
+    napi_value arr;
+    if (napi_create_array_with_length(env, (size_t)n_nodes, &arr) != napi_ok) { free(res); THROW(env, "array"); }
+    for (int32_t i = 0; i < n_nodes; i++) {
+        napi_value ro = result_object(env, &res[i]);
+        if (!ro) { free(res); return NULL; }
+        napi_set_element(env, arr, (uint32_t)i, ro);
+    }
+    free(res);
+    return arr;
+}
+/* the first n_min arguments are required, the rest (up to n_max) arrive as undefined when absent */
+static int get_args_opt(napi_env env, napi_callback_info info, size_t n_min, size_t n_max, napi_value* argv) {
+    size_t argc = n_max;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < n_min) {
+        napi_throw_type_error(env, "JSLP", "wrong number of arguments");
+        return 0;
+    }
+    return 1;
+}
+
 /* load(path) -> backend name */
 static napi_value fn_load(napi_env env, napi_callback_info info) {
     napi_value argv[1];
@@ -493,8 +545,8 @@ static napi_value fn_relax_from(napi_env env, napi_callback_info info) {
 
 /* relaxBatch(h, Int32Array offsets, type, varIndex, value, checkCycles, rhsOut|null, rowsOut|null, stride) -> [result] */
 static napi_value fn_relax_batch(napi_env env, napi_callback_info info) {
-    napi_value argv[9];
-    if (!get_args(env, info, 9, argv)) return NULL;
+    napi_value argv[11];
+    if (!get_args_opt(env, info, 9, 11, argv)) return NULL;  /* + the two optional packed-result arrays (batch_results) */
     jslp_engine* e = handle(env, argv[0]);
     if (!e) return NULL;
     void *o, *t, *v, *x, *rhs, *rows;
@@ -518,22 +570,14 @@ static napi_value fn_relax_batch(napi_env env, napi_callback_info info) {
                            check ? 1 : 0, res, (double*)rhs, (int32_t*)rows, stride);
     if (rc != JSLP_OK) free(res);
     ENGINE_OK(env, rc, "jslp_engine_relax_batch");
-    napi_value arr;
-    if (napi_create_array_with_length(env, (size_t)n_nodes, &arr) != napi_ok) { free(res); THROW(env, "array"); }
-    for (int32_t i = 0; i < n_nodes; i++) {
-        napi_value ro = result_object(env, &res[i]);
-        if (!ro) { free(res); return NULL; }
-        napi_set_element(env, arr, (uint32_t)i, ro);
-    }
-    free(res);
-    return arr;
+    return batch_results(env, res, n_nodes, argv[9], argv[10], "relax_batch: packed result arrays shorter than n_nodes * 10 / n_nodes * 2");
 }
 
 /* relaxBatchWatched(h, Int32Array offsets, type, varIndex, value, checkCycles, Int32Array rowsOut|null, Float64Array valuesOut|null)
    -> [result]: node i's watched variables at [i * nWatched, (i + 1) * nWatched) (setWatchedVariables first) */
 static napi_value fn_relax_batch_watched(napi_env env, napi_callback_info info) {
-    napi_value argv[8];
-    if (!get_args(env, info, 8, argv)) return NULL;
+    napi_value argv[10];
+    if (!get_args_opt(env, info, 8, 10, argv)) return NULL;  /* + the two optional packed-result arrays (batch_results) */
     jslp_engine* e = handle(env, argv[0]);
     if (!e) return NULL;
     void *o, *t, *v, *x, *wr, *wv;
@@ -559,15 +603,7 @@ static napi_value fn_relax_batch_watched(napi_env env, napi_callback_info info) 
                                    check ? 1 : 0, res, (int32_t*)wr, (double*)wv);
     if (rc != JSLP_OK) free(res);
     ENGINE_OK(env, rc, "jslp_engine_relax_batch_watched");
-    napi_value arr;
-    if (napi_create_array_with_length(env, (size_t)n_nodes, &arr) != napi_ok) { free(res); THROW(env, "array"); }
-    for (int32_t i = 0; i < n_nodes; i++) {
-        napi_value ro = result_object(env, &res[i]);
-        if (!ro) { free(res); return NULL; }
-        napi_set_element(env, arr, (uint32_t)i, ro);
-    }
-    free(res);
-    return arr;
+    return batch_results(env, res, n_nodes, argv[8], argv[9], "relax_batch_watched: packed result arrays shorter than n_nodes * 10 / n_nodes * 2");
 }
 
 /* dims(h) -> {height, width, nVarIndexes} */
@@ -829,8 +865,8 @@ static napi_value fn_pool_sync_root(napi_env env, napi_callback_info info) {
 }
 /* poolRelaxBatch(pool, Int32Array offsets, type, varIndex, value, checkCycles, rhsOut|null, rowsOut|null, stride) -> [result] */
 static napi_value fn_pool_relax_batch(napi_env env, napi_callback_info info) {
-    napi_value argv[9];
-    if (!get_args(env, info, 9, argv)) return NULL;
+    napi_value argv[11];
+    if (!get_args_opt(env, info, 9, 11, argv)) return NULL;  /* + the two optional packed-result arrays (batch_results) */
     int32_t cap = 0;
     jslp_pool* p = pool_handle(env, argv[0], &cap);
     if (!p) return NULL;
@@ -855,15 +891,7 @@ static napi_value fn_pool_relax_batch(napi_env env, napi_callback_info info) {
                                 check ? 1 : 0, res, (double*)rhs, (int32_t*)rows, stride);
     if (rc != JSLP_OK) free(res);
     ENGINE_OK(env, rc, "jslp_pool_relax_batch");
-    napi_value arr;
-    if (napi_create_array_with_length(env, (size_t)n_nodes, &arr) != napi_ok) { free(res); THROW(env, "array"); }
-    for (int32_t i = 0; i < n_nodes; i++) {
-        napi_value ro = result_object(env, &res[i]);
-        if (!ro) { free(res); return NULL; }
-        napi_set_element(env, arr, (uint32_t)i, ro);
-    }
-    free(res);
-    return arr;
+    return batch_results(env, res, n_nodes, argv[9], argv[10], "pool_relax_batch: packed result arrays shorter than n_nodes * 10 / n_nodes * 2");
 }
 
 /* poolSetWatchedVariables(pool, Int32Array varIndexes): jslp_pool_set_watched_variables (every member) */
@@ -885,8 +913,8 @@ static napi_value fn_pool_set_watched(napi_env env, napi_callback_info info) {
 /* poolRelaxBatchWatched(pool, Int32Array offsets, type, varIndex, value, checkCycles, Int32Array rowsOut, Float64Array valuesOut)
    -> [result]: the compact read-back (mip-utils.ts:43-61, 100-126 need only the integer variables' cells) over every member */
 static napi_value fn_pool_relax_batch_watched(napi_env env, napi_callback_info info) {
-    napi_value argv[8];
-    if (!get_args(env, info, 8, argv)) return NULL;
+    napi_value argv[10];
+    if (!get_args_opt(env, info, 8, 10, argv)) return NULL;  /* + the two optional packed-result arrays (batch_results) */
     jslp_pool* p = pool_handle(env, argv[0], NULL);
     if (!p) return NULL;
     void *o, *t, *v, *x, *wr, *wv, *bp = NULL;
@@ -913,15 +941,7 @@ static napi_value fn_pool_relax_batch_watched(napi_env env, napi_callback_info i
                                         check ? 1 : 0, res, (int32_t*)wr, (double*)wv);
     if (rc != JSLP_OK) free(res);
     ENGINE_OK(env, rc, "jslp_pool_relax_batch_watched");
-    napi_value arr;
-    if (napi_create_array_with_length(env, (size_t)n_nodes, &arr) != napi_ok) { free(res); THROW(env, "array"); }
-    for (int32_t i = 0; i < n_nodes; i++) {
-        napi_value ro = result_object(env, &res[i]);
-        if (!ro) { free(res); return NULL; }
-        napi_set_element(env, arr, (uint32_t)i, ro);
-    }
-    free(res);
-    return arr;
+    return batch_results(env, res, n_nodes, argv[8], argv[9], "pool_relax_batch_watched: packed result arrays shorter than n_nodes * 10 / n_nodes * 2");
 }
 
 /* ---- where a Solve() spends its time inside the binding ------------------------------------------------------------------------

@@ -633,6 +633,21 @@ function relaxFromCheckpoint(t, cp, cuts) {
 }
 
 // ---- batches of independent nodes (host/gpu-speculative-service.js) ----------------------------------------------------
+// The per-node results of a batch come back PACKED (addon/jslp_napi.c batch_results: 10 int32 + 2 doubles per node) and become the
+// objects the rest of this file reads here -- same fields, same key order as the addon's own result objects.  (Built through N-API
+// they cost 12 property stores per node: tens of microseconds for a 16-node batch, comparable to the batch's kernel.)
+const RES_I32 = 10, RES_F64 = 2;
+function unpackResults(I, F, n) {
+    const out = new Array(n);
+    for (let i = 0, a = 0, b = 0; i < n; i++, a += RES_I32, b += RES_F64) {
+        out[i] = {
+            feasible: I[a] !== 0, bounded: I[a + 1] !== 0, optimal: I[a + 2] !== 0, unboundedVarIndex: I[a + 3],
+            pivotsPhase1: I[a + 4], pivotsPhase2: I[a + 5], cyclePhase: I[a + 6], cycleStart: I[a + 7], cycleLength: I[a + 8],
+            height: I[a + 9], objCell: F[b], evaluation: F[b + 1],
+        };
+    }
+    return out;
+}
 // every node = restore() + addCutConstraints(cuts) + simplex() from the saved root, all nodes in ONE engine call
 function relaxBatch(t, cutLists) {
     const st = t.__gpu;
@@ -665,9 +680,10 @@ function relaxBatch(t, cutLists) {
     // root is fanned out over xGMI once per save(), every member has its own host thread and stream inside the library)
     const devices = installedOpts.devices;
     if (devices && devices.length > 1 && !st.pool) st.pool = addon.poolCreate(st.h, Int32Array.from(devices));
-    const results = st.pool
-        ? addon.poolRelaxBatch(st.pool, offsets, type, varIndex, value, check, st.batchRhs, st.batchRows, stride)
-        : addon.relaxBatch(st.h, offsets, type, varIndex, value, check, st.batchRhs, st.batchRows, stride);
+    const resI = new Int32Array(n * RES_I32), resF = new Float64Array(n * RES_F64);
+    if (st.pool) addon.poolRelaxBatch(st.pool, offsets, type, varIndex, value, check, st.batchRhs, st.batchRows, stride, resI, resF);
+    else addon.relaxBatch(st.h, offsets, type, varIndex, value, check, st.batchRhs, st.batchRows, stride, resI, resF);
+    const results = unpackResults(resI, resF, n);
     const out = new Array(n);
     for (let i = 0; i < n; i++) {
         const H = results[i].height;
@@ -726,9 +742,10 @@ function relaxBatchWatched(t, cutLists, varIndexes) {
     }
     const rows = new Int32Array(n * w), values = new Float64Array(n * w);
     const check = t.model ? t.model.checkForCycles === true : false;
-    const results = st.pool
-        ? addon.poolRelaxBatchWatched(st.pool, offsets, type, varIndex, value, check, rows, values)
-        : addon.relaxBatchWatched(st.h, offsets, type, varIndex, value, check, rows, values);
+    const resI = new Int32Array(n * RES_I32), resF = new Float64Array(n * RES_F64);
+    if (st.pool) addon.poolRelaxBatchWatched(st.pool, offsets, type, varIndex, value, check, rows, values, resI, resF);
+    else addon.relaxBatchWatched(st.h, offsets, type, varIndex, value, check, rows, values, resI, resF);
+    const results = unpackResults(resI, resF, n);
     const out = new Array(n);
     for (let i = 0; i < n; i++) out[i] = { res: results[i], rows: rows.subarray(i * w, (i + 1) * w), values: values.subarray(i * w, (i + 1) * w) };
     return out;

@@ -338,7 +338,7 @@ for (const fullReadBack of [false, true]) if (!filter && dir.indexOf("fixtures")
 }
 // compact read-back of a batch (relaxBatchWatched) against the full one, node by node
 // -- on one engine, and over the device pool (poolRelaxBatchWatched against poolRelaxBatch)
-let watchedOk = 0, poolWatchedOk = 0;
+let watchedOk = 0, poolWatchedOk = 0, packedOk = 0;
 for (const devices of [null, [0, 0, 0, 0]]) if (!filter && dir.indexOf("fixtures") >= 0) {
     uninstall();
     uninstall = gpu.install(Tableau, devices ? { SlackVariable, solver, speculate: 16, minCells: 0, devices } : { SlackVariable, solver, speculate: 16, minCells: 0 });
@@ -362,6 +362,22 @@ for (const devices of [null, [0, 0, 0, 0]]) if (!filter && dir.indexOf("fixtures
         if (!same) { fail += 1; console.log("FAIL watched batch, node", i, devices ? "(pool)" : ""); }
         else if (devices) poolWatchedOk += 1;
         else watchedOk += 1;
+    }
+    if (!devices) {
+        // round 5: the batch results come back PACKED (two typed arrays, unpacked in gpu-tableau.js); the addon still builds the array of
+        // objects itself when the two arrays are not passed -- both forms must be the same objects, key for key
+        const addon = require(path.join(root, "addon", "jslp_napi.node"));
+        const offsets = new Int32Array(lists.length + 1);
+        let total = 0;
+        for (let i = 0; i < lists.length; i++) { total += lists[i].length; offsets[i + 1] = total; }
+        const type = new Int8Array(total), varIndex = new Int32Array(total), value = new Float64Array(total);
+        for (let i = 0, k = 0; i < lists.length; i++) for (const c of lists[i]) { type[k] = c.type === "min" ? 0 : 1; varIndex[k] = c.varIndex; value[k] = c.value; k++; }
+        const legacy = addon.relaxBatchWatched(t.__gpu.h, offsets, type, varIndex, value, t.model.checkForCycles === true,
+            new Int32Array(lists.length * ints.length), new Float64Array(lists.length * ints.length));
+        for (let i = 0; i < lists.length; i++) {
+            if (JSON.stringify(legacy[i]) === JSON.stringify(compact[i].res) && Object.keys(legacy[i]).join() === Object.keys(full[i].res).join()) packedOk += 1;
+            else { fail += 1; console.log("FAIL packed batch results, node", i, JSON.stringify(legacy[i]), JSON.stringify(compact[i].res)); }
+        }
     }
     gpu.release(t);
 }
@@ -417,5 +433,5 @@ if (!filter && dir.indexOf("fixtures") >= 0) {
 }
 console.log(JSON.stringify({ backend, pass, fail, solved_on_engine: onGpu, defer_ok: deferOk, strategy_variants_ok: strategyOk,
     incremental_ok: incrementalOk, device_checkpoints: checkpointsTaken, mir_ok: mirOk, speculative_ok: speculativeOk, lookahead_ok: lookaheadOk, lookahead_ran: lookaheadNodes > 0,
-    size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, instance_ok: instanceOk, cycle_ok: cycleOk, pool_ok: poolOk, pool_full_ok: poolFullOk, watched_ok: watchedOk, pool_watched_ok: poolWatchedOk }));
+    size_policy_ok: policyOk, fuzz_ok: fuzzOk, edit_ok: editOk, released_ok: releasedOk, instance_ok: instanceOk, cycle_ok: cycleOk, pool_ok: poolOk, pool_full_ok: poolFullOk, watched_ok: watchedOk, pool_watched_ok: poolWatchedOk, packed_ok: packedOk }));
 process.exit(fail === 0 && pass > 0 ? 0 : 1);

@@ -48,7 +48,7 @@ def test_addon_exports_the_abi():
 # exact counts (not lower bounds): a regression that turns cases into skips must fail
 FIXTURE_COUNTS = {"fail": 0, "pass": 47, "solved_on_engine": 43, "strategy_variants_ok": 30, "incremental_ok": 114,
                   "device_checkpoints": 577, "mir_ok": 67, "speculative_ok": 15, "lookahead_ok": 15, "lookahead_ran": True, "size_policy_ok": 10, "defer_ok": 2, "fuzz_ok": 1063,
-                  "edit_ok": 20, "released_ok": 1, "instance_ok": 16, "cycle_ok": 13, "pool_ok": 13, "pool_full_ok": 13, "watched_ok": 25, "pool_watched_ok": 25}
+                  "edit_ok": 20, "released_ok": 1, "instance_ok": 16, "cycle_ok": 13, "pool_ok": 13, "pool_full_ok": 13, "watched_ok": 25, "pool_watched_ok": 25, "packed_ok": 25}
 
 
 def _check_fixture_counts(r, backend):
