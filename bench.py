@@ -64,10 +64,19 @@ def cpu_baseline(n, sample_pivots):
                              capture_output=True, text=True, timeout=900)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         r = json.loads(line)
-        return {"value": r["pivots_per_sec"], "unit": "pivots/s", "cores": 1, "kind": "reference",
+        base = {"value": r["pivots_per_sec"], "unit": "pivots/s", "cores": 1, "kind": "reference",
                 "sample": "first %d of the %d pivots of the same %dx%d instance, reference TS (type-erased) under node %s, "
                           "options.exitOnCycles=false, simplex() time only; host has %d cores"
                           % (r["pivots"], PIVOTS_3A.get(n, -1), n + 1, n + 1, r["node"], os.cpu_count())}
+        try:  # the reference's FULL run of the same instance on a box of this class, measured once per round (tools/gpu_round.sh cpufull)
+            with open(os.path.join(ROOT, "profiles", "r05_cpu_full_run.json")) as fh:
+                full = json.load(fh)
+            if full.get("n") == n:
+                base["full_run_committed"] = {"value": full["pivots_per_sec"], "pivots": full["pivots"], "seconds": full["seconds"],
+                                              "source": "profiles/r05_cpu_full_run.json (all %d pivots, not timed in this run)" % full["pivots"]}
+        except Exception:
+            pass
+        return base
     except Exception as e:  # the baseline is reported, never required
         return {"value": None, "unit": "pivots/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
 
