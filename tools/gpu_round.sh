@@ -33,14 +33,15 @@ for s in $steps; do
     config) timeout 900 python tools/config_times.py $out/config_times.md > $out/config_times.log 2>&1 < /dev/null; echo "config rc=$?"; cat $out/config_times.md ;;
     wgt) (JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py single; JSLP_HIP_LIBRARY=build/libjslp_hip_dbg.so timeout 120 python tools/wglds_timing.py batch
           timeout 120 python tools/wglds_timing.py rate; JSLP_GROUP_MAX=768 timeout 120 python tools/wglds_timing.py rate; timeout 120 python tools/wglds_timing.py single) > $out/wglds_timing.log 2>&1 < /dev/null; echo "wgt rc=$?"; grep -v "^{" $out/wglds_timing.log ;;
-    ab5) # round 5: the 512-thread batch kernels after their register diet (shipped) against the sources before it (base) and with the prefetch (pf512)
-         (for l in build/libjslp_dev_base.so shipped build/libjslp_dev_pf512.so; do
+    ab5) # A/B of builds of the batch node kernels: AB_LIBS="build/libX.so build/libY.so" (variant libraries built on the CPU box; `shipped` is always run too).
+         # Per library: outcome digests of the 2416-node batch (must be identical), compact rate x3, full read-back rate, node latency.  Round 5 used it for
+         # the register diet / the prefetch / flat work items / the in-flight loads (profiles/r05_batch_kernel_register_diet_ab.md, r05_batch_kernel_experiments.md)
+         (for l in shipped ${AB_LIBS:-}; do
             echo "== library: $l"; L="JSLP_HIP_LIBRARY=$l"; [ $l = shipped ] && L="JSLP_AB_NONE=1"
-            [ $l != build/libjslp_dev_base.so ] && env $L timeout 120 python tools/queue_check.py | head -3
-            for rep in 1 2; do env $L WATCHED=1 timeout 120 python tools/wglds_timing.py rate | tail -1; done
-            [ $l != build/libjslp_dev_pf512.so ] && env $L timeout 120 python tools/wglds_timing.py rate | tail -1
-            [ $l = shipped ] && env $L JSLP_NODE_COW=0 WATCHED=1 timeout 120 python tools/wglds_timing.py rate | tail -1
-            [ $l != build/libjslp_dev_pf512.so ] && env $L timeout 200 python tools/node_latency.py
+            env $L timeout 120 python tools/queue_check.py 2>/dev/null | head -3
+            for rep in 1 2 3; do env $L WATCHED=1 timeout 120 python tools/wglds_timing.py rate | tail -1; done
+            env $L timeout 120 python tools/wglds_timing.py rate | tail -1
+            env $L timeout 200 python tools/node_latency.py | tail -12
           done) > $out/ab5.log 2>&1 < /dev/null; echo "ab5 rc=$?"; cat $out/ab5.log ;;
     sqp) (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $GRAFT_REPO_ROOT/$out/pmc_sq_pivots -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py pivots > $GRAFT_REPO_ROOT/$out/pmc_sq_pivots.log 2>&1 < /dev/null); echo "sqp rc=$?"
          timeout 120 python tools/pmc_sq.py $out pivots "gpurun_out/$tag (tools/gpu_round.sh sqp)" $out/headline_sq_counters.md < /dev/null
