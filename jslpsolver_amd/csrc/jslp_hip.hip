@@ -1283,6 +1283,9 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                     HIPC(hipMemcpy(d.data(), rc.dbg + (size_t)512 * rc.G * 2, sizeof(u64_t) * 16384, hipMemcpyDeviceToHost));
                     FILE* fb = fopen("gpurun_out/resident_r0.bin", "wb");
                     if (fb) { fwrite(d.data(), 8, 16384, fb); fclose(fb); }
+                    HIPC(hipMemcpy(d.data(), rc.dbg, sizeof(u64_t) * 16384, hipMemcpyDeviceToHost));  // RT_STAMP: [8 epochs][MAXG][8 events]
+                    fb = fopen("gpurun_out/resident_stamps.bin", "wb");
+                    if (fb) { fwrite(d.data(), 8, 16384, fb); fclose(fb); }
                 }
 #endif
                 }  // !ERR_BARRIER

@@ -40,7 +40,12 @@
 // 32 words of decision / verdict, then the lean kernel's [2][G] 16-byte summary granules (JSLP_G16_STRIDE bytes apart)
 #define JSLP_R_SYNC_WORDS_GENERAL (2 * JSLP_F_MAXG * (JSLP_R_GRAN + 2) + 32)
 #define JSLP_R_FLAGCOPIES 16  // copies of every row flag, one per fetching wave (2 KB apart: 4096 waves reading ONE word per pivot is a hot spot)
-#define JSLP_R_SYNC_WORDS (JSLP_R_SYNC_WORDS_GENERAL + 2 * JSLP_F_MAXG * 8 + 2 * JSLP_R_FLAGCOPIES * JSLP_F_MAXG + JSLP_F_MAXG)  // (+ the lean kernel's granules, 64 bytes apart; + the row-flag copies; + the XCD-local build's placement census)
+// round 6: the lean phase 2 of the 2- / 4-column geometries publishes its candidate row NORMALISED (jslp_resident_pipe.hip.h, NPUB); what used to be
+// the 8-byte flag word per (parity, fetching wave, workgroup) is a 32-byte RECORD there: {checksum word, quot, -k0 / quot, 0}, behind the flag copies
+#define JSLP_R_REC_BYTES 32
+#define JSLP_R_REC_WORDS (2 * JSLP_R_FLAGCOPIES * JSLP_F_MAXG * (JSLP_R_REC_BYTES / 8))
+#define JSLP_R_REC_OFF ((2 * JSLP_F_MAXG * 8 + 2 * JSLP_R_FLAGCOPIES * JSLP_F_MAXG) * 8)  // bytes from the first summary granule (ResCtx::gran16) to the first record
+#define JSLP_R_SYNC_WORDS (JSLP_R_SYNC_WORDS_GENERAL + 2 * JSLP_F_MAXG * 8 + 2 * JSLP_R_FLAGCOPIES * JSLP_F_MAXG + JSLP_R_REC_WORDS + JSLP_F_MAXG)  // (+ the lean kernel's granules, 64 bytes apart; + the row-flag copies; + the row records; + the XCD-local build's placement census)
 #ifndef JSLP_RES_FAST
 #define JSLP_RES_FAST 1      // one barrier around the row flag (step E); the -k/quot entries of the pivot column computed by eight lanes in parallel while the winning row is in flight instead of one after the other by the lane that owns the column (step F)
 #endif
@@ -163,6 +168,9 @@ struct RSmem {
     // pair with a clear bit needs no suffix test at all (exact: bits are only ever set; a collision merely runs the test)
     unsigned cycbits_tail[JSLP_R_CYCEXTRA];
     int32_t cyc_need, cyc_filter_on;
+    int32_t cm_ent, cm_leav;  // lean pipelined loops, workgroup 0: the basis change whose GLOBAL commit is still pending (written and read by the one committing thread)
+    // ... and what that thread needs to issue the commit as seven fire-and-forget stores (no trip to the device copy of the context in front of them)
+    int32_t* gp_vibr; int32_t* gp_vibc; int32_t* gp_rbv; int32_t* gp_cbv; int2* gp_trace; long long gp_trace_cap;
 };
 
 // The leader's last FOUR waves gather every workgroup's summary of this epoch (all-gather with the data as the flag,
@@ -283,8 +291,15 @@ __device__ __forceinline__ int price_row_lds(const double (&x)[CPT], int c0, con
 
 #ifdef JSLP_DEBUG_RESIDENT
 #define RT_MARK(i) do { const u64_t _now = __builtin_amdgcn_s_memtime(); rt_acc[i] += _now - rt_prev; rt_prev = _now; } while (0)
+// round 6: event stamps of EIGHT consecutive pivots (epochs JSLP_STAMP_E0 ...) from thread 0 of EVERY workgroup, on the constant-rate clock all
+// CUs share (s_memrealtime, 100 MHz): who publishes its summary last, when the gather closes, when the row is in -- tools/resident_stamps.py
+#ifndef JSLP_STAMP_E0
+#define JSLP_STAMP_E0 4096u
+#endif
+#define RT_STAMP(k) do { if (tid == 0 && f.dbg && R.epoch - JSLP_STAMP_E0 < 8u) f.dbg[(((R.epoch - JSLP_STAMP_E0) * JSLP_F_MAXG) + b) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define RT_MARK(i) do { } while (0)
+#define RT_STAMP(k) do { } while (0)
 #endif
 
 __device__ __forceinline__ void reset_reductions(RSmem& sm) {  // one thread, before a barrier
@@ -1039,6 +1054,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     if (UNR)
         for (int v = tid; v < f.n_idx && v < JSLP_R_LUNR; v += (int)blockDim.x) sm.lunr[v] = c.unr[v];
     if (tid == 0) { reset_reductions(sm); sm.okbad = 0u; }
+    if (LEAN && tid == THREADS - 64) { sm.gp_vibr = c.vibr; sm.gp_vibc = c.vibc; sm.gp_rbv = c.rbv; sm.gp_cbv = c.cbv; sm.gp_trace = c.trace; sm.gp_trace_cap = c.trace_cap; }
     __syncthreads();
     // pricing batch of my columns (simplex.ts:118-127): fixed for the whole solve
     int pb[CPT];

@@ -75,6 +75,20 @@
 // gather's barrier all leave the critical path.  0: round 3's hand-over (winner drains, fences, raises the flag; readers wait, load).
 #define JSLP_PIPE_ROW_CHECKSUM 1
 #endif
+#ifndef JSLP_PIPE_LOOK_AHEAD
+// round 6: the polling waves' FIRST look at the summaries leaves right behind the barrier that closes the ratio test -- in front of the pending
+// pivot's row update -- and is examined behind it.  The pivot period is the loop time of the workgroup that stores its summary LAST
+// (tools/resident_stamps.py: it never waits for anybody, the other 250 wait for it), and for that workgroup everybody else's summary is in
+// memory when its look leaves: its update pass and its look's round trip (~0.8 us under this load) overlap instead of adding up.
+// (Round 4's JSLP_PIPE_EARLY_LOOKS issued one more look in front of examining the early ones and waited for it.)
+#define JSLP_PIPE_LOOK_AHEAD 0
+#endif
+#ifndef JSLP_PIPE_SPLIT_UPDATE
+#define JSLP_PIPE_SPLIT_UPDATE 0  // round 6: see SPLITU in resident_phase2_pipe
+#endif
+#ifndef JSLP_PIPE_NORM_PUB
+#define JSLP_PIPE_NORM_PUB 1  // round 6: the candidate row leaves NORMALISED (see NPUB in resident_phase2_pipe)
+#endif
 #ifndef JSLP_PIPE_ROW_CHECKSUM_MAXCPT
 #define JSLP_PIPE_ROW_CHECKSUM_MAXCPT 4  // the 6- / 8-column geometries keep round 3's hand-over: checksummed they ran 3001 x 3001 113.7 k -> 97.1 k and 2001 x 4001 116.0 k -> 100.8 k pivots/s (r04_y: three / four pairs to hash per lane in front of the pivot row's normalisation, in kernels at their register limit)
 #endif
@@ -96,7 +110,9 @@
 #define JSLP_PIPE_S_VIA_LDS 1
 #endif
 #define JSLP_PUB_SKEW 256     // bytes added to a workgroup's slot of the candidate-row buffer (see SLOT)
+#ifndef JSLP_G16_STRIDE
 #define JSLP_G16_STRIDE 64   // bytes between two workgroups' summary granules (a 64-byte line each)
+#endif
 #define JSLP_PIPE_KCHUNK 8    // pivot-column entries the update pass keeps in flight (registers: the tall / wide geometries have few to spare)
 
 // A HOST-requested abort, in the SHIPPED build (the test hooks above exist in the test library only).  Every JSLP_HOST_ABORT_PERIOD-th pivot,
@@ -254,14 +270,15 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
 //  dynamic index, which sends the whole register array to scratch: 456 bytes per lane, 1648 scratch instructions, 28-47 k cycles per
 //  update pass (r04_d).  An empty asm per iteration makes every comparison's operand its own opaque value.)
 #define JSLP_OPAQUE_SGPR(x) ({ int o_ = (x); asm volatile("" : "+s"(o_)); o_; })
-#define JSLP_XL_UPDATE_PASS()                                                                                                     \
+#define JSLP_XL_UPDATE_PASS() JSLP_XL_UPDATE_PASS_M(0u)
+#define JSLP_XL_UPDATE_PASS_M(SKIPMASK) /* SKIPMASK: rows of mine that have received this pivot already (JSLP_UPDATE_ONE_ROW) */     \
     do {                                                                                                                          \
         /* lane i < ROWS holds the pivot-column entry of my row i; the gate |k| > 1e-16 (simplex.ts:370-375) of all rows is ONE     \
            ballot, a row's k reaches the multiplier by two readlanes (scalar operands): per (row, column) a scalar bit test, a     \
            scalar branch and the two roundings -- no per-row LDS read, no per-cell select; the per-column gate is the EXEC mask of \
            the column's pass over the rows */                                                                                      \
         const double kl_ = lane < ROWS ? sm.colb[par_p][lane] : 0.0;                                                              \
-        const unsigned km_ = (unsigned)__ballot(nonzero16(kl_)); /* (rows beyond the workgroup's share hold zeros: bit clear) */   \
+        const unsigned km_ = (unsigned)__ballot(nonzero16(kl_)) & ~(unsigned)(SKIPMASK); /* (rows beyond the workgroup's share hold zeros: bit clear) */ \
         _Pragma("unroll") for (int j = 0; j < CPT; j++) { /* (measured, r04_e ... r04_g: per-row LDS reads + per-cell selects 5.4-6.9 k cycles per   \
             pass; this form 3.9-5.9 k; one pass over the rows with the column gate as an EXEC-masked branch per cell 5.1-8.5 k; a second,  \
             gate-free copy of the loop for dense pivot rows costs the register allocator ~400 spills) */                           \
@@ -272,7 +289,8 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         }                                                                                                                         \
         if (wv == ((pc_p / CPT) >> 6)) { /* the pivot column itself: -k / quot (simplex.ts:386), one lane of this wave */         \
             const int ol_ = __builtin_amdgcn_readfirstlane((pc_p / CPT) & 63), js_ = __builtin_amdgcn_readfirstlane(pc_p % CPT);  \
-            const double nvl_ = lane < ROWS ? sm.nv[lane] : 0.0;                                                                  \
+            /* (NPUB builds: -k / quot is computed HERE, by the one wave that needs it, behind the summary -- round 6; the others: by wave 0 in step N) */ \
+            const double nvl_ = lane < ROWS ? (NPUB ? -kl_ / quot_p : sm.nv[lane]) : 0.0;                                         \
             _Pragma("unroll") for (int j = 0; j < CPT; j++)                                                                       \
                 if (js_ == j) {                                                                                                   \
                     _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                              \
@@ -287,6 +305,31 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
             }                                                                                                                     \
         }                                                                                                                         \
         if (b == 0) { _Pragma("unroll") for (int j = 0; j < CPT; j++) a[0][j] = r0[j]; } /* workgroup 0 mirrors the cost row */   \
+    } while (0)
+// round 6 (SPLITU builds): the pending pivot applied to ONE row of mine -- the row that can win the next ratio test, which leaves normalised
+// right behind the summary; the other rows follow while the winning row is in flight (JSLP_XL_UPDATE_PASS_M with this row's bit).  Same steps
+// in the same order as the pass gives every row: elimination, the pivot column's own entry, the pivot row's replacement.
+#define JSLP_UPDATE_ONE_ROW(IROW)                                                                                                 \
+    do {                                                                                                                          \
+        const double kl_ = lane < ROWS ? sm.colb[par_p][lane] : 0.0;                                                              \
+        const unsigned km_ = (unsigned)__ballot(nonzero16(kl_));                                                                  \
+        const bool holds_ = wv == ((pc_p / CPT) >> 6);                                                                            \
+        const int ol_ = __builtin_amdgcn_readfirstlane((pc_p / CPT) & 63), js_ = __builtin_amdgcn_readfirstlane(pc_p % CPT);      \
+        const int ip_ = __builtin_amdgcn_readfirstlane(pr_p - r_begin);                                                           \
+        _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                          \
+            if (i == JSLP_OPAQUE_SGPR(IROW)) {                                                                                    \
+                if (km_ & (1u << i)) {                                                                                            \
+                    const double ki_ = readlane_f64(kl_, i);                                                                      \
+                    _Pragma("unroll") for (int j = 0; j < CPT; j++)                                                               \
+                        if ((nzm >> j) & 1u) a[i][j] = eliminate(a[i][j], ki_, p[j]);                                             \
+                    if (holds_) { /* (uniform: this wave holds the pivot column) */                                               \
+                        const double nv_ = -ki_ / quot_p;                                                                         \
+                        _Pragma("unroll") for (int j = 0; j < CPT; j++)                                                           \
+                            if (js_ == j && lane == ol_) a[i][j] = nv_;                                                           \
+                    }                                                                                                             \
+                }                                                                                                                 \
+                if (i == ip_) { _Pragma("unroll") for (int j = 0; j < CPT; j++) a[i][j] = p[j]; }                                 \
+            }                                                                                                                     \
     } while (0)
 // the row that can win, with the epoch tag INSIDE the data: {lo32 | tag}{hi32 | tag} per double (RCCL's LL scheme) -- the readers
 // poll the row itself, no flag, no drain, no ordering between stores to rely on; twice the bytes, which one XCD's L2 does not notice
@@ -319,35 +362,54 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         const bool torn_ = CKS && __builtin_amdgcn_readfirstlane((int)((F_TEST_LATE == 4 || F_TEST_LATE == 6) && wv == 0)) != 0;  \
         const bool early_lane_ = !torn_ || ((lane & 1) == (F_TEST_LATE == 6 ? 1 : 0));                                            \
         u64_t ck_ = 0;                                                                                                            \
-        if (colok) {                                                                                                              \
-            _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                      \
-                if (i == JSLP_OPAQUE_SGPR(ipub_)) {                                                                               \
-                    const int off_ = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;        \
-                    _Pragma("unroll") for (int j = 0; j < CPT; j += 2) {                                                          \
-                        if (c0 + j >= ld) continue;                                                                               \
-                        const u64_t lo_ = (u64_t)__double_as_longlong(a[i][j]), hi_ = (u64_t)__double_as_longlong(a[i][j + 1]);  \
-                        v4u_t v_;                                                                                                 \
-                        v_.x = (unsigned)lo_; v_.y = (unsigned)(lo_ >> 32); v_.z = (unsigned)hi_; v_.w = (unsigned)(hi_ >> 32);   \
-                        if (!flag_first_ && early_lane_) __builtin_amdgcn_raw_buffer_store_b128(v_, rsrc_rows, off_ + (j >> 1) * PAIR_STEP, 0, ST_AUX); \
-                        if (CKS) JSLP_CK_PAIR(ck_, lo_, hi_, j);                                              \
-                    }                                                                                                             \
+        double cand_[CPT]; /* my columns of the row that can win (the compare chain: see JSLP_OPAQUE_SGPR) */                     \
+        _Pragma("unroll") for (int j = 0; j < CPT; j++) cand_[j] = 0.0;                                                           \
+        _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                          \
+            if (i == JSLP_OPAQUE_SGPR(ipub_)) { _Pragma("unroll") for (int j = 0; j < CPT; j++) cand_[j] = a[i][j]; }             \
+        double quotc_ = 0.0, nv0c_ = 0.0;                                                                                         \
+        if (NPUB) {                                                                                                               \
+            /* round 6: the row leaves NORMALISED (simplex.ts:352-364): should it win, quot is its entry of the entering column --  \
+               which the ratio-test wave left in LDS for every row of mine (sm.colb: the value the update pass has just given the   \
+               cell) -- so the two divisions per lane every reader used to run between the row fetch and the next pricing run       \
+               HERE, once, while the summaries cross the fabric; quot itself and the cost row's new entry of the column            \
+               (-k0 / quot, simplex.ts:386: every workgroup prices with the same cost row) travel in the row record */             \
+            quotc_ = sm.colb[par][ipub_];                                                                                         \
+            nv0c_ = -pub_k0 / quotc_;                                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < CPT; j++) {                                                                     \
+                const int col_ = c0 + j;                                                                                          \
+                const double val_ = cand_[j];                                                                                     \
+                double v_ = 0.0;                                                                                                  \
+                if (col_ < W) {                                                                                                   \
+                    const bool innz_ = nonzero16(val_);                                                                           \
+                    v_ = innz_ ? val_ / quotc_ : 0.0;                                                                             \
+                    if (col_ == pub_pc) v_ = 1.0 / quotc_;                                                                            \
+                    if (innz_ && !nonzero16(v_) && v_ != 0.0) v_ = 0.0; /* (phase 2: some other row is always eliminated -- simplex.ts:381-383) */ \
                 }                                                                                                                 \
+                cand_[j] = v_;                                                                                                    \
+            }                                                                                                                     \
         }                                                                                                                         \
-        if (CKS) JSLP_CKS_RAISE_FLAG(ck_);                                                                                        \
+        const int off_ = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;                    \
+        if (colok) {                                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < CPT; j += 2) {                                                                  \
+                if (c0 + j >= ld) continue;                                                                                       \
+                const u64_t lo_ = (u64_t)__double_as_longlong(cand_[j]), hi_ = (u64_t)__double_as_longlong(cand_[j + 1]);         \
+                v4u_t v_;                                                                                                         \
+                v_.x = (unsigned)lo_; v_.y = (unsigned)(lo_ >> 32); v_.z = (unsigned)hi_; v_.w = (unsigned)(hi_ >> 32);           \
+                if (!flag_first_ && early_lane_) __builtin_amdgcn_raw_buffer_store_b128(v_, rsrc_rows, off_ + (j >> 1) * PAIR_STEP, 0, ST_AUX); \
+                if (CKS) JSLP_CK_PAIR(ck_, lo_, hi_, j);                                                                          \
+            }                                                                                                                     \
+        }                                                                                                                         \
+        if (CKS) { if (NPUB) JSLP_CKS_RAISE_REC(ck_, quotc_, nv0c_); else JSLP_CKS_RAISE_FLAG(ck_); }                              \
         if (flag_first_ || torn_) {                                                                                               \
             __builtin_amdgcn_s_sleep(127);                                                                                        \
             if (colok && (flag_first_ || !early_lane_)) {                                                                         \
-                _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                  \
-                    if (i == JSLP_OPAQUE_SGPR(ipub_)) {                                                                           \
-                        const int off_ = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;    \
-                        _Pragma("unroll") for (int j = 0; j < CPT; j += 2) {                                                      \
-                            if (c0 + j >= ld) continue;                                                                           \
-                            const u64_t lo_ = (u64_t)__double_as_longlong(a[i][j]), hi_ = (u64_t)__double_as_longlong(a[i][j + 1]); \
-                            v4u_t v_;                                                                                             \
-                            v_.x = (unsigned)lo_; v_.y = (unsigned)(lo_ >> 32); v_.z = (unsigned)hi_; v_.w = (unsigned)(hi_ >> 32); \
-                            __builtin_amdgcn_raw_buffer_store_b128(v_, rsrc_rows, off_ + (j >> 1) * PAIR_STEP, 0, ST_AUX);        \
-                        }                                                                                                         \
-                    }                                                                                                             \
+                _Pragma("unroll") for (int j = 0; j < CPT; j += 2) {                                                              \
+                    if (c0 + j >= ld) continue;                                                                                   \
+                    const u64_t lo_ = (u64_t)__double_as_longlong(cand_[j]), hi_ = (u64_t)__double_as_longlong(cand_[j + 1]);     \
+                    v4u_t v_;                                                                                                     \
+                    v_.x = (unsigned)lo_; v_.y = (unsigned)(lo_ >> 32); v_.z = (unsigned)hi_; v_.w = (unsigned)(hi_ >> 32);       \
+                    __builtin_amdgcn_raw_buffer_store_b128(v_, rsrc_rows, off_ + (j >> 1) * PAIR_STEP, 0, ST_AUX);                \
+                }                                                                                                                 \
             }                                                                                                                     \
         }                                                                                                                         \
     } while (0)
@@ -357,27 +419,72 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         const u64_t x_ = JSLP_CK_WAVE(CK) ^ JSLP_CK_TAGMIX(tag);                                                                  \
         if (lane == 0) AG_STORE(f.rowflagc[par] + wv * JSLP_F_MAXG + b, x_);                                                      \
     } while (0)
-// ... and the fetch: flag word and row in ONE look, repeated until the checksum of what arrived matches the word
-#define JSLP_CKS_FETCH_ROW()                                                                                                      \
+// round 6, NPUB builds: the 32-byte RECORD of (parity, wave, workgroup) instead of the 8-byte word: {checksum word, quot, -k0 / quot, 0}.  quot and
+// the cost row's entry are folded into the checksum word (odd multipliers), so a record whose halves belong to different epochs fails like a torn row
+#define JSLP_CK_QMIX(Q, NV) (((u64_t)__double_as_longlong(Q) * 0x9E3779B97F4A7C15ull) ^ ((u64_t)__double_as_longlong(NV) * 0xC2B2AE3D27D4EB4Full))
+#define JSLP_REC_OFF(PAR, WV, B) (JSLP_R_REC_OFF + (((PAR) * JSLP_R_FLAGCOPIES + (WV)) * JSLP_F_MAXG + (B)) * JSLP_R_REC_BYTES)
+#define JSLP_CKS_RAISE_REC(CK, Q, NV)                                                                                             \
+    do {                                                                                                                          \
+        const u64_t x_ = JSLP_CK_WAVE(CK) ^ JSLP_CK_TAGMIX(tag) ^ JSLP_CK_QMIX(Q, NV);                                            \
+        if (lane == 0) {                                                                                                          \
+            const u64_t qb_ = (u64_t)__double_as_longlong(Q), nb_ = (u64_t)__double_as_longlong(NV);                              \
+            v4u_t r0_, r1_;                                                                                                       \
+            r0_.x = (unsigned)x_; r0_.y = (unsigned)(x_ >> 32); r0_.z = (unsigned)qb_; r0_.w = (unsigned)(qb_ >> 32);             \
+            r1_.x = (unsigned)nb_; r1_.y = (unsigned)(nb_ >> 32); r1_.z = tag; r1_.w = 0u;                                        \
+            __builtin_amdgcn_raw_buffer_store_b128(r0_, rsrc_g16, JSLP_REC_OFF(par, wv, b), 0, ST_AUX);                           \
+            __builtin_amdgcn_raw_buffer_store_b128(r1_, rsrc_g16, JSLP_REC_OFF(par, wv, b) + 16, 0, ST_AUX);                      \
+        }                                                                                                                         \
+    } while (0)
+// ... and the fetch: flag word (NPUB: record) and row in ONE look, repeated until the checksum of what arrived matches the word
+// (SPLITU builds: the first look's loads leave, THEN the pending pivot's row update runs -- JSLP_CKS_BETWEEN -- and only then the look is examined)
+#define JSLP_CKS_ISSUE_LOOK()                                                                                                     \
+    do {                                                                                                                          \
+        if (__builtin_amdgcn_readfirstlane((int)((F_TEST_LATE & 1) != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);              \
+        if (NPUB) { /* (one address per wave: the record, 32 bytes, in flight with the row) */                                    \
+            rec0_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, JSLP_REC_OFF(par, wv, bw), 0, 16);                            \
+            rec1_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, JSLP_REC_OFF(par, wv, bw) + 16, 0, 16);                       \
+        } else {                                                                                                                  \
+            flag_ = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);                                                             \
+        }                                                                                                                         \
+        if (colok) {                                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < CPT; j += 2) {                                                                  \
+                if (c0 + j >= ld) continue;                                                                                       \
+                rowv_[j >> 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + (j >> 1) * PAIR_STEP, 0, 16);           \
+            }                                                                                                                     \
+        }                                                                                                                         \
+    } while (0)
+#define JSLP_CKS_FETCH_ROW() JSLP_CKS_FETCH_ROW_B(do { } while (0))
+#define JSLP_CKS_FETCH_ROW_B(BETWEEN)                                                                                             \
     do {                                                                                                                          \
         efetch += 1;                                                                                                              \
         unsigned spins_ = 0;                                                                                                      \
         const u64_t tmix_ = JSLP_CK_TAGMIX(tag);                                                                                  \
+        u64_t flag_ = 0;                                                                                                          \
+        v4u_t rec0_, rec1_, rowv_[CPT / 2];                                                                                       \
+        rec0_.x = rec0_.y = rec0_.z = rec0_.w = 0u; rec1_ = rec0_;                                                                \
+        _Pragma("unroll") for (int j = 0; j < CPT / 2; j++) rowv_[j] = rec0_;                                                     \
+        JSLP_CKS_ISSUE_LOOK();                                                                                                    \
+        BETWEEN;                                                                                                                  \
         for (;;) {                                                                                                                \
-            if (__builtin_amdgcn_readfirstlane((int)((F_TEST_LATE & 1) != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);          \
-            const u64_t flag_ = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);                                                 \
+            u64_t qm_ = 0;                                                                                                        \
             u64_t ck_ = 0;                                                                                                        \
             if (colok) {                                                                                                          \
                 _Pragma("unroll") for (int j = 0; j < CPT; j += 2) {                                                              \
                     if (c0 + j >= ld) continue;                                                                                   \
-                    const v4u_t v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + (j >> 1) * PAIR_STEP, 0, 16);      \
+                    const v4u_t v_ = rowv_[j >> 1];                                                                               \
                     const u64_t lo_ = (u64_t)v_.x | ((u64_t)v_.y << 32), hi_ = (u64_t)v_.z | ((u64_t)v_.w << 32);                 \
                     pv[j] = __longlong_as_double((long long)lo_);                                                                 \
                     pv[j + 1] = __longlong_as_double((long long)hi_);                                                             \
                     JSLP_CK_PAIR(ck_, lo_, hi_, j);                                                           \
                 }                                                                                                                 \
             }                                                                                                                     \
-            const u64_t x_ = JSLP_CK_WAVE(ck_) ^ tmix_;                                                                           \
+            if (NPUB) {                                                                                                           \
+                flag_ = (u64_t)rec0_.x | ((u64_t)rec0_.y << 32);                                                                  \
+                fq = __longlong_as_double((long long)((u64_t)rec0_.z | ((u64_t)rec0_.w << 32)));                                  \
+                fnv = __longlong_as_double((long long)((u64_t)rec1_.x | ((u64_t)rec1_.y << 32)));                                 \
+                qm_ = JSLP_CK_QMIX(fq, fnv);                                                                                      \
+            }                                                                                                                     \
+            const u64_t x_ = JSLP_CK_WAVE(ck_) ^ tmix_ ^ qm_;                                                                     \
             if (__builtin_amdgcn_readfirstlane((int)(x_ == flag_))) break;                                                        \
             JSLP_RT_RETRY();                                                                                                      \
             if (lane == 0) atomicAdd(f.abort_flag + 1, 1u); /* (health counter: looks that found flag word and row disagreeing) */ \
@@ -387,6 +494,7 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
             if ((spins_ & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead_ = true;                                                 \
             if (spins_ > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead_ = true; }                                     \
             if (dead_) { if (lane == 0) atomicMax(&sm.okbad, efetch); break; }                                                    \
+            JSLP_CKS_ISSUE_LOOK();                                                                                                \
         }                                                                                                                         \
     } while (0)
 #ifdef JSLP_DEBUG_RESIDENT
@@ -438,6 +546,36 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         }                                                                                                                         \
     } while (0)
 
+// round 6: the GLOBAL half of a pivot's basis change (simplex.ts:339-349: the four index maps in HBM, the pivot trace) is committed by ONE thread
+// of workgroup 0 -- a dependent trip to memory (the eight pointers come from the device copy of the context) that used to sit between the row
+// fetch and the next pricing: workgroup 0 reached every pricing barrier ~0.9 k cycles behind the other 250, and the whole chip waited for its
+// summary in the gather (section table, r06_a: pricing 3.2 k cycles in workgroup 0 against 2.36 k everywhere else).  The LDS maps are still
+// swapped where they were; the global stores follow in the NEXT iteration's update section (while the summaries cross the fabric) or behind
+// the loop, as fire-and-forget stores through pointers kept in LDS.  Same stores, same order, one pivot later.
+typedef __attribute__((address_space(1))) int32_t jslp_gi32_t;  // (a pointer into GLOBAL memory, as opposed to a generic one)
+#define JSLP_PIPE_COMMIT_GLOBAL()                                                                                                 \
+    do {                                                                                                                          \
+        if (cpend && tid == THREADS - 64 && b == 0) {                                                                             \
+            const int ent_ = sm.cm_ent, leav_ = sm.cm_leav; /* (pointers from LDS: nothing here waits for memory; GLOBAL stores, not flat \
+                ones -- behind a flat access the compiler waits vmcnt(0) wherever it waits at all, which would undo the look-ahead poll) */ \
+            jslp_gi32_t* const vibr_ = (jslp_gi32_t*)sm.gp_vibr;                                                                  \
+            jslp_gi32_t* const vibc_ = (jslp_gi32_t*)sm.gp_vibc;                                                                  \
+            jslp_gi32_t* const rbv_ = (jslp_gi32_t*)sm.gp_rbv;                                                                    \
+            jslp_gi32_t* const cbv_ = (jslp_gi32_t*)sm.gp_cbv;                                                                    \
+            vibr_[pr_p] = ent_;                                                                                                   \
+            vibc_[pc_p] = leav_;                                                                                                  \
+            rbv_[ent_] = pr_p;                                                                                                    \
+            rbv_[leav_] = -1;                                                                                                     \
+            cbv_[ent_] = -1;                                                                                                      \
+            cbv_[leav_] = pc_p;                                                                                                   \
+            if (R.trace_n - 1 < sm.gp_trace_cap) {                                                                                \
+                jslp_gi32_t* const tr_ = (jslp_gi32_t*)sm.gp_trace + 2 * (R.trace_n - 1);                                         \
+                tr_[0] = pr_p; tr_[1] = pc_p;                                                                                     \
+            }                                                                                                                     \
+        }                                                                                                                         \
+        cpend = false;                                                                                                            \
+    } while (0)
+
 // CHK = false: a build without any of the cycle check's code (the host launches it when the check is off: with the test's loops
 // inlined in the middle of the pivot loop the check-OFF solve ran 2 % slower)
 // UNR (round 4): unrestricted variables in the lean loops -- a per-lane bit mask of the columns whose variable is unrestricted (R.unr,
@@ -460,7 +598,17 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     constexpr bool CKS = !TAGGED && JSLP_PIPE_SPECPUB != 0 && JSLP_PIPE_ROW_CHECKSUM != 0 && CPT <= JSLP_PIPE_ROW_CHECKSUM_MAXCPT;  // checksummed hand-over of the candidate rows (see JSLP_PIPE_ROW_CHECKSUM)
     constexpr bool UPD_NEW_ = XL || (JSLP_PIPE_NEW_UPDATE != 0 && CPT <= 4 && !(OPT && ROWS > 8));
     constexpr int EARLY = (!XL && UPD_NEW_) ? JSLP_PIPE_EARLY_LOOKS : 0;  // looks at the summaries that leave during the row update
-    constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT && !CKS);  // quot comes with the fetch: no barrier behind it
+    constexpr bool LA = !XL && JSLP_PIPE_LOOK_AHEAD != 0;  // the first look leaves in front of the row update (see JSLP_PIPE_LOOK_AHEAD)
+    // round 6 -- NPUB: the candidate row is published NORMALISED (JSLP_PUBLISH_ROW_PLAIN) and quot / the cost row's new entry of the entering column come
+    // with the row's record: between the row fetch and the next pricing no division and no barrier are left (the update pass that publishes
+    // is JSLP_XL_UPDATE_PASS + JSLP_PUBLISH_ROW_PLAIN: the 2- / 4-column geometries; optional objectives need the raw row for their tiny-entry rule)
+    constexpr bool NPUB = CKS && !OPT && !XL && JSLP_PIPE_NEW_UPDATE != 0 && CPT <= 4 && JSLP_PIPE_NORM_PUB != 0;
+    // SPLITU (round 6): the pending pivot's row update in two parts -- the ONE row that can win right behind the summary (it is published from
+    // there), the other rows while the winning row's fetch is in flight.  The pivot period is the loop time of the workgroup whose summary
+    // arrives last (tools/resident_stamps.py), and that loop used to be summary -> whole update pass -> look at the summaries (one round trip)
+    // -> decide -> row fetch (another round trip): the pass now hides behind the second trip instead of standing in front of the first
+    constexpr bool SPLITU = NPUB && JSLP_PIPE_SPLIT_UPDATE != 0;
+    constexpr bool QDIRECT = TAGGED || NPUB || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT && !CKS);  // quot comes with the fetch: no barrier behind it
     // the ratio test's transposition (entry i of the entering column from the ONE lane that holds it to lane i) through LDS: as `x = lane
     // == i ? readlane(a[i][j]) : x` the compiler precomputes the 64-bit lane masks, spills them and pays two reloads, two moves and two
     // selects per row on top of the readlanes -- in the one wave the summary waits for
@@ -492,7 +640,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
     const int pub_stride = (int)((const char*)f.rows_pub[1] - (const char*)f.rows_pub[0]);  // (both carved from one arena, [0] first)
     const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + (TAGGED ? (WLL ? 1 : f.G) * ld * 16 : f.G * (CPT >= 6 ? THREADS * CPT * 8 + JSLP_PUB_SKEW : ld * 8)), 0x00020000);
-    const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, 2 * JSLP_F_MAXG * JSLP_G16_STRIDE, 0x00020000);
+    const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, JSLP_R_REC_OFF + JSLP_R_REC_WORDS * 8, 0x00020000);  // (the summary granules, the row-flag copies and the row records: one descriptor)
 #ifdef JSLP_DEBUG_RESIDENT
     u64_t (&rt_acc)[8] = R.rt_acc;
     u64_t& rt_prev = R.rt_prev;
@@ -502,7 +650,10 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     double p[CPT];      // its normalised pivot row, my columns
     unsigned nzm = 0;   // bit j: p[j] is non-zero by the reference's test (simplex.ts:379)
     int pr_p = 0, pc_p = 0, par_p = 0;  // its row, column and parity
+    double quot_p = 1.0;                // its pivot element (NPUB builds: -k / quot of the pivot column's own entries is computed when needed)
     bool pend = false;
+    bool cpend = false;  // the pending pivot's global commit has not been issued yet (JSLP_PIPE_COMMIT_GLOBAL)
+    unsigned emask = 0u;  // SPLITU: bit i = my row i has received the pending pivot already (JSLP_UPDATE_ONE_ROW)
 #pragma unroll
     for (int j = 0; j < CPT; j++) p[j] = 0.0;
     int okslot = 0;
@@ -539,7 +690,9 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         int pc;
         {
             int neg_now = 0;
+            RT_STAMP(5);  // at the pricing
             pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &k0, R.unr, &neg_now);
+            RT_STAMP(6);  // priced
             if (UNR) R.neg = neg_now;  // isReducedCostNegative of the entering column (simplex.ts:164-177): the ratio test's sign
         }
         bool opt_enter = false;  // the entering column is named by an optional objective: its main cost is within +-precision
@@ -598,9 +751,11 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 colv = x;
                 if (pend) {  // what the pending pivot makes of this cell (the update pass will compute the same)
                     const double ki = sm.colb[par_p][lane];
-                    const double nvv = sm.nv[lane];
                     if (r == pr_p) colv = pj;
-                    else if (r != 0 && r < r_end && nonzero16(ki)) colv = pc_p == pc ? nvv : (nzj ? eliminate(x, ki, pj) : x);
+                    else if (r != 0 && r < r_end && nonzero16(ki)) {
+                        if (__builtin_amdgcn_readfirstlane(pc_p) == __builtin_amdgcn_readfirstlane(pc)) colv = NPUB ? -ki / quot_p : sm.nv[lane];  // (uniform, rare: the column that has just left enters again -- simplex.ts:386)
+                        else colv = nzj ? eliminate(x, ki, pj) : x;
+                    }
                 }
                 sm.colb[par][lane] = colv;  // every thread's update pass of THIS pivot reads it (after the barrier below)
                 const double rhs = sm.rhsb[lane];
@@ -642,6 +797,10 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         }
         __syncthreads();
         const int pubrow = sm.pubrow;
+        RT_STAMP(0);  // summary stored (the claiming wave stored it in front of the barrier)
+        const double pub_k0 = k0;
+        const int pub_pc = pc;
+        (void)pub_k0; (void)pub_pc;
         RT_MARK(0);
         // ---- U + P: the pending pivot's row update (simplex.ts:367-391), ONE pass over my rows; the row that can win is
         //         published (16-byte write-through stores) as soon as it is up to date.  The summaries are crossing the fabric
@@ -657,8 +816,16 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         // examines them in order before it starts looking again
         v4u_t ge0 = g, ge1 = g;
         if (EARLY >= 2 && poller && used) ge0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
+        v4u_t gla = g;  // the look-ahead (JSLP_PIPE_LOOK_AHEAD): examined behind the update pass
+        if (LA && poller && used) gla = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
         // (the pending pivot's column entries of my rows: broadcast LDS reads, JSLP_PIPE_KCHUNK of them in flight together)
-        if (UPD_NEW) {
+        if (SPLITU) {  // only the row that can win, and its publication; the other rows: behind the decision, while the winning row is in flight
+            if (pubrow != 0) {
+                const int ipub = __builtin_amdgcn_readfirstlane(pubrow - r_begin);
+                if (pend) { JSLP_UPDATE_ONE_ROW(ipub); emask = 1u << ipub; }
+                JSLP_PUBLISH_ROW_PLAIN(pubrow);
+            }
+        } else if (UPD_NEW) {
             if (pend) JSLP_XL_UPDATE_PASS();
             if (EARLY >= 1 && poller && used) ge1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
             if (pubrow != 0) {
@@ -714,12 +881,15 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             }
         }
         }
-        pend = false;
+        JSLP_PIPE_COMMIT_GLOBAL();  // (the pending pivot's global maps + trace: behind my row stores, while the summaries cross the fabric)
+        if (!SPLITU) pend = false;
+        RT_STAMP(1);  // update + publication issued
         RT_MARK(2);
         // ---- C: gather: lane w of the first four waves polls workgroup w's granule ------------------------------------------------
         if (poller) {
             unsigned spins = 0;
             bool have = false;
+            if (LA && __all(gla.y == tag && (gla.w >> 16) == (tag & 0xffffu))) { g = gla; have = true; }
             if (EARLY >= 1) {
                 v4u_t gl = g;
                 if (used) gl = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);  // (leaves before the early looks are examined)
@@ -756,11 +926,13 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             x = ki_wave_min(x);
             if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; sm.part_rdeg[wv] = rdeg; }
         }
+        RT_STAMP(2);  // my wave's 64 summaries are in
         RT_MARK(1);
         if (QDIRECT && !OPT && tid == THREADS - 1) { sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff; }  // the next pricing's reductions: everybody read this pivot's before the barrier that closed S; the barrier below orders the reset in front of the next pricing
         if (!TAGGED && !CKS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2 (the winner's release below builds on it; XL / winner-only: the row carries its tags)
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
+        RT_STAMP(3);  // gather closed
         RT_MARK(3);
         // ---- D: every thread folds the four partial results ------------------------------------------------------------------
         int pr = 0, stop = 0;
@@ -847,6 +1019,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
         for (int j = 0; j < CPT; j++) pv[j] = 0.0;
         double quot = 0.0;
+        double fq = 0.0, fnv = 0.0;  // NPUB: quot and -k0 / quot as they came with the row's record
         double ook[JSLP_R_MAXOPT];  // the optional objectives' entries of column pc (OPT builds)
 #pragma unroll
         for (int o = 0; o < JSLP_R_MAXOPT; o++) ook[o] = 0.0;
@@ -855,6 +1028,8 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             // (see resident_phase's step E); a wave that gives up raises sm.okbad to this fetch's number
             if (TAGGED) {
                 JSLP_XL_FETCH_ROW(pc, quot);
+            } else if (SPLITU) {
+                JSLP_CKS_FETCH_ROW_B(do { if (pend) { JSLP_XL_UPDATE_PASS_M(emask); } pend = false; emask = 0u; } while (0));
             } else if (CKS) {
                 JSLP_CKS_FETCH_ROW();
             } else {
@@ -890,7 +1065,8 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 quot = (pc & 1) ? __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32))) : __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
             }
             }  // !XL
-            if (has_pc) {
+            if (NPUB) quot = fq;
+            if (!NPUB && has_pc) {
 #pragma unroll
                 for (int j = 0; j < CPT; j++)
                     if (pc == c0 + j) {
@@ -914,12 +1090,16 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             okslot ^= 1;  // the next use writes the other words: one barrier per use
         }
         if (R.end_code == 5) break;
+        RT_STAMP(4);  // row fetched
         RT_MARK(4);
         // ---- N: normalised pivot row (simplex.ts:352-364; phase 2: some other row is always eliminated, so the tiny entries
         //         simplex.ts:381-383 zeroes are zero) -----------------------------------------------------------------------------
         nzm = 0;
         int tiny = 0;
-        if (colok) {
+        if (NPUB) {  // the row arrived normalised (lanes beyond ld fetched nothing: zeros)
+#pragma unroll
+            for (int j = 0; j < CPT; j++) p[j] = pv[j];
+        } else if (colok) {
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
                 const int col = c0 + j;
@@ -983,7 +1163,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 if (r == pr) v = p0;
                 else if (r != 0 && r < r_end && nonzero16(ki) && nz0) v = eliminate(v, ki, p0);
                 sm.rhsb[lane] = v;
-                sm.nv[lane] = -ki / quot;
+                if (!NPUB) sm.nv[lane] = -ki / quot;  // (NPUB: computed where it is needed -- the update pass, the rare re-entering column)
             }
         }
         // ---- R0: the cost row (every workgroup its own copy) -----------------------------------------------------------------------
@@ -992,7 +1172,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             for (int j = 0; j < CPT; j++)
                 if ((nzm >> j) & 1u) r0[j] = eliminate(r0[j], k0, p[j]);
             if (has_pc) {
-                const double nv0 = -k0 / quot;
+                const double nv0 = NPUB ? fnv : -k0 / quot;  // (NPUB: the publisher's division, same operands -- every workgroup holds the same cost row)
 #pragma unroll
                 for (int j = 0; j < CPT; j++)
                     if (pc == c0 + j) r0[j] = nv0;
@@ -1003,19 +1183,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc];
             sm.lvibr[pr] = entering;
             sm.lvibc[pc] = leaving;
-            if (b == 0) {
-                // (the global maps and the trace are touched by this ONE thread of the chip: their eight pointers come from the device
-                //  copy of the context when needed instead of living in scalar registers through the whole pivot loop -- SGPR pressure,
-                //  jslp_resident.hip.h `ResCtx::cdev`)
-                const Ctx& g = *f.cdev;
-                g.vibr[pr] = entering;
-                g.vibc[pc] = leaving;
-                g.rbv[entering] = pr;
-                g.rbv[leaving] = -1;
-                g.cbv[entering] = -1;
-                g.cbv[leaving] = pc;
-                if (R.trace_n < g.trace_cap) g.trace[R.trace_n] = make_int2(pr, pc);
-            }
+            if (b == 0) { sm.cm_ent = entering; sm.cm_leav = leaving; }  // (the global maps and the trace follow one iteration later: JSLP_PIPE_COMMIT_GLOBAL)
         }
         if (UNR && has_pc) {
 #pragma unroll
@@ -1025,14 +1193,16 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         R.trace_n += 1;
         R.it2 += 1;
         R.epoch = epoch + 1;
-        pend = true; pr_p = pr; pc_p = pc; par_p = par;
+        pend = true; pr_p = pr; pc_p = pc; par_p = par; quot_p = quot;
+        cpend = true;
         RT_MARK(5);
     }
+    JSLP_PIPE_COMMIT_GLOBAL();  // (a basis change whose global half is still pending)
     if (pend && R.end_code != 5) {  // whoever leaves with a pivot pending (optimal, iteration cap, hand-over) brings the rows up to date
         const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;
         if (UPD_NEW) {
             (void)has_pc_p;
-            JSLP_XL_UPDATE_PASS();
+            JSLP_XL_UPDATE_PASS_M(emask);  // (SPLITU: an exit between the two parts of the update leaves one row already up to date)
         } else
 #pragma unroll
         for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
@@ -1069,6 +1239,11 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
     constexpr bool CKS = !TAGGED && JSLP_PIPE_SPECPUB != 0 && JSLP_PIPE_ROW_CHECKSUM != 0 && CPT <= JSLP_PIPE_ROW_CHECKSUM_MAXCPT;  // checksummed hand-over of the candidate rows (see JSLP_PIPE_ROW_CHECKSUM)
     constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT && !CKS);  // quot comes with the fetch: no barrier behind it
+    constexpr bool NPUB = false;  // (phase 1 knows its entering column only once the pivot row has arrived: the row travels as it is)
+    const double quot_p = 1.0, pub_k0 = 0.0;
+    const int pub_pc = 0;
+    double fq = 0.0, fnv = 0.0;
+    (void)quot_p; (void)pub_k0; (void)pub_pc; (void)fq; (void)fnv;
     // the ratio test's transposition (entry i of the entering column from the ONE lane that holds it to lane i) through LDS: as `x = lane
     // == i ? readlane(a[i][j]) : x` the compiler precomputes the 64-bit lane masks, spills them and pays two reloads, two moves and two
     // selects per row on top of the readlanes -- in the one wave the summary waits for
@@ -1100,7 +1275,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
     const int pub_stride = (int)((const char*)f.rows_pub[1] - (const char*)f.rows_pub[0]);
     const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + (TAGGED ? (WLL ? 1 : f.G) * ld * 16 : f.G * (CPT >= 6 ? THREADS * CPT * 8 + JSLP_PUB_SKEW : ld * 8)), 0x00020000);
-    const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, 2 * JSLP_F_MAXG * JSLP_G16_STRIDE, 0x00020000);
+    const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, JSLP_R_REC_OFF + JSLP_R_REC_WORDS * 8, 0x00020000);  // (the summary granules, the row-flag copies and the row records: one descriptor)
 #ifdef JSLP_DEBUG_RESIDENT
     u64_t (&rt_acc)[8] = R.rt_acc;
     u64_t& rt_prev = R.rt_prev;
@@ -1109,6 +1284,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     unsigned nzm = 0;
     int pr_p = 0, pc_p = 0, par_p = 0;
     bool pend = false;
+    bool cpend = false;  // the pending pivot's global commit has not been issued yet (JSLP_PIPE_COMMIT_GLOBAL)
 #pragma unroll
     for (int j = 0; j < CPT; j++) p[j] = 0.0;
     unsigned& efetch = R.efetch;  // row fetches of this workgroup so far (uniform; one count for both phases: sm.okbad only grows)
@@ -1229,6 +1405,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             }
         }
         }
+        JSLP_PIPE_COMMIT_GLOBAL();  // (the pending pivot's global maps + trace: behind my row stores, while the summaries cross the fabric)
         pend = false;
         RT_MARK(2);
         // ---- C: gather ----------------------------------------------------------------------------------------------------
@@ -1471,19 +1648,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc];
             sm.lvibr[pr] = entering;
             sm.lvibc[pc] = leaving;
-            if (b == 0) {
-                // (the global maps and the trace are touched by this ONE thread of the chip: their eight pointers come from the device
-                //  copy of the context when needed instead of living in scalar registers through the whole pivot loop -- SGPR pressure,
-                //  jslp_resident.hip.h `ResCtx::cdev`)
-                const Ctx& g = *f.cdev;
-                g.vibr[pr] = entering;
-                g.vibc[pc] = leaving;
-                g.rbv[entering] = pr;
-                g.rbv[leaving] = -1;
-                g.cbv[entering] = -1;
-                g.cbv[leaving] = pc;
-                if (R.trace_n < g.trace_cap) g.trace[R.trace_n] = make_int2(pr, pc);
-            }
+            if (b == 0) { sm.cm_ent = entering; sm.cm_leav = leaving; }  // (the global maps and the trace follow one iteration later: JSLP_PIPE_COMMIT_GLOBAL)
         }
         if (UNR && has_pc) {
 #pragma unroll
@@ -1494,8 +1659,10 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         R.it1 += 1;
         R.epoch = epoch + 1;
         pend = true; pr_p = pr; pc_p = pc; par_p = par;
+        cpend = true;
         RT_MARK(5);
     }
+    JSLP_PIPE_COMMIT_GLOBAL();  // (a basis change whose global half is still pending)
     if (pend && R.end_code != 5) {
         const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;
         if (UPD_NEW) {
@@ -1519,9 +1686,17 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #undef JSLP_PIPE_UPDATE_ROW
 #undef JSLP_OPAQUE_SGPR
 #undef JSLP_XL_UPDATE_PASS
+#undef JSLP_XL_UPDATE_PASS_M
+#undef JSLP_UPDATE_ONE_ROW
 #undef JSLP_XL_PUBLISH_ROW
 #undef JSLP_PUBLISH_ROW_PLAIN
 #undef JSLP_XL_FETCH_ROW
 #undef JSLP_CKS_FETCH_ROW
+#undef JSLP_CKS_FETCH_ROW_B
+#undef JSLP_CKS_ISSUE_LOOK
 #undef JSLP_CKS_RAISE_FLAG
+#undef JSLP_CKS_RAISE_REC
+#undef JSLP_REC_OFF
+#undef JSLP_CK_QMIX
 #undef JSLP_RT_RETRY
+#undef JSLP_PIPE_COMMIT_GLOBAL

@@ -77,6 +77,18 @@ for s in $steps; do
     qprof) (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/qprof -o q -- python $GRAFT_REPO_ROOT/tools/wglds_timing.py rate > $GRAFT_REPO_ROOT/$out/qprof.log 2>&1 < /dev/null); echo "qprof rc=$?"; tail -2 $out/qprof.log
           timeout 60 python tools/rocpd_stats.py $(ls $out/qprof/*.db | head -1) 2>/dev/null | head -12 ;;
     batchtests) timeout 900 python -m pytest tests -m gpu -q -x -k "batch or pool or relax" > $out/batchtests.log 2>&1 < /dev/null; echo "batchtests rc=$?"; tail -5 $out/batchtests.log ;;
+    tree) # round 6: N consecutive Monster_II trees, every C-ABI call timed; TREE_N (default 500), TREE_ENV="A=1 B=2" extra environment
+          env ${TREE_ENV:-JSLP_NOOP=1} timeout 900 python tools/tree_latency.py ${TREE_N:-500} $out/tree_latency${TREE_TAG:-}.md > $out/tree_latency${TREE_TAG:-}.log 2>&1 < /dev/null; echo "tree rc=$?"; grep -v Warning $out/tree_latency${TREE_TAG:-}.log | tail -25 ;;
+    devab) # round 6: A/B of development builds of the headline kernel (DEV_LIBS="build/libA.so build/libB.so"; `shipped` always runs first): config 3a / 3b rates + digests,
+           # and the per-section cycle table for every library whose name ends in _dbg.so (-DJSLP_DEBUG_RESIDENT)
+           (for l in shipped ${DEV_LIBS:-}; do
+              echo "== library: $l"; L="JSLP_HIP_LIBRARY=$l"; [ $l = shipped ] && L="JSLP_AB_NONE=1"
+              case $l in
+                *_dbg.so) env $L timeout 200 python tools/resident_phase_timing.py 2000 2>&1 | grep -v "^micro" ;;
+                *) env $L ${DEV_ENV:-JSLP_NOOP=1} timeout 300 python tools/dense_lp_times.py 2>&1 | tail -4 ;;
+              esac
+            done) > $out/devab.log 2>&1 < /dev/null; echo "devab rc=$?"; cat $out/devab.log ;;
+    cpt4) (JSLP_RES_CPT=4 timeout 300 python tools/dense_lp_times.py) > $out/cpt4.log 2>&1 < /dev/null; echo "cpt4 rc=$?"; cat $out/cpt4.log ;;
     wide) timeout 900 python -m pytest tests/test_wide_goldens.py -m gpu -q > $out/wide.log 2>&1 < /dev/null; echo "wide rc=$?"; tail -15 $out/wide.log ;;
   esac
 done
