@@ -168,6 +168,10 @@ struct RSmem {
     // pair with a clear bit needs no suffix test at all (exact: bits are only ever set; a collision merely runs the test)
     unsigned cycbits_tail[JSLP_R_CYCEXTRA];
     int32_t cyc_need, cyc_filter_on;
+    // lean pipelined phase 2 (price_row_pipe): the pricing's reduction words, double-buffered by pivot parity (reset one pivot ahead, a barrier away
+    // from every use) -- first batch holding a candidate, best value in it, first column with that value, isReducedCostNegative of the winner
+    int32_t pw_batch[2], pw_col[2], pw_neg[2];
+    u64_t pw_val[2];
     int32_t cm_ent, cm_leav;  // lean pipelined loops, workgroup 0: the basis change whose GLOBAL commit is still pending (written and read by the one committing thread)
     // ... and what that thread needs to issue the commit as seven fire-and-forget stores (no trip to the device copy of the context in front of them)
     int32_t* gp_vibr; int32_t* gp_vibc; int32_t* gp_rbv; int32_t* gp_cbv; int2* gp_trace; long long gp_trace_cap;

@@ -83,6 +83,23 @@
 // (Round 4's JSLP_PIPE_EARLY_LOOKS issued one more look in front of examining the early ones and waited for it.)
 #define JSLP_PIPE_LOOK_AHEAD 0
 #endif
+#ifndef JSLP_PIPE_ONE_POLL_WAVE
+// round 6: ONE wave gathers the <= 256 summaries (lane l looks at workgroups l, l + 64, l + 128, l + 192: four 16-byte loads in flight per lane) instead of
+// four waves of one load per lane each.  The four waves' looks returned at four different times and the barrier that closes the gather waited
+// for the slowest; every thread then folded four partial results.  One wave: one round trip, one partial result.
+#define JSLP_PIPE_ONE_POLL_WAVE 1
+#endif
+#ifndef JSLP_PIPE_LOOK_MID
+// round 6: the polling wave's first look at the summaries leaves between the pending pivot's row update and the publication of the candidate
+// row, and is examined behind the publication: the normalisation's divisions (NPUB) and the row's stores overlap the look's round trip
+#define JSLP_PIPE_LOOK_MID 0
+#endif
+#ifndef JSLP_PIPE_PRICE_IN_WAVE
+#define JSLP_PIPE_PRICE_IN_WAVE 0  // round 6: see price_row_pipe
+#endif
+#ifndef JSLP_PIPE_K_BROADCAST
+#define JSLP_PIPE_K_BROADCAST 1  // round 6: see JSLP_XL_UPDATE_PASS_M
+#endif
 #ifndef JSLP_PIPE_SPLIT_UPDATE
 #define JSLP_PIPE_SPLIT_UPDATE 0  // round 6: see SPLITU in resident_phase2_pipe
 #endif
@@ -131,7 +148,7 @@
 #define JSLP_HOST_ABORT 1
 #endif
 #define JSLP_HOST_ABORT_IN_SPIN(SPINS, SWEPT)                                                                                     \
-    if (JSLP_HOST_ABORT && (SPINS) == 1u && (epoch & (JSLP_HOST_ABORT_PERIOD - 1u)) == JSLP_HOST_ABORT_PERIOD - 1u && b == f.G - 1 && wv == 0) { \
+    if (JSLP_HOST_ABORT && (SPINS) == 1u && (epoch & (JSLP_HOST_ABORT_PERIOD - 1u)) == JSLP_HOST_ABORT_PERIOD - 1u && b == f.G - 1 && wv == HAWV) { \
         const unsigned* ha_ = *reinterpret_cast<const unsigned* const*>(reinterpret_cast<const char*>(f.cdev) + sizeof(Ctx));     \
         if (ha_ != nullptr && __hip_atomic_load(ha_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { /* (one address: uniform) */ \
             if (lane == 0) AG_STORE(f.abort_flag, 1u);                                                                            \
@@ -201,6 +218,89 @@ __device__ __forceinline__ u64_t u64_wave_add_halves(u64_t x) {
 }
 // a lane's checksum -> the wave's word
 #define JSLP_CK_WAVE(CK) u64_wave_add_halves((CK) * (u64_t)(unsigned)(2 * tid + 1))
+
+// ---- pricing of the lean pipelined phase 2 (simplex.ts:118-219), round 6 -------------------------------------------------------------------
+// Round one is price_row_lds's: every lane's best column among its own (earlier batch first, bigger value inside a batch, first index on ties),
+// one LDS atomicMin per wave on the batch, one barrier.  A pricing batch is 50-500 adjacent columns and a wave holds 64 x CPT adjacent columns,
+// so in ~60 % of the pivots the winning batch lies inside ONE wave -- known to every thread from the batch number alone.  Then that wave folds
+// value and column in registers (a DPP maximum of the bit patterns -- positive doubles order like their bits --, a ballot for the first lane
+// holding it), leaves them in LDS for the others and goes straight on to the ratio test, which is its job anyway (it holds the entering
+// column): the second and third barrier and their two rounds of LDS atomics are gone from that pivot; the other waves read column and value
+// behind the barrier that closes the ratio test.  A batch that spans two or more waves takes the two LDS-atomic rounds as before.
+// (Round 4 measured a form of this that lost to 14 more spilled SGPRs: there every wave ran the register fold and the result was needed by
+//  all threads before the ratio test.)
+// Returns the entering column (0: none -> optimal; uniform) -- or -1 in the waves that do not know it yet (`*late` set: read pw_col / pw_val /
+// pw_neg of this parity behind the next barrier); `*claim` = this wave runs the ratio test.
+template <int THREADS, int CPT, bool UNR>
+__device__ __forceinline__ int price_row_pipe(const double (&x)[CPT], int c0, const int (&pb)[CPT], const Ctx& c, RSmem& sm, int par,
+                                              double* value, unsigned unr, int* neg, bool* late, bool* claim) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double bv = c.precision;
+    int bi = 0, bb = 0, bneg = 0;
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {  // my columns in order: earlier batch first, bigger value inside a batch, first index on ties
+        const int col = c0 + j;
+        const bool isneg = UNR && ((unr >> j) & 1u) && x[j] < 0;
+        const double val = isneg ? -x[j] : x[j];
+        const bool ok = col >= 1 && col < c.W && val > c.precision;
+        const bool take = ok && (bi == 0 || pb[j] < bb || (pb[j] == bb && val > bv));
+        bv = take ? val : bv;
+        bi = take ? col : bi;
+        bb = take ? pb[j] : bb;
+        bneg = take ? (isneg ? 1 : 0) : bneg;
+    }
+    {   // batch ids grow with the lane index: the wave's earliest batch is that of its first candidate lane
+        const unsigned long long m = __ballot(bi != 0);
+        if (m != 0ull) {
+            const int first = __ffsll((long long)m) - 1;
+            const int wave_b = __builtin_amdgcn_readlane(bb, first);
+            if (lane == 0) atomicMin(&sm.pw_batch[par], wave_b);
+        }
+    }
+    __syncthreads();
+    const int wb = sm.pw_batch[par];
+    if (tid == THREADS - 1) { sm.pw_batch[par ^ 1] = 0x7fffffff; sm.pw_val[par ^ 1] = 0; sm.pw_col[par ^ 1] = 0x7fffffff; }  // the NEXT pivot's words: last read two barriers ago, first used behind two more
+    *late = false;
+    *claim = false;
+    if (wb == 0x7fffffff) return 0;  // uniform: no candidate anywhere -> optimal
+    const u64_t bits = (u64_t)__double_as_longlong(bv);
+    const bool cand = bi != 0 && bb == wb;
+    // the columns of batch wb (simplex.ts:118-127: batch k = columns 1 + k * batch ... (k + 1) * batch, the last one cut at W - 1) and the waves holding them
+    const int col_lo = 1 + wb * c.batch, col_hi = min(col_lo + c.batch - 1, c.W - 1);
+    const int fw = (col_lo / CPT) >> 6, lw = (col_hi / CPT) >> 6;
+    if (JSLP_PIPE_PRICE_IN_WAVE != 0 && c.use_partial && fw == lw) {  // (uniform)
+        *late = true;
+        if (wv != fw) return -1;
+        *late = false;
+        *claim = true;
+        const u64_t wmax = u64_wave_max(cand ? bits : 0ull);  // (> 0: some lane of this wave holds a candidate of batch wb -- the batch lies in this wave)
+        const unsigned long long m = __ballot(cand && bits == wmax);
+        const int first = __ffsll((long long)m) - 1;
+        const int pcol = __builtin_amdgcn_readlane(bi, first);
+        const int ng = UNR ? __builtin_amdgcn_readlane(bneg, first) : 0;
+        if (lane == 0) { sm.pw_col[par] = pcol; sm.pw_val[par] = wmax; sm.pw_neg[par] = ng; }
+        double v = __longlong_as_double((long long)wmax);
+        if (UNR) { *neg = ng; if (ng) v = -v; }
+        *value = v;
+        return pcol;
+    }
+    if (cand) atomicMax(&sm.pw_val[par], bits);
+    __syncthreads();
+    const u64_t wvv = sm.pw_val[par];
+    if (cand && bits == wvv) atomicMin(&sm.pw_col[par], bi);
+    __syncthreads();
+    const int pcol = sm.pw_col[par];
+    double v = __longlong_as_double((long long)wvv);
+    if (UNR) {  // the lane holding the winner knows the sign of its reduced cost
+        if (cand && bi == pcol) sm.pw_neg[par] = bneg;
+        __syncthreads();
+        *neg = sm.pw_neg[par];
+        if (*neg) v = -v;
+    }
+    *value = v;
+    *claim = wv == ((pcol / CPT) >> 6);
+    return pcol;
+}
 
 #define JSLP_R_MAXOPT 3  // optional objective rows the lean kernel keeps in registers (priorities "strong" / "medium" / "weak": model.ts:141-160)
 
@@ -279,13 +379,29 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
            the column's pass over the rows */                                                                                      \
         const double kl_ = lane < ROWS ? sm.colb[par_p][lane] : 0.0;                                                              \
         const unsigned km_ = (unsigned)__ballot(nonzero16(kl_)) & ~(unsigned)(SKIPMASK); /* (rows beyond the workgroup's share hold zeros: bit clear) */ \
-        _Pragma("unroll") for (int j = 0; j < CPT; j++) { /* (measured, r04_e ... r04_g: per-row LDS reads + per-cell selects 5.4-6.9 k cycles per   \
-            pass; this form 3.9-5.9 k; one pass over the rows with the column gate as an EXEC-masked branch per cell 5.1-8.5 k; a second,  \
-            gate-free copy of the loop for dense pivot rows costs the register allocator ~400 spills) */                           \
+        /* (measured, r04_e ... r04_g, XCD-local build: per-row LDS reads + per-cell SELECTS 5.4-6.9 k cycles per pass; readlane multipliers  \
+            3.9-5.9 k; one pass over the rows with the column gate as an EXEC-masked branch per cell 5.1-8.5 k; a second, gate-free copy of \
+            the loop for dense pivot rows costs the register allocator ~400 spills.  Round 6, JSLP_PIPE_K_BROADCAST: the multipliers of eight \
+            rows come as BROADCAST LDS reads (one address for the whole wave) into vector registers -- a cell is then scalar bit test,    \
+            branch, v_mul_f64, v_add_f64; the two v_readlane + s_nop per cell, which sixteen lock-step waves paid on the VALU port, are gone) */ \
+        if (JSLP_PIPE_K_BROADCAST) {                                                                                              \
+            _Pragma("unroll") for (int i0 = 0; i0 < ROWS; i0 += 8) {                                                              \
+                double kb_[8];                                                                                                    \
+                _Pragma("unroll") for (int i = 0; i < 8; i++) kb_[i] = (i0 + i < ROWS) ? sm.colb[par_p][i0 + i] : 0.0;            \
+                _Pragma("unroll") for (int j = 0; j < CPT; j++) {                                                                 \
+                    if ((nzm >> j) & 1u) {                                                                                        \
+                        _Pragma("unroll") for (int i = 0; i < 8; i++)                                                             \
+                            if (i0 + i < ROWS && (km_ & (1u << (i0 + i)))) a[i0 + i][j] = eliminate(a[i0 + i][j], kb_[i], p[j]);  \
+                    }                                                                                                             \
+                }                                                                                                                 \
+            }                                                                                                                     \
+        } else {                                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < CPT; j++) {                                                                         \
             if ((nzm >> j) & 1u) {                                                                                                \
                 _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                  \
                     if (km_ & (1u << i)) a[i][j] = eliminate(a[i][j], readlane_f64(kl_, i), p[j]);                                \
             }                                                                                                                     \
+        }                                                                                                                         \
         }                                                                                                                         \
         if (wv == ((pc_p / CPT) >> 6)) { /* the pivot column itself: -k / quot (simplex.ts:386), one lane of this wave */         \
             const int ol_ = __builtin_amdgcn_readfirstlane((pc_p / CPT) & 63), js_ = __builtin_amdgcn_readfirstlane(pc_p % CPT);  \
@@ -629,7 +745,11 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     const int SLOT = PERM ? THREADS * CPT * 8 + JSLP_PUB_SKEW : f.c.ld * 8;
     constexpr int PAIR_STEP = PERM ? THREADS * 16 : 16;           // bytes from a lane's pair j to its pair j + 2
     const int lane_off = PERM ? tid * 16 : tid * CPT * 8;          // ... and where its first pair sits in the slot
-    constexpr int NPOLLW = XL ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
+    constexpr bool P1W = !XL && JSLP_PIPE_ONE_POLL_WAVE != 0;  // one polling wave, four summaries per lane (see JSLP_PIPE_ONE_POLL_WAVE)
+    constexpr int NPOLLW = (XL || P1W) ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
+    constexpr int POLLWV = 1;  // ... which wave, when it is one (not wave 0: it carries the column-0 work; not the last: the commit)
+    constexpr int HAWV = P1W ? POLLWV : 0;  // the wave whose retry path looks at the host's abort word (JSLP_HOST_ABORT_IN_SPIN)
+    static_assert(THREADS / 64 > POLLWV, "the polling wave exists");
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
     const int c0 = tid * CPT;
@@ -668,6 +788,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
         for (int i = 0; i < ROWS; i++) sm.rhsb[i] = a[i][0];
         sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff;
+        for (int q = 0; q < 2; q++) { sm.pw_batch[q] = 0x7fffffff; sm.pw_val[q] = 0; sm.pw_col[q] = 0x7fffffff; sm.pw_neg[q] = 0; }
     }
     __syncthreads();
 
@@ -688,10 +809,11 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         // ---- G: price the cost row -> entering column (simplex.ts:118-219; three LDS-atomic rounds) -------------------------------
         double k0 = 0.0;  // reduced cost of the entering column
         int pc;
+        bool pc_late = false, claim = false;  // (price_row_pipe: the waves that learn column and value behind the ratio test's barrier; the wave that runs the ratio test)
         {
             int neg_now = 0;
             RT_STAMP(5);  // at the pricing
-            pc = price_row_lds<CPT, UNR>(r0, c0, pb, c, sm, &k0, R.unr, &neg_now);
+            pc = price_row_pipe<THREADS, CPT, UNR>(r0, c0, pb, c, sm, par, &k0, R.unr, &neg_now, &pc_late, &claim);
             RT_STAMP(6);  // priced
             if (UNR) R.neg = neg_now;  // isReducedCostNegative of the entering column (simplex.ts:164-177): the ratio test's sign
         }
@@ -715,7 +837,8 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         // ---- S: ratio test for column pc (simplex.ts:271-296) by the wave that holds the column: the ONE lane that holds it hands
         //      entry i to lane i (readlanes), lanes 0..ROWS-1 apply the pending pivot to their entry and classify their row in
         //      parallel (one division each), DPP reductions fold the verdicts -- no LDS round trip, no workgroup barrier inside ------
-        if (wv == ((pc / CPT) >> 6)) {
+        if (OPT && opt_enter) claim = wv == ((pc / CPT) >> 6);  // (an entering column named by an optional objective: every thread knows it)
+        if (claim) {
             const int ol = __builtin_amdgcn_readfirstlane((pc / CPT) & 63);  // the lane that holds column pc
             const int jsel = __builtin_amdgcn_readfirstlane(pc % CPT);        // ... as its column jsel
             double x = 0.0, pj = 0.0;
@@ -796,6 +919,11 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             }
         }
         __syncthreads();
+        if (pc_late) {  // the waves that did not hold the winning batch: column, value (and sign) as the claiming wave left them
+            pc = sm.pw_col[par];
+            k0 = __longlong_as_double((long long)sm.pw_val[par]);
+            if (UNR) { R.neg = sm.pw_neg[par]; if (R.neg) k0 = -k0; }
+        }
         const int pubrow = sm.pubrow;
         RT_STAMP(0);  // summary stored (the claiming wave stored it in front of the barrier)
         const double pub_k0 = k0;
@@ -806,7 +934,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         //         published (16-byte write-through stores) as soon as it is up to date.  The summaries are crossing the fabric
         //         meanwhile ----------------------------------------------------------------------------------------------------------
         bool swept = true;
-        const bool poller = tid < NPOLLW * 64;
+        const bool poller = P1W ? wv == POLLWV : tid < NPOLLW * 64;
         const bool used = tid < f.G;
         v4u_t g;
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;  // lanes beyond the grid: "no candidate"
@@ -816,6 +944,9 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         // examines them in order before it starts looking again
         v4u_t ge0 = g, ge1 = g;
         if (EARLY >= 2 && poller && used) ge0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
+        v4u_t gq[JSLP_F_MAXG / 64];  // the one polling wave's looks: lane l looks at workgroups l, l + 64, l + 128, l + 192
+#pragma unroll
+        for (int q = 0; q < JSLP_F_MAXG / 64; q++) gq[q] = g;
         v4u_t gla = g;  // the look-ahead (JSLP_PIPE_LOOK_AHEAD): examined behind the update pass
         if (LA && poller && used) gla = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
         // (the pending pivot's column entries of my rows: broadcast LDS reads, JSLP_PIPE_KCHUNK of them in flight together)
@@ -828,6 +959,14 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         } else if (UPD_NEW) {
             if (pend) JSLP_XL_UPDATE_PASS();
             if (EARLY >= 1 && poller && used) ge1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
+            if (P1W && JSLP_PIPE_LOOK_MID != 0 && poller) {  // the polling wave's first look leaves between the update pass and the publication: the
+                                                             // normalisation's divisions run while it is under way (see JSLP_PIPE_LOOK_MID)
+#pragma unroll
+                for (int q = 0; q < JSLP_F_MAXG / 64; q++) {
+                    gq[q] = g;
+                    if (lane + 64 * q < f.G) gq[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, (par * JSLP_F_MAXG + lane + 64 * q) * JSLP_G16_STRIDE, 0, 16);
+                }
+            }
             if (pubrow != 0) {
                 if (TAGGED) { if (XL) JSLP_XL_PUBLISH_ROW(pubrow); }  // (winner-only builds publish after the decision)
                 else if (JSLP_PIPE_SPECPUB) JSLP_PUBLISH_ROW_PLAIN(pubrow);
@@ -886,7 +1025,52 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         RT_STAMP(1);  // update + publication issued
         RT_MARK(2);
         // ---- C: gather: lane w of the first four waves polls workgroup w's granule ------------------------------------------------
-        if (poller) {
+        if (P1W && poller) {
+            unsigned spins = 0;
+            bool first = UPD_NEW && !SPLITU && JSLP_PIPE_LOOK_MID != 0;  // (that look is under way already)
+            for (;;) {
+                bool ok = true;
+                if (!first) {
+#pragma unroll
+                    for (int q = 0; q < JSLP_F_MAXG / 64; q++) {
+                        gq[q] = g;
+                        if (lane + 64 * q < f.G) gq[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, (par * JSLP_F_MAXG + lane + 64 * q) * JSLP_G16_STRIDE, 0, 16);
+                    }
+                }
+                first = false;
+#pragma unroll
+                for (int q = 0; q < JSLP_F_MAXG / 64; q++) ok = ok && gq[q].y == tag && (gq[q].w >> 16) == (tag & 0xffffu);
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                JSLP_HOST_ABORT_IN_SPIN(spins, swept);
+                if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { swept = false; break; }
+                if (spins > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
+            }
+            // my four workgroups' summaries -> mine -> the wave's: first degenerate row, else smallest quotient (first row on ties)
+            int rdeg = 0x7fffffff;
+            KI x = ki_none();
+#pragma unroll
+            for (int q = 0; q < JSLP_F_MAXG / 64; q++) {
+                const int row = (int)(gq[q].w & 0x7fffu);
+                const bool deg = (gq[q].w & 0x8000u) != 0u;
+                if (deg && row != 0) rdeg = min(rdeg, row);
+                KI y;
+                const bool cand = !deg && row != 0;
+                y.k = cand ? ((u64_t)gq[q].x | ((u64_t)gq[q].z << 32)) : KI_NONE_KEY;
+                y.i = cand ? row : 0x7fffffff;
+                y.pad = 0;
+                x = ki_min(x, y);
+            }
+            rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0xB1, 0xf, 0xf, false));
+            rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x4E, 0xf, 0xf, false));
+            rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x141, 0xf, 0xf, false));
+            rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x140, 0xf, 0xf, false));
+            rdeg = min(min(__builtin_amdgcn_readlane(rdeg, 0), __builtin_amdgcn_readlane(rdeg, 16)),
+                       min(__builtin_amdgcn_readlane(rdeg, 32), __builtin_amdgcn_readlane(rdeg, 48)));
+            x = ki_wave_min(x);
+            if (lane == 0) { sm.part_k[0] = x.k; sm.part_r[0] = x.k == KI_NONE_KEY ? 0 : x.i; sm.part_rdeg[0] = rdeg; }
+        } else if (poller) {
             unsigned spins = 0;
             bool have = false;
             if (LA && __all(gla.y == tag && (gla.w >> 16) == (tag & 0xffffu))) { g = gla; have = true; }
@@ -1239,6 +1423,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
     constexpr bool CKS = !TAGGED && JSLP_PIPE_SPECPUB != 0 && JSLP_PIPE_ROW_CHECKSUM != 0 && CPT <= JSLP_PIPE_ROW_CHECKSUM_MAXCPT;  // checksummed hand-over of the candidate rows (see JSLP_PIPE_ROW_CHECKSUM)
     constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT && !CKS);  // quot comes with the fetch: no barrier behind it
+    constexpr int HAWV = (!XL && JSLP_PIPE_ONE_POLL_WAVE != 0) ? 1 : 0;
     constexpr bool NPUB = false;  // (phase 1 knows its entering column only once the pivot row has arrived: the row travels as it is)
     const double quot_p = 1.0, pub_k0 = 0.0;
     const int pub_pc = 0;
@@ -1264,7 +1449,9 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     const int SLOT = PERM ? THREADS * CPT * 8 + JSLP_PUB_SKEW : f.c.ld * 8;
     constexpr int PAIR_STEP = PERM ? THREADS * 16 : 16;           // bytes from a lane's pair j to its pair j + 2
     const int lane_off = PERM ? tid * 16 : tid * CPT * 8;          // ... and where its first pair sits in the slot
-    constexpr int NPOLLW = XL ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
+    constexpr bool P1W = !XL && JSLP_PIPE_ONE_POLL_WAVE != 0;  // one polling wave, four summaries per lane (see JSLP_PIPE_ONE_POLL_WAVE)
+    constexpr int NPOLLW = (XL || P1W) ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
+    constexpr int POLLWV = 1;  // (wave 0 folds the next summary out of column 0; the last wave commits)
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
     const int c0 = tid * CPT;
@@ -1345,7 +1532,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         RT_MARK(0);
         // ---- U + P: the pending pivot's row update, the candidate row published from inside the pass ----------------------------
         bool swept = true;
-        const bool poller = tid < NPOLLW * 64;
+        const bool poller = P1W ? wv == POLLWV : tid < NPOLLW * 64;
         const bool used = tid < f.G;
         v4u_t g;
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;
@@ -1409,7 +1596,38 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         pend = false;
         RT_MARK(2);
         // ---- C: gather ----------------------------------------------------------------------------------------------------
-        if (poller) {
+        if (P1W && poller) {  // one wave, four summaries per lane (see phase 2)
+            unsigned spins = 0;
+            v4u_t gq[JSLP_F_MAXG / 64];
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < JSLP_F_MAXG / 64; q++) {
+                    gq[q] = g;
+                    if (lane + 64 * q < f.G) gq[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, (par * JSLP_F_MAXG + lane + 64 * q) * JSLP_G16_STRIDE, 0, 16);
+                }
+#pragma unroll
+                for (int q = 0; q < JSLP_F_MAXG / 64; q++) ok = ok && gq[q].y == tag && (gq[q].w >> 16) == (tag & 0xffffu);
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                JSLP_HOST_ABORT_IN_SPIN(spins, swept);
+                if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { swept = false; break; }
+                if (spins > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
+            }
+            KI x = ki_none();
+#pragma unroll
+            for (int q = 0; q < JSLP_F_MAXG / 64; q++) {
+                const int row = (int)(gq[q].w & 0x7fffu);
+                KI y;
+                y.k = row != 0 ? ((u64_t)gq[q].x | ((u64_t)gq[q].z << 32)) : KI_NONE_KEY;
+                y.i = row != 0 ? row : 0x7fffffff;
+                y.pad = 0;
+                x = ki_min(x, y);
+            }
+            x = ki_wave_min(x);
+            if (lane == 0) { sm.part_k[0] = x.k; sm.part_r[0] = x.k == KI_NONE_KEY ? 0 : x.i; }
+        } else if (poller) {
             unsigned spins = 0;
             for (;;) {
                 if (used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
