@@ -179,6 +179,17 @@ static napi_value result_object(napi_env env, const jslp_simplex_result* r) {
    the array of objects, as before. */
 #define JSLP_RES_I32 10
 #define JSLP_RES_F64 2
+/*  the optional packed-result arrays are checked BEFORE the engine call: a bad argument throws before the work is done, not after it */
+static bool packed_args_ok(napi_env env, int32_t n_nodes, napi_value packed_i, napi_value packed_f, const char* who) {
+    void *pi = NULL, *pf = NULL;
+    size_t ni = 0, nf = 0;
+    if (!typed(env, packed_i, napi_int32_array, &pi, &ni) || !typed(env, packed_f, napi_float64_array, &pf, &nf)) return false;
+    if ((pi || pf) && (!pi || !pf || ni < (size_t)n_nodes * JSLP_RES_I32 || nf < (size_t)n_nodes * JSLP_RES_F64)) {
+        napi_throw_error(env, "JSLP", who);
+        return false;
+    }
+    return true;
+}
 static napi_value batch_results(napi_env env, jslp_simplex_result* res, int32_t n_nodes, napi_value packed_i, napi_value packed_f, const char* who) {
     void *pi = NULL, *pf = NULL;
     size_t ni = 0, nf = 0;
@@ -565,6 +576,7 @@ static napi_value fn_relax_batch(napi_env env, napi_callback_info info) {
     if (stride < box_of(env, argv[0])->cap) THROW(env, "relaxBatch: stride below the row capacity");
     if ((rhs && nrhs < (size_t)n_nodes * (size_t)stride) || (rows && nrows < (size_t)n_nodes * (size_t)stride))
         THROW(env, "relaxBatch: output arrays shorter than n_nodes * stride");
+    if (!packed_args_ok(env, n_nodes, argv[9], argv[10], "relax_batch: packed result arrays shorter than n_nodes * 10 / n_nodes * 2")) return NULL;
     jslp_simplex_result* res = (jslp_simplex_result*)calloc((size_t)(n_nodes > 0 ? n_nodes : 1), sizeof *res);
     int rc = L.relax_batch(e, n_nodes, (const int32_t*)o, (const int8_t*)t, (const int32_t*)v, (const double*)x,
                            check ? 1 : 0, res, (double*)rhs, (int32_t*)rows, stride);
@@ -598,6 +610,7 @@ static napi_value fn_relax_batch_watched(napi_env env, napi_callback_info info) 
     const size_t n_watched = (size_t)nw_;
     if ((wr && nwr < (size_t)n_nodes * n_watched) || (wv && nwv < (size_t)n_nodes * n_watched))
         THROW(env, "relaxBatchWatched: output arrays shorter than n_nodes * nWatched");
+    if (!packed_args_ok(env, n_nodes, argv[8], argv[9], "relax_batch_watched: packed result arrays shorter than n_nodes * 10 / n_nodes * 2")) return NULL;
     jslp_simplex_result* res = (jslp_simplex_result*)calloc((size_t)(n_nodes > 0 ? n_nodes : 1), sizeof *res);
     int rc = L.relax_batch_watched(e, n_nodes, (const int32_t*)o, (const int8_t*)t, (const int32_t*)v, (const double*)x,
                                    check ? 1 : 0, res, (int32_t*)wr, (double*)wv);
@@ -886,6 +899,7 @@ static napi_value fn_pool_relax_batch(napi_env env, napi_callback_info info) {
     if (stride < cap) THROW(env, "poolRelaxBatch: stride below the row capacity");
     if ((rhs && nrhs < (size_t)n_nodes * (size_t)stride) || (rows && nrows < (size_t)n_nodes * (size_t)stride))
         THROW(env, "poolRelaxBatch: output arrays shorter than n_nodes * stride");
+    if (!packed_args_ok(env, n_nodes, argv[9], argv[10], "pool_relax_batch: packed result arrays shorter than n_nodes * 10 / n_nodes * 2")) return NULL;
     jslp_simplex_result* res = (jslp_simplex_result*)calloc((size_t)(n_nodes > 0 ? n_nodes : 1), sizeof *res);
     int rc = L.pool_relax_batch(p, n_nodes, (const int32_t*)o, (const int8_t*)t, (const int32_t*)v, (const double*)x,
                                 check ? 1 : 0, res, (double*)rhs, (int32_t*)rows, stride);
@@ -936,6 +950,7 @@ static napi_value fn_pool_relax_batch_watched(napi_env env, napi_callback_info i
     const size_t n_watched = (size_t)nwp_;
     if ((wr && nwr < (size_t)n_nodes * n_watched) || (wv && nwv < (size_t)n_nodes * n_watched))
         THROW(env, "poolRelaxBatchWatched: output arrays shorter than n_nodes * nWatched");
+    if (!packed_args_ok(env, n_nodes, argv[8], argv[9], "pool_relax_batch_watched: packed result arrays shorter than n_nodes * 10 / n_nodes * 2")) return NULL;
     jslp_simplex_result* res = (jslp_simplex_result*)calloc((size_t)(n_nodes > 0 ? n_nodes : 1), sizeof *res);
     int rc = L.pool_relax_batch_watched(p, n_nodes, (const int32_t*)o, (const int8_t*)t, (const int32_t*)v, (const double*)x,
                                         check ? 1 : 0, res, (int32_t*)wr, (double*)wv);
@@ -956,7 +971,7 @@ static napi_value timed_cb(napi_env env, napi_callback_info info) {
     size_t argc = 0;
     void* data = NULL;
     if (napi_get_cb_info(env, info, &argc, NULL, NULL, &data) != napi_ok || !data) THROW(env, "internal: function entry missing");
-    fn_entry* fe = (fn_entry*)data;
+    fn_entry* fe = (fn_entry*)data;  /* (this env's own copy of the table: see init) */
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     napi_value r = fe->fn(env, info);
@@ -990,18 +1005,20 @@ static napi_value fn_timings(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     bool reset = false;
     if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) == napi_ok && argc >= 1) napi_get_value_bool(env, argv[0], &reset);
+    fn_entry* tab = NULL;
+    if (napi_get_instance_data(env, (void**)&tab) != napi_ok || !tab) THROW(env, "timings: no table for this environment");
     napi_value o;
     NAPI_OK(env, napi_create_object(env, &o));
     for (size_t i = 0; i < N_FNS; i++) {
-        if (fns[i].calls == 0) continue;
+        if (tab[i].calls == 0) continue;
         napi_value pair, ms, calls;
         NAPI_OK(env, napi_create_array_with_length(env, 2, &pair));
-        NAPI_OK(env, napi_create_double(env, fns[i].ns / 1e6, &ms));
-        NAPI_OK(env, napi_create_double(env, (double)fns[i].calls, &calls));
+        NAPI_OK(env, napi_create_double(env, tab[i].ns / 1e6, &ms));
+        NAPI_OK(env, napi_create_double(env, (double)tab[i].calls, &calls));
         napi_set_element(env, pair, 0, ms);
         napi_set_element(env, pair, 1, calls);
-        NAPI_OK(env, napi_set_named_property(env, o, fns[i].name, pair));
-        if (reset) { fns[i].ns = 0; fns[i].calls = 0; }
+        NAPI_OK(env, napi_set_named_property(env, o, tab[i].name, pair));
+        if (reset) { tab[i].ns = 0; tab[i].calls = 0; }
     }
     return o;
 }
@@ -1028,11 +1045,18 @@ static napi_value fn_device_ms(napi_env env, napi_callback_info info) {
     return v;
 }
 
+static void free_table(napi_env env, void* data, void* hint) { (void)env; (void)hint; free(data); }
 static napi_value init(napi_env env, napi_value exports) {
+    /*  the timing table is PER ENVIRONMENT (napi_set_instance_data): the addon can be loaded from several Node worker threads of
+       one process, which used to race on one static table -- and timings(true) in one thread reset another's figures */
+    fn_entry* tab = (fn_entry*)malloc(sizeof fns);
+    if (!tab) return NULL;
+    memcpy(tab, fns, sizeof fns);
+    if (napi_set_instance_data(env, tab, free_table, NULL) != napi_ok) { free(tab); return NULL; }
     for (size_t i = 0; i < N_FNS; i++) {
         napi_value f;
-        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, timed_cb, &fns[i], &f) != napi_ok) return NULL;
-        if (napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) return NULL;
+        if (napi_create_function(env, tab[i].name, NAPI_AUTO_LENGTH, timed_cb, &tab[i], &f) != napi_ok) return NULL;
+        if (napi_set_named_property(env, exports, tab[i].name, f) != napi_ok) return NULL;
     }
     napi_value f;  /* (not timed itself) */
     if (napi_create_function(env, "timings", NAPI_AUTO_LENGTH, fn_timings, NULL, &f) != napi_ok) return NULL;

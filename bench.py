@@ -712,6 +712,55 @@ def relaxation_legs(ctx, args, reps=16):
                                    "reference's own loops touch (gated rows x live pivot-row columns, counted by the kernels: "
                                    "jslp_work_counters); SURVEY.md 8d's dense 16*H*W per restore and per pivot would be %.1fx that"
                                    % (dense / max(alg, 1.0))}
+    # (v) round 6 STRONG scaling of the batch: the SAME fixed batch (151 x reps nodes, whatever N) split round-robin over
+    #     the ranks by sharding.evaluate_nodes_sharded_watched -- one engine call per rank on its share, then the all-gather of the COMPACT
+    #     outcomes (RCCL; at N = 1 a one-rank group, so that the N = 1 figure walks the same code) and the ONE device-to-host copy of the
+    #     gathered block, all INSIDE the timed region; every rank checks every node's outcome (its own engine's verified compact outcomes
+    #     of the same cut lists: rank 0's were checked against the reference above, so a disagreement between GPUs cannot pass)
+    try:
+        import torch.distributed as dist
+        from jslpsolver_amd.sharding import EXCHANGE_STATS as XS, evaluate_nodes_sharded_watched
+        own_group = False
+        sgroup = ctx["group"]
+        if world == 1 and not dist.is_initialized():
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group(os.environ.get("JSLP_BENCH_BACKEND", "nccl"), init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+            own_group = True
+            sgroup = dist.group.WORLD
+        fixed = [c["cuts"] or [] for c in calls] * reps
+        packed_fixed = t.pack_cut_lists(fixed[rank::world])
+        # this rank's table of verified compact outcomes by cut list (mine[i] is cut list (rank + i * world) % len(calls): every residue occurs)
+        by_call = {}
+        for i in range(len(mine)):
+            by_call.setdefault((rank + i * world) % len(calls), i)
+        fns_ = lambda: evaluate_nodes_sharded_watched(t, fixed, True, sgroup, packed_mine=packed_fixed)
+        for k in XS:
+            XS[k] = 0 * XS[k]
+        outs, el_s, per_s = timed_calls(fns_, 3, 10)
+        xs = dict(XS)
+        for k in range(len(fixed)):
+            i = by_call[k % len(calls)]
+            r_k = outs.result(k)
+            if (r_k.height != res_w[i].height or bool(r_k.feasible) != bool(res_w[i].feasible) or not np.array_equal(outs.watched_rows(k), rows_w_keep[i])
+                    or not np.array_equal(outs.watched_values(k).view(np.int64), vals_w_keep[i].view(np.int64))):
+                raise WrongAnswer("sharded batch: node %d differs from this rank's verified outcome of the same cut list (rank %d)" % (k, rank))
+        calls_x = max(xs["calls"], 1)
+        out["sharded_batch"] = {"value": len(fixed) / el_s, "unit": "LP relaxations/s", "scaling": "strong", "nodes": len(fixed), "seconds": el_s,
+                                "exchange_ms": 1e3 * xs["seconds"] / calls_x, "bytes_per_rank": xs["bytes"] / calls_x,
+                                "per_call_us": [round(1e6 * x) for x in per_s], "ranks": world,
+                                "workload": "config 4: ONE fixed batch of %d Monster_II nodes (151 cut lists x%d) split round-robin over %d rank(s): "
+                                            "per rank one jslp_engine_relax_batch_watched_device call on its share, then all_gather_into_tensor of the "
+                                            "compact outcomes (%s) + one D2H of the gathered block, inside the timed region; every rank verified every node"
+                                            % (len(fixed), reps, world, dist.get_backend(sgroup))}
+        if own_group:
+            dist.destroy_process_group()
+    except WrongAnswer:
+        raise
+    except Exception as e:  # (never lose the whole line to this leg)
+        out["sharded_batch"] = {"value": None, "error": repr(e)[:300]}
     # (iv) the engine's own device pool (single process): 4 virtual devices on this GPU
     if world == 1:
         pool = DevicePool(t, [device] * 4)

@@ -348,6 +348,10 @@ function install(Tableau, options) {
             if (this.__gpu.active) dropEngine(this, this.__gpu, false);
             this.__gpu = undefined;
         }
+        // (ADVICE r05: the deferred-LP budget -- see P.simplex -- is armed only for a tableau that setModel has JUST built: this flag is
+        //  cleared by the first simplex() and by every editing call, so a tableau whose first solve was infeasible and which was then
+        //  edited through the dynamic-modification API is never rebuilt from its model)
+        this.__gpuFresh = true;
         if (opts.pinnedBuild === false || !eligible(this, opts)) return;
         const made = createEngine(this, opts);
         made.pinnedMatrix = addon.hostMatrix(made.h); // zero-filled like the Float64Array it replaces (tableau.ts:304)
@@ -366,6 +370,7 @@ function install(Tableau, options) {
         if (typeof P[name] !== "function") continue;
         origEditing[name] = P[name];
         P[name] = function () {
+            this.__gpuFresh = false;
             bringHome(this);
             return origEditing[name].apply(this, arguments);
         };
@@ -419,6 +424,7 @@ function install(Tableau, options) {
 
     // Tableau.applyMIRCuts (cutting-strategies.ts:199-212): the scan and the <= 10 new rows happen on the device
     P.applyMIRCuts = function () {
+        this.__gpuFresh = false;
         const st = state(this, opts);
         if (!st.active) return orig.applyMIRCuts.call(this);
         if (st.pendingRestore || st.pendingCuts) throw new Error("[gpu-tableau] applyMIRCuts before the pending simplex()");
@@ -434,7 +440,9 @@ function install(Tableau, options) {
 
     P.simplex = function () {
         const st = state(this, opts);
-        if (!st.active && st.deferred === true && this.simplexIters === 0) {
+        const fresh = this.__gpuFresh === true;  // built by setModel and untouched since (not: "no optimum reached yet")
+        this.__gpuFresh = false;
+        if (!st.active && st.deferred === true && fresh) {
             // a small-count LP: the reference's own loop with a time budget (see `deferrable`); the pivot() wrapper below throws BAIL
             const budgetMs = opts.cpuBudgetMs !== undefined ? opts.cpuBudgetMs : DEFAULT_CPU_BUDGET_MS;
             this.__gpuBudget = { t0: process.hrtime.bigint(), ns: BigInt(Math.round(budgetMs * 1e6)), pivots: 0 };
@@ -482,6 +490,7 @@ function install(Tableau, options) {
     };
 
     P.restore = function () {
+        this.__gpuFresh = false;
         const st = state(this, opts);
         if (!st.active) return orig.restore.call(this);
         if (st.saved === null) return; // backup.ts:54-56
@@ -494,6 +503,7 @@ function install(Tableau, options) {
     };
 
     P.addCutConstraints = function (cuts) {
+        this.__gpuFresh = false;
         const st = state(this, opts);
         if (!st.active) return orig.addCutConstraints.call(this, cuts);
         // host-side bookkeeping of cutting-strategies.ts:16-34,64-71; the rows themselves are built on the device

@@ -224,8 +224,12 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
         speculate = 1  # one workgroup per node only pays for small tableaus; big ones go node by node through the chip-wide kernels
     cache = {}          # heap sequence number -> _NodeEval
     # (JSLP_TREE_COMPACT=0: whole columns per speculated node, as before round 5)
-    compact_ok = evaluate_batch is None and os.environ.get("JSLP_TREE_COMPACT", "1") != "0" and len(model.integer_index_array) > 0 and hasattr(tableau, "applyCutsBatchWatched")
+    # (the engine takes at most row_capacity watched variables -- a model with more integers than rows + cut capacity keeps the
+    #  whole-column read-back instead of failing on its first speculative batch)
+    compact_ok = (evaluate_batch is None and os.environ.get("JSLP_TREE_COMPACT", "1") != "0" and hasattr(tableau, "applyCutsBatchWatched")
+                  and 0 < len(model.integer_index_array) <= getattr(tableau, "row_capacity", 0))
     watched_set = []
+    watched_before = list(getattr(tableau, "watched", []) or [])  # the caller's own registration, put back when the tree is done
     saved = False
     last_cuts = None    # cuts of the node the sequential run evaluated last
     speculated = 0
@@ -339,5 +343,7 @@ def branch_and_cut(tableau, model, speculate=1, evaluate_batch=None):
     elif speculate > 1 and saved and last_cuts is not None:
         # no incumbent: the reference's tableau is left on the node it evaluated last; put ours there too
         tableau.applyCuts(last_cuts, check_cycles=check)
+    if watched_set and watched_before != list(model.integer_index_array):
+        tableau.set_watched_variables(watched_before)  # (the caller's registration was borrowed for the compact read-back)
     tableau.speculated_nodes = speculated
     return iterations, found_integral

@@ -1222,11 +1222,18 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
                 // JSLP_INJECT_RESIDENT_ABORT_US=<n>: raise the host-abort word n microseconds into the launch -- the rollback path (kernel gives
                 // up mid-solve, slot 0 restored from the safety-net copy, the solve re-run through the streaming kernels) exercised on the
                 // library users load, whose kernels have no test hooks.  Read per launch (tests set it inside one process); once per solve.
+                // (parsed strictly -- a stray or garbage value no longer aborts every resident solve -- and announced once)
                 const char* inj = getenv("JSLP_INJECT_RESIDENT_ABORT_US");
-                if (inj && atoi(inj) >= 0 && !e->abort_injected) {
-                    e->abort_injected = 1;
-                    std::this_thread::sleep_for(std::chrono::microseconds(atoi(inj)));
-                    __atomic_store_n(e->h_abort_ptr, 1u, __ATOMIC_RELEASE);
+                if (inj && *inj && !e->abort_injected) {
+                    char* endp = nullptr;
+                    const long us = strtol(inj, &endp, 10);
+                    if (endp != inj && *endp == 0 && us >= 0 && us <= 10000000L) {
+                        static std::atomic<int> told{0};
+                        if (!told.exchange(1)) fprintf(stderr, "[jslp] JSLP_INJECT_RESIDENT_ABORT_US=%ld: every register-resident solve is aborted %ld us after its launch and re-run through the streaming kernels (fault injection)\n", us, us);
+                        e->abort_injected = 1;
+                        std::this_thread::sleep_for(std::chrono::microseconds(us));
+                        __atomic_store_n(e->h_abort_ptr, 1u, __ATOMIC_RELEASE);
+                    }
                 }
             }
             if (le == hipSuccess && lean) {  // did the lean kernel finish the solve?
@@ -2452,17 +2459,27 @@ struct PoolWorker {
         __builtin_ia32_pause();
 #endif
     }
+    // (the sleep / wake handshake is a Dekker pattern -- the worker stores `asleep` and then loads `submitted`, submit() bumps
+    //  `submitted` and then loads `asleep` -- so every access that takes part in it is seq_cst: with acquire loads in the predicate the
+    //  C++ memory model allows the store and the load to pass each other and a wake-up to be lost; both sides spin for a bounded TIME
+    //  -- ~0.5 ms in the worker, ~0.2 ms in the caller -- not for a number of iterations, before they give the core back)
+    static bool spin_for_us(const std::chrono::steady_clock::time_point& t0, unsigned& spins, double us) {
+        relax_cpu();
+        return (++spins & 0xffu) != 0 || std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < us;
+    }
     void loop() {
         unsigned seen = 0;
         for (;;) {
-            int spins = 0;
-            while (submitted.load(std::memory_order_acquire) == seen && !quit.load(std::memory_order_acquire)) {
-                if (++spins < 40000) { relax_cpu(); continue; }
+            unsigned spins = 0;
+            auto t0 = std::chrono::steady_clock::now();
+            while (submitted.load(std::memory_order_seq_cst) == seen && !quit.load(std::memory_order_seq_cst)) {
+                if (spin_for_us(t0, spins, 500.0)) continue;
                 std::unique_lock<std::mutex> lk(mu);
                 asleep.store(1, std::memory_order_seq_cst);
-                cv.wait(lk, [&] { return submitted.load(std::memory_order_acquire) != seen || quit.load(std::memory_order_acquire) != 0; });
+                cv.wait(lk, [&] { return submitted.load(std::memory_order_seq_cst) != seen || quit.load(std::memory_order_seq_cst) != 0; });
                 asleep.store(0, std::memory_order_seq_cst);
                 spins = 0;
+                t0 = std::chrono::steady_clock::now();
             }
             if (quit.load(std::memory_order_acquire)) return;
             seen = submitted.load(std::memory_order_acquire);
@@ -2483,9 +2500,10 @@ struct PoolWorker {
     }
     int wait() {
         unsigned spins = 0;
+        const auto t0 = std::chrono::steady_clock::now();
         while (done.load(std::memory_order_acquire) != submitted.load(std::memory_order_acquire)) {
-            if (++spins < 2000000u) relax_cpu();
-            else std::this_thread::sleep_for(std::chrono::microseconds(50));  // (a long job -- a root fan-out over a slow link: stop burning the core)
+            if (spin_for_us(t0, spins, 200.0)) continue;
+            std::this_thread::sleep_for(std::chrono::microseconds(20));  // (a long job -- a big batch, a root fan-out over a slow link: stop burning the core)
         }
         return rc;
     }

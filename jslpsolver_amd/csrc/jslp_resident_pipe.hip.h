@@ -147,6 +147,10 @@
 #ifndef JSLP_HOST_ABORT
 #define JSLP_HOST_ABORT 1
 #endif
+// (round 6: at those pivots that wave treats its FIRST look as failed whatever it found -- JSLP_HOST_ABORT_FORCE_RETRY -- so that the word is
+//  looked at every 1024 pivots for certain: with one polling wave whose first look leaves ~1 k cycles later than round 5's the last
+//  workgroup's look began to succeed at once and a 2833-pivot solve missed its abort -- tests/test_pool_and_extras.py, n = 1000)
+#define JSLP_HOST_ABORT_FORCE_RETRY(SPINS) (JSLP_HOST_ABORT && (SPINS) == 0u && (epoch & (JSLP_HOST_ABORT_PERIOD - 1u)) == JSLP_HOST_ABORT_PERIOD - 1u && b == f.G - 1 && wv == HAWV)
 #define JSLP_HOST_ABORT_IN_SPIN(SPINS, SWEPT)                                                                                     \
     if (JSLP_HOST_ABORT && (SPINS) == 1u && (epoch & (JSLP_HOST_ABORT_PERIOD - 1u)) == JSLP_HOST_ABORT_PERIOD - 1u && b == f.G - 1 && wv == HAWV) { \
         const unsigned* ha_ = *reinterpret_cast<const unsigned* const*>(reinterpret_cast<const char*>(f.cdev) + sizeof(Ctx));     \
@@ -668,6 +672,16 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
 // summary in the gather (section table, r06_a: pricing 3.2 k cycles in workgroup 0 against 2.36 k everywhere else).  The LDS maps are still
 // swapped where they were; the global stores follow in the NEXT iteration's update section (while the summaries cross the fabric) or behind
 // the loop, as fire-and-forget stores through pointers kept in LDS.  Same stores, same order, one pivot later.
+#define JSLP_PIPE_SWAP_LDS_MAPS()                                                                                                 \
+    do {                                                                                                                          \
+        if (lpend && tid == THREADS - 64) {                                                                                       \
+            const int leaving_ = sm.lvibr[pr_p], entering_ = sm.lvibc[pc_p];                                                      \
+            sm.lvibr[pr_p] = entering_;                                                                                           \
+            sm.lvibc[pc_p] = leaving_;                                                                                            \
+            if (b == 0) { sm.cm_ent = entering_; sm.cm_leav = leaving_; }                                                         \
+        }                                                                                                                         \
+        lpend = false;                                                                                                            \
+    } while (0)
 typedef __attribute__((address_space(1))) int32_t jslp_gi32_t;  // (a pointer into GLOBAL memory, as opposed to a generic one)
 #define JSLP_PIPE_COMMIT_GLOBAL()                                                                                                 \
     do {                                                                                                                          \
@@ -773,6 +787,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     double quot_p = 1.0;                // its pivot element (NPUB builds: -k / quot of the pivot column's own entries is computed when needed)
     bool pend = false;
     bool cpend = false;  // the pending pivot's global commit has not been issued yet (JSLP_PIPE_COMMIT_GLOBAL)
+    bool lpend = false;   // QDIRECT flows: the pending pivot's swap of my LDS maps has not happened yet (JSLP_PIPE_SWAP_LDS_MAPS)
     unsigned emask = 0u;  // SPLITU: bit i = my row i has received the pending pivot already (JSLP_UPDATE_ONE_ROW)
 #pragma unroll
     for (int j = 0; j < CPT; j++) p[j] = 0.0;
@@ -815,6 +830,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             RT_STAMP(5);  // at the pricing
             pc = price_row_pipe<THREADS, CPT, UNR>(r0, c0, pb, c, sm, par, &k0, R.unr, &neg_now, &pc_late, &claim);
             RT_STAMP(6);  // priced
+            JSLP_PIPE_SWAP_LDS_MAPS();  // (the pending pivot's basis change in my LDS maps: every wave is past its reads of them -- the pricing's barriers)
             if (UNR) R.neg = neg_now;  // isReducedCostNegative of the entering column (simplex.ts:164-177): the ratio test's sign
         }
         bool opt_enter = false;  // the entering column is named by an optional objective: its main cost is within +-precision
@@ -1040,7 +1056,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 first = false;
 #pragma unroll
                 for (int q = 0; q < JSLP_F_MAXG / 64; q++) ok = ok && gq[q].y == tag && (gq[q].w >> 16) == (tag & 0xffffu);
-                if (__all(ok)) break;
+                if (__all(ok) && !JSLP_HOST_ABORT_FORCE_RETRY(spins)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
                 JSLP_HOST_ABORT_IN_SPIN(spins, swept);
@@ -1085,7 +1101,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             for (;;) {
                 if (used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
                 const bool ok = g.y == tag && (g.w >> 16) == (tag & 0xffffu);
-                if (__all(ok)) break;
+                if (__all(ok) && !JSLP_HOST_ABORT_FORCE_RETRY(spins)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
                 JSLP_HOST_ABORT_IN_SPIN(spins, swept);
@@ -1363,12 +1379,16 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             }
         }
         // ---- commit the basis change (simplex.ts:339-349): every workgroup's LDS maps, workgroup 0 the global ones ---------------------
-        if (tid == THREADS - 64) {  // (not thread 0: its wave carries the column-0 work above)
+        // (QDIRECT flows have no barrier between the row fetch and this point: a wave that is through with its fetch must not swap the maps
+        //  while a slower one is still reading them behind the gather -- the leaving variable's "unrestricted" flag, the cycle check's pair.
+        //  There the swap waits for the next pricing's barriers: JSLP_PIPE_SWAP_LDS_MAPS.  Found by the chaos build, round 6.)
+        if (!QDIRECT && tid == THREADS - 64) {  // (not thread 0: its wave carries the column-0 work above)
             const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc];
             sm.lvibr[pr] = entering;
             sm.lvibc[pc] = leaving;
             if (b == 0) { sm.cm_ent = entering; sm.cm_leav = leaving; }  // (the global maps and the trace follow one iteration later: JSLP_PIPE_COMMIT_GLOBAL)
         }
+        lpend = QDIRECT;
         if (UNR && has_pc) {
 #pragma unroll
             for (int j = 0; j < CPT; j++)
@@ -1381,6 +1401,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         cpend = true;
         RT_MARK(5);
     }
+    JSLP_PIPE_SWAP_LDS_MAPS();  // (an exit in front of the pricing)
     JSLP_PIPE_COMMIT_GLOBAL();  // (a basis change whose global half is still pending)
     if (pend && R.end_code != 5) {  // whoever leaves with a pivot pending (optimal, iteration cap, hand-over) brings the rows up to date
         const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;
@@ -1608,7 +1629,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 }
 #pragma unroll
                 for (int q = 0; q < JSLP_F_MAXG / 64; q++) ok = ok && gq[q].y == tag && (gq[q].w >> 16) == (tag & 0xffffu);
-                if (__all(ok)) break;
+                if (__all(ok) && !JSLP_HOST_ABORT_FORCE_RETRY(spins)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
                 JSLP_HOST_ABORT_IN_SPIN(spins, swept);
@@ -1632,7 +1653,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             for (;;) {
                 if (used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
                 const bool ok = g.y == tag && (g.w >> 16) == (tag & 0xffffu);
-                if (__all(ok)) break;
+                if (__all(ok) && !JSLP_HOST_ABORT_FORCE_RETRY(spins)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
                 JSLP_HOST_ABORT_IN_SPIN(spins, swept);
@@ -1918,3 +1939,4 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #undef JSLP_CK_QMIX
 #undef JSLP_RT_RETRY
 #undef JSLP_PIPE_COMMIT_GLOBAL
+#undef JSLP_PIPE_SWAP_LDS_MAPS

@@ -209,6 +209,7 @@ class Tableau:
         self.lib.check(self.lib.jslp_engine_set_watched_variables(self._h, _capi.ptr_i32(w), int(w.shape[0])),
                        "jslp_engine_set_watched_variables")
         self.n_watched = int(w.shape[0])
+        self.watched = [int(i) for i in w]  # (what is registered: a caller that borrows the registration puts it back)
 
     def applyCutsWatched(self, cuts, check_cycles=True):
         """applyCuts whose read-back is only rowByVarIndex / the RHS cell of the watched variables"""

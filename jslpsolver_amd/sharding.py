@@ -308,7 +308,8 @@ def make_sharded_evaluator(tableau, check_cycles, group, watched=None):
     relaxations (the model's integer variables): the COMPACT exchange -- registered on the engine here, once (every rank passes the
     same list); None = whole RHS columns + row maps (JSLP_SHARD_COMPACT=0 forces that form)."""
     import os
-    if watched is not None and os.environ.get("JSLP_SHARD_COMPACT", "1") != "0" and len(watched) > 0:
+    # (ADVICE r05: the engine takes at most row_capacity watched variables; a model with more integers than that exchanges whole columns)
+    if watched is not None and os.environ.get("JSLP_SHARD_COMPACT", "1") != "0" and 0 < len(watched) <= tableau.row_capacity:
         tableau.set_watched_variables(watched)
 
         def evaluate_compact(cut_lists):

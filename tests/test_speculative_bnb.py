@@ -61,3 +61,38 @@ def test_pinned_batch_view_equals_copying_batch(oracle_lib):
         assert np.array_equal(rhs_a[i, :h].view(np.uint64), rhs_b[i, :h].view(np.uint64))
         assert np.array_equal(rows_a[i, :h], rows_b[i, :h])
     t.close()
+
+
+def test_more_integer_variables_than_rows_keeps_the_whole_column_read_back(oracle_lib):
+    """the compact read-back takes at most row_capacity watched variables (jslp_engine_set_watched_variables); a model with more
+    integer variables than rows + cut capacity must still run its speculative batches (whole columns), give the sequential result -- and a
+    watched list the caller registered on the tableau survives a tree that borrows the registration"""
+    prof = [19, 11, 27, 17, 6, 21, 26, 27, 28, 14, 30, 12, 4, 16]
+    wt = [3, 5, 7, 10, 11, 7, 4, 7, 6, 13, 10, 3, 6, 12]
+    model = {"optimize": "profit", "opType": "max", "constraints": {"weight": {"max": 65}},
+             "variables": {"x%d" % i: {"profit": prof[i], "weight": wt[i]} for i in range(14)},
+             "ints": {"x%d" % i: 1 for i in range(14)}, "options": {"presolve": False}}
+    seq = Solve(model, full=True, lib=oracle_lib)
+    par = Solve(model, full=True, lib=oracle_lib, speculate=4, row_capacity_extra=11)  # 2 rows + 11 cut rows = 13 < 14 integer variables
+    assert seq["iter"] == 11 and par["result"] == seq["result"] and par["iter"] == seq["iter"]
+    # the engine-level bound itself, and the borrowed registration
+    import numpy as np
+    from jslpsolver_amd import _capi
+    from jslpsolver_amd.branch_and_cut import branch_and_cut
+    from jslpsolver_amd.engine import Tableau
+    m = Model(model)
+    matrix, vibr, vibc = m.build_tableau()
+    n_int = len(m.integer_index_array)
+    t = Tableau(matrix, vibr, vibc, m.unrestricted, precision=m.precision, row_capacity=matrix.shape[0] + 2 * n_int, lib=oracle_lib)
+    mine = [int(m.integer_index_array[0])]
+    t.set_watched_variables(mine)
+    it, _ = branch_and_cut(t, m, speculate=4)
+    assert it == seq["iter"] and t.watched == mine and t.watched_count() == 1
+    t.close()
+    small = Tableau(matrix, vibr, vibc, m.unrestricted, precision=m.precision, row_capacity=n_int - 1, lib=oracle_lib)
+    small.applyCuts([], check_cycles=True)
+    small.save()
+    small.set_watched_variables(list(m.integer_index_array))
+    with pytest.raises(_capi.EngineError):  # (what the tree would have run into before the guard)
+        small.applyCutsBatchWatched([[]], check_cycles=True)
+    small.close()
