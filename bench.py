@@ -737,9 +737,11 @@ def relaxation_legs(ctx, args, reps=16):
         for i in range(len(mine)):
             by_call.setdefault((rank + i * world) % len(calls), i)
         fns_ = lambda: evaluate_nodes_sharded_watched(t, fixed, True, sgroup, packed_mine=packed_fixed)
+        for _ in range(3):  # (the first call creates the communicator: seconds)
+            fns_()
         for k in XS:
             XS[k] = 0 * XS[k]
-        outs, el_s, per_s = timed_calls(fns_, 3, 10)
+        outs, el_s, per_s = timed_calls(fns_, 0, 10)
         xs = dict(XS)
         for k in range(len(fixed)):
             i = by_call[k % len(calls)]
@@ -799,9 +801,12 @@ def relaxation_legs(ctx, args, reps=16):
     for st in (EVAL_STATS, EXCHANGE_STATS):
         for k in st:
             st[k] = 0 * st[k]
-    sol, el_tree, per_tree = timed_calls(solve_tree, 0, 5)
-    eval_ms = 1e3 * EVAL_STATS["seconds"] / 5
-    exch_ms = 1e3 * EXCHANGE_STATS["seconds"] / 5
+    N_TREE = 15
+    sol, el_tree, per_tree = timed_calls(solve_tree, 0, N_TREE)
+    eval_ms = 1e3 * EVAL_STATS["seconds"] / N_TREE
+    exch_ms = 1e3 * EXCHANGE_STATS["seconds"] / N_TREE
+    srt = sorted(per_tree)
+    med_tree, max_tree = srt[len(srt) // 2], srt[-1]
     if sol["iter"] != g["final"]["branchAndCutIterations"] or sol["result"].get("result") != want.get("result"):
         raise WrongAnswer("Monster_II tree: result %r after %d relaxations, the reference: %r after %d"
                           % (sol["result"].get("result"), sol["iter"], want.get("result"), g["final"]["branchAndCutIterations"]))
@@ -810,6 +815,11 @@ def relaxation_legs(ctx, args, reps=16):
                    "scaling": "strong", "ms_per_solve": 1e3 * el_tree, "solves_per_s": 1.0 / el_tree, "committed_relaxations_per_s": sol["iter"] / el_tree,
                    "result": sol["result"].get("result"), "result_checked": "result and relaxation count == the reference's (%s, %d)" % (want.get("result"), g["final"]["branchAndCutIterations"]),
                    "per_solve_ms": [round(1e3 * x, 2) for x in per_tree],
+                   # round 6 (one solve of a committed round-5 line took 592 ms): median and max beside the mean, and a
+                   # `health` note when a solve is an outlier -- profiles/r06_tree_latency.md: 2500 consecutive solves, max / median <= 1.61
+                   "median_ms": 1e3 * med_tree, "max_ms": 1e3 * max_tree, "solves": N_TREE,
+                   "health": ("OUTLIER: the slowest of %d solves took %.1f ms, %.1fx the median %.2f ms (rank 0's clock)" % (N_TREE, 1e3 * max_tree, max_tree / med_tree, 1e3 * med_tree))
+                             if max_tree > 10 * med_tree else "ok (max / median = %.2f)" % (max_tree / med_tree),
                    # what shards and what does not (rank 0's clock): the evaluation share = the speculative batches (engine calls +
                    # exchange step); the rest = model parsing, upload, root LP, tree bookkeeping on one host thread
                    "eval_ms": eval_ms, "exchange_ms": exch_ms, "host_ms": 1e3 * el_tree - eval_ms,
@@ -818,7 +828,7 @@ def relaxation_legs(ctx, args, reps=16):
                    "exchange_bytes_per_batch_per_rank": (EXCHANGE_STATS["bytes"] / EXCHANGE_STATS["calls"]) if EXCHANGE_STATS["calls"] else 0,
                    "exchange_bytes_per_node": (128 + 12 * len(g["tableau"]["integerVarIndexes"])) if world > 1 else 0,
                    "node_outcome": "compact (integer variables' rows + values; the committed leaf re-evaluated with the full read-back)",
-                   "eval_batches_per_solve": EVAL_STATS["batches"] / 5, "eval_nodes_per_solve": EVAL_STATS["nodes"] / 5, "includes": "model parsing, upload, root LP, the whole tree and the read-back (host logic in Python)",
+                   "eval_batches_per_solve": EVAL_STATS["batches"] / N_TREE, "eval_nodes_per_solve": EVAL_STATS["nodes"] / N_TREE, "includes": "model parsing, upload, root LP, the whole tree and the read-back (host logic in Python)",
                    "host": "python mirror of the reference host, no presolve (the drop-in is `dropin_js`: the reference's own host under node)"}
     return out if rank == 0 else None
 

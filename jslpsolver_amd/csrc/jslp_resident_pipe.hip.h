@@ -54,18 +54,10 @@
         }                                                                                                                 \
     } while (0)
 #endif
-#ifndef JSLP_PIPE_SPECPUB
-#define JSLP_PIPE_SPECPUB 1  // 1: every workgroup stores its candidate row while the summaries cross the fabric; 0: only the winner stores its row, after the decision (measured: config 3a 137 k against 143 k pivots/s, 4001x2001 105 k against 108 k, 2001x4001 91 k against 87 k)
-#endif
-#ifndef JSLP_PIPE_WINNER_LL
-#define JSLP_PIPE_WINNER_LL 0  // chip-wide lean builds: 1 = ONLY the winner stores its row, after the decision, with the epoch tag inside the data ({lo32 | tag}{hi32 | tag} per double, write-through); the readers poll the row itself -- no candidate rows (4 MB per pivot), no drain, no write-back fence, no flag
-#endif
-#ifndef JSLP_PIPE_QUOT_DIRECT
-#define JSLP_PIPE_QUOT_DIRECT 0  // chip-wide lean builds without optional objectives: 1 = every wave reads quot (the winning row's entry of the entering column) itself next to its columns of the row -- one address per wave -- instead of the LDS broadcast + barrier behind the fetch
-#endif
-#ifndef JSLP_PIPE_NEW_UPDATE
-#define JSLP_PIPE_NEW_UPDATE 1
-#endif
+// (Round 6 pruned the switches of measured-and-rejected variants out of this header -- winner-only publication with and without tags
+//  inside the data, quot read next to the row, early / mid / ahead looks at the summaries, the row update split around the gather, the
+//  in-wave pricing, the per-row update form of the 2- / 4-column geometries: profiles/r06_rejected_switches.patch re-applies them, DESIGN.md
+//  section 5 has their numbers.)
 #ifndef JSLP_PIPE_ROW_CHECKSUM
 // 1: the candidate row is handed over END TO END: each wave of the publishing workgroup stores, right behind its 16-byte stores of the
 // row, ONE 8-byte word = (64-bit checksum of what it stored) ^ (epoch tag x odd constant) into its copy of the row flag; the wave of a
@@ -75,33 +67,12 @@
 // gather's barrier all leave the critical path.  0: round 3's hand-over (winner drains, fences, raises the flag; readers wait, load).
 #define JSLP_PIPE_ROW_CHECKSUM 1
 #endif
-#ifndef JSLP_PIPE_LOOK_AHEAD
-// round 6: the polling waves' FIRST look at the summaries leaves right behind the barrier that closes the ratio test -- in front of the pending
-// pivot's row update -- and is examined behind it.  The pivot period is the loop time of the workgroup that stores its summary LAST
-// (tools/resident_stamps.py: it never waits for anybody, the other 250 wait for it), and for that workgroup everybody else's summary is in
-// memory when its look leaves: its update pass and its look's round trip (~0.8 us under this load) overlap instead of adding up.
-// (Round 4's JSLP_PIPE_EARLY_LOOKS issued one more look in front of examining the early ones and waited for it.)
-#define JSLP_PIPE_LOOK_AHEAD 0
-#endif
-#ifndef JSLP_PIPE_ONE_POLL_WAVE
 // round 6: ONE wave gathers the <= 256 summaries (lane l looks at workgroups l, l + 64, l + 128, l + 192: four 16-byte loads in flight per lane) instead of
 // four waves of one load per lane each.  The four waves' looks returned at four different times and the barrier that closes the gather waited
-// for the slowest; every thread then folded four partial results.  One wave: one round trip, one partial result.
-#define JSLP_PIPE_ONE_POLL_WAVE 1
-#endif
-#ifndef JSLP_PIPE_LOOK_MID
-// round 6: the polling wave's first look at the summaries leaves between the pending pivot's row update and the publication of the candidate
-// row, and is examined behind the publication: the normalisation's divisions (NPUB) and the row's stores overlap the look's round trip
-#define JSLP_PIPE_LOOK_MID 0
-#endif
-#ifndef JSLP_PIPE_PRICE_IN_WAVE
-#define JSLP_PIPE_PRICE_IN_WAVE 0  // round 6: see price_row_pipe
-#endif
+// for the slowest; every thread then folded four partial results.  One wave: one round trip, one partial result (config 3a 172.6 k -> 179 k
+// pivots/s together with the parity-buffered pricing words, 3b with the cycle check 145 k -> 155 k).
 #ifndef JSLP_PIPE_K_BROADCAST
 #define JSLP_PIPE_K_BROADCAST 1  // round 6: see JSLP_XL_UPDATE_PASS_M
-#endif
-#ifndef JSLP_PIPE_SPLIT_UPDATE
-#define JSLP_PIPE_SPLIT_UPDATE 0  // round 6: see SPLITU in resident_phase2_pipe
 #endif
 #ifndef JSLP_PIPE_NORM_PUB
 #define JSLP_PIPE_NORM_PUB 1  // round 6: the candidate row leaves NORMALISED (see NPUB in resident_phase2_pipe)
@@ -120,9 +91,6 @@
         (CK) += (u64_t)(unsigned)(HI) * JSLP_CK_K32(2 * (j) + 2) + (u64_t)(unsigned)((HI) >> 32) * JSLP_CK_K32(2 * (j) + 3);       \
     } while (0)
 #define JSLP_CK_TAGMIX(tag) ((u64_t)(tag) * 0xD6E8FEB86659FD93ull)    // what separates this epoch's flag word from the one two epochs back in the same slot
-#ifndef JSLP_PIPE_EARLY_LOOKS
-#define JSLP_PIPE_EARLY_LOOKS 0  // looks at the summaries issued DURING the row update (1: behind it, 2: also in front of it): measured 169.5-171.4 k pivots/s -> 167 k -> 163.6 k on config 3a (r04_x) -- the summaries are not there yet, and the extra loads sit in front of the row's stores in the wave's memory queue
-#endif
 #ifndef JSLP_PIPE_S_VIA_LDS
 #define JSLP_PIPE_S_VIA_LDS 1
 #endif
@@ -224,20 +192,17 @@ __device__ __forceinline__ u64_t u64_wave_add_halves(u64_t x) {
 #define JSLP_CK_WAVE(CK) u64_wave_add_halves((CK) * (u64_t)(unsigned)(2 * tid + 1))
 
 // ---- pricing of the lean pipelined phase 2 (simplex.ts:118-219), round 6 -------------------------------------------------------------------
-// Round one is price_row_lds's: every lane's best column among its own (earlier batch first, bigger value inside a batch, first index on ties),
-// one LDS atomicMin per wave on the batch, one barrier.  A pricing batch is 50-500 adjacent columns and a wave holds 64 x CPT adjacent columns,
-// so in ~60 % of the pivots the winning batch lies inside ONE wave -- known to every thread from the batch number alone.  Then that wave folds
-// value and column in registers (a DPP maximum of the bit patterns -- positive doubles order like their bits --, a ballot for the first lane
-// holding it), leaves them in LDS for the others and goes straight on to the ratio test, which is its job anyway (it holds the entering
-// column): the second and third barrier and their two rounds of LDS atomics are gone from that pivot; the other waves read column and value
-// behind the barrier that closes the ratio test.  A batch that spans two or more waves takes the two LDS-atomic rounds as before.
-// (Round 4 measured a form of this that lost to 14 more spilled SGPRs: there every wave ran the register fold and the result was needed by
-//  all threads before the ratio test.)
-// Returns the entering column (0: none -> optimal; uniform) -- or -1 in the waves that do not know it yet (`*late` set: read pw_col / pw_val /
-// pw_neg of this parity behind the next barrier); `*claim` = this wave runs the ratio test.
+// price_row_lds's three LDS-atomic rounds (first batch holding a candidate, best value in it, first column with that value) on reduction words
+// that are DOUBLE-BUFFERED by pivot parity: the words of the next pivot are reset right behind this pivot's first barrier -- two barriers behind
+// their last read, two in front of their next use -- so no reset sits in front of the gather's barrier or behind the row fetch any more (the
+// QDIRECT flows have no barrier there).  `*claim` = this wave holds the entering column and runs the ratio test.
+// (Measured and rejected twice -- round 4, and round 6 with the registers to spare: when the winning batch lies inside ONE wave, ~60 % of the
+//  pivots, that wave folds value and column in registers and goes straight on to the ratio test, two barriers fewer: 163.1 k against 179.1 k
+//  pivots/s on config 3a, profiles/r06_rejected_switches.patch.)
+// Returns the entering column (0: none -> optimal; uniform).
 template <int THREADS, int CPT, bool UNR>
 __device__ __forceinline__ int price_row_pipe(const double (&x)[CPT], int c0, const int (&pb)[CPT], const Ctx& c, RSmem& sm, int par,
-                                              double* value, unsigned unr, int* neg, bool* late, bool* claim) {
+                                              double* value, unsigned unr, int* neg, bool* claim) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double bv = c.precision;
     int bi = 0, bb = 0, bneg = 0;
@@ -264,30 +229,10 @@ __device__ __forceinline__ int price_row_pipe(const double (&x)[CPT], int c0, co
     __syncthreads();
     const int wb = sm.pw_batch[par];
     if (tid == THREADS - 1) { sm.pw_batch[par ^ 1] = 0x7fffffff; sm.pw_val[par ^ 1] = 0; sm.pw_col[par ^ 1] = 0x7fffffff; }  // the NEXT pivot's words: last read two barriers ago, first used behind two more
-    *late = false;
     *claim = false;
     if (wb == 0x7fffffff) return 0;  // uniform: no candidate anywhere -> optimal
     const u64_t bits = (u64_t)__double_as_longlong(bv);
     const bool cand = bi != 0 && bb == wb;
-    // the columns of batch wb (simplex.ts:118-127: batch k = columns 1 + k * batch ... (k + 1) * batch, the last one cut at W - 1) and the waves holding them
-    const int col_lo = 1 + wb * c.batch, col_hi = min(col_lo + c.batch - 1, c.W - 1);
-    const int fw = (col_lo / CPT) >> 6, lw = (col_hi / CPT) >> 6;
-    if (JSLP_PIPE_PRICE_IN_WAVE != 0 && c.use_partial && fw == lw) {  // (uniform)
-        *late = true;
-        if (wv != fw) return -1;
-        *late = false;
-        *claim = true;
-        const u64_t wmax = u64_wave_max(cand ? bits : 0ull);  // (> 0: some lane of this wave holds a candidate of batch wb -- the batch lies in this wave)
-        const unsigned long long m = __ballot(cand && bits == wmax);
-        const int first = __ffsll((long long)m) - 1;
-        const int pcol = __builtin_amdgcn_readlane(bi, first);
-        const int ng = UNR ? __builtin_amdgcn_readlane(bneg, first) : 0;
-        if (lane == 0) { sm.pw_col[par] = pcol; sm.pw_val[par] = wmax; sm.pw_neg[par] = ng; }
-        double v = __longlong_as_double((long long)wmax);
-        if (UNR) { *neg = ng; if (ng) v = -v; }
-        *value = v;
-        return pcol;
-    }
     if (cand) atomicMax(&sm.pw_val[par], bits);
     __syncthreads();
     const u64_t wvv = sm.pw_val[par];
@@ -374,15 +319,14 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
 //  dynamic index, which sends the whole register array to scratch: 456 bytes per lane, 1648 scratch instructions, 28-47 k cycles per
 //  update pass (r04_d).  An empty asm per iteration makes every comparison's operand its own opaque value.)
 #define JSLP_OPAQUE_SGPR(x) ({ int o_ = (x); asm volatile("" : "+s"(o_)); o_; })
-#define JSLP_XL_UPDATE_PASS() JSLP_XL_UPDATE_PASS_M(0u)
-#define JSLP_XL_UPDATE_PASS_M(SKIPMASK) /* SKIPMASK: rows of mine that have received this pivot already (JSLP_UPDATE_ONE_ROW) */     \
+#define JSLP_XL_UPDATE_PASS()                                                                                                     \
     do {                                                                                                                          \
         /* lane i < ROWS holds the pivot-column entry of my row i; the gate |k| > 1e-16 (simplex.ts:370-375) of all rows is ONE     \
            ballot, a row's k reaches the multiplier by two readlanes (scalar operands): per (row, column) a scalar bit test, a     \
            scalar branch and the two roundings -- no per-row LDS read, no per-cell select; the per-column gate is the EXEC mask of \
            the column's pass over the rows */                                                                                      \
         const double kl_ = lane < ROWS ? sm.colb[par_p][lane] : 0.0;                                                              \
-        const unsigned km_ = (unsigned)__ballot(nonzero16(kl_)) & ~(unsigned)(SKIPMASK); /* (rows beyond the workgroup's share hold zeros: bit clear) */ \
+        const unsigned km_ = (unsigned)__ballot(nonzero16(kl_)); /* (rows beyond the workgroup's share hold zeros: bit clear) */   \
         /* (measured, r04_e ... r04_g, XCD-local build: per-row LDS reads + per-cell SELECTS 5.4-6.9 k cycles per pass; readlane multipliers  \
             3.9-5.9 k; one pass over the rows with the column gate as an EXEC-masked branch per cell 5.1-8.5 k; a second, gate-free copy of \
             the loop for dense pivot rows costs the register allocator ~400 spills.  Round 6, JSLP_PIPE_K_BROADCAST: the multipliers of eight \
@@ -426,31 +370,6 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         }                                                                                                                         \
         if (b == 0) { _Pragma("unroll") for (int j = 0; j < CPT; j++) a[0][j] = r0[j]; } /* workgroup 0 mirrors the cost row */   \
     } while (0)
-// round 6 (SPLITU builds): the pending pivot applied to ONE row of mine -- the row that can win the next ratio test, which leaves normalised
-// right behind the summary; the other rows follow while the winning row is in flight (JSLP_XL_UPDATE_PASS_M with this row's bit).  Same steps
-// in the same order as the pass gives every row: elimination, the pivot column's own entry, the pivot row's replacement.
-#define JSLP_UPDATE_ONE_ROW(IROW)                                                                                                 \
-    do {                                                                                                                          \
-        const double kl_ = lane < ROWS ? sm.colb[par_p][lane] : 0.0;                                                              \
-        const unsigned km_ = (unsigned)__ballot(nonzero16(kl_));                                                                  \
-        const bool holds_ = wv == ((pc_p / CPT) >> 6);                                                                            \
-        const int ol_ = __builtin_amdgcn_readfirstlane((pc_p / CPT) & 63), js_ = __builtin_amdgcn_readfirstlane(pc_p % CPT);      \
-        const int ip_ = __builtin_amdgcn_readfirstlane(pr_p - r_begin);                                                           \
-        _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                          \
-            if (i == JSLP_OPAQUE_SGPR(IROW)) {                                                                                    \
-                if (km_ & (1u << i)) {                                                                                            \
-                    const double ki_ = readlane_f64(kl_, i);                                                                      \
-                    _Pragma("unroll") for (int j = 0; j < CPT; j++)                                                               \
-                        if ((nzm >> j) & 1u) a[i][j] = eliminate(a[i][j], ki_, p[j]);                                             \
-                    if (holds_) { /* (uniform: this wave holds the pivot column) */                                               \
-                        const double nv_ = -ki_ / quot_p;                                                                         \
-                        _Pragma("unroll") for (int j = 0; j < CPT; j++)                                                           \
-                            if (js_ == j && lane == ol_) a[i][j] = nv_;                                                           \
-                    }                                                                                                             \
-                }                                                                                                                 \
-                if (i == ip_) { _Pragma("unroll") for (int j = 0; j < CPT; j++) a[i][j] = p[j]; }                                 \
-            }                                                                                                                     \
-    } while (0)
 // the row that can win, with the epoch tag INSIDE the data: {lo32 | tag}{hi32 | tag} per double (RCCL's LL scheme) -- the readers
 // poll the row itself, no flag, no drain, no ordering between stores to rely on; twice the bytes, which one XCD's L2 does not notice
 #define JSLP_XL_PUBLISH_ROW(ROW)                                                                                                  \
@@ -459,7 +378,7 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         if (colok) {                                                                                                              \
             _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                      \
                 if (i == JSLP_OPAQUE_SGPR(ipub_)) {                                                                                                 \
-                    const int off_ = par * pub_stride + ((WLL ? 0 : b) * ld + c0) * 16; /* (winner-only: ONE row per pivot, one slot) */ \
+                    const int off_ = par * pub_stride + (b * ld + c0) * 16;                                                       \
                     _Pragma("unroll") for (int j = 0; j < CPT; j++) {                                                             \
                         if (c0 + j >= ld) continue;                                                                               \
                         const u64_t d_ = (u64_t)__double_as_longlong(a[i][j]);                                                    \
@@ -556,7 +475,6 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         }                                                                                                                         \
     } while (0)
 // ... and the fetch: flag word (NPUB: record) and row in ONE look, repeated until the checksum of what arrived matches the word
-// (SPLITU builds: the first look's loads leave, THEN the pending pivot's row update runs -- JSLP_CKS_BETWEEN -- and only then the look is examined)
 #define JSLP_CKS_ISSUE_LOOK()                                                                                                     \
     do {                                                                                                                          \
         if (__builtin_amdgcn_readfirstlane((int)((F_TEST_LATE & 1) != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);              \
@@ -573,8 +491,7 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
             }                                                                                                                     \
         }                                                                                                                         \
     } while (0)
-#define JSLP_CKS_FETCH_ROW() JSLP_CKS_FETCH_ROW_B(do { } while (0))
-#define JSLP_CKS_FETCH_ROW_B(BETWEEN)                                                                                             \
+#define JSLP_CKS_FETCH_ROW()                                                                                                      \
     do {                                                                                                                          \
         efetch += 1;                                                                                                              \
         unsigned spins_ = 0;                                                                                                      \
@@ -584,7 +501,6 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         rec0_.x = rec0_.y = rec0_.z = rec0_.w = 0u; rec1_ = rec0_;                                                                \
         _Pragma("unroll") for (int j = 0; j < CPT / 2; j++) rowv_[j] = rec0_;                                                     \
         JSLP_CKS_ISSUE_LOOK();                                                                                                    \
-        BETWEEN;                                                                                                                  \
         for (;;) {                                                                                                                \
             u64_t qm_ = 0;                                                                                                        \
             u64_t ck_ = 0;                                                                                                        \
@@ -627,19 +543,9 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
     do {                                                                                                                          \
         efetch += 1;                                                                                                              \
         unsigned spins_ = 0;                                                                                                      \
-        const int off_ = par * pub_stride + ((WLL ? 0 : bw) * ld + c0) * 16;                                                      \
-        const int offq_ = par * pub_stride + ((WLL ? 0 : bw) * ld + (PCCOL)) * 16; /* (PCCOL > 0: every lane also reads the row's entry of the \
+        const int off_ = par * pub_stride + (bw * ld + c0) * 16;                                                                  \
+        const int offq_ = par * pub_stride + (bw * ld + (PCCOL)) * 16; /* (PCCOL > 0: every lane also reads the row's entry of the \
             entering column -- quot, simplex.ts:333 -- one address per wave: no LDS broadcast, no barrier behind the fetch) */      \
-        if (WLL) { /* the winner stores only now: look at ONE word per wave until it is up (4096 waves x 16 bytes per look instead \
-                      of 256 workgroups x 32 KB), then fetch -- and verify -- the row */                                           \
-            unsigned probes_ = 0;                                                                                                 \
-            for (;;) {                                                                                                            \
-                const v4u_t q_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, offq_, 0, 16);                                  \
-                if (q_.y == tag && q_.w == tag) break;                                                                            \
-                __builtin_amdgcn_s_sleep(1);                                                                                      \
-                if ((++probes_ & 63u) == 0 && (AG_LOAD(f.abort_flag) != 0u || probes_ > F_SPIN)) break; /* (the loop below gives up properly) */ \
-            }                                                                                                                     \
-        }                                                                                                                         \
         for (;;) {                                                                                                                \
             if (__builtin_amdgcn_readfirstlane((int)(F_TEST_LATE != 0 && wv == 0))) __builtin_amdgcn_s_sleep(127);          \
             bool ok_ = true;                                                                                                      \
@@ -723,29 +629,20 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     // would drop the line and send the readers to memory) and are read with `sc1` loads (L1-bypassing, L2-served); no write-back
     // fence anywhere (tools/micro/xcd_handoff_bench.hip flavour 1: 1.9 k cycles per 32 -> 32 exchange against 8.3 k chip-wide)
     constexpr int ST_AUX = XL ? 0 : 16;           // aux of the hand-off stores: 16 = sc1 (write-through to memory)
-    constexpr bool WLL = !XL && JSLP_PIPE_WINNER_LL != 0;  // winner-only tagged row (see JSLP_PIPE_WINNER_LL)
-    constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
-    constexpr bool CKS = !TAGGED && JSLP_PIPE_SPECPUB != 0 && JSLP_PIPE_ROW_CHECKSUM != 0 && CPT <= JSLP_PIPE_ROW_CHECKSUM_MAXCPT;  // checksummed hand-over of the candidate rows (see JSLP_PIPE_ROW_CHECKSUM)
-    constexpr bool UPD_NEW_ = XL || (JSLP_PIPE_NEW_UPDATE != 0 && CPT <= 4 && !(OPT && ROWS > 8));
-    constexpr int EARLY = (!XL && UPD_NEW_) ? JSLP_PIPE_EARLY_LOOKS : 0;  // looks at the summaries that leave during the row update
-    constexpr bool LA = !XL && JSLP_PIPE_LOOK_AHEAD != 0;  // the first look leaves in front of the row update (see JSLP_PIPE_LOOK_AHEAD)
+    constexpr bool TAGGED = XL;                   // rows travel with their tags: 16 bytes per double
+    constexpr bool CKS = !TAGGED && JSLP_PIPE_ROW_CHECKSUM != 0 && CPT <= JSLP_PIPE_ROW_CHECKSUM_MAXCPT;  // checksummed hand-over of the candidate rows (see JSLP_PIPE_ROW_CHECKSUM)
     // round 6 -- NPUB: the candidate row is published NORMALISED (JSLP_PUBLISH_ROW_PLAIN) and quot / the cost row's new entry of the entering column come
     // with the row's record: between the row fetch and the next pricing no division and no barrier are left (the update pass that publishes
     // is JSLP_XL_UPDATE_PASS + JSLP_PUBLISH_ROW_PLAIN: the 2- / 4-column geometries; optional objectives need the raw row for their tiny-entry rule)
-    constexpr bool NPUB = CKS && !OPT && !XL && JSLP_PIPE_NEW_UPDATE != 0 && CPT <= 4 && JSLP_PIPE_NORM_PUB != 0;
-    // SPLITU (round 6): the pending pivot's row update in two parts -- the ONE row that can win right behind the summary (it is published from
-    // there), the other rows while the winning row's fetch is in flight.  The pivot period is the loop time of the workgroup whose summary
-    // arrives last (tools/resident_stamps.py), and that loop used to be summary -> whole update pass -> look at the summaries (one round trip)
-    // -> decide -> row fetch (another round trip): the pass now hides behind the second trip instead of standing in front of the first
-    constexpr bool SPLITU = NPUB && JSLP_PIPE_SPLIT_UPDATE != 0;
-    constexpr bool QDIRECT = TAGGED || NPUB || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT && !CKS);  // quot comes with the fetch: no barrier behind it
+    constexpr bool NPUB = CKS && !OPT && !XL && CPT <= 4 && JSLP_PIPE_NORM_PUB != 0;
+    constexpr bool QDIRECT = TAGGED || NPUB;  // quot comes with the fetch: no barrier behind it
     // the ratio test's transposition (entry i of the entering column from the ONE lane that holds it to lane i) through LDS: as `x = lane
     // == i ? readlane(a[i][j]) : x` the compiler precomputes the 64-bit lane masks, spills them and pays two reloads, two moves and two
     // selects per row on top of the readlanes -- in the one wave the summary waits for
     constexpr bool S_LDS = XL || JSLP_PIPE_S_VIA_LDS != 0;
     // the pending pivot's row update in the XCD-local build's form (JSLP_XL_UPDATE_PASS: one ballot for the row gate, readlane multipliers,
     // the special rows fixed up once per pivot) instead of JSLP_PIPE_UPDATE_ROW's ~55 instructions per row
-    constexpr bool UPD_NEW = XL || (JSLP_PIPE_NEW_UPDATE != 0 && CPT <= 4 && !(OPT && ROWS > 8));  // (the 6- / 8-column geometries and the tall OPT build would spill 14-94 VGPRs with it)
+    constexpr bool UPD_NEW = XL || (CPT <= 4 && !(OPT && ROWS > 8));  // (the 6- / 8-column geometries and the tall OPT build would spill 14-94 VGPRs with it)
     // candidate rows in the publication buffer (chip-wide builds): pair j of lane t at ((j / 2) * THREADS + t) * 16 inside the
     // workgroup's slot -- a wave's store of one pair is 1 KB of whole lines (with lane t's CPT columns adjacent, as they sit in the
     // tableau, the 512-thread geometries wrote 16 bytes into each of 64 lines per instruction: the partial-line writers of round 3);
@@ -759,10 +656,8 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     const int SLOT = PERM ? THREADS * CPT * 8 + JSLP_PUB_SKEW : f.c.ld * 8;
     constexpr int PAIR_STEP = PERM ? THREADS * 16 : 16;           // bytes from a lane's pair j to its pair j + 2
     const int lane_off = PERM ? tid * 16 : tid * CPT * 8;          // ... and where its first pair sits in the slot
-    constexpr bool P1W = !XL && JSLP_PIPE_ONE_POLL_WAVE != 0;  // one polling wave, four summaries per lane (see JSLP_PIPE_ONE_POLL_WAVE)
-    constexpr int NPOLLW = (XL || P1W) ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
-    constexpr int POLLWV = 1;  // ... which wave, when it is one (not wave 0: it carries the column-0 work; not the last: the commit)
-    constexpr int HAWV = P1W ? POLLWV : 0;  // the wave whose retry path looks at the host's abort word (JSLP_HOST_ABORT_IN_SPIN)
+    constexpr int POLLWV = 1;  // the ONE polling wave (not wave 0: it carries the column-0 work; not the last: the commit): lane l looks at workgroups l, l + 64, ...
+    constexpr int HAWV = POLLWV;  // the wave whose retry path looks at the host's abort word (JSLP_HOST_ABORT_IN_SPIN)
     static_assert(THREADS / 64 > POLLWV, "the polling wave exists");
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
@@ -773,7 +668,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     double (&r0)[CPT] = R.r0;
     typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
     const int pub_stride = (int)((const char*)f.rows_pub[1] - (const char*)f.rows_pub[0]);  // (both carved from one arena, [0] first)
-    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + (TAGGED ? (WLL ? 1 : f.G) * ld * 16 : f.G * (CPT >= 6 ? THREADS * CPT * 8 + JSLP_PUB_SKEW : ld * 8)), 0x00020000);
+    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + (TAGGED ? f.G * ld * 16 : f.G * (CPT >= 6 ? THREADS * CPT * 8 + JSLP_PUB_SKEW : ld * 8)), 0x00020000);
     const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, JSLP_R_REC_OFF + JSLP_R_REC_WORDS * 8, 0x00020000);  // (the summary granules, the row-flag copies and the row records: one descriptor)
 #ifdef JSLP_DEBUG_RESIDENT
     u64_t (&rt_acc)[8] = R.rt_acc;
@@ -788,7 +683,6 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     bool pend = false;
     bool cpend = false;  // the pending pivot's global commit has not been issued yet (JSLP_PIPE_COMMIT_GLOBAL)
     bool lpend = false;   // QDIRECT flows: the pending pivot's swap of my LDS maps has not happened yet (JSLP_PIPE_SWAP_LDS_MAPS)
-    unsigned emask = 0u;  // SPLITU: bit i = my row i has received the pending pivot already (JSLP_UPDATE_ONE_ROW)
 #pragma unroll
     for (int j = 0; j < CPT; j++) p[j] = 0.0;
     int okslot = 0;
@@ -802,7 +696,6 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < ROWS; i++) sm.rhsb[i] = a[i][0];
-        sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff;
         for (int q = 0; q < 2; q++) { sm.pw_batch[q] = 0x7fffffff; sm.pw_val[q] = 0; sm.pw_col[q] = 0x7fffffff; sm.pw_neg[q] = 0; }
     }
     __syncthreads();
@@ -824,11 +717,11 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         // ---- G: price the cost row -> entering column (simplex.ts:118-219; three LDS-atomic rounds) -------------------------------
         double k0 = 0.0;  // reduced cost of the entering column
         int pc;
-        bool pc_late = false, claim = false;  // (price_row_pipe: the waves that learn column and value behind the ratio test's barrier; the wave that runs the ratio test)
+        bool claim = false;  // (price_row_pipe: this wave holds the entering column and runs the ratio test)
         {
             int neg_now = 0;
             RT_STAMP(5);  // at the pricing
-            pc = price_row_pipe<THREADS, CPT, UNR>(r0, c0, pb, c, sm, par, &k0, R.unr, &neg_now, &pc_late, &claim);
+            pc = price_row_pipe<THREADS, CPT, UNR>(r0, c0, pb, c, sm, par, &k0, R.unr, &neg_now, &claim);
             RT_STAMP(6);  // priced
             JSLP_PIPE_SWAP_LDS_MAPS();  // (the pending pivot's basis change in my LDS maps: every wave is past its reads of them -- the pricing's barriers)
             if (UNR) R.neg = neg_now;  // isReducedCostNegative of the entering column (simplex.ts:164-177): the ratio test's sign
@@ -935,11 +828,6 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             }
         }
         __syncthreads();
-        if (pc_late) {  // the waves that did not hold the winning batch: column, value (and sign) as the claiming wave left them
-            pc = sm.pw_col[par];
-            k0 = __longlong_as_double((long long)sm.pw_val[par]);
-            if (UNR) { R.neg = sm.pw_neg[par]; if (R.neg) k0 = -k0; }
-        }
         const int pubrow = sm.pubrow;
         RT_STAMP(0);  // summary stored (the claiming wave stored it in front of the barrier)
         const double pub_k0 = k0;
@@ -950,42 +838,15 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         //         published (16-byte write-through stores) as soon as it is up to date.  The summaries are crossing the fabric
         //         meanwhile ----------------------------------------------------------------------------------------------------------
         bool swept = true;
-        const bool poller = P1W ? wv == POLLWV : tid < NPOLLW * 64;
-        const bool used = tid < f.G;
+        const bool poller = wv == POLLWV;
         v4u_t g;
-        g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;  // lanes beyond the grid: "no candidate"
-        const int goff = (par * JSLP_F_MAXG + tid) * JSLP_G16_STRIDE;
-        // early looks at the summaries (JSLP_PIPE_EARLY_LOOKS): a look costs one trip to memory and back, during which this wave has the
-        // row update to do -- the first look leaves in front of the update, the second between update and publication, and the gather
-        // examines them in order before it starts looking again
-        v4u_t ge0 = g, ge1 = g;
-        if (EARLY >= 2 && poller && used) ge0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
-        v4u_t gq[JSLP_F_MAXG / 64];  // the one polling wave's looks: lane l looks at workgroups l, l + 64, l + 128, l + 192
-#pragma unroll
-        for (int q = 0; q < JSLP_F_MAXG / 64; q++) gq[q] = g;
-        v4u_t gla = g;  // the look-ahead (JSLP_PIPE_LOOK_AHEAD): examined behind the update pass
-        if (LA && poller && used) gla = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
+        g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;  // workgroups beyond the grid: "no candidate"
         // (the pending pivot's column entries of my rows: broadcast LDS reads, JSLP_PIPE_KCHUNK of them in flight together)
-        if (SPLITU) {  // only the row that can win, and its publication; the other rows: behind the decision, while the winning row is in flight
-            if (pubrow != 0) {
-                const int ipub = __builtin_amdgcn_readfirstlane(pubrow - r_begin);
-                if (pend) { JSLP_UPDATE_ONE_ROW(ipub); emask = 1u << ipub; }
-                JSLP_PUBLISH_ROW_PLAIN(pubrow);
-            }
-        } else if (UPD_NEW) {
+        if (UPD_NEW) {
             if (pend) JSLP_XL_UPDATE_PASS();
-            if (EARLY >= 1 && poller && used) ge1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
-            if (P1W && JSLP_PIPE_LOOK_MID != 0 && poller) {  // the polling wave's first look leaves between the update pass and the publication: the
-                                                             // normalisation's divisions run while it is under way (see JSLP_PIPE_LOOK_MID)
-#pragma unroll
-                for (int q = 0; q < JSLP_F_MAXG / 64; q++) {
-                    gq[q] = g;
-                    if (lane + 64 * q < f.G) gq[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, (par * JSLP_F_MAXG + lane + 64 * q) * JSLP_G16_STRIDE, 0, 16);
-                }
-            }
             if (pubrow != 0) {
-                if (TAGGED) { if (XL) JSLP_XL_PUBLISH_ROW(pubrow); }  // (winner-only builds publish after the decision)
-                else if (JSLP_PIPE_SPECPUB) JSLP_PUBLISH_ROW_PLAIN(pubrow);
+                if (TAGGED) JSLP_XL_PUBLISH_ROW(pubrow);
+                else JSLP_PUBLISH_ROW_PLAIN(pubrow);
             }
         } else {
         u64_t ck = 0;
@@ -1001,7 +862,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
             for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) {
                 if (pend) JSLP_PIPE_UPDATE_ROW(i);
-                if (JSLP_PIPE_SPECPUB && !WLL && pubrow != 0 && r_begin + i == pubrow && colok) {  // (uniform but for colok)
+                if (pubrow != 0 && r_begin + i == pubrow && colok) {  // (uniform but for colok)
                     const int off = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;
 #pragma unroll
                     for (int j = 0; j < CPT; j += 2) {
@@ -1037,23 +898,20 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         }
         }
         JSLP_PIPE_COMMIT_GLOBAL();  // (the pending pivot's global maps + trace: behind my row stores, while the summaries cross the fabric)
-        if (!SPLITU) pend = false;
+        pend = false;
         RT_STAMP(1);  // update + publication issued
         RT_MARK(2);
-        // ---- C: gather: lane w of the first four waves polls workgroup w's granule ------------------------------------------------
-        if (P1W && poller) {
+        // ---- C: gather: ONE wave, lane l looks at the granules of workgroups l, l + 64, l + 128, l + 192 (four 16-byte loads in flight) --------
+        if (poller) {
             unsigned spins = 0;
-            bool first = UPD_NEW && !SPLITU && JSLP_PIPE_LOOK_MID != 0;  // (that look is under way already)
+            v4u_t gq[JSLP_F_MAXG / 64];
             for (;;) {
                 bool ok = true;
-                if (!first) {
 #pragma unroll
-                    for (int q = 0; q < JSLP_F_MAXG / 64; q++) {
-                        gq[q] = g;
-                        if (lane + 64 * q < f.G) gq[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, (par * JSLP_F_MAXG + lane + 64 * q) * JSLP_G16_STRIDE, 0, 16);
-                    }
+                for (int q = 0; q < JSLP_F_MAXG / 64; q++) {
+                    gq[q] = g;
+                    if (lane + 64 * q < f.G) gq[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, (par * JSLP_F_MAXG + lane + 64 * q) * JSLP_G16_STRIDE, 0, 16);
                 }
-                first = false;
 #pragma unroll
                 for (int q = 0; q < JSLP_F_MAXG / 64; q++) ok = ok && gq[q].y == tag && (gq[q].w >> 16) == (tag & 0xffffu);
                 if (__all(ok) && !JSLP_HOST_ABORT_FORCE_RETRY(spins)) break;
@@ -1086,68 +944,18 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                        min(__builtin_amdgcn_readlane(rdeg, 32), __builtin_amdgcn_readlane(rdeg, 48)));
             x = ki_wave_min(x);
             if (lane == 0) { sm.part_k[0] = x.k; sm.part_r[0] = x.k == KI_NONE_KEY ? 0 : x.i; sm.part_rdeg[0] = rdeg; }
-        } else if (poller) {
-            unsigned spins = 0;
-            bool have = false;
-            if (LA && __all(gla.y == tag && (gla.w >> 16) == (tag & 0xffffu))) { g = gla; have = true; }
-            if (EARLY >= 1) {
-                v4u_t gl = g;
-                if (used) gl = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);  // (leaves before the early looks are examined)
-                if (EARLY >= 2 && __all(ge0.y == tag && (ge0.w >> 16) == (tag & 0xffffu))) { g = ge0; have = true; }
-                else if (__all(ge1.y == tag && (ge1.w >> 16) == (tag & 0xffffu))) { g = ge1; have = true; }
-                else if (__all(gl.y == tag && (gl.w >> 16) == (tag & 0xffffu))) { g = gl; have = true; }
-            }
-            if (!have)
-            for (;;) {
-                if (used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
-                const bool ok = g.y == tag && (g.w >> 16) == (tag & 0xffffu);
-                if (__all(ok) && !JSLP_HOST_ABORT_FORCE_RETRY(spins)) break;
-                __builtin_amdgcn_s_sleep(1);
-                ++spins;
-                JSLP_HOST_ABORT_IN_SPIN(spins, swept);
-                if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { swept = false; break; }
-                if (spins > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
-            }
-            // my workgroup's summary -> the wave's: first degenerate row, else smallest quotient (first row on ties)
-            const int row = (int)(g.w & 0x7fffu);
-            const bool deg = (g.w & 0x8000u) != 0u;
-            int rdeg = (deg && row != 0) ? row : 0x7fffffff;
-            rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0xB1, 0xf, 0xf, false));
-            rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x4E, 0xf, 0xf, false));
-            rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x141, 0xf, 0xf, false));
-            rdeg = min(rdeg, __builtin_amdgcn_update_dpp(rdeg, rdeg, 0x140, 0xf, 0xf, false));
-            rdeg = min(min(__builtin_amdgcn_readlane(rdeg, 0), __builtin_amdgcn_readlane(rdeg, 16)),
-                       min(__builtin_amdgcn_readlane(rdeg, 32), __builtin_amdgcn_readlane(rdeg, 48)));
-            KI x;  // quotients are > precision > 0: positive doubles order like their bit patterns
-            const bool cand = !deg && row != 0;
-            x.k = cand ? ((u64_t)g.x | ((u64_t)g.z << 32)) : KI_NONE_KEY;
-            x.i = cand ? row : 0x7fffffff;
-            x.pad = 0;
-            x = ki_wave_min(x);
-            if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; sm.part_rdeg[wv] = rdeg; }
         }
         RT_STAMP(2);  // my wave's 64 summaries are in
         RT_MARK(1);
-        if (QDIRECT && !OPT && tid == THREADS - 1) { sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff; }  // the next pricing's reductions: everybody read this pivot's before the barrier that closed S; the barrier below orders the reset in front of the next pricing
         if (!TAGGED && !CKS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2 (the winner's release below builds on it; XL / winner-only: the row carries its tags)
         const int all_swept = __syncthreads_and(swept ? 1 : 0);
         if (!all_swept) { R.end_code = 5; break; }
         RT_STAMP(3);  // gather closed
         RT_MARK(3);
-        // ---- D: every thread folds the four partial results ------------------------------------------------------------------
+        // ---- D: every thread reads the polling wave's verdict ------------------------------------------------------------------
         int pr = 0, stop = 0;
         {
-            u64_t wk = sm.part_k[0];
-            int wr = sm.part_r[0], wrdeg = sm.part_rdeg[0];
-#pragma unroll
-            for (int i = 1; i < NPOLLW; i++) {
-                const u64_t k2 = sm.part_k[i];
-                const int r2 = sm.part_r[i], rd2 = sm.part_rdeg[i];
-                const bool take = r2 != 0 && (wr == 0 || k2 < wk || (k2 == wk && r2 < wr));
-                wk = take ? k2 : wk;
-                wr = take ? r2 : wr;
-                wrdeg = rd2 < wrdeg ? rd2 : wrdeg;
-            }
+            const int wr = sm.part_r[0], wrdeg = sm.part_rdeg[0];
             if (wrdeg != 0x7fffffff) pr = wrdeg;
             else if (wr != 0) pr = wr;
             else stop = 3;  // unbounded (simplex.ts:298-303)
@@ -1181,27 +989,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         //      whose row is going to be read, here, 139 k -- 149 k with the drain in front of the barrier that closes the gather instead of
         //      a barrier of its own here (155 k with the unsound release) -------------------------------------------------------------
         const int bw = pr / f.rpb;
-        if (WLL && bw == b) JSLP_XL_PUBLISH_ROW(pr);  // (only the winner, only now: 32 KB per pivot instead of 4 MB of candidates; the tags are the flag)
         if (!TAGGED && !CKS && bw == b) {  // (uniform: pr is the row I published -- my candidate was the chip's best; XL: tags inside the row, no flag)
-            if (!JSLP_PIPE_SPECPUB && colok) {  // the row leaves only now, and only from here: 16 KB per pivot instead of 4 MB of candidates
-#pragma unroll
-                for (int i = 0; i < ROWS; i++) {
-                    if (r_begin + i != pr) continue;  // (uniform)
-                    const int off = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;
-#pragma unroll
-                    for (int j = 0; j < CPT; j += 2) {
-                        if (c0 + j >= ld) continue;
-                        const u64_t lo = (u64_t)__double_as_longlong(a[i][j]), hi = (u64_t)__double_as_longlong(a[i][j + 1]);
-                        v4u_t v;
-                        v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_rows, off + (j >> 1) * PAIR_STEP, 0, ST_AUX);
-                    }
-                }
-            }
-            if (!JSLP_PIPE_SPECPUB) {  // (stored a moment ago: wait for them here)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
             if (tid < THREADS / 64) {  // (every wave's stores reached the L2 before the barrier that closed the gather)
                 if (XL) {  // ... which is where every reader looks: a plain flag store behind the drained row stores is the whole release
                     *reinterpret_cast<volatile u64_t*>(f.rowflagc[par] + tid * JSLP_F_MAXG + b) = (u64_t)tag;
@@ -1228,8 +1016,6 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             // (see resident_phase's step E); a wave that gives up raises sm.okbad to this fetch's number
             if (TAGGED) {
                 JSLP_XL_FETCH_ROW(pc, quot);
-            } else if (SPLITU) {
-                JSLP_CKS_FETCH_ROW_B(do { if (pend) { JSLP_XL_UPDATE_PASS_M(emask); } pend = false; emask = 0u; } while (0));
             } else if (CKS) {
                 JSLP_CKS_FETCH_ROW();
             } else {
@@ -1260,10 +1046,6 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                     pv[j + 1] = __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32)));
                 }
             }
-            if (QDIRECT) {  // the pair of the row that holds column pc: the same 16 bytes in every lane (behind the same look at the flag)
-                const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, par * pub_stride + bw * SLOT + (PERM ? ((((pc % CPT) >> 1) * THREADS) + pc / CPT) * 16 : (pc & ~1) * 8), 0, 16);
-                quot = (pc & 1) ? __longlong_as_double((long long)((u64_t)v.z | ((u64_t)v.w << 32))) : __longlong_as_double((long long)((u64_t)v.x | ((u64_t)v.y << 32)));
-            }
             }  // !XL
             if (NPUB) quot = fq;
             if (!NPUB && has_pc) {
@@ -1277,8 +1059,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                         }
                     }
             }
-            if (!(QDIRECT && !OPT)) {  // (XL / winner-only / JSLP_PIPE_QUOT_DIRECT: quot came with the fetch, the reductions were reset in front of the gather's barrier, and a wave that gave up is noticed behind the next pricing's first barrier)
-            if (tid == 0) { sm.p_batch = 0x7fffffff; sm.p_val = 0; sm.p_col = 0x7fffffff; }  // the next pricing's reductions (reset before a barrier)
+            if (!(QDIRECT && !OPT)) {  // (XL / NPUB: quot came with the fetch, and a wave that gave up is noticed behind the next pricing's first barrier)
             __syncthreads();
             if (sm.okbad == efetch) R.end_code = 5;
             quot = sm.xq2[okslot];
@@ -1407,7 +1188,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         const bool has_pc_p = colok && pc_p >= c0 && pc_p < c0 + CPT;
         if (UPD_NEW) {
             (void)has_pc_p;
-            JSLP_XL_UPDATE_PASS_M(emask);  // (SPLITU: an exit between the two parts of the update leaves one row already up to date)
+            JSLP_XL_UPDATE_PASS();
         } else
 #pragma unroll
         for (int i0 = 0; i0 < ROWS; i0 += JSLP_PIPE_KCHUNK) {
@@ -1440,11 +1221,9 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     // would drop the line and send the readers to memory) and are read with `sc1` loads (L1-bypassing, L2-served); no write-back
     // fence anywhere (tools/micro/xcd_handoff_bench.hip flavour 1: 1.9 k cycles per 32 -> 32 exchange against 8.3 k chip-wide)
     constexpr int ST_AUX = XL ? 0 : 16;           // aux of the hand-off stores: 16 = sc1 (write-through to memory)
-    constexpr bool WLL = !XL && JSLP_PIPE_WINNER_LL != 0;  // winner-only tagged row (see JSLP_PIPE_WINNER_LL)
-    constexpr bool TAGGED = XL || WLL;            // rows travel with their tags: 16 bytes per double
-    constexpr bool CKS = !TAGGED && JSLP_PIPE_SPECPUB != 0 && JSLP_PIPE_ROW_CHECKSUM != 0 && CPT <= JSLP_PIPE_ROW_CHECKSUM_MAXCPT;  // checksummed hand-over of the candidate rows (see JSLP_PIPE_ROW_CHECKSUM)
-    constexpr bool QDIRECT = TAGGED || (JSLP_PIPE_QUOT_DIRECT != 0 && !OPT && !CKS);  // quot comes with the fetch: no barrier behind it
-    constexpr int HAWV = (!XL && JSLP_PIPE_ONE_POLL_WAVE != 0) ? 1 : 0;
+    constexpr bool TAGGED = XL;                   // rows travel with their tags: 16 bytes per double
+    constexpr bool CKS = !TAGGED && JSLP_PIPE_ROW_CHECKSUM != 0 && CPT <= JSLP_PIPE_ROW_CHECKSUM_MAXCPT;  // checksummed hand-over of the candidate rows (see JSLP_PIPE_ROW_CHECKSUM)
+    constexpr int HAWV = 1;
     constexpr bool NPUB = false;  // (phase 1 knows its entering column only once the pivot row has arrived: the row travels as it is)
     const double quot_p = 1.0, pub_k0 = 0.0;
     const int pub_pc = 0;
@@ -1456,7 +1235,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     constexpr bool S_LDS = XL || JSLP_PIPE_S_VIA_LDS != 0;
     // the pending pivot's row update in the XCD-local build's form (JSLP_XL_UPDATE_PASS: one ballot for the row gate, readlane multipliers,
     // the special rows fixed up once per pivot) instead of JSLP_PIPE_UPDATE_ROW's ~55 instructions per row
-    constexpr bool UPD_NEW = XL || (JSLP_PIPE_NEW_UPDATE != 0 && CPT <= 4 && !(OPT && ROWS > 8));  // (the 6- / 8-column geometries and the tall OPT build would spill 14-94 VGPRs with it)
+    constexpr bool UPD_NEW = XL || (CPT <= 4 && !(OPT && ROWS > 8));  // (the 6- / 8-column geometries and the tall OPT build would spill 14-94 VGPRs with it)
     // candidate rows in the publication buffer (chip-wide builds): pair j of lane t at ((j / 2) * THREADS + t) * 16 inside the
     // workgroup's slot -- a wave's store of one pair is 1 KB of whole lines (with lane t's CPT columns adjacent, as they sit in the
     // tableau, the 512-thread geometries wrote 16 bytes into each of 64 lines per instruction: the partial-line writers of round 3);
@@ -1470,9 +1249,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     const int SLOT = PERM ? THREADS * CPT * 8 + JSLP_PUB_SKEW : f.c.ld * 8;
     constexpr int PAIR_STEP = PERM ? THREADS * 16 : 16;           // bytes from a lane's pair j to its pair j + 2
     const int lane_off = PERM ? tid * 16 : tid * CPT * 8;          // ... and where its first pair sits in the slot
-    constexpr bool P1W = !XL && JSLP_PIPE_ONE_POLL_WAVE != 0;  // one polling wave, four summaries per lane (see JSLP_PIPE_ONE_POLL_WAVE)
-    constexpr int NPOLLW = (XL || P1W) ? 1 : JSLP_F_MAXG / 64;  // polling waves (lane w = workgroup w)
-    constexpr int POLLWV = 1;  // (wave 0 folds the next summary out of column 0; the last wave commits)
+    constexpr int POLLWV = 1;  // the one polling wave (wave 0 folds the next summary out of column 0; the last wave commits)
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
     const int c0 = tid * CPT;
@@ -1482,7 +1259,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     double (&r0)[CPT] = R.r0;
     typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
     const int pub_stride = (int)((const char*)f.rows_pub[1] - (const char*)f.rows_pub[0]);
-    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + (TAGGED ? (WLL ? 1 : f.G) * ld * 16 : f.G * (CPT >= 6 ? THREADS * CPT * 8 + JSLP_PUB_SKEW : ld * 8)), 0x00020000);
+    const auto rsrc_rows = __builtin_amdgcn_make_buffer_rsrc(f.rows_pub[0], 0, pub_stride + (TAGGED ? f.G * ld * 16 : f.G * (CPT >= 6 ? THREADS * CPT * 8 + JSLP_PUB_SKEW : ld * 8)), 0x00020000);
     const auto rsrc_g16 = __builtin_amdgcn_make_buffer_rsrc(f.gran16, 0, JSLP_R_REC_OFF + JSLP_R_REC_WORDS * 8, 0x00020000);  // (the summary granules, the row-flag copies and the row records: one descriptor)
 #ifdef JSLP_DEBUG_RESIDENT
     u64_t (&rt_acc)[8] = R.rt_acc;
@@ -1553,16 +1330,14 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         RT_MARK(0);
         // ---- U + P: the pending pivot's row update, the candidate row published from inside the pass ----------------------------
         bool swept = true;
-        const bool poller = P1W ? wv == POLLWV : tid < NPOLLW * 64;
-        const bool used = tid < f.G;
+        const bool poller = wv == POLLWV;
         v4u_t g;
         g.x = 0; g.y = tag; g.z = 0; g.w = (tag & 0xffffu) << 16;
-        const int goff = (par * JSLP_F_MAXG + tid) * JSLP_G16_STRIDE;
         if (UPD_NEW) {
             if (pend) JSLP_XL_UPDATE_PASS();
             if (pubrow != 0) {
-                if (TAGGED) { if (XL) JSLP_XL_PUBLISH_ROW(pubrow); }  // (winner-only builds publish after the decision)
-                else if (JSLP_PIPE_SPECPUB) JSLP_PUBLISH_ROW_PLAIN(pubrow);
+                if (TAGGED) JSLP_XL_PUBLISH_ROW(pubrow);
+                else JSLP_PUBLISH_ROW_PLAIN(pubrow);
             }
         } else {
         u64_t ck = 0;
@@ -1578,7 +1353,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #pragma unroll
             for (int i = i0; i < i0 + JSLP_PIPE_KCHUNK && i < ROWS; i++) {
                 if (pend) JSLP_PIPE_UPDATE_ROW(i);
-                if (!WLL && pubrow != 0 && r_begin + i == pubrow && colok) {
+                if (pubrow != 0 && r_begin + i == pubrow && colok) {
                     const int off = PERM ? par * pub_stride + b * SLOT + lane_off : par * pub_stride + (b * ld + c0) * 8;
 #pragma unroll
                     for (int j = 0; j < CPT; j += 2) {
@@ -1617,7 +1392,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         pend = false;
         RT_MARK(2);
         // ---- C: gather ----------------------------------------------------------------------------------------------------
-        if (P1W && poller) {  // one wave, four summaries per lane (see phase 2)
+        if (poller) {  // one wave, four summaries per lane (see phase 2)
             unsigned spins = 0;
             v4u_t gq[JSLP_F_MAXG / 64];
             for (;;) {
@@ -1648,25 +1423,6 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             }
             x = ki_wave_min(x);
             if (lane == 0) { sm.part_k[0] = x.k; sm.part_r[0] = x.k == KI_NONE_KEY ? 0 : x.i; }
-        } else if (poller) {
-            unsigned spins = 0;
-            for (;;) {
-                if (used) g = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, goff, 0, 16);
-                const bool ok = g.y == tag && (g.w >> 16) == (tag & 0xffffu);
-                if (__all(ok) && !JSLP_HOST_ABORT_FORCE_RETRY(spins)) break;
-                __builtin_amdgcn_s_sleep(1);
-                ++spins;
-                JSLP_HOST_ABORT_IN_SPIN(spins, swept);
-                if ((spins & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) { swept = false; break; }
-                if (spins > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); swept = false; break; }
-            }
-            const int row = (int)(g.w & 0x7fffu);
-            KI x;
-            x.k = row != 0 ? ((u64_t)g.x | ((u64_t)g.z << 32)) : KI_NONE_KEY;
-            x.i = row != 0 ? row : 0x7fffffff;
-            x.pad = 0;
-            x = ki_wave_min(x);
-            if (lane == 0) { sm.part_k[wv] = x.k; sm.part_r[wv] = x.k == KI_NONE_KEY ? 0 : x.i; }
         }
         RT_MARK(1);
         if (!TAGGED && !CKS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: my stores of the candidate row have reached the L2
@@ -1674,25 +1430,11 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         if (!all_swept) { R.end_code = 5; break; }
         RT_MARK(3);
         // ---- D ---------------------------------------------------------------------------------------------------------------
-        int pr = 0;
-        {
-            u64_t wk = sm.part_k[0];
-            int wr = sm.part_r[0];
-#pragma unroll
-            for (int i = 1; i < NPOLLW; i++) {
-                const u64_t k2 = sm.part_k[i];
-                const int r2 = sm.part_r[i];
-                const bool take = r2 != 0 && (wr == 0 || k2 < wk || (k2 == wk && r2 < wr));
-                wk = take ? k2 : wk;
-                wr = take ? r2 : wr;
-            }
-            pr = wr;
-        }
+        const int pr = sm.part_r[0];  // (the polling wave's verdict)
         if (pr == 0) { done = true; break; }  // no violated row: feasible (simplex.ts:51-54); uniform
         const bool leaving_unr = UNR && sm.lunr[sm.lvibr[pr]] != 0;  // (see phase 2)
         // ---- the winner releases its row (see phase 2) ---------------------------------------------------------------------------
         const int bw = pr / f.rpb;
-        if (WLL && bw == b) JSLP_XL_PUBLISH_ROW(pr);
         if (!TAGGED && !CKS && bw == b && tid < THREADS / 64) {  // (every wave's stores reached the L2 before the barrier that closed the gather)
             if (XL) {
                 *reinterpret_cast<volatile u64_t*>(f.rowflagc[par] + tid * JSLP_F_MAXG + b) = (u64_t)tag;
@@ -1925,13 +1667,10 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #undef JSLP_PIPE_UPDATE_ROW
 #undef JSLP_OPAQUE_SGPR
 #undef JSLP_XL_UPDATE_PASS
-#undef JSLP_XL_UPDATE_PASS_M
-#undef JSLP_UPDATE_ONE_ROW
 #undef JSLP_XL_PUBLISH_ROW
 #undef JSLP_PUBLISH_ROW_PLAIN
 #undef JSLP_XL_FETCH_ROW
 #undef JSLP_CKS_FETCH_ROW
-#undef JSLP_CKS_FETCH_ROW_B
 #undef JSLP_CKS_ISSUE_LOOK
 #undef JSLP_CKS_RAISE_FLAG
 #undef JSLP_CKS_RAISE_REC
