@@ -1179,6 +1179,10 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
             if (geometry != 1 || !lean || e->n_opt > 0) return fail(JSLP_ERR_UNSUPPORTED, "development build: headline lean geometry only");
             le = check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2, 8, false, true, false, true>, dim3(rc.G), dim3(1024), args, 0, s)
                               : hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2, 8, false, true, false, false>, dim3(rc.G), dim3(1024), args, 0, s);
+#elif defined(JSLP_DEV_TALL_ONLY)  /* development builds: only the tall lean instances <512, 4, 16> (register budget work; -DJSLP_DEV_TALL_ONLY=2: the OPT ones); never shipped */
+            if (geometry != 3 || !lean || (e->n_opt > 0) != (JSLP_DEV_TALL_ONLY == 2) || unr) return fail(JSLP_ERR_UNSUPPORTED, "development build: tall lean geometry only");
+            le = check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 4, 16, false, true, JSLP_DEV_TALL_ONLY == 2, true>, dim3(rc.G), dim3(512), args, 0, s)
+                              : hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 4, 16, false, true, JSLP_DEV_TALL_ONLY == 2, false>, dim3(rc.G), dim3(512), args, 0, s);
 #elif defined(JSLP_DEV_XL_ONLY)  /* development builds: only the XCD-local instances are compiled (40 s instead of 2.5 min); never shipped */
             if (geometry != 6) return fail(JSLP_ERR_UNSUPPORTED, "development build: XCD-local geometry only");
             le = check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<512, 2, 32, false, true, false, true, true>, dim3(JSLP_XL_SPREAD * rc.G), dim3(512), args, 0, s)

@@ -404,7 +404,10 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         double cand_[CPT]; /* my columns of the row that can win (the compare chain: see JSLP_OPAQUE_SGPR) */                     \
         _Pragma("unroll") for (int j = 0; j < CPT; j++) cand_[j] = 0.0;                                                           \
         _Pragma("unroll") for (int i = 0; i < ROWS; i++)                                                                          \
-            if (i == JSLP_OPAQUE_SGPR(ipub_)) { _Pragma("unroll") for (int j = 0; j < CPT; j++) cand_[j] = a[i][j]; }             \
+            if (i == JSLP_OPAQUE_SGPR(ipub_)) { /* (each copy behind an opaque barrier: as plain selects the optimizer folds the chain into ONE   \
+                dynamically indexed read of a[][] -- the whole register array went to scratch in the tall geometry, 600 B per lane, 23 k pivots/s) */ \
+                _Pragma("unroll") for (int j = 0; j < CPT; j++) { double t_ = a[i][j]; asm volatile("" : "+v"(t_)); cand_[j] = t_; }               \
+            }                                                                                                                     \
         double quotc_ = 0.0, nv0c_ = 0.0;                                                                                         \
         if (NPUB) {                                                                                                               \
             /* round 6: the row leaves NORMALISED (simplex.ts:352-364): should it win, quot is its entry of the entering column --  \
@@ -484,12 +487,6 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         } else {                                                                                                                  \
             flag_ = AG_LOAD(f.rowflagc[par] + wv * JSLP_F_MAXG + bw);                                                             \
         }                                                                                                                         \
-        if (colok) {                                                                                                              \
-            _Pragma("unroll") for (int j = 0; j < CPT; j += 2) {                                                                  \
-                if (c0 + j >= ld) continue;                                                                                       \
-                rowv_[j >> 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + (j >> 1) * PAIR_STEP, 0, 16);           \
-            }                                                                                                                     \
-        }                                                                                                                         \
     } while (0)
 #define JSLP_CKS_FETCH_ROW()                                                                                                      \
     do {                                                                                                                          \
@@ -497,17 +494,18 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         unsigned spins_ = 0;                                                                                                      \
         const u64_t tmix_ = JSLP_CK_TAGMIX(tag);                                                                                  \
         u64_t flag_ = 0;                                                                                                          \
-        v4u_t rec0_, rec1_, rowv_[CPT / 2];                                                                                       \
+        v4u_t rec0_, rec1_;                                                                                                       \
         rec0_.x = rec0_.y = rec0_.z = rec0_.w = 0u; rec1_ = rec0_;                                                                \
-        _Pragma("unroll") for (int j = 0; j < CPT / 2; j++) rowv_[j] = rec0_;                                                     \
-        JSLP_CKS_ISSUE_LOOK();                                                                                                    \
         for (;;) {                                                                                                                \
+            JSLP_CKS_ISSUE_LOOK(); /* (ONE site: with a second copy of these loads at the loop's bottom the register allocator split the   \
+                row array's live ranges around the loop and the tall geometry spilled 600 B per lane -- 125 k -> 23 k pivots/s, r06) */    \
             u64_t qm_ = 0;                                                                                                        \
             u64_t ck_ = 0;                                                                                                        \
             if (colok) {                                                                                                          \
                 _Pragma("unroll") for (int j = 0; j < CPT; j += 2) {                                                              \
                     if (c0 + j >= ld) continue;                                                                                   \
-                    const v4u_t v_ = rowv_[j >> 1];                                                                               \
+                    const v4u_t v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rows, off_in + (j >> 1) * PAIR_STEP, 0, 16); /* (straight into  \
+                        pv: staged through an array of their own these loads cost the tall geometry, at its register limit, 600 B of scratch per lane) */ \
                     const u64_t lo_ = (u64_t)v_.x | ((u64_t)v_.y << 32), hi_ = (u64_t)v_.z | ((u64_t)v_.w << 32);                 \
                     pv[j] = __longlong_as_double((long long)lo_);                                                                 \
                     pv[j + 1] = __longlong_as_double((long long)hi_);                                                             \
@@ -530,7 +528,6 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
             if ((spins_ & 63u) == 0 && AG_LOAD(f.abort_flag) != 0u) dead_ = true;                                                 \
             if (spins_ > F_SPIN) { if (lane == 0) AG_STORE(f.abort_flag, 1u); dead_ = true; }                                     \
             if (dead_) { if (lane == 0) atomicMax(&sm.okbad, efetch); break; }                                                    \
-            JSLP_CKS_ISSUE_LOOK();                                                                                                \
         }                                                                                                                         \
     } while (0)
 #ifdef JSLP_DEBUG_RESIDENT
@@ -578,6 +575,18 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
 // summary in the gather (section table, r06_a: pricing 3.2 k cycles in workgroup 0 against 2.36 k everywhere else).  The LDS maps are still
 // swapped where they were; the global stores follow in the NEXT iteration's update section (while the summaries cross the fabric) or behind
 // the loop, as fire-and-forget stores through pointers kept in LDS.  Same stores, same order, one pivot later.
+// (the tall OPT build commits in place, as round 5 did -- through the device copy of the context, in step N: see CM_AT_N)
+#define JSLP_PIPE_COMMIT_GLOBAL_NOW()                                                                                             \
+    do {                                                                                                                          \
+        const Ctx& g_ = *f.cdev;                                                                                                  \
+        g_.vibr[pr] = entering;                                                                                                   \
+        g_.vibc[pc] = leaving;                                                                                                    \
+        g_.rbv[entering] = pr;                                                                                                    \
+        g_.rbv[leaving] = -1;                                                                                                     \
+        g_.cbv[entering] = -1;                                                                                                    \
+        g_.cbv[leaving] = pc;                                                                                                     \
+        if (R.trace_n < g_.trace_cap) g_.trace[R.trace_n] = make_int2(pr, pc);                                                    \
+    } while (0)
 #define JSLP_PIPE_SWAP_LDS_MAPS()                                                                                                 \
     do {                                                                                                                          \
         if (lpend && tid == THREADS - 64) {                                                                                       \
@@ -588,16 +597,23 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         }                                                                                                                         \
         lpend = false;                                                                                                            \
     } while (0)
+__device__ __forceinline__ void* jslp_uniform_ptr(const void* p) {  // the same pointer, as a wave-uniform (scalar) value
+    const unsigned long long b = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
+}
 typedef __attribute__((address_space(1))) int32_t jslp_gi32_t;  // (a pointer into GLOBAL memory, as opposed to a generic one)
 #define JSLP_PIPE_COMMIT_GLOBAL()                                                                                                 \
     do {                                                                                                                          \
         if (cpend && tid == THREADS - 64 && b == 0) {                                                                             \
             const int ent_ = sm.cm_ent, leav_ = sm.cm_leav; /* (pointers from LDS: nothing here waits for memory; GLOBAL stores, not flat \
                 ones -- behind a flat access the compiler waits vmcnt(0) wherever it waits at all, which would undo the look-ahead poll) */ \
-            jslp_gi32_t* const vibr_ = (jslp_gi32_t*)sm.gp_vibr;                                                                  \
-            jslp_gi32_t* const vibc_ = (jslp_gi32_t*)sm.gp_vibc;                                                                  \
-            jslp_gi32_t* const rbv_ = (jslp_gi32_t*)sm.gp_rbv;                                                                    \
-            jslp_gi32_t* const cbv_ = (jslp_gi32_t*)sm.gp_cbv;                                                                    \
+            /* (the base pointers as SCALARS -- readfirstlane of what LDS returned -- so that a store is `global_store v_offset, v_data, s[base]`:   \
+                as seven 64-bit vector addresses the commit cost the tall OPT build, at its register limit, 550 B of scratch per lane) */ \
+            jslp_gi32_t* const vibr_ = (jslp_gi32_t*)jslp_uniform_ptr(sm.gp_vibr);                                               \
+            jslp_gi32_t* const vibc_ = (jslp_gi32_t*)jslp_uniform_ptr(sm.gp_vibc);                                               \
+            jslp_gi32_t* const rbv_ = (jslp_gi32_t*)jslp_uniform_ptr(sm.gp_rbv);                                                 \
+            jslp_gi32_t* const cbv_ = (jslp_gi32_t*)jslp_uniform_ptr(sm.gp_cbv);                                                 \
             vibr_[pr_p] = ent_;                                                                                                   \
             vibc_[pc_p] = leav_;                                                                                                  \
             rbv_[ent_] = pr_p;                                                                                                    \
@@ -605,7 +621,7 @@ typedef __attribute__((address_space(1))) int32_t jslp_gi32_t;  // (a pointer in
             cbv_[ent_] = -1;                                                                                                      \
             cbv_[leav_] = pc_p;                                                                                                   \
             if (R.trace_n - 1 < sm.gp_trace_cap) {                                                                                \
-                jslp_gi32_t* const tr_ = (jslp_gi32_t*)sm.gp_trace + 2 * (R.trace_n - 1);                                         \
+                jslp_gi32_t* const tr_ = (jslp_gi32_t*)jslp_uniform_ptr(sm.gp_trace) + 2 * (R.trace_n - 1);                       \
                 tr_[0] = pr_p; tr_[1] = pc_p;                                                                                     \
             }                                                                                                                     \
         }                                                                                                                         \
@@ -634,7 +650,9 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     // round 6 -- NPUB: the candidate row is published NORMALISED (JSLP_PUBLISH_ROW_PLAIN) and quot / the cost row's new entry of the entering column come
     // with the row's record: between the row fetch and the next pricing no division and no barrier are left (the update pass that publishes
     // is JSLP_XL_UPDATE_PASS + JSLP_PUBLISH_ROW_PLAIN: the 2- / 4-column geometries; optional objectives need the raw row for their tiny-entry rule)
-    constexpr bool NPUB = CKS && !OPT && !XL && CPT <= 4 && JSLP_PIPE_NORM_PUB != 0;
+    // (ROWS <= 8: the tall geometry <512, 4, 16> sits at its register limit -- with the record's loads and the normalisation's temporaries it spilled
+    //  600 B per lane and ran 4001 x 2001 at 23 k pivots/s instead of 125 k; it keeps the raw row and round 4's 8-byte flag word)
+    constexpr bool NPUB = CKS && !OPT && !XL && CPT <= 4 && ROWS <= 8 && JSLP_PIPE_NORM_PUB != 0;
     constexpr bool QDIRECT = TAGGED || NPUB;  // quot comes with the fetch: no barrier behind it
     // the ratio test's transposition (entry i of the entering column from the ONE lane that holds it to lane i) through LDS: as `x = lane
     // == i ? readlane(a[i][j]) : x` the compiler precomputes the 64-bit lane masks, spills them and pays two reloads, two moves and two
@@ -656,6 +674,9 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
     const int SLOT = PERM ? THREADS * CPT * 8 + JSLP_PUB_SKEW : f.c.ld * 8;
     constexpr int PAIR_STEP = PERM ? THREADS * 16 : 16;           // bytes from a lane's pair j to its pair j + 2
     const int lane_off = PERM ? tid * 16 : tid * CPT * 8;          // ... and where its first pair sits in the slot
+    // the tall OPT build, at its register limit, issues the pending pivot's global commit where round 5 committed (step N: next to the row update's
+    // temporaries the block cost it 550 B of scratch per lane); everybody else in the update section, off the critical path
+    constexpr bool CM_AT_N = OPT && ROWS > 8;
     constexpr int POLLWV = 1;  // the ONE polling wave (not wave 0: it carries the column-0 work; not the last: the commit): lane l looks at workgroups l, l + 64, ...
     constexpr int HAWV = POLLWV;  // the wave whose retry path looks at the host's abort word (JSLP_HOST_ABORT_IN_SPIN)
     static_assert(THREADS / 64 > POLLWV, "the polling wave exists");
@@ -829,6 +850,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         }
         __syncthreads();
         const int pubrow = sm.pubrow;
+        if (!CM_AT_N) JSLP_PIPE_COMMIT_GLOBAL();  // (the pending pivot's global maps + trace, while the summaries cross the fabric)
         RT_STAMP(0);  // summary stored (the claiming wave stored it in front of the barrier)
         const double pub_k0 = k0;
         const int pub_pc = pc;
@@ -897,7 +919,6 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             }
         }
         }
-        JSLP_PIPE_COMMIT_GLOBAL();  // (the pending pivot's global maps + trace: behind my row stores, while the summaries cross the fabric)
         pend = false;
         RT_STAMP(1);  // update + publication issued
         RT_MARK(2);
@@ -1167,7 +1188,10 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc];
             sm.lvibr[pr] = entering;
             sm.lvibc[pc] = leaving;
-            if (b == 0) { sm.cm_ent = entering; sm.cm_leav = leaving; }  // (the global maps and the trace follow one iteration later: JSLP_PIPE_COMMIT_GLOBAL)
+            if (b == 0) {
+                if (CM_AT_N) JSLP_PIPE_COMMIT_GLOBAL_NOW();
+                else { sm.cm_ent = entering; sm.cm_leav = leaving; }  // (the global maps and the trace follow one iteration later: JSLP_PIPE_COMMIT_GLOBAL)
+            }
         }
         lpend = QDIRECT;
         if (UNR && has_pc) {
@@ -1179,7 +1203,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         R.it2 += 1;
         R.epoch = epoch + 1;
         pend = true; pr_p = pr; pc_p = pc; par_p = par; quot_p = quot;
-        cpend = true;
+        cpend = !CM_AT_N;
         RT_MARK(5);
     }
     JSLP_PIPE_SWAP_LDS_MAPS();  // (an exit in front of the pricing)
@@ -1249,6 +1273,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
     const int SLOT = PERM ? THREADS * CPT * 8 + JSLP_PUB_SKEW : f.c.ld * 8;
     constexpr int PAIR_STEP = PERM ? THREADS * 16 : 16;           // bytes from a lane's pair j to its pair j + 2
     const int lane_off = PERM ? tid * 16 : tid * CPT * 8;          // ... and where its first pair sits in the slot
+    constexpr bool CM_AT_N = OPT && ROWS > 8;  // (see phase 2)
     constexpr int POLLWV = 1;  // the one polling wave (wave 0 folds the next summary out of column 0; the last wave commits)
     const int ld = c.ld, W = c.W;
     const double precision = c.precision;
@@ -1327,6 +1352,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         }
         __syncthreads();
         const int pubrow = sm.pubrow;
+        if (!CM_AT_N) JSLP_PIPE_COMMIT_GLOBAL();  // (the pending pivot's global maps + trace, while the summaries cross the fabric)
         RT_MARK(0);
         // ---- U + P: the pending pivot's row update, the candidate row published from inside the pass ----------------------------
         bool swept = true;
@@ -1388,7 +1414,6 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             }
         }
         }
-        JSLP_PIPE_COMMIT_GLOBAL();  // (the pending pivot's global maps + trace: behind my row stores, while the summaries cross the fabric)
         pend = false;
         RT_MARK(2);
         // ---- C: gather ----------------------------------------------------------------------------------------------------
@@ -1629,7 +1654,10 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             const int leaving = sm.lvibr[pr], entering = sm.lvibc[pc];
             sm.lvibr[pr] = entering;
             sm.lvibc[pc] = leaving;
-            if (b == 0) { sm.cm_ent = entering; sm.cm_leav = leaving; }  // (the global maps and the trace follow one iteration later: JSLP_PIPE_COMMIT_GLOBAL)
+            if (b == 0) {
+                if (CM_AT_N) JSLP_PIPE_COMMIT_GLOBAL_NOW();
+                else { sm.cm_ent = entering; sm.cm_leav = leaving; }  // (the global maps and the trace follow one iteration later: JSLP_PIPE_COMMIT_GLOBAL)
+            }
         }
         if (UNR && has_pc) {
 #pragma unroll
@@ -1640,7 +1668,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         R.it1 += 1;
         R.epoch = epoch + 1;
         pend = true; pr_p = pr; pc_p = pc; par_p = par;
-        cpend = true;
+        cpend = !CM_AT_N;
         RT_MARK(5);
     }
     JSLP_PIPE_COMMIT_GLOBAL();  // (a basis change whose global half is still pending)
@@ -1679,3 +1707,4 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #undef JSLP_RT_RETRY
 #undef JSLP_PIPE_COMMIT_GLOBAL
 #undef JSLP_PIPE_SWAP_LDS_MAPS
+#undef JSLP_PIPE_COMMIT_GLOBAL_NOW
