@@ -785,6 +785,30 @@ def relaxation_legs(ctx, args, reps=16):
         out["pool_virtual4"]["compact"] = {"value": len(mine) / el4w, "unit": "LP relaxations/s", "per_call_us": [round(1e6 * x) for x in per4w],
                                            "vs_single_engine_compact": (len(mine) / el4w) / (len(mine) / el_w)}
         pool.close()
+        #  ... and the same in-process pool over the REAL devices when this process sees more than one (the driver's 8-GPU node; the
+        # gpurun box has one): the primary's saved root fanned out with hipMemcpyPeerAsync, the fixed batch split over the members -- strong scaling
+        # inside one process, no collective.  Never run on hardware by the builder: wrapped so that a failure costs this leg, not the line.
+        try:
+            import torch
+            ndev = min(torch.cuda.device_count(), 8)
+            if ndev >= 2:
+                devs = [device] + [d for d in range(ndev) if d != device]
+                poolN = DevicePool(t, devs)
+                poolN.set_watched_variables(ints)
+                fnpn = lambda: poolN.applyCutsBatchWatched(None, check_cycles=True, packed=packed, copy=False)
+                (rN, rowsN, valsN), elN, perN = timed_calls(fnpn, 5, 10)
+                for i in range(len(mine)):
+                    if (rN[i].height != res_w[i].height or rN[i].feasible != res_w[i].feasible or not np.array_equal(rowsN[i], rows_w_keep[i])
+                            or not np.array_equal(valsN[i].view(np.int64), vals_w_keep[i].view(np.int64))):
+                        raise WrongAnswer("device pool over %d devices: node %d differs from the single engine's" % (ndev, i))
+                out["pool_devices"] = {"value": len(mine) / elN, "unit": "LP relaxations/s", "members": poolN.size, "devices": devs, "scaling": "strong",
+                                       "per_call_us": [round(1e6 * x) for x in perN], "vs_single_engine_compact": (len(mine) / elN) / (len(mine) / el_w),
+                                       "note": "jslp_pool_relax_batch_watched_pinned over the visible devices (one engine + host thread + stream each, root fan-out by peer copy)"}
+                poolN.close()
+        except WrongAnswer:
+            raise
+        except Exception as e:
+            out["pool_devices"] = {"value": None, "error": repr(e)[:300]}
     t.close()
     # (iii) strong scaling: one real branch-and-bound tree, speculative batches of 8 x world nodes sharded over the ranks
     group = ctx["group"]

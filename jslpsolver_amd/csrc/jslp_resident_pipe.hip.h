@@ -416,7 +416,12 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
                HERE, once, while the summaries cross the fabric; quot itself and the cost row's new entry of the column            \
                (-k0 / quot, simplex.ts:386: every workgroup prices with the same cost row) travel in the row record */             \
             quotc_ = sm.colb[par][ipub_];                                                                                         \
-            nv0c_ = -pub_k0 / quotc_;                                                                                                 \
+            /* (the two divisions only ONE lane of the workgroup needs -- 1 / quot for the entering column's own cell, -k0 / quot for the    \
+               reader lane that holds that column, which reads THIS wave's record -- run in the one wave that holds the column, behind a    \
+               uniform branch: as per-lane selects all sixteen lock-step waves paid for them) */                                   \
+            const bool holds_pc_ = __builtin_amdgcn_readfirstlane((int)(wv == ((pub_pc / CPT) >> 6))) != 0;                       \
+            double rq_ = 0.0;                                                                                                     \
+            if (holds_pc_) { rq_ = 1.0 / quotc_; nv0c_ = -pub_k0 / quotc_; }                                                      \
             _Pragma("unroll") for (int j = 0; j < CPT; j++) {                                                                     \
                 const int col_ = c0 + j;                                                                                          \
                 const double val_ = cand_[j];                                                                                     \
@@ -424,7 +429,7 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
                 if (col_ < W) {                                                                                                   \
                     const bool innz_ = nonzero16(val_);                                                                           \
                     v_ = innz_ ? val_ / quotc_ : 0.0;                                                                             \
-                    if (col_ == pub_pc) v_ = 1.0 / quotc_;                                                                            \
+                    if (col_ == pub_pc) v_ = rq_;                                                                                 \
                     if (innz_ && !nonzero16(v_) && v_ != 0.0) v_ = 0.0; /* (phase 2: some other row is always eliminated -- simplex.ts:381-383) */ \
                 }                                                                                                                 \
                 cand_[j] = v_;                                                                                                    \
@@ -821,7 +826,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0xB1, 0xf, 0xf, false));
             brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0x4E, 0xf, 0xf, false));
             brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0x141, 0xf, 0xf, false));
-            brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0x140, 0xf, 0xf, false));
+            if (ROWS > 8) brdeg = min(brdeg, __builtin_amdgcn_update_dpp(brdeg, brdeg, 0x140, 0xf, 0xf, false));  // (<= 8 rows: lanes 0..7 hold them, three exchanges fold them into lane 0)
             brdeg = ROWS > 16 ? min(__builtin_amdgcn_readlane(brdeg, 0), __builtin_amdgcn_readlane(brdeg, 16))
                               : __builtin_amdgcn_readlane(brdeg, 0);  // (ROWS <= 16: the candidates sit in the first 16-lane row; <= 32: in the first two)
             static_assert(ROWS <= 32, "the summary's DPP folds cover two 16-lane rows");
@@ -832,7 +837,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
             bk = ki_min(bk, ki_dpp<0xB1>(bk));
             bk = ki_min(bk, ki_dpp<0x4E>(bk));
             bk = ki_min(bk, ki_dpp<0x141>(bk));
-            bk = ki_min(bk, ki_dpp<0x140>(bk));
+            if (ROWS > 8) bk = ki_min(bk, ki_dpp<0x140>(bk));
             bk = ROWS > 16 ? ki_min(ki_readlane(bk, 0), ki_readlane(bk, 16)) : ki_readlane(bk, 0);
             if (lane == 0) {
                 const bool deg = brdeg != 0x7fffffff;
@@ -1335,7 +1340,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
             bk = ki_min(bk, ki_dpp<0xB1>(bk));
             bk = ki_min(bk, ki_dpp<0x4E>(bk));
             bk = ki_min(bk, ki_dpp<0x141>(bk));
-            bk = ki_min(bk, ki_dpp<0x140>(bk));
+            if (ROWS > 8) bk = ki_min(bk, ki_dpp<0x140>(bk));
             bk = ROWS > 16 ? ki_min(ki_readlane(bk, 0), ki_readlane(bk, 16)) : ki_readlane(bk, 0);
             if (lane == 0) {
                 const bool have = bk.k != KI_NONE_KEY;
