@@ -823,6 +823,10 @@ static bool xl_fits(const jslp_engine* e, int H) {
 // (an uploaded tableau need not follow the reference's contiguous numbering -- Model index reuse / removal, a direct C-API caller --
 //  so the largest index upload() saw in the two maps counts too: the lean kernels' LDS copy of the "unrestricted" flags is indexed with it)
 static int live_index_bound(const jslp_engine* e, int H) { return std::min<int>(e->n_idx, std::max<int>(e->W + H + 2, e->max_uploaded_idx + 1)); }
+#if defined(JSLP_SPLIT_TU)
+extern "C" __attribute__((visibility("hidden"))) int jslpx_resident_launch_1(const int* key, unsigned grid, const void* rc, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int jslpx_resident_launch_2(const int* key, unsigned grid, const void* rc, void* stream);
+#endif
 static int resident_geometry(const jslp_engine* e, int H) {
     if (e->no_resident || e->force_path == 2 || e->precision < 1e-15) return 0;  // (see k_pivot_fused for the precision condition)
     const int rpb = (H + JSLP_F_MAXG - 1) / JSLP_F_MAXG;
@@ -1175,7 +1179,15 @@ static int run_simplex(jslp_engine* e, int check_cycles) {
 #define JSLP_RES_LAUNCH_LEAN_ONLY(T, C, R)                                                                                          \
     do { if (lean) le = JSLP_RES_LAUNCH_LEAN(T, C, R); } while (0)
           resident_relaunch:
-#if defined(JSLP_DEV_HEADLINE_ONLY)  /* development builds: only the headline lean instances are compiled; never shipped */
+#if defined(JSLP_SPLIT_TU)  /* the product build: the instances live in jslp_tu_resident.hip (two parts, compiled side by side with this unit) */
+            {
+                static const int geo[7][3] = {{0, 0, 0}, {1024, 2, 8}, {512, 4, 8}, {512, 4, 16}, {512, 6, 12}, {512, 8, 8}, {512, 2, 32}};
+                const int key[8] = {geo[geometry][0], geo[geometry][1], geo[geometry][2], unr ? 1 : 0, lean ? 1 : 0, e->n_opt > 0 ? 1 : 0, check_cycles ? 1 : 0, geometry == 6 ? 1 : 0};
+                int r1 = jslpx_resident_launch_1(key, (unsigned)rc.G, &rc, s);
+                if (r1 == -1) r1 = jslpx_resident_launch_2(key, (unsigned)rc.G, &rc, s);
+                le = r1 == -1 ? hipErrorInvalidValue : (hipError_t)r1;  // (-1: no such instance -- what the switch below leaves `le` at)
+            }
+#elif defined(JSLP_DEV_HEADLINE_ONLY)  /* development builds: only the headline lean instances are compiled; never shipped */
             if (geometry != 1 || !lean || e->n_opt > 0) return fail(JSLP_ERR_UNSUPPORTED, "development build: headline lean geometry only");
             le = check_cycles ? hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2, 8, false, true, false, true>, dim3(rc.G), dim3(1024), args, 0, s)
                               : hipLaunchCooperativeKernel((const void*)k_simplex_resident<1024, 2, 8, false, true, false, false>, dim3(rc.G), dim3(1024), args, 0, s);
