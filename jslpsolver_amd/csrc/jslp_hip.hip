@@ -1924,6 +1924,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
                             const int32_t* var_index, const double* value, int check_cycles, jslp_simplex_result* out,
                             double* rhs, int32_t* var_index_by_row, int32_t out_stride, int pinned, int want_rhs,
                             int want_rows, int checkpoint = -1, int compact = 0) {
+    const auto t_enter = std::chrono::steady_clock::now();  // (JSLP_DEBUG_STALL)
     const bool dev_out = e && e->dev_states != nullptr;  // outcomes stay on the device (jslp_engine_relax_batch_device)
     if (e && !dev_out) e->dev_prev_valid = 0;
     if (!e || n_nodes < 0 || !cut_offsets || (!out && !dev_out)) return fail(JSLP_ERR_ARG, "relax_batch: null pointer");
@@ -2197,6 +2198,15 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
+        }
+        // JSLP_DEBUG_STALL=<ms> (diagnosis): a dependent batch normally takes ~70 us; say on stderr when one took longer than
+        // that many milliseconds and whether the time went in front of the poll (cut-list staging, the launch call) or in it (the GPU side)
+        static const double stall_ms = [] { const char* t = getenv("JSLP_DEBUG_STALL"); return t ? atof(t) : 0.0; }();
+        if (stall_ms > 0) {
+            const auto t_end = std::chrono::steady_clock::now();
+            const double host_ms = std::chrono::duration<double, std::milli>(t_begin - t_enter).count(), poll_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+            if (host_ms + poll_ms > stall_ms)
+                fprintf(stderr, "[jslp] stall: a %d-node polled batch took %.3f ms in front of the poll (staging + launch) and %.3f ms polling (%u spins)\n", (int)n_nodes, host_ms, poll_ms, spins);
         }
     }
     if (!arrived) {  // every other shape -- and a polled batch that did not show up in 5 s: let the runtime report the fault
