@@ -33,8 +33,12 @@
 //   * pricing moved to the top of the loop (the loop is entered with the tableau whole and leaves a pending update to its epilogue);
 //   * 6 workgroup barriers per pivot instead of 8 (cycle check off).
 //
-// (The lab notebook of these loops -- every variant measured and left out in rounds 3 and 4, with its numbers -- lives in DESIGN.md,
-//  "Appendix: experiments on the lean pipelined loops"; the switches it refers to are the JSLP_PIPE_* macros below.)
+// Round 6 (profiles/r06_headline_sections.md): the 2- / 4-column geometries with <= 8 rows per workgroup publish the candidate row already NORMALISED, with
+// quot and the cost row's new entry in a checksummed 32-byte record (NPUB: no division and no barrier between the row fetch and the next pricing); ONE wave polls
+// the summaries, four looks per lane; the pricing's reduction words are double-buffered by pivot parity; workgroup 0's global commit follows one iteration
+// later as fire-and-forget stores; 5 workgroup barriers per pivot.
+// (The lab notebook of these loops -- every variant measured and left out, with its numbers -- lives in profiles/r02_r04_measurement_log.md (rounds 3 and 4)
+//  and profiles/r06_headline_sections.md (round 6); the rejected variants' code is profiles/r06_rejected_switches.patch.)
 // ===================================================================================================================
 // -DJSLP_CHAOS_BUILD (tests / diagnosis only, never the shipped library): at every phase boundary of the pipelined loops one wave of
 // the workgroup -- a different one per pivot and boundary -- sleeps ~6 k cycles (JSLP_TEST_RESIDENT_LATE_WAVE0=2), and with =3 every
