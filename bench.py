@@ -747,7 +747,7 @@ def relaxation_legs(ctx, args, reps=16):
         by_call = {}
         for i in range(len(mine)):
             by_call.setdefault((rank + i * world) % len(calls), i)
-        fns_ = lambda: evaluate_nodes_sharded_watched(t, fixed, True, sgroup, packed_mine=packed_fixed)
+        fns_ = lambda: evaluate_nodes_sharded_watched(t, fixed, True, sgroup, packed_mine=packed_fixed, copy=False)  # (views of the pinned landing buffer: checked below, before any further exchange)
         for _ in range(3):  # (the first call creates the communicator: seconds)
             fns_()
         for k in XS:

@@ -220,8 +220,13 @@ static int node_cow() {  // queue kernel: copy-on-write slots (no restore betwee
 static int node_queue() {  // a batch in one launch of resident workgroups pulling nodes from a queue
     static int v = -1;
     if (v < 0) {
-        const char* t = getenv("JSLP_NODE_QUEUE");  // tuning knob: 0 = one launch per group, 2 = hand the nodes out most-cuts-first
-        v = t ? atoi(t) : 1;                        // (measured slower on the Monster_II batch: 2.73 M/s against 2.94 M/s in call order)
+        // tuning knob: 0 = one launch per group, 1 = the queue hands the nodes out in call order, 2 (default since round 6) = most cuts first.
+        // The cut count predicts a node's repair pivots, and 2416 nodes on 768 resident workgroups are 3.15 rounds: longest-first keeps the last
+        // workgroups to finish on the cheap nodes.  Round 2 measured it SLOWER (2.73 M/s against 2.94 M in call order: a node then cost ~3x what it
+        // costs now and the order array's extra trip per node showed); re-measured on round 6's kernels, same session, compact read-back,
+        // tools/wglds_timing.py: 4.94-5.06 M relaxations/s against 4.14-4.41 M in call order (+14 %); outcome digests identical (tools/queue_check.py)
+        const char* t = getenv("JSLP_NODE_QUEUE");
+        v = t ? atoi(t) : 2;
     }
     return v;
 }
@@ -2074,7 +2079,12 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         Snapshot sn = root_snapshot(e);
         e->last_path = "workgroup";
         e->node_queue_launches += 1;
-        const int32_t* order = node_queue() == 2 ? e->d_cut_order : (const int32_t*)nullptr;
+        // (an order only where it can matter: more nodes than resident workgroups -- a batch that starts all at once pays the order array's trip per node
+        //  for nothing: the four-member pool's 604-node shares lost 6 % to it; JSLP_NODE_QUEUE_ORDER_FULL=1 hands the FULL read-back out longest-first too; its bound is
+        //  the PCIe link and it measured 3.41-3.42 M against 3.52-3.54 M relaxations/s in call order: the heavy nodes' outcomes then leave in one burst)
+        static const int order_full = [] { const char* t = getenv("JSLP_NODE_QUEUE_ORDER_FULL"); return t ? atoi(t) : 0; }();
+        const bool pcie_bound = zc && !compact && (want_rhs || want_rows);
+        const int32_t* order = (node_queue() == 2 && n_nodes > group && (order_full || !pcie_bound)) ? e->d_cut_order : (const int32_t*)nullptr;
         if (e->s.n_opt > 0)  // optional objectives: the OPT build (eager restores)
             hipLaunchKernelGGL((k_node_queue<512, false, true>), dim3(group), dim3(512), lds, s, e->s, sn, cu, (int)n_nodes, order, e->d_queue, check_cycles,
                                cap, (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states, g_stride);

@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SETTINGS = [{}, {"JSLP_NODE_COW": "0"}, {"JSLP_SNAPSHOT_TRANSPOSE": "0"}, {"JSLP_NODE_COW": "0", "JSLP_SNAPSHOT_TRANSPOSE": "0"},
-            {"JSLP_NODE_QUEUE": "0"}, {"JSLP_NODE_QUEUE": "2"}, {"JSLP_ZERO_COPY": "0"}, {"JSLP_GROUP_MAX": "100"},
+            {"JSLP_NODE_QUEUE": "0"}, {"JSLP_NODE_QUEUE": "1"}, {"JSLP_NODE_QUEUE": "2"}, {"JSLP_ZERO_COPY": "0"}, {"JSLP_GROUP_MAX": "100"},
             {"JSLP_NODE_QUEUE": "0", "JSLP_NO_WGLDS": "1"}]
 
 

@@ -73,7 +73,7 @@ for s in $steps; do
            C=FETCH_SIZE; [ $c = write ] && C=WRITE_SIZE
            (cd /tmp && JSLP_NODE_COW=$cow timeout 600 rocprofv3 --pmc $C -d $GRAFT_REPO_ROOT/$out/pmc_relax_$c -o p -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py relax > $GRAFT_REPO_ROOT/$out/pmc_relax_$c.log 2>&1 < /dev/null); echo "pmc relax cow=$cow $c rc=$?"
          done; timeout 120 python tools/pmc_latest.py $out relax "gpurun_out/$tag (tools/gpu_round.sh pmcrelax, JSLP_NODE_COW=$cow)" < /dev/null | grep "bytes_per_unit\|traffic_over"; rm -rf $out/pmc_relax_fetch $out/pmc_relax_write; done ;;
-    qcheck) (for cfg in "JSLP_NODE_QUEUE=0 JSLP_SNAPSHOT_TRANSPOSE=0" "JSLP_NODE_COW=0" "JSLP_NODE_COW=1" "JSLP_NODE_COW=1 JSLP_SNAPSHOT_TRANSPOSE=0" "JSLP_NODE_QUEUE=2" "JSLP_ZERO_COPY=0" "JSLP_GROUP_MAX=100"; do echo "== $cfg"; env $cfg timeout 120 python tools/queue_check.py; done) > $out/queue_check.log 2>&1 < /dev/null; echo "qcheck rc=$?"; cat $out/queue_check.log ;;
+    qcheck) (for cfg in "JSLP_NODE_QUEUE=0 JSLP_SNAPSHOT_TRANSPOSE=0" "JSLP_NODE_COW=0" "JSLP_NODE_COW=1" "JSLP_NODE_COW=1 JSLP_SNAPSHOT_TRANSPOSE=0" "JSLP_NODE_QUEUE=1" "JSLP_NODE_QUEUE=2" "JSLP_ZERO_COPY=0" "JSLP_GROUP_MAX=100"; do echo "== $cfg"; env $cfg timeout 120 python tools/queue_check.py; done) > $out/queue_check.log 2>&1 < /dev/null; echo "qcheck rc=$?"; cat $out/queue_check.log ;;
     qprof) (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/qprof -o q -- python $GRAFT_REPO_ROOT/tools/wglds_timing.py rate > $GRAFT_REPO_ROOT/$out/qprof.log 2>&1 < /dev/null); echo "qprof rc=$?"; tail -2 $out/qprof.log
           timeout 60 python tools/rocpd_stats.py $(ls $out/qprof/*.db | head -1) 2>/dev/null | head -12 ;;
     batchtests) timeout 900 python -m pytest tests -m gpu -q -x -k "batch or pool or relax" > $out/batchtests.log 2>&1 < /dev/null; echo "batchtests rc=$?"; tail -5 $out/batchtests.log ;;
