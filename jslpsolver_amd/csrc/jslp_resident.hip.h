@@ -175,6 +175,7 @@ struct RSmem {
     int32_t cm_ent, cm_leav;  // lean pipelined loops, workgroup 0: the basis change whose GLOBAL commit is still pending (written and read by the one committing thread)
     // ... and what that thread needs to issue the commit as seven fire-and-forget stores (no trip to the device copy of the context in front of them)
     int32_t* gp_vibr; int32_t* gp_vibc; int32_t* gp_rbv; int32_t* gp_cbv; int2* gp_trace; long long gp_trace_cap;
+    int2* gp_hist;  // ... and workgroup 0's global copy of the cycle-check history (thread 0: one store per pivot, no trip through the device copy of the context)
 };
 
 // The leader's last FOUR waves gather every workgroup's summary of this epoch (all-gather with the data as the flag,
@@ -1058,7 +1059,7 @@ __global__ void __launch_bounds__(THREADS) k_simplex_resident(ResCtx f) {
     if (UNR)
         for (int v = tid; v < f.n_idx && v < JSLP_R_LUNR; v += (int)blockDim.x) sm.lunr[v] = c.unr[v];
     if (tid == 0) { reset_reductions(sm); sm.okbad = 0u; }
-    if (LEAN && tid == THREADS - 64) { sm.gp_vibr = c.vibr; sm.gp_vibc = c.vibc; sm.gp_rbv = c.rbv; sm.gp_cbv = c.cbv; sm.gp_trace = c.trace; sm.gp_trace_cap = c.trace_cap; }
+    if (LEAN && tid == THREADS - 64) { sm.gp_vibr = c.vibr; sm.gp_vibc = c.vibc; sm.gp_rbv = c.rbv; sm.gp_cbv = c.cbv; sm.gp_trace = c.trace; sm.gp_trace_cap = c.trace_cap; sm.gp_hist = c.hist; }
     __syncthreads();
     // pricing batch of my columns (simplex.ts:118-127): fixed for the whole solve
     int pb[CPT];

@@ -596,6 +596,13 @@ __device__ __forceinline__ int price_optional_regs(const double (&x)[CPT], const
         g_.cbv[leaving] = pc;                                                                                                     \
         if (R.trace_n < g_.trace_cap) g_.trace[R.trace_n] = make_int2(pr, pc);                                                    \
     } while (0)
+// (workgroup 0's global copy of the cycle-check history: thread 0's store through a pointer kept in LDS -- `f.cdev->hist[...]` was a dependent trip to memory in
+//  front of the store, in the one workgroup everybody waits for: the cycle check cost 0.53 us per pivot of which this was the larger part, round 6)
+#define JSLP_PIPE_HIST_GLOBAL(PAIR)                                                                                               \
+    do {                                                                                                                          \
+        jslp_gi32_t* const h_ = (jslp_gi32_t*)jslp_uniform_ptr(sm.gp_hist) + 2 * R.hist_n;                                        \
+        h_[0] = (PAIR).x; h_[1] = (PAIR).y;                                                                                       \
+    } while (0)
 #define JSLP_PIPE_SWAP_LDS_MAPS()                                                                                                 \
     do {                                                                                                                          \
         if (lpend && tid == THREADS - 64) {                                                                                       \
@@ -995,7 +1002,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 const int2 pair = make_int2(sm.lvibr[pr], sm.lvibc[pc]);
                 if (R.hist_n < JSLP_PIPE_LHIST) sm.lhist[R.hist_n] = pair;
                 if (f.hist_all) f.hist_all[(size_t)b * JSLP_PIPE_GHIST + R.hist_n] = pair;  // my own copy of the whole history
-                if (b == 0) f.cdev->hist[R.hist_n] = pair;  // the host's cycle message; the general kernel's history should this one outgrow its room
+                if (b == 0) JSLP_PIPE_HIST_GLOBAL(pair);  // the host's cycle message; the general kernel's history should this one outgrow its room
                 sm.cyc_need = sm.cyc_filter_on ? cyc_pair_seen(sm, pair) : 1;
             }
             __syncthreads();
@@ -1575,7 +1582,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 const int2 pair = make_int2(sm.lvibr[pr], sm.lvibc[pc]);
                 if (R.hist_n < JSLP_PIPE_LHIST) sm.lhist[R.hist_n] = pair;
                 if (f.hist_all) f.hist_all[(size_t)b * JSLP_PIPE_GHIST + R.hist_n] = pair;  // my own copy of the whole history
-                if (b == 0) f.cdev->hist[R.hist_n] = pair;
+                if (b == 0) JSLP_PIPE_HIST_GLOBAL(pair);
                 sm.cyc_need = sm.cyc_filter_on ? cyc_pair_seen(sm, pair) : 1;
             }
             __syncthreads();
@@ -1716,4 +1723,5 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
 #undef JSLP_RT_RETRY
 #undef JSLP_PIPE_COMMIT_GLOBAL
 #undef JSLP_PIPE_SWAP_LDS_MAPS
+#undef JSLP_PIPE_HIST_GLOBAL
 #undef JSLP_PIPE_COMMIT_GLOBAL_NOW
