@@ -390,10 +390,17 @@ def main():
             if path_used == "resident":
                 # register-resident: the HBM roofline is not the bound (see resident_latency_floor); the fraction on algorithmic
                 # bytes stays as a figure of merit against a streaming implementation, the real HBM use comes from the PMC passes
+                # round 6 (VERDICT r05, (d) caveat): the TOP-LEVEL figures are SURVEY.md 8(d)'s -- algorithmic bytes per pivot / measured kernel time
+                # per pivot against the HBM peak -- as the contract of this line says; the fraction exceeds 1 because this kernel does the work without
+                # streaming the tableau (its real HBM use is `traffic`, from the PMC passes).  The on-chip latency floor it is priced against -- what
+                # actually bounds it -- is the `latency_floor` sub-object (round 5's top level).
                 fl = resident_latency_floor(H, W)
-                roofline = {"bound": "on-chip sync latency", "kernel": kernel_name, "achieved": rate, "peak": 1e6 / fl["floor_us"],
-                            "unit": "pivots/s (one kernel, one tableau)", "frac": fl["floor_us"] / (avg_s * 1e6) if launches else None,
-                            "floor_model": fl, "avg_unit_us": avg_s * 1e6}
+                roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK, "avg_unit_us": avg_s * 1e6,
+                            "frac_note": "> 1: the register-resident kernel keeps the tableau in the chip's vector registers for the whole solve -- the 16*H*W algorithmic "
+                                         "bytes of a pivot never cross HBM (traffic = what does); see latency_floor for what bounds it",
+                            "latency_floor": {"bound": "on-chip sync latency", "achieved": rate, "peak": 1e6 / fl["floor_us"], "unit": "pivots/s (one kernel, one tableau)",
+                                              "frac": fl["floor_us"] / (avg_s * 1e6) if launches else None, "floor_model": fl}}
             else:
                 roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK, "avg_unit_us": avg_s * 1e6}
