@@ -755,12 +755,16 @@ def relaxation_legs(ctx, args, reps=16):
         for i in range(len(mine)):
             by_call.setdefault((rank + i * world) % len(calls), i)
         fns_ = lambda: evaluate_nodes_sharded_watched(t, fixed, True, sgroup, packed_mine=packed_fixed, copy=False)  # (views of the pinned landing buffer: checked below, before any further exchange)
-        for _ in range(3):  # (the first call creates the communicator: seconds)
+        for _ in range(25):  # (the first call creates the communicator: seconds; and, as for the legs above, the few-ms stall ~3-15 ms into a new burst of work)
             fns_()
         for k in XS:
             XS[k] = 0 * XS[k]
-        outs, el_s, per_s = timed_calls(fns_, 0, 10)
+        outs, el_s, per_s = timed_calls(fns_, 0, 20)
         xs = dict(XS)
+        # (the rate is taken over the MEDIAN call: one call in a few hundred stalls for milliseconds inside the runtime -- 10.4 ms among ten 545 us calls in one of the
+        #  round's runs, profiles/r06_tree_latency.md -- and a mean over ten or twenty calls then reports the stall, not the path; mean, max and a health note beside it)
+        srt_s = sorted(per_s)
+        med_s = max_over_ranks(srt_s[len(srt_s) // 2])
         for k in range(len(fixed)):
             i = by_call[k % len(calls)]
             r_k = outs.result(k)
@@ -768,7 +772,9 @@ def relaxation_legs(ctx, args, reps=16):
                     or not np.array_equal(outs.watched_values(k).view(np.int64), vals_w_keep[i].view(np.int64))):
                 raise WrongAnswer("sharded batch: node %d differs from this rank's verified outcome of the same cut list (rank %d)" % (k, rank))
         calls_x = max(xs["calls"], 1)
-        out["sharded_batch"] = {"value": len(fixed) / el_s, "unit": "LP relaxations/s", "scaling": "strong", "nodes": len(fixed), "seconds": el_s,
+        out["sharded_batch"] = {"value": len(fixed) / med_s, "unit": "LP relaxations/s", "scaling": "strong", "nodes": len(fixed), "seconds": med_s,
+                                "value_over_mean_call": len(fixed) / el_s, "mean_call_seconds": el_s, "max_call_us": round(1e6 * srt_s[-1]),
+                                "health": "ok" if srt_s[-1] < 10 * med_s else "OUTLIER: the slowest of %d calls took %.2f ms against a median of %.3f ms (rank 0)" % (len(per_s), 1e3 * srt_s[-1], 1e3 * med_s),
                                 "exchange_ms": 1e3 * xs["seconds"] / calls_x, "bytes_per_rank": xs["bytes"] / calls_x,
                                 "per_call_us": [round(1e6 * x) for x in per_s], "ranks": world,
                                 "workload": "config 4: ONE fixed batch of %d Monster_II nodes (151 cut lists x%d) split round-robin over %d rank(s): "

@@ -2220,8 +2220,16 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
         }
     }
     if (!arrived) {  // every other shape -- and a polled batch that did not show up in 5 s: let the runtime report the fault
+        const auto t_sync = std::chrono::steady_clock::now();
         HIPC(hipStreamSynchronize(e->copy_stream));
         HIPC(hipStreamSynchronize(s));
+        static const double stall_ms2 = [] { const char* t = getenv("JSLP_DEBUG_STALL"); return t ? atof(t) : 0.0; }();
+        if (stall_ms2 > 0) {  // (the same diagnostic for the synchronising shapes: enqueue time vs time inside the two stream synchronisations)
+            const auto t_end = std::chrono::steady_clock::now();
+            const double host_ms = std::chrono::duration<double, std::milli>(t_sync - t_enter).count(), sync_ms = std::chrono::duration<double, std::milli>(t_end - t_sync).count();
+            if (host_ms + sync_ms > stall_ms2)
+                fprintf(stderr, "[jslp] stall: a %d-node batch took %.3f ms to enqueue (staging + launches) and %.3f ms in hipStreamSynchronize\n", (int)n_nodes, host_ms, sync_ms);
+        }
     }
     if (wg && e->timing) {
         float ms = 0;
