@@ -2052,10 +2052,6 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     }
     rc = ensure_out(e, (size_t)n_nodes);  // laid out for ALL nodes: [states | rhs | rows]
     if (rc) return rc;
-    if (!e->copy_stream) {  // created on first use: a stream costs a Solve of a tiny model more than its pivots do
-        HIPC(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-        HIPC(hipEventCreateWithFlags(&e->ev_group, hipEventDisableTiming));
-    }
     if (e->timing) HIPC(hipEventRecord(e->ev_begin, s));
     // where the kernels leave the outcomes: the device staging buffer (copied group by group on the copy stream) or, zero-copy,
     // the pinned host buffer itself - the stores cross PCIe while the other workgroups compute
@@ -2073,6 +2069,12 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
             (void)hipGetLastError();
             zc = false;
         }
+    }
+    if (!zc && !dev_out && !e->copy_stream) {
+        // created on first use, and only by the calls that copy their outcomes back (JSLP_ZERO_COPY=0, no mapped pinned memory): a stream costs a Solve of a
+        // tiny model more than its pivots do
+        HIPC(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        HIPC(hipEventCreateWithFlags(&e->ev_group, hipEventDisableTiming));
     }
     if (const size_t lds = wglds_smem(e); wg && lds && node_queue() && n_nodes > group && checkpoint < 0 && e->has_save && e->slot0_synced &&
         group <= e->slots_synced && !e->timing && e->one_launch_nodes && wg_batch_threads() == 512) {
@@ -2221,7 +2223,7 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
     }
     if (!arrived) {  // every other shape -- and a polled batch that did not show up in 5 s: let the runtime report the fault
         const auto t_sync = std::chrono::steady_clock::now();
-        HIPC(hipStreamSynchronize(e->copy_stream));
+        if (e->copy_stream) HIPC(hipStreamSynchronize(e->copy_stream));
         HIPC(hipStreamSynchronize(s));
         static const double stall_ms2 = [] { const char* t = getenv("JSLP_DEBUG_STALL"); return t ? atof(t) : 0.0; }();
         if (stall_ms2 > 0) {  // (the same diagnostic for the synchronising shapes: enqueue time vs time inside the two stream synchronisations)
@@ -2747,9 +2749,19 @@ static int pool_relax(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets,
     double* g_rhs = reinterpret_cast<double*>(p->h_out + (size_t)n_nodes * sizeof(DevState));
     int32_t* g_rows = reinterpret_cast<int32_t*>(p->h_out + (size_t)n_nodes * (sizeof(DevState) + cap * 8));
     const int M = (int)p->members.size();
+    // JSLP_DEBUG_POOL=1 (diagnosis, tools/pool_handoff.py): per call, when every member's job started and ended relative to the call's entry -- what of a
+    // pool call is thread hand-off (the start delays, the join after the last end) and what is the members' own work
+    static const int dbg_pool = [] { const char* t = getenv("JSLP_DEBUG_POOL"); return t ? atoi(t) : 0; }();
+    const auto t_call = std::chrono::steady_clock::now();
+    static double dbg_t[2][64];
     auto job = [=](int mi) -> int {
         jslp_engine* m = p->members[mi];
         const int first = (int)((long long)n_nodes * mi / M), last = (int)((long long)n_nodes * (mi + 1) / M), cnt = last - first;
+        struct Stamp {
+            int on, mi; std::chrono::steady_clock::time_point t0;
+            Stamp(int on_, int mi_, std::chrono::steady_clock::time_point t) : on(on_), mi(mi_), t0(t) { if (on && mi < 64) dbg_t[0][mi] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+            ~Stamp() { if (on && mi < 64) dbg_t[1][mi] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+        } stamp(dbg_pool, mi, t_call);
         if (cnt <= 0) return JSLP_OK;
         std::vector<int32_t>& o = p->offs[mi];
         o.resize((size_t)cnt + 1);
@@ -2778,6 +2790,12 @@ static int pool_relax(jslp_pool* p, int32_t n_nodes, const int32_t* cut_offsets,
     for (int mi = 1; mi < M; mi++) p->workers[mi]->submit([job, mi] { return job(mi); });
     rc = job(0);
     rc = pool_join(p, rc);
+    if (dbg_pool) {
+        const double t_join = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
+        fprintf(stderr, "[jslp] pool call, %d nodes: joined at %.1f us; members (start -> end, us):", (int)n_nodes, t_join);
+        for (int mi = 0; mi < M && mi < 64; mi++) fprintf(stderr, " %.1f -> %.1f", dbg_t[0][mi], dbg_t[1][mi]);
+        fprintf(stderr, "\n");
+    }
     hipSetDevice(e->device);
     return rc;
 }
