@@ -34,6 +34,7 @@ struct FCand {       // per-workgroup ratio-test summary
 };
 #define JSLP_F_THREADS 1024
 #define JSLP_F_RG 8          // rows processed per group (kept in registers)
+#define JSLP_F_COLLECT 64    // rows whose candidate-column entries are collected in LDS between two barriers (a power of two, <= 64: one lane of wave 0 per row)
 #define JSLP_F_MAXG 256      // workgroups (= CUs)
 
 struct FusedCtx {
@@ -92,8 +93,8 @@ struct FSmem {
     Smem red;
     FCand wave[JSLP_F_THREADS / 64];
     FCand win;
-    double col[JSLP_F_RG];
-    double rhs[JSLP_F_RG];
+    double col[JSLP_F_COLLECT];  // the entering column's new entries / the new RHS of up to JSLP_F_COLLECT rows between two barriers (k_pivot_fused)
+    double rhs[JSLP_F_COLLECT];
     int neg;  // pricing with unrestricted variables: isReducedCostNegative of the winner
 };
 
@@ -503,49 +504,126 @@ __global__ void __launch_bounds__(JSLP_F_THREADS) k_pivot_fused(FusedCtx f, int 
     if (OPT && cn == 0) cn = price_optional<NT, UNR>(n0, c0, um, c, sm, f.oo[in_buf], true, pc, quot, p, &neg);
 
     // ---- stream my rows ---------------------------------------------------------------------------
-    FCand best = fcand_none();  // kept by lanes 0..7 of wave 0: lane i sees rows r_begin+i, +8, ... in order
-    for (int g0 = r_begin; g0 < r_end; g0 += JSLP_F_RG) {
+    // Round 6: (a) ROLLING prefetch -- as soon as row i of a step (a group of JSLP_F_RG rows x one tile) has been stored, the load of
+    // row i of the NEXT step goes out into the same registers: the loads of a step used to leave together only after the previous step's last store (and,
+    // behind the two barriers of the candidate collection, after those too), so every step began with one exposed memory latency; (b) the entering
+    // column's new entries are collected for up to JSLP_F_COLLECT rows between barriers (they were 8: two barriers per step) and lane j of wave 0 then
+    // looks at row j of that block -- the (q, r) / min-rdeg orders of the reduction are total, which lane sees which row does not matter.
+    FCand best = fcand_none();  // kept by wave 0: lane j sees rows r_begin + j, + JSLP_F_COLLECT, ...
+#ifndef JSLP_F_ROLL_MAXNT
+#define JSLP_F_ROLL_MAXNT 1
+#endif
+#ifndef JSLP_F_COLLECT_ROLL
+#define JSLP_F_COLLECT_ROLL JSLP_F_COLLECT
+#endif
+#ifndef JSLP_F_COLLECT_STEP
+#define JSLP_F_COLLECT_STEP JSLP_F_RG
+#endif
+    constexpr int CR = JSLP_F_COLLECT_ROLL, CS = JSLP_F_COLLECT_STEP;  // rows between two collection barriers, rolling / step-at-a-time loop
+    static_assert(CR <= JSLP_F_COLLECT && CS <= JSLP_F_COLLECT && (CR & (CR - 1)) == 0 && (CS & (CS - 1)) == 0 && CR >= JSLP_F_RG && CS >= JSLP_F_RG, "collection block");
+    if (NT <= JSLP_F_ROLL_MAXNT) {
+        const int n_steps = ((r_end - r_begin + JSLP_F_RG - 1) / JSLP_F_RG) * NT;
+        int g0 = r_begin, t_cur = 0;
+        for (int step = 0; step < n_steps; step++) {
+            const int tn = (t_cur + 1 == NT) ? 0 : t_cur + 1, gn = (t_cur + 1 == NT) ? g0 + JSLP_F_RG : g0;  // the next step
+            const bool more = step + 1 < n_steps;
+            const int ct = c0 + t_cur * JSLP_F_TW, ctn = c0 + tn * JSLP_F_TW;
+            const bool colok = ct < ld, colokn = ctn < ld;
+            // (NT is a template parameter but the tile of a step is not a compile-time constant any more: p / v0 / v1 / has_pc are picked by selects)
+            double2 pt = p[0]; bool v0t = v0[0], v1t = v1[0], hpt = has_pc[0];
+    #pragma unroll
+            for (int t = 1; t < NT; t++)
+                if (t_cur == t) { pt = p[t]; v0t = v0[t]; v1t = v1[t]; hpt = has_pc[t]; }
+    #pragma unroll
+            for (int i = 0; i < JSLP_F_RG; i++) {
+                const int r = g0 + i;
+                if (r < r_end) {
+                    double2 x = a[i];
+                    if (r == pr) {
+                        x = pt;
+                    } else if (nonzero16(k[i])) {
+                        if (v0t) x.x = eliminate(x.x, k[i], pt.x);
+                        if (v1t) x.y = eliminate(x.y, k[i], pt.y);
+                        if (hpt) { const double nv = -k[i] / quot; if (pc == ct) x.x = nv; else x.y = nv; }
+                    }
+                    if (colok) st_stream(Mout + (long long)r * ld + ct, x, f.nt);
+                    if (cn != 0) {
+                        const int slot = (r - r_begin) & (CR - 1);
+                        if (cn == ct) sm.col[slot] = x.x; else if (cn == ct + 1) sm.col[slot] = x.y;
+                        if (t_cur == 0 && tid == 0) sm.rhs[slot] = x.x;
+                    }
+                }
+                if (more) {  // row i of the next step: its registers are free now
+                    const int rn = gn + i;
+                    if (tn == 0) k[i] = rn < r_end ? pin[rn] : 0.0;
+                    a[i] = make_double2(0, 0);
+                    if (rn < r_end && colokn) a[i] = ld_stream(Min + (long long)rn * ld + ctn, f.nt);
+                }
+            }
+            // a block of CR rows is complete (or the last row is done): wave 0 looks at it
+            const int done_rows = min(r_end, g0 + JSLP_F_RG) - r_begin;
+            if (cn != 0 && t_cur == NT - 1 && ((done_rows & (CR - 1)) == 0 || !more)) {
+                __syncthreads();
+                const int blk0 = r_begin + ((done_rows - 1) & ~(CR - 1));
+                if (tid < CR && blk0 + tid < r_begin + done_rows) {
+                    const int r = blk0 + tid;
+                    const double colv = sm.col[tid];
+                    pout[r] = colv;
+                    if (r >= 1) fcand_consider(best, r, colv, sm.rhs[tid], precision, neg);
+                }
+                if (more) __syncthreads();
+            }
+            g0 = gn; t_cur = tn;
+        }
+    } else {
+        // two or more tiles per lane: a step's loads leave together, as before (rolling measured slower there: profiles/r06_streaming_rolling_prefetch.md)
+        for (int g0 = r_begin; g0 < r_end; g0 += JSLP_F_RG) {
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const int ct = c0 + t * JSLP_F_TW;
-            const bool colok = ct < ld;
-            if (g0 != r_begin || t != 0) {  // the first group's first tile was prefetched at the top
+            for (int t = 0; t < NT; t++) {
+                const int ct = c0 + t * JSLP_F_TW;
+                const bool colok = ct < ld;
+                if (g0 != r_begin || t != 0) {  // the first group's first tile was prefetched at the top
+#pragma unroll
+                    for (int i = 0; i < JSLP_F_RG; i++) {
+                        const int r = g0 + i;
+                        if (t == 0) k[i] = r < r_end ? pin[r] : 0.0;
+                        a[i] = make_double2(0, 0);
+                        if (r < r_end && colok) a[i] = ld_stream(Min + (long long)r * ld + ct, f.nt);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < JSLP_F_RG; i++) {
                     const int r = g0 + i;
-                    if (t == 0) k[i] = r < r_end ? pin[r] : 0.0;
-                    a[i] = make_double2(0, 0);
-                    if (r < r_end && colok) a[i] = ld_stream(Min + (long long)r * ld + ct, f.nt);
+                    if (r >= r_end) break;
+                    double2 x = a[i];
+                    if (r == pr) {
+                        x = p[t];
+                    } else if (nonzero16(k[i])) {
+                        if (v0[t]) x.x = eliminate(x.x, k[i], p[t].x);
+                        if (v1[t]) x.y = eliminate(x.y, k[i], p[t].y);
+                        if (has_pc[t]) { const double nv = -k[i] / quot; if (pc == ct) x.x = nv; else x.y = nv; }
+                    }
+                    if (colok) st_stream(Mout + (long long)r * ld + ct, x, f.nt);
+                    if (cn != 0) {
+                        const int slot = (r - r_begin) & (CS - 1);
+                        if (cn == ct) sm.col[slot] = x.x; else if (cn == ct + 1) sm.col[slot] = x.y;
+                        if (t == 0 && tid == 0) sm.rhs[slot] = x.x;
+                    }
                 }
             }
-#pragma unroll
-            for (int i = 0; i < JSLP_F_RG; i++) {
-                const int r = g0 + i;
-                if (r >= r_end) break;
-                double2 x = a[i];
-                if (r == pr) {
-                    x = p[t];
-                } else if (nonzero16(k[i])) {
-                    if (v0[t]) x.x = eliminate(x.x, k[i], p[t].x);
-                    if (v1[t]) x.y = eliminate(x.y, k[i], p[t].y);
-                    if (has_pc[t]) { const double nv = -k[i] / quot; if (pc == ct) x.x = nv; else x.y = nv; }
+            const int done_rows = min(r_end, g0 + JSLP_F_RG) - r_begin;
+            const bool more = g0 + JSLP_F_RG < r_end;
+            if (cn != 0 && ((done_rows & (CS - 1)) == 0 || !more)) {
+                __syncthreads();
+                const int blk0 = r_begin + ((done_rows - 1) & ~(CS - 1));
+                if (tid < CS && blk0 + tid < r_begin + done_rows) {
+                    const int r = blk0 + tid;
+                    const double colv = sm.col[tid];
+                    pout[r] = colv;
+                    if (r >= 1) fcand_consider(best, r, colv, sm.rhs[tid], precision, neg);
                 }
-                if (colok) st_stream(Mout + (long long)r * ld + ct, x, f.nt);
-                if (cn != 0) {
-                    if (cn == ct) sm.col[i] = x.x; else if (cn == ct + 1) sm.col[i] = x.y;
-                    if (t == 0 && tid == 0) sm.rhs[i] = x.x;
-                }
+                if (more) __syncthreads();
             }
-        }
-        if (cn != 0) {
-            __syncthreads();
-            if (tid < JSLP_F_RG && g0 + tid < r_end) {
-                const int r = g0 + tid;
-                const double colv = sm.col[tid];
-                pout[r] = colv;
-                if (r >= 1) fcand_consider(best, r, colv, sm.rhs[tid], precision, neg);
-            }
-            __syncthreads();
         }
     }
     if (cn != 0 && tid < 64) {
