@@ -239,7 +239,52 @@ def pmc_sq(key, kernel):
         return {"note": "no SQ-counter summary committed for %s" % key}
 
 
+def pool_devices_leg(device, ndev, reps):
+    """child process of the relaxation legs (N = 1, several devices visible): the fixed 151 x reps Monster_II batch through ONE engine on `device` (compact
+    read-back: the comparison base) and through jslp_pool_relax_batch_watched_pinned over devices [device, others...]; every node of the pool's last call is
+    compared with the single engine's outcome; prints one JSON object."""
+    import gzip
+    import numpy as np
+    from jslpsolver_amd import Model, _capi
+    from jslpsolver_amd.engine import DevicePool, Tableau
+    lib = _capi.load_hip()
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "fixtures", "Monster_II.json.gz"), "rt") as fh:
+        g = json.load(fh)
+    model = Model(g["model"])
+    m, vibr, vibc = model.build_tableau()
+    nodes = [c["cuts"] or [] for c in g["simplexCalls"][1:]] * reps
+    t = Tableau(m, vibr, vibc, model.unrestricted, precision=model.precision, row_capacity=m.shape[0] + 2 * len(model.integerVariables), device=device, lib=lib)
+    t.applyCuts([], check_cycles=True)
+    t.save()
+    ints = [int(v) for v in model.integer_index_array]
+    t.set_watched_variables(ints)
+    packed = t.pack_cut_lists(nodes)
+    r1, rows1, vals1 = t.applyCutsBatchWatched(None, check_cycles=True, packed=packed, copy=True)
+    devs = [device] + [d for d in range(ndev) if d != device]
+    pool = DevicePool(t, devs)
+    pool.set_watched_variables(ints)
+    fn = lambda: pool.applyCutsBatchWatched(None, check_cycles=True, packed=packed, copy=False)
+    for _ in range(8):
+        fn()
+    per = []
+    for _ in range(10):
+        t0 = time.perf_counter(); rN, rowsN, valsN = fn(); per.append(time.perf_counter() - t0)
+    for i in range(len(nodes)):
+        if (rN[i].height != r1[i].height or rN[i].feasible != r1[i].feasible or not np.array_equal(rowsN[i], rows1[i])
+                or not np.array_equal(np.asarray(valsN[i]).view(np.int64), np.asarray(vals1[i]).view(np.int64))):
+            raise WrongAnswer("device pool over %d devices: node %d differs from the single engine's" % (ndev, i))
+    el = sum(per) / len(per)
+    print(json.dumps({"value": len(nodes) / el, "unit": "LP relaxations/s", "members": pool.size, "devices": devs, "scaling": "strong",
+                      "per_call_us": [round(1e6 * x) for x in per], "outcomes_checked": "every node of the last call == the single engine's compact outcome",
+                      "note": "jslp_pool_relax_batch_watched_pinned over the visible devices (one engine + host thread + stream each, root fan-out by peer copy); "
+                              "run in a child process under a time limit"}))
+    pool.close()
+    t.close()
+
+
 def main():
+    if len(sys.argv) == 5 and sys.argv[1] == "--pool-devices-leg":  # (the relaxation legs' child process: see pool_devices_leg)
+        return pool_devices_leg(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -811,26 +856,21 @@ def relaxation_legs(ctx, args, reps=16):
         pool.close()
         #  ... and the same in-process pool over the REAL devices when this process sees more than one (the driver's 8-GPU node; the
         # gpurun box has one): the primary's saved root fanned out with hipMemcpyPeerAsync, the fixed batch split over the members -- strong scaling
-        # inside one process, no collective.  Never run on hardware by the builder: wrapped so that a failure costs this leg, not the line.
+        # inside one process, no collective.  Never run on hardware by the builder: it runs in a child process under a time limit (`--pool-devices-leg`),
+        # so that a fault or a hang in it costs this leg, not the line.
         try:
+            import subprocess
             import torch
             ndev = min(torch.cuda.device_count(), 8)
             if ndev >= 2:
-                devs = [device] + [d for d in range(ndev) if d != device]
-                poolN = DevicePool(t, devs)
-                poolN.set_watched_variables(ints)
-                fnpn = lambda: poolN.applyCutsBatchWatched(None, check_cycles=True, packed=packed, copy=False)
-                (rN, rowsN, valsN), elN, perN = timed_calls(fnpn, 5, 10)
-                for i in range(len(mine)):
-                    if (rN[i].height != res_w[i].height or rN[i].feasible != res_w[i].feasible or not np.array_equal(rowsN[i], rows_w_keep[i])
-                            or not np.array_equal(valsN[i].view(np.int64), vals_w_keep[i].view(np.int64))):
-                        raise WrongAnswer("device pool over %d devices: node %d differs from the single engine's" % (ndev, i))
-                out["pool_devices"] = {"value": len(mine) / elN, "unit": "LP relaxations/s", "members": poolN.size, "devices": devs, "scaling": "strong",
-                                       "per_call_us": [round(1e6 * x) for x in perN], "vs_single_engine_compact": (len(mine) / elN) / (len(mine) / el_w),
-                                       "note": "jslp_pool_relax_batch_watched_pinned over the visible devices (one engine + host thread + stream each, root fan-out by peer copy)"}
-                poolN.close()
-        except WrongAnswer:
-            raise
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--pool-devices-leg", str(device), str(ndev), str(reps)],
+                                       capture_output=True, text=True, timeout=240)
+                lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+                if child.returncode == 0 and lines:
+                    out["pool_devices"] = json.loads(lines[-1])
+                    out["pool_devices"]["vs_single_engine_compact"] = out["pool_devices"]["value"] / (len(mine) / el_w)
+                else:
+                    out["pool_devices"] = {"value": None, "error": ("rc %d: " % child.returncode) + (child.stderr or child.stdout)[-300:]}
         except Exception as e:
             out["pool_devices"] = {"value": None, "error": repr(e)[:300]}
     t.close()

@@ -92,3 +92,14 @@ def test_bench_multi_rank_code_path_on_one_gpu(hip_lib):
     assert line["relaxations"]["tree"]["scaling"] == "strong" and line["relaxations"]["tree"]["result"] == 20631
     assert line["cycle_check_on"]["pivot_digest"] == "1cda2607"
     assert "cpu_baseline" not in line
+
+
+@pytest.mark.gpu
+def test_bench_pool_devices_leg_runs_as_a_child_process():
+    """bench.py runs the real-devices pool leg in a child process under a time limit (never run on several GPUs by the builder): the child's entry
+    point, here over the one visible device (a pool of one member), prints one JSON object with every node checked against the single engine"""
+    import json, subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pool-devices-leg", "0", "1", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    leg = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert leg["value"] > 0 and leg["members"] == 1 and leg["devices"] == [0] and len(leg["per_call_us"]) == 10
