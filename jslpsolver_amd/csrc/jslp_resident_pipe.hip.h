@@ -95,6 +95,9 @@
         (CK) += (u64_t)(unsigned)(HI) * JSLP_CK_K32(2 * (j) + 2) + (u64_t)(unsigned)((HI) >> 32) * JSLP_CK_K32(2 * (j) + 3);       \
     } while (0)
 #define JSLP_CK_TAGMIX(tag) ((u64_t)(tag) * 0xD6E8FEB86659FD93ull)    // what separates this epoch's flag word from the one two epochs back in the same slot
+#ifndef JSLP_PIPE_POLL_MISSING_ONLY
+#define JSLP_PIPE_POLL_MISSING_ONLY 1  // the gather re-issues only the looks whose summary is still missing (0: all four looks of every lane, every time)
+#endif
 #ifndef JSLP_PIPE_S_VIA_LDS
 #define JSLP_PIPE_S_VIA_LDS 1
 #endif
@@ -942,8 +945,28 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
         if (poller) {
             unsigned spins = 0;
             v4u_t gq[JSLP_F_MAXG / 64];
+#if JSLP_PIPE_POLL_MISSING_ONLY
+            unsigned have = 0;  // bit q: my look q has its summary (a look beyond the grid holds a copy of my own workgroup's: it is there)
+#pragma unroll
+            for (int q = 0; q < JSLP_F_MAXG / 64; q++) {
+                gq[q] = g;
+                if (lane + 64 * q >= f.G) have |= 1u << q;
+            }
+#endif
             for (;;) {
                 bool ok = true;
+#if JSLP_PIPE_POLL_MISSING_ONLY
+                // Round 6: only the looks whose summary has NOT arrived go out again.  Most summaries are there at the first look, and a look is an sc1 load
+                // that memory serves: 251 workgroups x 251 granules per round trip otherwise -- traffic that delays the very stores it waits for
+                // (184.7 k -> 193.3 k pivots/s on config 3a; two staggered sets of looks, i.e. MORE traffic, measured 158 k: profiles/r06_poll_traffic.md)
+#pragma unroll
+                for (int q = 0; q < JSLP_F_MAXG / 64; q++)
+                    if (!((have >> q) & 1u)) gq[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, (par * JSLP_F_MAXG + lane + 64 * q) * JSLP_G16_STRIDE, 0, 16);
+#pragma unroll
+                for (int q = 0; q < JSLP_F_MAXG / 64; q++)
+                    if (gq[q].y == tag && (gq[q].w >> 16) == (tag & 0xffffu)) have |= 1u << q;
+                ok = have == (1u << (JSLP_F_MAXG / 64)) - 1u;
+#else
 #pragma unroll
                 for (int q = 0; q < JSLP_F_MAXG / 64; q++) {
                     gq[q] = g;
@@ -951,6 +974,7 @@ __device__ __forceinline__ void resident_phase2_pipe(const ResCtx& f, RSmem& sm,
                 }
 #pragma unroll
                 for (int q = 0; q < JSLP_F_MAXG / 64; q++) ok = ok && gq[q].y == tag && (gq[q].w >> 16) == (tag & 0xffffu);
+#endif
                 if (__all(ok) && !JSLP_HOST_ABORT_FORCE_RETRY(spins)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
@@ -1436,8 +1460,28 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
         if (poller) {  // one wave, four summaries per lane (see phase 2)
             unsigned spins = 0;
             v4u_t gq[JSLP_F_MAXG / 64];
+#if JSLP_PIPE_POLL_MISSING_ONLY
+            unsigned have = 0;  // bit q: my look q has its summary (a look beyond the grid holds a copy of my own workgroup's: it is there)
+#pragma unroll
+            for (int q = 0; q < JSLP_F_MAXG / 64; q++) {
+                gq[q] = g;
+                if (lane + 64 * q >= f.G) have |= 1u << q;
+            }
+#endif
             for (;;) {
                 bool ok = true;
+#if JSLP_PIPE_POLL_MISSING_ONLY
+                // Round 6: only the looks whose summary has NOT arrived go out again.  Most summaries are there at the first look, and a look is an sc1 load
+                // that memory serves: 251 workgroups x 251 granules per round trip otherwise -- traffic that delays the very stores it waits for
+                // (184.7 k -> 193.3 k pivots/s on config 3a; two staggered sets of looks, i.e. MORE traffic, measured 158 k: profiles/r06_poll_traffic.md)
+#pragma unroll
+                for (int q = 0; q < JSLP_F_MAXG / 64; q++)
+                    if (!((have >> q) & 1u)) gq[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_g16, (par * JSLP_F_MAXG + lane + 64 * q) * JSLP_G16_STRIDE, 0, 16);
+#pragma unroll
+                for (int q = 0; q < JSLP_F_MAXG / 64; q++)
+                    if (gq[q].y == tag && (gq[q].w >> 16) == (tag & 0xffffu)) have |= 1u << q;
+                ok = have == (1u << (JSLP_F_MAXG / 64)) - 1u;
+#else
 #pragma unroll
                 for (int q = 0; q < JSLP_F_MAXG / 64; q++) {
                     gq[q] = g;
@@ -1445,6 +1489,7 @@ __device__ __forceinline__ void resident_phase1_pipe(const ResCtx& f, RSmem& sm,
                 }
 #pragma unroll
                 for (int q = 0; q < JSLP_F_MAXG / 64; q++) ok = ok && gq[q].y == tag && (gq[q].w >> 16) == (tag & 0xffffu);
+#endif
                 if (__all(ok) && !JSLP_HOST_ABORT_FORCE_RETRY(spins)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
