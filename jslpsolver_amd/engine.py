@@ -8,6 +8,41 @@ from . import _capi
 from ._capi import SimplexResult
 
 
+class PackedCuts(tuple):
+    """(n_nodes, cut_offsets, type, var_index, value) as Tableau.pack_cut_lists returns it -- a plain 5-tuple to every caller -- that also keeps the four
+    ctypes pointers of its arrays: `a.ctypes.data_as(...)` costs ~2 us per array, four times per call, which is a fifth of a 40 us single-node batch."""
+
+    def ptrs(self):
+        p = self.__dict__.get("_ptrs")
+        if p is None:
+            _, offs, t, v, x = self
+            p = self.__dict__["_ptrs"] = (_capi.ptr_i32(offs), _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x))
+        return p
+
+
+def _cut_ptrs(packed):
+    f = getattr(packed, "ptrs", None)
+    if f is not None:
+        return f()
+    _, offs, t, v, x = packed
+    return _capi.ptr_i32(offs), _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x)
+
+
+_VIEWS = {}
+
+
+def _pinned_view(ptr, shape):
+    """numpy view of an engine-owned pinned buffer (np.ctypeslib.as_array costs ~2 us a time): one view object per (address, shape, type) -- the
+    engine hands out the same buffer call after call; a re-allocated buffer has another address and gets another view"""
+    key = (_capi.C.cast(ptr, _capi.C.c_void_p).value, shape, ptr._type_)
+    v = _VIEWS.get(key)
+    if v is None:
+        if len(_VIEWS) > 256:
+            _VIEWS.clear()
+        v = _VIEWS[key] = np.ctypeslib.as_array(ptr, shape=shape)
+    return v
+
+
 class Tableau:
     """Device-resident dense simplex tableau (one `jslp_engine`).
 
@@ -140,12 +175,13 @@ class Tableau:
             flat.extend(cuts)
             offs[i + 1] = len(flat)
         _, t, v, x = self._pack_cuts(flat)
-        return n_nodes, offs, t, v, x
+        return PackedCuts((n_nodes, offs, t, v, x))
 
     def applyCutsBatch(self, cut_lists, check_cycles=True, packed=None, want_rows=True, copy=True):
         """Independent branch-and-bound nodes in one call.  copy=False returns views of the engine's pinned read-back
         buffer (jslp_engine_relax_batch_pinned): valid until the next call on this tableau."""
-        n_nodes, offs, t, v, x = packed if packed is not None else self.pack_cut_lists(cut_lists)
+        pk = packed if packed is not None else self.pack_cut_lists(cut_lists)
+        n_nodes, offs, t, v, x = pk
         out = (SimplexResult * max(n_nodes, 1))()
         stride = self.row_capacity
         if copy:
@@ -160,12 +196,12 @@ class Tableau:
         p_rows = _capi._i32p()
         c_stride = _capi.C.c_int32()
         self.lib.check(self.lib.jslp_engine_relax_batch_pinned(
-            self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x),
+            self._h, n_nodes, *_cut_ptrs(pk),
             int(bool(check_cycles)), out, _capi.C.byref(p_rhs), _capi.C.byref(p_rows) if want_rows else None,
             _capi.C.byref(c_stride)), "jslp_engine_relax_batch_pinned")
         shape = (max(n_nodes, 1), c_stride.value)
-        rhs = np.ctypeslib.as_array(p_rhs, shape=shape)
-        vibr = np.ctypeslib.as_array(p_rows, shape=shape) if want_rows else None
+        rhs = _pinned_view(p_rhs, shape)
+        vibr = _pinned_view(p_rows, shape) if want_rows else None
         return out, rhs, vibr
 
     # ---- outcomes left in device memory (the one-process-per-GPU path: sharding.py) ----------------------------------
@@ -175,18 +211,18 @@ class Tableau:
     def applyCutsBatchDevice(self, packed, check_cycles, states_ptr, rhs_ptr, rows_ptr, row_stride):
         """jslp_engine_relax_batch_device: raw addresses of memory on the engine's device (torch tensors' data_ptr(); plain host
         memory for the oracle library) receive the per-node state records, RHS columns and row maps; nothing is copied back"""
-        n_nodes, offs, t, v, x = packed
+        n_nodes = packed[0]
         self.lib.check(self.lib.jslp_engine_relax_batch_device(
-            self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)),
+            self._h, n_nodes, *_cut_ptrs(packed), int(bool(check_cycles)),
             _capi.C.c_void_p(states_ptr), _capi.C.c_void_p(rhs_ptr), _capi.C.c_void_p(rows_ptr), int(row_stride)),
             "jslp_engine_relax_batch_device")
 
     def applyCutsBatchWatchedDevice(self, packed, check_cycles, states_ptr, rows_ptr, values_ptr):
         """jslp_engine_relax_batch_watched_device: the COMPACT outcome (state record + row / RHS cell of the watched variables per node)
         left in memory of the engine's device -- the exchange payload of the multi-process path (sharding.py)"""
-        n_nodes, offs, t, v, x = packed
+        n_nodes = packed[0]
         self.lib.check(self.lib.jslp_engine_relax_batch_watched_device(
-            self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)),
+            self._h, n_nodes, *_cut_ptrs(packed), int(bool(check_cycles)),
             _capi.C.c_void_p(states_ptr), _capi.C.c_void_p(rows_ptr), _capi.C.c_void_p(values_ptr)),
             "jslp_engine_relax_batch_watched_device")
 
@@ -227,16 +263,17 @@ class Tableau:
         """applyCutsBatch whose read-back is, per node, rowByVarIndex / the RHS cell of the watched variables only: what a host
         that walks the tree itself reads per node, and ~10x fewer bytes over PCIe than the full RHS columns + row maps.
         copy=False returns views of the engine's pinned buffer (valid until the next call on this tableau)."""
-        n_nodes, offs, t, v, x = packed if packed is not None else self.pack_cut_lists(cut_lists)
+        pk = packed if packed is not None else self.pack_cut_lists(cut_lists)
+        n_nodes, offs, t, v, x = pk
         out = (SimplexResult * max(n_nodes, 1))()
         if not copy:
             p_rows = _capi._i32p()
             p_vals = _capi._f64p()
             self.lib.check(self.lib.jslp_engine_relax_batch_watched_pinned(
-                self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t), _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)), out,
+                self._h, n_nodes, *_cut_ptrs(pk), int(bool(check_cycles)), out,
                 _capi.C.byref(p_rows), _capi.C.byref(p_vals)), "jslp_engine_relax_batch_watched_pinned")
             shape = (max(n_nodes, 1), self.n_watched)
-            return out, np.ctypeslib.as_array(p_rows, shape=shape), np.ctypeslib.as_array(p_vals, shape=shape)
+            return out, _pinned_view(p_rows, shape), _pinned_view(p_vals, shape)
         rows = np.empty((max(n_nodes, 1), self.n_watched), dtype=np.int32)
         vals = np.empty((max(n_nodes, 1), self.n_watched), dtype=np.float64)
         self.lib.check(self.lib.jslp_engine_relax_batch_watched(self._h, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(t), _capi.ptr_i32(v),
@@ -428,7 +465,8 @@ class DevicePool:
     def applyCutsBatch(self, cut_lists, check_cycles=True, packed=None, want_rows=True, copy=True):
         """Tableau.applyCutsBatch over every member of the pool"""
         t = self.t
-        n_nodes, offs, ty, v, x = packed if packed is not None else t.pack_cut_lists(cut_lists)
+        pk = packed if packed is not None else t.pack_cut_lists(cut_lists)
+        n_nodes, offs, ty, v, x = pk
         out = (SimplexResult * max(n_nodes, 1))()
         stride = t.row_capacity
         if copy:
@@ -442,12 +480,12 @@ class DevicePool:
         p_rows = _capi._i32p()
         c_stride = _capi.C.c_int32()
         self.lib.check(self.lib.jslp_pool_relax_batch_pinned(
-            self._p, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(ty), _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)),
+            self._p, n_nodes, *_cut_ptrs(pk), int(bool(check_cycles)),
             out, _capi.C.byref(p_rhs), _capi.C.byref(p_rows) if want_rows else None, _capi.C.byref(c_stride)),
             "jslp_pool_relax_batch_pinned")
         shape = (max(n_nodes, 1), c_stride.value)
-        rhs = np.ctypeslib.as_array(p_rhs, shape=shape)
-        vibr = np.ctypeslib.as_array(p_rows, shape=shape) if want_rows else None
+        rhs = _pinned_view(p_rhs, shape)
+        vibr = _pinned_view(p_rows, shape) if want_rows else None
         return out, rhs, vibr
 
     def set_watched_variables(self, var_indexes):
@@ -461,7 +499,8 @@ class DevicePool:
         """Tableau.applyCutsBatchWatched over every member of the pool: per node rowByVarIndex / the RHS cell of the watched
         variables (what mip-utils.ts:43-61, 100-126 read between relaxations); copy=False: views of the pool's pinned buffer"""
         t = self.t
-        n_nodes, offs, ty, v, x = packed if packed is not None else t.pack_cut_lists(cut_lists)
+        pk = packed if packed is not None else t.pack_cut_lists(cut_lists)
+        n_nodes, offs, ty, v, x = pk
         out = (SimplexResult * max(n_nodes, 1))()
         # (ADVICE r04: the outputs are sized by what the LIBRARY will write -- jslp_pool_watched_count -- not by a Python-side shadow
         #  that a direct set_watched_variables on the primary engine would leave behind)
@@ -474,9 +513,9 @@ class DevicePool:
             p_rows = _capi._i32p()
             p_vals = _capi._f64p()
             self.lib.check(self.lib.jslp_pool_relax_batch_watched_pinned(
-                self._p, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(ty), _capi.ptr_i32(v), _capi.ptr_f64(x), int(bool(check_cycles)), out,
+                self._p, n_nodes, *_cut_ptrs(pk), int(bool(check_cycles)), out,
                 _capi.C.byref(p_rows), _capi.C.byref(p_vals)), "jslp_pool_relax_batch_watched_pinned")
-            return out, np.ctypeslib.as_array(p_rows, shape=shape), np.ctypeslib.as_array(p_vals, shape=shape)
+            return out, _pinned_view(p_rows, shape), _pinned_view(p_vals, shape)
         rows = np.empty(shape, dtype=np.int32)
         vals = np.empty(shape, dtype=np.float64)
         self.lib.check(self.lib.jslp_pool_relax_batch_watched(self._p, n_nodes, _capi.ptr_i32(offs), _capi.ptr_i8(ty), _capi.ptr_i32(v),
