@@ -15,7 +15,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 n_rows = int(sys.argv[2]) if len(sys.argv) > 2 else n  # (variables, constraints): 2000 4000 = the tall geometry
 m, vibr, vibc = generators.dense_resource_allocation_tableau(12345, n, n_rows)
 t = Tableau(m, vibr, vibc, lib=lib)
-res = t.simplex(check_cycles=False)
+res = t.simplex(check_cycles=os.environ.get("PHASE_TIMING_CHECK", "0") == "1")  # (PHASE_TIMING_CHECK=1: the cycle check on)
 print("pivots", len(t.pivot_trace()), "path", t.last_path())
 d = np.fromfile("gpurun_out/resident_r0.bin", dtype=np.uint64)[12288:]
 names = ["A cands", "B row stores", "C sweep/drain/sync", "D decide/poll", "E0 rowflag", "E row load+norm", "F update", "G price"]
