@@ -828,6 +828,12 @@ def relaxation_legs(ctx, args, reps=16):
                                             % (len(fixed), reps, world, dist.get_backend(sgroup))}
         if own_group:
             dist.destroy_process_group()
+        if world > 1:
+            #  at N > 1 the leg that PAYS for its communication is the relaxation figure: the weak-scaling leg (independent batches per rank, no
+            # exchange in the timed region) moves into `weak_scaling`
+            out["weak_scaling"] = {k: out[k] for k in ("value", "unit", "nodes", "pivots", "seconds", "scaling", "per_rank_relaxations_per_s") if k in out}
+            out["value"], out["nodes"], out["seconds"], out["scaling"] = out["sharded_batch"]["value"], out["sharded_batch"]["nodes"], out["sharded_batch"]["seconds"], "strong"
+            out["value_leg"] = "sharded_batch: ONE fixed batch split over the ranks, all-gather of the compact outcomes + D2H inside the timed region (the per-rank independent batches: weak_scaling)"
     except WrongAnswer:
         raise
     except Exception as e:  # (never lose the whole line to this leg)

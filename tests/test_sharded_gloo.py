@@ -82,13 +82,15 @@ def test_bench_multi_rank_code_path_on_one_gpu(hip_lib):
     assert line["n_gpus"] == 2 and line["unit"] == "pivots/s" and line["value"] > 0
     assert line["config"]["pivot_digest"] == "1cda2607"  # the reference's digest for n = 500
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - 2 * 657) < 1e-6 * 2 * 657
-    assert line["relaxations"]["nodes"] == 2 * 16 * 151
+    assert line["relaxations"]["weak_scaling"]["nodes"] == 2 * 16 * 151 and line["relaxations"]["weak_scaling"]["scaling"] == "weak"
     # round 6: the STRONG-scaling leg -- one fixed batch split over the ranks, the exchange inside the timed region
     sb = line["relaxations"]["sharded_batch"]
     assert sb["scaling"] == "strong" and sb["nodes"] == 16 * 151 and sb["ranks"] == 2 and sb["value"] > 0, sb
     assert sb["exchange_ms"] > 0 and sb["bytes_per_rank"] >= (16 * 151 // 2) * (128 + 12 * 112), sb  # (state record + 12 B per integer variable per node of the rank's share)
     assert abs(sb["value"] * sb["seconds"] - sb["nodes"]) < 1e-6 * sb["nodes"] and 1e-3 * sb["exchange_ms"] < sb["seconds"], sb  # (the rate is over the median call's time, which contains the exchange)
     assert sb["value_over_mean_call"] > 0 and sb["max_call_us"] >= 1e6 * sb["seconds"] * 0.999 and "health" in sb, sb
+    # ... and at N > 1 it IS the relaxation figure (the weak leg moved into `weak_scaling`)
+    assert line["relaxations"]["value"] == sb["value"] and line["relaxations"]["scaling"] == "strong" and line["relaxations"]["nodes"] == sb["nodes"], line["relaxations"]["value_leg"]
     assert line["relaxations"]["tree"]["scaling"] == "strong" and line["relaxations"]["tree"]["result"] == 20631
     assert line["cycle_check_on"]["pivot_digest"] == "1cda2607"
     assert "cpu_baseline" not in line
