@@ -2136,6 +2136,15 @@ static int relax_batch_impl(jslp_engine* e, int32_t n_nodes, const int32_t* cut_
                         (void)hipGetLastError();
                     }
                 }
+                // (round 6) copy-on-write start here too, as the queue kernel and the single-node call have it: a node READS what its slot's earlier nodes
+                // dirtied from the root instead of restoring those rows first -- the eager restore was 8.6 k of the 78 k cycles of a node of an 8-node batch
+                // (tools/wglds_timing.py one 8, debug build), in front of everything else; JSLP_NODE_COW_SMALL=0: eager restores
+                static const int cow_small = getenv("JSLP_NODE_COW_SMALL") ? atoi(getenv("JSLP_NODE_COW_SMALL")) : 1;
+                if (cow_small && node_cow())
+                    hipLaunchKernelGGL((k_node_lds<1024, false, true>), dim3(g), dim3(1024), lds, s, e->s, sn, cu, first, check_cycles, cap,
+                                       (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states,
+                                       g_stride, first, d_flag, seq, d_flag ? e->d_done_count : (int*)nullptr);
+                else
                 hipLaunchKernelGGL((k_node_lds<1024>), dim3(g), dim3(1024), lds, s, e->s, sn, cu, first, check_cycles, cap,
                                    (int)e->cap_rows, want_rhs ? o_rhs : nullptr, want_rows ? o_rows : nullptr, o_states,
                                    g_stride, first, d_flag, seq, d_flag ? e->d_done_count : (int*)nullptr);

@@ -35,3 +35,16 @@ def test_node_batch_is_the_same_under_every_launch_shape(hip_lib):
         assert sha["2"] == base_sha["2"], extra
         for k in ("relaxations", "simplex_calls", "pivots", "gated_cells", "gated_rows", "cut_rows", "height_sum"):
             assert cnt[k] == base_cnt[k], (extra, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cow_small", ["1", "0"])
+def test_small_dependent_batches_copy_on_write_or_eager_restore_give_the_verified_outcomes(cow_small):
+    """round 6: a one-group batch of the 1024-thread node kernel (<= 16 nodes: the tree's speculative batches) starts copy-on-write by default
+    (JSLP_NODE_COW_SMALL=0: eager restores, as until round 6); tools/node_latency.py checks every node of its 1 / 8 / 16-node batches against the verified
+    full read-back -- repeated calls, so that a slot's rows dirtied by the previous call are what the next call starts from"""
+    env = dict(os.environ, JSLP_NODE_COW_SMALL=cow_small)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "node_latency.py"), os.path.join("/tmp", "node_latency_cow_%s.md" % cow_small)],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("== the verified full read-back") == 3, out.stdout[-2000:]

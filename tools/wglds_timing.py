@@ -17,7 +17,23 @@ t = Tableau(m, vibr, vibc, model.unrestricted, precision=model.precision, row_ca
 t.applyCuts([], check_cycles=True)
 t.save()
 mode = sys.argv[1]
-if mode == "single":
+if mode == "one":
+    # round 6: the latency shape of bench.py's small_batch_latency -- node 3 of the reference's tree (1 pivot) or nodes 3..10 (17 pivots), compact read-back,
+    # one call at a time; with the -DJSLP_DEBUG_WGLDS build get_counters() prints the kernel's section table for exactly these calls
+    n_small = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    sub = base[3:3 + n_small]
+    t.set_watched_variables([int(v) for v in model.integer_index_array])
+    packed = t.pack_cut_lists(sub)
+    for _ in range(50):
+        t.applyCutsBatchWatched(None, check_cycles=True, packed=packed, copy=False)
+    t.set_counting(True)
+    ts = []
+    for _ in range(200):
+        t0 = time.perf_counter(); t.applyCutsBatchWatched(None, check_cycles=True, packed=packed, copy=False); ts.append(time.perf_counter() - t0)
+    ts.sort()
+    print("%d node(s) per call, 200 calls (counting on): median %.1f us, min %.1f us" % (n_small, 1e6 * ts[100], 1e6 * ts[0]), flush=True)
+    print(t.get_counters(), flush=True)
+elif mode == "single":
     for cuts in base[:20]:
         t.applyCuts(cuts, check_cycles=True)
     t.set_counting(True)
