@@ -48,3 +48,65 @@ def test_small_dependent_batches_copy_on_write_or_eager_restore_give_the_verifie
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count("== the verified full read-back") == 3, out.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_mixed_batch_shapes_back_to_back_on_one_engine_are_the_reference(hip_lib):
+    """one engine, one saved Monster_II root, and calls of every shape one after the other -- single nodes, one-group batches of 2 .. 16 nodes (copy-on-write start
+    since round 6), a 40-node and a 300-node batch, the 2416-node queue batch, compact and full read-back mixed -- so that what one call leaves dirty in its slots
+    is what the next one starts from: every node's outcome must be the reference's (height, feasibility, sha256 of RHS column + row map; the compact read-back
+    against the same full outcome)"""
+    import gzip
+    import hashlib
+    import json
+
+    import numpy as np
+
+    from jslpsolver_amd import Model
+    from jslpsolver_amd.engine import Tableau
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "fixtures", "Monster_II.json.gz"), "rt") as fh:
+        g = json.load(fh)
+    model = Model(g["model"])
+    m, vibr, vibc = model.build_tableau()
+    calls = g["simplexCalls"][1:]
+    t = Tableau(m, vibr, vibc, model.unrestricted, precision=model.precision, row_capacity=m.shape[0] + 2 * len(model.integerVariables), lib=hip_lib)
+    try:
+        t.applyCuts([], check_cycles=True)
+        t.save()
+        ints = np.asarray([int(v) for v in model.integer_index_array])
+        t.set_watched_variables([int(v) for v in ints])
+
+        def check_full(which, res, rhs, rows):
+            for i, k in enumerate(which):
+                call, h = calls[k % len(calls)], res[i].height
+                sha = hashlib.sha256(np.ascontiguousarray(rhs[i, :h]).tobytes() + np.ascontiguousarray(rows[i, :h]).tobytes()).hexdigest()
+                assert h == call["height"] and bool(res[i].feasible) == call["feasible"] and sha == call["rhsSha"], ("full", len(which), k)
+
+        def check_compact(which, res, wrows, wvals):
+            # against a full read-back of the same nodes taken right now (itself checked against the reference)
+            full = t.applyCutsBatch([calls[k % len(calls)]["cuts"] or [] for k in which], check_cycles=True)
+            check_full(which, *full)
+            fres, frhs, frows = full
+            for i in range(len(which)):
+                h = fres[i].height
+                row_of = np.full(int(max(frows[i, :h].max(), ints.max())) + 1, -1, dtype=np.int64)
+                row_of[frows[i, 1:h]] = np.arange(1, h)
+                r = row_of[ints]
+                want = np.where(r > 0, frhs[i, np.maximum(r, 0)], 0.0)
+                assert res[i].height == h and bool(res[i].feasible) == bool(fres[i].feasible), ("compact", len(which), i)
+                assert np.array_equal(np.asarray(wrows[i]), r.astype(np.int32)) and np.array_equal(np.asarray(wvals[i]).view(np.int64), want.view(np.int64)), ("compact", len(which), i)
+
+        start = 0
+        for n, compact in ((1, True), (8, True), (16, False), (2, True), (1, False), (40, True), (16, True), (300, False), (3, True), (151 * 16, True), (8, False),
+                           (1, True), (16, True), (151 * 16, False), (5, True)):
+            which = [(start + i) % len(calls) for i in range(n)]
+            start += 7
+            nodes = [calls[k]["cuts"] or [] for k in which]
+            for rep in range(2):  # (twice: the second call starts from what the first left in the slots)
+                if compact:
+                    res, wrows, wvals = t.applyCutsBatchWatched(nodes, check_cycles=True)
+                    check_compact(which, res, wrows, wvals)
+                else:
+                    check_full(which, *t.applyCutsBatch(nodes, check_cycles=True))
+    finally:
+        t.close()
